@@ -1,0 +1,129 @@
+/* oracle/orc.h -- CPU ORACLE for the VOLDOR per-frame VO inner loop.
+ *
+ * TEST INFRASTRUCTURE ONLY.  A plain-C restatement of the reference algorithm
+ * (htkseason/VOLDOR, /root/reference) used as the parity checker for the HIP
+ * product path in voldor_amd/.  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load this library.  The product never does.
+ *
+ * PARITY PINNING: the reference ships no tests / golden vectors for this path
+ *  and its CUDA+OpenCV build cannot run here.  The pieces of
+ * the reference that DO compile on the host (lambdatwist/*.h, residual_model.h,
+ * rodrigues.h+svd3_cuda.h) are built in place into oracle/_ref and this oracle is
+ * checked against them (tests/test_oracle_vs_ref.py, tests/golden/ref_*.npz).
+ * Everything else (pixel passes, fb_smooth, collect, mean-shift, robust Gaussian,
+ * EM schedule) is "parity unpinned": restated from the cited source lines only.
+ *
+ * Deliberate, documented deviations from the reference:
+ *  D1 random numbers: counter-based hash (orc_rng) instead of cuRAND XORWOW.
+ *  D2 bilinear sampling: exact fp32 weights, clamp per layer (no 8-bit weights,
+ *     no bleeding between stacked layers) -- gmat.h:175-179.
+ *  D3 random sample index clamped to N_pts-1 (reference can read one past the end,
+ *     solve_batch_lambdatwist.cu:16-19).
+ *  D4 one depth buffer shared by the depth and the pose half (the reference keeps a
+ *     stale un-normalised copy in optimize_depth.cu).
+ *
+ * All citations are file:line relative to /root/reference.
+ */
+#ifndef ORC_H
+#define ORC_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_MAX_FRAMES 16
+
+/* ---- RNG (deviation D1) ---- */
+uint32_t orc_rng(uint32_t seed, uint32_t stream, uint32_t counter);
+float orc_u01(uint32_t r); /* (0,1] like curand_uniform */
+
+/* ---- residual model: gpu-kernels/residual_model.h:6-68 ---- */
+float orc_fun_fmag_c(float fmag);
+float orc_fun_fmag_scale(float fmag);
+float orc_fisk_dist_pdf(float x, float c, float scale);
+float orc_fun_rigidness(float dx1, float dy1, float dx2, float dy2, float lambda, float abs_rf);
+float orc_fun_depth_rigidness(float d1, float d2, float basefocal, float omega, float abs_rf);
+
+/* ---- depth half: gpu-kernels/optimize_depth.cu:54-520, fb_smooth.h:17-109 ---- */
+typedef struct {
+    int N, N_dp, w, h;
+    float K[9];
+    float Rs[ORC_MAX_FRAMES][9], ts[ORC_MAX_FRAMES][3];
+    float dp_Rs[ORC_MAX_FRAMES][9], dp_ts[ORC_MAX_FRAMES][3];
+    float abs_resize_factor, basefocal;
+    int n_rand_samples, global_prop_step, local_prop_width;
+    float lambda, omega, disp_delta, delta;
+    int fb_smooth;
+    float s0_ems_prob, no_change_prob, range_factor;
+    int update_rigidness_only;
+} orc_od_params;
+
+/* flows [N][h][w][2]; rig [N][h][w] in/out; priors/pconfs [N_dp][h][w]; confs in/out;
+ * depth [h][w] in/out; cost [h][w] out (scratch); rand_epoch in/out (persistent RNG counter). */
+void orc_optimize_depth(const orc_od_params* p, const float* flows, float* rig,
+                        const float* priors, const float* pconfs, float* confs,
+                        float* depth, float* cost, uint32_t* rand_epoch);
+void orc_fb_smooth(float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob);
+void orc_compute_cost_map(const orc_od_params* p, const float* flows, const float* rig,
+                          const float* priors, const float* pconfs, const float* confs,
+                          const float* depth, float* cost);
+void orc_update_rigidnesses(const orc_od_params* p, const float* flows, float* rig,
+                            const float* priors, float* confs, const float* depth);
+/* gpu-kernels/gblur.cu:12-72 */
+int orc_gblur(const float* src, float* dst, int w, int h, int d, float sigma, int ksize);
+
+/* ---- pose half ---- */
+/* gpu-kernels/collect_p3p_instances.cu:70-145; maps are NaN where invalid */
+void orc_collect_p3p(const float* flows, const float* rig, const float* depth, const float* K,
+                     const float (*Rs)[9], const float (*ts)[3], float* p2_map, float* p3_map,
+                     int N, int w, int h, int active_idx, float rigidness_thresh,
+                     float rigidness_sum_thresh, float sample_min_depth, float sample_max_depth,
+                     int max_trace_on_flow);
+/* voldor/geometry.cpp:68-80 row-major compaction; returns n_points */
+int orc_compact_p3p(const float* p2_map, const float* p3_map, int npx, float* pts2, float* pts3);
+/* 4 random indices of pose sample `idx` (deviation D1,D3) */
+void orc_pose_sample_indices(int idx, int n_pts, int out4[4]);
+/* lambdatwist/lambdatwist_p4p.h:5-62; use_double selects _T (0: GPU path float, 1: CPU path) */
+int orc_lambdatwist_p4p(const float* y8, const float* x12, float fx, float fy, float cx, float cy,
+                        int use_double, float* R9, float* t3);
+/* gpu-kernels/solve_batch_ap3p.cu:294-378 (4 points -> best of <=4 AP3P solutions) */
+int orc_ap3p_p4p(const float* y8, const float* x12, float fx, float fy, float cx, float cy,
+                 float* R9, float* t3);
+/* gpu-kernels/rodrigues.h:82-114 (project to SO(3), then angle-axis :5-79) */
+void orc_rodrigues(const float* R9, float* rvec3);
+void orc_rotmat_to_angle_axis(const float* R9, float* rvec3);
+void orc_rvec_to_rotmat(const float* rvec3, float* R9); /* cv::Rodrigues(vec->mat), OpenCV 3.4 */
+/* gpu-kernels/solve_batch_lambdatwist.cu:51-102 / solve_batch_ap3p.cu:387-437 */
+void orc_solve_batch_p3p(const float* pts3, const float* pts2, float* rvecs, float* tvecs,
+                         const float* K, int n_pts, int n_poses, int use_ap3p, int use_double);
+/* gpu-kernels/meanshift.cu:34-150 */
+void orc_meanshift(const float* space, float kernel_var, float* io_mean, float* o_confidence,
+                   int* used_iters, int use_external_init_mean, int N, int dims, float epsilon,
+                   int max_iters, int max_init_trials, float good_init_confidence);
+/* gpu-kernels/fit_robust_gaussian.cu:101-286 ; returns 0 iff reliable */
+int orc_fit_robust_gaussian(const float* space, float* io_mean, float* io_covar, float trunc_sigma,
+                            float covar_reg_lambda, float* o_density, int* used_iters, int N,
+                            int dims, float epsilon, int max_iters);
+
+/* ---- bootstrap: voldor/geometry.cpp:267-332 ---- */
+void orc_estimate_depth_closed_form(const float* flow, float* depth, const float* K,
+                                    const float* R9, const float* t3, int w, int h,
+                                    float min_depth, float max_depth);
+int orc_estimate_pose_epipolar(const float* flow, const float* K, int w, int h, int step,
+                               float* R9, float* t3);
+
+/* ---- whole window: voldor/py_export.cpp:5-79 + voldor/voldor.cpp:4-317 ---- */
+int orc_voldor(const float* flows, const float* disparity, const float* disparity_pconf,
+               const float* depth_priors, const float* depth_prior_poses,
+               const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+               float basefocal, int N, int N_dp, int w, int h, const char* config,
+               int* n_registered, float* poses, float* poses_covar, float* depth,
+               float* depth_conf);
+
+void orc_set_threads(int n);
+int orc_get_max_threads(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,2 @@
+#pragma once
+#include "cuda_stub_common.h"
