@@ -1,0 +1,88 @@
+/* include/voldor_hip.h -- C-ABI (extern "C") of libvoldor_hip.so: plain pointers and sizes only.
+ *
+ * Section A re-exports the six B-inner entry points of include/gpu_kernels.h
+ * (= /root/reference/gpu-kernels/gpu_kernels.h:11-58) with `int` in place of `bool`, for FFI
+ * callers that cannot bind mangled C++ names (ctypes / cgo / JNI).
+ * Section B is the B-outer window call, = /root/reference/voldor/py_export.h:3-11 with
+ * `int* n_registered` in place of `int&`; vk_voldor_device() is the same call for inputs that are
+ * already resident in HBM (any pointer may be a device pointer; direction is inferred).
+ * Section C: inspection / control helpers used by tests, bench.py and multi-GPU launchers.
+ * All functions return 0 on success, else a HIP error code (message on stderr) unless noted.
+ */
+#ifndef VOLDOR_HIP_H
+#define VOLDOR_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+#pragma GCC visibility push(default)
+
+/* ---- A. B-inner (host pointers, NULL = keep device copy / skip download) ---- */
+int vk_meanshift_gpu(float* h_space, float kernel_var, float* h_io_mean, float* h_o_confidence,
+                     int* used_iters, int use_external_init_mean, int N, int dims, float epsilon,
+                     int max_iters, int max_init_trials, float good_init_confidence);
+int vk_fit_robust_gaussian(float* h_space, float* h_io_mean, float* h_io_covar, float trunc_sigma,
+                           float covar_reg_lambda, float* h_o_density, int* used_iters, int N,
+                           int dims, float epsilon, int max_iters);
+int vk_collect_p3p_instances(float** h_flows, float** h_rigidnesses, float* h_depth, float* h_K,
+                             float** h_Rs, float** h_ts, float* h_o_p2_map, float* h_o_p3_map,
+                             int N, int w, int h, int active_idx, float rigidness_thresh,
+                             float rigidness_sum_thresh, float sample_min_depth,
+                             float sample_max_depth, int max_trace_on_flow);
+int vk_solve_batch_p3p_ap3p_gpu(float* h_p3s, float* h_p2s, float* h_o_rvecs, float* h_o_tvecs,
+                                float* h_K, int N_pts, int N_poses);
+int vk_solve_batch_p3p_lambdatwist_gpu(float* h_p3s, float* h_p2s, float* h_o_rvecs,
+                                       float* h_o_tvecs, float* h_K, int N_pts, int N_poses);
+/* same sampling, solver scalar = double (the reference's CPU instantiation, geometry.cpp:112) */
+int vk_solve_batch_p3p_lambdatwist_f64_gpu(float* h_p3s, float* h_p2s, float* h_o_rvecs,
+                                           float* h_o_tvecs, float* h_K, int N_pts, int N_poses);
+int vk_optimize_depth_gpu(float** h_flows, float** h_rigidnesses, float** h_o_rigidnesses,
+                          float** h_depth_priors, float** h_depth_prior_pconfs,
+                          float** h_depth_prior_confs, float** h_o_depth_prior_confs,
+                          float* h_depth, float* h_o_depth, float* h_K, float** h_Rs, float** h_ts,
+                          float** h_dp_Rs, float** h_dp_ts, float abs_resize_factor, int N, int N_dp,
+                          int w, int h, float basefocal, int n_rand_samples, int global_prop_step,
+                          int local_prop_width, float lambda, float omega, float disp_delta,
+                          float delta, int fb_smooth, float s0_ems_prob, float no_change_prob,
+                          float range_factor, int update_rigidness_only);
+/* gblur_gpu (gpu-kernels/gblur.cu:47-72) on host arrays [d][h][w]; ksize 0 = max(ceil(6 sigma),3) */
+int vk_gblur(const float* h_src, float* h_dst, int w, int h, int d, float sigma, int ksize);
+
+/* ---- B. B-outer ---- */
+int vk_py_voldor_wrapper(const float* flows, const float* disparity, const float* disparity_pconf,
+                         const float* depth_priors, const float* depth_prior_poses,
+                         const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+                         float basefocal, int N, int N_dp, int w, int h, const char* config,
+                         int* n_registered, float* poses, float* poses_covar, float* depth,
+                         float* depth_conf);
+/* identical semantics; image-sized arguments (flows, disparity*, depth_priors, depth_prior_pconfs,
+ * depth, depth_conf) may be DEVICE pointers (e.g. torch tensors); depth_prior_poses, poses,
+ * poses_covar, n_registered are host memory. */
+int vk_voldor_device(const float* flows, const float* disparity, const float* disparity_pconf,
+                     const float* depth_priors, const float* depth_prior_poses,
+                     const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+                     float basefocal, int N, int N_dp, int w, int h, const char* config,
+                     int* n_registered, float* poses, float* poses_covar, float* depth,
+                     float* depth_conf);
+/* per-camera statistics of the last window (voldor/utils.h:41-45): arrays of length >= N */
+int vk_last_camera_stats(int* pose_sample_count, float* pose_density, float* pose_rigidness_density,
+                         int* ms_iters, int* gu_iters, int n);
+/* bootstrap pieces (voldor/geometry.cpp:267-332) exposed for parity tests; host pointers */
+int vk_estimate_pose_epipolar(const float* h_flow, const float* h_K, int w, int h, float* h_o_R9, float* h_o_t3);
+int vk_estimate_depth_closed_form(const float* h_flow, const float* h_K, const float* h_R9, const float* h_t3,
+                                  int w, int h, float* h_o_depth);
+
+/* ---- C. helpers ---- */
+int vk_get_compacted_points(float* h_o_pts2, float* h_o_pts3, int max_points); /* returns n_points (<0 error) */
+int vk_set_rand_epoch(unsigned epoch);   /* depth-sampling RNG counter of the current context */
+unsigned vk_get_rand_epoch(void);
+int vk_profile_enable(int on);           /* HIP-event timing of kernel groups on the library's stream */
+int vk_profile_get(const char* name, double* total_ms, long* count);
+int vk_device_count(void);
+int vk_set_device(int dev);
+const char* vk_version(void);
+
+#pragma GCC visibility pop
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,47 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        from voldor_amd import capi
+        return capi.lib().vk_device_count() > 0
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no HIP device visible")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import orc as o
+    o.build()
+    return o
+
+
+@pytest.fixture(scope="session")
+def small_scene():
+    from voldor_amd import synth
+    return synth.make_scene(w=160, h=120, n_flows=4, fx=80, fy=80, cx=80, cy=60, seed=7)
+
+
+def K9(fx, fy, cx, cy):
+    return np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], np.float32)

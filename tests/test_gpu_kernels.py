@@ -1,0 +1,296 @@
+"""Parity of every HIP stage against the CPU oracle, through the C-ABI (B-inner).
+
+Tolerances: the per-pixel model is fp32 with different transcendental implementations on the
+two sides (glibc powf/expf/logf vs. v_log/v_exp), so maps are compared at 2e-4 relative; the
+discrete `cost < best` decisions of the depth search can flip on near-ties, so depth maps are
+compared on the fraction of pixels that agree (>= 99 %).
+"""
+import numpy as np
+import pytest
+
+from conftest import K9
+
+pytestmark = pytest.mark.gpu
+
+
+def _state(scene, rng, noise=0.1):
+    from voldor_amd import synth
+    flows = scene["flows"]
+    N, h, w, _ = flows.shape
+    gt = scene["poses_gt"]
+    Rs = np.stack([synth.rodrigues(gt[i, :3]) for i in range(N)]).astype(np.float32)
+    ts = gt[:, 3:].astype(np.float32)
+    depth = (scene["depth_gt"] * (1 + rng.normal(0, noise, (h, w)))).astype(np.float32)
+    rig = rng.uniform(0.2, 1.0, (N, h, w)).astype(np.float32)
+    return flows, Rs, ts, depth, rig
+
+
+def _od_kwargs(**over):
+    kw = dict(abs_resize_factor=1.0, basefocal=0.0, n_rand_samples=10, global_prop_step=8, local_prop_width=32,
+              lambda_=0.15, omega=0.15, disp_delta=-1.0, delta=0.5, fb_smooth=1, s0_ems_prob=0.5, no_change_prob=0.9,
+              range_factor=1.0, update_rigidness_only=0)
+    kw.update(over)
+    return kw
+
+
+def _run_both(orc, scene, K, flows, Rs, ts, depth, rig, priors=None, pconfs=None, confs=None, dp_Rs=None, dp_ts=None, epoch=5, **over):
+    from voldor_amd import kernels
+    N, h, w, _ = flows.shape
+    N_dp = 0 if priors is None else priors.shape[0]
+    kw = _od_kwargs(**over)
+    p = orc.make_od_params(N, N_dp, w, h, K, Rs, ts, dp_Rs, dp_ts, **kw)
+    o_depth, o_rig, o_confs, o_cost, o_ep = orc.optimize_depth(p, flows, rig, depth, priors, pconfs, confs, rand_epoch=epoch)
+    kernels.set_rand_epoch(epoch)
+    g_depth, g_rig, g_confs = kernels.optimize_depth_gpu(
+        flows, rig, priors, pconfs, confs, depth, K, Rs, ts, dp_Rs, dp_ts, kw["abs_resize_factor"], N, N_dp, w, h,
+        kw["basefocal"], kw["n_rand_samples"], kw["global_prop_step"], kw["local_prop_width"], kw["lambda_"], kw["omega"],
+        kw["disp_delta"], kw["delta"], kw["fb_smooth"], kw["s0_ems_prob"], kw["no_change_prob"], kw["range_factor"],
+        kw["update_rigidness_only"])
+    assert kernels.get_rand_epoch() == o_ep
+    return (o_depth, o_rig, o_confs), (g_depth, g_rig, g_confs)
+
+
+def test_update_rigidness_only_matches_oracle(orc, small_scene):
+    rng = np.random.default_rng(0)
+    K = K9(*small_scene["K"])
+    flows, Rs, ts, depth, rig = _state(small_scene, rng)
+    (od, orig, _), (gd, grig, _) = _run_both(orc, small_scene, K, flows, Rs, ts, depth, rig, update_rigidness_only=1)
+    np.testing.assert_array_equal(od, gd)  # depth untouched
+    assert np.abs(orig - grig).max() < 2e-4
+
+
+def test_fb_smooth_and_cost_path(orc, small_scene):
+    # no random samples, no propagation: fb_smooth -> cost map -> E-step only; depth must not move
+    rng = np.random.default_rng(1)
+    K = K9(*small_scene["K"])
+    flows, Rs, ts, depth, rig = _state(small_scene, rng)
+    (od, orig, _), (gd, grig, _) = _run_both(orc, small_scene, K, flows, Rs, ts, depth, rig, n_rand_samples=0,
+                                             global_prop_step=0, local_prop_width=0)
+    np.testing.assert_array_equal(od, gd)
+    assert np.abs(orig - grig).max() < 2e-4
+
+
+@pytest.mark.parametrize("stage", ["rand", "global", "local", "all"])
+def test_depth_search_stages(orc, small_scene, stage):
+    rng = np.random.default_rng(2)
+    K = K9(*small_scene["K"])
+    flows, Rs, ts, depth, rig = _state(small_scene, rng, noise=0.3)
+    over = dict(n_rand_samples=0, global_prop_step=0, local_prop_width=0, fb_smooth=0)
+    if stage in ("rand", "all"): over["n_rand_samples"] = 10
+    if stage in ("global", "all"): over["global_prop_step"] = 8
+    if stage in ("local", "all"): over["local_prop_width"] = 32
+    if stage == "all": over["fb_smooth"] = 1
+    (od, orig, _), (gd, grig, _) = _run_both(orc, small_scene, K, flows, Rs, ts, depth, rig, **over)
+    agree = np.mean(np.abs(od - gd) <= 1e-5 * np.abs(od))
+    assert agree >= 0.99, f"{stage}: only {agree:.4f} of depth pixels agree"
+    same = np.abs(od - gd) <= 1e-5 * np.abs(od)
+    assert np.abs(orig - grig)[:, same].max() < 5e-4
+
+
+def test_ragged_size_and_small_segments(orc):
+    from voldor_amd import synth
+    sc = synth.make_scene(w=83, h=67, n_flows=3, fx=40, fy=40, cx=41, cy=33, seed=11)  # not multiples of 64/32/8
+    rng = np.random.default_rng(3)
+    K = K9(*sc["K"])
+    flows, Rs, ts, depth, rig = _state(sc, rng, noise=0.3)
+    (od, orig, _), (gd, grig, _) = _run_both(orc, sc, K, flows, Rs, ts, depth, rig, global_prop_step=3, local_prop_width=7)
+    agree = np.mean(np.abs(od - gd) <= 1e-5 * np.abs(od))
+    assert agree >= 0.985
+
+
+def test_global_step1_serial_chain(orc):
+    from voldor_amd import synth
+    sc = synth.make_scene(w=64, h=48, n_flows=2, fx=32, fy=32, cx=32, cy=24, seed=12)
+    rng = np.random.default_rng(4)
+    K = K9(*sc["K"])
+    flows, Rs, ts, depth, rig = _state(sc, rng, noise=0.3)
+    (od, _, _), (gd, _, _) = _run_both(orc, sc, K, flows, Rs, ts, depth, rig, global_prop_step=1, local_prop_width=0, n_rand_samples=2, fb_smooth=0)
+    agree = np.mean(np.abs(od - gd) <= 1e-5 * np.abs(od))
+    assert agree >= 0.97  # one flipped decision propagates along a serial chain
+
+
+def test_depth_priors_and_disparity(orc):
+    from voldor_amd import synth
+    sc = synth.make_scene(w=128, h=96, n_flows=3, fx=64, fy=64, cx=64, cy=48, seed=13, basefocal=30.0)
+    rng = np.random.default_rng(5)
+    K = K9(*sc["K"])
+    flows, Rs, ts, depth, rig = _state(sc, rng, noise=0.2)
+    h, w = depth.shape
+    priors = np.stack([30.0 / sc["disparity"], sc["depth_gt"] * 1.02]).astype(np.float32)
+    priors[1, :5, :] = 0  # invalid prior region (target_depth <= 0)
+    pconfs = rng.uniform(0.5, 1, (2, h, w)).astype(np.float32)
+    confs = rng.uniform(0.5, 1, (2, h, w)).astype(np.float32)
+    dp_Rs = np.stack([np.eye(3), synth.rodrigues([0.002, -0.001, 0.001])]).astype(np.float32)
+    dp_ts = np.array([[0, 0, 0], [0.01, 0.0, -0.05]], np.float32)
+    (od, orig, ocf), (gd, grig, gcf) = _run_both(orc, sc, K, flows, Rs, ts, depth, rig, priors, pconfs, confs, dp_Rs, dp_ts,
+                                                basefocal=30.0, disp_delta=1.0, delta=0.2)
+    agree = np.mean(np.abs(od - gd) <= 1e-5 * np.abs(od))
+    assert agree >= 0.99
+    same = np.abs(od - gd) <= 1e-5 * np.abs(od)
+    assert np.abs(orig - grig)[:, same].max() < 5e-4
+    assert np.abs(ocf - gcf)[:, same].max() < 5e-4
+
+
+def test_only_depth_priors_N0(orc):
+    from voldor_amd import synth
+    sc = synth.make_scene(w=96, h=64, n_flows=2, fx=48, fy=48, cx=48, cy=32, seed=14)
+    rng = np.random.default_rng(6)
+    K = K9(*sc["K"])
+    h, w = sc["depth_gt"].shape
+    priors = (sc["depth_gt"][None] * np.array([1.0, 1.05])[:, None, None]).astype(np.float32)
+    pconfs = np.ones((2, h, w), np.float32)
+    confs = np.ones((2, h, w), np.float32)
+    dp_Rs = np.stack([np.eye(3)] * 2).astype(np.float32)
+    dp_ts = np.zeros((2, 3), np.float32)
+    flows = sc["flows"][:0]
+    depth = priors[0].copy()
+    rig = np.zeros((0, h, w), np.float32)
+    (od, _, ocf), (gd, _, gcf) = _run_both(orc, sc, K, flows, None, None, depth, rig, priors, pconfs, confs, dp_Rs, dp_ts, delta=0.5)
+    agree = np.mean(np.abs(od - gd) <= 1e-5 * np.abs(od))
+    assert agree >= 0.99
+
+
+def test_null_protocol_reuses_device_copies(orc, small_scene):
+    """Second call with NULL inputs must reuse what the first call left on the device
+    (optimize_depth.cu:372-459), exactly like two chained oracle calls."""
+    from voldor_amd import kernels
+    rng = np.random.default_rng(7)
+    K = K9(*small_scene["K"])
+    flows, Rs, ts, depth, rig = _state(small_scene, rng, noise=0.3)
+    N, h, w, _ = flows.shape
+    kw = _od_kwargs()
+    p = orc.make_od_params(N, 0, w, h, K, Rs, ts, **kw)
+    d1, r1, _, _, ep = orc.optimize_depth(p, flows, rig, depth, rand_epoch=0)
+    d2, r2, _, _, ep = orc.optimize_depth(p, flows, r1, d1, rand_epoch=ep)
+    kernels.set_rand_epoch(0)
+    args = (kw["abs_resize_factor"], N, 0, w, h, kw["basefocal"], kw["n_rand_samples"], kw["global_prop_step"], kw["local_prop_width"],
+            kw["lambda_"], kw["omega"], kw["disp_delta"], kw["delta"], kw["fb_smooth"], kw["s0_ems_prob"], kw["no_change_prob"],
+            kw["range_factor"], kw["update_rigidness_only"])
+    kernels.optimize_depth_gpu(flows, rig, None, None, None, depth, K, Rs, ts, None, None, *args, download=False)
+    g2, gr2, _ = kernels.optimize_depth_gpu(None, None, None, None, None, None, None, None, None, None, None, *args)
+    agree = np.mean(np.abs(d2 - g2) <= 1e-5 * np.abs(d2))
+    assert agree >= 0.98
+
+
+def test_collect_and_compaction(orc, small_scene):
+    from voldor_amd import kernels
+    rng = np.random.default_rng(8)
+    K = K9(*small_scene["K"])
+    flows, Rs, ts, depth, rig = _state(small_scene, rng, noise=0.05)
+    rig[:, 10:30, 20:60] = 0.1  # low rigidness region -> rejected
+    depth[50:60, :] = 0.01      # below sample_min_depth
+    N, h, w, _ = flows.shape
+    for active in range(N):
+        o2, o3 = orc.collect_p3p(flows, rig, depth, K, Rs, ts, active)
+        g2, g3 = kernels.collect_p3p_instances(flows, rig, depth, K, Rs, ts, N, w, h, active)
+        fin_o, fin_g = np.isfinite(o2[..., 0]), np.isfinite(g2[..., 0])
+        assert np.mean(fin_o != fin_g) < 1e-3
+        both = fin_o & fin_g
+        assert both.sum() > 1000
+        assert np.abs(o2[both] - g2[both]).max() < 2e-3
+        assert np.abs(o3[both] - g3[both]).max() < 1e-4 * max(1.0, np.abs(o3[both]).max())
+        # ordered compaction == row-major host scan (geometry.cpp:68-80)
+        c2, c3 = kernels.get_compacted_points(w * h)
+        assert c2.shape[0] == fin_g.sum()
+        np.testing.assert_array_equal(c2, g2[fin_g])
+        np.testing.assert_array_equal(c3, g3[fin_g])
+
+
+def _corr(orc, scene, active=1):
+    rng = np.random.default_rng(9)
+    K = K9(*scene["K"])
+    flows, Rs, ts, depth, rig = _state(scene, rng, noise=0.02)
+    rig[:] = 1.0
+    p2, p3 = orc.collect_p3p(flows, rig, depth, K, Rs, ts, active)
+    return orc.compact_p3p(p2, p3) + (K,)
+
+
+@pytest.mark.parametrize("solver", ["lambdatwist", "ap3p", "lambdatwist_f64"])
+def test_pose_sampling(orc, small_scene, solver):
+    from voldor_amd import kernels
+    pts2, pts3, K = _corr(orc, small_scene)
+    n = 4096
+    if solver == "lambdatwist":
+        orv, otv = orc.solve_batch_p3p(pts3, pts2, K, n)
+        grv, gtv = kernels.solve_batch_p3p_lambdatwist_gpu(pts3, pts2, K, n)
+    elif solver == "lambdatwist_f64":
+        orv, otv = orc.solve_batch_p3p(pts3, pts2, K, n, use_double=True)
+        grv, gtv = kernels.solve_batch_p3p_lambdatwist_f64_gpu(pts3, pts2, K, n)
+    else:
+        orv, otv = orc.solve_batch_p3p(pts3, pts2, K, n, use_ap3p=True)
+        grv, gtv = kernels.solve_batch_p3p_ap3p_gpu(pts3, pts2, K, n)
+    fo = np.isfinite(orv.sum(1) + otv.sum(1))
+    fg = np.isfinite(grv.sum(1) + gtv.sum(1))
+    assert fo.mean() > 0.5
+    assert np.mean(fo != fg) < 0.02
+    both = fo & fg
+    err = np.maximum(np.abs(orv - grv).max(1), np.abs(otv - gtv).max(1))[both]
+    # minimal solvers are ill-conditioned on some 4-tuples: compare the bulk, not the tail
+    tol = 1e-6 if solver == "lambdatwist_f64" else 2e-3
+    assert np.mean(err < tol) > (0.99 if solver == "lambdatwist_f64" else 0.93), np.percentile(err, [50, 90, 99])
+
+
+def test_meanshift_and_robust_gaussian(orc, small_scene):
+    from voldor_amd import kernels
+    pts2, pts3, K = _corr(orc, small_scene)
+    rv, tv = orc.solve_batch_p3p(pts3, pts2, K, 8192)
+    fin = np.isfinite(rv.sum(1) + tv.sum(1))
+    pool = np.concatenate([rv[fin] * 25.0, tv[fin]], 1).astype(np.float32)
+    init = np.zeros(6, np.float32)
+    for ext in (True, False):
+        om, oc, oi = orc.meanshift(pool, 0.2, init, ext)
+        gm, gc, gi = kernels.meanshift_gpu(pool, 0.2, init, ext)
+        assert np.abs(om - gm).max() < 2e-4
+        assert abs(oc - gc) < 1e-4 * max(1, oc)
+        assert abs(oi - gi) <= 2
+    cov0 = (np.eye(6) * 0.2 * 1e4).astype(np.float32)
+    orc_rc, omean, ocov, odens, oit = orc.fit_robust_gaussian(pool * 100, om * 100, cov0)
+    rc, gmean, gcov, gdens, git = kernels.fit_robust_gaussian(pool * 100, om * 100, cov0)
+    assert rc == orc_rc == 0
+    assert abs(odens - gdens) < 2e-3
+    assert np.abs(omean - gmean).max() < 5e-2  # pose x100 units
+    assert np.abs(ocov - gcov).max() < 2e-2 * np.abs(ocov).max()
+
+
+def test_robust_gaussian_rejects_degenerate(orc):
+    from voldor_amd import kernels
+    rng = np.random.default_rng(10)
+    pool = np.zeros((2048, 6), np.float32)
+    pool[:, 0] = rng.normal(0, 1, 2048)  # rank-1 cloud -> singular covariance
+    cov0 = np.zeros((6, 6), np.float32)
+    rc_o = orc.fit_robust_gaussian(pool, np.zeros(6, np.float32), cov0)[0]
+    rc_g = kernels.fit_robust_gaussian(pool, np.zeros(6, np.float32), cov0)[0]
+    assert rc_o != 0 and rc_g != 0
+
+
+def test_meanshift_generic_dims(orc):
+    from voldor_amd import kernels
+    rng = np.random.default_rng(11)
+    space = np.concatenate([rng.normal(0.3, 0.05, (3000, 3)), rng.uniform(-2, 2, (3000, 3))]).astype(np.float32)
+    om, oc, oi = orc.meanshift(space, 0.05, np.zeros(3, np.float32), True)
+    gm, gc, gi = kernels.meanshift_gpu(space, 0.05, np.zeros(3, np.float32), True)
+    assert np.abs(om - gm).max() < 1e-4 and np.abs(gm - 0.3).max() < 0.02
+
+
+def test_gblur(orc):
+    from voldor_amd import kernels
+    rng = np.random.default_rng(12)
+    src = rng.uniform(0, 1, (2, 37, 53)).astype(np.float32)
+    for sigma, ks in ((1.5, 0), (3.0, 9)):
+        rc_o, o = orc.gblur(src, sigma, ks)
+        rc_g, g = kernels.gblur_gpu(src, sigma, ks)
+        assert rc_o == 0 and rc_g == 0
+        assert np.abs(o - g).max() < 1e-5
+    assert kernels.gblur_gpu(src, 100.0, 0)[0] != 0  # half kernel > 128 taps -> error like the reference
+
+
+def test_bootstrap_pieces(orc, small_scene):
+    from voldor_amd import kernels
+    K = K9(*small_scene["K"])
+    ok_o, Ro, to = orc.estimate_pose_epipolar(small_scene["flows"][0], K)
+    ok_g, Rg, tg = kernels.estimate_pose_epipolar(small_scene["flows"][0], K)
+    assert ok_o and ok_g
+    assert np.abs(Ro - Rg).max() < 1e-5 and np.abs(to - tg).max() < 1e-5
+    do = orc.estimate_depth_closed_form(small_scene["flows"][0], K, Ro, to)
+    dg = kernels.estimate_depth_closed_form(small_scene["flows"][0], K, Ro, to)
+    assert np.mean(np.abs(do - dg) <= 1e-3 * np.abs(do)) > 0.99

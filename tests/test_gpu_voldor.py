@@ -1,0 +1,121 @@
+"""End-to-end parity of the B-outer window call (pyvoldor.voldor -> py_voldor_wrapper) against the
+oracle's orc_voldor on the same synthetic optical-flow input, and against analytic ground truth.
+
+north_star tolerance: poses within 1e-3 rad / 1e-3 relative translation of the reference path.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MONO = "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 8"
+STEREO = "--silent --meanshift_kernel_var 0.1 --disp_delta 1 --delta 0.2 --max_iters 8"
+
+
+def _cmp(out_g, out_o, rot_tol=1e-3, tr_tol=1e-3):
+    from voldor_amd import synth
+    assert out_g["n_registered"] == out_o["n_registered"]
+    rot, tr = synth.pose_errors(out_g["poses"], out_o["poses"])
+    assert rot.max() <= rot_tol, rot
+    assert tr.max() <= tr_tol, tr
+
+
+def test_mono_window_matches_oracle(orc):
+    from voldor_amd import pyvoldor, synth
+    sc = synth.make_scene(w=320, h=240, n_flows=5, fx=160, fy=160, cx=160, cy=120, seed=233)
+    fx, fy, cx, cy = sc["K"]
+    g = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config=MONO)
+    o = orc.voldor(sc["flows"], fx, fy, cx, cy, config=MONO)
+    assert g["n_registered"] == 5
+    _cmp(g, o)
+    # covariance of the last-iteration robust fit: same scale
+    assert np.all(np.diagonal(g["poses_covar"], axis1=1, axis2=2) > 0)
+    ratio = np.diagonal(g["poses_covar"], axis1=1, axis2=2) / np.diagonal(o["poses_covar"], axis1=1, axis2=2)
+    assert np.all((ratio > 0.8) & (ratio < 1.25)), ratio
+    # depth: confident pixels agree with the oracle
+    m = (g["depth_conf"] > 0.5) & (o["depth_conf"] > 0.5)
+    rel = np.abs(g["depth"][m] - o["depth"][m]) / o["depth"][m]
+    assert np.mean(rel < 1e-3) > 0.90, np.mean(rel < 1e-3)
+    assert np.median(rel) < 1e-4
+    # and with analytic ground truth up to the monocular scale
+    gt = sc["poses_gt"].copy()
+    s = np.mean(np.linalg.norm(gt[:, 3:], axis=1))
+    gt[:, 3:] /= s
+    rot, tr = synth.pose_errors(g["poses"], gt)
+    assert rot.max() < 3e-3 and tr.max() < 5e-2
+
+
+def test_stereo_window_matches_oracle(orc):
+    from voldor_amd import pyvoldor, synth
+    sc = synth.make_scene(w=312, h=96, n_flows=4, fx=180, fy=180, cx=152, cy=46, seed=236, basefocal=97.0)
+    fx, fy, cx, cy = sc["K"]
+    g = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, basefocal=97.0, disparity=sc["disparity"], config=STEREO)
+    o = orc.voldor(sc["flows"], fx, fy, cx, cy, basefocal=97.0, disparity=sc["disparity"], config=STEREO)
+    _cmp(g, o)
+    rot, tr = synth.pose_errors(g["poses"], sc["poses_gt"])  # metric scale from the disparity prior
+    assert rot.max() < 3e-3 and tr.max() < 5e-2
+
+
+def test_depth_priors_window(orc):
+    from voldor_amd import pyvoldor, synth
+    sc = synth.make_scene(w=160, h=120, n_flows=3, fx=80, fy=80, cx=80, cy=60, seed=237)
+    fx, fy, cx, cy = sc["K"]
+    pri = np.stack([sc["depth_gt"], sc["depth_gt"] * 1.01]).astype(np.float32)
+    poses = np.array([[0, 0, 0, 0, 0, 0], [0.001, 0, 0, 0.01, 0, 0]], np.float32)
+    pc = np.full_like(pri, 0.8)
+    cfg = "--silent --max_iters 4 --delta 0.5"
+    for pconfs in (None, pc):
+        g = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, depth_priors=pri, depth_prior_poses=poses, depth_prior_pconfs=pconfs, config=cfg)
+        o = orc.voldor(sc["flows"], fx, fy, cx, cy, depth_priors=pri, depth_prior_poses=poses, depth_prior_pconfs=pconfs, config=cfg)
+        _cmp(g, o, 2e-3, 2e-3)
+        assert g["depth"].shape == (120, 160) and g["depth_conf"].dtype == np.float32
+
+
+def test_truncation_on_noise_flows(orc):
+    """Window whose last flows are pure noise: both sides must truncate at the same camera
+    (voldor.cpp:187-194)."""
+    from voldor_amd import pyvoldor, synth
+    sc = synth.make_scene(w=160, h=120, n_flows=5, fx=80, fy=80, cx=80, cy=60, seed=238)
+    fx, fy, cx, cy = sc["K"]
+    rng = np.random.default_rng(0)
+    flows = sc["flows"].copy()
+    flows[3:] = rng.uniform(-40, 40, flows[3:].shape).astype(np.float32)
+    g = pyvoldor.voldor(flows, fx, fy, cx, cy, config=MONO)
+    o = orc.voldor(flows, fx, fy, cx, cy, config=MONO)
+    assert g["n_registered"] == o["n_registered"]
+    assert g["n_registered"] < 5
+    assert g["poses"].shape == (g["n_registered"], 6)
+
+
+def test_config_errors_and_flags():
+    from voldor_amd import pyvoldor, synth, capi
+    sc = synth.make_scene(w=64, h=48, n_flows=2, fx=32, fy=32, cx=32, cy=24, seed=1)
+    fx, fy, cx, cy = sc["K"]
+    with pytest.raises(capi.VoldorHipError):
+        pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config="--no_such_key 1")
+    with pytest.raises(capi.VoldorHipError):
+        pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config="--max_iters")
+    with pytest.raises(ValueError):
+        pyvoldor.voldor(sc["flows"].astype(np.float64), fx, fy, cx, cy)
+    out = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config="--silent --max_iters 2 --lambdatwist 0")  # AP3P path
+    assert set(out) == {"n_registered", "poses", "poses_covar", "depth", "depth_conf"}
+    out = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config="--silent --max_iters 2 --optimize_depth 0 --fb_smooth 0 --rg_refine 0")
+    assert np.all(out["poses_covar"] == 0)
+
+
+def test_device_resident_call_matches_host_call():
+    import torch
+    from voldor_amd import pyvoldor, synth
+    sc = synth.make_scene(w=160, h=120, n_flows=3, fx=80, fy=80, cx=80, cy=60, seed=239)
+    fx, fy, cx, cy = sc["K"]
+    a = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config=MONO)
+    fl = torch.from_numpy(sc["flows"]).cuda()
+    d = torch.empty(120, 160, device="cuda")
+    dc = torch.empty(120, 160, device="cuda")
+    b = pyvoldor.voldor_device(fl, fx, fy, cx, cy, config=MONO, depth_out=d, depth_conf_out=dc)
+    # NB the depth RNG counter persists across calls like the reference's cuRAND states
+    # (optimize_depth.cu:358-361), so the two calls draw different samples: statistical equality
+    from voldor_amd import synth as s
+    rot, tr = s.pose_errors(a["poses"], b["poses"])
+    assert rot.max() < 1e-3 and tr.max() < 2e-2
+    assert torch.isfinite(d).all()

@@ -1,0 +1,67 @@
+"""Build libvoldor_hip.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m voldor_amd.build [--force]
+
+The shared library lands in voldor_amd/lib/ (git-ignored, but shipped to the GPU box with the
+repo snapshot).  hipcc cross-compiles gfx950 code objects without a GPU.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libvoldor_hip.so")
+SOURCES = ["vk_abi.hip", "vk_depth.hip", "vk_pose.hip", "vk_bootstrap.hip", "vk_voldor.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
+         "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if p and (os.path.sep not in p or os.path.exists(p)):
+            return p
+    return "hipcc"
+
+
+def _deps():
+    out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
+    inc = os.path.join(os.path.dirname(HERE), "include")
+    out += [os.path.join(inc, f) for f in os.listdir(inc)]
+    return out
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    objdir = os.path.join(LIBDIR, "obj")
+    os.makedirs(objdir, exist_ok=True)
+    newest = max(os.path.getmtime(p) for p in _deps())
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
+        return LIB
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) >= newest:
+            return obj
+        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,381 @@
+// voldor_amd/csrc/vk_abi.hip -- the drop-in boundary "B-inner": the six VO entry points of
+// gpu-kernels/gpu_kernels.h:11-58 with identical names, C++ linkage, argument order, default
+// arguments (in include/gpu_kernels.h), NULL protocol and return convention (0 = success,
+// otherwise the runtime error code as int), so voldor/*.cpp links against this library
+// unchanged.  An extern "C" facade (include/voldor_hip.h) re-exports them for ctypes / FFI.
+#include "vk_common.hpp"
+#include "vk_internal.hpp"
+#include "../../include/gpu_kernels.h"
+#include "../../include/voldor_hip.h"
+#include <mutex>
+
+namespace vk {
+
+int Context::init(int dev) {
+    device = dev;
+    VK_CHECK(hipSetDevice(dev));
+    VK_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    VK_CHECK(hipEventCreate(&ev0));
+    VK_CHECK(hipEventCreate(&ev1));
+    return 0;
+}
+void Context::destroy() {
+    DevBuf* bufs[] = { &od.flows, &od.rig, &od.depth, &od.cost, &od.priors, &od.pconfs, &od.confs, &od.pose,
+                       &cp.flows, &cp.rig, &cp.depth, &cp.cost, &cp.priors, &cp.pconfs, &cp.confs, &cp.pose,
+                       &fb_scratch, &rig_partial, &p2_map, &p3_map, &blk_counts, &blk_offsets, &pts2, &pts3, &n_points,
+                       &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp };
+    for (DevBuf* b : bufs) b->release();
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    if (stream) (void)hipStreamDestroy(stream);
+    stream = nullptr; ev0 = ev1 = nullptr;
+    od.pose_init = cp.pose_init = false;
+}
+
+static std::mutex g_mu;
+static std::map<int, Context*> g_ctx;  // one default context per HIP device
+
+Context* default_context() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) {
+        fprintf(stderr, "voldor_hip: no HIP device available (hipGetDevice failed); the HIP path has no CPU fallback\n");
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ctx.find(dev);
+    if (it != g_ctx.end()) return it->second;
+    Context* c = new Context();
+    if (c->init(dev) != 0) { delete c; return nullptr; }
+    g_ctx[dev] = c;
+    return c;
+}
+
+int prof_begin(Context* c) { return (int)hipEventRecord(c->ev0, c->stream); }
+int prof_end(Context* c, const char* name) {
+    VK_CHECK(hipEventRecord(c->ev1, c->stream));
+    VK_CHECK(hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    VK_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    ProfEntry& e = c->prof_acc[name];
+    e.ms += ms; e.count += 1;
+    return 0;
+}
+
+// -------- helpers ----------------------------------------------------------------------------
+static int upload_K(Context* c, ImageSet& S, const float* h_K) {
+    // K4 = fx,cx,fy,cy ; K4inv = 1/fx,-cx/fx,1/fy,-cy/fy  (optimize_depth.cu:343-350)
+    float k[8] = { h_K[0], h_K[2], h_K[4], h_K[5], 1.f / h_K[0], -h_K[2] / h_K[0], 1.f / h_K[4], -h_K[5] / h_K[4] };
+    VK_CHECK(hipMemcpyAsync(S.pb()->K4, k, sizeof k, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+static int upload_rows(Context* c, float* dst, float* const* src, int n, size_t row_floats) {
+    float tmp[MAX_FRAMES * 9];
+    for (int f = 0; f < n; f++) memcpy(tmp + (size_t)f * row_floats, src[f], row_floats * sizeof(float));
+    VK_CHECK(hipMemcpyAsync(dst, tmp, sizeof(float) * row_floats * n, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+static int upload_layers(Context* c, DevBuf& buf, float* const* src, int n, size_t layer_floats) {
+    for (int f = 0; f < n; f++)
+        VK_CHECK(hipMemcpyAsync(buf.as<float>() + (size_t)f * layer_floats, src[f], sizeof(float) * layer_floats,
+                                hipMemcpyHostToDevice, c->stream));
+    return 0;
+}
+static int download_layers(Context* c, const DevBuf& buf, float* const* dst, int n, size_t layer_floats) {
+    for (int f = 0; f < n; f++)
+        VK_CHECK(hipMemcpyAsync(dst[f], buf.as<float>() + (size_t)f * layer_floats, sizeof(float) * layer_floats,
+                                hipMemcpyDeviceToHost, c->stream));
+    return 0;
+}
+
+}  // namespace vk
+
+using namespace vk;
+
+// ============================================================================================
+// gpu_kernels.h:44-58 / optimize_depth.cu:293-520
+int optimize_depth_gpu(float* h_flows[], float* h_rigidnesses[], float* h_o_rigidnesses[], float* h_depth_priors[],
+                       float* h_depth_prior_pconfs[], float* h_depth_prior_confs[], float* h_o_depth_prior_confs[],
+                       float* h_depth, float* h_o_depth, float* h_K, float* h_Rs[], float* h_ts[], float* h_dp_Rs[],
+                       float* h_dp_ts[], float abs_resize_factor, int N, int N_dp, int w, int h, float basefocal,
+                       int n_rand_samples, int global_prop_step, int local_prop_width, float lambda, float omega,
+                       float disp_delta, float delta, bool fb_smooth, float s0_ems_prob, float no_change_prob,
+                       float range_factor, bool update_rigidness_only) {
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    if (N > MAX_FRAMES || N_dp > MAX_DISP_FRAMES || N < 0 || N_dp < 0 || w <= 0 || h <= 0) return (int)hipErrorInvalidValue;
+    ImageSet& S = c->od;
+    const size_t npx = (size_t)w * h;
+    S.w = w; S.h = h;
+    if (int e = S.ensure_pose()) return e;
+    if (h_K) { if (int e = upload_K(c, S, h_K)) return e; }
+    if (int e = S.depth.reserve(sizeof(float) * npx)) return e;
+    if (h_depth) VK_CHECK(hipMemcpyAsync(S.depth.p, h_depth, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
+    if (N > 0) {
+        if (h_Rs) { if (int e = upload_rows(c, &S.pb()->Rs[0][0], h_Rs, N, 9)) return e; }
+        if (h_ts) { if (int e = upload_rows(c, &S.pb()->ts[0][0], h_ts, N, 3)) return e; }
+        if (int e = S.flows.reserve(sizeof(float) * 2 * npx * N)) return e;
+        if (h_flows) { if (int e = upload_layers(c, S.flows, h_flows, N, npx * 2)) return e; }
+        if (int e = S.rig.reserve(sizeof(float) * npx * N)) return e;
+        if (h_rigidnesses) { if (int e = upload_layers(c, S.rig, h_rigidnesses, N, npx)) return e; }
+    }
+    if (N_dp > 0) {
+        if (h_dp_Rs) { if (int e = upload_rows(c, &S.pb()->dpRs[0][0], h_dp_Rs, N_dp, 9)) return e; }
+        if (h_dp_ts) { if (int e = upload_rows(c, &S.pb()->dpts[0][0], h_dp_ts, N_dp, 3)) return e; }
+        if (int e = S.priors.reserve(sizeof(float) * npx * N_dp)) return e;
+        if (h_depth_priors) { if (int e = upload_layers(c, S.priors, h_depth_priors, N_dp, npx)) return e; }
+        if (int e = S.pconfs.reserve(sizeof(float) * npx * N_dp)) return e;
+        if (h_depth_prior_pconfs) { if (int e = upload_layers(c, S.pconfs, h_depth_prior_pconfs, N_dp, npx)) return e; }
+        if (int e = S.confs.reserve(sizeof(float) * npx * N_dp)) return e;
+        if (h_depth_prior_confs) { if (int e = upload_layers(c, S.confs, h_depth_prior_confs, N_dp, npx)) return e; }
+    }
+    OdParams p;
+    p.abs_resize_factor = abs_resize_factor; p.N = N; p.N_dp = N_dp; p.w = w; p.h = h; p.basefocal = basefocal;
+    p.n_rand_samples = n_rand_samples; p.global_prop_step = global_prop_step; p.local_prop_width = local_prop_width;
+    p.lambda = lambda; p.omega = omega; p.disp_delta = disp_delta; p.delta = delta; p.fb_smooth = fb_smooth;
+    p.s0_ems_prob = s0_ems_prob; p.no_change_prob = no_change_prob; p.range_factor = range_factor;
+    p.update_rigidness_only = update_rigidness_only;
+    if (int e = optimize_depth_device(c, S, p)) return e;
+    if (h_o_depth) VK_CHECK(hipMemcpyAsync(h_o_depth, S.depth.p, sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
+    if (h_o_rigidnesses && N > 0) { if (int e = download_layers(c, S.rig, h_o_rigidnesses, N, npx)) return e; }
+    if (h_o_depth_prior_confs && N_dp > 0) { if (int e = download_layers(c, S.confs, h_o_depth_prior_confs, N_dp, npx)) return e; }
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// gpu_kernels.h:24-35 / collect_p3p_instances.cu:147-250
+int collect_p3p_instances(float* h_flows[], float* h_rigidnesses[], float* h_depth, float* h_K, float* h_Rs[], float* h_ts[],
+                          float* h_o_p2_map, float* h_o_p3_map, int N, int w, int h, int active_idx, float rigidness_thresh,
+                          float rigidness_sum_thresh, float sample_min_depth, float sample_max_depth, int max_trace_on_flow) {
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    if (N > MAX_FRAMES || N <= 0 || w <= 0 || h <= 0 || active_idx < 0 || active_idx >= N) return (int)hipErrorInvalidValue;
+    ImageSet& S = c->cp;
+    const size_t npx = (size_t)w * h;
+    S.w = w; S.h = h;
+    if (int e = S.ensure_pose()) return e;
+    if (h_K) { if (int e = upload_K(c, S, h_K)) return e; }
+    if (h_Rs) { if (int e = upload_rows(c, &S.pb()->Rs[0][0], h_Rs, N, 9)) return e; }
+    if (h_ts) { if (int e = upload_rows(c, &S.pb()->ts[0][0], h_ts, N, 3)) return e; }
+    if (int e = S.flows.reserve(sizeof(float) * 2 * npx * N)) return e;
+    if (h_flows) { if (int e = upload_layers(c, S.flows, h_flows, N, npx * 2)) return e; }
+    if (int e = S.rig.reserve(sizeof(float) * npx * N)) return e;
+    if (h_rigidnesses) { if (int e = upload_layers(c, S.rig, h_rigidnesses, N, npx)) return e; }
+    if (int e = S.depth.reserve(sizeof(float) * npx)) return e;
+    if (h_depth) VK_CHECK(hipMemcpyAsync(S.depth.p, h_depth, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
+    if (int e = collect_device(c, S, N, w, h, active_idx, rigidness_thresh, rigidness_sum_thresh, sample_min_depth,
+                               sample_max_depth, max_trace_on_flow, nullptr))
+        return e;
+    if (h_o_p2_map) VK_CHECK(hipMemcpyAsync(h_o_p2_map, c->p2_map.p, sizeof(float) * 2 * npx, hipMemcpyDeviceToHost, c->stream));
+    if (h_o_p3_map) VK_CHECK(hipMemcpyAsync(h_o_p3_map, c->p3_map.p, sizeof(float) * 3 * npx, hipMemcpyDeviceToHost, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+static int solve_batch_host(float* h_p3s, float* h_p2s, float* h_o_rvecs, float* h_o_tvecs, float* h_K, int N_pts, int N_poses,
+                            int solver) {
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    if (N_pts <= 0 || N_poses <= 0 || !h_K) return (int)hipErrorInvalidValue;
+    if (int e = c->pts2.reserve(sizeof(float) * 2 * (size_t)N_pts)) return e;
+    if (int e = c->pts3.reserve(sizeof(float) * 3 * (size_t)N_pts)) return e;
+    if (int e = c->n_points.reserve(sizeof(int) * 4)) return e;
+    VK_CHECK(hipMemcpyAsync(c->pts2.p, h_p2s, sizeof(float) * 2 * (size_t)N_pts, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipMemcpyAsync(c->pts3.p, h_p3s, sizeof(float) * 3 * (size_t)N_pts, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipMemcpyAsync(c->n_points.p, &N_pts, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    if (int e = solve_device(c, c->pts2.as<float>(), c->pts3.as<float>(), c->n_points.as<int>(), h_K[0], h_K[4], h_K[2], h_K[5],
+                             N_poses, solver))
+        return e;
+    VK_CHECK(hipMemcpyAsync(h_o_rvecs, c->rvecs.p, sizeof(float) * 3 * (size_t)N_poses, hipMemcpyDeviceToHost, c->stream));
+    VK_CHECK(hipMemcpyAsync(h_o_tvecs, c->tvecs.p, sizeof(float) * 3 * (size_t)N_poses, hipMemcpyDeviceToHost, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+// gpu_kernels.h:37-42
+int solve_batch_p3p_ap3p_gpu(float* h_p3s, float* h_p2s, float* h_o_rvecs, float* h_o_tvecs, float* h_K, int N_pts, int N_poses) {
+    return solve_batch_host(h_p3s, h_p2s, h_o_rvecs, h_o_tvecs, h_K, N_pts, N_poses, 1);
+}
+int solve_batch_p3p_lambdatwist_gpu(float* h_p3s, float* h_p2s, float* h_o_rvecs, float* h_o_tvecs, float* h_K, int N_pts,
+                                    int N_poses) {
+    return solve_batch_host(h_p3s, h_p2s, h_o_rvecs, h_o_tvecs, h_K, N_pts, N_poses, 0);
+}
+
+// gpu_kernels.h:11-15 / meanshift.cu:34-150
+int meanshift_gpu(float* h_space, float kernel_var, float* h_io_mean, float* h_o_confidence, int* used_iters,
+                  bool use_external_init_mean, int N, int dims, float epsilon, int max_iters, int max_init_trials,
+                  float good_init_confidence) {
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    if (dims > MAX_POSE_DIMS || dims <= 0 || N <= 0) return (int)hipErrorInvalidValue;
+    if (int e = c->pool.reserve(sizeof(float) * (size_t)N * dims)) return e;
+    if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
+    float io[64] = { 0 };
+    memcpy(io, h_io_mean, sizeof(float) * dims);
+    VK_CHECK(hipMemcpyAsync(c->pool.p, h_space, sizeof(float) * (size_t)N * dims, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipMemcpyAsync(c->ms_io.p, io, sizeof io, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    ModeParams mp{};
+    mp.dims = dims; mp.kernel_var = kernel_var; mp.ms_epsilon = epsilon; mp.ms_max_iters = max_iters;
+    mp.ms_max_init_trials = max_init_trials; mp.ms_good_init_confidence = good_init_confidence;
+    mp.use_external_init_mean = use_external_init_mean ? 1 : 0;
+    if (used_iters) *used_iters = 0;
+    int* ioi = reinterpret_cast<int*>(c->ms_io.as<float>() + 64);
+    if (int e = meanshift_device(c, c->pool.as<float>(), N, mp, c->ms_io.as<float>(), ioi)) return e;
+    int hi[2] = { 0, 0 };
+    VK_CHECK(hipMemcpyAsync(io, c->ms_io.p, sizeof io, hipMemcpyDeviceToHost, c->stream));
+    VK_CHECK(hipMemcpyAsync(hi, ioi, sizeof hi, hipMemcpyDeviceToHost, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(h_io_mean, io, sizeof(float) * dims);
+    if (max_iters > 0) {
+        if (h_o_confidence) *h_o_confidence = io[16];
+        if (used_iters) *used_iters = hi[0];
+    }
+    return 0;
+}
+
+// gpu_kernels.h:17-22 / fit_robust_gaussian.cu:101-286. Returns 0 iff the fit is reliable.
+int fit_robust_gaussian(float* h_space, float* h_io_mean, float* h_io_covar, float trunc_sigma, float covar_reg_lambda,
+                        float* h_o_density, int* used_iters, int N, int dims, float epsilon, int max_iters) {
+    // The reference does a bare `throw` for dims>6 (fit_robust_gaussian.cu:107-108), i.e.
+    // std::terminate; a library should not kill its host process, so report an error instead.
+    if (dims > 6 || dims <= 0 || N <= 0) return (int)hipErrorInvalidValue;
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    if (int e = c->pool.reserve(sizeof(float) * (size_t)N * dims)) return e;
+    if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
+    float io[64] = { 0 };
+    memcpy(io, h_io_mean, sizeof(float) * dims);
+    memcpy(io + 6, h_io_covar, sizeof(float) * dims * dims);
+    VK_CHECK(hipMemcpyAsync(c->pool.p, h_space, sizeof(float) * (size_t)N * dims, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipMemcpyAsync(c->ms_io.p, io, sizeof io, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    ModeParams mp{};
+    mp.dims = dims; mp.rg_trunc_sigma = trunc_sigma; mp.rg_covar_reg_lambda = covar_reg_lambda; mp.rg_epsilon = epsilon;
+    mp.rg_max_iters = max_iters;
+    if (used_iters) *used_iters = 0;
+    int* ioi = reinterpret_cast<int*>(c->ms_io.as<float>() + 64);
+    if (int e = robust_gaussian_device(c, c->pool.as<float>(), N, mp, c->ms_io.as<float>(), ioi)) return e;
+    int hi[2] = { 0, 0 };
+    VK_CHECK(hipMemcpyAsync(io, c->ms_io.p, sizeof io, hipMemcpyDeviceToHost, c->stream));
+    VK_CHECK(hipMemcpyAsync(hi, ioi, sizeof hi, hipMemcpyDeviceToHost, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    if (hi[1] == 0) {
+        if (h_o_density) *h_o_density = io[42];
+        if (used_iters) *used_iters = hi[0];
+        memcpy(h_io_mean, io, sizeof(float) * dims);
+        memcpy(h_io_covar, io + 6, sizeof(float) * dims * dims);
+        return 0;
+    }
+    return 1;  // !cudaSuccess (fit_robust_gaussian.cu:282-285)
+}
+
+// gblur_gpu (gpu-kernels/gblur.cu:47-72) takes GMatf objects in the reference; host-pointer form here.
+static int gblur_host(const float* h_src, float* h_dst, int w, int h, int d, float sigma, int ksize) {
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    const size_t n = (size_t)w * h * d;
+    if (int e = c->tmp.reserve(sizeof(float) * (3 * n + 128))) return e;
+    float* src = c->tmp.as<float>(); float* dst = src + n; float* tmp = dst + n; float* gk = tmp + n;
+    VK_CHECK(hipMemcpyAsync(src, h_src, sizeof(float) * n, hipMemcpyHostToDevice, c->stream));
+    if (int e = gblur_device(c, src, dst, tmp, gk, w, h, d, sigma, ksize)) return e;
+    VK_CHECK(hipMemcpyAsync(h_dst, dst, sizeof(float) * n, hipMemcpyDeviceToHost, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ============================================================================================
+// extern "C" facade (include/voldor_hip.h)
+extern "C" {
+
+int vk_meanshift_gpu(float* h_space, float kernel_var, float* h_io_mean, float* h_o_confidence, int* used_iters,
+                     int use_external_init_mean, int N, int dims, float epsilon, int max_iters, int max_init_trials,
+                     float good_init_confidence) {
+    return meanshift_gpu(h_space, kernel_var, h_io_mean, h_o_confidence, used_iters, use_external_init_mean != 0, N, dims, epsilon,
+                         max_iters, max_init_trials, good_init_confidence);
+}
+int vk_fit_robust_gaussian(float* h_space, float* h_io_mean, float* h_io_covar, float trunc_sigma, float covar_reg_lambda,
+                           float* h_o_density, int* used_iters, int N, int dims, float epsilon, int max_iters) {
+    return fit_robust_gaussian(h_space, h_io_mean, h_io_covar, trunc_sigma, covar_reg_lambda, h_o_density, used_iters, N, dims,
+                               epsilon, max_iters);
+}
+int vk_collect_p3p_instances(float** h_flows, float** h_rigidnesses, float* h_depth, float* h_K, float** h_Rs, float** h_ts,
+                             float* h_o_p2_map, float* h_o_p3_map, int N, int w, int h, int active_idx, float rigidness_thresh,
+                             float rigidness_sum_thresh, float sample_min_depth, float sample_max_depth, int max_trace_on_flow) {
+    return collect_p3p_instances(h_flows, h_rigidnesses, h_depth, h_K, h_Rs, h_ts, h_o_p2_map, h_o_p3_map, N, w, h, active_idx,
+                                 rigidness_thresh, rigidness_sum_thresh, sample_min_depth, sample_max_depth, max_trace_on_flow);
+}
+int vk_solve_batch_p3p_ap3p_gpu(float* h_p3s, float* h_p2s, float* h_o_rvecs, float* h_o_tvecs, float* h_K, int N_pts, int N_poses) {
+    return solve_batch_p3p_ap3p_gpu(h_p3s, h_p2s, h_o_rvecs, h_o_tvecs, h_K, N_pts, N_poses);
+}
+int vk_solve_batch_p3p_lambdatwist_gpu(float* h_p3s, float* h_p2s, float* h_o_rvecs, float* h_o_tvecs, float* h_K, int N_pts,
+                                       int N_poses) {
+    return solve_batch_p3p_lambdatwist_gpu(h_p3s, h_p2s, h_o_rvecs, h_o_tvecs, h_K, N_pts, N_poses);
+}
+int vk_solve_batch_p3p_lambdatwist_f64_gpu(float* h_p3s, float* h_p2s, float* h_o_rvecs, float* h_o_tvecs, float* h_K, int N_pts,
+                                           int N_poses) {
+    return solve_batch_host(h_p3s, h_p2s, h_o_rvecs, h_o_tvecs, h_K, N_pts, N_poses, 2);
+}
+int vk_optimize_depth_gpu(float** h_flows, float** h_rigidnesses, float** h_o_rigidnesses, float** h_depth_priors,
+                          float** h_depth_prior_pconfs, float** h_depth_prior_confs, float** h_o_depth_prior_confs, float* h_depth,
+                          float* h_o_depth, float* h_K, float** h_Rs, float** h_ts, float** h_dp_Rs, float** h_dp_ts,
+                          float abs_resize_factor, int N, int N_dp, int w, int h, float basefocal, int n_rand_samples,
+                          int global_prop_step, int local_prop_width, float lambda, float omega, float disp_delta, float delta,
+                          int fb_smooth, float s0_ems_prob, float no_change_prob, float range_factor, int update_rigidness_only) {
+    return optimize_depth_gpu(h_flows, h_rigidnesses, h_o_rigidnesses, h_depth_priors, h_depth_prior_pconfs, h_depth_prior_confs,
+                              h_o_depth_prior_confs, h_depth, h_o_depth, h_K, h_Rs, h_ts, h_dp_Rs, h_dp_ts, abs_resize_factor, N,
+                              N_dp, w, h, basefocal, n_rand_samples, global_prop_step, local_prop_width, lambda, omega, disp_delta,
+                              delta, fb_smooth != 0, s0_ems_prob, no_change_prob, range_factor, update_rigidness_only != 0);
+}
+int vk_gblur(const float* h_src, float* h_dst, int w, int h, int d, float sigma, int ksize) {
+    return gblur_host(h_src, h_dst, w, h, d, sigma, ksize);
+}
+// Host copy of the compacted correspondences produced by the last collect call (what the host
+// loop of voldor/geometry.cpp:68-80 builds); returns n_points or a negative error.
+int vk_get_compacted_points(float* h_o_pts2, float* h_o_pts3, int max_points) {
+    Context* c = default_context();
+    if (!c || !c->n_points.p) return -1;
+    int n = 0;
+    if (hipMemcpy(&n, c->n_points.p, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) return -2;
+    int m = n < max_points ? n : max_points;
+    if (m > 0) {
+        if (h_o_pts2 && hipMemcpy(h_o_pts2, c->pts2.p, sizeof(float) * 2 * (size_t)m, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+        if (h_o_pts3 && hipMemcpy(h_o_pts3, c->pts3.p, sizeof(float) * 3 * (size_t)m, hipMemcpyDeviceToHost) != hipSuccess) return -3;
+    }
+    return n;
+}
+int vk_set_rand_epoch(unsigned epoch) {
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    c->rand_epoch = epoch;
+    return 0;
+}
+unsigned vk_get_rand_epoch(void) {
+    Context* c = default_context();
+    return c ? c->rand_epoch : 0u;
+}
+int vk_profile_enable(int on) {
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    c->prof = on != 0;
+    if (on) c->prof_acc.clear();
+    return 0;
+}
+int vk_profile_get(const char* name, double* total_ms, long* count) {
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    auto it = c->prof_acc.find(name);
+    if (it == c->prof_acc.end()) { *total_ms = 0; *count = 0; return 1; }
+    *total_ms = it->second.ms; *count = it->second.count;
+    return 0;
+}
+int vk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+int vk_set_device(int dev) { return (int)hipSetDevice(dev); }
+const char* vk_version(void) { return "voldor_hip 0.1 (gfx950)"; }
+
+}  // extern "C"

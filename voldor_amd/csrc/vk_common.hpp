@@ -1,0 +1,156 @@
+// voldor_amd/csrc/vk_common.hpp -- shared host-side plumbing for the MI355X (gfx950) VOLDOR
+// kernel library: error handling, device buffers, the per-device context.
+//
+// The reference keeps file-static device buffers per translation unit
+// (gpu-kernels/optimize_depth.cu:45-52, collect_p3p_instances.cu:29-34), which makes it
+// single-device and non re-entrant.  Here every buffer hangs off a Context that is bound to
+// one HIP device and one stream, so one process per GPU (or several contexts) is possible.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include <string>
+#include <map>
+
+namespace vk {
+
+constexpr int MAX_FRAMES = 16;       // gpu-kernels/optimize_depth.cu:20
+constexpr int MAX_DISP_FRAMES = 16;  // gpu-kernels/optimize_depth.cu:21
+constexpr unsigned RAND_SEED = 233;  // gpu-kernels/utils.h:18
+constexpr int MAX_POSE_DIMS = 16;    // gpu-kernels/meanshift.cu:5
+
+// gpuErrchk equivalent (gpu-kernels/utils.h:21-26): print, return the error code as int.
+#define VK_CHECK(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            fprintf(stderr, "GPUassert : %s\n%s at line %d\n", hipGetErrorString(_e), __FILE__, \
+                    __LINE__);                                                                 \
+            return (int)_e;                                                                    \
+        }                                                                                      \
+    } while (0)
+#define VK_CHECK_LAST() VK_CHECK(hipGetLastError())
+
+// Device-resident camera intrinsics + poses.  Kernels read it through a pointer (uniform
+// address -> scalar loads); the pose kernels write new poses straight into it, so the EM
+// loop never round-trips poses through the host.  Layout mirrors the reference's
+// __constant__ block (optimize_depth.cu:24-29).
+struct PoseBlock {
+    float K4[4];   // fx, cx, fy, cy
+    float K4i[4];  // 1/fx, -cx/fx, 1/fy, -cy/fy
+    float Rs[MAX_FRAMES][9];
+    float ts[MAX_FRAMES][3];
+    float dpRs[MAX_DISP_FRAMES][9];
+    float dpts[MAX_DISP_FRAMES][3];
+};
+
+// Per-camera state kept on the device (voldor/utils.h:31-45 Camera, minus OpenCV).
+struct CamState {
+    float rvec[3];
+    float t[3];
+    float covar[36];
+    float pose_density;
+    float pose_rigidness_density;
+    int pose_sample_count;
+    int last_used_ms_iters;
+    int last_used_gu_iters;
+    int success;   // result of the last optimize_camera_pose (geometry.cpp:5-265 return value)
+    int n_points;  // correspondences that survived compaction (geometry.cpp:68-88)
+    int pad;
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    // grow-only allocation, like GMat::create(lazy) (gpu-kernels/gmat.h:19-33)
+    int reserve(size_t bytes) {
+        if (bytes <= cap) return 0;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) {
+            fprintf(stderr, "GPUassert : %s (hipMalloc %zu bytes)\n", hipGetErrorString(e), bytes);
+            return (int)e;
+        }
+        cap = bytes;
+        return 0;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// One set of window images (flows, rigidness, depth, priors ...), row-major, x fastest,
+// layer stride w*h (the reference's GMat contract, gmat.h:171-173, without the pitch).
+struct ImageSet {
+    int w = 0, h = 0;
+    DevBuf flows;   // [N][h][w] float2
+    DevBuf rig;     // [N][h][w]
+    DevBuf depth;   // [h][w]
+    DevBuf cost;    // [h][w]
+    DevBuf priors, pconfs, confs;  // [N_dp][h][w]
+    DevBuf pose;    // PoseBlock
+    bool pose_init = false;
+    int ensure_pose() {
+        int e = pose.reserve(sizeof(PoseBlock));
+        if (e) return e;
+        if (!pose_init) {
+            if (hipMemset(pose.p, 0, sizeof(PoseBlock)) != hipSuccess) return 1;
+            pose_init = true;
+        }
+        return 0;
+    }
+    PoseBlock* pb() const { return pose.as<PoseBlock>(); }
+};
+
+struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-58)
+    float abs_resize_factor = 1.f;
+    int N = 0, N_dp = 0, w = 0, h = 0;
+    float basefocal = 0.f;
+    int n_rand_samples = 10, global_prop_step = 8, local_prop_width = 32;
+    float lambda = 0.15f, omega = 0.15f, disp_delta = 1.f, delta = 0.5f;
+    bool fb_smooth = true;
+    float s0_ems_prob = 0.5f, no_change_prob = 0.9f, range_factor = 1.f;
+    bool update_rigidness_only = false;
+};
+
+struct ProfEntry { double ms = 0; long count = 0; };
+
+struct Context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // B-inner keeps the reference's two independent caches (optimize_depth.cu vs
+    // collect_p3p_instances.cu statics); the B-outer pipeline uses `od` for everything.
+    ImageSet od, cp;
+    DevBuf fb_scratch;            // forward messages, shared between calls (fb_smooth.h:14-15)
+    DevBuf rig_partial;           // per-block rigidness sums -> pose_rigidness_density
+    DevBuf p2_map, p3_map;        // [h*w][2], [h*w][3] (collect_p3p_instances.cu:27-34)
+    DevBuf blk_counts, blk_offsets;
+    DevBuf pts2, pts3;            // compacted correspondences (geometry.cpp:68-80)
+    DevBuf n_points;              // int
+    DevBuf rvecs, tvecs;          // [n_poses][3]
+    DevBuf pool;                  // [n_poses][dims]
+    DevBuf ms_io;                 // small float/int scratch for B-inner meanshift / robust fit
+    DevBuf cams;                  // CamState[MAX_FRAMES]
+    DevBuf tmp;                   // misc scratch (gblur, depth_conf ...)
+    uint32_t rand_epoch = 0;      // persistent depth-sampling RNG counter (optimize_depth.cu:358-361)
+    int rand_w = 0, rand_h = 0;
+    // profiling (off by default): HIP events on ctx.stream around kernel groups
+    bool prof = false;
+    std::map<std::string, ProfEntry> prof_acc;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int init(int dev);
+    void destroy();
+};
+
+Context* default_context();          // lazily created on the current HIP device
+int prof_begin(Context* c);
+int prof_end(Context* c, const char* name);
+
+}  // namespace vk

@@ -1,0 +1,38 @@
+// voldor_amd/csrc/vk_internal.hpp -- launchers implemented in the .hip translation units.
+#pragma once
+#include "vk_common.hpp"
+
+namespace vk {
+
+struct ModeParams {
+    int dims;
+    float kernel_var, ms_epsilon; int ms_max_iters, ms_max_init_trials; float ms_good_init_confidence;
+    int use_external_init_mean;  // -1: derive from CamState.pose_sample_count on the device
+    float rvec_scale, rg_pose_scaling;
+    int do_rg; float rg_trunc_sigma, rg_covar_reg_lambda, rg_epsilon; int rg_max_iters;
+};
+
+// vk_depth.hip
+int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p);
+int cost_map_device(Context* c, ImageSet& S, const OdParams& p);
+int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob);
+int fill_device(Context* c, float* p, float v, size_t n);
+int scale_device(Context* c, float* p, const float* s_dev, size_t n);
+int disp_to_depth_device(Context* c, const float* disp, float* out, float bf, size_t n);
+int depth_conf_device(Context* c, const float* rig, const float* confs, float* out, int n_flows, int n_dp, size_t npx);
+int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk_dev, int w, int h, int d, float sigma, int ksize);
+
+// vk_pose.hip
+int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
+                   float min_depth, float max_depth, int max_trace, CamState* cam_dev);
+int solve_device(Context* c, const float* pts2, const float* pts3, const int* n_pts_dev, float fx, float fy, float cx, float cy,
+                 int n_poses, int solver);
+int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
+int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
+int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
+int world_scale_device(Context* c, PoseBlock* P, CamState* cams, int n_flows, float* scale_dev);
+
+// vk_bootstrap.hip
+int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, float cx, float cy, CamState* cam0_dev);
+
+}  // namespace vk

@@ -1,0 +1,442 @@
+// voldor_amd/csrc/vk_p3p.hpp -- per-lane minimal pose solvers, everything in registers.
+//   * LambdaTwist P3P (Persson & Nordberg, ECCV'18) + 4th-point disambiguation: what the
+//     reference runs through lambdatwist/lambdatwist_p4p.h:5-62 / lambdatwist_p3p.h:19-294.
+//   * AP3P (Ke & Roumeliotis, CVPR'17) as in gpu-kernels/solve_batch_ap3p.cu:28-378.
+//   * rotation matrix -> nearest rotation -> angle-axis (gpu-kernels/rodrigues.h:5-114).
+// Written for one pose hypothesis per lane of a wave64; no local arrays are indexed
+// dynamically, so nothing spills to scratch.  `S` is the solver scalar (float = the
+// reference's GPU instantiation).
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace vk {
+
+template <typename S> struct V3 { S x, y, z; };
+template <typename S> __device__ __forceinline__ S dot(V3<S> a, V3<S> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <typename S> __device__ __forceinline__ V3<S> cross(V3<S> a, V3<S> b) {
+    return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
+}
+template <typename S> __device__ __forceinline__ V3<S> sub(V3<S> a, V3<S> b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+template <typename S> __device__ __forceinline__ V3<S> scale(V3<S> a, S s) { return { a.x * s, a.y * s, a.z * s }; }
+template <typename S> __device__ __forceinline__ V3<S> normalized(V3<S> a) { return scale(a, S(1) / sqrt(dot(a, a))); }
+template <typename S> struct M3 { S m[9]; };  // row-major
+
+// x^2 + b x + c = 0, numerically stable pair (solve_cubic.h:13-35)
+template <typename S> __device__ __forceinline__ bool root2real(S b, S c, S& r1, S& r2) {
+    S v = b * b - S(4) * c;
+    if (v < S(0)) { r1 = r2 = S(0.5) * b; return false; }
+    S y = sqrt(v);
+    if (b < S(0)) { r1 = S(0.5) * (-b + y); r2 = S(0.5) * (-b - y); }
+    else { r1 = S(2) * c / (-b + y); r2 = S(2) * c / (-b - y); }
+    return true;
+}
+
+// One real root of x^3 + b x^2 + c x + d with the steepest derivative (solve_cubic.h:154-210)
+template <typename S> __device__ __forceinline__ S cubic_root(S b, S c, S d) {
+    S r0;
+    if (b * b >= S(3) * c) {
+        S v = sqrt(b * b - S(3) * c);
+        S t1 = (-b - v) / S(3);
+        S k = ((t1 + b) * t1 + c) * t1 + d;
+        if (k > S(0)) r0 = t1 - sqrt(-k / (S(3) * t1 + b));
+        else {
+            S t2 = (-b + v) / S(3);
+            k = ((t2 + b) * t2 + c) * t2 + d;
+            r0 = t2 + sqrt(-k / (S(3) * t2 + b));
+        }
+    } else {
+        r0 = -b / S(3);
+        if (fabs((S(3) * r0 + S(2) * b) * r0 + c) < S(1e-4)) r0 += S(1);
+    }
+    const S lim = sizeof(S) == 4 ? S(1e-7) : S(1e-13);
+    for (int cnt = 0; cnt < 50; ++cnt) {
+        S fx = ((r0 + b) * r0 + c) * r0 + d;
+        if (cnt < 7 || fabs(fx) > lim) {
+            S fpx = (S(3) * r0 + S(2) * b) * r0 + c;
+            r0 -= fx / fpx;
+        } else
+            break;
+    }
+    return r0;
+}
+
+// Eigen-decomposition of a symmetric 3x3 with one known zero eigenvalue (solve_eig0.h:11-80).
+// Only the first two columns of the eigenvector matrix are needed by the caller.
+template <typename S>
+__device__ __forceinline__ void eig_known0(const S* x, S& e1, S& e2, V3<S>& v1, V3<S>& v2) {
+    S x01s = x[1] * x[1];
+    S b = -x[0] - x[4] - x[8];
+    S c = -x01s - x[2] * x[2] - x[5] * x[5] + x[0] * (x[4] + x[8]) + x[4] * x[8];
+    root2real(b, c, e1, e2);
+    if (fabs(e1) < fabs(e2)) { S t = e1; e1 = e2; e2 = t; }
+    S mx0011 = -x[0] * x[4];
+    S prec0 = x[1] * x[5] - x[2] * x[4];
+    S prec1 = x[1] * x[2] - x[0] * x[5];
+    {
+        S tmp = S(1) / (e1 * (x[0] + x[4]) + mx0011 - e1 * e1 + x01s);
+        S a1 = -(e1 * x[2] + prec0) * tmp, a2 = -(e1 * x[5] + prec1) * tmp;
+        S rn = S(1) / sqrt(a1 * a1 + a2 * a2 + S(1));
+        v1 = { a1 * rn, a2 * rn, rn };
+    }
+    {
+        S tmp = S(1) / (e2 * (x[0] + x[4]) + mx0011 - e2 * e2 + x01s);
+        S a1 = -(e2 * x[2] + prec0) * tmp, a2 = -(e2 * x[5] + prec1) * tmp;
+        S rn = S(1) / sqrt(a1 * a1 + a2 * a2 + S(1));
+        v2 = { a1 * rn, a2 * rn, rn };
+    }
+}
+
+// 5 Gauss-Newton steps on the three law-of-cosines residuals (refine_lambda.h:5-102)
+template <typename S>
+__device__ __forceinline__ void refine_lambda(V3<S>& L, S a12, S a13, S a23, S b12, S b13, S b23) {
+#pragma unroll 1
+    for (int i = 0; i < 5; ++i) {
+        S l1 = L.x, l2 = L.y, l3 = L.z;
+        S r1 = l1 * l1 + l2 * l2 + b12 * l1 * l2 - a12;
+        S r2 = l1 * l1 + l3 * l3 + b13 * l1 * l3 - a13;
+        S r3 = l2 * l2 + l3 * l3 + b23 * l2 * l3 - a23;
+        S e0 = fabs(r1) + fabs(r2) + fabs(r3);
+        if (e0 < S(1e-10)) break;
+        S v0 = S(2) * l1 + b12 * l2, v1 = S(2) * l2 + b12 * l1;
+        S v3 = S(2) * l1 + b13 * l3, v5 = S(2) * l3 + b13 * l1;
+        S v7 = S(2) * l2 + b23 * l3, v8 = S(2) * l3 + b23 * l2;
+        S det = S(1) / (-v0 * v5 * v7 - v1 * v3 * v8);
+        V3<S> n = { l1 - det * (-v5 * v7 * r1 - v1 * v8 * r2 + v1 * v5 * r3),
+                    l2 - det * (-v3 * v8 * r1 + v0 * v8 * r2 - v0 * v5 * r3),
+                    l3 - det * (v3 * v7 * r1 - v0 * v7 * r2 - v1 * v3 * r3) };
+        S q1 = n.x * n.x + n.y * n.y + b12 * n.x * n.y - a12;
+        S q2 = n.x * n.x + n.z * n.z + b13 * n.x * n.z - a13;
+        S q3 = n.y * n.y + n.z * n.z + b23 * n.y * n.z - a23;
+        if (fabs(q1) + fabs(q2) + fabs(q3) > e0) break;
+        L = n;
+    }
+}
+
+// Candidate bookkeeping without dynamically indexed arrays: the best (min 4th-point
+// reprojection) pose is tracked while candidates are generated.
+template <typename S> struct BestPose {
+    S R[9]; S t[3]; S err; int n;
+};
+
+template <typename S>
+__device__ __forceinline__ void consider(BestPose<S>& B, V3<S> L, bool blk0, S a12, S a13, S a23, S b12, S b13, S b23,
+                                         V3<S> y1, V3<S> y2, V3<S> y3, V3<S> x1, const S* Xi, V3<S> x4, S y4u, S y4v,
+                                         S fx, S fy, S cx, S cy) {
+    (void)blk0;
+    refine_lambda(L, a12, a13, a23, b12, b13, b23);
+    V3<S> ry1 = scale(y1, L.x), ry2 = scale(y2, L.y), ry3 = scale(y3, L.z);
+    V3<S> yd1 = sub(ry1, ry2), yd2 = sub(ry1, ry3), yc = cross(yd1, yd2);
+    // R = Y * X^-1, Y = [yd1 yd2 yc] (columns)
+    S R[9];
+    R[0] = yd1.x * Xi[0] + yd2.x * Xi[3] + yc.x * Xi[6]; R[1] = yd1.x * Xi[1] + yd2.x * Xi[4] + yc.x * Xi[7]; R[2] = yd1.x * Xi[2] + yd2.x * Xi[5] + yc.x * Xi[8];
+    R[3] = yd1.y * Xi[0] + yd2.y * Xi[3] + yc.y * Xi[6]; R[4] = yd1.y * Xi[1] + yd2.y * Xi[4] + yc.y * Xi[7]; R[5] = yd1.y * Xi[2] + yd2.y * Xi[5] + yc.y * Xi[8];
+    R[6] = yd1.z * Xi[0] + yd2.z * Xi[3] + yc.z * Xi[6]; R[7] = yd1.z * Xi[1] + yd2.z * Xi[4] + yc.z * Xi[7]; R[8] = yd1.z * Xi[2] + yd2.z * Xi[5] + yc.z * Xi[8];
+    S t0 = ry1.x - (R[0] * x1.x + R[1] * x1.y + R[2] * x1.z);
+    S t1 = ry1.y - (R[3] * x1.x + R[4] * x1.y + R[5] * x1.z);
+    S t2 = ry1.z - (R[6] * x1.x + R[7] * x1.y + R[8] * x1.z);
+    S X = R[0] * x4.x + R[1] * x4.y + R[2] * x4.z + t0;
+    S Y = R[3] * x4.x + R[4] * x4.y + R[5] * x4.z + t1;
+    S Z = R[6] * x4.x + R[7] * x4.y + R[8] * x4.z + t2;
+    S du = cx + fx * X / Z - y4u, dv = cy + fy * Y / Z - y4v;
+    S err = du * du + dv * dv;
+    // lambdatwist_p4p.h:31-41: first candidate always taken, later ones only if strictly better
+    if (B.n == 0 || B.err > err) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) B.R[k] = R[k];
+        B.t[0] = t0; B.t[1] = t1; B.t[2] = t2; B.err = err;
+    }
+    B.n++;
+}
+
+// y: 4 pixel observations (u,v), x: 4 3-D points. Returns false if P3P has no solution.
+template <typename S>
+__device__ static bool lambdatwist_p4p(const float* yu, const float* yv, const float (*xp)[3], float fxf, float fyf,
+                                       float cxf, float cyf, float* Rout, float* tout) {
+    V3<S> y1 = normalized<S>({ (S)((yu[0] - cxf) / fxf), (S)((yv[0] - cyf) / fyf), S(1) });
+    V3<S> y2 = normalized<S>({ (S)((yu[1] - cxf) / fxf), (S)((yv[1] - cyf) / fyf), S(1) });
+    V3<S> y3 = normalized<S>({ (S)((yu[2] - cxf) / fxf), (S)((yv[2] - cyf) / fyf), S(1) });
+    V3<S> x1 = { (S)xp[0][0], (S)xp[0][1], (S)xp[0][2] }, x2 = { (S)xp[1][0], (S)xp[1][1], (S)xp[1][2] };
+    V3<S> x3 = { (S)xp[2][0], (S)xp[2][1], (S)xp[2][2] }, x4 = { (S)xp[3][0], (S)xp[3][1], (S)xp[3][2] };
+    S b12 = S(-2) * dot(y1, y2), b13 = S(-2) * dot(y1, y3), b23 = S(-2) * dot(y2, y3);
+    V3<S> d12 = sub(x1, x2), d13 = sub(x1, x3), d23 = sub(x2, x3), dc = cross(d12, d13);
+    S a12 = dot(d12, d12), a13 = dot(d13, d13), a23 = dot(d23, d23);
+    S c31 = S(-0.5) * b13, c23 = S(-0.5) * b23, c12 = S(-0.5) * b12;
+    S blob = c12 * c23 * c31 - S(1);
+    S s31 = S(1) - c31 * c31, s23 = S(1) - c23 * c23, s12 = S(1) - c12 * c12;
+    S p3 = a13 * (a23 * s31 - a13 * s23);
+    S p2 = S(2) * blob * a23 * a13 + a13 * (S(2) * a12 + a13) * s23 + a23 * (a23 - a12) * s31;
+    S p1 = a23 * (a13 - a23) * s12 - a12 * a12 * s23 - S(2) * a12 * (blob * a23 + a13 * s23);
+    S p0 = a12 * (a12 * s23 - a23 * s12);
+    p3 = S(1) / p3;
+    S g = cubic_root<S>(p2 * p3, p1 * p3, p0 * p3);
+
+    S A[9];
+    A[0] = a23 * (S(1) - g); A[1] = a23 * b12 * S(0.5); A[2] = a23 * b13 * g * S(-0.5);
+    A[4] = a23 - a12 + a13 * g; A[5] = b23 * (a13 * g - a12) * S(0.5); A[8] = g * (a13 - a23) - a12;
+    A[3] = A[1]; A[6] = A[2]; A[7] = A[5];
+    S e1, e2; V3<S> v1, v2;
+    eig_known0<S>(A, e1, e2, v1, v2);
+    S ratio = -e2 / e1;
+    S v = sqrt(ratio > S(0) ? ratio : S(0));
+
+    // X^-1 with X = [d12 d13 d12xd13] columns (matrix.h:636-656 adjugate form)
+    S Xm[9] = { d12.x, d13.x, dc.x, d12.y, d13.y, dc.y, d12.z, d13.z, dc.z };
+    S Xi[9];
+    {
+        S M0 = Xm[4] * Xm[8] - Xm[5] * Xm[7], M1 = Xm[2] * Xm[7] - Xm[1] * Xm[8], M2 = Xm[1] * Xm[5] - Xm[2] * Xm[4];
+        S M3_ = Xm[5] * Xm[6] - Xm[3] * Xm[8], M4 = Xm[0] * Xm[8] - Xm[2] * Xm[6], M5 = Xm[2] * Xm[3] - Xm[0] * Xm[5];
+        S M6 = Xm[3] * Xm[7] - Xm[4] * Xm[6], M7 = Xm[1] * Xm[6] - Xm[0] * Xm[7], M8 = Xm[0] * Xm[4] - Xm[1] * Xm[3];
+        S idet = S(1) / (Xm[0] * M0 + Xm[1] * M3_ + Xm[2] * M6);
+        Xi[0] = M0 * idet; Xi[1] = M1 * idet; Xi[2] = M2 * idet; Xi[3] = M3_ * idet; Xi[4] = M4 * idet;
+        Xi[5] = M5 * idet; Xi[6] = M6 * idet; Xi[7] = M7 * idet; Xi[8] = M8 * idet;
+    }
+    BestPose<S> B;
+    B.n = 0; B.err = S(0);
+    const S y4u = (S)yu[3], y4v = (S)yv[3];
+    const S fx = (S)fxf, fy = (S)fyf, cx = (S)cxf, cy = (S)cyf;
+#pragma unroll 1
+    for (int blk = 0; blk < 2; blk++) {  // s = +v, then s = -v (lambdatwist_p3p.h:140-240)
+        S s = blk == 0 ? v : -v;
+        S w2 = S(1) / (s * v2.x - v1.x);
+        S w0 = (v1.y - s * v2.y) * w2;
+        S w1 = (v1.z - s * v2.z) * w2;
+        S a = S(1) / ((a13 - a12) * w1 * w1 - a12 * b13 * w1 - a12);
+        S b = (a13 * b12 * w1 - a12 * b13 * w0 - S(2) * w0 * w1 * (a12 - a13)) * a;
+        S c = ((a13 - a12) * w0 * w0 + a13 * b12 * w0 + a13) * a;
+        if (b * b - S(4) * c >= S(0)) {
+            S tau1, tau2;
+            root2real(b, c, tau1, tau2);
+#pragma unroll 1
+            for (int k = 0; k < 2; k++) {
+                S tau = k == 0 ? tau1 : tau2;
+                if (tau > S(0)) {
+                    S d = a23 / (tau * (b23 + tau) + S(1));
+                    if (d > S(0)) {  // the +v block relies on sqrt(NaN) failing l1>=0: same outcome
+                        S l2 = sqrt(d), l3 = tau * l2, l1 = w0 * l2 + w1 * l3;
+                        if (l1 >= S(0))
+                            consider<S>(B, { l1, l2, l3 }, blk == 0, a12, a13, a23, b12, b13, b23, y1, y2, y3, x1, Xi, x4,
+                                        y4u, y4v, fx, fy, cx, cy);
+                    }
+                }
+            }
+        }
+    }
+    if (B.n == 0) return false;
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rout[k] = (float)B.R[k];
+    tout[0] = (float)B.t[0]; tout[1] = (float)B.t[1]; tout[2] = (float)B.t[2];
+    return true;
+}
+
+// ---- rotation matrix -> angle-axis -----------------------------------------------------------
+// Nearest rotation by Newton iteration on the polar factor, X <- (X + X^-T)/2 (the reference
+// gets the same factor as U*V^T from an approximate SVD, rodrigues.h:82-108), then Ceres'
+// atan2 formula (rodrigues.h:5-79).
+__device__ __forceinline__ void nearest_rotation(float* X) {
+#pragma unroll 1
+    for (int it = 0; it < 12; it++) {
+        float c0 = X[4] * X[8] - X[5] * X[7], c1 = X[5] * X[6] - X[3] * X[8], c2 = X[3] * X[7] - X[4] * X[6];
+        float c3 = X[2] * X[7] - X[1] * X[8], c4 = X[0] * X[8] - X[2] * X[6], c5 = X[1] * X[6] - X[0] * X[7];
+        float c6 = X[1] * X[5] - X[2] * X[4], c7 = X[2] * X[3] - X[0] * X[5], c8 = X[0] * X[4] - X[1] * X[3];
+        float det = X[0] * c0 + X[1] * c1 + X[2] * c2;
+        if (!(fabsf(det) > 1e-30f)) break;
+        float id = 0.5f / det;
+        float n0 = 0.5f * X[0] + c0 * id, n1 = 0.5f * X[1] + c1 * id, n2 = 0.5f * X[2] + c2 * id;
+        float n3 = 0.5f * X[3] + c3 * id, n4 = 0.5f * X[4] + c4 * id, n5 = 0.5f * X[5] + c5 * id;
+        float n6 = 0.5f * X[6] + c6 * id, n7 = 0.5f * X[7] + c7 * id, n8 = 0.5f * X[8] + c8 * id;
+        float delta = fabsf(n0 - X[0]) + fabsf(n1 - X[1]) + fabsf(n2 - X[2]) + fabsf(n3 - X[3]) + fabsf(n4 - X[4]) +
+                      fabsf(n5 - X[5]) + fabsf(n6 - X[6]) + fabsf(n7 - X[7]) + fabsf(n8 - X[8]);
+        X[0] = n0; X[1] = n1; X[2] = n2; X[3] = n3; X[4] = n4; X[5] = n5; X[6] = n6; X[7] = n7; X[8] = n8;
+        if (delta < 1e-6f) break;
+    }
+}
+__device__ __forceinline__ void rotmat_to_angle_axis(const float* R, float* aa) {
+    float a0 = R[7] - R[5], a1 = R[2] - R[6], a2 = R[3] - R[1];
+    float costheta = fminf(fmaxf((R[0] + R[4] + R[8] - 1.f) * 0.5f, -1.f), 1.f);
+    float sintheta = fminf(sqrtf(a0 * a0 + a1 * a1 + a2 * a2) * 0.5f, 1.f);
+    const float theta = atan2f(sintheta, costheta);
+    if (sintheta > 1.1920929e-07f) {
+        const float r = theta / (2.f * sintheta);
+        aa[0] = a0 * r; aa[1] = a1 * r; aa[2] = a2 * r;
+        return;
+    }
+    if (costheta > 0.f) { aa[0] = a0 * 0.5f; aa[1] = a1 * 0.5f; aa[2] = a2 * 0.5f; return; }
+    // theta ~ pi: axis magnitudes from the diagonal; sintheta >= 0 here, so the reference's
+    // sign fix-up (rodrigues.h:72-77) only flips negative components when sintheta > 0.
+    const float inv = 1.f / (1.f - costheta);
+    float b0 = theta * sqrtf((R[0] - costheta) * inv), b1 = theta * sqrtf((R[4] - costheta) * inv),
+          b2 = theta * sqrtf((R[8] - costheta) * inv);
+    if (sintheta > 0.f) { if (b0 < 0.f) b0 = -b0; if (b1 < 0.f) b1 = -b1; if (b2 < 0.f) b2 = -b2; }
+    aa[0] = b0; aa[1] = b1; aa[2] = b2;
+}
+// angle-axis -> rotation matrix (cv::Rodrigues vec->mat as used at voldor/geometry.cpp:258)
+__host__ __device__ __forceinline__ void angle_axis_to_rotmat(const float* rv, float* R) {
+    double rx = rv[0], ry = rv[1], rz = rv[2];
+    double th = sqrt(rx * rx + ry * ry + rz * rz);
+    if (th < 2.220446049250313e-16) {
+        R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
+        return;
+    }
+    double c = cos(th), s = sin(th), c1 = 1. - c, it = 1. / th;
+    rx *= it; ry *= it; rz *= it;
+    R[0] = (float)(c + c1 * rx * rx);      R[1] = (float)(c1 * rx * ry - s * rz); R[2] = (float)(c1 * rx * rz + s * ry);
+    R[3] = (float)(c1 * rx * ry + s * rz); R[4] = (float)(c + c1 * ry * ry);      R[5] = (float)(c1 * ry * rz - s * rx);
+    R[6] = (float)(c1 * rx * rz - s * ry); R[7] = (float)(c1 * ry * rz + s * rx); R[8] = (float)(c + c1 * rz * rz);
+}
+
+// ---- AP3P ------------------------------------------------------------------------------------
+// Float-complex helpers with the semantics of CUDA's cuComplex.h as the reference uses them.
+struct Cx { float x, y; };
+__device__ __forceinline__ float cx_abs(Cx z) {
+    float a = fabsf(z.x), b = fabsf(z.y), v = fmaxf(a, b), w = fminf(a, b);
+    float t = w / v;
+    t = v * sqrtf(1.0f + t * t);
+    if (v == 0.0f || v > 3.402823466e38f || w > 3.402823466e38f) t = v + w;
+    return t;
+}
+__device__ __forceinline__ Cx cx_div(Cx x, Cx y) {
+    float s = fabsf(y.x) + fabsf(y.y), oos = 1.0f / s;
+    float ars = x.x * oos, ais = x.y * oos, brs = y.x * oos, bis = y.y * oos;
+    s = brs * brs + bis * bis; oos = 1.0f / s;
+    return { (ars * brs + ais * bis) * oos, (ais * brs - ars * bis) * oos };
+}
+__device__ __forceinline__ Cx cx_sqrt(Cx x) {  // solve_batch_ap3p.cu:9-15 (principal root, Im <= 0)
+    float m = cx_abs(x), u = x.x / m;
+    return { sqrtf(m * (u + 1.0f) / 2.0f), -fabsf(sqrtf(m * (1.0f - u) / 2.0f)) };
+}
+// Ferrari quartic as written at solve_batch_ap3p.cu:28-82, INCLUDING the double square root
+// in the q3<0 branch (:57, differs from OpenCV's ap3p.cpp): result parity with the reference
+// wins over fixing it; the two Newton polish steps (:85-98) follow.
+__device__ static void ap3p_quartic(float a4, float a3, float a2, float a1, float a0, float& r0, float& r1, float& r2, float& r3) {
+    float a4_2 = a4 * a4, a3_2 = a3 * a3, a4_3 = a4_2 * a4, a2a4 = a2 * a4;
+    float p4 = (8 * a2a4 - 3 * a3_2) / (8 * a4_2);
+    float q4 = (a3_2 * a3 - 4 * a2a4 * a3 + 8 * a1 * a4_2) / (8 * a4_3);
+    float r4 = (256 * a0 * a4_3 - 3 * (a3_2 * a3_2) - 64 * a1 * a3 * a4_2 + 16 * a2a4 * a3_2) / (256 * (a4_3 * a4));
+    float p3 = ((p4 * p4) / 12 + r4) / 3;
+    float q3 = (72 * r4 * p4 - 2 * p4 * p4 * p4 - 27 * q4 * q4) / 432;
+    float t;
+    Cx w = cx_sqrt({ q3 * q3 - p3 * p3 * p3, 0.f });
+    if (q3 >= 0) { w.x = -w.x - q3; w.y = -w.y; }
+    else { w = cx_sqrt(w); w.x = w.x - q3; }
+    if (w.y == 0.0f) { w.x = cbrtf(w.x); t = 2.0f * (w.x + p3 / w.x); }
+    else {
+        float theta = atan2f(w.y, w.x), mag = powf(cx_abs(w), 1.0f / 3.0f);
+        t = 4.0f * (mag * cosf(theta * (1.0f / 3.0f)));
+    }
+    Cx sq2m = cx_sqrt({ -2 * p4 / 3 + t, 0.f });
+    float B_4A = -a3 / (4 * a4);
+    Cx c1 = { 4 * p4 / 3 + t, 0.f };
+    Cx c2 = cx_div({ 2 * q4, 0.f }, sq2m);
+    float h = sq2m.x * 0.5f;
+    float s1 = cx_sqrt({ -(c1.x + c2.x), -(c1.y + c2.y) }).x * 0.5f;
+    float s2 = cx_sqrt({ -(c1.x - c2.x), -(c1.y - c2.y) }).x * 0.5f;
+    r0 = B_4A + h + s1; r1 = B_4A + h - s1; r2 = B_4A - h + s2; r3 = B_4A - h - s2;
+}
+__device__ __forceinline__ float ap3p_polish(float r, float c0, float c1, float c2, float c3, float c4) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        float err = (((c0 * r + c1) * r + c2) * r + c3) * r + c4;
+        float der = ((4 * c0 * r + 3 * c1) * r + 2 * c2) * r + c3;
+        r -= err / der;
+    }
+    return r;
+}
+// cross product with the reference's vect_cross operand order (solve_batch_ap3p.cu:100-104)
+__device__ __forceinline__ V3<float> vcross(V3<float> a, V3<float> b) {
+    return { a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x };
+}
+__device__ static bool ap3p_p4p(const float* yu, const float* yv, const float (*xp)[3], float fx, float fy, float cx,
+                                float cy, float* Rout, float* tout) {
+    typedef V3<float> F3;
+    F3 bv[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {  // solve_all :294-318
+        float u = (yu[i] - cx) / fx, v = (yv[i] - cy) / fy;
+        float k = 1.f / sqrtf(u * u + v * v + 1);
+        bv[i] = { u * k, v * k, k };
+    }
+    F3 w1 = { xp[0][0], xp[0][1], xp[0][2] }, w2 = { xp[1][0], xp[1][1], xp[1][2] }, w3 = { xp[2][0], xp[2][1], xp[2][2] };
+    F3 b1 = bv[0], b2 = bv[1], b3 = bv[2];
+    // computePoses :152-292
+    F3 u0 = sub(w1, w2);
+    float nu0 = sqrtf(dot(u0, u0));
+    F3 k1 = { u0.x / nu0, u0.y / nu0, u0.z / nu0 };
+    F3 k3 = vcross(b1, b2);
+    float nk3 = sqrtf(dot(k3, k3));
+    k3 = { k3.x / nk3, k3.y / nk3, k3.z / nk3 };
+    F3 tz = vcross(b1, k3), v1 = vcross(b1, b3), v2 = vcross(b2, b3);
+    F3 u1 = sub(w1, w3);
+    float u1k1 = dot(u1, k1), k3b3 = dot(k3, b3);
+    float f11 = k3b3, f13 = dot(k3, v1), f15 = -u1k1 * f11;
+    F3 nl = vcross(u1, k1);
+    float delta = sqrtf(dot(nl, nl));
+    nl = { nl.x / delta, nl.y / delta, nl.z / delta };
+    f11 *= delta; f13 *= delta;
+    float u2k1 = u1k1 - nu0;
+    float f21 = dot(tz, v2), f22 = nk3 * k3b3, f23 = dot(k3, v2);
+    float f24 = u2k1 * f22, f25 = -u2k1 * f21;
+    f21 *= delta; f22 *= delta; f23 *= delta;
+    float g1 = f13 * f22, g2 = f13 * f25 - f15 * f23, g3 = f11 * f23 - f13 * f21, g4 = -f13 * f24;
+    float g5 = f11 * f22, g6 = f11 * f25 - f15 * f21, g7 = -f15 * f24;
+    float q0 = g5 * g5 + g1 * g1 + g3 * g3;
+    float q1 = 2 * (g5 * g6 + g1 * g2 + g3 * g4);
+    float q2 = g6 * g6 + 2 * g5 * g7 + g2 * g2 + g4 * g4 - g1 * g1 - g3 * g3;
+    float q3 = 2 * (g6 * g7 - g1 * g2 - g3 * g4);
+    float q4 = g7 * g7 - g2 * g2 - g4 * g4;
+    float s0, s1, s2, s3;
+    ap3p_quartic(q0, q1, q2, q3, q4, s0, s1, s2, s3);
+    // polishQuarticRoots interleaves the 4 roots per iteration but roots are independent
+    s0 = ap3p_polish(s0, q0, q1, q2, q3, q4); s1 = ap3p_polish(s1, q0, q1, q2, q3, q4);
+    s2 = ap3p_polish(s2, q0, q1, q2, q3, q4); s3 = ap3p_polish(s3, q0, q1, q2, q3, q4);
+    F3 tmp = vcross(k1, nl);
+    // Ck1nl = [k1 nl tmp] (columns), Cb1k3tzT = rows b1,k3,tz
+    F3 b3p = scale(b3, delta / k3b3);
+    const F3 x4 = { xp[3][0], xp[3][1], xp[3][2] };
+    int n = 0;
+    float best = 0.f;
+#pragma unroll 1
+    for (int i = 0; i < 4; i++) {
+        float ct1 = i == 0 ? s0 : (i == 1 ? s1 : (i == 2 ? s2 : s3));
+        if (fabsf(ct1) > 1) continue;
+        float st1 = sqrtf(1 - ct1 * ct1);
+        st1 = (k3b3 > 0) ? st1 : -st1;
+        float ct3 = g1 * ct1 + g2, st3 = g3 * ct1 + g4;
+        float nt3 = st1 / ((g5 * ct1 + g6) * ct1 + g7);
+        ct3 *= nt3; st3 *= nt3;
+        // C13 rows
+        float C[9] = { ct3, 0, -st3, st1 * st3, ct1, st1 * ct3, ct1 * st3, -st1, ct1 * ct3 };
+        // T = Ck1nl * C13
+        float T[9];
+        const float A[9] = { k1.x, nl.x, tmp.x, k1.y, nl.y, tmp.y, k1.z, nl.z, tmp.z };
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) T[r * 3 + c] = A[r * 3] * C[c] + A[r * 3 + 1] * C[3 + c] + A[r * 3 + 2] * C[6 + c];
+        const float Bm[9] = { b1.x, b1.y, b1.z, k3.x, k3.y, k3.z, tz.x, tz.y, tz.z };
+        float R[9];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) R[r * 3 + c] = T[r * 3] * Bm[c] + T[r * 3 + 1] * Bm[3 + c] + T[r * 3 + 2] * Bm[6 + c];
+        // rp3 = R^T w3 ; t = st1*b3p - rp3 ; solution rotation = R^T (:263-287)
+        float rp0 = w3.x * R[0] + w3.y * R[3] + w3.z * R[6];
+        float rp1 = w3.x * R[1] + w3.y * R[4] + w3.z * R[7];
+        float rp2 = w3.x * R[2] + w3.y * R[5] + w3.z * R[8];
+        float t0 = b3p.x * st1 - rp0, t1 = b3p.y * st1 - rp1, t2 = b3p.z * st1 - rp2;
+        float Rt[9] = { R[0], R[3], R[6], R[1], R[4], R[7], R[2], R[5], R[8] };
+        float X = Rt[0] * x4.x + Rt[1] * x4.y + Rt[2] * x4.z + t0;
+        float Y = Rt[3] * x4.x + Rt[4] * x4.y + Rt[5] * x4.z + t1;
+        float Z = Rt[6] * x4.x + Rt[7] * x4.y + Rt[8] * x4.z + t2;
+        float du = cx + fx * X / Z - yu[3], dv = cy + fy * Y / Z - yv[3];
+        float err = du * du + dv * dv;
+        if (n == 0 || best > err) {
+#pragma unroll
+            for (int k = 0; k < 9; k++) Rout[k] = Rt[k];
+            tout[0] = t0; tout[1] = t1; tout[2] = t2; best = err;
+        }
+        n++;
+    }
+    return n > 0;
+}
+
+}  // namespace vk

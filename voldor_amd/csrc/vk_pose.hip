@@ -1,0 +1,622 @@
+// voldor_amd/csrc/vk_pose.hip -- pose half of the EM loop on gfx950, device resident.
+// Replaces gpu-kernels/collect_p3p_instances.cu:57-145, the host compaction loop of
+// voldor/geometry.cpp:68-88, solve_batch_{lambdatwist,ap3p}.cu, meanshift.cu:34-150 (+ its
+// host-driven reductions, reduce_vector_sum.h) and fit_robust_gaussian.cu:101-286 (+ the host
+// 6x6 algebra of aux_funs.cpp:101-141).
+//
+// Reference flow per camera per EM iteration: D2H of 6 MB of NaN-sparse maps, a 307k-iteration
+// host scan, H2D of the compacted list, 5 cudaMalloc/cudaFree, ~3 launches + 2 blocking D2H per
+// mean-shift iteration.  Here: collect -> wave-ballot ordered compaction -> one lane per pose
+// hypothesis -> ONE single-workgroup kernel that runs the whole mean-shift (and robust
+// Gaussian) iteration loop with shuffle/LDS reductions and writes the new pose straight into
+// the device PoseBlock.  Only a CamState record is ever read back.
+#include "vk_common.hpp"
+#include "vk_device.hpp"
+#include "vk_p3p.hpp"
+#include "vk_internal.hpp"
+
+namespace vk {
+
+// ---- collect_p3p_instances.cu:70-145, 1-D pixel indexing so that block order == row-major order
+__global__ __launch_bounds__(256) static void k_collect(const float2* __restrict__ flows, const float* __restrict__ rig,
+                                                         const float* __restrict__ depth, const PoseBlock* __restrict__ P,
+                                                         float* __restrict__ p2_map, float* __restrict__ p3_map,
+                                                         int* __restrict__ blk_counts, int N, int w, int h, int active_idx,
+                                                         float rig_thresh, float rig_sum_thresh, float min_depth,
+                                                         float max_depth, int max_trace) {
+    const int npx = w * h;
+    const int pi = blockIdx.x * 256 + threadIdx.x;
+    const float qnan = __builtin_nanf("");
+    bool valid = false;
+    float px = qnan, py = qnan;
+    P3 o = { qnan, qnan, qnan };
+    if (pi < npx) {
+        const int x = pi % w, y = pi / w;
+        float d = depth[pi];
+        bool ok = !(d < min_depth || (max_depth > 0.f && d > max_depth));
+        if (ok && rig_sum_thresh > (float)(N + 1)) {  // inert unless thr > N+1 (sic, :88-90)
+            float rs = 0.f;
+            for (int i = 0; i < N; i++) rs += rig[(size_t)i * npx + pi];
+            if (rs < rig_sum_thresh) ok = false;
+        }
+        int n_trace = 0;
+        if (ok) {
+            float prod = 1.f;
+            const int lo = max_trace > 0 ? max(0, active_idx - max_trace + 1) : 0;
+            for (int i = active_idx; i >= lo; i--) {
+                prod *= rig[(size_t)i * npx + pi];
+                if (prod > rig_thresh) n_trace++;
+                else break;
+            }
+            ok = n_trace > 0;
+        }
+        if (ok) {
+            o = backproject(P, (float)x, (float)y, d);
+            bool out = false;
+            for (int i = 0; i <= active_idx; i++) {
+                if (i >= active_idx - n_trace + 1) {
+                    if (i == active_idx - n_trace + 1) project(P, o, px, py);
+                    if (px > 0.f && px < (float)w && py > 0.f && py < (float)h) {  // strict (:120)
+                        float2 f2 = bilinear2(flows + (size_t)i * npx, w, h, px, py);
+                        px += f2.x; py += f2.y;
+                    } else { out = true; break; }
+                }
+                if (i < active_idx) o = transform(P->Rs[i], P->ts[i], o);
+            }
+            valid = !out && o.z > min_depth && (max_depth <= 0.f || o.z < max_depth);
+            // geometry.cpp:73 keeps only entries whose sum is finite
+            valid = valid && isfinite(px + py + o.x + o.y + o.z);
+        }
+        p2_map[(size_t)pi * 2] = valid ? px : qnan; p2_map[(size_t)pi * 2 + 1] = valid ? py : qnan;
+        p3_map[(size_t)pi * 3] = valid ? o.x : qnan; p3_map[(size_t)pi * 3 + 1] = valid ? o.y : qnan;
+        p3_map[(size_t)pi * 3 + 2] = valid ? o.z : qnan;
+    }
+    __shared__ int s_cnt[4];
+    unsigned long long m = __ballot(valid);
+    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) blk_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// exclusive scan of the per-block counts (single workgroup), total -> *n_points
+__global__ __launch_bounds__(1024) static void k_scan_counts(const int* __restrict__ counts, int* __restrict__ offsets, int n,
+                                                              int* __restrict__ n_points, CamState* cam) {
+    __shared__ int s_wave[16];
+    __shared__ int s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = 0; base < n; base += 1024) {
+        int i = base + threadIdx.x;
+        int v = i < n ? counts[i] : 0;
+        int incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        int wave_off = 0;
+        for (int k = 0; k < wv; k++) wave_off += s_wave[k];
+        int carry = s_carry;
+        if (i < n) offsets[i] = carry + wave_off + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = carry + wave_off + incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { *n_points = s_carry; if (cam) cam->n_points = s_carry; }
+}
+
+// ordered compaction of the finite entries (voldor/geometry.cpp:68-80) with wave ballots
+__global__ __launch_bounds__(256) static void k_compact(const float* __restrict__ p2_map, const float* __restrict__ p3_map,
+                                                         const int* __restrict__ offsets, float* __restrict__ pts2,
+                                                         float* __restrict__ pts3, int npx) {
+    const int pi = blockIdx.x * 256 + threadIdx.x;
+    float a = 0, b = 0, cx = 0, cy = 0, cz = 0;
+    bool valid = false;
+    if (pi < npx) {
+        a = p2_map[(size_t)pi * 2]; b = p2_map[(size_t)pi * 2 + 1];
+        cx = p3_map[(size_t)pi * 3]; cy = p3_map[(size_t)pi * 3 + 1]; cz = p3_map[(size_t)pi * 3 + 2];
+        valid = isfinite(a + b + cx + cy + cz);
+    }
+    __shared__ int s_cnt[4];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    unsigned long long m = __ballot(valid);
+    if (lane == 0) s_cnt[wv] = __popcll(m);
+    __syncthreads();
+    int off = offsets[blockIdx.x];
+    for (int k = 0; k < wv; k++) off += s_cnt[k];
+    if (valid) {
+        int r = off + __popcll(m & ((1ull << lane) - 1ull));
+        pts2[(size_t)r * 2] = a; pts2[(size_t)r * 2 + 1] = b;
+        pts3[(size_t)r * 3] = cx; pts3[(size_t)r * 3 + 1] = cy; pts3[(size_t)r * 3 + 2] = cz;
+    }
+}
+
+// ---- batched pose hypotheses: one lane each (solve_batch_lambdatwist.cu:11-42, solve_batch_ap3p.cu:331-378)
+template <int SOLVER>  // 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>
+__global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ pts2, const float* __restrict__ pts3,
+                                                      float* __restrict__ rvecs, float* __restrict__ tvecs,
+                                                      const int* __restrict__ n_pts_dev, float fx, float fy, float cx, float cy,
+                                                      int n_poses) {
+    const int idx = blockIdx.x * 64 + threadIdx.x;
+    if (idx >= n_poses) return;
+    const int n_pts = *n_pts_dev;
+    const float qnan = __builtin_nanf("");
+    float R[9], t[3];
+    bool ok = false;
+    if (n_pts >= 1) {
+        float yu[4], yv[4], xp[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            // 4 indices per hypothesis; the reference re-seeds per call so the pattern depends only
+            // on (idx, n_pts) (solve_batch_lambdatwist.cu:16-19,80-81). u in (0,1]: clamp the
+            // one-past-the-end index the reference can produce.
+            int i = (int)(u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)k)) * (float)n_pts);
+            i = min(i, n_pts - 1);
+            yu[k] = pts2[(size_t)i * 2]; yv[k] = pts2[(size_t)i * 2 + 1];
+            xp[k][0] = pts3[(size_t)i * 3]; xp[k][1] = pts3[(size_t)i * 3 + 1]; xp[k][2] = pts3[(size_t)i * 3 + 2];
+        }
+        if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t);
+        else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t);
+        else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t);
+    }
+    float aa[3] = { qnan, qnan, qnan };
+    if (ok) { nearest_rotation(R); rotmat_to_angle_axis(R, aa); }
+    rvecs[(size_t)idx * 3] = aa[0]; rvecs[(size_t)idx * 3 + 1] = aa[1]; rvecs[(size_t)idx * 3 + 2] = aa[2];
+    tvecs[(size_t)idx * 3] = ok ? t[0] : qnan; tvecs[(size_t)idx * 3 + 1] = ok ? t[1] : qnan; tvecs[(size_t)idx * 3 + 2] = ok ? t[2] : qnan;
+}
+
+// ---- single-workgroup mode finding ---------------------------------------------------------------
+constexpr int MS_THREADS = 1024;
+struct BlockRed {  // all-reduce of NV floats over the 1024-thread workgroup, fixed order
+    float wave[16][32];
+    float total[32];
+};
+template <int NV>
+__device__ __forceinline__ void block_allreduce(float* v, BlockRed& br) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        float s = wave_sum(v[k]);
+        if (lane == 0) br.wave[wv][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; j++) s += br.wave[j][threadIdx.x];
+        br.total[threadIdx.x] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = br.total[k];
+    __syncthreads();
+}
+
+
+// mean-shift on `space[N][dims]` (generic dims<=16): returns via LDS-broadcast state.
+// mean_io: in = current mean (io semantics of h_io_mean), out = mode.
+__device__ static void meanshift_block(const float* __restrict__ space, int N, int dims, const ModeParams& mp,
+                                       float* mean_io /*LDS [16]*/, float* c_mean /*LDS [16]*/, BlockRed& br,
+                                       float* o_conf, int* o_iters) {
+    __shared__ int s_stop;
+    const int tid = threadIdx.x;
+    const float inv2v = 1.f / (2.f * mp.kernel_var);
+    if (mp.use_external_init_mean) {
+        if (tid < dims) c_mean[tid] = mean_io[tid];
+        __syncthreads();
+    } else {  // best of <= max_init_trials random samples (meanshift.cu:72-95), host rand() -> rng3
+        float best = 0.f; int best_idx = 0; bool have = false;
+        for (int trial = 0; trial < mp.ms_max_init_trials; trial++) {
+            int idx_rand = (int)(rng3(RAND_SEED, (uint32_t)trial, 0x4D53u) % (uint32_t)N);
+            float acc[1] = { 0.f };
+            for (int i = tid; i < N; i += MS_THREADS) {
+                float l2 = 0.f;
+                for (int d = 0; d < dims; d++) { float df = space[(size_t)i * dims + d] - space[(size_t)idx_rand * dims + d]; l2 += df * df; }
+                acc[0] += __expf(-l2 * inv2v);
+            }
+            block_allreduce<1>(acc, br);
+            if (acc[0] > best) { best = acc[0]; best_idx = idx_rand; have = true; }
+            if (best > mp.ms_good_init_confidence * (float)N) break;
+        }
+        (void)have;
+        if (tid < dims) c_mean[tid] = space[(size_t)best_idx * dims + tid];
+        __syncthreads();
+    }
+    int iters = 0;
+    float conf = 0.f;
+    for (int iter = 0; iter < mp.ms_max_iters; iter++) {  // meanshift.cu:103-134
+        float acc[17];
+#pragma unroll
+        for (int k = 0; k < 17; k++) acc[k] = 0.f;
+        if (dims == 6) {
+            float m0 = c_mean[0], m1 = c_mean[1], m2 = c_mean[2], m3 = c_mean[3], m4 = c_mean[4], m5 = c_mean[5];
+            for (int i = tid; i < N; i += MS_THREADS) {
+                const float* s = space + (size_t)i * 6;
+                float x0 = s[0], x1 = s[1], x2 = s[2], x3 = s[3], x4 = s[4], x5 = s[5];
+                float l2 = (x0 - m0) * (x0 - m0) + (x1 - m1) * (x1 - m1) + (x2 - m2) * (x2 - m2) + (x3 - m3) * (x3 - m3) +
+                           (x4 - m4) * (x4 - m4) + (x5 - m5) * (x5 - m5);
+                float wgt = __expf(-l2 * inv2v);
+                acc[0] += wgt; acc[1] += wgt * x0; acc[2] += wgt * x1; acc[3] += wgt * x2; acc[4] += wgt * x3;
+                acc[5] += wgt * x4; acc[6] += wgt * x5;
+            }
+            block_allreduce<7>(acc, br);
+        } else {
+            for (int i = tid; i < N; i += MS_THREADS) {
+                float l2 = 0.f;
+                for (int d = 0; d < dims; d++) { float df = space[(size_t)i * dims + d] - c_mean[d]; l2 += df * df; }
+                float wgt = __expf(-l2 * inv2v);
+                acc[0] += wgt;
+#pragma unroll
+                for (int d = 0; d < 16; d++) if (d < dims) acc[1 + d] += wgt * space[(size_t)i * dims + d];
+            }
+            block_allreduce<17>(acc, br);
+        }
+        conf = acc[0] / (float)N;
+        iters = iter + 1;
+        if (tid == 0) {
+            float disp = 0.f;
+            for (int d = 0; d < dims; d++) {
+                float m = acc[1 + d] / acc[0];
+                disp += (mean_io[d] - m) * (mean_io[d] - m);  // vs. the stale io mean on the 1st pass (SURVEY B-6)
+                mean_io[d] = m;
+                c_mean[d] = m;
+            }
+            s_stop = sqrtf(disp) < mp.ms_epsilon;
+        }
+        __syncthreads();
+        if (s_stop) break;
+    }
+    *o_conf = conf;
+    *o_iters = iters;
+}
+
+// 6x6 (n<=6) inverse + determinant in double by LU with partial pivoting (aux_funs.cpp:101-118:
+// cv::determinant / cv::Matx::inv). Runs on one lane.
+__device__ static double lu_inverse6(const double* A, double* Ainv, int n) {
+    double a[36], b[36];
+    for (int i = 0; i < n * n; i++) { a[i] = A[i]; b[i] = 0.0; }
+    for (int i = 0; i < n; i++) b[i * n + i] = 1.0;
+    double det = 1.0;
+    for (int i = 0; i < n; i++) {
+        int k = i;
+        for (int j = i + 1; j < n; j++) if (fabs(a[j * n + i]) > fabs(a[k * n + i])) k = j;
+        if (fabs(a[k * n + i]) < 2.220446049250313e-16) return 0.0;
+        if (k != i) {
+            for (int j = 0; j < n; j++) {
+                double t = a[i * n + j]; a[i * n + j] = a[k * n + j]; a[k * n + j] = t;
+                t = b[i * n + j]; b[i * n + j] = b[k * n + j]; b[k * n + j] = t;
+            }
+            det = -det;
+        }
+        det *= a[i * n + i];
+        double d = -1.0 / a[i * n + i];
+        for (int j = i + 1; j < n; j++) {
+            double alpha = a[j * n + i] * d;
+            for (int c = i + 1; c < n; c++) a[j * n + c] += alpha * a[i * n + c];
+            for (int c = 0; c < n; c++) b[j * n + c] += alpha * b[i * n + c];
+        }
+    }
+    if (det > 0.0) {
+        for (int i = n - 1; i >= 0; i--)
+            for (int c = 0; c < n; c++) {
+                double s = b[i * n + c];
+                for (int k = i + 1; k < n; k++) s -= a[i * n + k] * b[k * n + c];
+                b[i * n + c] = s / a[i * n + i];
+            }
+        for (int i = 0; i < n * n; i++) Ainv[i] = b[i];
+    }
+    return det;
+}
+
+// robust Gaussian on `space[N][dims]`, dims<=6 (fit_robust_gaussian.cu:131-263).
+// mean[6]/covar_half[21] in LDS: in = initial, out = result (only if reliable). returns reliable.
+__device__ static bool robust_gaussian_block(const float* __restrict__ space, int N, int dims, float scale, const ModeParams& mp,
+                                             float* mean /*LDS[6]*/, float* covar_half /*LDS[21]*/, float* cinv_half /*LDS[21]*/,
+                                             BlockRed& br, float* o_density, int* o_iters) {
+    __shared__ int s_flag;  // 0 continue, 1 converged, 2 unreliable
+    const int tid = threadIdx.x;
+    const int dc = (dims * dims + dims) / 2;
+    float weight = 0.f;
+    int iter = 0;
+    bool reliable = true;
+    for (iter = 0; iter < mp.rg_max_iters; iter++) {
+        if (tid == 0) {
+            double full[36], inv[36];
+            for (int d1 = 0; d1 < dims; d1++)
+                for (int d2 = 0; d2 <= d1; d2++) {
+                    full[d1 * dims + d2] = (double)covar_half[(d1 * d1 + d1) / 2 + d2];
+                    full[d2 * dims + d1] = full[d1 * dims + d2];
+                }
+            if (iter > 0 && mp.rg_covar_reg_lambda > 0.f) {  // Ledoit-Wolf, fixed lambda (aux_funs.cpp:124-141)
+                double tr = 0;
+                for (int d = 0; d < dims; d++) tr += full[d * dims + d];
+                const double m = tr / (double)dims, lam = (double)mp.rg_covar_reg_lambda;
+                for (int i = 0; i < dims; i++)
+                    for (int j = 0; j < dims; j++) full[i * dims + j] = lam * m * (i == j ? 1.0 : 0.0) + (1 - lam) * full[i * dims + j];
+            }
+            double det = lu_inverse6(full, inv, dims);
+            if (det <= 0) s_flag = 2;
+            else {
+                s_flag = 0;
+                for (int d1 = 0; d1 < dims; d1++)
+                    for (int d2 = 0; d2 <= d1; d2++) {
+                        covar_half[(d1 * d1 + d1) / 2 + d2] = (float)full[d1 * dims + d2];
+                        cinv_half[(d1 * d1 + d1) / 2 + d2] = (float)inv[d1 * dims + d2];
+                    }
+            }
+        }
+        __syncthreads();
+        if (s_flag == 2) { reliable = false; break; }
+        const float prev_density = weight / (float)N;
+        float acc[28];
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc[k] = 0.f;
+        for (int i = tid; i < N; i += MS_THREADS) {  // e_step (fit_robust_gaussian.cu:56-97)
+            float x[6], diff[6];
+#pragma unroll
+            for (int d = 0; d < 6; d++) { x[d] = d < dims ? space[(size_t)i * dims + d] * scale : 0.f; diff[d] = d < dims ? x[d] - mean[d] : 0.f; }
+            float z = 0.f;
+#pragma unroll
+            for (int d1 = 0; d1 < 6; d1++) {
+                float tmp = 0.f;
+#pragma unroll
+                for (int d2 = 0; d2 < 6; d2++) {
+                    if (d1 < dims && d2 < dims) {
+                        int hi = d1 >= d2 ? d1 : d2, lo = d1 >= d2 ? d2 : d1;
+                        tmp += cinv_half[(hi * hi + hi) / 2 + lo] * diff[d2];
+                    }
+                }
+                z += tmp * diff[d1];
+            }
+            z = sqrtf(z);
+            const float wgt = z < mp.rg_trunc_sigma ? 1.f : 0.f;
+            acc[0] += wgt;
+#pragma unroll
+            for (int d = 0; d < 6; d++) acc[1 + d] += wgt * x[d];
+#pragma unroll
+            for (int d1 = 0; d1 < 6; d1++)
+#pragma unroll
+                for (int d2 = 0; d2 <= d1; d2++) acc[7 + (d1 * d1 + d1) / 2 + d2] += wgt * diff[d1] * diff[d2];
+        }
+        block_allreduce<28>(acc, br);
+        weight = acc[0];
+        if (!isfinite(weight)) { reliable = false; break; }
+        const float density_change = fabsf(weight / (float)N - prev_density);
+        if (density_change < mp.rg_epsilon) { reliable = true; break; }
+        if (tid == 0) {
+            for (int d = 0; d < dims; d++) mean[d] = acc[1 + d] / weight;
+            for (int k = 0; k < dc; k++) covar_half[k] = acc[7 + k] / weight;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    *o_density = weight / (float)N;
+    *o_iters = iter;
+    return reliable;
+}
+
+// ---- the per-camera mode kernel of the device-resident pipeline (voldor/geometry.cpp:156-263)
+__global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
+                                                                  float* __restrict__ pool, int n_poses, ModeParams mp,
+                                                                  CamState* cam, PoseBlock* P, int cam_idx,
+                                                                  const int* __restrict__ n_points_dev) {
+    __shared__ BlockRed br;
+    __shared__ float s_mean[16], s_cmean[16], s_rgmean[6], s_cov[21], s_cinv[21];
+    __shared__ int s_wave_cnt[16];
+    __shared__ int s_used;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    // successive pose? (voldor.cpp:177: pose_sample_count != 0), decided on the device
+    if (mp.use_external_init_mean < 0) mp.use_external_init_mean = cam->pose_sample_count != 0;
+    __syncthreads();
+    if (*n_points_dev < 4) {  // geometry.cpp:84-88
+        if (tid == 0) cam->success = 0;
+        return;
+    }
+    // ordered compaction of the finite hypotheses into pool[used][6], rvec pre-scaled (:156-165,:191)
+    if (tid == 0) s_used = 0;
+    __syncthreads();
+    for (int base = 0; base < n_poses; base += MS_THREADS) {
+        const int i = base + tid;
+        float v[6] = { 0, 0, 0, 0, 0, 0 };
+        bool fin = false;
+        if (i < n_poses) {
+            v[0] = rvecs[(size_t)i * 3]; v[1] = rvecs[(size_t)i * 3 + 1]; v[2] = rvecs[(size_t)i * 3 + 2];
+            v[3] = tvecs[(size_t)i * 3]; v[4] = tvecs[(size_t)i * 3 + 1]; v[5] = tvecs[(size_t)i * 3 + 2];
+            fin = isfinite(v[0] + v[1] + v[2] + v[3] + v[4] + v[5]);
+        }
+        unsigned long long m = __ballot(fin);
+        if (lane == 0) s_wave_cnt[wv] = __popcll(m);
+        __syncthreads();
+        int off = s_used, tot = 0;
+        for (int k = 0; k < 16; k++) { if (k < wv) off += s_wave_cnt[k]; tot += s_wave_cnt[k]; }
+        if (fin) {
+            int r = off + __popcll(m & ((1ull << lane) - 1ull));
+            float* d = pool + (size_t)r * 6;
+            d[0] = v[0] * mp.rvec_scale; d[1] = v[1] * mp.rvec_scale; d[2] = v[2] * mp.rvec_scale;
+            d[3] = v[3]; d[4] = v[4]; d[5] = v[5];
+        }
+        __syncthreads();
+        if (tid == 0) s_used += tot;
+        __syncthreads();
+    }
+    const int used = s_used;
+    if (used == 0) {
+        if (tid == 0) cam->success = 0;
+        return;
+    }
+    __threadfence_block();
+    if (tid < 3) s_mean[tid] = cam->rvec[tid] * mp.rvec_scale;
+    else if (tid < 6) s_mean[tid] = cam->t[tid - 3];
+    __syncthreads();
+    float conf; int ms_iters;
+    meanshift_block(pool, used, 6, mp, s_mean, s_cmean, br, &conf, &ms_iters);
+    float density = conf;
+    int gu_iters = cam->last_used_gu_iters;
+    bool rg_ok = false;
+    if (mp.do_rg) {  // geometry.cpp:201-246
+        const float sc = mp.rg_pose_scaling;
+        if (tid < 6) s_rgmean[tid] = s_mean[tid] * sc;
+        if (tid < 21) s_cov[tid] = 0.f;
+        __syncthreads();
+        if (tid < 6) s_cov[(tid * tid + tid) / 2 + tid] = mp.kernel_var * (sc * sc);
+        __syncthreads();
+        float dens; int it;
+        rg_ok = robust_gaussian_block(pool, used, 6, sc, mp, s_rgmean, s_cov, s_cinv, br, &dens, &it);
+        if (rg_ok) { density = dens; gu_iters = it; }
+        else gu_iters = 0;  // fit_robust_gaussian.cu:158-159 resets *used_iters on entry
+        if (tid == 0) {
+            if (rg_ok) {
+                for (int i1 = 0; i1 < 6; i1++)
+                    for (int i2 = 0; i2 < 6; i2++) {
+                        int hi = i1 >= i2 ? i1 : i2, lo = i1 >= i2 ? i2 : i1;
+                        float c = s_cov[(hi * hi + hi) / 2 + lo] / (sc * sc);
+                        if (i1 < 3 || i2 < 3) c /= mp.rvec_scale;
+                        if (i1 < 3 && i2 < 3) c /= mp.rvec_scale;
+                        cam->covar[i1 * 6 + i2] = c;
+                    }
+                for (int d = 0; d < 6; d++) s_mean[d] = s_rgmean[d] / sc;
+            } else {
+                for (int k = 0; k < 36; k++) cam->covar[k] = 0.f;
+                for (int d = 0; d < 6; d++) s_mean[d] = (s_mean[d] * sc) / sc;  // pose_opm *= sc; /= sc (:210,:238)
+            }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        float pose[6];
+        for (int d = 0; d < 3; d++) pose[d] = s_mean[d] / mp.rvec_scale;  // :249
+        for (int d = 3; d < 6; d++) pose[d] = s_mean[d];
+        bool ok = true;
+        for (int d = 0; d < 6; d++) ok = ok && isfinite(pose[d]);  // checkRange :256
+        cam->pose_sample_count = used;
+        cam->pose_density = density;
+        cam->last_used_ms_iters = ms_iters;
+        cam->last_used_gu_iters = gu_iters;
+        cam->success = ok ? 1 : 0;
+        if (ok) {
+            for (int d = 0; d < 3; d++) { cam->rvec[d] = pose[d]; cam->t[d] = pose[3 + d]; P->ts[cam_idx][d] = pose[3 + d]; }
+            float R[9];
+            angle_axis_to_rotmat(pose, R);
+            for (int k = 0; k < 9; k++) P->Rs[cam_idx][k] = R[k];
+        }
+    }
+}
+
+// ---- stand-alone kernels behind the host-pointer API (B-inner) -------------------------------
+// io (floats): [0..15] mean in/out, [16] confidence/density out ; ioi (ints): [0] iters, [1] status
+__global__ __launch_bounds__(MS_THREADS) static void k_meanshift_only(const float* __restrict__ space, int N, ModeParams mp,
+                                                                       float* __restrict__ io, int* __restrict__ ioi) {
+    __shared__ BlockRed br;
+    __shared__ float s_mean[16], s_cmean[16];
+    if (threadIdx.x < mp.dims) s_mean[threadIdx.x] = io[threadIdx.x];
+    __syncthreads();
+    float conf; int iters;
+    meanshift_block(space, N, mp.dims, mp, s_mean, s_cmean, br, &conf, &iters);
+    __syncthreads();
+    if (threadIdx.x < mp.dims) io[threadIdx.x] = s_mean[threadIdx.x];
+    if (threadIdx.x == 0) { io[16] = conf; ioi[0] = iters; ioi[1] = 0; }
+}
+// io: [0..5] mean in/out, [6..41] covar full in/out, [42] density out
+__global__ __launch_bounds__(MS_THREADS) static void k_robust_gaussian_only(const float* __restrict__ space, int N, ModeParams mp,
+                                                                             float* __restrict__ io, int* __restrict__ ioi) {
+    __shared__ BlockRed br;
+    __shared__ float s_mean[6], s_cov[21], s_cinv[21];
+    const int dims = mp.dims, tid = threadIdx.x;
+    if (tid < dims) s_mean[tid] = io[tid];
+    if (tid == 0)
+        for (int d1 = 0; d1 < dims; d1++)
+            for (int d2 = 0; d2 <= d1; d2++) s_cov[(d1 * d1 + d1) / 2 + d2] = io[6 + d1 * dims + d2];
+    __syncthreads();
+    float dens; int it;
+    bool ok = robust_gaussian_block(space, N, dims, 1.f, mp, s_mean, s_cov, s_cinv, br, &dens, &it);
+    if (tid == 0) {
+        ioi[1] = ok ? 0 : 1;
+        if (ok) {
+            ioi[0] = it;
+            io[42] = dens;
+            for (int d = 0; d < dims; d++) io[d] = s_mean[d];
+            for (int d1 = 0; d1 < dims; d1++)
+                for (int d2 = 0; d2 <= d1; d2++) {
+                    io[6 + d1 * dims + d2] = s_cov[(d1 * d1 + d1) / 2 + d2];
+                    io[6 + d2 * dims + d1] = s_cov[(d1 * d1 + d1) / 2 + d2];
+                }
+        }
+    }
+}
+
+// ---- host launchers ------------------------------------------------------------------------------
+int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
+                   float min_depth, float max_depth, int max_trace, CamState* cam_dev) {
+    const int npx = w * h, nblk = (npx + 255) / 256;
+    if (int e = c->p2_map.reserve(sizeof(float) * 2 * (size_t)npx)) return e;
+    if (int e = c->p3_map.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
+    if (int e = c->pts2.reserve(sizeof(float) * 2 * (size_t)npx)) return e;
+    if (int e = c->pts3.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
+    if (int e = c->blk_counts.reserve(sizeof(int) * (size_t)nblk)) return e;
+    if (int e = c->blk_offsets.reserve(sizeof(int) * (size_t)nblk)) return e;
+    if (int e = c->n_points.reserve(sizeof(int) * 4)) return e;
+    hipLaunchKernelGGL(k_collect, dim3(nblk), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
+                       S.pb(), c->p2_map.as<float>(), c->p3_map.as<float>(), c->blk_counts.as<int>(), N, w, h, active_idx,
+                       rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace);
+    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, c->stream, c->blk_counts.as<int>(), c->blk_offsets.as<int>(), nblk,
+                       c->n_points.as<int>(), cam_dev);
+    hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(256), 0, c->stream, c->p2_map.as<float>(), c->p3_map.as<float>(),
+                       c->blk_offsets.as<int>(), c->pts2.as<float>(), c->pts3.as<float>(), npx);
+    VK_CHECK_LAST();
+    return 0;
+}
+
+int solve_device(Context* c, const float* pts2, const float* pts3, const int* n_pts_dev, float fx, float fy, float cx, float cy,
+                 int n_poses, int solver) {
+    if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
+    if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
+    dim3 g((n_poses + 63) / 64), b(64);
+    if (solver == 0)
+        hipLaunchKernelGGL(k_solve<0>, g, b, 0, c->stream, pts2, pts3, c->rvecs.as<float>(), c->tvecs.as<float>(), n_pts_dev, fx, fy, cx, cy, n_poses);
+    else if (solver == 1)
+        hipLaunchKernelGGL(k_solve<1>, g, b, 0, c->stream, pts2, pts3, c->rvecs.as<float>(), c->tvecs.as<float>(), n_pts_dev, fx, fy, cx, cy, n_poses);
+    else
+        hipLaunchKernelGGL(k_solve<2>, g, b, 0, c->stream, pts2, pts3, c->rvecs.as<float>(), c->tvecs.as<float>(), n_pts_dev, fx, fy, cx, cy, n_poses);
+    VK_CHECK_LAST();
+    return 0;
+}
+
+int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx) {
+    if (int e = c->pool.reserve(sizeof(float) * MAX_POSE_DIMS * (size_t)n_poses)) return e;
+    hipLaunchKernelGGL(k_pose_mode, dim3(1), dim3(MS_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(),
+                       c->pool.as<float>(), n_poses, mp, cam_dev, P, cam_idx, c->n_points.as<int>());
+    VK_CHECK_LAST();
+    return 0;
+}
+
+int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev) {
+    hipLaunchKernelGGL(k_meanshift_only, dim3(1), dim3(MS_THREADS), 0, c->stream, space_dev, N, mp, io_dev, ioi_dev);
+    VK_CHECK_LAST();
+    return 0;
+}
+int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev) {
+    hipLaunchKernelGGL(k_robust_gaussian_only, dim3(1), dim3(MS_THREADS), 0, c->stream, space_dev, N, mp, io_dev, ioi_dev);
+    VK_CHECK_LAST();
+    return 0;
+}
+
+// normalize_world_scale on the device (voldor.cpp:309-317): scale = n_flows / sum ||t_i||
+__global__ static void k_world_scale(PoseBlock* P, CamState* cams, int n_flows, float* scale_out) {
+    if (threadIdx.x != 0) return;
+    float ws = 0.f;
+    for (int i = 0; i < n_flows; i++) {
+        const float* t = P->ts[i];
+        ws += (float)sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2]);
+    }
+    const float s = (float)n_flows / ws;
+    for (int i = 0; i < n_flows; i++)
+        for (int d = 0; d < 3; d++) { P->ts[i][d] *= s; cams[i].t[d] = P->ts[i][d]; }
+    *scale_out = s;
+}
+int world_scale_device(Context* c, PoseBlock* P, CamState* cams, int n_flows, float* scale_dev) {
+    hipLaunchKernelGGL(k_world_scale, dim3(1), dim3(64), 0, c->stream, P, cams, n_flows, scale_dev);
+    VK_CHECK_LAST();
+    return 0;
+}
+
+}  // namespace vk

@@ -1,0 +1,322 @@
+// voldor_amd/csrc/vk_voldor.hip -- the drop-in boundary "B-outer": py_voldor_wrapper
+// (voldor/py_export.h:3-11, py_export.cpp:5-79) = one visual-odometry window.
+//
+// Host orchestration of the EM schedule of voldor/voldor.cpp:4-317 (init / solve / bootstrap /
+// optimize_cameras / optimize_depth / normalize_world_scale) and the config grammar of
+// voldor/config.h:4-253, re-designed so that every image and every pose stays resident in HBM
+// for the whole window: the reference downloads depth + N rigidness maps after every
+// optimize_depth call, downloads 6 MB of correspondence maps per camera, compacts on the CPU
+// and re-uploads.  Here the host only reads one CamState record per camera.
+#include "vk_common.hpp"
+#include "vk_internal.hpp"
+#include "vk_p3p.hpp"
+#include "../../include/py_export.h"
+#include "../../include/voldor_hip.h"
+#include <string>
+#include <sstream>
+#include <iostream>
+#include <cmath>
+#include <cstddef>
+
+namespace vk {
+
+// ---- Config: voldor/config.h:4-82 (defaults), :110-253 (grammar) ------------------------------
+struct Config {
+    float omega = 0.15f, disp_delta = 1.f, delta = 0.5f, basefocal = 0;
+    int rg_refine = 1, rg_refine_last_only = 1; float rg_trunc_sigma = 3.f, rg_covar_reg_lambda = 0.001f, rg_pose_scaling = 100.f;
+    int rg_max_iters = 100; float rg_epsilon = 1e-5f;
+    float resize_factor = 1.0f, abs_resize_factor = 1.0f, fx = 0, fy = 0, cx = 0, cy = 0; int exclusive_gpu_context = 1;
+    bool debug = false, silent = false, save_everything = false; int viz_img_per_row = 2; float viz_depth_scale = 5;
+    float lambda = 0.15f, meanshift_kernel_var = 0.1f, meanshift_rvec_scale = 25.0f; int norm_world_scale = 1;
+    int cpu_p3p = 0, lambdatwist = 1, n_poses_to_sample = 8192; float pose_sample_min_depth = 0.1f, pose_sample_max_depth = 1000.0f;
+    int max_trace_on_flow = 3; float rigidness_threshold = 0.5f, rigidness_sum_threshold = 1.f;
+    float trunc_rigidness_density = 0.05f, trunc_sample_density = 0.001f, no_trunc_iters = 2; int max_iters = 5, min_iters_after_trunc = 3;
+    int fb_smooth = 1; float fb_emm = 0.5f, fb_no_change_prob = 0.9f;
+    int optimize_depth = 1, depth_rand_samples = 10, depth_global_prop_step = 8, depth_local_prop_width = 32; float depth_range_factor = 1.f;
+    int meanshift_max_iters = 100, meanshift_max_init_trials = 20; float meanshift_good_init_confidence = 0.5f, meanshift_epsilon = 1e-5f;
+    int kitti_estimate_ground = 0, kitti_ground_holo_width = 5; float kitti_ground_roi = 0.4f, kitti_ground_meanshift_kernel_var = 0.01f;
+
+    // Returns 0, or non-zero where the reference prints and calls exit(1) (config.h:101-108,245-248):
+    // a library must not exit its host process, so the error is reported to the caller instead.
+    int read_config(const std::string& s) {
+        struct Key { const char* name; int kind; void* p; };  // kind 0 float, 1 int
+#define KF(n) { "--" #n, 0, &this->n }
+#define KI(n) { "--" #n, 1, &this->n }
+        const Key keys[] = {
+            KF(basefocal), KF(omega), KF(disp_delta), KF(delta), KI(rg_refine), KI(rg_refine_last_only), KF(rg_trunc_sigma),
+            KF(rg_covar_reg_lambda), KF(rg_epsilon), KI(rg_max_iters), KF(rg_pose_scaling), KF(resize_factor), KF(abs_resize_factor),
+            KF(fx), KF(fy), KF(cx), KF(cy), KI(viz_img_per_row), KF(viz_depth_scale), KI(exclusive_gpu_context), KF(lambda),
+            KF(meanshift_kernel_var), KF(meanshift_rvec_scale), KI(norm_world_scale), KI(cpu_p3p), KI(lambdatwist), KI(max_trace_on_flow),
+            KI(n_poses_to_sample), KF(pose_sample_min_depth), KF(pose_sample_max_depth), KF(rigidness_threshold),
+            KF(rigidness_sum_threshold), KF(trunc_rigidness_density), KF(trunc_sample_density), KI(max_iters), KF(no_trunc_iters),
+            KI(min_iters_after_trunc), KI(fb_smooth), KF(fb_emm), KF(fb_no_change_prob), KI(optimize_depth), KI(depth_rand_samples),
+            KI(depth_global_prop_step), KI(depth_local_prop_width), KF(depth_range_factor), KI(meanshift_max_iters),
+            KI(meanshift_max_init_trials), KF(meanshift_good_init_confidence), KF(meanshift_epsilon), KI(kitti_estimate_ground),
+            KI(kitti_ground_holo_width), KF(kitti_ground_roi), KF(kitti_ground_meanshift_kernel_var),
+        };
+#undef KF
+#undef KI
+        std::istringstream iss(s);
+        std::string tok;
+        while (iss >> tok) {
+            if (tok == "--debug") { debug = true; continue; }
+            if (tok == "--silent") { silent = true; continue; }
+            if (tok == "--save_everything") { save_everything = true; continue; }
+            const Key* k = nullptr;
+            for (const Key& c : keys) if (tok == c.name) { k = &c; break; }
+            if (!k) { std::cout << "Invalid input config : " << tok << std::endl; return 1; }
+            std::string val;
+            if (!(iss >> val)) { std::cout << "Config array index out of bound." << std::endl; return 2; }
+            // str_to_arg falls through i->l->f->d (config.h:85-99): the stored value is stod(str)
+            // converted to the field type.
+            double v;
+            try { v = std::stod(val); } catch (...) { std::cout << "Invalid value for " << tok << " : " << val << std::endl; return 3; }
+            if (k->kind == 1) *static_cast<int*>(k->p) = (int)v;
+            else *static_cast<float*>(k->p) = (float)v;
+        }
+        return 0;
+    }
+};
+
+enum OdFlag { OD_DEFAULT = 0, OD_ONLY_USE_DEPTH_PRIOR = 1, OD_UPDATE_RIGIDNESS_ONLY = 2 };  // voldor.h:7-11
+
+struct Voldor {
+    Context* c = nullptr;
+    Config cfg;
+    int n_flows = 0, n_flows_init = 0, n_dp = 0, w = 0, h = 0, iters_cur = 0, iters_remain = 0;
+    bool has_disparity = false;
+    CamState hcams[MAX_FRAMES];
+
+    CamState* dcams() { return c->cams.as<CamState>(); }
+
+    // voldor.cpp:4-128
+    int init(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
+             const float* depth_prior_poses, const float* depth_prior_pconfs, int N, int N_dp_in, int w_, int h_) {
+        w = w_; h = h_;
+        n_flows = n_flows_init = N;
+        iters_cur = 0; iters_remain = cfg.max_iters;
+        n_dp = N_dp_in + (disparity ? 1 : 0);
+        has_disparity = disparity != nullptr;
+        if (N < 1 || N > MAX_FRAMES || n_dp > MAX_DISP_FRAMES || w <= 0 || h <= 0) return (int)hipErrorInvalidValue;
+        if (cfg.resize_factor != 1.f) {
+            std::cout << "resize_factor != 1 is deprecated in the reference (config.h:23) and not supported" << std::endl;
+            return (int)hipErrorInvalidValue;
+        }
+        ImageSet& S = c->od;
+        hipStream_t st = c->stream;
+        const size_t npx = (size_t)w * h;
+        S.w = w; S.h = h;
+        if (int e = S.ensure_pose()) return e;
+        if (int e = S.flows.reserve(sizeof(float) * 2 * npx * N)) return e;
+        if (int e = S.rig.reserve(sizeof(float) * npx * N)) return e;
+        if (int e = S.depth.reserve(sizeof(float) * npx)) return e;
+        if (int e = S.cost.reserve(sizeof(float) * npx)) return e;
+        if (int e = c->cams.reserve(sizeof(CamState) * MAX_FRAMES)) return e;
+        VK_CHECK(hipMemcpyAsync(S.flows.p, flows, sizeof(float) * 2 * npx * N, hipMemcpyDefault, st));
+        if (int e = fill_device(c, S.rig.as<float>(), 1.f, npx * N)) return e;
+        PoseBlock pb;
+        memset(&pb, 0, sizeof pb);
+        pb.K4[0] = cfg.fx; pb.K4[1] = cfg.cx; pb.K4[2] = cfg.fy; pb.K4[3] = cfg.cy;
+        pb.K4i[0] = 1.f / cfg.fx; pb.K4i[1] = -cfg.cx / cfg.fx; pb.K4i[2] = 1.f / cfg.fy; pb.K4i[3] = -cfg.cy / cfg.fy;
+        for (int i = 0; i < MAX_FRAMES; i++) { pb.Rs[i][0] = pb.Rs[i][4] = pb.Rs[i][8] = 1.f; pb.dpRs[i][0] = pb.dpRs[i][4] = pb.dpRs[i][8] = 1.f; }
+        if (n_dp > 0) {
+            if (int e = S.priors.reserve(sizeof(float) * npx * n_dp)) return e;
+            if (int e = S.pconfs.reserve(sizeof(float) * npx * n_dp)) return e;
+            if (int e = S.confs.reserve(sizeof(float) * npx * n_dp)) return e;
+            int o = 0;
+            if (disparity) {  // :31-49
+                if (int e = c->tmp.reserve(sizeof(float) * npx)) return e;
+                VK_CHECK(hipMemcpyAsync(c->tmp.p, disparity, sizeof(float) * npx, hipMemcpyDefault, st));
+                if (int e = disp_to_depth_device(c, c->tmp.as<float>(), S.priors.as<float>(), cfg.basefocal, npx)) return e;
+                if (disparity_pconf) VK_CHECK(hipMemcpyAsync(S.pconfs.p, disparity_pconf, sizeof(float) * npx, hipMemcpyDefault, st));
+                else if (int e = fill_device(c, S.pconfs.as<float>(), 1.f, npx)) return e;
+                o = 1;
+            }
+            for (int i = 0; i < N_dp_in; i++) {  // :51-67
+                VK_CHECK(hipMemcpyAsync(S.priors.as<float>() + (size_t)(o + i) * npx, depth_priors + (size_t)i * npx, sizeof(float) * npx, hipMemcpyDefault, st));
+                if (depth_prior_pconfs)
+                    VK_CHECK(hipMemcpyAsync(S.pconfs.as<float>() + (size_t)(o + i) * npx, depth_prior_pconfs + (size_t)i * npx, sizeof(float) * npx, hipMemcpyDefault, st));
+                else if (int e = fill_device(c, S.pconfs.as<float>() + (size_t)(o + i) * npx, 1.f, npx)) return e;
+                angle_axis_to_rotmat(depth_prior_poses + i * 6, pb.dpRs[o + i]);
+                for (int d = 0; d < 3; d++) pb.dpts[o + i][d] = depth_prior_poses[i * 6 + 3 + d];
+            }
+            if (int e = fill_device(c, S.confs.as<float>(), 1.f, npx * n_dp)) return e;
+        }
+        VK_CHECK(hipMemcpyAsync(S.pose.p, &pb, sizeof pb, hipMemcpyHostToDevice, st));
+        memset(hcams, 0, sizeof hcams);
+        for (int i = 0; i < MAX_FRAMES; i++) hcams[i].pose_rigidness_density = 1.f;  // rigidness maps start at 1 (:96-98)
+        VK_CHECK(hipMemcpyAsync(c->cams.p, hcams, sizeof hcams, hipMemcpyHostToDevice, st));
+        VK_CHECK(hipStreamSynchronize(st));  // pb / hcams live on the host stack of this object
+        if (n_dp > 0) {  // :106-117
+            VK_CHECK(hipMemcpyAsync(S.depth.p, S.priors.p, sizeof(float) * npx, hipMemcpyDeviceToDevice, st));
+            if (!disparity) { if (int e = optimize_depth(OD_ONLY_USE_DEPTH_PRIOR)) return e; }
+        } else if (int e = fill_device(c, S.depth.as<float>(), 1.f, npx)) return e;
+        return 0;
+    }
+
+    // voldor.cpp:203-307 (the upload / "minimal cache" branches collapse: everything is resident)
+    int optimize_depth(OdFlag flag) {
+        if (n_flows == 0 && n_dp == 0) return 0;
+        OdParams p;
+        p.abs_resize_factor = cfg.abs_resize_factor;
+        p.N = (flag == OD_ONLY_USE_DEPTH_PRIOR) ? 0 : n_flows; p.N_dp = n_dp; p.w = w; p.h = h; p.basefocal = cfg.basefocal;
+        p.n_rand_samples = cfg.depth_rand_samples; p.global_prop_step = cfg.depth_global_prop_step; p.local_prop_width = cfg.depth_local_prop_width;
+        p.lambda = cfg.lambda; p.omega = cfg.omega; p.disp_delta = has_disparity ? cfg.disp_delta : -1.f; p.delta = cfg.delta;
+        p.fb_smooth = cfg.fb_smooth != 0; p.s0_ems_prob = cfg.fb_emm; p.no_change_prob = cfg.fb_no_change_prob;
+        p.range_factor = cfg.depth_range_factor; p.update_rigidness_only = (flag == OD_UPDATE_RIGIDNESS_ONLY);
+        return optimize_depth_device(c, c->od, p);
+    }
+
+    // voldor/geometry.cpp:5-265, all on the device; success / density come back in CamState
+    int optimize_camera_pose(int i, bool rg_refine) {
+        ImageSet& S = c->od;
+        if (c->prof) prof_begin(c);
+        if (int e = collect_device(c, S, n_flows, w, h, i, cfg.rigidness_threshold, cfg.rigidness_sum_threshold,
+                                   cfg.pose_sample_min_depth, cfg.pose_sample_max_depth, cfg.max_trace_on_flow, dcams() + i))
+            return e;
+        // cpu_p3p=1 selects the reference's CPU instantiation lambdatwist_p4p<double,...> (geometry.cpp:112)
+        const int solver = cfg.lambdatwist ? (cfg.cpu_p3p ? 2 : 0) : 1;
+        if (int e = solve_device(c, c->pts2.as<float>(), c->pts3.as<float>(), c->n_points.as<int>(), cfg.fx, cfg.fy, cfg.cx, cfg.cy,
+                                 cfg.n_poses_to_sample, solver))
+            return e;
+        ModeParams mp{};
+        mp.dims = 6; mp.kernel_var = cfg.meanshift_kernel_var; mp.ms_epsilon = cfg.meanshift_epsilon;
+        mp.ms_max_iters = cfg.meanshift_max_iters; mp.ms_max_init_trials = cfg.meanshift_max_init_trials;
+        mp.ms_good_init_confidence = cfg.meanshift_good_init_confidence; mp.use_external_init_mean = -1;
+        mp.rvec_scale = cfg.meanshift_rvec_scale; mp.rg_pose_scaling = cfg.rg_pose_scaling; mp.do_rg = rg_refine ? 1 : 0;
+        mp.rg_trunc_sigma = cfg.rg_trunc_sigma; mp.rg_covar_reg_lambda = cfg.rg_covar_reg_lambda; mp.rg_epsilon = cfg.rg_epsilon;
+        mp.rg_max_iters = cfg.rg_max_iters;
+        if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e;
+        if (c->prof) prof_end(c, "optimize_camera_pose");
+        return 0;
+    }
+
+    // voldor.cpp:164-201
+    int optimize_cameras() {
+        const bool allow_trunc = iters_cur > cfg.no_trunc_iters;
+        // rigidness densities were reduced on the device by the last optimize_depth (voldor.cpp:171)
+        VK_CHECK(hipMemcpyAsync(hcams, c->cams.p, sizeof(CamState) * n_flows, hipMemcpyDeviceToHost, c->stream));
+        VK_CHECK(hipStreamSynchronize(c->stream));
+        for (int i = 0; i < n_flows; i++) {
+            int ok = 0;
+            if (!allow_trunc || hcams[i].pose_rigidness_density > cfg.trunc_rigidness_density) {
+                if (int e = optimize_camera_pose(i, cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0))) return e;
+                VK_CHECK(hipMemcpyAsync(&hcams[i], dcams() + i, sizeof(CamState), hipMemcpyDeviceToHost, c->stream));
+                VK_CHECK(hipStreamSynchronize(c->stream));
+                ok = hcams[i].success;
+            }
+            if (!cfg.silent) print_cam(i);
+            if (!ok || (allow_trunc && hcams[i].pose_density < cfg.trunc_sample_density)) {
+                if (!cfg.silent) std::cout << "truncated at camera " << i << std::endl;
+                iters_remain = std::max(iters_remain, cfg.min_iters_after_trunc);
+                n_flows = i;
+                break;
+            }
+        }
+        return 0;
+    }
+    void print_cam(int i) {  // Camera::print_info (utils.h:66-76), without the OpenCV-derived lines
+        const CamState& s = hcams[i];
+        std::cout << "pose pool size = " << s.pose_sample_count << std::endl
+                  << "rigidness density = " << s.pose_rigidness_density << std::endl
+                  << "pose density = " << s.pose_density << std::endl
+                  << "last used meanshift iters = " << s.last_used_ms_iters << std::endl
+                  << "last used gu iters = " << s.last_used_gu_iters << std::endl << std::endl;
+    }
+
+    // voldor.cpp:309-317, on the device: no host round trip of depth or translations
+    int normalize_world_scale() {
+        if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
+        float* s_dev = c->ms_io.as<float>() + 48;
+        if (int e = world_scale_device(c, c->od.pb(), dcams(), n_flows, s_dev)) return e;
+        return scale_device(c, c->od.depth.as<float>(), s_dev, (size_t)w * h);
+    }
+
+    // voldor.cpp:130-149
+    int solve() {
+        if (n_dp == 0) {  // bootstrap :151-162
+            if (c->prof) prof_begin(c);
+            if (int e = bootstrap_device(c, c->od, w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, dcams())) return e;
+            if (c->prof) prof_end(c, "bootstrap");
+        }
+        while (iters_remain > 0 && n_flows > 0) {
+            iters_cur++; iters_remain--;
+            if (int e = optimize_cameras()) return e;
+            if (int e = optimize_depth(cfg.optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY)) return e;
+            if (cfg.norm_world_scale && n_dp == 0 && n_flows > 0) { if (int e = normalize_world_scale()) return e; }
+        }
+        return 0;
+    }
+};
+
+static thread_local Voldor g_last;  // stats of the last window (vk_last_camera_stats)
+
+static int voldor_run(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
+                      const float* depth_prior_poses, const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+                      float basefocal, int N, int N_dp, int w, int h, const char* config, int* n_registered, float* poses,
+                      float* poses_covar, float* depth, float* depth_conf) {
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    Voldor& v = g_last;
+    v = Voldor();
+    v.c = c;
+    v.cfg.fx = fx; v.cfg.cx = cx; v.cfg.fy = fy; v.cfg.cy = cy; v.cfg.basefocal = basefocal;  // py_export.cpp:19-25
+    if (int e = v.cfg.read_config(config ? config : "")) return 1000 + e;
+    if (int e = v.init(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, N, N_dp, w, h)) return e;
+    if (int e = v.solve()) return e;
+    // outputs: py_export.cpp:56-76
+    const size_t npx = (size_t)w * h;
+    VK_CHECK(hipMemcpyAsync(v.hcams, c->cams.p, sizeof(CamState) * MAX_FRAMES, hipMemcpyDeviceToHost, c->stream));
+    if (depth) VK_CHECK(hipMemcpyAsync(depth, c->od.depth.p, sizeof(float) * npx, hipMemcpyDefault, c->stream));
+    if (depth_conf) {
+        if (int e = c->tmp.reserve(sizeof(float) * npx)) return e;
+        if (int e = depth_conf_device(c, c->od.rig.as<float>(), c->od.confs.as<float>(), c->tmp.as<float>(), v.n_flows, v.n_dp, npx)) return e;
+        VK_CHECK(hipMemcpyAsync(depth_conf, c->tmp.p, sizeof(float) * npx, hipMemcpyDefault, c->stream));
+    }
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    *n_registered = v.n_flows;
+    for (int i = 0; i < v.n_flows; i++) {
+        if (poses) { memcpy(poses + i * 6, v.hcams[i].rvec, 12); memcpy(poses + i * 6 + 3, v.hcams[i].t, 12); }
+        if (poses_covar) memcpy(poses_covar + i * 36, v.hcams[i].covar, sizeof(float) * 36);
+    }
+    return 0;
+}
+
+}  // namespace vk
+
+// voldor/py_export.h:3-11
+int py_voldor_wrapper(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
+                      const float* depth_prior_poses, const float* depth_prior_pconfs, const float fx, const float fy,
+                      const float cx, const float cy, const float basefocal, const int N, const int N_dp, const int w, const int h,
+                      const char* config, int& n_registered, float* poses, float* poses_covar, float* depth, float* depth_conf) {
+    return vk::voldor_run(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, fx, fy, cx, cy,
+                          basefocal, N, N_dp, w, h, config, &n_registered, poses, poses_covar, depth, depth_conf);
+}
+
+extern "C" {
+int vk_py_voldor_wrapper(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
+                         const float* depth_prior_poses, const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+                         float basefocal, int N, int N_dp, int w, int h, const char* config, int* n_registered, float* poses,
+                         float* poses_covar, float* depth, float* depth_conf) {
+    return vk::voldor_run(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, fx, fy, cx, cy,
+                          basefocal, N, N_dp, w, h, config, n_registered, poses, poses_covar, depth, depth_conf);
+}
+int vk_voldor_device(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
+                     const float* depth_prior_poses, const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+                     float basefocal, int N, int N_dp, int w, int h, const char* config, int* n_registered, float* poses,
+                     float* poses_covar, float* depth, float* depth_conf) {
+    return vk::voldor_run(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, fx, fy, cx, cy,
+                          basefocal, N, N_dp, w, h, config, n_registered, poses, poses_covar, depth, depth_conf);
+}
+int vk_last_camera_stats(int* pose_sample_count, float* pose_density, float* pose_rigidness_density, int* ms_iters, int* gu_iters, int n) {
+    for (int i = 0; i < n && i < vk::MAX_FRAMES; i++) {
+        const vk::CamState& s = vk::g_last.hcams[i];
+        if (pose_sample_count) pose_sample_count[i] = s.pose_sample_count;
+        if (pose_density) pose_density[i] = s.pose_density;
+        if (pose_rigidness_density) pose_rigidness_density[i] = s.pose_rigidness_density;
+        if (ms_iters) ms_iters[i] = s.last_used_ms_iters;
+        if (gu_iters) gu_iters[i] = s.last_used_gu_iters;
+    }
+    return 0;
+}
+}
