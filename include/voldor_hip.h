@@ -81,6 +81,16 @@ int vk_device_count(void);
 int vk_set_device(int dev);
 const char* vk_version(void);
 
+/* ---- D. host builds of the per-lane solver math (same source as the device code), for CPU-only
+ * verification against the oracle; not part of the product path ---- */
+int vk_host_lambdatwist_p4p(const float* y8, const float* x12, float fx, float fy, float cx, float cy,
+                            int use_double, float* R9, float* t3);
+int vk_host_ap3p_p4p(const float* y8, const float* x12, float fx, float fy, float cx, float cy, float* R9, float* t3);
+void vk_host_rodrigues(const float* R9, float* rvec3);
+void vk_host_rvec_to_rotmat(const float* rvec3, float* R9);
+unsigned vk_host_rng(unsigned seed, unsigned stream, unsigned counter);
+float vk_host_u01(unsigned r);
+
 #pragma GCC visibility pop
 #ifdef __cplusplus
 }

@@ -19,6 +19,9 @@
  *     no bleeding between stacked layers) -- gmat.h:175-179.
  *  D3 random sample index clamped to N_pts-1 (reference can read one past the end,
  *     solve_batch_lambdatwist.cu:16-19).
+ *  D3b inside the window pipeline the 4 correspondences of a hypothesis are drawn uniformly from the
+ *     valid set by rejection over the map instead of by index into the compacted list (same
+ *     distribution; a 1-pixel change of the set no longer re-draws all 8192 hypotheses).
  *  D4 one depth buffer shared by the depth and the pose half (the reference keeps a
  *     stale un-normalised copy in optimize_depth.cu).
  *
@@ -83,6 +86,9 @@ void orc_collect_p3p(const float* flows, const float* rig, const float* depth, c
 int orc_compact_p3p(const float* p2_map, const float* p3_map, int npx, float* pts2, float* pts3);
 /* 4 random indices of pose sample `idx` (deviation D1,D3) */
 void orc_pose_sample_indices(int idx, int n_pts, int out4[4]);
+int orc_pose_sample_pixels(int idx, int npx, const float* p2_map, int out4[4]);
+void orc_solve_batch_p3p_maps(const float* p2_map, const float* p3_map, int npx, int n_valid, float* rvecs,
+                              float* tvecs, const float* K, int n_poses, int use_ap3p, int use_double);
 /* lambdatwist/lambdatwist_p4p.h:5-62; use_double selects _T (0: GPU path float, 1: CPU path) */
 int orc_lambdatwist_p4p(const float* y8, const float* x12, float fx, float fy, float cx, float cy,
                         int use_double, float* R9, float* t3);

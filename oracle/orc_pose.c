@@ -92,7 +92,10 @@ void orc_collect_p3p(const float* flows, const float* rig, const float* depth, c
                     o[0] = a + t[0]; o[1] = b + t[1]; o[2] = c + t[2];
                 }
             }
-            if (!out && o[2] > sample_min_depth && (sample_max_depth <= 0 || o[2] < sample_max_depth)) {
+            /* geometry.cpp:73 drops entries whose sum is not finite; do it here so that map validity and
+             * compacted-list membership are the same set */
+            if (!out && o[2] > sample_min_depth && (sample_max_depth <= 0 || o[2] < sample_max_depth) &&
+                isfinite(px + py + o[0] + o[1] + o[2])) {
                 p2_map[pi * 2] = px; p2_map[pi * 2 + 1] = py;
                 p3_map[pi * 3] = o[0]; p3_map[pi * 3 + 1] = o[1]; p3_map[pi * 3 + 2] = o[2];
             }
@@ -123,6 +126,25 @@ void orc_pose_sample_indices(int idx, int n_pts, int out4[4]) {
         if (i > n_pts - 1) i = n_pts - 1;
         out4[k] = i;
     }
+}
+
+/* Window-pipeline variant of the draw (deviation D3b, DESIGN.md "sampling stability"): the same
+ * uniform distribution over the valid correspondences, drawn by rejection over the NaN-marked map
+ * instead of indexing the compacted list, so that a one-pixel change of the valid set only
+ * perturbs the hypotheses that hit that pixel.  <=256 tries per point, else the hypothesis fails. */
+#define ORC_DRAW_MAX_TRIES 256
+int orc_pose_sample_pixels(int idx, int npx, const float* p2_map, int out4[4]) {
+    for (int k = 0; k < 4; k++) {
+        int found = -1;
+        for (int j = 0; j < ORC_DRAW_MAX_TRIES; j++) {
+            uint32_t r = orc_rng(233u, (uint32_t)idx, (uint32_t)(k * ORC_DRAW_MAX_TRIES + j));
+            int cand = (int)(((uint64_t)r * (uint64_t)npx) >> 32);
+            if (isfinite(p2_map[(size_t)cand * 2])) { found = cand; break; }
+        }
+        if (found < 0) return 0;
+        out4[k] = found;
+    }
+    return 1;
 }
 
 /* ------------------------------------------------------------------ rotation helpers
@@ -391,6 +413,32 @@ void orc_solve_batch_p3p(const float* pts3, const float* pts2, float* rvecs, flo
         }
         int ok = use_ap3p ? orc_ap3p_p4p(y, x, fx, fy, cx, cy, R, t)
                           : orc_lambdatwist_p4p(y, x, fx, fy, cx, cy, use_double, R, t);
+        if (!ok) {
+            for (int k = 0; k < 3; k++) { rvecs[idx * 3 + k] = qnan; tvecs[idx * 3 + k] = qnan; }
+            continue;
+        }
+        for (int k = 0; k < 3; k++) tvecs[idx * 3 + k] = t[k];
+        orc_rodrigues(R, rvecs + idx * 3);
+    }
+}
+
+/* same as orc_solve_batch_p3p but drawing from the maps (n_valid = number of finite map entries) */
+void orc_solve_batch_p3p_maps(const float* p2_map, const float* p3_map, int npx, int n_valid, float* rvecs, float* tvecs,
+                              const float* K, int n_poses, int use_ap3p, int use_double) {
+    const float fx = K[0], cx = K[2], fy = K[4], cy = K[5];
+    const float qnan = __builtin_nanf("");
+#pragma omp parallel for schedule(static)
+    for (int idx = 0; idx < n_poses; idx++) {
+        int id[4];
+        float y[8], x[12], R[9], t[3];
+        int ok = n_valid >= 4 && orc_pose_sample_pixels(idx, npx, p2_map, id);
+        if (ok) {
+            for (int k = 0; k < 4; k++) {
+                y[k * 2] = p2_map[(size_t)id[k] * 2]; y[k * 2 + 1] = p2_map[(size_t)id[k] * 2 + 1];
+                x[k * 3] = p3_map[(size_t)id[k] * 3]; x[k * 3 + 1] = p3_map[(size_t)id[k] * 3 + 1]; x[k * 3 + 2] = p3_map[(size_t)id[k] * 3 + 2];
+            }
+            ok = use_ap3p ? orc_ap3p_p4p(y, x, fx, fy, cx, cy, R, t) : orc_lambdatwist_p4p(y, x, fx, fy, cx, cy, use_double, R, t);
+        }
         if (!ok) {
             for (int k = 0; k < 3; k++) { rvecs[idx * 3 + k] = qnan; tvecs[idx * 3 + k] = qnan; }
             continue;

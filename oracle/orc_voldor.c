@@ -139,20 +139,20 @@ static int v_optimize_camera_pose(orc_voldor_t* v, int active_idx, int successiv
     float (*ts)[3] = malloc(sizeof(float) * 3 * ORC_MAX_FRAMES);
     for (int i = 0; i < v->n_flows; i++) { memcpy(Rs[i], v->cams[i].R, 36); memcpy(ts[i], v->cams[i].t, 12); }
     float* p2m = malloc(sizeof(float) * npx * 2); float* p3m = malloc(sizeof(float) * npx * 3);
-    float* pts2 = malloc(sizeof(float) * npx * 2); float* pts3 = malloc(sizeof(float) * npx * 3);
     orc_collect_p3p(v->flows, v->rig, v->depth, K, (const float (*)[9])Rs, (const float (*)[3])ts, p2m, p3m,
                     v->n_flows, w, h, active_idx, c->rigidness_threshold, c->rigidness_sum_threshold,
                     c->pose_sample_min_depth, c->pose_sample_max_depth, c->max_trace_on_flow);
-    int n_points = orc_compact_p3p(p2m, p3m, npx, pts2, pts3);
-    free(Rs); free(ts); free(p2m); free(p3m);
-    if (n_points < 4) { free(pts2); free(pts3); return 0; } /* :84 */
+    int n_points = 0; /* geometry.cpp:68-80: number of finite correspondences */
+    for (int i = 0; i < npx; i++) if (isfinite(p2m[i * 2])) n_points++;
+    free(Rs); free(ts);
+    if (n_points < 4) { free(p2m); free(p3m); return 0; } /* :84 */
 
     const int np = c->n_poses_to_sample;
     float* rv = malloc(sizeof(float) * np * 3); float* tv = malloc(sizeof(float) * np * 3);
     float* pool = malloc(sizeof(float) * np * 6);
-    /* :99-170. cpu_p3p=1 is the reference's CPU path: lambdatwist_p4p<double,...> (:112); the
-     * oracle keeps the same sample indices for both (host rand() is not restated). */
-    orc_solve_batch_p3p(pts3, pts2, rv, tv, K, n_points, np, !c->lambdatwist, c->cpu_p3p ? 1 : 0);
+    /* :99-170. cpu_p3p=1 is the reference's CPU path: lambdatwist_p4p<double,...> (:112). Draws: D3b. */
+    orc_solve_batch_p3p_maps(p2m, p3m, npx, n_points, rv, tv, K, np, !c->lambdatwist, c->cpu_p3p ? 1 : 0);
+    free(p2m); free(p3m);
     int used = 0;
     for (int i = 0; i < np; i++) {
         float s = rv[i * 3] + rv[i * 3 + 1] + rv[i * 3 + 2] + tv[i * 3] + tv[i * 3 + 1] + tv[i * 3 + 2];
@@ -161,7 +161,7 @@ static int v_optimize_camera_pose(orc_voldor_t* v, int active_idx, int successiv
             used++;
         }
     }
-    free(rv); free(tv); free(pts2); free(pts3);
+    free(rv); free(tv);
     if (used == 0) { free(pool); return 0; }
     cam->pose_sample_count = used;
 
@@ -492,7 +492,8 @@ int orc_voldor(const float* flows, const float* disparity, const float* disparit
         v->iters_cur++; v->iters_remain--;
         v_optimize_cameras(v);
         v_optimize_depth(v, c->optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY);
-        if (c->norm_world_scale && v->n_dp == 0) v_normalize_world_scale(v);
+        /* the reference also runs this with n_flows==0 (0/0 -> NaN depth on a lost window): guarded, D6 */
+        if (c->norm_world_scale && v->n_dp == 0 && v->n_flows > 0) v_normalize_world_scale(v);
     }
     /* ---- outputs: py_export.cpp:56-76 ---- */
     *n_registered = v->n_flows;

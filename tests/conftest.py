@@ -4,6 +4,15 @@ import sys
 import numpy as np
 import pytest
 
+# torch bundles its own libamdhip64.so.7; if it is loaded AFTER the system one that
+# libvoldor_hip.so links against, torch sees "No HIP GPUs". Importing torch first makes both
+# share one HIP runtime (same soname). Only needed for tests that mix torch and the library.
+if os.environ.get("VOLDOR_TESTS_NO_TORCH") != "1" and os.path.exists("/dev/kfd"):
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

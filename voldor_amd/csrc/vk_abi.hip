@@ -165,7 +165,7 @@ int collect_p3p_instances(float* h_flows[], float* h_rigidnesses[], float* h_dep
     if (int e = S.depth.reserve(sizeof(float) * npx)) return e;
     if (h_depth) VK_CHECK(hipMemcpyAsync(S.depth.p, h_depth, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
     if (int e = collect_device(c, S, N, w, h, active_idx, rigidness_thresh, rigidness_sum_thresh, sample_min_depth,
-                               sample_max_depth, max_trace_on_flow, nullptr))
+                               sample_max_depth, max_trace_on_flow, nullptr, true))
         return e;
     if (h_o_p2_map) VK_CHECK(hipMemcpyAsync(h_o_p2_map, c->p2_map.p, sizeof(float) * 2 * npx, hipMemcpyDeviceToHost, c->stream));
     if (h_o_p3_map) VK_CHECK(hipMemcpyAsync(h_o_p3_map, c->p3_map.p, sizeof(float) * 3 * npx, hipMemcpyDeviceToHost, c->stream));
@@ -349,6 +349,7 @@ int vk_set_rand_epoch(unsigned epoch) {
     Context* c = default_context();
     if (!c) return (int)hipErrorNoDevice;
     c->rand_epoch = epoch;
+    c->rand_w = c->rand_h = -1;  // explicit seed: the next call adopts its size without resetting
     return 0;
 }
 unsigned vk_get_rand_epoch(void) {

@@ -31,6 +31,7 @@ __global__ static void k_extract_corr(const float2* __restrict__ flow, float* __
 // geometry.cpp:267-285; M = K R K^-1 (row-major), b = K t
 __global__ __launch_bounds__(256) static void k_depth_closed_form(const float2* __restrict__ flow, float* __restrict__ depth, int w, int h,
                                                                    const float* __restrict__ Mb, float min_depth, float max_depth) {
+#pragma clang fp contract(off)  // same fp32 op sequence as the un-fused host loop of geometry.cpp:272-284
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
     const float b1 = Mb[9], b2 = Mb[10], b3 = Mb[11];

@@ -317,7 +317,8 @@ int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p) {
     const int w = p.w, h = p.h;
     if (int e = S.cost.reserve(sizeof(float) * (size_t)w * h)) return e;
     if (c->rand_w != w || c->rand_h != h) {  // reference re-inits the RNG when the size changes (:358-361)
-        c->rand_w = w; c->rand_h = h; c->rand_epoch = 0;
+        if (c->rand_w != -1) c->rand_epoch = 0;  // (-1: epoch was set explicitly through vk_set_rand_epoch)
+        c->rand_w = w; c->rand_h = h;
     }
     Img I = make_img(S, p);
     const dim3 gpx((w + 63) / 64, (h + 3) / 4), bpx(256);

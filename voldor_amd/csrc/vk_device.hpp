@@ -79,15 +79,21 @@ __device__ __forceinline__ float depth_ratio(float d1, float d2, float basefocal
 
 // ---- geometry (optimize_depth.cu:54-81) -------------------------------------------------
 struct P3 { float x, y, z; };
+// Geometry and bilinear weights are evaluated with the reference's operation order, true
+// division and NO fma contraction, so pixel positions, in-bounds decisions and gather weights are
+// bit-identical to an un-fused fp32 evaluation (the oracle); only the transcendental part of the
+// residual model differs between the two.
 __device__ __forceinline__ P3 backproject(const PoseBlock* P, float px, float py, float d) {
+#pragma clang fp contract(off)
     return { (P->K4i[0] * px + P->K4i[1]) * d, (P->K4i[2] * py + P->K4i[3]) * d, d };
 }
 __device__ __forceinline__ void project(const PoseBlock* P, P3 o, float& px, float& py) {
-    float iz = 1.f / o.z;
-    px = (P->K4[0] * o.x + P->K4[1] * o.z) * iz;
-    py = (P->K4[2] * o.y + P->K4[3] * o.z) * iz;
+#pragma clang fp contract(off)
+    px = (P->K4[0] * o.x + P->K4[1] * o.z) / o.z;
+    py = (P->K4[2] * o.y + P->K4[3] * o.z) / o.z;
 }
 __device__ __forceinline__ P3 transform(const float* R, const float* t, P3 o) {
+#pragma clang fp contract(off)
     return { o.x * R[0] + o.y * R[1] + o.z * R[2] + t[0],
              o.x * R[3] + o.y * R[4] + o.z * R[5] + t[1],
              o.x * R[6] + o.y * R[7] + o.z * R[8] + t[2] };
@@ -96,6 +102,7 @@ __device__ __forceinline__ P3 transform(const float* R, const float* t, P3 o) {
 // ---- bilinear fetch, clamp-to-edge per layer, exact fp32 weights ------------------------
 struct BilIdx { int i00, i10, i01, i11; float a, b; };
 __device__ __forceinline__ BilIdx bil_index(float x, float y, int w, int h) {
+#pragma clang fp contract(off)
     float fx = floorf(x), fy = floorf(y);
     BilIdx r;
     r.a = x - fx; r.b = y - fy;
@@ -106,6 +113,7 @@ __device__ __forceinline__ BilIdx bil_index(float x, float y, int w, int h) {
     return r;
 }
 __device__ __forceinline__ float2 bilinear2(const float2* __restrict__ img, int w, int h, float x, float y) {
+#pragma clang fp contract(off)
     BilIdx k = bil_index(x, y, w, h);
     float2 t00 = img[k.i00], t10 = img[k.i10], t01 = img[k.i01], t11 = img[k.i11];
     float w00 = (1.f - k.a) * (1.f - k.b), w10 = k.a * (1.f - k.b), w01 = (1.f - k.a) * k.b, w11 = k.a * k.b;
@@ -113,6 +121,7 @@ __device__ __forceinline__ float2 bilinear2(const float2* __restrict__ img, int 
                        w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y);
 }
 __device__ __forceinline__ float bilinear1(const float* __restrict__ img, int w, int h, float x, float y) {
+#pragma clang fp contract(off)
     BilIdx k = bil_index(x, y, w, h);
     float w00 = (1.f - k.a) * (1.f - k.b), w10 = k.a * (1.f - k.b), w01 = (1.f - k.a) * k.b, w11 = k.a * k.b;
     return w00 * img[k.i00] + w10 * img[k.i10] + w01 * img[k.i01] + w11 * img[k.i11];

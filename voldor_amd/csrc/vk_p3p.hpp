@@ -8,51 +8,80 @@
 // reference's GPU instantiation).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cmath>
+// the solvers are plain arithmetic: compiled for host and device so the host build can be
+// checked against the oracle without a GPU (vk_host_* entry points, tests/test_host_math.py)
+#define VK_HD __host__ __device__
 
 namespace vk {
 
+// Overload-by-argument-type math, like the std:: overloads the reference relies on: a double
+// argument (e.g. `b * b - 3.0 * c`) takes the double routine, a float one the float routine.
+VK_HD __forceinline__ float vk_sqrt(float x) { return sqrtf(x); }
+VK_HD __forceinline__ double vk_sqrt(double x) { return ::sqrt(x); }
+VK_HD __forceinline__ float vk_abs(float x) { return fabsf(x); }
+VK_HD __forceinline__ double vk_abs(double x) { return ::fabs(x); }
+
 template <typename S> struct V3 { S x, y, z; };
-template <typename S> __device__ __forceinline__ S dot(V3<S> a, V3<S> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
-template <typename S> __device__ __forceinline__ V3<S> cross(V3<S> a, V3<S> b) {
+template <typename S> VK_HD __forceinline__ S dot(V3<S> a, V3<S> b) {
+#pragma clang fp contract(off)
+    S s = S(0);  // matrix.h:846-851 accumulates from zero
+    s += a.x * b.x; s += a.y * b.y; s += a.z * b.z;
+    return s;
+}
+template <typename S> VK_HD __forceinline__ V3<S> cross(V3<S> a, V3<S> b) {
+#pragma clang fp contract(off)
     return { a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x };
 }
-template <typename S> __device__ __forceinline__ V3<S> sub(V3<S> a, V3<S> b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
-template <typename S> __device__ __forceinline__ V3<S> scale(V3<S> a, S s) { return { a.x * s, a.y * s, a.z * s }; }
-template <typename S> __device__ __forceinline__ V3<S> normalized(V3<S> a) { return scale(a, S(1) / sqrt(dot(a, a))); }
+template <typename S> VK_HD __forceinline__ V3<S> sub(V3<S> a, V3<S> b) { return { a.x - b.x, a.y - b.y, a.z - b.z }; }
+template <typename S> VK_HD __forceinline__ V3<S> scale(V3<S> a, S s) { return { a.x * s, a.y * s, a.z * s }; }
+template <typename S> VK_HD __forceinline__ V3<S> normalized(V3<S> a) { return scale(a, S(1.0) / vk_sqrt(dot(a, a))); }
 template <typename S> struct M3 { S m[9]; };  // row-major
 
+// NUMERICS NOTE.  The reference instantiates its solver with _T=float but keeps double
+// literals (2.0, 0.5, 4.0 ...) in many expressions, so parts of every hypothesis are evaluated in
+// double and rounded back (lambdatwist_p3p.h:38-137, solve_cubic.h:17-34,160-207, solve_eig0.h:
+// 40-67, refine_lambda.h:31-57).  P3P on noisy flow is ill-conditioned for a few percent of the
+// 4-tuples, and those samples move the mean-shift mode by ~1e-3 if they are evaluated with a
+// different rounding sequence.  To stay inside the 1e-3 pose tolerance against the reference's
+// float path, the literals below are written with the reference's types (a bare `2.0` is a
+// double on purpose, `S(2.0)` is the solver scalar) and fma contraction is disabled.
+
 // x^2 + b x + c = 0, numerically stable pair (solve_cubic.h:13-35)
-template <typename S> __device__ __forceinline__ bool root2real(S b, S c, S& r1, S& r2) {
-    S v = b * b - S(4) * c;
-    if (v < S(0)) { r1 = r2 = S(0.5) * b; return false; }
-    S y = sqrt(v);
-    if (b < S(0)) { r1 = S(0.5) * (-b + y); r2 = S(0.5) * (-b - y); }
-    else { r1 = S(2) * c / (-b + y); r2 = S(2) * c / (-b - y); }
+template <typename S> VK_HD __forceinline__ bool root2real(S b, S c, S& r1, S& r2) {
+#pragma clang fp contract(off)
+    S v = b * b - 4.0 * c;
+    if (v < 0) { r1 = r2 = 0.5 * b; return false; }
+    S y = vk_sqrt(v);
+    if (b < 0) { r1 = 0.5 * (-b + y); r2 = 0.5 * (-b - y); }
+    else { r1 = 2.0 * c / (-b + y); r2 = 2.0 * c / (-b - y); }
     return true;
 }
 
 // One real root of x^3 + b x^2 + c x + d with the steepest derivative (solve_cubic.h:154-210)
-template <typename S> __device__ __forceinline__ S cubic_root(S b, S c, S d) {
+template <typename S> VK_HD __forceinline__ S cubic_root(S b, S c, S d) {
+#pragma clang fp contract(off)
     S r0;
-    if (b * b >= S(3) * c) {
-        S v = sqrt(b * b - S(3) * c);
-        S t1 = (-b - v) / S(3);
+    if (b * b >= 3.0 * c) {
+        S v = vk_sqrt(b * b - 3.0 * c);
+        S t1 = (-b - v) / (3.0);
         S k = ((t1 + b) * t1 + c) * t1 + d;
-        if (k > S(0)) r0 = t1 - sqrt(-k / (S(3) * t1 + b));
+        if (k > 0.0) r0 = t1 - vk_sqrt(-k / (3.0 * t1 + b));
         else {
-            S t2 = (-b + v) / S(3);
+            S t2 = (-b + v) / (3.0);
             k = ((t2 + b) * t2 + c) * t2 + d;
-            r0 = t2 + sqrt(-k / (S(3) * t2 + b));
+            r0 = t2 + vk_sqrt(-k / (3.0 * t2 + b));
         }
     } else {
-        r0 = -b / S(3);
-        if (fabs((S(3) * r0 + S(2) * b) * r0 + c) < S(1e-4)) r0 += S(1);
+        r0 = -b / 3.0;
+        if (vk_abs(((S(3.0) * r0 + S(2.0) * b) * r0 + c)) < 1e-4) r0 += 1;
     }
-    const S lim = sizeof(S) == 4 ? S(1e-7) : S(1e-13);
+    const S lim = sizeof(S) == 4 ? S(1e-7) : S(1e-13);  // get_numeric_limit<T>() (solve_cubic.h:87-108)
+#pragma unroll 1
     for (int cnt = 0; cnt < 50; ++cnt) {
-        S fx = ((r0 + b) * r0 + c) * r0 + d;
-        if (cnt < 7 || fabs(fx) > lim) {
-            S fpx = (S(3) * r0 + S(2) * b) * r0 + c;
+        S fx = (((r0 + b) * r0 + c) * r0 + d);
+        if (cnt < 7 || vk_abs(fx) > lim) {
+            S fpx = ((S(3.0) * r0 + S(2.0) * b) * r0 + c);
             r0 -= fx / fpx;
         } else
             break;
@@ -63,51 +92,57 @@ template <typename S> __device__ __forceinline__ S cubic_root(S b, S c, S d) {
 // Eigen-decomposition of a symmetric 3x3 with one known zero eigenvalue (solve_eig0.h:11-80).
 // Only the first two columns of the eigenvector matrix are needed by the caller.
 template <typename S>
-__device__ __forceinline__ void eig_known0(const S* x, S& e1, S& e2, V3<S>& v1, V3<S>& v2) {
+VK_HD __forceinline__ void eig_known0(const S* x, S& e1, S& e2, V3<S>& v1, V3<S>& v2) {
+#pragma clang fp contract(off)
     S x01s = x[1] * x[1];
     S b = -x[0] - x[4] - x[8];
     S c = -x01s - x[2] * x[2] - x[5] * x[5] + x[0] * (x[4] + x[8]) + x[4] * x[8];
     root2real(b, c, e1, e2);
-    if (fabs(e1) < fabs(e2)) { S t = e1; e1 = e2; e2 = t; }
+    if (vk_abs(e1) < vk_abs(e2)) { S t = e1; e1 = e2; e2 = t; }
     S mx0011 = -x[0] * x[4];
     S prec0 = x[1] * x[5] - x[2] * x[4];
     S prec1 = x[1] * x[2] - x[0] * x[5];
     {
-        S tmp = S(1) / (e1 * (x[0] + x[4]) + mx0011 - e1 * e1 + x01s);
+        S tmp = 1.0 / (e1 * (x[0] + x[4]) + mx0011 - e1 * e1 + x01s);
         S a1 = -(e1 * x[2] + prec0) * tmp, a2 = -(e1 * x[5] + prec1) * tmp;
-        S rn = S(1) / sqrt(a1 * a1 + a2 * a2 + S(1));
-        v1 = { a1 * rn, a2 * rn, rn };
+        S rn = ((S)1.0) / vk_sqrt(a1 * a1 + a2 * a2 + 1.0);
+        a1 *= rn; a2 *= rn;
+        v1 = { a1, a2, rn };
     }
     {
-        S tmp = S(1) / (e2 * (x[0] + x[4]) + mx0011 - e2 * e2 + x01s);
+        S tmp = 1.0 / (e2 * (x[0] + x[4]) + mx0011 - e2 * e2 + x01s);
         S a1 = -(e2 * x[2] + prec0) * tmp, a2 = -(e2 * x[5] + prec1) * tmp;
-        S rn = S(1) / sqrt(a1 * a1 + a2 * a2 + S(1));
-        v2 = { a1 * rn, a2 * rn, rn };
+        S rn = 1.0 / vk_sqrt(a1 * a1 + a2 * a2 + 1.0);
+        a1 *= rn; a2 *= rn;
+        v2 = { a1, a2, rn };
     }
 }
 
 // 5 Gauss-Newton steps on the three law-of-cosines residuals (refine_lambda.h:5-102)
 template <typename S>
-__device__ __forceinline__ void refine_lambda(V3<S>& L, S a12, S a13, S a23, S b12, S b13, S b23) {
+VK_HD __forceinline__ void refine_lambda(V3<S>& L, S a12, S a13, S a23, S b12, S b13, S b23) {
+#pragma clang fp contract(off)
 #pragma unroll 1
     for (int i = 0; i < 5; ++i) {
         S l1 = L.x, l2 = L.y, l3 = L.z;
         S r1 = l1 * l1 + l2 * l2 + b12 * l1 * l2 - a12;
         S r2 = l1 * l1 + l3 * l3 + b13 * l1 * l3 - a13;
         S r3 = l2 * l2 + l3 * l3 + b23 * l2 * l3 - a23;
-        S e0 = fabs(r1) + fabs(r2) + fabs(r3);
-        if (e0 < S(1e-10)) break;
-        S v0 = S(2) * l1 + b12 * l2, v1 = S(2) * l2 + b12 * l1;
-        S v3 = S(2) * l1 + b13 * l3, v5 = S(2) * l3 + b13 * l1;
-        S v7 = S(2) * l2 + b23 * l3, v8 = S(2) * l3 + b23 * l2;
-        S det = S(1) / (-v0 * v5 * v7 - v1 * v3 * v8);
-        V3<S> n = { l1 - det * (-v5 * v7 * r1 - v1 * v8 * r2 + v1 * v5 * r3),
-                    l2 - det * (-v3 * v8 * r1 + v0 * v8 * r2 - v0 * v5 * r3),
-                    l3 - det * (v3 * v7 * r1 - v0 * v7 * r2 - v1 * v3 * r3) };
+        if (vk_abs(r1) + vk_abs(r2) + vk_abs(r3) < 1e-10) break;
+        S v0 = (2.0) * l1 + b12 * l2, v1 = (2.0) * l2 + b12 * l1;
+        S v3 = (2.0) * l1 + b13 * l3, v5 = (2.0) * l3 + b13 * l1;
+        S v7 = (2.0) * l2 + b23 * l3, v8 = (2.0) * l3 + b23 * l2;
+        S det = (1.0) / (-v0 * v5 * v7 - v1 * v3 * v8);
+        // L1 = L - det * (Ji * r), the product accumulated from zero as matrix.h:795-810 does
+        S s0 = S(0), s1 = S(0), s2 = S(0);
+        s0 += (-v5 * v7) * r1; s0 += (-v1 * v8) * r2; s0 += (v1 * v5) * r3;
+        s1 += (-v3 * v8) * r1; s1 += (v0 * v8) * r2; s1 += (-v0 * v5) * r3;
+        s2 += (v3 * v7) * r1; s2 += (-v0 * v7) * r2; s2 += (-v1 * v3) * r3;
+        V3<S> n = { l1 - s0 * det, l2 - s1 * det, l3 - s2 * det };
         S q1 = n.x * n.x + n.y * n.y + b12 * n.x * n.y - a12;
         S q2 = n.x * n.x + n.z * n.z + b13 * n.x * n.z - a13;
         S q3 = n.y * n.y + n.z * n.z + b23 * n.y * n.z - a23;
-        if (fabs(q1) + fabs(q2) + fabs(q3) > e0) break;
+        if (vk_abs(q1) + vk_abs(q2) + vk_abs(q3) > vk_abs(r1) + vk_abs(r2) + vk_abs(r3)) break;
         L = n;
     }
 }
@@ -119,65 +154,79 @@ template <typename S> struct BestPose {
 };
 
 template <typename S>
-__device__ __forceinline__ void consider(BestPose<S>& B, V3<S> L, bool blk0, S a12, S a13, S a23, S b12, S b13, S b23,
-                                         V3<S> y1, V3<S> y2, V3<S> y3, V3<S> x1, const S* Xi, V3<S> x4, S y4u, S y4v,
-                                         S fx, S fy, S cx, S cy) {
-    (void)blk0;
+VK_HD __forceinline__ void consider(BestPose<S>& B, V3<S> L, S a12, S a13, S a23, S b12, S b13, S b23,
+                                         V3<S> y1, V3<S> y2, V3<S> y3, V3<S> x1, const S* Xi, const float* x4, float y4u, float y4v,
+                                         float fx, float fy, float cx, float cy) {
+#pragma clang fp contract(off)
     refine_lambda(L, a12, a13, a23, b12, b13, b23);
     V3<S> ry1 = scale(y1, L.x), ry2 = scale(y2, L.y), ry3 = scale(y3, L.z);
     V3<S> yd1 = sub(ry1, ry2), yd2 = sub(ry1, ry3), yc = cross(yd1, yd2);
-    // R = Y * X^-1, Y = [yd1 yd2 yc] (columns)
+    // R = Y * X^-1, Y = [yd1 yd2 yc] (columns); sums start from zero like matrix.h:795-810
+    const S Y[9] = { yd1.x, yd2.x, yc.x, yd1.y, yd2.y, yc.y, yd1.z, yd2.z, yc.z };
     S R[9];
-    R[0] = yd1.x * Xi[0] + yd2.x * Xi[3] + yc.x * Xi[6]; R[1] = yd1.x * Xi[1] + yd2.x * Xi[4] + yc.x * Xi[7]; R[2] = yd1.x * Xi[2] + yd2.x * Xi[5] + yc.x * Xi[8];
-    R[3] = yd1.y * Xi[0] + yd2.y * Xi[3] + yc.y * Xi[6]; R[4] = yd1.y * Xi[1] + yd2.y * Xi[4] + yc.y * Xi[7]; R[5] = yd1.y * Xi[2] + yd2.y * Xi[5] + yc.y * Xi[8];
-    R[6] = yd1.z * Xi[0] + yd2.z * Xi[3] + yc.z * Xi[6]; R[7] = yd1.z * Xi[1] + yd2.z * Xi[4] + yc.z * Xi[7]; R[8] = yd1.z * Xi[2] + yd2.z * Xi[5] + yc.z * Xi[8];
-    S t0 = ry1.x - (R[0] * x1.x + R[1] * x1.y + R[2] * x1.z);
-    S t1 = ry1.y - (R[3] * x1.x + R[4] * x1.y + R[5] * x1.z);
-    S t2 = ry1.z - (R[6] * x1.x + R[7] * x1.y + R[8] * x1.z);
-    S X = R[0] * x4.x + R[1] * x4.y + R[2] * x4.z + t0;
-    S Y = R[3] * x4.x + R[4] * x4.y + R[5] * x4.z + t1;
-    S Z = R[6] * x4.x + R[7] * x4.y + R[8] * x4.z + t2;
-    S du = cx + fx * X / Z - y4u, dv = cy + fy * Y / Z - y4v;
-    S err = du * du + dv * dv;
-    // lambdatwist_p4p.h:31-41: first candidate always taken, later ones only if strictly better
+#pragma unroll
+    for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            S sum = S(0);
+            sum += Y[r * 3] * Xi[c]; sum += Y[r * 3 + 1] * Xi[3 + c]; sum += Y[r * 3 + 2] * Xi[6 + c];
+            R[r * 3 + c] = sum;
+        }
+    S t[3];
+    const S ry[3] = { ry1.x, ry1.y, ry1.z };
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        S sum = S(0);
+        sum += R[r * 3] * x1.x; sum += R[r * 3 + 1] * x1.y; sum += R[r * 3 + 2] * x1.z;
+        t[r] = ry[r] - sum;
+    }
+    // 4th-point reprojection (lambdatwist_p4p.h:31-41): _T * float products, float intrinsics
+    S X = R[0] * x4[0] + R[1] * x4[1] + R[2] * x4[2] + t[0];
+    S Yp = R[3] * x4[0] + R[4] * x4[1] + R[5] * x4[2] + t[1];
+    S Z = R[6] * x4[0] + R[7] * x4[1] + R[8] * x4[2] + t[2];
+    S mu = cx + fx * X / Z, mv = cy + fy * Yp / Z;
+    S err = (mu - y4u) * (mu - y4u) + (mv - y4v) * (mv - y4v);
+    // first candidate always taken, later ones only if strictly better
     if (B.n == 0 || B.err > err) {
 #pragma unroll
         for (int k = 0; k < 9; k++) B.R[k] = R[k];
-        B.t[0] = t0; B.t[1] = t1; B.t[2] = t2; B.err = err;
+        B.t[0] = t[0]; B.t[1] = t[1]; B.t[2] = t[2]; B.err = err;
     }
     B.n++;
 }
 
 // y: 4 pixel observations (u,v), x: 4 3-D points. Returns false if P3P has no solution.
 template <typename S>
-__device__ static bool lambdatwist_p4p(const float* yu, const float* yv, const float (*xp)[3], float fxf, float fyf,
+VK_HD static bool lambdatwist_p4p(const float* yu, const float* yv, const float (*xp)[3], float fxf, float fyf,
                                        float cxf, float cyf, float* Rout, float* tout) {
-    V3<S> y1 = normalized<S>({ (S)((yu[0] - cxf) / fxf), (S)((yv[0] - cyf) / fyf), S(1) });
-    V3<S> y2 = normalized<S>({ (S)((yu[1] - cxf) / fxf), (S)((yv[1] - cyf) / fyf), S(1) });
-    V3<S> y3 = normalized<S>({ (S)((yu[2] - cxf) / fxf), (S)((yv[2] - cyf) / fyf), S(1) });
+#pragma clang fp contract(off)
+    // bearings are formed in float and then widened (lambdatwist_p4p.h:13-15)
+    V3<S> y1 = normalized<S>({ (S)((yu[0] - cxf) / fxf), (S)((yv[0] - cyf) / fyf), S(1.0) });
+    V3<S> y2 = normalized<S>({ (S)((yu[1] - cxf) / fxf), (S)((yv[1] - cyf) / fyf), S(1.0) });
+    V3<S> y3 = normalized<S>({ (S)((yu[2] - cxf) / fxf), (S)((yv[2] - cyf) / fyf), S(1.0) });
     V3<S> x1 = { (S)xp[0][0], (S)xp[0][1], (S)xp[0][2] }, x2 = { (S)xp[1][0], (S)xp[1][1], (S)xp[1][2] };
-    V3<S> x3 = { (S)xp[2][0], (S)xp[2][1], (S)xp[2][2] }, x4 = { (S)xp[3][0], (S)xp[3][1], (S)xp[3][2] };
-    S b12 = S(-2) * dot(y1, y2), b13 = S(-2) * dot(y1, y3), b23 = S(-2) * dot(y2, y3);
+    V3<S> x3 = { (S)xp[2][0], (S)xp[2][1], (S)xp[2][2] };
+    S b12 = -2.0 * (dot(y1, y2)), b13 = -2.0 * (dot(y1, y3)), b23 = -2.0 * (dot(y2, y3));
     V3<S> d12 = sub(x1, x2), d13 = sub(x1, x3), d23 = sub(x2, x3), dc = cross(d12, d13);
     S a12 = dot(d12, d12), a13 = dot(d13, d13), a23 = dot(d23, d23);
-    S c31 = S(-0.5) * b13, c23 = S(-0.5) * b23, c12 = S(-0.5) * b12;
-    S blob = c12 * c23 * c31 - S(1);
-    S s31 = S(1) - c31 * c31, s23 = S(1) - c23 * c23, s12 = S(1) - c12 * c12;
-    S p3 = a13 * (a23 * s31 - a13 * s23);
-    S p2 = S(2) * blob * a23 * a13 + a13 * (S(2) * a12 + a13) * s23 + a23 * (a23 - a12) * s31;
-    S p1 = a23 * (a13 - a23) * s12 - a12 * a12 * s23 - S(2) * a12 * (blob * a23 + a13 * s23);
+    S c31 = -0.5 * b13, c23 = -0.5 * b23, c12 = -0.5 * b12;
+    S blob = (c12 * c23 * c31 - 1.0);
+    S s31 = 1.0 - c31 * c31, s23 = 1.0 - c23 * c23, s12 = 1.0 - c12 * c12;
+    S p3 = (a13 * (a23 * s31 - a13 * s23));
+    S p2 = 2.0 * blob * a23 * a13 + a13 * (2.0 * a12 + a13) * s23 + a23 * (a23 - a12) * s31;
+    S p1 = a23 * (a13 - a23) * s12 - a12 * a12 * s23 - 2.0 * a12 * (blob * a23 + a13 * s23);
     S p0 = a12 * (a12 * s23 - a23 * s12);
-    p3 = S(1) / p3;
-    S g = cubic_root<S>(p2 * p3, p1 * p3, p0 * p3);
+    p3 = 1.0 / p3;
+    p2 *= p3; p1 *= p3; p0 *= p3;
+    S g = cubic_root<S>(p2, p1, p0);
 
     S A[9];
-    A[0] = a23 * (S(1) - g); A[1] = a23 * b12 * S(0.5); A[2] = a23 * b13 * g * S(-0.5);
-    A[4] = a23 - a12 + a13 * g; A[5] = b23 * (a13 * g - a12) * S(0.5); A[8] = g * (a13 - a23) - a12;
+    A[0] = a23 * (1.0 - g); A[1] = (a23 * b12) * 0.5; A[2] = (a23 * b13 * g) * (-0.5);
+    A[4] = a23 - a12 + a13 * g; A[5] = b23 * (a13 * g - a12) * 0.5; A[8] = g * (a13 - a23) - a12;
     A[3] = A[1]; A[6] = A[2]; A[7] = A[5];
     S e1, e2; V3<S> v1, v2;
     eig_known0<S>(A, e1, e2, v1, v2);
-    S ratio = -e2 / e1;
-    S v = sqrt(ratio > S(0) ? ratio : S(0));
+    S v = vk_sqrt(-e2 / e1 > 0 ? -e2 / e1 : S(0));
 
     // X^-1 with X = [d12 d13 d12xd13] columns (matrix.h:636-656 adjugate form)
     S Xm[9] = { d12.x, d13.x, dc.x, d12.y, d13.y, dc.y, d12.z, d13.z, dc.z };
@@ -186,36 +235,34 @@ __device__ static bool lambdatwist_p4p(const float* yu, const float* yv, const f
         S M0 = Xm[4] * Xm[8] - Xm[5] * Xm[7], M1 = Xm[2] * Xm[7] - Xm[1] * Xm[8], M2 = Xm[1] * Xm[5] - Xm[2] * Xm[4];
         S M3_ = Xm[5] * Xm[6] - Xm[3] * Xm[8], M4 = Xm[0] * Xm[8] - Xm[2] * Xm[6], M5 = Xm[2] * Xm[3] - Xm[0] * Xm[5];
         S M6 = Xm[3] * Xm[7] - Xm[4] * Xm[6], M7 = Xm[1] * Xm[6] - Xm[0] * Xm[7], M8 = Xm[0] * Xm[4] - Xm[1] * Xm[3];
-        S idet = S(1) / (Xm[0] * M0 + Xm[1] * M3_ + Xm[2] * M6);
+        S idet = S(1.0) / (Xm[0] * M0 + Xm[1] * M3_ + Xm[2] * M6);
         Xi[0] = M0 * idet; Xi[1] = M1 * idet; Xi[2] = M2 * idet; Xi[3] = M3_ * idet; Xi[4] = M4 * idet;
         Xi[5] = M5 * idet; Xi[6] = M6 * idet; Xi[7] = M7 * idet; Xi[8] = M8 * idet;
     }
     BestPose<S> B;
     B.n = 0; B.err = S(0);
-    const S y4u = (S)yu[3], y4v = (S)yv[3];
-    const S fx = (S)fxf, fy = (S)fyf, cx = (S)cxf, cy = (S)cyf;
 #pragma unroll 1
     for (int blk = 0; blk < 2; blk++) {  // s = +v, then s = -v (lambdatwist_p3p.h:140-240)
         S s = blk == 0 ? v : -v;
-        S w2 = S(1) / (s * v2.x - v1.x);
+        S w2 = S(1.0) / (s * v2.x - v1.x);
         S w0 = (v1.y - s * v2.y) * w2;
         S w1 = (v1.z - s * v2.z) * w2;
-        S a = S(1) / ((a13 - a12) * w1 * w1 - a12 * b13 * w1 - a12);
-        S b = (a13 * b12 * w1 - a12 * b13 * w0 - S(2) * w0 * w1 * (a12 - a13)) * a;
+        S a = S(1.0) / ((a13 - a12) * w1 * w1 - a12 * b13 * w1 - a12);
+        S b = (a13 * b12 * w1 - a12 * b13 * w0 - S(2.0) * w0 * w1 * (a12 - a13)) * a;
         S c = ((a13 - a12) * w0 * w0 + a13 * b12 * w0 + a13) * a;
-        if (b * b - S(4) * c >= S(0)) {
+        if (b * b - 4.0 * c >= 0) {
             S tau1, tau2;
             root2real(b, c, tau1, tau2);
 #pragma unroll 1
             for (int k = 0; k < 2; k++) {
                 S tau = k == 0 ? tau1 : tau2;
-                if (tau > S(0)) {
-                    S d = a23 / (tau * (b23 + tau) + S(1));
-                    if (d > S(0)) {  // the +v block relies on sqrt(NaN) failing l1>=0: same outcome
-                        S l2 = sqrt(d), l3 = tau * l2, l1 = w0 * l2 + w1 * l3;
-                        if (l1 >= S(0))
-                            consider<S>(B, { l1, l2, l3 }, blk == 0, a12, a13, a23, b12, b13, b23, y1, y2, y3, x1, Xi, x4,
-                                        y4u, y4v, fx, fy, cx, cy);
+                if (tau > 0) {
+                    S d = a23 / (tau * (b23 + tau) + S(1.0));
+                    if (d > 0) {  // the +v block relies on vk_sqrt(NaN) failing l1>=0: same outcome
+                        S l2 = vk_sqrt(d), l3 = tau * l2, l1 = w0 * l2 + w1 * l3;
+                        if (l1 >= 0)
+                            consider<S>(B, { l1, l2, l3 }, a12, a13, a23, b12, b13, b23, y1, y2, y3, x1, Xi, xp[3], yu[3], yv[3],
+                                        fxf, fyf, cxf, cyf);
                     }
                 }
             }
@@ -232,25 +279,31 @@ __device__ static bool lambdatwist_p4p(const float* yu, const float* yv, const f
 // Nearest rotation by Newton iteration on the polar factor, X <- (X + X^-T)/2 (the reference
 // gets the same factor as U*V^T from an approximate SVD, rodrigues.h:82-108), then Ceres'
 // atan2 formula (rodrigues.h:5-79).
-__device__ __forceinline__ void nearest_rotation(float* X) {
+VK_HD __forceinline__ void nearest_rotation(float* Rf) {
+#pragma clang fp contract(off)
+    // fp64: P3P on degenerate 4-tuples returns near-singular "rotations" whose polar factor is
+    // ill-conditioned; evaluating it in double keeps those hypotheses reproducible (8192 lanes
+    // x ~10 iterations of 3x3 algebra is negligible next to the per-pixel passes).
+    double X[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) X[i] = (double)Rf[i];
 #pragma unroll 1
-    for (int it = 0; it < 12; it++) {
-        float c0 = X[4] * X[8] - X[5] * X[7], c1 = X[5] * X[6] - X[3] * X[8], c2 = X[3] * X[7] - X[4] * X[6];
-        float c3 = X[2] * X[7] - X[1] * X[8], c4 = X[0] * X[8] - X[2] * X[6], c5 = X[1] * X[6] - X[0] * X[7];
-        float c6 = X[1] * X[5] - X[2] * X[4], c7 = X[2] * X[3] - X[0] * X[5], c8 = X[0] * X[4] - X[1] * X[3];
-        float det = X[0] * c0 + X[1] * c1 + X[2] * c2;
-        if (!(fabsf(det) > 1e-30f)) break;
-        float id = 0.5f / det;
-        float n0 = 0.5f * X[0] + c0 * id, n1 = 0.5f * X[1] + c1 * id, n2 = 0.5f * X[2] + c2 * id;
-        float n3 = 0.5f * X[3] + c3 * id, n4 = 0.5f * X[4] + c4 * id, n5 = 0.5f * X[5] + c5 * id;
-        float n6 = 0.5f * X[6] + c6 * id, n7 = 0.5f * X[7] + c7 * id, n8 = 0.5f * X[8] + c8 * id;
-        float delta = fabsf(n0 - X[0]) + fabsf(n1 - X[1]) + fabsf(n2 - X[2]) + fabsf(n3 - X[3]) + fabsf(n4 - X[4]) +
-                      fabsf(n5 - X[5]) + fabsf(n6 - X[6]) + fabsf(n7 - X[7]) + fabsf(n8 - X[8]);
-        X[0] = n0; X[1] = n1; X[2] = n2; X[3] = n3; X[4] = n4; X[5] = n5; X[6] = n6; X[7] = n7; X[8] = n8;
-        if (delta < 1e-6f) break;
+    for (int it = 0; it < 30; it++) {
+        double c[9];
+        c[0] = X[4] * X[8] - X[5] * X[7]; c[1] = X[5] * X[6] - X[3] * X[8]; c[2] = X[3] * X[7] - X[4] * X[6];
+        c[3] = X[2] * X[7] - X[1] * X[8]; c[4] = X[0] * X[8] - X[2] * X[6]; c[5] = X[1] * X[6] - X[0] * X[7];
+        c[6] = X[1] * X[5] - X[2] * X[4]; c[7] = X[2] * X[3] - X[0] * X[5]; c[8] = X[0] * X[4] - X[1] * X[3];
+        double det = X[0] * c[0] + X[1] * c[1] + X[2] * c[2];
+        if (!(vk_abs(det) > 1e-300)) break;
+        double delta = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) { double y = 0.5 * (X[i] + c[i] / det); delta += vk_abs(y - X[i]); X[i] = y; }
+        if (delta < 1e-15) break;
     }
+#pragma unroll
+    for (int i = 0; i < 9; i++) Rf[i] = (float)X[i];
 }
-__device__ __forceinline__ void rotmat_to_angle_axis(const float* R, float* aa) {
+VK_HD __forceinline__ void rotmat_to_angle_axis(const float* R, float* aa) {
     float a0 = R[7] - R[5], a1 = R[2] - R[6], a2 = R[3] - R[1];
     float costheta = fminf(fmaxf((R[0] + R[4] + R[8] - 1.f) * 0.5f, -1.f), 1.f);
     float sintheta = fminf(sqrtf(a0 * a0 + a1 * a1 + a2 * a2) * 0.5f, 1.f);
@@ -270,7 +323,7 @@ __device__ __forceinline__ void rotmat_to_angle_axis(const float* R, float* aa) 
     aa[0] = b0; aa[1] = b1; aa[2] = b2;
 }
 // angle-axis -> rotation matrix (cv::Rodrigues vec->mat as used at voldor/geometry.cpp:258)
-__host__ __device__ __forceinline__ void angle_axis_to_rotmat(const float* rv, float* R) {
+VK_HD __forceinline__ void angle_axis_to_rotmat(const float* rv, float* R) {
     double rx = rv[0], ry = rv[1], rz = rv[2];
     double th = sqrt(rx * rx + ry * ry + rz * rz);
     if (th < 2.220446049250313e-16) {
@@ -287,27 +340,27 @@ __host__ __device__ __forceinline__ void angle_axis_to_rotmat(const float* rv, f
 // ---- AP3P ------------------------------------------------------------------------------------
 // Float-complex helpers with the semantics of CUDA's cuComplex.h as the reference uses them.
 struct Cx { float x, y; };
-__device__ __forceinline__ float cx_abs(Cx z) {
+VK_HD __forceinline__ float cx_abs(Cx z) {
     float a = fabsf(z.x), b = fabsf(z.y), v = fmaxf(a, b), w = fminf(a, b);
     float t = w / v;
     t = v * sqrtf(1.0f + t * t);
     if (v == 0.0f || v > 3.402823466e38f || w > 3.402823466e38f) t = v + w;
     return t;
 }
-__device__ __forceinline__ Cx cx_div(Cx x, Cx y) {
+VK_HD __forceinline__ Cx cx_div(Cx x, Cx y) {
     float s = fabsf(y.x) + fabsf(y.y), oos = 1.0f / s;
     float ars = x.x * oos, ais = x.y * oos, brs = y.x * oos, bis = y.y * oos;
     s = brs * brs + bis * bis; oos = 1.0f / s;
     return { (ars * brs + ais * bis) * oos, (ais * brs - ars * bis) * oos };
 }
-__device__ __forceinline__ Cx cx_sqrt(Cx x) {  // solve_batch_ap3p.cu:9-15 (principal root, Im <= 0)
+VK_HD __forceinline__ Cx cx_sqrt(Cx x) {  // solve_batch_ap3p.cu:9-15 (principal root, Im <= 0)
     float m = cx_abs(x), u = x.x / m;
     return { sqrtf(m * (u + 1.0f) / 2.0f), -fabsf(sqrtf(m * (1.0f - u) / 2.0f)) };
 }
 // Ferrari quartic as written at solve_batch_ap3p.cu:28-82, INCLUDING the double square root
 // in the q3<0 branch (:57, differs from OpenCV's ap3p.cpp): result parity with the reference
 // wins over fixing it; the two Newton polish steps (:85-98) follow.
-__device__ static void ap3p_quartic(float a4, float a3, float a2, float a1, float a0, float& r0, float& r1, float& r2, float& r3) {
+VK_HD static void ap3p_quartic(float a4, float a3, float a2, float a1, float a0, float& r0, float& r1, float& r2, float& r3) {
     float a4_2 = a4 * a4, a3_2 = a3 * a3, a4_3 = a4_2 * a4, a2a4 = a2 * a4;
     float p4 = (8 * a2a4 - 3 * a3_2) / (8 * a4_2);
     float q4 = (a3_2 * a3 - 4 * a2a4 * a3 + 8 * a1 * a4_2) / (8 * a4_3);
@@ -332,7 +385,7 @@ __device__ static void ap3p_quartic(float a4, float a3, float a2, float a1, floa
     float s2 = cx_sqrt({ -(c1.x - c2.x), -(c1.y - c2.y) }).x * 0.5f;
     r0 = B_4A + h + s1; r1 = B_4A + h - s1; r2 = B_4A - h + s2; r3 = B_4A - h - s2;
 }
-__device__ __forceinline__ float ap3p_polish(float r, float c0, float c1, float c2, float c3, float c4) {
+VK_HD __forceinline__ float ap3p_polish(float r, float c0, float c1, float c2, float c3, float c4) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
         float err = (((c0 * r + c1) * r + c2) * r + c3) * r + c4;
@@ -342,10 +395,10 @@ __device__ __forceinline__ float ap3p_polish(float r, float c0, float c1, float 
     return r;
 }
 // cross product with the reference's vect_cross operand order (solve_batch_ap3p.cu:100-104)
-__device__ __forceinline__ V3<float> vcross(V3<float> a, V3<float> b) {
+VK_HD __forceinline__ V3<float> vcross(V3<float> a, V3<float> b) {
     return { a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x };
 }
-__device__ static bool ap3p_p4p(const float* yu, const float* yv, const float (*xp)[3], float fx, float fy, float cx,
+VK_HD static bool ap3p_p4p(const float* yu, const float* yv, const float (*xp)[3], float fx, float fy, float cx,
                                 float cy, float* Rout, float* tout) {
     typedef V3<float> F3;
     F3 bv[3];

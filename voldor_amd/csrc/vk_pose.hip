@@ -132,10 +132,19 @@ __global__ __launch_bounds__(256) static void k_compact(const float* __restrict_
 }
 
 // ---- batched pose hypotheses: one lane each (solve_batch_lambdatwist.cu:11-42, solve_batch_ap3p.cu:331-378)
-template <int SOLVER>  // 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>
+// Two ways to draw the 4 correspondences of a hypothesis, both uniform over the valid set:
+//  FROM_MAP=false  index into the compacted list, (int)(u*N_pts) like the reference kernel -- used by
+//                  the host-pointer API solve_batch_p3p_*_gpu, which receives that list;
+//  FROM_MAP=true   rejection sampling over the NaN-marked correspondence maps -- used by the
+//                  device-resident window pipeline.  Same distribution, no compaction pass, and a
+//                  one-pixel change of the valid set only changes the hypotheses that hit that
+//                  pixel instead of re-drawing all of them (with list indices a single insertion
+//                  shifts every later index; DESIGN.md "sampling stability").
+constexpr int DRAW_MAX_TRIES = 256;
+template <int SOLVER, bool FROM_MAP>  // SOLVER: 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>
 __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ pts2, const float* __restrict__ pts3,
                                                       float* __restrict__ rvecs, float* __restrict__ tvecs,
-                                                      const int* __restrict__ n_pts_dev, float fx, float fy, float cx, float cy,
+                                                      const int* __restrict__ n_pts_dev, int npx, float fx, float fy, float cx, float cy,
                                                       int n_poses) {
     const int idx = blockIdx.x * 64 + threadIdx.x;
     if (idx >= n_poses) return;
@@ -143,21 +152,35 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
     const float qnan = __builtin_nanf("");
     float R[9], t[3];
     bool ok = false;
-    if (n_pts >= 1) {
+    if (n_pts >= (FROM_MAP ? 4 : 1)) {
         float yu[4], yv[4], xp[4][3];
+        bool drawn = true;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            // 4 indices per hypothesis; the reference re-seeds per call so the pattern depends only
-            // on (idx, n_pts) (solve_batch_lambdatwist.cu:16-19,80-81). u in (0,1]: clamp the
-            // one-past-the-end index the reference can produce.
-            int i = (int)(u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)k)) * (float)n_pts);
-            i = min(i, n_pts - 1);
+            int i;
+            if (FROM_MAP) {
+                i = -1;
+                for (int j = 0; j < DRAW_MAX_TRIES; j++) {
+                    uint32_t r = rng3(RAND_SEED, (uint32_t)idx, (uint32_t)(k * DRAW_MAX_TRIES + j));
+                    int cand = (int)(((unsigned long long)r * (unsigned long long)npx) >> 32);
+                    if (isfinite(pts2[(size_t)cand * 2])) { i = cand; break; }
+                }
+                if (i < 0) { drawn = false; i = 0; }
+            } else {
+                // the reference re-seeds per call, so the pattern depends only on (idx, n_pts)
+                // (solve_batch_lambdatwist.cu:16-19,80-81). u in (0,1]: clamp the one-past-the-end
+                // index the reference can produce.
+                i = (int)(u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)k)) * (float)n_pts);
+                i = min(i, n_pts - 1);
+            }
             yu[k] = pts2[(size_t)i * 2]; yv[k] = pts2[(size_t)i * 2 + 1];
             xp[k][0] = pts3[(size_t)i * 3]; xp[k][1] = pts3[(size_t)i * 3 + 1]; xp[k][2] = pts3[(size_t)i * 3 + 2];
         }
-        if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t);
-        else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t);
-        else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t);
+        if (drawn) {
+            if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t);
+            else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t);
+            else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t);
+        }
     }
     float aa[3] = { qnan, qnan, qnan };
     if (ok) { nearest_rotation(R); rotmat_to_angle_axis(R, aa); }
@@ -546,12 +569,10 @@ __global__ __launch_bounds__(MS_THREADS) static void k_robust_gaussian_only(cons
 
 // ---- host launchers ------------------------------------------------------------------------------
 int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
-                   float min_depth, float max_depth, int max_trace, CamState* cam_dev) {
+                   float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact) {
     const int npx = w * h, nblk = (npx + 255) / 256;
     if (int e = c->p2_map.reserve(sizeof(float) * 2 * (size_t)npx)) return e;
     if (int e = c->p3_map.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
-    if (int e = c->pts2.reserve(sizeof(float) * 2 * (size_t)npx)) return e;
-    if (int e = c->pts3.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
     if (int e = c->blk_counts.reserve(sizeof(int) * (size_t)nblk)) return e;
     if (int e = c->blk_offsets.reserve(sizeof(int) * (size_t)nblk)) return e;
     if (int e = c->n_points.reserve(sizeof(int) * 4)) return e;
@@ -560,25 +581,35 @@ int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int activ
                        rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace);
     hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, c->stream, c->blk_counts.as<int>(), c->blk_offsets.as<int>(), nblk,
                        c->n_points.as<int>(), cam_dev);
-    hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(256), 0, c->stream, c->p2_map.as<float>(), c->p3_map.as<float>(),
-                       c->blk_offsets.as<int>(), c->pts2.as<float>(), c->pts3.as<float>(), npx);
+    if (compact) {  // the host-pointer API hands the compacted list to its caller (geometry.cpp:68-80)
+        if (int e = c->pts2.reserve(sizeof(float) * 2 * (size_t)npx)) return e;
+        if (int e = c->pts3.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
+        hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(256), 0, c->stream, c->p2_map.as<float>(), c->p3_map.as<float>(),
+                           c->blk_offsets.as<int>(), c->pts2.as<float>(), c->pts3.as<float>(), npx);
+    }
     VK_CHECK_LAST();
     return 0;
 }
 
-int solve_device(Context* c, const float* pts2, const float* pts3, const int* n_pts_dev, float fx, float fy, float cx, float cy,
-                 int n_poses, int solver) {
+template <bool FROM_MAP>
+static int solve_launch(Context* c, const float* pts2, const float* pts3, const int* n_pts_dev, int npx, float fx, float fy, float cx,
+                        float cy, int n_poses, int solver) {
     if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     dim3 g((n_poses + 63) / 64), b(64);
-    if (solver == 0)
-        hipLaunchKernelGGL(k_solve<0>, g, b, 0, c->stream, pts2, pts3, c->rvecs.as<float>(), c->tvecs.as<float>(), n_pts_dev, fx, fy, cx, cy, n_poses);
-    else if (solver == 1)
-        hipLaunchKernelGGL(k_solve<1>, g, b, 0, c->stream, pts2, pts3, c->rvecs.as<float>(), c->tvecs.as<float>(), n_pts_dev, fx, fy, cx, cy, n_poses);
-    else
-        hipLaunchKernelGGL(k_solve<2>, g, b, 0, c->stream, pts2, pts3, c->rvecs.as<float>(), c->tvecs.as<float>(), n_pts_dev, fx, fy, cx, cy, n_poses);
+    float* rv = c->rvecs.as<float>(); float* tv = c->tvecs.as<float>();
+    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, npx, fx, fy, cx, cy, n_poses);
+    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, npx, fx, fy, cx, cy, n_poses);
+    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, npx, fx, fy, cx, cy, n_poses);
     VK_CHECK_LAST();
     return 0;
+}
+int solve_device(Context* c, const float* pts2, const float* pts3, const int* n_pts_dev, float fx, float fy, float cx, float cy,
+                 int n_poses, int solver) {
+    return solve_launch<false>(c, pts2, pts3, n_pts_dev, 0, fx, fy, cx, cy, n_poses, solver);
+}
+int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver) {
+    return solve_launch<true>(c, c->p2_map.as<float>(), c->p3_map.as<float>(), c->n_points.as<int>(), npx, fx, fy, cx, cy, n_poses, solver);
 }
 
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx) {
