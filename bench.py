@@ -1,0 +1,171 @@
+#!/usr/bin/env python
+"""bench.py -- VO frames/s of the MI355X VOLDOR inner loop (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one VO window = one py_voldor_wrapper call: BASELINE config 2,
+640x480, N_flow=5, 8 EM iterations, monocular, synthetic flows of scene S already resident in
+HBM when the timed region starts (vk_voldor_device).  With N>1 every rank owns one sequence
+(seed 233+rank, weak scaling) and the ranks exchange their pose blocks with one RCCL all-gather
+per step.  Rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     optimize_depth kernel group: algorithmic bytes B_od = w*h*(40N+36N_dp+12)
+                / average group duration measured with HIP events on the library's
+               stream (vk_profile_*), against the 8 TB/s HBM peak.
+  cpu_baseline the oracle (C restatement of the reference path, OpenMP) timed on this box's host
+               cores on the same workload, a bounded number of windows (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch  # noqa: E402  (first: shares its HIP runtime with libvoldor_hip.so)
+import torch.distributed as dist  # noqa: E402
+
+W, H, N_FLOW, EM_ITERS = 640, 480, 5, 8
+FX = FY = 320.0
+CX, CY = 320.0, 240.0
+CONFIG = f"--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters {EM_ITERS}"  # mono mode of voldor_slam.py:153
+HBM_PEAK_GBS = 8000.0
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-windows", type=int, default=2)
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # backend nccl == RCCL on ROCm
+
+    from voldor_amd import capi, pyvoldor, synth
+
+    lib = capi.lib()
+    sc = synth.make_scene(w=W, h=H, n_flows=N_FLOW, fx=FX, fy=FY, cx=CX, cy=CY, seed=233 + rank)
+    flows = torch.from_numpy(sc["flows"]).cuda()
+    depth = torch.empty(H, W, device="cuda")
+    conf = torch.empty(H, W, device="cuda")
+    blk = 1 + 6 * N_FLOW + 36 * N_FLOW
+    send = torch.zeros(blk, device="cuda")
+    recv = torch.zeros(world * blk, device="cuda")
+
+    def step():
+        out = pyvoldor.voldor_device(flows, FX, FY, CX, CY, config=CONFIG, depth_out=depth, depth_conf_out=conf)
+        if world > 1:  # pose exchange: [n_registered | poses N x 6 | covar N x 36] per rank
+            n = out["n_registered"]
+            host = np.zeros(blk, np.float32)
+            host[0] = n
+            host[1:1 + 6 * n] = out["poses"].reshape(-1)
+            host[1 + 6 * N_FLOW:1 + 6 * N_FLOW + 36 * n] = out["poses_covar"].reshape(-1)
+            send.copy_(torch.from_numpy(host), non_blocking=True)
+            dist.all_gather_into_tensor(recv, send)
+        return out
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = world * args.steps / dt
+
+    # ---- roofline of the optimize_depth kernel group (HIP events on the library's own stream) ----
+    roof = None
+    if rank == 0:
+        lib.vk_profile_enable(1)
+        nprof = max(2, min(5, args.steps))
+        for _ in range(nprof):
+            out = step()
+        torch.cuda.synchronize()
+        tot, cnt = C.c_double(0), C.c_long(0)
+        groups = {}
+        for name in ("optimize_depth", "optimize_camera_pose", "bootstrap"):
+            if lib.vk_profile_get(name.encode(), C.byref(tot), C.byref(cnt)) == 0 and cnt.value > 0:
+                groups[name] = {"avg_us": tot.value / cnt.value * 1e3, "calls_per_window": cnt.value / nprof}
+        lib.vk_profile_enable(0)
+        b_od = W * H * (40 * N_FLOW + 36 * 0 + 12)  # bytes per optimize_depth call
+        if "optimize_depth" in groups:
+            t_s = groups["optimize_depth"]["avg_us"] * 1e-6
+            ach = b_od / t_s / 1e9
+            roof = {"bound": "hbm", "kernel": "optimize_depth kernel group (fb_rows, fb_cols, cost_rand, global_prop x4, local_prop x4, update_rigidness)",
+                    "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
+                    "algorithmic_bytes": b_od, "avg_us": round(groups["optimize_depth"]["avg_us"], 2), "traffic": None,
+                    "groups": {k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in groups.items()}}
+
+    # ---- CPU baseline: the oracle on the host cores (rank 0, N=1 only, bounded sample) ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            from oracle import orc
+            orc.build()
+            cores = orc.max_threads()
+            orc.voldor(sc["flows"][:, :60, :80].copy(), 40.0, 40.0, 40.0, 30.0, config="--silent --max_iters 1")  # warm-up
+            t0 = time.perf_counter()
+            for _ in range(args.cpu_windows):
+                ref = orc.voldor(sc["flows"], FX, FY, CX, CY, config=CONFIG)
+            tc = time.perf_counter() - t0
+            rot, tr = synth.pose_errors(out["poses"], ref["poses"])
+            cpu = {"value": round(args.cpu_windows / tc, 4), "unit": "frames/s", "cores": cores, "kind": "port",
+                   "sample": f"{args.cpu_windows} windows of the same 640x480 N_flow=5 8-iteration workload, oracle/liborc.so (C restatement, OpenMP {cores} threads)",
+                   "pose_vs_gpu": {"rot_rad_max": float(rot.max()) if len(rot) else None, "rel_trans_max": float(tr.max()) if len(tr) else None}}
+        except Exception as e:  # the baseline is a reported number, never a reason to fail the bench
+            cpu = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
+
+    if rank == 0:
+        gt = sc["poses_gt"].copy()
+        s = np.mean(np.linalg.norm(gt[:, 3:], axis=1))
+        gt[:, 3:] /= s
+        rot, tr = synth.pose_errors(out["poses"], gt)
+        line = {
+            "metric": "VO frames/s (640x480, N_flow=5, 8 EM iters)", "value": round(value, 3), "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE cfg2: 640x480, N_flow=5, monocular, 8 EM iterations, scene S seed 233+rank, flows resident in HBM",
+                       "voldor_config": CONFIG, "parallelism": f"one sequence per GPU x{world}, RCCL all-gather of pose blocks"},
+            "n_registered": int(out["n_registered"]),
+            "pose_rpe_vs_gt": {"rot_rad_max": float(rot.max()) if len(rot) else None, "rel_trans_max": float(tr.max()) if len(tr) else None},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
