@@ -144,7 +144,7 @@ int lmeds_essential_host(const float* p2, int nx, int ny, int step, float fxf, f
             const double num = x2 * Ex0 + y2 * Ex1 + Ex2;
             errs[j] = num * num / (Ex0 * Ex0 + Ex1 * Ex1 + Et0 * Et0 + Et1 * Et1);
         }
-        std::sort(errs.begin(), errs.end());
+        std::nth_element(errs.begin(), errs.begin() + ns / 2, errs.end());  // the ns/2-th order statistic
         const double med = errs[ns / 2];
         if (med < best_med) { best_med = med; memcpy(bestE, E, sizeof E); }
     }

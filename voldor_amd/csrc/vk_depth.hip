@@ -27,37 +27,65 @@ struct Img {
     float lambda, omega, inv_arf, basefocal, disp_delta, delta;
 };
 
-// compute_pixel_cost, optimize_depth.cu:140-198
-__device__ static float pixel_cost(const Img& I, int px, int py, float depth) {
+// compute_pixel_cost, optimize_depth.cu:140-198.
+// Three phases so that the N bilinear gathers of one hypothesis are all in flight together instead
+// of one L2 round trip per frame (the sampling positions depend on depth and poses only, not on
+// the flow values): (1) rigid chain -> positions + validity mask, (2) issue every gather,
+// (3) residual model.  NMAX is the compile-time frame bound (arrays stay in registers).
+template <int NMAX>
+__device__ __forceinline__ static float pixel_cost(const Img& I, int px, int py, float depth) {
     const int w = I.w, h = I.h, npx = w * h, pi = py * w + px;
     const PoseBlock* P = I.P;
+    float qx[NMAX], qy[NMAX], rdx[NMAX], rdy[NMAX];
+    unsigned valid = 0;
+    {
+        P3 o = backproject(P, (float)px, (float)py, depth);
+        float px1 = (float)px, py1 = (float)py;
+#pragma unroll
+        for (int f = 0; f < NMAX; f++) {
+            qx[f] = 0.f; qy[f] = 0.f; rdx[f] = 0.f; rdy[f] = 0.f;
+            if (f < I.N) {
+                o = transform(P->Rs[f], P->ts[f], o);
+                float px2, py2;
+                project(P, o, px2, py2);
+                if (o.z > 0.f && px1 >= 0.f && px1 < (float)w && py1 >= 0.f && py1 < (float)h) {
+                    valid |= 1u << f;
+                    qx[f] = px1; qy[f] = py1; rdx[f] = px2 - px1; rdy[f] = py2 - py1;
+                    px1 = px2; py1 = py2;  // advances on contributing frames only (:162-164)
+                }
+            }
+        }
+    }
+    float2 obs[NMAX];
+    float wgt[NMAX];
+#pragma unroll
+    for (int f = 0; f < NMAX; f++) {
+        obs[f] = make_float2(0.f, 0.f); wgt[f] = 0.f;
+        if (f < I.N) {  // unconditional (clamped) gathers: no divergent branch around the loads
+            obs[f] = bilinear2(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
+            wgt[f] = I.rig[(size_t)f * npx + pi];
+        }
+    }
     float cost_sum = 0.f, wsum = 0.f;
-    P3 o = backproject(P, (float)px, (float)py, depth);
-    float px1 = (float)px, py1 = (float)py;
-    for (int f = 0; f < I.N; f++) {
-        o = transform(P->Rs[f], P->ts[f], o);
-        float px2, py2;
-        project(P, o, px2, py2);
-        if (o.z > 0.f && px1 >= 0.f && px1 < (float)w && py1 >= 0.f && py1 < (float)h) {
-            float2 d2 = bilinear2(I.flows + (size_t)f * npx, w, h, px1, py1);
-            float wgt = I.rig[(size_t)f * npx + pi];
-            cost_sum += wgt * neglog_rigidness_from_flows(px2 - px1, py2 - py1, d2.x, d2.y, I.lambda, I.inv_arf);
-            wsum += wgt;
-            px1 = px2; py1 = py2;
+#pragma unroll
+    for (int f = 0; f < NMAX; f++) {
+        if (f < I.N && ((valid >> f) & 1u)) {
+            cost_sum += wgt[f] * neglog_rigidness_from_flows(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.inv_arf);
+            wsum += wgt[f];
         }
     }
     for (int f = 0; f < I.N_dp; f++) {
         P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
-        float qx, qy;
-        project(P, q, qx, qy);
-        if (q.z > 0.f && qx >= 0.f && qx < (float)w && qy >= 0.f && qy < (float)h) {
-            float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx, qy);
+        float qx2, qy2;
+        project(P, q, qx2, qy2);
+        if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
+            float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
             if (td > 0.f) {
-                float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx, qy);
-                float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx, qy);
-                float wgt = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
-                cost_sum += wgt * __logf(1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf));
-                wsum += wgt;
+                float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
+                float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
+                float wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
+                cost_sum += wg * __logf(1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf));
+                wsum += wg;
             }
         }
     }
@@ -66,17 +94,18 @@ __device__ static float pixel_cost(const Img& I, int px, int py, float depth) {
 }
 
 // ---- cost map + all random samples, fused (optimize_depth.cu:279-284 + :269-277 x n_rand) ----
+template <int NMAX>
 __global__ __launch_bounds__(256) static void k_cost_rand(Img I, int n_rand, uint32_t epoch0, float range_factor) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= I.w || y >= I.h) return;
     const int pi = y * I.w + x;
     float d = I.depth[pi];
-    float c = pixel_cost(I, x, y, d);
+    float c = pixel_cost<NMAX>(I, x, y, d);
     for (int it = 0; it < n_rand; it++) {
         float u = u01(rng3(RAND_SEED, (uint32_t)pi, epoch0 + (uint32_t)it));
         float dn = 1.0f / (range_factor * u + (1.0f / 1e5f));  // MAXIMUM_DEPTH, :15,:273
-        float cn = pixel_cost(I, x, y, dn);
+        float cn = pixel_cost<NMAX>(I, x, y, dn);
         if (cn < c) { c = cn; d = dn; }
     }
     I.depth[pi] = d;
@@ -84,102 +113,220 @@ __global__ __launch_bounds__(256) static void k_cost_rand(Img I, int n_rand, uin
 }
 
 // replace_if_better_depth, optimize_depth.cu:201-207
+template <int NMAX>
 __device__ __forceinline__ static void try_depth(const Img& I, int x, int y, float cand) {
     const int pi = y * I.w + x;
-    float c = pixel_cost(I, x, y, cand);
+    float c = pixel_cost<NMAX>(I, x, y, cand);
     if (c < I.cost[pi]) { I.depth[pi] = cand; I.cost[pi] = c; }
 }
 
 // ---- global propagation (optimize_depth.cu:209-235). With step>=2 the sites of one pass are
 // independent (reads x-1, writes x): one thread per site.  dir: 0 L2R,
 // 1 T2B, 2 R2L, 3 B2T.
+template <int NMAX>
 __global__ __launch_bounds__(256) static void k_global_prop_sites(Img I, int dir, int step, int nsites) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;  // site index along the pass direction
     const int l = blockIdx.y;                             // line (row for 0/2, column for 1/3)
     if (s >= nsites) return;
-    if (dir == 0) { int x = 1 + s * step; try_depth(I, x, l, I.depth[l * I.w + x - 1]); }
-    else if (dir == 2) { int x = I.w - 2 - s * step; try_depth(I, x, l, I.depth[l * I.w + x + 1]); }
-    else if (dir == 1) { int y = 1 + s * step; try_depth(I, l, y, I.depth[(y - 1) * I.w + l]); }
-    else { int y = I.h - 2 - s * step; try_depth(I, l, y, I.depth[(y + 1) * I.w + l]); }
+    if (dir == 0) { int x = 1 + s * step; try_depth<NMAX>(I, x, l, I.depth[l * I.w + x - 1]); }
+    else if (dir == 2) { int x = I.w - 2 - s * step; try_depth<NMAX>(I, x, l, I.depth[l * I.w + x + 1]); }
+    else if (dir == 1) { int y = 1 + s * step; try_depth<NMAX>(I, l, y, I.depth[(y - 1) * I.w + l]); }
+    else { int y = I.h - 2 - s * step; try_depth<NMAX>(I, l, y, I.depth[(y + 1) * I.w + l]); }
 }
 // step==1: a true serial chain per line (not used by any shipped config; kept for parity)
+template <int NMAX>
 __global__ static void k_global_prop_serial(Img I, int dir) {
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (dir == 0 || dir == 2) {
         if (l >= I.h) return;
-        if (dir == 0) for (int x = 1; x < I.w; x++) try_depth(I, x, l, I.depth[l * I.w + x - 1]);
-        else for (int x = I.w - 2; x >= 0; x--) try_depth(I, x, l, I.depth[l * I.w + x + 1]);
+        if (dir == 0) for (int x = 1; x < I.w; x++) try_depth<NMAX>(I, x, l, I.depth[l * I.w + x - 1]);
+        else for (int x = I.w - 2; x >= 0; x--) try_depth<NMAX>(I, x, l, I.depth[l * I.w + x + 1]);
     } else {
         if (l >= I.w) return;
-        if (dir == 1) for (int y = 1; y < I.h; y++) try_depth(I, l, y, I.depth[(y - 1) * I.w + l]);
-        else for (int y = I.h - 2; y >= 0; y--) try_depth(I, l, y, I.depth[(y + 1) * I.w + l]);
+        if (dir == 1) for (int y = 1; y < I.h; y++) try_depth<NMAX>(I, l, y, I.depth[(y - 1) * I.w + l]);
+        else for (int y = I.h - 2; y >= 0; y--) try_depth<NMAX>(I, l, y, I.depth[(y + 1) * I.w + l]);
     }
 }
 
-// ---- local propagation (optimize_depth.cu:237-267): serial chain inside each `width` segment.
-// One thread per (segment, line). Row passes put adjacent lanes on adjacent rows, so each lane
-// walks its own cache line; column passes put adjacent lanes on adjacent columns (coalesced).
+// ---- local propagation (optimize_depth.cu:237-267): a true serial chain inside each `width`
+// segment -- the candidate of step k+1 is the (possibly replaced) depth of step k -- so the pass is
+// bound by the latency of ONE cost evaluation times (width-1).  To shorten that critical path a
+// chain is driven by a group of 8 adjacent lanes: every lane walks the (cheap, ALU-only) rigid
+// chain, then evaluates only the frames it owns (f = g, g+8: gather + residual model), and the
+// per-frame terms are summed in frame order through 8-wide shuffles, so the cost has the same
+// summation order as the one-thread evaluation.  640x480: 9600 chains x 8 lanes = 1200 waves
+// (the reference runs 9600 threads, one full evaluation per step each).
+__device__ __forceinline__ static float cost_split8(const Img& I, int px, int py, float depth, int g) {
+    const int w = I.w, h = I.h, npx = w * h, pi = py * w + px;
+    const PoseBlock* P = I.P;
+    float qx0 = 0.f, qy0 = 0.f, rx0 = 0.f, ry0 = 0.f, qx1 = 0.f, qy1 = 0.f, rx1 = 0.f, ry1 = 0.f;
+    bool v0 = false, v1 = false;
+    {
+        P3 o = backproject(P, (float)px, (float)py, depth);
+        float px1 = (float)px, py1 = (float)py;
+        for (int f = 0; f < I.N; f++) {  // uniform trip count: no divergence inside the group
+            o = transform(P->Rs[f], P->ts[f], o);
+            float px2, py2;
+            project(P, o, px2, py2);
+            const bool valid = o.z > 0.f && px1 >= 0.f && px1 < (float)w && py1 >= 0.f && py1 < (float)h;
+            if (f == g) { v0 = valid; qx0 = px1; qy0 = py1; rx0 = px2 - px1; ry0 = py2 - py1; }
+            if (f == g + 8) { v1 = valid; qx1 = px1; qy1 = py1; rx1 = px2 - px1; ry1 = py2 - py1; }
+            if (valid) { px1 = px2; py1 = py2; }
+        }
+    }
+    float ct0 = 0.f, wt0 = 0.f, ct1 = 0.f, wt1 = 0.f;
+    if (v0) {
+        float2 ob = bilinear2(I.flows + (size_t)g * npx, w, h, qx0, qy0);
+        wt0 = I.rig[(size_t)g * npx + pi];
+        ct0 = wt0 * neglog_rigidness_from_flows(rx0, ry0, ob.x, ob.y, I.lambda, I.inv_arf);
+    }
+    if (I.N > 8 && v1) {
+        float2 ob = bilinear2(I.flows + (size_t)(g + 8) * npx, w, h, qx1, qy1);
+        wt1 = I.rig[(size_t)(g + 8) * npx + pi];
+        ct1 = wt1 * neglog_rigidness_from_flows(rx1, ry1, ob.x, ob.y, I.lambda, I.inv_arf);
+    }
+    float cp0 = 0.f, wp0 = 0.f, cp1 = 0.f, wp1 = 0.f;
+    for (int s = 0; s < 2; s++) {  // depth priors owned by this lane: f = g, g+8 (optimize_depth.cu:170-190)
+        const int f = g + 8 * s;
+        if (f < I.N_dp) {
+            P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
+            float qx2, qy2;
+            project(P, q, qx2, qy2);
+            if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
+                float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+                if (td > 0.f) {
+                    float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
+                    float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
+                    float wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
+                    float cc = wg * (0.6931471805599453f * fast_log2(1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf)));
+                    if (s == 0) { cp0 = cc; wp0 = wg; } else { cp1 = cc; wp1 = wg; }
+                }
+            }
+        }
+    }
+    float cost_sum = 0.f, wsum = 0.f;
+    for (int f = 0; f < I.N; f++) {  // frame order, like the serial loop (adding an exact 0 for skipped frames)
+        const float c = __shfl((f & 8) ? ct1 : ct0, f & 7, 8), wg = __shfl((f & 8) ? wt1 : wt0, f & 7, 8);
+        cost_sum += c; wsum += wg;
+    }
+    for (int f = 0; f < I.N_dp; f++) {
+        const float c = __shfl((f & 8) ? cp1 : cp0, f & 7, 8), wg = __shfl((f & 8) ? wp1 : wp0, f & 7, 8);
+        cost_sum += c; wsum += wg;
+    }
+    if (wsum == 0.f) return INFINITY;
+    return cost_sum / fmaxf(wsum, 1.1920929e-07f);
+}
+// One 8-lane group walks one chain; pi0/stride/n describe it, `cand` is the first candidate.
+__device__ __forceinline__ static void local_chain8(const Img& I, int pi0, int stride, int n, float cand, int g, bool live) {
+    // n is uniform per group; groups of one wave may have different n (ragged last segment): loop to the wave max
+    int nmax = n;
+#pragma unroll
+    for (int o = 32; o >= 8; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o, 64));
+    float d_cur = 0.f, c_cur = 0.f;
+    if (live && n > 0) { d_cur = I.depth[pi0]; c_cur = I.cost[pi0]; }
+    for (int k = 0; k < nmax; k++) {
+        const bool on = live && k < n;
+        const int pi = on ? pi0 + k * stride : 0;
+        float d_nxt = 0.f, c_nxt = 0.f;
+        if (on && k + 1 < n) { d_nxt = I.depth[pi + stride]; c_nxt = I.cost[pi + stride]; }
+        const int x = pi % I.w, y = pi / I.w;
+        const float c = cost_split8(I, x, y, on ? cand : 1.f, g);  // all 64 lanes take part in the shuffles
+        if (on) {
+            if (c < c_cur) { if (g == 0) { I.depth[pi] = cand; I.cost[pi] = c; } }  // replace_if_better_depth (:201-207)
+            else cand = d_cur;
+            d_cur = d_nxt; c_cur = c_nxt;
+        }
+    }
+}
 __global__ __launch_bounds__(64) static void k_local_prop(Img I, int dir, int width) {
     const int w = I.w, h = I.h;
+    const int g = threadIdx.x & 7, line = blockIdx.x * 8 + (threadIdx.x >> 3), seg = blockIdx.y;
     if (dir == 0 || dir == 2) {
-        const int y = blockIdx.x * 64 + threadIdx.x, seg = blockIdx.y;
-        if (y >= h) return;
+        const int y = line;
+        const bool live = y < h;
         const int px = seg * width;
-        if (dir == 0) {
-            for (int x = max(1, px + 1); x < min(w, px + width); x++) try_depth(I, x, y, I.depth[y * w + x - 1]);
-        } else {
-            for (int x = min(w - 2, px + width - 2); x >= max(0, px); x--) try_depth(I, x, y, I.depth[y * w + x + 1]);
+        if (dir == 0) {  // x = max(1,px+1) .. min(w,px+width)-1 ascending, candidate depth[x-1]
+            const int x0 = max(1, px + 1), n = live ? min(w, px + width) - x0 : 0;
+            local_chain8(I, y * w + x0, 1, n, (live && n > 0) ? I.depth[y * w + x0 - 1] : 1.f, g, live);
+        } else {         // x = min(w-2,px+width-2) .. max(0,px) descending, candidate depth[x+1]
+            const int x0 = min(w - 2, px + width - 2), n = live ? x0 - max(0, px) + 1 : 0;
+            local_chain8(I, y * w + x0, -1, n, (live && n > 0) ? I.depth[y * w + x0 + 1] : 1.f, g, live);
         }
     } else {
-        const int x = blockIdx.x * 64 + threadIdx.x, seg = blockIdx.y;
-        if (x >= w) return;
+        const int x = line;
+        const bool live = x < w;
         const int py = seg * width;
         if (dir == 1) {
-            for (int y = max(1, py + 1); y < min(h, py + width); y++) try_depth(I, x, y, I.depth[(y - 1) * w + x]);
+            const int y0 = max(1, py + 1), n = live ? min(h, py + width) - y0 : 0;
+            local_chain8(I, y0 * w + x, w, n, (live && n > 0) ? I.depth[(y0 - 1) * w + x] : 1.f, g, live);
         } else {
-            for (int y = min(h - 2, py + width - 2); y >= max(0, py); y--) try_depth(I, x, y, I.depth[(y + 1) * w + x]);
+            const int y0 = min(h - 2, py + width - 2), n = live ? y0 - max(0, py) + 1 : 0;
+            local_chain8(I, y0 * w + x, -w, n, (live && n > 0) ? I.depth[(y0 + 1) * w + x] : 1.f, g, live);
         }
     }
 }
 
 // ---- E-step (optimize_depth.cu:84-138) + per-block sums of each rigidness map (the density
-// test of voldor.cpp:171 then needs no D2H of the maps).
+// test of voldor.cpp:171 then needs no D2H of the maps).  Same three-phase structure as pixel_cost.
+template <int NMAX>
 __global__ __launch_bounds__(256) static void k_update_rigidness(Img I, float* __restrict__ partial) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63);
     const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
     const bool live = x < I.w && y < I.h;
-    const int w = I.w, h = I.h, npx = w * h, pi = y * w + x;
+    const int w = I.w, h = I.h, npx = w * h, pi = live ? y * w + x : 0;
     const PoseBlock* P = I.P;
-    __shared__ float s_part[4];
+    __shared__ float s_part[NMAX][4];
     const int blk = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
-    float d = live ? I.depth[pi] : 1.f;
-    P3 o = backproject(P, (float)x, (float)y, d);
-    float px1 = (float)x, py1 = (float)y;
-    for (int f = 0; f < I.N; f++) {
-        o = transform(P->Rs[f], P->ts[f], o);
-        float px2, py2;
-        project(P, o, px2, py2);
-        float r = 0.f;
-        if (live && o.z > 0.f && px1 >= 0.f && px1 < (float)w && py1 >= 0.f && py1 < (float)h) {
-            float2 d2 = bilinear2(I.flows + (size_t)f * npx, w, h, px1, py1);
-            r = rigidness_from_flows(px2 - px1, py2 - py1, d2.x, d2.y, I.lambda, I.inv_arf);
-            px1 = px2; py1 = py2;
+    const float d = live ? I.depth[pi] : 1.f;
+    float qx[NMAX], qy[NMAX], rdx[NMAX], rdy[NMAX];
+    unsigned valid = 0;
+    {
+        P3 o = backproject(P, (float)x, (float)y, d);
+        float px1 = (float)x, py1 = (float)y;
+#pragma unroll
+        for (int f = 0; f < NMAX; f++) {
+            qx[f] = 0.f; qy[f] = 0.f; rdx[f] = 0.f; rdy[f] = 0.f;
+            if (f < I.N) {
+                o = transform(P->Rs[f], P->ts[f], o);
+                float px2, py2;
+                project(P, o, px2, py2);
+                if (live && o.z > 0.f && px1 >= 0.f && px1 < (float)w && py1 >= 0.f && py1 < (float)h) {
+                    valid |= 1u << f;
+                    qx[f] = px1; qy[f] = py1; rdx[f] = px2 - px1; rdy[f] = py2 - py1;
+                    px1 = px2; py1 = py2;  // NOT advanced on invalid frames
+                }
+            }
         }
-        if (live) I.rig[(size_t)f * npx + pi] = r;
-        float ws = wave_sum(live ? r : 0.f);
-        if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = ws;
-        __syncthreads();
-        if (threadIdx.x == 0) partial[(size_t)f * nblk + blk] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
-        __syncthreads();
+    }
+    float2 obs[NMAX];
+#pragma unroll
+    for (int f = 0; f < NMAX; f++) {
+        obs[f] = make_float2(0.f, 0.f);
+        if (f < I.N) obs[f] = bilinear2(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < NMAX; f++) {
+        if (f < I.N) {
+            float r = 0.f;
+            if ((valid >> f) & 1u) r = rigidness_from_flows(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.inv_arf);
+            if (live) I.rig[(size_t)f * npx + pi] = r;
+            float ws = wave_sum(live ? r : 0.f);
+            if ((threadIdx.x & 63) == 0) s_part[f][threadIdx.x >> 6] = ws;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NMAX && (int)threadIdx.x < I.N) {
+        const int f = threadIdx.x;
+        partial[(size_t)f * nblk + blk] = (s_part[f][0] + s_part[f][1]) + (s_part[f][2] + s_part[f][3]);
     }
     if (!live) return;
     for (int f = 0; f < I.N_dp; f++) {
         P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)x, (float)y, d));
-        float qx, qy;
-        project(P, q, qx, qy);
-        if (q.z > 0.f && qx >= 0.f && qx < (float)w && qy >= 0.f && qy < (float)h) {
-            float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx, qy);
-            if (td > 0.f)
+        float qx2, qy2;
+        project(P, q, qx2, qy2);
+        if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
+            float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+            if (td > 0.f)  // else: the confidence is left untouched (:129)
                 I.confs[(size_t)f * npx + pi] = 1.f / (1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf));
         } else
             I.confs[(size_t)f * npx + pi] = 0.f;
@@ -198,72 +345,104 @@ __global__ static void k_reduce_density(const float* __restrict__ partial, int n
 }
 
 // ---- forward-backward smoothing (fb_smooth.h:26-70) -------------------------------------
-// Row pass: one wave owns 64 rows of one map and walks the columns in 64-wide chunks that
-// are staged through LDS, so global traffic is coalesced (the reference reads with a
-// row-pitch stride between adjacent lanes) while each lane runs its row's serial recurrence.
-__global__ __launch_bounds__(64) static void k_fb_rows(float* __restrict__ maps, float* __restrict__ fwd, int w, int h,
-                                                        float e0, float p) {
-    __shared__ float tE[64][65];
-    __shared__ float tF[64][65];
-    const int lane = threadIdx.x, r0 = blockIdx.x * 64;
+// The recurrences are serial along a line, so the kernels are latency-bound; what matters is that
+// no step of the chain waits on global memory and that the chain itself is short: the
+// normalisation uses v_rcp_f32 (1 ulp) instead of the ~15-instruction IEEE division.
+//
+// Row pass: one workgroup (4 waves) owns 64 rows of one map and walks the columns in 64-wide
+// chunks.  All 256 threads stage the 64x64 tile of the NEXT chunk (16 independent coalesced loads
+// per thread, issued before the compute of the current chunk so the HBM/L2 latency hides under it)
+// while wave 0 runs the 64 row recurrences out of LDS ([64][65] padding: conflict-free column
+// walk).  The reference reads with a row-pitch stride between adjacent lanes instead
+// (fb_smooth.h:27-46, 480*N threads, uncoalesced).
+constexpr int FB_T = 64;
+__device__ __forceinline__ void fb_tile_load(const float* __restrict__ m, int w, int h, int r0, int c0, float (&reg)[16]) {
+    const int col = c0 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int row = r0 + rg * 16 + k;
+        reg[k] = (row < h && col < w) ? m[(size_t)row * w + col] : 0.5f;
+    }
+}
+__device__ __forceinline__ void fb_tile_to_lds(float (*t)[FB_T + 1], const float (&reg)[16]) {
+    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; k++) t[rg * 16 + k][col] = reg[k];
+}
+__device__ __forceinline__ void fb_tile_store(float* __restrict__ m, int w, int h, int r0, int c0, const float (*t)[FB_T + 1]) {
+    const int col = c0 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        const int row = r0 + rg * 16 + k;
+        if (row < h && col < w) m[(size_t)row * w + col] = t[rg * 16 + k][threadIdx.x & 63];
+    }
+}
+__global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps, float* __restrict__ fwd, int w, int h,
+                                                         float e0, float p) {
+    __shared__ float tE[2][FB_T][FB_T + 1];
+    __shared__ float tF[2][FB_T][FB_T + 1];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r0 = blockIdx.x * FB_T;
     float* m = maps + (size_t)blockIdx.y * w * h;
     float* fw = fwd + (size_t)blockIdx.y * w * h;
-    const int row = r0 + lane;
-    const bool live = row < h;
-    const int nchunk = (w + 63) / 64;
+    const int nchunk = (w + FB_T - 1) / FB_T;
     const float q = 1.f - p;
-    float prev = live ? m[(size_t)row * w] : 0.5f;
-    for (int ch = 0; ch < nchunk; ch++) {  // forward messages, FB_MSG_L2R :27-36
-        const int c0 = ch * 64;
-        for (int r = 0; r < 64; r++) {
-            int rr = r0 + r, cc = c0 + lane;
-            tE[r][lane] = (rr < h && cc < w) ? m[(size_t)rr * w + cc] : 0.5f;
+    float regE[16], regF[16];
+    // ---------------- forward messages, FB_MSG_L2R (fb_smooth.h:27-36)
+    float prev = 0.5f;
+    if (wv == 0 && r0 + lane < h) prev = m[(size_t)(r0 + lane) * w];
+    fb_tile_load(m, w, h, r0, 0, regE);
+    fb_tile_to_lds(tE[0], regE);
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ch++) {
+        const int c0 = ch * FB_T, cur = ch & 1;
+        if (ch + 1 < nchunk) fb_tile_load(m, w, h, r0, c0 + FB_T, regE);  // in flight during the chain below
+        if (wv == 0) {
+            const int nc = min(FB_T, w - c0);
+            for (int j = 0; j < nc; j++) {
+                float e1 = tE[cur][lane][j];
+                float s0 = (prev * q + (1.f - prev) * p) * e0;
+                float s1 = (prev * p + (1.f - prev) * q) * e1;
+                prev = s1 * fast_rcp(s0 + s1);
+                tF[0][lane][j] = prev;
+            }
         }
         __syncthreads();
-        const int nc = min(64, w - c0);
-        for (int j = 0; j < nc; j++) {
-            float e1 = tE[lane][j];
-            float s0 = (prev * q + (1.f - prev) * p) * e0;
-            float s1 = (prev * p + (1.f - prev) * q) * e1;
-            prev = s1 / (s0 + s1);
-            tF[lane][j] = prev;
-        }
-        __syncthreads();
-        for (int r = 0; r < 64; r++) {
-            int rr = r0 + r, cc = c0 + lane;
-            if (rr < h && cc < w) fw[(size_t)rr * w + cc] = tF[r][lane];
-        }
+        fb_tile_store(fw, w, h, r0, c0, tF[0]);
+        if (ch + 1 < nchunk) fb_tile_to_lds(tE[cur ^ 1], regE);
         __syncthreads();
     }
-    prev = live ? m[(size_t)row * w + (w - 1)] : 0.5f;
-    for (int ch = nchunk - 1; ch >= 0; ch--) {  // backward messages :37-46 fused with posterior :65-69
-        const int c0 = ch * 64;
-        for (int r = 0; r < 64; r++) {
-            int rr = r0 + r, cc = c0 + lane;
-            bool ok = rr < h && cc < w;
-            tE[r][lane] = ok ? m[(size_t)rr * w + cc] : 0.5f;
-            tF[r][lane] = ok ? fw[(size_t)rr * w + cc] : 0.5f;
+    // ---------------- backward messages (:37-46) fused with the posterior (:65-69), written in place
+    prev = 0.5f;
+    if (wv == 0 && r0 + lane < h) prev = m[(size_t)(r0 + lane) * w + (w - 1)];
+    fb_tile_load(m, w, h, r0, (nchunk - 1) * FB_T, regE);
+    fb_tile_load(fw, w, h, r0, (nchunk - 1) * FB_T, regF);
+    fb_tile_to_lds(tE[(nchunk - 1) & 1], regE);
+    fb_tile_to_lds(tF[(nchunk - 1) & 1], regF);
+    __syncthreads();
+    for (int ch = nchunk - 1; ch >= 0; ch--) {
+        const int c0 = ch * FB_T, cur = ch & 1;
+        if (ch > 0) { fb_tile_load(m, w, h, r0, c0 - FB_T, regE); fb_tile_load(fw, w, h, r0, c0 - FB_T, regF); }
+        if (wv == 0) {
+            const int nc = min(FB_T, w - c0);
+            for (int j = nc - 1; j >= 0; j--) {
+                float e1 = tE[cur][lane][j];
+                float s0 = prev * e1 * q + (1.f - prev) * p * e0;
+                float s1 = prev * e1 * p + (1.f - prev) * q * e0;
+                prev = s1 * fast_rcp(s0 + s1);
+                float F = tF[cur][lane][j];
+                float a1 = F * prev, a0 = (1.f - F) * (1.f - prev);
+                tE[cur][lane][j] = a1 * fast_rcp(a0 + a1);
+            }
         }
         __syncthreads();
-        const int nc = min(64, w - c0);
-        for (int j = nc - 1; j >= 0; j--) {
-            float e1 = tE[lane][j];
-            float s0 = prev * e1 * q + (1.f - prev) * p * e0;
-            float s1 = prev * e1 * p + (1.f - prev) * q * e0;
-            prev = s1 / (s0 + s1);
-            float F = tF[lane][j];
-            float a1 = F * prev, a0 = (1.f - F) * (1.f - prev);
-            tE[lane][j] = a1 / (a0 + a1);
-        }
-        __syncthreads();
-        for (int r = 0; r < 64; r++) {
-            int rr = r0 + r, cc = c0 + lane;
-            if (rr < h && cc < w) m[(size_t)rr * w + cc] = tE[r][lane];
-        }
+        fb_tile_store(m, w, h, r0, c0, tE[cur]);
+        if (ch > 0) { fb_tile_to_lds(tE[cur ^ 1], regE); fb_tile_to_lds(tF[cur ^ 1], regF); }
         __syncthreads();
     }
 }
-// Column pass: lane = column, naturally coalesced (FB_MSG_T2B/B2T :47-64 + posterior).
+// Column pass: lane = column, naturally coalesced (FB_MSG_T2B/B2T :47-64 + posterior). The loads
+// of the next FB_PF rows are issued as one batch ahead of the dependent chain.
+constexpr int FB_PF = 16;
 __global__ __launch_bounds__(64) static void k_fb_cols(float* __restrict__ maps, float* __restrict__ fwd, int w, int h,
                                                         float e0, float p) {
     const int x = blockIdx.x * 64 + threadIdx.x;
@@ -272,22 +451,55 @@ __global__ __launch_bounds__(64) static void k_fb_cols(float* __restrict__ maps,
     float* fw = fwd + (size_t)blockIdx.y * w * h + x;
     const float q = 1.f - p;
     float prev = m[0];
-    for (int i = 0; i < h; i++) {
-        float e1 = m[(size_t)i * w];
-        float s0 = (prev * q + (1.f - prev) * p) * e0;
-        float s1 = (prev * p + (1.f - prev) * q) * e1;
-        prev = s1 / (s0 + s1);
-        fw[(size_t)i * w] = prev;
+    float en[FB_PF], Fn[FB_PF];
+#pragma unroll
+    for (int k = 0; k < FB_PF; k++) en[k] = (k < h) ? m[(size_t)k * w] : 0.5f;
+    for (int i0 = 0; i0 < h; i0 += FB_PF) {
+        float e[FB_PF];
+#pragma unroll
+        for (int k = 0; k < FB_PF; k++) e[k] = en[k];
+#pragma unroll
+        for (int k = 0; k < FB_PF; k++) {  // next batch in flight while this one runs the chain
+            const int i = i0 + FB_PF + k;
+            en[k] = (i < h) ? m[(size_t)i * w] : 0.5f;
+        }
+#pragma unroll
+        for (int k = 0; k < FB_PF; k++) {
+            if (i0 + k < h) {
+                float s0 = (prev * q + (1.f - prev) * p) * e0;
+                float s1 = (prev * p + (1.f - prev) * q) * e[k];
+                prev = s1 * fast_rcp(s0 + s1);
+                fw[(size_t)(i0 + k) * w] = prev;
+            }
+        }
     }
     prev = m[(size_t)(h - 1) * w];
-    for (int i = h - 1; i >= 0; i--) {
-        float e1 = m[(size_t)i * w];
-        float s0 = prev * e1 * q + (1.f - prev) * p * e0;
-        float s1 = prev * e1 * p + (1.f - prev) * q * e0;
-        prev = s1 / (s0 + s1);
-        float F = fw[(size_t)i * w];
-        float a1 = F * prev, a0 = (1.f - F) * (1.f - prev);
-        m[(size_t)i * w] = a1 / (a0 + a1);
+#pragma unroll
+    for (int k = 0; k < FB_PF; k++) {
+        const int i = h - 1 - k;
+        en[k] = (i >= 0) ? m[(size_t)i * w] : 0.5f;
+        Fn[k] = (i >= 0) ? fw[(size_t)i * w] : 0.5f;
+    }
+    for (int i0 = h - 1; i0 >= 0; i0 -= FB_PF) {
+        float e[FB_PF], F[FB_PF];
+#pragma unroll
+        for (int k = 0; k < FB_PF; k++) { e[k] = en[k]; F[k] = Fn[k]; }
+#pragma unroll
+        for (int k = 0; k < FB_PF; k++) {
+            const int i = i0 - FB_PF - k;
+            en[k] = (i >= 0) ? m[(size_t)i * w] : 0.5f;
+            Fn[k] = (i >= 0) ? fw[(size_t)i * w] : 0.5f;
+        }
+#pragma unroll
+        for (int k = 0; k < FB_PF; k++) {
+            if (i0 - k >= 0) {
+                float s0 = prev * e[k] * q + (1.f - prev) * p * e0;
+                float s1 = prev * e[k] * p + (1.f - prev) * q * e0;
+                prev = s1 * fast_rcp(s0 + s1);
+                float a1 = F[k] * prev, a0 = (1.f - F[k]) * (1.f - prev);
+                m[(size_t)(i0 - k) * w] = a1 * fast_rcp(a0 + a1);
+            }
+        }
     }
 }
 
@@ -295,7 +507,7 @@ int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0
     if (n_maps <= 0) return 0;
     if (int e = c->fb_scratch.reserve(sizeof(float) * (size_t)w * h * n_maps)) return e;
     float* fwd = c->fb_scratch.as<float>();
-    hipLaunchKernelGGL(k_fb_rows, dim3((h + 63) / 64, n_maps), dim3(64), 0, c->stream, maps, fwd, w, h, s0_ems_prob, no_change_prob);
+    hipLaunchKernelGGL(k_fb_rows, dim3((h + 63) / 64, n_maps), dim3(256), 0, c->stream, maps, fwd, w, h, s0_ems_prob, no_change_prob);
     hipLaunchKernelGGL(k_fb_cols, dim3((w + 63) / 64, n_maps), dim3(64), 0, c->stream, maps, fwd, w, h, s0_ems_prob, no_change_prob);
     VK_CHECK_LAST();
     return 0;
@@ -313,22 +525,22 @@ static Img make_img(const ImageSet& S, const OdParams& p) {
 }
 
 // Device-resident optimize_depth: all inputs already in `S`. Stage order optimize_depth.cu:462-494.
-int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p) {
+template <int NMAX>
+static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_only) {
     const int w = p.w, h = p.h;
-    if (int e = S.cost.reserve(sizeof(float) * (size_t)w * h)) return e;
-    if (c->rand_w != w || c->rand_h != h) {  // reference re-inits the RNG when the size changes (:358-361)
-        if (c->rand_w != -1) c->rand_epoch = 0;  // (-1: epoch was set explicitly through vk_set_rand_epoch)
-        c->rand_w = w; c->rand_h = h;
-    }
     Img I = make_img(S, p);
     const dim3 gpx((w + 63) / 64, (h + 3) / 4), bpx(256);
-    if (c->prof) prof_begin(c);
+    if (cost_only) {
+        hipLaunchKernelGGL(k_cost_rand<NMAX>, gpx, bpx, 0, c->stream, I, 0, 0u, p.range_factor);
+        VK_CHECK_LAST();
+        return 0;
+    }
     if (!p.update_rigidness_only) {
         if (p.fb_smooth) {
             if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob)) return e;
             if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob)) return e;
         }
-        hipLaunchKernelGGL(k_cost_rand, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
+        hipLaunchKernelGGL(k_cost_rand<NMAX>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
         c->rand_epoch += (uint32_t)(p.n_rand_samples > 0 ? p.n_rand_samples : 0);
         if (p.global_prop_step > 0) {
             const int order[4] = { 0, 3, 2, 1 };  // L2R, B2T, R2L, T2B (:481-484)
@@ -339,10 +551,10 @@ int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p) {
                 if (p.global_prop_step >= 2) {
                     const int nsites = (len - 1 + p.global_prop_step - 1) / p.global_prop_step;
                     if (nsites > 0)
-                        hipLaunchKernelGGL(k_global_prop_sites, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream,
-                                           I, dir, p.global_prop_step, nsites);
+                        hipLaunchKernelGGL(k_global_prop_sites<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir,
+                                           p.global_prop_step, nsites);
                 } else
-                    hipLaunchKernelGGL(k_global_prop_serial, dim3((lines + 63) / 64), dim3(64), 0, c->stream, I, dir);
+                    hipLaunchKernelGGL(k_global_prop_serial<NMAX>, dim3((lines + 63) / 64), dim3(64), 0, c->stream, I, dir);
             }
         }
         if (p.local_prop_width > 0) {
@@ -352,18 +564,37 @@ int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p) {
                 const bool rowpass = (dir == 0 || dir == 2);
                 const int len = rowpass ? w : h, lines = rowpass ? h : w;
                 const int nseg = (len + p.local_prop_width - 1) / p.local_prop_width;
-                hipLaunchKernelGGL(k_local_prop, dim3((lines + 63) / 64, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
+                hipLaunchKernelGGL(k_local_prop, dim3((lines + 7) / 8, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
             }
         }
     }
     const int nblk = gpx.x * gpx.y;
-    if (int e = c->rig_partial.reserve(sizeof(float) * (size_t)nblk * MAX_FRAMES)) return e;
-    if (int e = c->cams.reserve(sizeof(CamState) * MAX_FRAMES)) return e;
-    hipLaunchKernelGGL(k_update_rigidness, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
+    hipLaunchKernelGGL(k_update_rigidness<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
     if (p.N > 0)
         hipLaunchKernelGGL(k_reduce_density, dim3(p.N), dim3(256), 0, c->stream, c->rig_partial.as<float>(), nblk, w * h,
                            c->cams.as<CamState>());
     VK_CHECK_LAST();
+    return 0;
+}
+static int optimize_depth_dispatch(Context* c, ImageSet& S, const OdParams& p, bool cost_only) {
+    if (p.N <= 4) return optimize_depth_launch<4>(c, S, p, cost_only);
+    if (p.N <= 6) return optimize_depth_launch<6>(c, S, p, cost_only);  // the SLAM driver's window is 5 flows (voldor_slam.py:85)
+    if (p.N <= 8) return optimize_depth_launch<8>(c, S, p, cost_only);
+    return optimize_depth_launch<16>(c, S, p, cost_only);
+}
+
+int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p) {
+    const int w = p.w, h = p.h;
+    if (int e = S.cost.reserve(sizeof(float) * (size_t)w * h)) return e;
+    if (c->rand_w != w || c->rand_h != h) {  // reference re-inits the RNG when the size changes (:358-361)
+        if (c->rand_w != -1) c->rand_epoch = 0;  // (-1: epoch was set explicitly through vk_set_rand_epoch)
+        c->rand_w = w; c->rand_h = h;
+    }
+    const int nblk = ((w + 63) / 64) * ((h + 3) / 4);
+    if (int e = c->rig_partial.reserve(sizeof(float) * (size_t)nblk * MAX_FRAMES)) return e;
+    if (int e = c->cams.reserve(sizeof(CamState) * MAX_FRAMES)) return e;
+    if (c->prof) prof_begin(c);
+    if (int e = optimize_depth_dispatch(c, S, p, false)) return e;
     if (c->prof) prof_end(c, "optimize_depth");
     return 0;
 }
@@ -371,10 +602,7 @@ int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p) {
 // compute_cost_map alone (tests / parity probes)
 int cost_map_device(Context* c, ImageSet& S, const OdParams& p) {
     if (int e = S.cost.reserve(sizeof(float) * (size_t)p.w * p.h)) return e;
-    Img I = make_img(S, p);
-    hipLaunchKernelGGL(k_cost_rand, dim3((p.w + 63) / 64, (p.h + 3) / 4), dim3(256), 0, c->stream, I, 0, 0u, p.range_factor);
-    VK_CHECK_LAST();
-    return 0;
+    return optimize_depth_dispatch(c, S, p, true);
 }
 
 // ---- small per-pixel helpers used by the host pipeline -------------------------------------

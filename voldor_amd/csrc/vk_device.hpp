@@ -33,48 +33,56 @@ __host__ __device__ __forceinline__ float u01(uint32_t r) {
 // rigidness = p / (p + mu) where p = pdf(err), mu = pdf(lambda * |flow|): c and 1/s cancel:
 //   mu/p = [q_mu / (r_mu (1+q_mu)^2)] * [r (1+q)^2 / q],   q = r^-c = exp2(-c log2 r)
 // so  rigidness = 1 / (1 + mu/p)  and  -log(rigidness) = log(1 + mu/p).
+// Hardware transcendental / reciprocal instructions (1 ulp class): v_log_f32, v_exp_f32, v_rcp_f32,
+// v_sqrt_f32.  The per-pixel chains are latency-bound on dependent VALU work, so the IEEE
+// div/sqrt expansions (10-15 instructions each) are kept out of the residual model.
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+
 struct FiskParams { float c, inv_s; };
 __device__ __forceinline__ FiskParams fisk_params(float fmag) {
     float g = fminf(fmaxf(fmag * 0.5f, 2.f), 100.f);  // residual_model.h:16, :22
     FiskParams p;
     p.c = 1.0f - 0.0022f * g;                          // FISK_B1 + FISK_B2*g
     // s = 0.01*exp(0.09 g)  ->  1/s = 100 * exp2(-0.09*log2(e)*g)
-    p.inv_s = 100.f * exp2f(-0.12984255368000671f * g);
+    p.inv_s = 100.f * fast_exp2(-0.12984255368000671f * g);
     return p;
 }
-// returns t = mu/p given the error magnitude `e` and the strictness magnitude `m` (both
-// already divided by abs_rf).  All quantities stay finite for e,m >= 0.
-__device__ __forceinline__ float fisk_ratio(float e, float m, FiskParams fp) {
-    const float eps = 1.1920929e-07f;  // ZDE = FLT_EPSILON (utils.h:19)
-    float xe = fmaxf(e * 0.5f, eps), xm = fmaxf(m * 0.5f, eps);
-    float r = xe * xe * fp.inv_s, rm = xm * xm * fp.inv_s;
-    float q = exp2f(-fp.c * __log2f(r)), qm = exp2f(-fp.c * __log2f(rm));
-    // mu/p = (qm * r * (1+q)^2) / (q * rm * (1+qm)^2); evaluate as a product of ratios to
-    // keep intermediates in range (q can reach ~1e12 at e -> 0).
-    float a = (1.f + q) / (1.f + qm);
-    return (qm / q) * (r / rm) * a * a;
+// t = mu/p from the SQUARED error magnitude e2 and squared strictness magnitude m2 (both already
+// divided by abs_rf^2).  With l = log2 r, lm = log2 r_mu, q = 2^(-c l), q_mu = 2^(-c lm):
+//   mu/p = (q_mu/q) (r/r_mu) ((1+q)/(1+q_mu))^2 = 2^((c+1)(l-lm)) ((1+q)/(1+q_mu))^2
+// 2 log2 + 3 exp2 + 1 rcp; all quantities stay finite for e2,m2 >= 0 (r >= eps^2/s > 0).
+__device__ __forceinline__ float fisk_ratio_sq(float e2, float m2, FiskParams fp) {
+    const float eps2 = 1.1920929e-07f * 1.1920929e-07f;  // ZDE^2 (utils.h:19), x = max(.5x, ZDE)
+    float re = fmaxf(0.25f * e2, eps2) * fp.inv_s, rm = fmaxf(0.25f * m2, eps2) * fp.inv_s;
+    float l = fast_log2(re), lm = fast_log2(rm);
+    float q = fast_exp2(-fp.c * l), qm = fast_exp2(-fp.c * lm);
+    float a = (1.f + q) * fast_rcp(1.f + qm);
+    return fast_exp2((fp.c + 1.f) * (l - lm)) * a * a;
+}
+__device__ __forceinline__ float flow_ratio(float dx1, float dy1, float dx2, float dy2, float lambda, float inv_arf) {
+    const float ia2 = inv_arf * inv_arf;
+    float obs2 = (dx2 * dx2 + dy2 * dy2) * ia2;
+    float ex = dx1 - dx2, ey = dy1 - dy2;
+    float e2 = (ex * ex + ey * ey) * ia2;
+    return fisk_ratio_sq(e2, lambda * lambda * obs2, fisk_params(fast_sqrt(obs2)));
 }
 __device__ __forceinline__ float rigidness_from_flows(float dx1, float dy1, float dx2, float dy2,
                                                       float lambda, float inv_arf) {
-    float obs = sqrtf(dx2 * dx2 + dy2 * dy2) * inv_arf;
-    float ex = dx1 - dx2, ey = dy1 - dy2;
-    float diff = sqrtf(ex * ex + ey * ey) * inv_arf;
-    float t = fisk_ratio(diff, lambda * obs, fisk_params(obs));
-    return 1.f / (1.f + t);
+    return fast_rcp(1.f + flow_ratio(dx1, dy1, dx2, dy2, lambda, inv_arf));
 }
 // -log(rigidness): cost contribution of one frame (residual_model.h:45-49)
 __device__ __forceinline__ float neglog_rigidness_from_flows(float dx1, float dy1, float dx2, float dy2,
                                                              float lambda, float inv_arf) {
-    float obs = sqrtf(dx2 * dx2 + dy2 * dy2) * inv_arf;
-    float ex = dx1 - dx2, ey = dy1 - dy2;
-    float diff = sqrtf(ex * ex + ey * ey) * inv_arf;
-    float t = fisk_ratio(diff, lambda * obs, fisk_params(obs));
-    return __logf(1.f + t);
+    return 0.6931471805599453f * fast_log2(1.f + flow_ratio(dx1, dy1, dx2, dy2, lambda, inv_arf));
 }
 // depth-prior variant on disparities (residual_model.h:51-68)
 __device__ __forceinline__ float depth_ratio(float d1, float d2, float basefocal, float omega, float inv_arf) {
     float disp1 = (basefocal / d1) * inv_arf, disp2 = (basefocal / d2) * inv_arf;
-    return fisk_ratio(fabsf(disp1 - disp2), omega * disp2, fisk_params(disp2));
+    float dd = disp1 - disp2, om = omega * disp2;
+    return fisk_ratio_sq(dd * dd, om * om, fisk_params(disp2));
 }
 
 // ---- geometry (optimize_depth.cu:54-81) -------------------------------------------------
@@ -97,6 +105,20 @@ __device__ __forceinline__ P3 transform(const float* R, const float* t, P3 o) {
     return { o.x * R[0] + o.y * R[1] + o.z * R[2] + t[0],
              o.x * R[3] + o.y * R[4] + o.z * R[5] + t[1],
              o.x * R[6] + o.y * R[7] + o.z * R[8] + t[2] };
+}
+
+// Hypothesis evaluation (pixel_cost, ~15x per pixel per EM iteration) uses v_rcp_f32 instead of
+// the two IEEE divisions: a 1-ulp change of a sampling position moves a cost by ~1e-7 relative,
+// the same class of difference as the transcendental implementations.
+__device__ __forceinline__ void project_fast(const PoseBlock* P, P3 o, float& px, float& py) {
+    const float iz = fast_rcp(o.z);
+    px = (P->K4[0] * o.x + P->K4[1] * o.z) * iz;
+    py = (P->K4[2] * o.y + P->K4[3] * o.z) * iz;
+}
+__device__ __forceinline__ P3 transform_fast(const float* R, const float* t, P3 o) {
+    return { fmaf(o.x, R[0], fmaf(o.y, R[1], fmaf(o.z, R[2], t[0]))),
+             fmaf(o.x, R[3], fmaf(o.y, R[4], fmaf(o.z, R[5], t[1]))),
+             fmaf(o.x, R[6], fmaf(o.y, R[7], fmaf(o.z, R[8], t[2]))) };
 }
 
 // ---- bilinear fetch, clamp-to-edge per layer, exact fp32 weights ------------------------
@@ -127,11 +149,33 @@ __device__ __forceinline__ float bilinear1(const float* __restrict__ img, int w,
     return w00 * img[k.i00] + w10 * img[k.i10] + w01 * img[k.i01] + w11 * img[k.i11];
 }
 
+__device__ __forceinline__ float2 bilinear2_fast(const float2* __restrict__ img, int w, int h, float x, float y) {
+    BilIdx k = bil_index(x, y, w, h);
+    float2 t00 = img[k.i00], t10 = img[k.i10], t01 = img[k.i01], t11 = img[k.i11];
+    float tx = fmaf(k.a, t10.x - t00.x, t00.x), ty = fmaf(k.a, t10.y - t00.y, t00.y);
+    float bx = fmaf(k.a, t11.x - t01.x, t01.x), by = fmaf(k.a, t11.y - t01.y, t01.y);
+    return make_float2(fmaf(k.b, bx - tx, tx), fmaf(k.b, by - ty, ty));
+}
+
 // ---- wave64 / block reductions ----------------------------------------------------------
+// Sum over the 64 lanes, result in every lane.  Row (16-lane) butterflies run on the VALU through
+// DPP modifiers (quad_perm / row_half_mirror / row_mirror); the four row sums are then combined
+// through v_readlane.  __shfl_xor would go through the LDS crossbar (ds_bpermute): with 28 sums x 16
+// waves per mode-finding iteration that alone cost several microseconds per iteration.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_mov<0x141>(v);  // row_half_mirror
+    v += dpp_mov<0x140>(v);  // row_mirror  -> every lane holds its 16-lane row sum
+    const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+    const float r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+    const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+    const float r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+    return (r0 + r1) + (r2 + r3);
 }
 
 }  // namespace vk

@@ -293,42 +293,188 @@ __device__ static void meanshift_block(const float* __restrict__ space, int N, i
     *o_iters = iters;
 }
 
-// 6x6 (n<=6) inverse + determinant in double by LU with partial pivoting (aux_funs.cpp:101-118:
-// cv::determinant / cv::Matx::inv). Runs on one lane.
-__device__ static double lu_inverse6(const double* A, double* Ainv, int n) {
-    double a[36], b[36];
-    for (int i = 0; i < n * n; i++) { a[i] = A[i]; b[i] = 0.0; }
-    for (int i = 0; i < n; i++) b[i * n + i] = 1.0;
+// n x n (n<=6) inverse + determinant in double by LU with partial pivoting, the algorithm behind
+// cv::determinant / cv::Matx::inv that the reference calls on the host every iteration
+// (aux_funs.cpp:101-118).  Lane r (< n) of ONE wave holds row r of A and of the right-hand side B
+// (starts as I) in registers; pivot columns and pivot rows are broadcast with v_readlane (the
+// source lane is wave-uniform), so there is no LDS or scratch traffic on the critical path.  Within
+// an elimination step every element update is independent, hence each element sees exactly the
+// operation sequence of the serial algorithm: the result is bit-identical to it.
+// Must be called by all 64 lanes of the wave; lanes >= n carry don't-care rows.
+__device__ __forceinline__ double readlane_d(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double lu_inverse_rows(double (&a)[6], double (&b)[6], int n) {
+    const int lane = threadIdx.x & 63;
     double det = 1.0;
-    for (int i = 0; i < n; i++) {
-        int k = i;
-        for (int j = i + 1; j < n; j++) if (fabs(a[j * n + i]) > fabs(a[k * n + i])) k = j;
-        if (fabs(a[k * n + i]) < 2.220446049250313e-16) return 0.0;
-        if (k != i) {
-            for (int j = 0; j < n; j++) {
-                double t = a[i * n + j]; a[i * n + j] = a[k * n + j]; a[k * n + j] = t;
-                t = b[i * n + j]; b[i * n + j] = b[k * n + j]; b[k * n + j] = t;
+    bool singular = false;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        if (i < n && !singular) {
+            int k = i;
+            double best = fabs(readlane_d(a[i], i));
+#pragma unroll
+            for (int j = i + 1; j < 6; j++) {
+                if (j < n) {
+                    const double v = fabs(readlane_d(a[i], j));
+                    if (v > best) { best = v; k = j; }
+                }
             }
-            det = -det;
-        }
-        det *= a[i * n + i];
-        double d = -1.0 / a[i * n + i];
-        for (int j = i + 1; j < n; j++) {
-            double alpha = a[j * n + i] * d;
-            for (int c = i + 1; c < n; c++) a[j * n + c] += alpha * a[i * n + c];
-            for (int c = 0; c < n; c++) b[j * n + c] += alpha * b[i * n + c];
+            if (best < 2.220446049250313e-16) singular = true;
+            else {
+                if (k != i) {  // row swap i <-> k
+#pragma unroll
+                    for (int c = 0; c < 6; c++) {
+                        const double ai = readlane_d(a[c], i), ak = readlane_d(a[c], k);
+                        const double bi = readlane_d(b[c], i), bk = readlane_d(b[c], k);
+                        if (lane == i) { a[c] = ak; b[c] = bk; }
+                        else if (lane == k) { a[c] = ai; b[c] = bi; }
+                    }
+                    det = -det;
+                }
+                const double piv = readlane_d(a[i], i);
+                det *= piv;
+                const double d = -1.0 / piv;
+                const double alpha = a[i] * d;  // own row, column i
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    const double ric = readlane_d(a[c], i), bic = readlane_d(b[c], i);
+                    if (lane > i && lane < n && c < n) {
+                        if (c > i) a[c] += alpha * ric;
+                        b[c] += alpha * bic;
+                    }
+                }
+            }
         }
     }
+    if (singular) return 0.0;
     if (det > 0.0) {
-        for (int i = n - 1; i >= 0; i--)
-            for (int c = 0; c < n; c++) {
-                double s = b[i * n + c];
-                for (int k = i + 1; k < n; k++) s -= a[i * n + k] * b[k * n + c];
-                b[i * n + c] = s / a[i * n + i];
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {  // back substitution, row i lives in lane i
+            if (i < n) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double sacc = b[c];
+#pragma unroll
+                    for (int k = i + 1; k < 6; k++) {
+                        if (k < n) sacc -= a[k] * readlane_d(b[c], k);
+                    }
+                    const double q = sacc / a[i];
+                    if (lane == i && c < n) b[c] = q;
+                }
             }
-        for (int i = 0; i < n * n; i++) Ainv[i] = b[i];
+        }
     }
     return det;
+}
+
+// One robust-Gaussian "prepare" step (fit_robust_gaussian.cu:172-205): packed half -> full, Ledoit-
+// Wolf shrinkage with fixed lambda (aux_funs.cpp:124-141), inverse; writes the (regularised) covariance
+// and its inverse back in packed form.  Called by all lanes of wave 0; returns false when det <= 0.
+__device__ static bool rg_prepare_wave(float* covar_half, float* cinv_half, int dims, bool regularise, float lambda) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane < dims ? lane : 0;
+    double a[6], b[6];
+    double tr = 0;
+#pragma unroll
+    for (int d = 0; d < 6; d++) if (d < dims) tr += (double)covar_half[(d * d + d) / 2 + d];
+    const double m = tr / (double)dims, lam = (double)lambda;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const int hi = r >= c ? r : c, lo = r >= c ? c : r;
+        double full = (c < dims) ? (double)covar_half[(hi * hi + hi) / 2 + lo] : 0.0;
+        if (regularise) full = lam * m * (r == c ? 1.0 : 0.0) + (1 - lam) * full;
+        a[c] = full;
+        b[c] = (r == c) ? 1.0 : 0.0;
+    }
+    double keep[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) keep[c] = a[c];
+    const double det = lu_inverse_rows(a, b, dims);
+    if (det <= 0) return false;
+    if (lane < dims) {
+#pragma unroll
+        for (int c = 0; c < 6; c++) {
+            if (c <= r && c < dims) {
+                covar_half[(r * r + r) / 2 + c] = (float)keep[c];
+                cinv_half[(r * r + r) / 2 + c] = (float)b[c];
+            }
+        }
+    }
+    return true;
+}
+
+// The same prepare step with the matrices in LDS (A, B: 36 doubles each) and one lane per element:
+// a handful of registers instead of ~100, for kernels whose register budget is pinned elsewhere.
+// Element updates are independent within a step -> still bit-identical to the serial LU.
+__device__ __forceinline__ bool rg_prepare_lds(float* covar_half, float* cinv_half, float lambda, bool regularise, double* lds72) {
+    const int n = 6;
+    const int lane = threadIdx.x & 63;
+    const bool act = lane < n * n;
+    const int r = act ? lane / n : 0, c = act ? lane % n : 0;
+    double* A = lds72; double* B = lds72 + 36;
+    {
+        const int hi = r >= c ? r : c, lo = r >= c ? c : r;
+        double full = (double)covar_half[(hi * hi + hi) / 2 + lo];
+        if (regularise) {
+            double tr = 0;
+#pragma unroll 1
+            for (int d = 0; d < n; d++) tr += (double)covar_half[(d * d + d) / 2 + d];
+            const double m = tr / (double)n, lam = (double)lambda;
+            full = lam * m * (r == c ? 1.0 : 0.0) + (1 - lam) * full;
+        }
+        __builtin_amdgcn_wave_barrier();
+        if (act) { A[lane] = full; B[lane] = (r == c) ? 1.0 : 0.0; }
+        if (act && r >= c) covar_half[(r * r + r) / 2 + c] = (float)full;
+        __builtin_amdgcn_wave_barrier();
+    }
+    double det = 1.0;
+    bool ok = true;
+#pragma unroll 1
+    for (int i = 0; i < n && ok; i++) {
+        int k = i;
+        double best = fabs(A[i * n + i]);
+#pragma unroll 1
+        for (int j = i + 1; j < n; j++) {
+            const double v = fabs(A[j * n + i]);
+            if (v > best) { best = v; k = j; }
+        }
+        if (best < 2.220446049250313e-16) { ok = false; break; }
+        if (k != i) {
+            double ta = 0, tb = 0;
+            const int other = (r == i) ? k * n + c : i * n + c;
+            if (act && (r == i || r == k)) { ta = A[other]; tb = B[other]; }
+            __builtin_amdgcn_wave_barrier();
+            if (act && (r == i || r == k)) { A[lane] = ta; B[lane] = tb; }
+            __builtin_amdgcn_wave_barrier();
+            det = -det;
+        }
+        const double piv = A[i * n + i];
+        det *= piv;
+        const double d = -1.0 / piv;
+        if (act && r > i) {
+            const double alpha = A[r * n + i] * d;
+            const double air = A[i * n + c], bir = B[i * n + c];
+            if (c > i) A[lane] += alpha * air;
+            B[lane] += alpha * bir;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!ok || det <= 0.0) return false;
+#pragma unroll 1
+    for (int i = n - 1; i >= 0; i--) {
+        if (act && r == i) {
+            double sacc = B[lane];
+#pragma unroll 1
+            for (int k = i + 1; k < n; k++) sacc -= A[i * n + k] * B[k * n + c];
+            B[lane] = sacc / A[i * n + i];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (act && r >= c) cinv_half[(r * r + r) / 2 + c] = (float)B[lane];
+    return true;
 }
 
 // robust Gaussian on `space[N][dims]`, dims<=6 (fit_robust_gaussian.cu:131-263).
@@ -336,37 +482,16 @@ __device__ static double lu_inverse6(const double* A, double* Ainv, int n) {
 __device__ static bool robust_gaussian_block(const float* __restrict__ space, int N, int dims, float scale, const ModeParams& mp,
                                              float* mean /*LDS[6]*/, float* covar_half /*LDS[21]*/, float* cinv_half /*LDS[21]*/,
                                              BlockRed& br, float* o_density, int* o_iters) {
-    __shared__ int s_flag;  // 0 continue, 1 converged, 2 unreliable
+    __shared__ int s_flag;  // 0 continue, 2 unreliable
     const int tid = threadIdx.x;
     const int dc = (dims * dims + dims) / 2;
     float weight = 0.f;
     int iter = 0;
     bool reliable = true;
     for (iter = 0; iter < mp.rg_max_iters; iter++) {
-        if (tid == 0) {
-            double full[36], inv[36];
-            for (int d1 = 0; d1 < dims; d1++)
-                for (int d2 = 0; d2 <= d1; d2++) {
-                    full[d1 * dims + d2] = (double)covar_half[(d1 * d1 + d1) / 2 + d2];
-                    full[d2 * dims + d1] = full[d1 * dims + d2];
-                }
-            if (iter > 0 && mp.rg_covar_reg_lambda > 0.f) {  // Ledoit-Wolf, fixed lambda (aux_funs.cpp:124-141)
-                double tr = 0;
-                for (int d = 0; d < dims; d++) tr += full[d * dims + d];
-                const double m = tr / (double)dims, lam = (double)mp.rg_covar_reg_lambda;
-                for (int i = 0; i < dims; i++)
-                    for (int j = 0; j < dims; j++) full[i * dims + j] = lam * m * (i == j ? 1.0 : 0.0) + (1 - lam) * full[i * dims + j];
-            }
-            double det = lu_inverse6(full, inv, dims);
-            if (det <= 0) s_flag = 2;
-            else {
-                s_flag = 0;
-                for (int d1 = 0; d1 < dims; d1++)
-                    for (int d2 = 0; d2 <= d1; d2++) {
-                        covar_half[(d1 * d1 + d1) / 2 + d2] = (float)full[d1 * dims + d2];
-                        cinv_half[(d1 * d1 + d1) / 2 + d2] = (float)inv[d1 * dims + d2];
-                    }
-            }
+        if (tid < 64) {
+            const bool ok = rg_prepare_wave(covar_half, cinv_half, dims, iter > 0 && mp.rg_covar_reg_lambda > 0.f, mp.rg_covar_reg_lambda);
+            if (tid == 0) s_flag = ok ? 0 : 2;
         }
         __syncthreads();
         if (s_flag == 2) { reliable = false; break; }
@@ -419,27 +544,235 @@ __device__ static bool robust_gaussian_block(const float* __restrict__ space, in
 }
 
 // ---- the per-camera mode kernel of the device-resident pipeline (voldor/geometry.cpp:156-263)
+// One 1024-thread workgroup; every thread keeps SPT hypotheses (6 floats each) in registers for
+// the whole mean-shift / robust-Gaussian iteration, so an iteration is ~200 VALU ops + one
+// shuffle/LDS all-reduce with a single barrier (the reference does 3 launches + 2 blocking D2H per
+// iteration, meanshift.cu:103-134).  Sample i lives in thread i%1024, slot i/1024.
+constexpr int SPT_MAX = 8;  // 8 * 1024 = 8192 hypotheses (cfg.n_poses_to_sample default)
+struct RedBuf { float w[2][16][28]; float t[2][28]; };
+// All-reduce of NV per-thread partial sums over the workgroup, fixed summation order.  Second stage
+// by NV threads (one value each) + a broadcast read: summing the 16 wave partials of all NV values
+// in every thread would make the compiler batch NV*16 LDS loads into registers (it did: 400+ VGPR
+// spills in the refit kernel).
+template <int NV, int NW = 16>
+__device__ __forceinline__ void allreduce_regs(float* v, RedBuf& rb, int parity) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+        float s = wave_sum(v[k]);
+        if (lane == 0) rb.w[parity][wv][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < NW; j++) s += rb.w[parity][j][threadIdx.x];
+        rb.t[parity][threadIdx.x] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = rb.t[parity][k];  // same address for all lanes: LDS broadcast
+}
+
+// hypotheses -> registers; returns the number of finite ones (geometry.cpp:156-165), rvec pre-scaled (:191)
+template <int THREADS, int SPT>
+__device__ __forceinline__ int load_hypotheses(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses,
+                                               float rvec_scale, float (&x)[SPT][6], unsigned& finmask, int (*s_cnt)[16]) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    finmask = 0;
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        const int i = k * THREADS + tid;
+        bool fin = false;
+#pragma unroll
+        for (int d = 0; d < 6; d++) x[k][d] = 0.f;
+        if (i < n_poses) {
+            float r0 = rvecs[(size_t)i * 3], r1 = rvecs[(size_t)i * 3 + 1], r2 = rvecs[(size_t)i * 3 + 2];
+            float t0 = tvecs[(size_t)i * 3], t1 = tvecs[(size_t)i * 3 + 1], t2 = tvecs[(size_t)i * 3 + 2];
+            fin = isfinite(r0 + r1 + r2 + t0 + t1 + t2);
+            if (fin) { x[k][0] = r0 * rvec_scale; x[k][1] = r1 * rvec_scale; x[k][2] = r2 * rvec_scale; x[k][3] = t0; x[k][4] = t1; x[k][5] = t2; }
+        }
+        const unsigned long long b = __ballot(fin);
+        if (fin) finmask |= 1u << k;
+        if (lane == 0) s_cnt[k][wv] = __popcll(b);
+    }
+    __syncthreads();
+    int used = 0;
+#pragma unroll
+    for (int k = 0; k < SPT; k++)
+#pragma unroll
+        for (int j = 0; j < THREADS / 64; j++) used += s_cnt[k][j];
+    return used;
+}
+
+// geometry.cpp:249-263: unscale, checkRange, write the pose into CamState and the PoseBlock (thread 0)
+__device__ __forceinline__ void finalize_pose(const float* mean6 /*scaled space*/, float rvec_scale, int used, float density, int ms_iters,
+                                              int gu_iters, CamState* cam, PoseBlock* P, int cam_idx) {
+    float pose[6];
+    for (int d = 0; d < 3; d++) pose[d] = mean6[d] / rvec_scale;  // :249
+    for (int d = 3; d < 6; d++) pose[d] = mean6[d];
+    bool ok = true;
+    for (int d = 0; d < 6; d++) ok = ok && isfinite(pose[d]);  // checkRange :256
+    cam->pose_sample_count = used;
+    cam->pose_density = density;
+    cam->last_used_ms_iters = ms_iters;
+    cam->last_used_gu_iters = gu_iters;
+    cam->success = ok ? 1 : 0;
+    if (ok) {
+        for (int d = 0; d < 3; d++) { cam->rvec[d] = pose[d]; cam->t[d] = pose[3 + d]; P->ts[cam_idx][d] = pose[3 + d]; }
+        float R[9];
+        angle_axis_to_rotmat(pose, R);
+        for (int k = 0; k < 9; k++) P->Rs[cam_idx][k] = R[k];
+    }
+}
+
+// mean-shift stage. DEFER=false: also finalises the pose. DEFER=true (robust-Gaussian refit follows,
+// geometry.cpp:201): leaves {mean[6], confidence, iters, used} in `handoff` for k_pose_refit.
+template <bool DEFER>
 __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
-                                                                  float* __restrict__ pool, int n_poses, ModeParams mp,
-                                                                  CamState* cam, PoseBlock* P, int cam_idx,
-                                                                  const int* __restrict__ n_points_dev) {
-    __shared__ BlockRed br;
-    __shared__ float s_mean[16], s_cmean[16], s_rgmean[6], s_cov[21], s_cinv[21];
-    __shared__ int s_wave_cnt[16];
-    __shared__ int s_used;
+                                                                  int n_poses, ModeParams mp, CamState* cam, PoseBlock* P, int cam_idx,
+                                                                  const int* __restrict__ n_points_dev, float* __restrict__ handoff) {
+    __shared__ RedBuf rb;
+    __shared__ int s_cnt[SPT_MAX][16];
+    __shared__ float s_pick[6];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // successive pose? (voldor.cpp:177: pose_sample_count != 0), decided on the device
-    if (mp.use_external_init_mean < 0) mp.use_external_init_mean = cam->pose_sample_count != 0;
-    __syncthreads();
+    const bool external_init = mp.use_external_init_mean < 0 ? (cam->pose_sample_count != 0) : (mp.use_external_init_mean != 0);
     if (*n_points_dev < 4) {  // geometry.cpp:84-88
-        if (tid == 0) cam->success = 0;
+        if (tid == 0) { cam->success = 0; if (DEFER) handoff[8] = 0.f; }
         return;
     }
-    // ordered compaction of the finite hypotheses into pool[used][6], rvec pre-scaled (:156-165,:191)
-    if (tid == 0) s_used = 0;
-    __syncthreads();
-    for (int base = 0; base < n_poses; base += MS_THREADS) {
-        const int i = base + tid;
+    float x[SPT_MAX][6];
+    unsigned finmask;
+    const int used = load_hypotheses<MS_THREADS, SPT_MAX>(rvecs, tvecs, n_poses, mp.rvec_scale, x, finmask, s_cnt);
+    if (used == 0) {
+        if (tid == 0) { cam->success = 0; if (DEFER) handoff[8] = 0.f; }
+        return;
+    }
+    // ---- mean-shift (meanshift.cu:34-150)
+    float io_mean[6], c_mean[6];
+#pragma unroll
+    for (int d = 0; d < 3; d++) { io_mean[d] = cam->rvec[d] * mp.rvec_scale; io_mean[3 + d] = cam->t[d]; }
+    const float inv2v = 1.f / (2.f * mp.kernel_var);
+    int parity = 0;
+    if (external_init) {
+#pragma unroll
+        for (int d = 0; d < 6; d++) c_mean[d] = io_mean[d];
+    } else {  // best of <= max_init_trials random hypotheses (meanshift.cu:72-95), host rand() -> rng3
+        float best = 0.f;
+        float bestx[6] = { 0, 0, 0, 0, 0, 0 };
+        bool have = false;
+        for (int trial = 0; trial < mp.ms_max_init_trials; trial++) {
+            const int target = (int)(rng3(RAND_SEED, (uint32_t)trial, 0x4D53u) % (uint32_t)used);
+            // locate the target-th finite hypothesis in index order (slot-major, then thread)
+            int base = 0;
+#pragma unroll
+            for (int k = 0; k < SPT_MAX; k++) {
+                int wbase = base;
+                for (int j = 0; j < 16; j++) { if (j < wv) wbase += s_cnt[k][j]; base += s_cnt[k][j]; }
+                const unsigned long long b = __ballot((finmask >> k) & 1u);
+                if ((finmask >> k) & 1u) {
+                    int r = wbase + __popcll(b & ((1ull << lane) - 1ull));
+                    if (r == target) {
+#pragma unroll
+                        for (int d = 0; d < 6; d++) s_pick[d] = x[k][d];
+                    }
+                }
+            }
+            __syncthreads();
+            float c[6];
+#pragma unroll
+            for (int d = 0; d < 6; d++) c[d] = s_pick[d];
+            float acc[1] = { 0.f };
+#pragma unroll
+            for (int k = 0; k < SPT_MAX; k++) {
+                if ((finmask >> k) & 1u) {
+                    float l2 = 0.f;
+#pragma unroll
+                    for (int d = 0; d < 6; d++) { float df = x[k][d] - c[d]; l2 += df * df; }
+                    acc[0] += __expf(-l2 * inv2v);
+                }
+            }
+            allreduce_regs<1>(acc, rb, parity); parity ^= 1;
+            if (acc[0] > best) {
+                best = acc[0];
+#pragma unroll
+                for (int d = 0; d < 6; d++) bestx[d] = c[d];
+                have = true;
+            }
+            if (best > mp.ms_good_init_confidence * (float)used) break;
+        }
+        if (!have) {  // no trial had positive weight (the reference would index element -1)
+#pragma unroll
+            for (int d = 0; d < 6; d++) bestx[d] = io_mean[d];
+        }
+#pragma unroll
+        for (int d = 0; d < 6; d++) c_mean[d] = bestx[d];
+    }
+    int ms_iters = 0;
+    float conf = 0.f;
+    for (int iter = 0; iter < mp.ms_max_iters; iter++) {  // meanshift.cu:103-134
+        float acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < SPT_MAX; k++) {
+            if ((finmask >> k) & 1u) {
+                float l2 = 0.f;
+#pragma unroll
+                for (int d = 0; d < 6; d++) { float df = x[k][d] - c_mean[d]; l2 += df * df; }
+                float wgt = __expf(-l2 * inv2v);
+                acc[0] += wgt;
+#pragma unroll
+                for (int d = 0; d < 6; d++) acc[1 + d] += wgt * x[k][d];
+            }
+        }
+        allreduce_regs<7>(acc, rb, parity); parity ^= 1;
+        conf = acc[0] / (float)used;
+        ms_iters = iter + 1;
+        float disp = 0.f;
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            float m = acc[1 + d] / acc[0];
+            disp += (io_mean[d] - m) * (io_mean[d] - m);  // vs. the stale io mean on the first pass (SURVEY B-6)
+            io_mean[d] = m; c_mean[d] = m;
+        }
+        if (sqrtf(disp) < mp.ms_epsilon) break;  // uniform: every thread holds the same totals
+    }
+    if (tid == 0) {
+        if (DEFER) {
+            for (int d = 0; d < 6; d++) handoff[d] = io_mean[d];
+            handoff[6] = conf; handoff[7] = (float)ms_iters; handoff[8] = (float)used;
+        } else
+            finalize_pose(io_mean, mp.rvec_scale, used, conf, ms_iters, cam->last_used_gu_iters, cam, P, cam_idx);
+    }
+}
+
+// robust-Gaussian refit + finalisation (geometry.cpp:201-263, fit_robust_gaussian.cu:131-263); runs
+// on the last EM iteration only, ~30-50 gate/refit iterations per camera.  The 8192 scaled
+// hypotheses stay on chip for the whole loop: coordinates 0-3 in LDS (128 KiB, [dim][sample] so
+// that a wave reads consecutive addresses), coordinates 4-5 in registers.  (All six in registers
+// does not fit the 128-VGPR budget of a 1024-thread workgroup next to the fp64 6x6 inverse; all
+// six in LDS would need 192 KiB.)
+constexpr int RF_THREADS = 1024, RF_SPT = 8, RF_N = RF_THREADS * RF_SPT;
+__global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
+                                                                   int n_poses, ModeParams mp, CamState* cam, PoseBlock* P, int cam_idx,
+                                                                   const float* __restrict__ handoff) {
+#pragma clang fp contract(fast)  // the gate / scatter sums are not part of the solver's exact-rounding contract
+    __shared__ float xs[4][RF_N];
+    __shared__ RedBuf rb;
+    __shared__ int s_cnt[16];
+    __shared__ float s_cinv[21], s_cov[21];
+    __shared__ int s_flag;
+    __shared__ double s_lu[72];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (handoff[8] == 0.f) return;  // the mean-shift stage already reported failure
+    const float sc = mp.rg_pose_scaling;
+    // stage: x = [rvec * rvec_scale | t] * rg_pose_scaling (geometry.cpp:191,211); non-finite -> masked out
+    float xr[RF_SPT][2];
+    unsigned finmask = 0;
+    int mycnt = 0;
+#pragma unroll
+    for (int k = 0; k < RF_SPT; k++) {
+        const int i = k * RF_THREADS + tid;
         float v[6] = { 0, 0, 0, 0, 0, 0 };
         bool fin = false;
         if (i < n_poses) {
@@ -447,81 +780,113 @@ __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __
             v[3] = tvecs[(size_t)i * 3]; v[4] = tvecs[(size_t)i * 3 + 1]; v[5] = tvecs[(size_t)i * 3 + 2];
             fin = isfinite(v[0] + v[1] + v[2] + v[3] + v[4] + v[5]);
         }
-        unsigned long long m = __ballot(fin);
-        if (lane == 0) s_wave_cnt[wv] = __popcll(m);
-        __syncthreads();
-        int off = s_used, tot = 0;
-        for (int k = 0; k < 16; k++) { if (k < wv) off += s_wave_cnt[k]; tot += s_wave_cnt[k]; }
-        if (fin) {
-            int r = off + __popcll(m & ((1ull << lane) - 1ull));
-            float* d = pool + (size_t)r * 6;
-            d[0] = v[0] * mp.rvec_scale; d[1] = v[1] * mp.rvec_scale; d[2] = v[2] * mp.rvec_scale;
-            d[3] = v[3]; d[4] = v[4]; d[5] = v[5];
+        if (fin) { finmask |= 1u << k; mycnt++; }
+        xs[0][i] = fin ? (v[0] * mp.rvec_scale) * sc : 0.f;
+        xs[1][i] = fin ? (v[1] * mp.rvec_scale) * sc : 0.f;
+        xs[2][i] = fin ? (v[2] * mp.rvec_scale) * sc : 0.f;
+        xs[3][i] = fin ? v[3] * sc : 0.f;
+        xr[k][0] = fin ? v[4] * sc : 0.f;
+        xr[k][1] = fin ? v[5] * sc : 0.f;
+    }
+    {
+        int c = mycnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+        if (lane == 0) s_cnt[wv] = c;
+    }
+    if (tid < 21) s_cov[tid] = 0.f;
+    __syncthreads();
+    int used = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) used += s_cnt[j];
+    if (tid < 6) s_cov[(tid * tid + tid) / 2 + tid] = mp.kernel_var * (sc * sc);  // :203-206
+    float rg_mean[6];
+#pragma unroll
+    for (int d = 0; d < 6; d++) rg_mean[d] = handoff[d] * sc;
+    __syncthreads();
+    float weight = 0.f;
+    int iter = 0, parity = 0;
+    bool reliable = true;
+    for (iter = 0; iter < mp.rg_max_iters; iter++) {
+        if (tid < 64) {
+            const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, iter > 0 && mp.rg_covar_reg_lambda > 0.f, s_lu);
+            if (tid == 0) s_flag = ok ? 0 : 2;
         }
         __syncthreads();
-        if (tid == 0) s_used += tot;
-        __syncthreads();
-    }
-    const int used = s_used;
-    if (used == 0) {
-        if (tid == 0) cam->success = 0;
-        return;
-    }
-    __threadfence_block();
-    if (tid < 3) s_mean[tid] = cam->rvec[tid] * mp.rvec_scale;
-    else if (tid < 6) s_mean[tid] = cam->t[tid - 3];
-    __syncthreads();
-    float conf; int ms_iters;
-    meanshift_block(pool, used, 6, mp, s_mean, s_cmean, br, &conf, &ms_iters);
-    float density = conf;
-    int gu_iters = cam->last_used_gu_iters;
-    bool rg_ok = false;
-    if (mp.do_rg) {  // geometry.cpp:201-246
-        const float sc = mp.rg_pose_scaling;
-        if (tid < 6) s_rgmean[tid] = s_mean[tid] * sc;
-        if (tid < 21) s_cov[tid] = 0.f;
-        __syncthreads();
-        if (tid < 6) s_cov[(tid * tid + tid) / 2 + tid] = mp.kernel_var * (sc * sc);
-        __syncthreads();
-        float dens; int it;
-        rg_ok = robust_gaussian_block(pool, used, 6, sc, mp, s_rgmean, s_cov, s_cinv, br, &dens, &it);
-        if (rg_ok) { density = dens; gu_iters = it; }
-        else gu_iters = 0;  // fit_robust_gaussian.cu:158-159 resets *used_iters on entry
-        if (tid == 0) {
-            if (rg_ok) {
-                for (int i1 = 0; i1 < 6; i1++)
-                    for (int i2 = 0; i2 < 6; i2++) {
-                        int hi = i1 >= i2 ? i1 : i2, lo = i1 >= i2 ? i2 : i1;
-                        float c = s_cov[(hi * hi + hi) / 2 + lo] / (sc * sc);
-                        if (i1 < 3 || i2 < 3) c /= mp.rvec_scale;
-                        if (i1 < 3 && i2 < 3) c /= mp.rvec_scale;
-                        cam->covar[i1 * 6 + i2] = c;
+        if (s_flag == 2) { reliable = false; break; }
+        const float prev_density = weight / (float)used;
+        float ci[21];
+#pragma unroll
+        for (int k = 0; k < 21; k++) ci[k] = s_cinv[k];
+        // e_step (fit_robust_gaussian.cu:56-97): gate, weight, weighted sample and weighted scatter about
+        // the CURRENT mean in one pass -> one 28-value all-reduce per iteration
+        float acc[28];
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc[k] = 0.f;
+#pragma unroll
+        for (int k = 0; k < RF_SPT; k++) {
+            if ((finmask >> k) & 1u) {
+                const int i = k * RF_THREADS + tid;
+                const float xv[6] = { xs[0][i], xs[1][i], xs[2][i], xs[3][i], xr[k][0], xr[k][1] };
+                float diff[6];
+#pragma unroll
+                for (int d = 0; d < 6; d++) diff[d] = xv[d] - rg_mean[d];
+                float z = 0.f;
+#pragma unroll
+                for (int d1 = 0; d1 < 6; d1++) {
+                    float tmp = 0.f;
+#pragma unroll
+                    for (int d2 = 0; d2 < 6; d2++) {
+                        const int hi = d1 >= d2 ? d1 : d2, lo = d1 >= d2 ? d2 : d1;
+                        tmp += ci[(hi * hi + hi) / 2 + lo] * diff[d2];
                     }
-                for (int d = 0; d < 6; d++) s_mean[d] = s_rgmean[d] / sc;
-            } else {
-                for (int k = 0; k < 36; k++) cam->covar[k] = 0.f;
-                for (int d = 0; d < 6; d++) s_mean[d] = (s_mean[d] * sc) / sc;  // pose_opm *= sc; /= sc (:210,:238)
+                    z += tmp * diff[d1];
+                }
+                if (sqrtf(z) < mp.rg_trunc_sigma) {
+                    acc[0] += 1.f;
+#pragma unroll
+                    for (int d = 0; d < 6; d++) acc[1 + d] += xv[d];
+#pragma unroll
+                    for (int d1 = 0; d1 < 6; d1++)
+#pragma unroll
+                        for (int d2 = 0; d2 <= d1; d2++) acc[7 + (d1 * d1 + d1) / 2 + d2] += diff[d1] * diff[d2];
+                }
             }
         }
+        allreduce_regs<28>(acc, rb, parity); parity ^= 1;
+        weight = acc[0];
+        if (!isfinite(weight)) { reliable = false; break; }
+        if (fabsf(weight / (float)used - prev_density) < mp.rg_epsilon) { reliable = true; break; }
+        // M-step (:234-246): mean and covariance of the gated set (no -1: it is regularised next)
+#pragma unroll
+        for (int d = 0; d < 6; d++) rg_mean[d] = acc[1 + d] / weight;
+        if (tid == 0) {  // s_cov was last read before the all-reduce barriers
+#pragma unroll
+            for (int k = 0; k < 21; k++) s_cov[k] = acc[7 + k] / weight;
+        }
         __syncthreads();
     }
+    __syncthreads();
     if (tid == 0) {
-        float pose[6];
-        for (int d = 0; d < 3; d++) pose[d] = s_mean[d] / mp.rvec_scale;  // :249
-        for (int d = 3; d < 6; d++) pose[d] = s_mean[d];
-        bool ok = true;
-        for (int d = 0; d < 6; d++) ok = ok && isfinite(pose[d]);  // checkRange :256
-        cam->pose_sample_count = used;
-        cam->pose_density = density;
-        cam->last_used_ms_iters = ms_iters;
-        cam->last_used_gu_iters = gu_iters;
-        cam->success = ok ? 1 : 0;
-        if (ok) {
-            for (int d = 0; d < 3; d++) { cam->rvec[d] = pose[d]; cam->t[d] = pose[3 + d]; P->ts[cam_idx][d] = pose[3 + d]; }
-            float R[9];
-            angle_axis_to_rotmat(pose, R);
-            for (int k = 0; k < 9; k++) P->Rs[cam_idx][k] = R[k];
+        float mean6[6];
+        float density = handoff[6];
+        int gu_iters = 0;  // fit_robust_gaussian.cu:158-159 resets *used_iters on entry
+        if (reliable) {
+            density = weight / (float)used; gu_iters = iter;
+            for (int i1 = 0; i1 < 6; i1++)
+                for (int i2 = 0; i2 < 6; i2++) {
+                    const int hi = i1 >= i2 ? i1 : i2, lo = i1 >= i2 ? i2 : i1;
+                    float c = s_cov[(hi * hi + hi) / 2 + lo] / (sc * sc);  // :224-233
+                    if (i1 < 3 || i2 < 3) c /= mp.rvec_scale;
+                    if (i1 < 3 && i2 < 3) c /= mp.rvec_scale;
+                    cam->covar[i1 * 6 + i2] = c;
+                }
+            for (int d = 0; d < 6; d++) mean6[d] = rg_mean[d] / sc;
+        } else {
+            for (int k = 0; k < 36; k++) cam->covar[k] = 0.f;
+            for (int d = 0; d < 6; d++) mean6[d] = (handoff[d] * sc) / sc;  // pose_opm *= sc; /= sc (:210,:238)
         }
+        finalize_pose(mean6, mp.rvec_scale, used, density, (int)handoff[7], gu_iters, cam, P, cam_idx);
     }
 }
 
@@ -613,9 +978,21 @@ int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, fl
 }
 
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx) {
-    if (int e = c->pool.reserve(sizeof(float) * MAX_POSE_DIMS * (size_t)n_poses)) return e;
-    hipLaunchKernelGGL(k_pose_mode, dim3(1), dim3(MS_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(),
-                       c->pool.as<float>(), n_poses, mp, cam_dev, P, cam_idx, c->n_points.as<int>());
+    if (n_poses > SPT_MAX * MS_THREADS) {
+        fprintf(stderr, "voldor_hip: n_poses_to_sample=%d exceeds the %d hypotheses the mode kernel keeps in registers\n", n_poses,
+                SPT_MAX * MS_THREADS);
+        return (int)hipErrorInvalidValue;
+    }
+    if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
+    float* handoff = c->ms_io.as<float>() + 32;
+    if (mp.do_rg) {
+        hipLaunchKernelGGL(k_pose_mode<true>, dim3(1), dim3(MS_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), handoff);
+        hipLaunchKernelGGL(k_pose_refit, dim3(1), dim3(RF_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp,
+                           cam_dev, P, cam_idx, handoff);
+    } else
+        hipLaunchKernelGGL(k_pose_mode<false>, dim3(1), dim3(MS_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), handoff);
     VK_CHECK_LAST();
     return 0;
 }
