@@ -68,6 +68,8 @@ int vk_last_camera_stats(int* pose_sample_count, float* pose_density, float* pos
                          int* ms_iters, int* gu_iters, int n);
 /* bootstrap pieces (voldor/geometry.cpp:267-332) exposed for parity tests; host pointers */
 int vk_estimate_pose_epipolar(const float* h_flow, const float* h_K, int w, int h, float* h_o_R9, float* h_o_t3);
+/* the GPU bootstrap of the window pipeline on one host flow [h][w][2] (pose + closed-form depth) */
+int vk_bootstrap_gpu(const float* h_flow, const float* h_K, int w, int h, float* h_o_R9, float* h_o_t3, float* h_o_depth);
 int vk_estimate_depth_closed_form(const float* h_flow, const float* h_K, const float* h_R9, const float* h_t3,
                                   int w, int h, float* h_o_depth);
 

@@ -380,6 +380,7 @@ int orc_estimate_pose_epipolar(const float* flow, const float* K, int w, int h, 
             double Et0 = E[0] * x2 + E[3] * y2 + E[6], Et1 = E[1] * x2 + E[4] * y2 + E[7];
             double num = x2 * Ex0 + y2 * Ex1 + Ex2;
             errs[j] = num * num / (Ex0 * Ex0 + Ex1 * Ex1 + Et0 * Et0 + Et1 * Et1);
+            if (!(errs[j] == errs[j])) errs[j] = INFINITY; /* a degenerate hypothesis ranks last */
         }
         qsort(errs, ns, sizeof(double), cmp_double);
         double med = errs[ns / 2];

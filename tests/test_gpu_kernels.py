@@ -292,6 +292,10 @@ def test_bootstrap_pieces(orc, small_scene):
     ok_g, Rg, tg = kernels.estimate_pose_epipolar(small_scene["flows"][0], K)
     assert ok_o and ok_g
     assert np.abs(Ro - Rg).max() < 1e-5 and np.abs(to - tg).max() < 1e-5
+    Rb, tb, db = kernels.bootstrap_gpu(small_scene["flows"][0], K)  # the kernels the window pipeline runs
+    np.testing.assert_array_equal(Rb, Rg)  # same source, fp64, no contraction: identical bits host vs device
+    np.testing.assert_array_equal(tb, tg)
     do = orc.estimate_depth_closed_form(small_scene["flows"][0], K, Ro, to)
+    np.testing.assert_array_equal(db, do)
     dg = kernels.estimate_depth_closed_form(small_scene["flows"][0], K, Ro, to)
     assert np.mean(np.abs(do - dg) <= 1e-3 * np.abs(do)) > 0.99

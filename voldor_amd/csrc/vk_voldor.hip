@@ -189,20 +189,22 @@ struct Voldor {
         return 0;
     }
 
-    // voldor.cpp:164-201
+    // voldor.cpp:164-201.  The reference decides after every camera (on the host) whether to go on; here
+    // all cameras of the iteration are enqueued back to back and the host looks at the per-camera
+    // records once.  That is equivalent: a camera that fails or is skipped truncates the window at
+    // its index, so whatever the speculatively executed later cameras wrote (their own pose slots
+    // only) is never read again.
     int optimize_cameras() {
         const bool allow_trunc = iters_cur > cfg.no_trunc_iters;
-        // rigidness densities were reduced on the device by the last optimize_depth (voldor.cpp:171)
+        const bool rg = cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0);
+        for (int i = 0; i < n_flows; i++)
+            if (int e = optimize_camera_pose(i, rg)) return e;
+        // rigidness densities (reduced on the device by the last optimize_depth, voldor.cpp:171) and results
         VK_CHECK(hipMemcpyAsync(hcams, c->cams.p, sizeof(CamState) * n_flows, hipMemcpyDeviceToHost, c->stream));
         VK_CHECK(hipStreamSynchronize(c->stream));
         for (int i = 0; i < n_flows; i++) {
             int ok = 0;
-            if (!allow_trunc || hcams[i].pose_rigidness_density > cfg.trunc_rigidness_density) {
-                if (int e = optimize_camera_pose(i, cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0))) return e;
-                VK_CHECK(hipMemcpyAsync(&hcams[i], dcams() + i, sizeof(CamState), hipMemcpyDeviceToHost, c->stream));
-                VK_CHECK(hipStreamSynchronize(c->stream));
-                ok = hcams[i].success;
-            }
+            if (!allow_trunc || hcams[i].pose_rigidness_density > cfg.trunc_rigidness_density) ok = hcams[i].success;
             if (!cfg.silent) print_cam(i);
             if (!ok || (allow_trunc && hcams[i].pose_density < cfg.trunc_sample_density)) {
                 if (!cfg.silent) std::cout << "truncated at camera " << i << std::endl;

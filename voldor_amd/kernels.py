@@ -137,6 +137,17 @@ def estimate_pose_epipolar(flow, K):
     return rc == 0, R.reshape(3, 3), t
 
 
+def bootstrap_gpu(flow, K):
+    """GPU bootstrap kernels of the window pipeline (pose by LMedS + closed-form depth)."""
+    flow = f32(flow)
+    h, w, _ = flow.shape
+    R = np.zeros(9, np.float32)
+    t = np.zeros(3, np.float32)
+    d = np.zeros((h, w), np.float32)
+    capi.check(capi.lib().vk_bootstrap_gpu(fp(flow), fp(f32(K).reshape(9)), w, h, fp(R), fp(t), fp(d)), "vk_bootstrap_gpu")
+    return R.reshape(3, 3), t, d
+
+
 def estimate_depth_closed_form(flow, K, R, t):
     flow = f32(flow)
     h, w, _ = flow.shape
