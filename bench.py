@@ -62,25 +62,21 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world)  # backend nccl == RCCL on ROCm
 
     from voldor_amd import capi, pyvoldor, synth
+    from voldor_amd import dist as vdist
 
     lib = capi.lib()
     sc = synth.make_scene(w=W, h=H, n_flows=N_FLOW, fx=FX, fy=FY, cx=CX, cy=CY, seed=233 + rank)
     flows = torch.from_numpy(sc["flows"]).cuda()
     depth = torch.empty(H, W, device="cuda")
     conf = torch.empty(H, W, device="cuda")
-    blk = 1 + 6 * N_FLOW + 36 * N_FLOW
+    blk = vdist.block_len(N_FLOW)
     send = torch.zeros(blk, device="cuda")
     recv = torch.zeros(world * blk, device="cuda")
 
     def step():
         out = pyvoldor.voldor_device(flows, FX, FY, CX, CY, config=CONFIG, depth_out=depth, depth_conf_out=conf)
         if world > 1:  # pose exchange: [n_registered | poses N x 6 | covar N x 36] per rank
-            n = out["n_registered"]
-            host = np.zeros(blk, np.float32)
-            host[0] = n
-            host[1:1 + 6 * n] = out["poses"].reshape(-1)
-            host[1 + 6 * N_FLOW:1 + 6 * N_FLOW + 36 * n] = out["poses_covar"].reshape(-1)
-            send.copy_(torch.from_numpy(host), non_blocking=True)
+            send.copy_(torch.from_numpy(vdist.pack_pose_block(out, N_FLOW)), non_blocking=True)
             dist.all_gather_into_tensor(recv, send)
         return out
 
