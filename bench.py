@@ -111,17 +111,30 @@ def main():
         torch.cuda.synchronize()
         tot, cnt = C.c_double(0), C.c_long(0)
         groups = {}
-        for name in ("optimize_depth", "optimize_camera_pose", "bootstrap"):
+        for name in ("optimize_depth", "optimize_camera_pose", "bootstrap", "k_local_prop"):
             if lib.vk_profile_get(name.encode(), C.byref(tot), C.byref(cnt)) == 0 and cnt.value > 0:
                 groups[name] = {"avg_us": tot.value / cnt.value * 1e3, "calls_per_window": cnt.value / nprof}
         lib.vk_profile_enable(0)
         b_od = W * H * (40 * N_FLOW + 36 * 0 + 12)  # bytes per optimize_depth call
-        if "optimize_depth" in groups:
-            t_s = groups["optimize_depth"]["avg_us"] * 1e-6
-            ach = b_od / t_s / 1e9
-            roof = {"bound": "hbm", "kernel": "optimize_depth kernel group (fb_rows, fb_cols, cost_rand, global_prop x4, local_prop x4, update_rigidness)",
+        # dominant kernel of the path: one local-propagation pass (4 launches per optimize_depth call).
+        # Algorithmic bytes of one pass = every map it must touch once: flows 8N + rigidness 4N + depth and
+        # cost read 8 + written 8  ->  w*h*(12N+16)  (DESIGN.md section 3).
+        b_lp = W * H * (12 * N_FLOW + 16)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = pmc["kernels"]["vk::k_local_prop"]["hbm_bytes_per_launch"]  # PMC pass of the same command, see the file
+        except Exception:
+            pass
+        if "k_local_prop" in groups and "optimize_depth" in groups:
+            t_lp = groups["k_local_prop"]["avg_us"] * 1e-6
+            ach = b_lp / t_lp / 1e9
+            t_od = groups["optimize_depth"]["avg_us"] * 1e-6
+            roof = {"bound": "hbm", "kernel": "vk::k_local_prop (one of the 4 local-propagation passes)",
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                    "algorithmic_bytes": b_od, "avg_us": round(groups["optimize_depth"]["avg_us"], 2), "traffic": None,
+                    "algorithmic_bytes": b_lp, "avg_us": round(groups["k_local_prop"]["avg_us"], 2), "traffic": traffic,
+                    "optimize_depth_group": {"algorithmic_bytes": b_od, "avg_us": round(groups["optimize_depth"]["avg_us"], 2),
+                                             "achieved": round(b_od / t_od / 1e9, 2), "frac": round(b_od / t_od / 1e9 / HBM_PEAK_GBS, 5)},
                     "groups": {k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in groups.items()}}
 
     # ---- CPU baseline: the oracle on the host cores (rank 0, N=1 only, bounded sample) ----

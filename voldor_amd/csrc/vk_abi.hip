@@ -17,6 +17,8 @@ int Context::init(int dev) {
     VK_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     VK_CHECK(hipEventCreate(&ev0));
     VK_CHECK(hipEventCreate(&ev1));
+    VK_CHECK(hipEventCreate(&ev2));
+    VK_CHECK(hipEventCreate(&ev3));
     return 0;
 }
 void Context::destroy() {
@@ -27,8 +29,10 @@ void Context::destroy() {
     for (DevBuf* b : bufs) b->release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
+    if (ev2) (void)hipEventDestroy(ev2);
+    if (ev3) (void)hipEventDestroy(ev3);
     if (stream) (void)hipStreamDestroy(stream);
-    stream = nullptr; ev0 = ev1 = nullptr;
+    stream = nullptr; ev0 = ev1 = ev2 = ev3 = nullptr;
     od.pose_init = cp.pose_init = false;
 }
 
@@ -58,6 +62,18 @@ int prof_end(Context* c, const char* name) {
     VK_CHECK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     ProfEntry& e = c->prof_acc[name];
     e.ms += ms; e.count += 1;
+    return 0;
+}
+
+// inner scope (a run of identical launches inside an outer scope); resolved when the outer scope ends
+int prof_begin_inner(Context* c) { return (int)hipEventRecord(c->ev2, c->stream); }
+int prof_end_inner(Context* c, const char* name, int launches) {
+    VK_CHECK(hipEventRecord(c->ev3, c->stream));
+    VK_CHECK(hipEventSynchronize(c->ev3));
+    float ms = 0.f;
+    VK_CHECK(hipEventElapsedTime(&ms, c->ev2, c->ev3));
+    ProfEntry& e = c->prof_acc[name];
+    e.ms += ms; e.count += launches;
     return 0;
 }
 

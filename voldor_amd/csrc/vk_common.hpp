@@ -144,7 +144,7 @@ struct Context {
     // profiling (off by default): HIP events on ctx.stream around kernel groups
     bool prof = false;
     std::map<std::string, ProfEntry> prof_acc;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // outer / inner scope
     int init(int dev);
     void destroy();
 };
@@ -152,5 +152,7 @@ struct Context {
 Context* default_context();          // lazily created on the current HIP device
 int prof_begin(Context* c);
 int prof_end(Context* c, const char* name);
+int prof_begin_inner(Context* c);
+int prof_end_inner(Context* c, const char* name, int launches);  // accumulates per-launch time
 
 }  // namespace vk

@@ -559,6 +559,7 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
         }
         if (p.local_prop_width > 0) {
             const int order[4] = { 0, 3, 2, 1 };  // (:487-490)
+            if (c->prof) prof_begin_inner(c);
             for (int k = 0; k < 4; k++) {
                 const int dir = order[k];
                 const bool rowpass = (dir == 0 || dir == 2);
@@ -566,6 +567,7 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                 const int nseg = (len + p.local_prop_width - 1) / p.local_prop_width;
                 hipLaunchKernelGGL(k_local_prop, dim3((lines + 7) / 8, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
             }
+            if (c->prof) prof_end_inner(c, "k_local_prop", 4);
         }
     }
     const int nblk = gpx.x * gpx.y;
