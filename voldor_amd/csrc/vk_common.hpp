@@ -130,6 +130,7 @@ struct Context {
     ImageSet od, cp;
     DevBuf fb_scratch;            // forward messages, shared between calls (fb_smooth.h:14-15)
     DevBuf rig_partial;           // per-block rigidness sums -> pose_rigidness_density
+    DevBuf local_tbl;             // [h][w] candidate-cost table of a local propagation pass
     DevBuf p2_map, p3_map;        // [h*w][2], [h*w][3] (collect_p3p_instances.cu:27-34)
     DevBuf blk_counts, blk_offsets;
     DevBuf pts2, pts3;            // compacted correspondences (geometry.cpp:68-80)
