@@ -549,11 +549,12 @@ __device__ static bool robust_gaussian_block(const float* __restrict__ space, in
 // shuffle/LDS all-reduce with a single barrier (the reference does 3 launches + 2 blocking D2H per
 // iteration, meanshift.cu:103-134).  Sample i lives in thread i%1024, slot i/1024.
 constexpr int SPT_MAX = 8;  // 8 * 1024 = 8192 hypotheses (cfg.n_poses_to_sample default)
-struct RedBuf { float w[2][16][28]; float t[2][28]; };
-// All-reduce of NV per-thread partial sums over the workgroup, fixed summation order.  Second stage
-// by NV threads (one value each) + a broadcast read: summing the 16 wave partials of all NV values
-// in every thread would make the compiler batch NV*16 LDS loads into registers (it did: 400+ VGPR
-// spills in the refit kernel).
+struct RedBuf { float w[2][16][28]; };
+// All-reduce of NV per-thread partial sums over the workgroup, fixed summation order, ONE barrier:
+// wave partials -> LDS -> barrier -> in every wave lane k (< NV) sums the NW partials of value k, and the
+// totals are broadcast inside the wave with v_readlane.  (Summing all NV*NW partials in every thread
+// makes the compiler batch NV*NW LDS loads into registers: 400+ VGPR spills in the refit kernel; a
+// second barrier for a shared total costs more than the redundant 16-term sums.)
 template <int NV, int NW = 16>
 __device__ __forceinline__ void allreduce_regs(float* v, RedBuf& rb, int parity) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -563,15 +564,13 @@ __device__ __forceinline__ void allreduce_regs(float* v, RedBuf& rb, int parity)
         if (lane == 0) rb.w[parity][wv][k] = s;
     }
     __syncthreads();
-    if (threadIdx.x < NV) {
-        float s = 0.f;
+    float tot = 0.f;
+    if (lane < NV) {
 #pragma unroll
-        for (int j = 0; j < NW; j++) s += rb.w[parity][j][threadIdx.x];
-        rb.t[parity][threadIdx.x] = s;
+        for (int j = 0; j < NW; j++) tot += rb.w[parity][j][lane];
     }
-    __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = rb.t[parity][k];  // same address for all lanes: LDS broadcast
+    for (int k = 0; k < NV; k++) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), k));
 }
 
 // hypotheses -> registers; returns the number of finite ones (geometry.cpp:156-165), rvec pre-scaled (:191)
