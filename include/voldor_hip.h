@@ -46,6 +46,8 @@ int vk_optimize_depth_gpu(float** h_flows, float** h_rigidnesses, float** h_o_ri
                           float range_factor, int update_rigidness_only);
 /* gblur_gpu (gpu-kernels/gblur.cu:47-72) on host arrays [d][h][w]; ksize 0 = max(ceil(6 sigma),3) */
 int vk_gblur(const float* h_src, float* h_dst, int w, int h, int d, float sigma, int ksize);
+/* fb_smooth (gpu-kernels/fb_smooth.h:72-108) alone: rows then columns, in place on host maps [n_maps][h][w] */
+int vk_fb_smooth(float* h_maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob);
 
 /* ---- B. B-outer ---- */
 int vk_py_voldor_wrapper(const float* flows, const float* disparity, const float* disparity_pconf,

@@ -299,3 +299,20 @@ def test_bootstrap_pieces(orc, small_scene):
     np.testing.assert_array_equal(db, do)
     dg = kernels.estimate_depth_closed_form(small_scene["flows"][0], K, Ro, to)
     assert np.mean(np.abs(do - dg) <= 1e-3 * np.abs(do)) > 0.99
+
+
+@pytest.mark.parametrize("w,h", [(160, 120), (161, 123), (64, 16), (37, 15), (640, 480)])
+def test_fb_smooth_alone_matches_oracle(orc, w, h):
+    """fb_smooth.h:72-108 on its own, sizes that exercise the 16-step register batches, their tails and the
+    unaligned-row path.  The HIP recurrence is the Moebius regrouping of the same step with
+    v_rcp_f32: a few ulp per step, contractive."""
+    from voldor_amd import kernels
+    rng = np.random.default_rng(w * 1000 + h)
+    maps = rng.uniform(0.02, 0.98, (3, h, w)).astype(np.float32)
+    maps[1, :, : w // 2] = 0.999
+    maps[2, h // 3:, :] = 1e-3
+    o = orc.fb_smooth(maps, 0.5, 0.9)
+    rc, g = kernels.fb_smooth_gpu(maps, 0.5, 0.9)
+    assert rc == 0
+    assert np.isfinite(g).all()
+    assert np.abs(o - g).max() < 2e-5

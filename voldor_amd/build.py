@@ -24,7 +24,11 @@ SOURCES = ["vk_abi.hip", "vk_depth.hip", "vk_pose.hip", "vk_bootstrap.hip", "vk_
 PER_FILE_FLAGS = {"vk_pose.hip": ["-ffp-contract=off"], "vk_bootstrap.hip": ["-ffp-contract=off"],
                   "vk_hostcheck.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
-         "-Wno-unused-result"]
+         "-Wno-unused-result",
+         # the SLP vectorizer packs scalar fp32 math into v_pk_* pairs and pays for it with ~30 % extra
+         # v_mov traffic and 2x the registers in the latency-bound per-pixel kernels (k_cost_rand: 3335 ->
+         # 2541 VALU instructions, 151 -> fewer VGPRs without it); results are equal up to fma-contraction choices.
+         "-fno-slp-vectorize"]
 
 
 def _hipcc() -> str:

@@ -347,6 +347,18 @@ int vk_optimize_depth_gpu(float** h_flows, float** h_rigidnesses, float** h_o_ri
 int vk_gblur(const float* h_src, float* h_dst, int w, int h, int d, float sigma, int ksize) {
     return gblur_host(h_src, h_dst, w, h, d, sigma, ksize);
 }
+// fb_smooth (gpu-kernels/fb_smooth.h:72-108) alone, in place on host maps [n_maps][h][w]
+int vk_fb_smooth(float* h_maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob) {
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    const size_t bytes = sizeof(float) * (size_t)n_maps * w * h;
+    if (int e = c->tmp.reserve(bytes)) return e;
+    VK_CHECK(hipMemcpyAsync(c->tmp.p, h_maps, bytes, hipMemcpyHostToDevice, c->stream));
+    if (int e = fb_smooth_device(c, c->tmp.as<float>(), n_maps, w, h, s0_ems_prob, no_change_prob)) return e;
+    VK_CHECK(hipMemcpyAsync(h_maps, c->tmp.p, bytes, hipMemcpyDeviceToHost, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
 // Host copy of the compacted correspondences produced by the last collect call (what the host
 // loop of voldor/geometry.cpp:68-80 builds); returns n_points or a negative error.
 int vk_get_compacted_points(float* h_o_pts2, float* h_o_pts3, int max_points) {

@@ -398,161 +398,167 @@ __global__ static void k_reduce_density(const float* __restrict__ partial, int n
 }
 
 // ---- forward-backward smoothing (fb_smooth.h:26-70) -------------------------------------
-// The recurrences are serial along a line, so the kernels are latency-bound; what matters is that
-// no step of the chain waits on global memory and that the chain itself is short: the
-// normalisation uses v_rcp_f32 (1 ulp) instead of the ~15-instruction IEEE division.
-//
-// Row pass: one workgroup (4 waves) owns 64 rows of one map and walks the columns in 64-wide
-// chunks.  All 256 threads stage the 64x64 tile of the NEXT chunk (16 independent coalesced loads
-// per thread, issued before the compute of the current chunk so the HBM/L2 latency hides under it)
-// while wave 0 runs the 64 row recurrences out of LDS ([64][65] padding: conflict-free column
-// walk).  The reference reads with a row-pitch stride between adjacent lanes instead
-// (fb_smooth.h:27-46, 480*N threads, uncoalesced).
-constexpr int FB_T = 64;
-__device__ __forceinline__ void fb_tile_load(const float* __restrict__ m, int w, int h, int r0, int c0, float (&reg)[16]) {
-    const int col = c0 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+// A line is a serial recurrence, so both passes are bound by (steps per line) x (latency of one
+// step): 640x480xN=5 gives only 2400 row chains / 3200 column chains, a few dozen waves on a 1024-SIMD
+// chip.  What matters is therefore the length of the dependent chain of ONE step.  The reference step
+//     s0 = (x(1-p) + (1-x)p) e0 ;  s1 = (xp + (1-x)(1-p)) e1 ;  x' = s1 / (s0 + s1)
+// is 7 dependent operations.  Both s1 and s0+s1 are affine in x, so the step is the Moebius map
+//     x' = (c1 + c2 x) / (c3 + c4 x)
+// whose coefficients depend on the emission only and are computed OFF the chain; the chain is
+// fma -> v_rcp_f32 -> mul (3 operations).  The regrouping changes rounding by a few ulp per step (the
+// recurrence is contractive, errors do not accumulate); DESIGN.md lists it as deviation D7.
+// The loads of the next 16 steps are issued as one batch ahead of the chain, no step waits on memory.
+constexpr int FB_B = 16;  // steps per register batch
+struct FbCoef { float q, dd, e0p, e0dd, qe0, pqe0, pq, p; };
+__device__ __forceinline__ FbCoef fb_coef(float e0, float p) {
+    FbCoef k;
+    k.p = p; k.q = 1.f - p; k.dd = p - k.q; k.e0p = e0 * p; k.e0dd = e0 * k.dd; k.qe0 = k.q * e0; k.pq = p + k.q; k.pqe0 = k.pq * e0;
+    return k;
+}
+// forward messages (FB_MSG_L2R / T2B): `e` in step order, out[k] = message after step k
+__device__ __forceinline__ void fb_forward_batch(const FbCoef& K, const float (&e)[FB_B], float& x, float (&out)[FB_B]) {
+    float c1[FB_B], c2[FB_B], c3[FB_B], c4[FB_B];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int row = r0 + rg * 16 + k;
-        reg[k] = (row < h && col < w) ? m[(size_t)row * w + col] : 0.5f;
+    for (int k = 0; k < FB_B; k++) { c1[k] = e[k] * K.q; c2[k] = e[k] * K.dd; c3[k] = K.e0p + c1[k]; c4[k] = c2[k] - K.e0dd; }
+#pragma unroll
+    for (int k = 0; k < FB_B; k++) {
+        const float num = fmaf(c2[k], x, c1[k]), den = fmaf(c4[k], x, c3[k]);
+        x = num * fast_rcp(den);
+        out[k] = x;
     }
 }
-__device__ __forceinline__ void fb_tile_to_lds(float (*t)[FB_T + 1], const float (&reg)[16]) {
-    const int col = threadIdx.x & 63, rg = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < 16; k++) t[rg * 16 + k][col] = reg[k];
+__device__ __forceinline__ float fb_forward_step(const FbCoef& K, float e, float x) {
+    const float c1 = e * K.q, c2 = e * K.dd;
+    return fmaf(c2, x, c1) * fast_rcp(fmaf(c2 - K.e0dd, x, K.e0p + c1));
 }
-__device__ __forceinline__ void fb_tile_store(float* __restrict__ m, int w, int h, int r0, int c0, const float (*t)[FB_T + 1]) {
-    const int col = c0 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+// backward messages (FB_MSG_R2L / B2T) fused with the posterior (FB_POSTERIOR): `e`, `F` in step order
+__device__ __forceinline__ void fb_backward_batch(const FbCoef& K, const float (&e)[FB_B], const float (&F)[FB_B], float& x,
+                                                  float (&out)[FB_B]) {
+    float c2[FB_B], c4[FB_B], b[FB_B];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const int row = r0 + rg * 16 + k;
-        if (row < h && col < w) m[(size_t)row * w + col] = t[rg * 16 + k][threadIdx.x & 63];
+    for (int k = 0; k < FB_B; k++) { c2[k] = e[k] * K.p - K.qe0; c4[k] = K.pq * e[k] - K.pqe0; }
+#pragma unroll
+    for (int k = 0; k < FB_B; k++) {
+        const float num = fmaf(c2[k], x, K.qe0), den = fmaf(c4[k], x, K.pqe0);
+        x = num * fast_rcp(den);
+        b[k] = x;
     }
-}
-__global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps, float* __restrict__ fwd, int w, int h,
-                                                         float e0, float p) {
-    __shared__ float tE[2][FB_T][FB_T + 1];
-    __shared__ float tF[2][FB_T][FB_T + 1];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, r0 = blockIdx.x * FB_T;
-    float* m = maps + (size_t)blockIdx.y * w * h;
-    float* fw = fwd + (size_t)blockIdx.y * w * h;
-    const int nchunk = (w + FB_T - 1) / FB_T;
-    const float q = 1.f - p;
-    float regE[16], regF[16];
-    // ---------------- forward messages, FB_MSG_L2R (fb_smooth.h:27-36)
-    float prev = 0.5f;
-    if (wv == 0 && r0 + lane < h) prev = m[(size_t)(r0 + lane) * w];
-    fb_tile_load(m, w, h, r0, 0, regE);
-    fb_tile_to_lds(tE[0], regE);
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ch++) {
-        const int c0 = ch * FB_T, cur = ch & 1;
-        if (ch + 1 < nchunk) fb_tile_load(m, w, h, r0, c0 + FB_T, regE);  // in flight during the chain below
-        if (wv == 0) {
-            const int nc = min(FB_T, w - c0);
-            for (int j = 0; j < nc; j++) {
-                float e1 = tE[cur][lane][j];
-                float s0 = (prev * q + (1.f - prev) * p) * e0;
-                float s1 = (prev * p + (1.f - prev) * q) * e1;
-                prev = s1 * fast_rcp(s0 + s1);
-                tF[0][lane][j] = prev;
-            }
-        }
-        __syncthreads();
-        fb_tile_store(fw, w, h, r0, c0, tF[0]);
-        if (ch + 1 < nchunk) fb_tile_to_lds(tE[cur ^ 1], regE);
-        __syncthreads();
-    }
-    // ---------------- backward messages (:37-46) fused with the posterior (:65-69), written in place
-    prev = 0.5f;
-    if (wv == 0 && r0 + lane < h) prev = m[(size_t)(r0 + lane) * w + (w - 1)];
-    fb_tile_load(m, w, h, r0, (nchunk - 1) * FB_T, regE);
-    fb_tile_load(fw, w, h, r0, (nchunk - 1) * FB_T, regF);
-    fb_tile_to_lds(tE[(nchunk - 1) & 1], regE);
-    fb_tile_to_lds(tF[(nchunk - 1) & 1], regF);
-    __syncthreads();
-    for (int ch = nchunk - 1; ch >= 0; ch--) {
-        const int c0 = ch * FB_T, cur = ch & 1;
-        if (ch > 0) { fb_tile_load(m, w, h, r0, c0 - FB_T, regE); fb_tile_load(fw, w, h, r0, c0 - FB_T, regF); }
-        if (wv == 0) {
-            const int nc = min(FB_T, w - c0);
-            for (int j = nc - 1; j >= 0; j--) {
-                float e1 = tE[cur][lane][j];
-                float s0 = prev * e1 * q + (1.f - prev) * p * e0;
-                float s1 = prev * e1 * p + (1.f - prev) * q * e0;
-                prev = s1 * fast_rcp(s0 + s1);
-                float F = tF[cur][lane][j];
-                float a1 = F * prev, a0 = (1.f - F) * (1.f - prev);
-                tE[cur][lane][j] = a1 * fast_rcp(a0 + a1);
-            }
-        }
-        __syncthreads();
-        fb_tile_store(m, w, h, r0, c0, tE[cur]);
-        if (ch > 0) { fb_tile_to_lds(tE[cur ^ 1], regE); fb_tile_to_lds(tF[cur ^ 1], regF); }
-        __syncthreads();
+#pragma unroll
+    for (int k = 0; k < FB_B; k++) {
+        const float a1 = F[k] * b[k], a0 = (1.f - F[k]) * (1.f - b[k]);
+        out[k] = a1 * fast_rcp(a0 + a1);
     }
 }
-// Column pass: lane = column, naturally coalesced (FB_MSG_T2B/B2T :47-64 + posterior). The loads
-// of the next FB_PF rows are issued as one batch ahead of the dependent chain.
-constexpr int FB_PF = 16;
-__global__ __launch_bounds__(64) static void k_fb_cols(float* __restrict__ maps, float* __restrict__ fwd, int w, int h,
-                                                        float e0, float p) {
-    const int x = blockIdx.x * 64 + threadIdx.x;
-    if (x >= w) return;
-    float* m = maps + (size_t)blockIdx.y * w * h + x;
-    float* fw = fwd + (size_t)blockIdx.y * w * h + x;
-    const float q = 1.f - p;
-    float prev = m[0];
-    float en[FB_PF], Fn[FB_PF];
+__device__ __forceinline__ float fb_backward_step(const FbCoef& K, float e, float F, float& x) {
+    x = fmaf(e * K.p - K.qe0, x, K.qe0) * fast_rcp(fmaf(K.pq * e - K.pqe0, x, K.pqe0));
+    const float a1 = F * x, a0 = (1.f - F) * (1.f - x);
+    return a1 * fast_rcp(a0 + a1);
+}
+
+// Row pass: lane = row, the lane walks its own row in 16-column batches (4 x 16-byte accesses when the
+// row pitch allows it: every 64-byte sector that is touched is used completely; the reference reads one
+// float per lane with the same row stride, fb_smooth.h:27-46).  One wave per workgroup: no barriers.
+template <bool VEC4>
+__device__ __forceinline__ void fb_row_load(const float* __restrict__ rowp, int c0, float (&v)[FB_B]) {
+    if (VEC4) {
 #pragma unroll
-    for (int k = 0; k < FB_PF; k++) en[k] = (k < h) ? m[(size_t)k * w] : 0.5f;
-    for (int i0 = 0; i0 < h; i0 += FB_PF) {
-        float e[FB_PF];
-#pragma unroll
-        for (int k = 0; k < FB_PF; k++) e[k] = en[k];
-#pragma unroll
-        for (int k = 0; k < FB_PF; k++) {  // next batch in flight while this one runs the chain
-            const int i = i0 + FB_PF + k;
-            en[k] = (i < h) ? m[(size_t)i * w] : 0.5f;
+        for (int k = 0; k < FB_B / 4; k++) {
+            const float4 t = *reinterpret_cast<const float4*>(rowp + c0 + 4 * k);
+            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
         }
+    } else {
 #pragma unroll
-        for (int k = 0; k < FB_PF; k++) {
-            if (i0 + k < h) {
-                float s0 = (prev * q + (1.f - prev) * p) * e0;
-                float s1 = (prev * p + (1.f - prev) * q) * e[k];
-                prev = s1 * fast_rcp(s0 + s1);
-                fw[(size_t)(i0 + k) * w] = prev;
-            }
+        for (int k = 0; k < FB_B; k++) v[k] = rowp[c0 + k];
+    }
+}
+template <bool VEC4>
+__device__ __forceinline__ void fb_row_store(float* __restrict__ rowp, int c0, const float (&v)[FB_B]) {
+    if (VEC4) {
+#pragma unroll
+        for (int k = 0; k < FB_B / 4; k++)
+            *reinterpret_cast<float4*>(rowp + c0 + 4 * k) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < FB_B; k++) rowp[c0 + k] = v[k];
+    }
+}
+template <bool VEC4>
+__global__ __launch_bounds__(64) static void k_fb_rows(float* __restrict__ maps, float* __restrict__ fwd, int w, int h, float e0, float p) {
+    const int row = blockIdx.x * 64 + threadIdx.x;
+    if (row >= h) return;
+    float* m = maps + (size_t)blockIdx.y * w * h + (size_t)row * w;
+    float* fw = fwd + (size_t)blockIdx.y * w * h + (size_t)row * w;
+    const FbCoef K = fb_coef(e0, p);
+    const int nfull = w / FB_B;
+    float x = m[0];
+    float en[FB_B], Fn[FB_B], e[FB_B], F[FB_B], out[FB_B];
+    if (nfull > 0) fb_row_load<VEC4>(m, 0, en);
+    for (int b = 0; b < nfull; b++) {
+#pragma unroll
+        for (int k = 0; k < FB_B; k++) e[k] = en[k];
+        if (b + 1 < nfull) fb_row_load<VEC4>(m, (b + 1) * FB_B, en);  // in flight during the chain below
+        fb_forward_batch(K, e, x, out);
+        fb_row_store<VEC4>(fw, b * FB_B, out);
+    }
+    for (int c = nfull * FB_B; c < w; c++) { x = fb_forward_step(K, m[c], x); fw[c] = x; }
+    x = m[w - 1];
+    for (int c = w - 1; c >= nfull * FB_B; c--) m[c] = fb_backward_step(K, m[c], fw[c], x);
+    if (nfull > 0) { fb_row_load<VEC4>(m, (nfull - 1) * FB_B, en); fb_row_load<VEC4>(fw, (nfull - 1) * FB_B, Fn); }
+    for (int b = nfull - 1; b >= 0; b--) {
+#pragma unroll
+        for (int k = 0; k < FB_B; k++) { e[k] = en[FB_B - 1 - k]; F[k] = Fn[FB_B - 1 - k]; }  // step order = descending column
+        if (b > 0) { fb_row_load<VEC4>(m, (b - 1) * FB_B, en); fb_row_load<VEC4>(fw, (b - 1) * FB_B, Fn); }
+        fb_backward_batch(K, e, F, x, out);
+        float o2[FB_B];
+#pragma unroll
+        for (int k = 0; k < FB_B; k++) o2[k] = out[FB_B - 1 - k];
+        fb_row_store<VEC4>(m, b * FB_B, o2);
+    }
+}
+// Column pass: lane = column, every access is a coalesced 256-byte row segment (FB_MSG_T2B/B2T :47-64).
+__global__ __launch_bounds__(64) static void k_fb_cols(float* __restrict__ maps, float* __restrict__ fwd, int w, int h, float e0, float p) {
+    const int col = blockIdx.x * 64 + threadIdx.x;
+    if (col >= w) return;
+    float* m = maps + (size_t)blockIdx.y * w * h + col;
+    float* fw = fwd + (size_t)blockIdx.y * w * h + col;
+    const FbCoef K = fb_coef(e0, p);
+    const int nfull = h / FB_B;
+    float x = m[0];
+    float en[FB_B], Fn[FB_B], e[FB_B], F[FB_B], out[FB_B];
+    if (nfull > 0) {
+#pragma unroll
+        for (int k = 0; k < FB_B; k++) en[k] = m[(size_t)k * w];
+    }
+    for (int b = 0; b < nfull; b++) {
+#pragma unroll
+        for (int k = 0; k < FB_B; k++) e[k] = en[k];
+        if (b + 1 < nfull) {
+#pragma unroll
+            for (int k = 0; k < FB_B; k++) en[k] = m[(size_t)((b + 1) * FB_B + k) * w];
+        }
+        fb_forward_batch(K, e, x, out);
+#pragma unroll
+        for (int k = 0; k < FB_B; k++) fw[(size_t)(b * FB_B + k) * w] = out[k];
+    }
+    for (int r = nfull * FB_B; r < h; r++) { x = fb_forward_step(K, m[(size_t)r * w], x); fw[(size_t)r * w] = x; }
+    x = m[(size_t)(h - 1) * w];
+    for (int r = h - 1; r >= nfull * FB_B; r--) m[(size_t)r * w] = fb_backward_step(K, m[(size_t)r * w], fw[(size_t)r * w], x);
+    if (nfull > 0) {
+#pragma unroll
+        for (int k = 0; k < FB_B; k++) {  // step order = descending row
+            en[k] = m[(size_t)(nfull * FB_B - 1 - k) * w]; Fn[k] = fw[(size_t)(nfull * FB_B - 1 - k) * w];
         }
     }
-    prev = m[(size_t)(h - 1) * w];
+    for (int b = nfull - 1; b >= 0; b--) {
 #pragma unroll
-    for (int k = 0; k < FB_PF; k++) {
-        const int i = h - 1 - k;
-        en[k] = (i >= 0) ? m[(size_t)i * w] : 0.5f;
-        Fn[k] = (i >= 0) ? fw[(size_t)i * w] : 0.5f;
-    }
-    for (int i0 = h - 1; i0 >= 0; i0 -= FB_PF) {
-        float e[FB_PF], F[FB_PF];
+        for (int k = 0; k < FB_B; k++) { e[k] = en[k]; F[k] = Fn[k]; }
+        if (b > 0) {
 #pragma unroll
-        for (int k = 0; k < FB_PF; k++) { e[k] = en[k]; F[k] = Fn[k]; }
-#pragma unroll
-        for (int k = 0; k < FB_PF; k++) {
-            const int i = i0 - FB_PF - k;
-            en[k] = (i >= 0) ? m[(size_t)i * w] : 0.5f;
-            Fn[k] = (i >= 0) ? fw[(size_t)i * w] : 0.5f;
+            for (int k = 0; k < FB_B; k++) { en[k] = m[(size_t)(b * FB_B - 1 - k) * w]; Fn[k] = fw[(size_t)(b * FB_B - 1 - k) * w]; }
         }
+        fb_backward_batch(K, e, F, x, out);
 #pragma unroll
-        for (int k = 0; k < FB_PF; k++) {
-            if (i0 - k >= 0) {
-                float s0 = prev * e[k] * q + (1.f - prev) * p * e0;
-                float s1 = prev * e[k] * p + (1.f - prev) * q * e0;
-                prev = s1 * fast_rcp(s0 + s1);
-                float a1 = F[k] * prev, a0 = (1.f - F[k]) * (1.f - prev);
-                m[(size_t)(i0 - k) * w] = a1 * fast_rcp(a0 + a1);
-            }
-        }
+        for (int k = 0; k < FB_B; k++) m[(size_t)(b * FB_B + FB_B - 1 - k) * w] = out[k];
     }
 }
 
@@ -560,7 +566,9 @@ int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0
     if (n_maps <= 0) return 0;
     if (int e = c->fb_scratch.reserve(sizeof(float) * (size_t)w * h * n_maps)) return e;
     float* fwd = c->fb_scratch.as<float>();
-    hipLaunchKernelGGL(k_fb_rows, dim3((h + 63) / 64, n_maps), dim3(256), 0, c->stream, maps, fwd, w, h, s0_ems_prob, no_change_prob);
+    const bool vec4 = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(maps) % 16) == 0;
+    if (vec4) hipLaunchKernelGGL(k_fb_rows<true>, dim3((h + 63) / 64, n_maps), dim3(64), 0, c->stream, maps, fwd, w, h, s0_ems_prob, no_change_prob);
+    else hipLaunchKernelGGL(k_fb_rows<false>, dim3((h + 63) / 64, n_maps), dim3(64), 0, c->stream, maps, fwd, w, h, s0_ems_prob, no_change_prob);
     hipLaunchKernelGGL(k_fb_cols, dim3((w + 63) / 64, n_maps), dim3(64), 0, c->stream, maps, fwd, w, h, s0_ems_prob, no_change_prob);
     VK_CHECK_LAST();
     return 0;

@@ -120,6 +120,13 @@ def fit_robust_gaussian(space, io_mean, io_covar, trunc_sigma=3.0, covar_reg_lam
     return rc, mean, covar, dens.value, iters.value
 
 
+def fb_smooth_gpu(maps, s0_ems_prob=0.5, no_change_prob=0.9):
+    m = f32(maps).copy()
+    n, h, w = m.shape
+    rc = capi.lib().vk_fb_smooth(fp(m), n, w, h, C.c_float(s0_ems_prob), C.c_float(no_change_prob))
+    return rc, m
+
+
 def gblur_gpu(src, sigma, ksize=0):
     src = f32(src)
     d, h, w = src.shape
