@@ -128,7 +128,6 @@ struct Context {
     // B-inner keeps the reference's two independent caches (optimize_depth.cu vs
     // collect_p3p_instances.cu statics); the B-outer pipeline uses `od` for everything.
     ImageSet od, cp;
-    DevBuf fb_scratch;            // forward messages, shared between calls (fb_smooth.h:14-15)
     DevBuf rig_partial;           // per-block rigidness sums -> pose_rigidness_density
     DevBuf local_tbl;             // [h][w] candidate-cost table of a local propagation pass
     DevBuf p2_map, p3_map;        // [h*w][2], [h*w][3] (collect_p3p_instances.cu:27-34)

@@ -398,178 +398,170 @@ __global__ static void k_reduce_density(const float* __restrict__ partial, int n
 }
 
 // ---- forward-backward smoothing (fb_smooth.h:26-70) -------------------------------------
-// A line is a serial recurrence, so both passes are bound by (steps per line) x (latency of one
-// step): 640x480xN=5 gives only 2400 row chains / 3200 column chains, a few dozen waves on a 1024-SIMD
-// chip.  What matters is therefore the length of the dependent chain of ONE step.  The reference step
-//     s0 = (x(1-p) + (1-x)p) e0 ;  s1 = (xp + (1-x)(1-p)) e1 ;  x' = s1 / (s0 + s1)
-// is 7 dependent operations.  Both s1 and s0+s1 are affine in x, so the step is the Moebius map
-//     x' = (c1 + c2 x) / (c3 + c4 x)
-// whose coefficients depend on the emission only and are computed OFF the chain; the chain is
-// fma -> v_rcp_f32 -> mul (3 operations).  The regrouping changes rounding by a few ulp per step (the
-// recurrence is contractive, errors do not accumulate); DESIGN.md lists it as deviation D7.
-// The loads of the next 16 steps are issued as one batch ahead of the chain, no step waits on memory.
-constexpr int FB_B = 16;  // steps per register batch
-struct FbCoef { float q, dd, e0p, e0dd, qe0, pqe0, pq, p; };
+// A line (row or column) is a serial recurrence of 640 / 480 steps and there are only N*h (N*w) lines:
+// run one lane per line, as the reference does, and the pass is a few dozen waves each walking a ~1300
+// step dependent chain -- 100 us on a chip that is 99 % idle.  Two things remove that:
+//
+// (1) one step is a projective-linear map.  Forward (fb_smooth.h:27-36):
+//         s0 = (x(1-p) + (1-x)p) e0 ;  s1 = (xp + (1-x)(1-p)) e ;  x' = s1 / (s0 + s1)
+//     is  (a1,a0)' = diag(e,e0) T (a1,a0),  x = a1/(a1+a0),  T = [[p,q],[q,p]],  q = 1-p;  backward
+//     (:37-46) is  (b1,b0)' = T diag(e,e0) (b1,b0).  Maps compose, so a line is cut into segments of
+//     <= FB_SEG steps, one LANE per segment: each lane multiplies up the 2x2 matrix of its segment
+//     (all entries positive: no cancellation; renormalised every 8 steps), the segment matrices of a
+//     line are chained through LDS (<= a few dozen 2x2 applications), and every lane then re-walks its
+//     own segment from the now-known incoming message.  Dependent chain: ~2*FB_SEG steps instead of
+//     2*w, on 16x more lanes.
+// (2) the re-walk uses the Moebius form of the step,  x' = (c1 + c2 x) / (c3 + c4 x), whose coefficients
+//     depend on the emission only and sit off the chain: fma -> v_rcp_f32 -> mul.
+//
+// A segment lives in registers (emissions + forward messages), so each map is read once and written
+// once per pass and the forward-message scratch of the reference (fb_smooth.h:14-15) is not needed.
+// Rounding differs from the step-by-step evaluation by a few ulp per step (the recurrence contracts,
+// nothing accumulates): deviation D7 in DESIGN.md, stage parity test_fb_smooth_alone_matches_oracle.
+constexpr int FB_SEG = 40;  // steps per lane (multiple of 4: 16-byte row accesses)
+struct FbCoef { float p, q, dd, e0, e0p, e0dd, qe0, pqe0, pq; };
 __device__ __forceinline__ FbCoef fb_coef(float e0, float p) {
     FbCoef k;
-    k.p = p; k.q = 1.f - p; k.dd = p - k.q; k.e0p = e0 * p; k.e0dd = e0 * k.dd; k.qe0 = k.q * e0; k.pq = p + k.q; k.pqe0 = k.pq * e0;
+    k.p = p; k.q = 1.f - p; k.dd = p - k.q; k.e0 = e0; k.e0p = e0 * p; k.e0dd = e0 * k.dd; k.qe0 = k.q * e0; k.pq = p + k.q;
+    k.pqe0 = k.pq * e0;
     return k;
 }
-// forward messages (FB_MSG_L2R / T2B): `e` in step order, out[k] = message after step k
-__device__ __forceinline__ void fb_forward_batch(const FbCoef& K, const float (&e)[FB_B], float& x, float (&out)[FB_B]) {
-    float c1[FB_B], c2[FB_B], c3[FB_B], c4[FB_B];
+struct FbMat { float a, b, c, d; };  // acts on (x, 1-x): x' = (a x + b (1-x)) / ((a+c) x + (b+d)(1-x))
+__device__ __forceinline__ float fb_apply(const FbMat& M, float x) {
+    const float y = 1.f - x, n1 = M.a * x + M.b * y, n0 = M.c * x + M.d * y;
+    return n1 * fast_rcp(n1 + n0);
+}
+// segment matrices: F = A_{n-1} ... A_0 with A_t = diag(e_t, e0) T ; B = C_0 ... C_{n-1} with C_t = T diag(e_t, e0)
+__device__ __forceinline__ void fb_compose(const FbCoef& K, const float (&e)[FB_SEG], int n, FbMat& F, FbMat& B) {
+    F = { 1.f, 0.f, 0.f, 1.f }; B = { 1.f, 0.f, 0.f, 1.f };
 #pragma unroll
-    for (int k = 0; k < FB_B; k++) { c1[k] = e[k] * K.q; c2[k] = e[k] * K.dd; c3[k] = K.e0p + c1[k]; c4[k] = c2[k] - K.e0dd; }
-#pragma unroll
-    for (int k = 0; k < FB_B; k++) {
-        const float num = fmaf(c2[k], x, c1[k]), den = fmaf(c4[k], x, c3[k]);
-        x = num * fast_rcp(den);
-        out[k] = x;
+    for (int k = 0; k < FB_SEG; k++) {
+        if (k < n) {
+            const float e1 = e[k];
+            const float fa = (K.p * F.a + K.q * F.c) * e1, fb = (K.p * F.b + K.q * F.d) * e1;
+            const float fc = (K.q * F.a + K.p * F.c) * K.e0, fd = (K.q * F.b + K.p * F.d) * K.e0;
+            F = { fa, fb, fc, fd };
+            const float ba = (B.a * K.p + B.b * K.q) * e1, bb = (B.a * K.q + B.b * K.p) * K.e0;
+            const float bc = (B.c * K.p + B.d * K.q) * e1, bd = (B.c * K.q + B.d * K.p) * K.e0;
+            B = { ba, bb, bc, bd };
+            if ((k & 7) == 7) {
+                const float sf = fast_rcp((F.a + F.b) + (F.c + F.d)), sb = fast_rcp((B.a + B.b) + (B.c + B.d));
+                F = { F.a * sf, F.b * sf, F.c * sf, F.d * sf };
+                B = { B.a * sb, B.b * sb, B.c * sb, B.d * sb };
+            }
+        }
     }
 }
-__device__ __forceinline__ float fb_forward_step(const FbCoef& K, float e, float x) {
-    const float c1 = e * K.q, c2 = e * K.dd;
-    return fmaf(c2, x, c1) * fast_rcp(fmaf(c2 - K.e0dd, x, K.e0p + c1));
-}
-// backward messages (FB_MSG_R2L / B2T) fused with the posterior (FB_POSTERIOR): `e`, `F` in step order
-__device__ __forceinline__ void fb_backward_batch(const FbCoef& K, const float (&e)[FB_B], const float (&F)[FB_B], float& x,
-                                                  float (&out)[FB_B]) {
-    float c2[FB_B], c4[FB_B], b[FB_B];
+// re-walk of one segment: forward messages, then backward messages fused with the posterior (:65-69);
+// e[] is overwritten with the smoothed values
+__device__ __forceinline__ void fb_walk(const FbCoef& K, float (&e)[FB_SEG], int n, float xf, float xb) {
+    float Fm[FB_SEG];
 #pragma unroll
-    for (int k = 0; k < FB_B; k++) { c2[k] = e[k] * K.p - K.qe0; c4[k] = K.pq * e[k] - K.pqe0; }
-#pragma unroll
-    for (int k = 0; k < FB_B; k++) {
-        const float num = fmaf(c2[k], x, K.qe0), den = fmaf(c4[k], x, K.pqe0);
-        x = num * fast_rcp(den);
-        b[k] = x;
+    for (int k = 0; k < FB_SEG; k++) {
+        Fm[k] = 0.f;
+        if (k < n) {
+            const float c1 = e[k] * K.q, c2 = e[k] * K.dd;
+            xf = fmaf(c2, xf, c1) * fast_rcp(fmaf(c2 - K.e0dd, xf, K.e0p + c1));
+            Fm[k] = xf;
+        }
     }
 #pragma unroll
-    for (int k = 0; k < FB_B; k++) {
-        const float a1 = F[k] * b[k], a0 = (1.f - F[k]) * (1.f - b[k]);
-        out[k] = a1 * fast_rcp(a0 + a1);
+    for (int k = FB_SEG - 1; k >= 0; k--) {
+        if (k < n) {
+            xb = fmaf(e[k] * K.p - K.qe0, xb, K.qe0) * fast_rcp(fmaf(K.pq * e[k] - K.pqe0, xb, K.pqe0));
+            const float a1 = Fm[k] * xb, a0 = (1.f - Fm[k]) * (1.f - xb);
+            e[k] = a1 * fast_rcp(a0 + a1);
+        }
     }
 }
-__device__ __forceinline__ float fb_backward_step(const FbCoef& K, float e, float F, float& x) {
-    x = fmaf(e * K.p - K.qe0, x, K.qe0) * fast_rcp(fmaf(K.pq * e - K.pqe0, x, K.pqe0));
-    const float a1 = F * x, a0 = (1.f - F) * (1.f - x);
-    return a1 * fast_rcp(a0 + a1);
+// incoming messages of segment `seg` of a line whose segment matrices are sF[i*stride], sB[i*stride], i < S
+__device__ __forceinline__ void fb_incoming(const FbMat* sF, const FbMat* sB, int stride, int seg, int S, float first, float last,
+                                            float& xf, float& xb) {
+    xf = first;  // the chains start from the raw end values (fb_smooth.h:28, :38)
+    for (int i = 0; i < seg; i++) xf = fb_apply(sF[i * stride], xf);
+    xb = last;
+    for (int i = S - 1; i > seg; i--) xb = fb_apply(sB[i * stride], xb);
 }
 
-// Row pass: lane = row, the lane walks its own row in 16-column batches (4 x 16-byte accesses when the
-// row pitch allows it: every 64-byte sector that is touched is used completely; the reference reads one
-// float per lane with the same row stride, fb_smooth.h:27-46).  One wave per workgroup: no barriers.
+// Row pass: thread = (row, segment), segments of a row on adjacent lanes -> a wave reads whole contiguous row
+// pieces (160 bytes per lane).  256 threads = floor(256/S) rows.
 template <bool VEC4>
-__device__ __forceinline__ void fb_row_load(const float* __restrict__ rowp, int c0, float (&v)[FB_B]) {
+__global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps, int w, int h, int S, float e0, float p) {
+    __shared__ FbMat sF[256], sB[256];
+    const int lpb = 256 / S, tid = threadIdx.x;
+    const int ll = tid / S, seg = tid - ll * S, row = blockIdx.x * lpb + ll;
+    const bool live = ll < lpb && row < h;
+    const int c0 = seg * FB_SEG, n = live ? min(FB_SEG, w - c0) : 0;
+    float* m = maps + (size_t)blockIdx.y * w * h + (size_t)(live ? row : 0) * w;
+    const FbCoef K = fb_coef(e0, p);
+    float e[FB_SEG];
     if (VEC4) {
 #pragma unroll
-        for (int k = 0; k < FB_B / 4; k++) {
-            const float4 t = *reinterpret_cast<const float4*>(rowp + c0 + 4 * k);
-            v[4 * k] = t.x; v[4 * k + 1] = t.y; v[4 * k + 2] = t.z; v[4 * k + 3] = t.w;
+        for (int k = 0; k < FB_SEG / 4; k++) {
+            float4 t = make_float4(0.5f, 0.5f, 0.5f, 0.5f);
+            if (4 * k < n) t = *reinterpret_cast<const float4*>(m + c0 + 4 * k);
+            e[4 * k] = t.x; e[4 * k + 1] = t.y; e[4 * k + 2] = t.z; e[4 * k + 3] = t.w;
         }
     } else {
 #pragma unroll
-        for (int k = 0; k < FB_B; k++) v[k] = rowp[c0 + k];
+        for (int k = 0; k < FB_SEG; k++) e[k] = (k < n) ? m[c0 + k] : 0.5f;
     }
-}
-template <bool VEC4>
-__device__ __forceinline__ void fb_row_store(float* __restrict__ rowp, int c0, const float (&v)[FB_B]) {
+    const float first = m[0], last = m[w - 1];
+    FbMat F, B;
+    fb_compose(K, e, n, F, B);
+    sF[tid] = F; sB[tid] = B;
+    __syncthreads();
+    if (!live) return;
+    float xf, xb;
+    fb_incoming(sF + ll * S, sB + ll * S, 1, seg, S, first, last, xf, xb);
+    fb_walk(K, e, n, xf, xb);
     if (VEC4) {
 #pragma unroll
-        for (int k = 0; k < FB_B / 4; k++)
-            *reinterpret_cast<float4*>(rowp + c0 + 4 * k) = make_float4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        for (int k = 0; k < FB_SEG / 4; k++)
+            if (4 * k < n) *reinterpret_cast<float4*>(m + c0 + 4 * k) = make_float4(e[4 * k], e[4 * k + 1], e[4 * k + 2], e[4 * k + 3]);
     } else {
 #pragma unroll
-        for (int k = 0; k < FB_B; k++) rowp[c0 + k] = v[k];
+        for (int k = 0; k < FB_SEG; k++) if (k < n) m[c0 + k] = e[k];
     }
 }
-template <bool VEC4>
-__global__ __launch_bounds__(64) static void k_fb_rows(float* __restrict__ maps, float* __restrict__ fwd, int w, int h, float e0, float p) {
-    const int row = blockIdx.x * 64 + threadIdx.x;
-    if (row >= h) return;
-    float* m = maps + (size_t)blockIdx.y * w * h + (size_t)row * w;
-    float* fw = fwd + (size_t)blockIdx.y * w * h + (size_t)row * w;
+// Column pass: thread = (segment, column); FB_CW adjacent columns share a workgroup, so every access is a
+// contiguous 64-byte row piece and a workgroup is FB_CW * S threads (S <= 64).
+constexpr int FB_CW = 16;
+__global__ __launch_bounds__(1024) static void k_fb_cols(float* __restrict__ maps, int w, int h, int S, float e0, float p) {
+    __shared__ FbMat sF[1024], sB[1024];
+    const int tid = threadIdx.x, seg = tid / FB_CW, cl = tid - seg * FB_CW, col = blockIdx.x * FB_CW + cl;
+    const bool live = col < w;
+    const int r0 = seg * FB_SEG, n = live ? min(FB_SEG, h - r0) : 0;
+    float* m = maps + (size_t)blockIdx.y * w * h + (live ? col : 0);
     const FbCoef K = fb_coef(e0, p);
-    const int nfull = w / FB_B;
-    float x = m[0];
-    float en[FB_B], Fn[FB_B], e[FB_B], F[FB_B], out[FB_B];
-    if (nfull > 0) fb_row_load<VEC4>(m, 0, en);
-    for (int b = 0; b < nfull; b++) {
+    float e[FB_SEG];
 #pragma unroll
-        for (int k = 0; k < FB_B; k++) e[k] = en[k];
-        if (b + 1 < nfull) fb_row_load<VEC4>(m, (b + 1) * FB_B, en);  // in flight during the chain below
-        fb_forward_batch(K, e, x, out);
-        fb_row_store<VEC4>(fw, b * FB_B, out);
-    }
-    for (int c = nfull * FB_B; c < w; c++) { x = fb_forward_step(K, m[c], x); fw[c] = x; }
-    x = m[w - 1];
-    for (int c = w - 1; c >= nfull * FB_B; c--) m[c] = fb_backward_step(K, m[c], fw[c], x);
-    if (nfull > 0) { fb_row_load<VEC4>(m, (nfull - 1) * FB_B, en); fb_row_load<VEC4>(fw, (nfull - 1) * FB_B, Fn); }
-    for (int b = nfull - 1; b >= 0; b--) {
+    for (int k = 0; k < FB_SEG; k++) e[k] = (k < n) ? m[(size_t)(r0 + k) * w] : 0.5f;
+    const float first = m[0], last = m[(size_t)(h - 1) * w];
+    FbMat F, B;
+    fb_compose(K, e, n, F, B);
+    sF[tid] = F; sB[tid] = B;
+    __syncthreads();
+    if (!live) return;
+    float xf, xb;
+    fb_incoming(sF + cl, sB + cl, FB_CW, seg, S, first, last, xf, xb);
+    fb_walk(K, e, n, xf, xb);
 #pragma unroll
-        for (int k = 0; k < FB_B; k++) { e[k] = en[FB_B - 1 - k]; F[k] = Fn[FB_B - 1 - k]; }  // step order = descending column
-        if (b > 0) { fb_row_load<VEC4>(m, (b - 1) * FB_B, en); fb_row_load<VEC4>(fw, (b - 1) * FB_B, Fn); }
-        fb_backward_batch(K, e, F, x, out);
-        float o2[FB_B];
-#pragma unroll
-        for (int k = 0; k < FB_B; k++) o2[k] = out[FB_B - 1 - k];
-        fb_row_store<VEC4>(m, b * FB_B, o2);
-    }
-}
-// Column pass: lane = column, every access is a coalesced 256-byte row segment (FB_MSG_T2B/B2T :47-64).
-__global__ __launch_bounds__(64) static void k_fb_cols(float* __restrict__ maps, float* __restrict__ fwd, int w, int h, float e0, float p) {
-    const int col = blockIdx.x * 64 + threadIdx.x;
-    if (col >= w) return;
-    float* m = maps + (size_t)blockIdx.y * w * h + col;
-    float* fw = fwd + (size_t)blockIdx.y * w * h + col;
-    const FbCoef K = fb_coef(e0, p);
-    const int nfull = h / FB_B;
-    float x = m[0];
-    float en[FB_B], Fn[FB_B], e[FB_B], F[FB_B], out[FB_B];
-    if (nfull > 0) {
-#pragma unroll
-        for (int k = 0; k < FB_B; k++) en[k] = m[(size_t)k * w];
-    }
-    for (int b = 0; b < nfull; b++) {
-#pragma unroll
-        for (int k = 0; k < FB_B; k++) e[k] = en[k];
-        if (b + 1 < nfull) {
-#pragma unroll
-            for (int k = 0; k < FB_B; k++) en[k] = m[(size_t)((b + 1) * FB_B + k) * w];
-        }
-        fb_forward_batch(K, e, x, out);
-#pragma unroll
-        for (int k = 0; k < FB_B; k++) fw[(size_t)(b * FB_B + k) * w] = out[k];
-    }
-    for (int r = nfull * FB_B; r < h; r++) { x = fb_forward_step(K, m[(size_t)r * w], x); fw[(size_t)r * w] = x; }
-    x = m[(size_t)(h - 1) * w];
-    for (int r = h - 1; r >= nfull * FB_B; r--) m[(size_t)r * w] = fb_backward_step(K, m[(size_t)r * w], fw[(size_t)r * w], x);
-    if (nfull > 0) {
-#pragma unroll
-        for (int k = 0; k < FB_B; k++) {  // step order = descending row
-            en[k] = m[(size_t)(nfull * FB_B - 1 - k) * w]; Fn[k] = fw[(size_t)(nfull * FB_B - 1 - k) * w];
-        }
-    }
-    for (int b = nfull - 1; b >= 0; b--) {
-#pragma unroll
-        for (int k = 0; k < FB_B; k++) { e[k] = en[k]; F[k] = Fn[k]; }
-        if (b > 0) {
-#pragma unroll
-            for (int k = 0; k < FB_B; k++) { en[k] = m[(size_t)(b * FB_B - 1 - k) * w]; Fn[k] = fw[(size_t)(b * FB_B - 1 - k) * w]; }
-        }
-        fb_backward_batch(K, e, F, x, out);
-#pragma unroll
-        for (int k = 0; k < FB_B; k++) m[(size_t)(b * FB_B + FB_B - 1 - k) * w] = out[k];
-    }
+    for (int k = 0; k < FB_SEG; k++) if (k < n) m[(size_t)(r0 + k) * w] = e[k];
 }
 
 int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob) {
     if (n_maps <= 0) return 0;
-    if (int e = c->fb_scratch.reserve(sizeof(float) * (size_t)w * h * n_maps)) return e;
-    float* fwd = c->fb_scratch.as<float>();
+    const int Sr = (w + FB_SEG - 1) / FB_SEG, Sc = (h + FB_SEG - 1) / FB_SEG;
+    if (Sr > 256 || Sc * FB_CW > 1024) {
+        fprintf(stderr, "voldor_hip: fb_smooth supports images up to %d x %d\n", 256 * FB_SEG, 1024 / FB_CW * FB_SEG);
+        return (int)hipErrorInvalidValue;
+    }
+    const int lpb = 256 / Sr;
     const bool vec4 = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(maps) % 16) == 0;
-    if (vec4) hipLaunchKernelGGL(k_fb_rows<true>, dim3((h + 63) / 64, n_maps), dim3(64), 0, c->stream, maps, fwd, w, h, s0_ems_prob, no_change_prob);
-    else hipLaunchKernelGGL(k_fb_rows<false>, dim3((h + 63) / 64, n_maps), dim3(64), 0, c->stream, maps, fwd, w, h, s0_ems_prob, no_change_prob);
-    hipLaunchKernelGGL(k_fb_cols, dim3((w + 63) / 64, n_maps), dim3(64), 0, c->stream, maps, fwd, w, h, s0_ems_prob, no_change_prob);
+    if (vec4) hipLaunchKernelGGL(k_fb_rows<true>, dim3((h + lpb - 1) / lpb, n_maps), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob);
+    else hipLaunchKernelGGL(k_fb_rows<false>, dim3((h + lpb - 1) / lpb, n_maps), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob);
+    hipLaunchKernelGGL(k_fb_cols, dim3((w + FB_CW - 1) / FB_CW, n_maps), dim3(FB_CW * Sc), 0, c->stream, maps, w, h, Sc, s0_ems_prob, no_change_prob);
     VK_CHECK_LAST();
     return 0;
 }
