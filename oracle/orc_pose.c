@@ -184,10 +184,11 @@ static void polar_rotation(const float* R9, float* Q9) {
         c[6] = X[1] * X[5] - X[2] * X[4]; c[7] = X[2] * X[3] - X[0] * X[5]; c[8] = X[0] * X[4] - X[1] * X[3];
         double det = X[0] * c[0] + X[1] * c[1] + X[2] * c[2];
         if (!(fabs(det) > 1e-300)) break;
+        const double idet = 1.0 / det;
         double delta = 0;
-        for (int i = 0; i < 9; i++) { Y[i] = 0.5 * (X[i] + c[i] / det); delta += fabs(Y[i] - X[i]); } /* cof/det = X^-T */
+        for (int i = 0; i < 9; i++) { Y[i] = 0.5 * (X[i] + c[i] * idet); delta += fabs(Y[i] - X[i]); } /* cof/det = X^-T */
         memcpy(X, Y, sizeof X);
-        if (delta < 1e-15) break;
+        if (delta < 1e-10) break; /* quadratic convergence: the next step would move X by ~delta^2 */
     }
     for (int i = 0; i < 9; i++) Q9[i] = (float)X[i];
 }

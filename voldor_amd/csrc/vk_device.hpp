@@ -134,11 +134,33 @@ __device__ __forceinline__ BilIdx bil_index(float x, float y, int w, int h) {
     r.i00 = y0 * w + x0; r.i10 = y0 * w + x1; r.i01 = y1 * w + x0; r.i11 = y1 * w + x1;
     return r;
 }
+// Two horizontally adjacent flow texels in ONE 16-byte access (8-byte aligned; gfx950 global loads
+// are alignment-free).  The per-pixel kernels are bound by the number of distinct cache lines their
+// uncoalesced gathers touch per wave instruction, not by bytes: a bilinear fetch is 2 line accesses
+// instead of 4.  Border handling picks the clamped texels out of the pair, so the values are the same
+// as four clamped single-texel fetches.
+struct __attribute__((aligned(8))) TexPair { float ax, ay, bx, by; };
 __device__ __forceinline__ float2 bilinear2(const float2* __restrict__ img, int w, int h, float x, float y) {
 #pragma clang fp contract(off)
-    BilIdx k = bil_index(x, y, w, h);
-    float2 t00 = img[k.i00], t10 = img[k.i10], t01 = img[k.i01], t11 = img[k.i11];
-    float w00 = (1.f - k.a) * (1.f - k.b), w10 = k.a * (1.f - k.b), w01 = (1.f - k.a) * k.b, w11 = k.a * k.b;
+    float fx = floorf(x), fy = floorf(y);
+    const float a = x - fx, b = y - fy;
+    int x0 = (int)fx, y0 = (int)fy;
+    const int x1 = min(max(x0 + 1, 0), w - 1), y1 = min(max(y0 + 1, 0), h - 1);
+    x0 = min(max(x0, 0), w - 1); y0 = min(max(y0, 0), h - 1);
+    float2 t00, t10, t01, t11;
+    if (w >= 2) {
+        const int xb = min(x0, w - 2);
+        const TexPair r0 = *reinterpret_cast<const TexPair*>(img + (y0 * w + xb));
+        const TexPair r1 = *reinterpret_cast<const TexPair*>(img + (y1 * w + xb));
+        const bool lo0 = x0 == xb, lo1 = x1 == xb;
+        t00 = lo0 ? make_float2(r0.ax, r0.ay) : make_float2(r0.bx, r0.by);
+        t10 = lo1 ? make_float2(r0.ax, r0.ay) : make_float2(r0.bx, r0.by);
+        t01 = lo0 ? make_float2(r1.ax, r1.ay) : make_float2(r1.bx, r1.by);
+        t11 = lo1 ? make_float2(r1.ax, r1.ay) : make_float2(r1.bx, r1.by);
+    } else {
+        t00 = img[y0 * w + x0]; t10 = img[y0 * w + x1]; t01 = img[y1 * w + x0]; t11 = img[y1 * w + x1];
+    }
+    float w00 = (1.f - a) * (1.f - b), w10 = a * (1.f - b), w01 = (1.f - a) * b, w11 = a * b;
     return make_float2(w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x,
                        w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y);
 }

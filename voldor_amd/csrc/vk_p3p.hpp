@@ -295,10 +295,11 @@ VK_HD __forceinline__ void nearest_rotation(float* Rf) {
         c[6] = X[1] * X[5] - X[2] * X[4]; c[7] = X[2] * X[3] - X[0] * X[5]; c[8] = X[0] * X[4] - X[1] * X[3];
         double det = X[0] * c[0] + X[1] * c[1] + X[2] * c[2];
         if (!(vk_abs(det) > 1e-300)) break;
+        const double idet = 1.0 / det;
         double delta = 0;
 #pragma unroll
-        for (int i = 0; i < 9; i++) { double y = 0.5 * (X[i] + c[i] / det); delta += vk_abs(y - X[i]); X[i] = y; }
-        if (delta < 1e-15) break;
+        for (int i = 0; i < 9; i++) { double y = 0.5 * (X[i] + c[i] * idet); delta += vk_abs(y - X[i]); X[i] = y; }
+        if (delta < 1e-10) break;  // quadratic convergence: the next step would move X by ~delta^2
     }
 #pragma unroll
     for (int i = 0; i < 9; i++) Rf[i] = (float)X[i];
