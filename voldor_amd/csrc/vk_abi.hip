@@ -196,7 +196,7 @@ static int solve_batch_host(float* h_p3s, float* h_p2s, float* h_o_rvecs, float*
     if (N_pts <= 0 || N_poses <= 0 || !h_K) return (int)hipErrorInvalidValue;
     if (int e = c->pts2.reserve(sizeof(float) * 2 * (size_t)N_pts)) return e;
     if (int e = c->pts3.reserve(sizeof(float) * 3 * (size_t)N_pts)) return e;
-    if (int e = c->n_points.reserve(sizeof(int) * 4)) return e;
+    if (int e = c->ensure_n_points()) return e;
     VK_CHECK(hipMemcpyAsync(c->pts2.p, h_p2s, sizeof(float) * 2 * (size_t)N_pts, hipMemcpyHostToDevice, c->stream));
     VK_CHECK(hipMemcpyAsync(c->pts3.p, h_p3s, sizeof(float) * 3 * (size_t)N_pts, hipMemcpyHostToDevice, c->stream));
     VK_CHECK(hipMemcpyAsync(c->n_points.p, &N_pts, sizeof(int), hipMemcpyHostToDevice, c->stream));

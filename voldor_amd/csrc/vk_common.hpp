@@ -134,6 +134,7 @@ struct Context {
     DevBuf blk_counts, blk_offsets;
     DevBuf pts2, pts3;            // compacted correspondences (geometry.cpp:68-80)
     DevBuf n_points;              // int
+    int n_map_blocks = 0;         // workgroups of the last k_collect launch (length of blk_counts)
     DevBuf rvecs, tvecs;          // [n_poses][3]
     DevBuf pool;                  // [n_poses][dims]
     DevBuf ms_io;                 // small float/int scratch for B-inner meanshift / robust fit
@@ -145,6 +146,7 @@ struct Context {
     bool prof = false;
     std::map<std::string, ProfEntry> prof_acc;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // outer / inner scope
+    int ensure_n_points() { return n_points.reserve(sizeof(int) * 4); }
     int init(int dev);
     void destroy();
 };

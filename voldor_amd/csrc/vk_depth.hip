@@ -62,7 +62,9 @@ __device__ __forceinline__ static float pixel_cost(const Img& I, int px, int py,
     for (int f = 0; f < NMAX; f++) {
         obs[f] = make_float2(0.f, 0.f); wgt[f] = 0.f;
         if (f < I.N) {  // unconditional (clamped) gathers: no divergent branch around the loads
-            obs[f] = bilinear2(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
+            // frame 0 is sampled at the pixel itself: weights (1,0,0,0), the fetch is the texel (and it does not
+            // depend on the depth hypothesis, so it leaves the candidate loops)
+            obs[f] = (f == 0) ? I.flows[pi] : bilinear2(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
             wgt[f] = I.rig[(size_t)f * npx + pi];
         }
     }
@@ -355,7 +357,7 @@ __global__ __launch_bounds__(256) static void k_update_rigidness(Img I, float* _
 #pragma unroll
     for (int f = 0; f < NMAX; f++) {
         obs[f] = make_float2(0.f, 0.f);
-        if (f < I.N) obs[f] = bilinear2(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
+        if (f < I.N) obs[f] = (f == 0) ? I.flows[pi] : bilinear2(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
     }
 #pragma unroll
     for (int f = 0; f < NMAX; f++) {

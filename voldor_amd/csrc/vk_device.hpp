@@ -150,8 +150,10 @@ __device__ __forceinline__ float2 bilinear2(const float2* __restrict__ img, int 
     float2 t00, t10, t01, t11;
     if (w >= 2) {
         const int xb = min(x0, w - 2);
-        const TexPair r0 = *reinterpret_cast<const TexPair*>(img + (y0 * w + xb));
-        const TexPair r1 = *reinterpret_cast<const TexPair*>(img + (y1 * w + xb));
+        // unsigned 32-bit byte offsets from the (wave-uniform) layer base: scalar base + vector offset addressing
+        const char* base = reinterpret_cast<const char*>(img);
+        const TexPair r0 = *reinterpret_cast<const TexPair*>(base + (unsigned)(y0 * w + xb) * 8u);
+        const TexPair r1 = *reinterpret_cast<const TexPair*>(base + (unsigned)(y1 * w + xb) * 8u);
         const bool lo0 = x0 == xb, lo1 = x1 == xb;
         t00 = lo0 ? make_float2(r0.ax, r0.ay) : make_float2(r0.bx, r0.by);
         t10 = lo1 ? make_float2(r0.ax, r0.ay) : make_float2(r0.bx, r0.by);

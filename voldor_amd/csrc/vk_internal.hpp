@@ -25,9 +25,9 @@ int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk
 // vk_pose.hip
 int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
                    float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact);
-int solve_device(Context* c, const float* pts2, const float* pts3, const int* n_pts_dev, float fx, float fy, float cx, float cy,
+int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, float fx, float fy, float cx, float cy,
                  int n_poses, int solver);
-int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver);
+int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev);
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);

@@ -144,35 +144,76 @@ constexpr int DRAW_MAX_TRIES = 256;
 template <int SOLVER, bool FROM_MAP>  // SOLVER: 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>
 __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ pts2, const float* __restrict__ pts3,
                                                       float* __restrict__ rvecs, float* __restrict__ tvecs,
-                                                      const int* __restrict__ n_pts_dev, int npx, float fx, float fy, float cx, float cy,
-                                                      int n_poses) {
+                                                      int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk,
+                                                      CamState* cam, int npx, float fx, float fy, float cx, float cy, int n_poses) {
     const int idx = blockIdx.x * 64 + threadIdx.x;
+    int n_pts;
+    if (FROM_MAP) {
+        // number of valid correspondences = sum of k_collect's per-workgroup counts; every wave adds them up itself
+        // (a few coalesced loads) instead of a separate single-workgroup launch between collect and solve
+        int part = 0;
+        for (int i0 = 0; i0 < nblk; i0 += 64 * 8) {  // 8 independent loads in flight per lane
+            int v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + (int)threadIdx.x; v[u] = i < nblk ? blk_counts[i] : 0; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) part += v[u];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+        n_pts = part;
+        if (idx == 0) { *n_pts_dev = n_pts; if (cam) cam->n_points = n_pts; }
+    } else
+        n_pts = *n_pts_dev;
     if (idx >= n_poses) return;
-    const int n_pts = *n_pts_dev;
     const float qnan = __builtin_nanf("");
     float R[9], t[3];
     bool ok = false;
     if (n_pts >= (FROM_MAP ? 4 : 1)) {
         float yu[4], yv[4], xp[4][3];
         bool drawn = true;
+        int sel[4];
+        if (FROM_MAP) {
+            // Rejection draw over the NaN-marked correspondence map: point k takes the first valid pixel of its
+            // own candidate sequence j = 0,1,2,...  A probe is a random read (one L2/HBM round trip), so the
+            // probes are issued DRAW_BATCH tries x 4 points at a time instead of one dependent read per try;
+            // the selected pixels are the same.
+            constexpr int DRAW_BATCH = 4;
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int i;
-            if (FROM_MAP) {
-                i = -1;
-                for (int j = 0; j < DRAW_MAX_TRIES; j++) {
-                    uint32_t r = rng3(RAND_SEED, (uint32_t)idx, (uint32_t)(k * DRAW_MAX_TRIES + j));
-                    int cand = (int)(((unsigned long long)r * (unsigned long long)npx) >> 32);
-                    if (isfinite(pts2[(size_t)cand * 2])) { i = cand; break; }
-                }
-                if (i < 0) { drawn = false; i = 0; }
-            } else {
+            for (int k = 0; k < 4; k++) sel[k] = -1;
+            for (int j0 = 0; j0 < DRAW_MAX_TRIES; j0 += DRAW_BATCH) {
+                if (sel[0] >= 0 && sel[1] >= 0 && sel[2] >= 0 && sel[3] >= 0) break;
+                int cand[4][DRAW_BATCH];
+                float probe[4][DRAW_BATCH];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int j = 0; j < DRAW_BATCH; j++) {
+                        const uint32_t r = rng3(RAND_SEED, (uint32_t)idx, (uint32_t)(k * DRAW_MAX_TRIES + j0 + j));
+                        cand[k][j] = (int)(((unsigned long long)r * (unsigned long long)npx) >> 32);
+                        probe[k][j] = pts2[(size_t)cand[k][j] * 2];
+                    }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+#pragma unroll
+                    for (int j = 0; j < DRAW_BATCH; j++)
+                        if (sel[k] < 0 && isfinite(probe[k][j])) sel[k] = cand[k][j];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) if (sel[k] < 0) { drawn = false; sel[k] = 0; }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
                 // the reference re-seeds per call, so the pattern depends only on (idx, n_pts)
                 // (solve_batch_lambdatwist.cu:16-19,80-81). u in (0,1]: clamp the one-past-the-end
                 // index the reference can produce.
-                i = (int)(u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)k)) * (float)n_pts);
-                i = min(i, n_pts - 1);
+                int i = (int)(u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)k)) * (float)n_pts);
+                sel[k] = min(i, n_pts - 1);
             }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = sel[k];
             yu[k] = pts2[(size_t)i * 2]; yv[k] = pts2[(size_t)i * 2 + 1];
             xp[k][0] = pts3[(size_t)i * 3]; xp[k][1] = pts3[(size_t)i * 3 + 1]; xp[k][2] = pts3[(size_t)i * 3 + 2];
         }
@@ -939,13 +980,14 @@ int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int activ
     if (int e = c->p3_map.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
     if (int e = c->blk_counts.reserve(sizeof(int) * (size_t)nblk)) return e;
     if (int e = c->blk_offsets.reserve(sizeof(int) * (size_t)nblk)) return e;
-    if (int e = c->n_points.reserve(sizeof(int) * 4)) return e;
+    if (int e = c->ensure_n_points()) return e;
     hipLaunchKernelGGL(k_collect, dim3(nblk), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
                        S.pb(), c->p2_map.as<float>(), c->p3_map.as<float>(), c->blk_counts.as<int>(), N, w, h, active_idx,
                        rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace);
-    hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, c->stream, c->blk_counts.as<int>(), c->blk_offsets.as<int>(), nblk,
-                       c->n_points.as<int>(), cam_dev);
+    c->n_map_blocks = nblk;
     if (compact) {  // the host-pointer API hands the compacted list to its caller (geometry.cpp:68-80)
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, c->stream, c->blk_counts.as<int>(), c->blk_offsets.as<int>(), nblk,
+                           c->n_points.as<int>(), cam_dev);
         if (int e = c->pts2.reserve(sizeof(float) * 2 * (size_t)npx)) return e;
         if (int e = c->pts3.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
         hipLaunchKernelGGL(k_compact, dim3(nblk), dim3(256), 0, c->stream, c->p2_map.as<float>(), c->p3_map.as<float>(),
@@ -956,24 +998,26 @@ int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int activ
 }
 
 template <bool FROM_MAP>
-static int solve_launch(Context* c, const float* pts2, const float* pts3, const int* n_pts_dev, int npx, float fx, float fy, float cx,
-                        float cy, int n_poses, int solver) {
+static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, CamState* cam, int npx, float fx, float fy,
+                        float cx, float cy, int n_poses, int solver) {
     if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     dim3 g((n_poses + 63) / 64), b(64);
     float* rv = c->rvecs.as<float>(); float* tv = c->tvecs.as<float>();
-    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, npx, fx, fy, cx, cy, n_poses);
-    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, npx, fx, fy, cx, cy, n_poses);
-    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, npx, fx, fy, cx, cy, n_poses);
+    const int* bc = c->blk_counts.as<int>(); const int nb = c->n_map_blocks;
+    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses);
+    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses);
+    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses);
     VK_CHECK_LAST();
     return 0;
 }
-int solve_device(Context* c, const float* pts2, const float* pts3, const int* n_pts_dev, float fx, float fy, float cx, float cy,
+int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, float fx, float fy, float cx, float cy,
                  int n_poses, int solver) {
-    return solve_launch<false>(c, pts2, pts3, n_pts_dev, 0, fx, fy, cx, cy, n_poses, solver);
+    return solve_launch<false>(c, pts2, pts3, n_pts_dev, nullptr, 0, fx, fy, cx, cy, n_poses, solver);
 }
-int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver) {
-    return solve_launch<true>(c, c->p2_map.as<float>(), c->p3_map.as<float>(), c->n_points.as<int>(), npx, fx, fy, cx, cy, n_poses, solver);
+int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev) {
+    return solve_launch<true>(c, c->p2_map.as<float>(), c->p3_map.as<float>(), c->n_points.as<int>(), cam_dev, npx, fx, fy, cx, cy, n_poses,
+                              solver);
 }
 
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx) {

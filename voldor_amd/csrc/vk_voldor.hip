@@ -176,7 +176,7 @@ struct Voldor {
             return e;
         // cpu_p3p=1 selects the reference's CPU instantiation lambdatwist_p4p<double,...> (geometry.cpp:112)
         const int solver = cfg.lambdatwist ? (cfg.cpu_p3p ? 2 : 0) : 1;
-        if (int e = solve_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver)) return e;
+        if (int e = solve_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i)) return e;
         ModeParams mp{};
         mp.dims = 6; mp.kernel_var = cfg.meanshift_kernel_var; mp.ms_epsilon = cfg.meanshift_epsilon;
         mp.ms_max_iters = cfg.meanshift_max_iters; mp.ms_max_init_trials = cfg.meanshift_max_init_trials;
