@@ -99,8 +99,9 @@ __device__ __forceinline__ static float pixel_cost(const Img& I, int px, int py,
 // ---- cost map + all random samples, fused (optimize_depth.cu:279-284 + :269-277 x n_rand) ----
 template <int NMAX>
 __global__ __launch_bounds__(256) static void k_cost_rand(Img I, int n_rand, uint32_t epoch0, float range_factor) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
+    const int y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
     if (x >= I.w || y >= I.h) return;
     const int pi = y * I.w + x;
     float d = I.depth[pi];
@@ -128,8 +129,9 @@ __device__ __forceinline__ static void try_depth(const Img& I, int x, int y, flo
 // 1 T2B, 2 R2L, 3 B2T.
 template <int NMAX>
 __global__ __launch_bounds__(256) static void k_global_prop_sites(Img I, int dir, int step, int nsites) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;  // site index along the pass direction
-    const int l = blockIdx.y;                             // line (row for 0/2, column for 1/3)
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int s = (tile % gridDim.x) * blockDim.x + threadIdx.x;  // site index along the pass direction
+    const int l = tile / gridDim.x;                               // line (row for 0/2, column for 1/3)
     if (s >= nsites) return;
     if (dir == 0) { int x = 1 + s * step; try_depth<NMAX>(I, x, l, I.depth[l * I.w + x - 1]); }
     else if (dir == 2) { int x = I.w - 2 - s * step; try_depth<NMAX>(I, x, l, I.depth[l * I.w + x + 1]); }
@@ -261,7 +263,8 @@ __global__ __launch_bounds__(64) static void k_local_serial(Img I, int dir, int 
 // exactly the cost step p evaluates whenever its predecessor was NOT replaced in this pass.
 template <int NMAX>
 __global__ __launch_bounds__(256) static void k_local_table(Img I, int dir, int width, float* __restrict__ tbl) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63), y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
     if (x >= I.w || y >= I.h) return;
     const int w = I.w, h = I.h;
     bool member; int nb;
@@ -282,7 +285,8 @@ __global__ __launch_bounds__(256) static void k_local_table(Img I, int dir, int 
 // (measured replacement rates: ~40 % of the steps in the first EM iteration, ~6 % later).
 __global__ __launch_bounds__(64) static void k_local_runs(Img I, int dir, int width, const float* __restrict__ tbl) {
     const int lane = threadIdx.x, g = lane >> 3, sub = lane & 7;
-    const ChainGeom cg = chain_geom(I.w, I.h, dir, width, blockIdx.x, blockIdx.y);
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);  // (line, segment), segment-major
+    const ChainGeom cg = chain_geom(I.w, I.h, dir, width, tile % gridDim.x, tile / gridDim.x);
     const int n = cg.n;
     if (n <= 0) return;
     const bool has = lane < n;
@@ -325,13 +329,14 @@ __global__ __launch_bounds__(64) static void k_local_runs(Img I, int dir, int wi
 // test of voldor.cpp:171 then needs no D2H of the maps).  Same three-phase structure as pixel_cost.
 template <int NMAX>
 __global__ __launch_bounds__(256) static void k_update_rigidness(Img I, float* __restrict__ partial) {
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
+    const int y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
     const bool live = x < I.w && y < I.h;
     const int w = I.w, h = I.h, npx = w * h, pi = live ? y * w + x : 0;
     const PoseBlock* P = I.P;
     __shared__ float s_part[NMAX][4];
-    const int blk = blockIdx.y * gridDim.x + blockIdx.x, nblk = gridDim.x * gridDim.y;
+    const int blk = tile, nblk = gridDim.x * gridDim.y;
     const float d = live ? I.depth[pi] : 1.f;
     float qx[NMAX], qy[NMAX], rdx[NMAX], rdy[NMAX];
     unsigned valid = 0;
@@ -595,7 +600,9 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
             if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob)) return e;
             if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob)) return e;
         }
+        if (c->prof) prof_begin_inner(c);
         hipLaunchKernelGGL(k_cost_rand<NMAX>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
+        if (c->prof) prof_end_inner(c, "cost_rand", 1);
         c->rand_epoch += (uint32_t)(p.n_rand_samples > 0 ? p.n_rand_samples : 0);
         if (p.global_prop_step > 0) {
             const int order[4] = { 0, 3, 2, 1 };  // L2R, B2T, R2L, T2B (:481-484)

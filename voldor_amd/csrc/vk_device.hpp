@@ -181,6 +181,19 @@ __device__ __forceinline__ float2 bilinear2_fast(const float2* __restrict__ img,
     return make_float2(fmaf(k.b, bx - tx, tx), fmaf(k.b, by - ty, ty));
 }
 
+// ---- XCD-aware workgroup order ---------------------------------------------------------------
+// MI355X dispatches consecutive workgroup ids round-robin over its 8 XCDs, each with a private 4 MB L2.
+// The per-pixel kernels gather from the N flow layers around their own pixel: with the default order every
+// XCD touches every part of every layer (12 MB at 640x480 N=5, 100+ MB at 1080p) and the gathers miss L2.
+// This remap gives XCD k the k-th contiguous eighth of the (row-major) tile list, i.e. a band of image rows,
+// so an L2 only ever sees one band (+ halo) of each layer.  Returns the tile this workgroup should process.
+__device__ __forceinline__ int xcd_band_tile(int bid, int nb) {
+    constexpr int NXCD = 8;
+    const int per = nb / NXCD;
+    if (bid >= per * NXCD) return bid;  // remainder tiles keep their place
+    return (bid % NXCD) * per + bid / NXCD;
+}
+
 // ---- wave64 / block reductions ----------------------------------------------------------
 // Sum over the 64 lanes, result in every lane.  Row (16-lane) butterflies run on the VALU through
 // DPP modifiers (quad_perm / row_half_mirror / row_mirror); the four row sums are then combined

@@ -25,7 +25,8 @@ __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict
                                                          float rig_thresh, float rig_sum_thresh, float min_depth,
                                                          float max_depth, int max_trace) {
     const int npx = w * h;
-    const int pi = blockIdx.x * 256 + threadIdx.x;
+    const int tile = xcd_band_tile(blockIdx.x, gridDim.x);  // XCD k works on the k-th band of rows (vk_device.hpp)
+    const int pi = tile * 256 + threadIdx.x;
     const float qnan = __builtin_nanf("");
     bool valid = false;
     float px = qnan, py = qnan;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict
     unsigned long long m = __ballot(valid);
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
     __syncthreads();
-    if (threadIdx.x == 0) blk_counts[blockIdx.x] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (threadIdx.x == 0) blk_counts[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
 }
 
 // exclusive scan of the per-block counts (single workgroup), total -> *n_points
