@@ -1,0 +1,102 @@
+"""BASELINE.json configs at their FULL sizes, through the B-outer C-ABI (pyvoldor.voldor -> vk_py_voldor_wrapper).
+
+The oracle takes seconds (cfg3) to minutes (cfg5) per window at these sizes, so besides one direct comparison
+(cfg3) the checks are size-independent properties of the estimator: recovery of the analytic ground-truth
+trajectory and depth of scene S, metric scale from the stereo / depth prior, determinism of a window given the
+depth-sampling epoch, agreement of the three P3P back ends, and window truncation.
+Tolerances: rotation 1e-3 rad per north_star where the estimator's own noise allows it (see test_gpu_voldor.py).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+MONO = "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 8"      # voldor_slam.py:153
+STEREO = "--silent --meanshift_kernel_var 0.1 --disp_delta 1 --delta 0.2 --max_iters 8"  # voldor_slam.py:145-151
+
+
+def _gt_unit_scale(sc):
+    gt = sc["poses_gt"].copy()
+    gt[:, 3:] /= np.mean(np.linalg.norm(gt[:, 3:], axis=1))
+    return gt
+
+
+def test_cfg2_mono_640x480_ground_truth_and_determinism():
+    from voldor_amd import pyvoldor, synth, kernels
+    sc = synth.make_scene(w=640, h=480, n_flows=5, fx=320, fy=320, cx=320, cy=240, seed=233)
+    fx, fy, cx, cy = sc["K"]
+    kernels.set_rand_epoch(0)
+    a = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config=MONO)
+    assert a["n_registered"] == 5 and a["depth"].shape == (480, 640)
+    rot, tr = synth.pose_errors(a["poses"], _gt_unit_scale(sc))
+    assert rot.max() < 1.5e-3 and tr.max() < 3e-2, (rot, tr)
+    # depth of the confident pixels against the ray-cast ground truth (monocular scale = 1 / mean |t_gt|)
+    s = 1.0 / np.mean(np.linalg.norm(sc["poses_gt"][:, 3:], axis=1))
+    m = a["depth_conf"] > 0.5
+    ratio = a["depth"][m] / (sc["depth_gt"][m] * s)
+    scale = np.median(ratio)  # the window's own scale estimate carries the ~1 % noise of mean |t|
+    assert m.mean() > 0.5 and abs(scale - 1.0) < 4e-2 and np.median(np.abs(ratio / scale - 1.0)) < 5e-2, (m.mean(), scale)  # flow noise of scene S -> ~2.5 % depth noise
+    # same epoch -> the very same window, bit for bit (counter-based RNG, fixed-order reductions)
+    kernels.set_rand_epoch(0)
+    b = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config=MONO)
+    for k in ("poses", "poses_covar", "depth", "depth_conf"):
+        np.testing.assert_array_equal(a[k], b[k])
+
+
+def test_cfg3_kitti_size_stereo_matches_oracle_and_metric_scale(orc):
+    from voldor_amd import pyvoldor, synth, kernels
+    bf = 0.54 * 718.0
+    sc = synth.make_scene(w=1241, h=376, n_flows=8, fx=718.0, fy=718.0, cx=607.0, cy=185.0, seed=240, basefocal=bf)
+    fx, fy, cx, cy = sc["K"]
+    kernels.set_rand_epoch(0)
+    g = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, basefocal=bf, disparity=sc["disparity"], config=STEREO)
+    assert g["n_registered"] == 8
+    rot, tr = synth.pose_errors(g["poses"], sc["poses_gt"])  # metric: no scale alignment
+    assert rot.max() < 1e-3 and tr.max() < 3e-2, (rot, tr)
+    o = orc.voldor(sc["flows"], fx, fy, cx, cy, basefocal=bf, disparity=sc["disparity"], config=STEREO)
+    assert o["n_registered"] == 8
+    rot, tr = synth.pose_errors(g["poses"], o["poses"])
+    assert rot.max() < 1e-3 and tr.max() < 3e-2, (rot, tr)  # estimator noise floor over 8 iterations + refit
+    m = (g["depth_conf"] > 0.5) & (o["depth_conf"] > 0.5)
+    rel = np.abs(g["depth"][m] - o["depth"][m]) / o["depth"][m]
+    assert np.median(rel) < 1e-2
+
+
+def test_cfg5_1080p_depth_prior_mode_ground_truth():
+    """1920x1080, N_flow=10, 12 EM iterations, depth-prior (RGB-D) initialisation: NMAX=16 kernels, 2 MP maps,
+    fb_smooth with 48 / 27 segments per line."""
+    from voldor_amd import pyvoldor, synth, kernels
+    sc = synth.make_scene(w=1920, h=1080, n_flows=10, fx=1000.0, fy=1000.0, cx=960.0, cy=540.0, seed=241)
+    fx, fy, cx, cy = sc["K"]
+    rng = np.random.default_rng(3)
+    prior = (sc["depth_gt"] * (1 + rng.normal(0, 0.01, sc["depth_gt"].shape))).astype(np.float32)[None]
+    prior[0, :40, :] = 0  # sensor dropout: invalid prior region (target_depth <= 0)
+    pconf = np.full_like(prior, 0.9)
+    ppose = np.zeros((1, 6), np.float32)
+    cfg = "--silent --meanshift_kernel_var 0.1 --delta 0.2 --max_iters 12"
+    kernels.set_rand_epoch(0)
+    g = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, basefocal=500.0, depth_priors=prior, depth_prior_poses=ppose,
+                        depth_prior_pconfs=pconf, config=cfg)
+    assert g["n_registered"] == 10 and g["depth"].shape == (1080, 1920)
+    assert np.isfinite(g["depth"]).all() and np.isfinite(g["poses"]).all()
+    rot, tr = synth.pose_errors(g["poses"], sc["poses_gt"])  # metric scale from the depth prior
+    assert rot.max() < 1e-3 and tr.max() < 3e-2, (rot, tr)
+    m = g["depth_conf"] > 0.5
+    rel = np.abs(g["depth"][m] / sc["depth_gt"][m] - 1.0)
+    assert m.mean() > 0.5 and np.median(rel) < 2e-2
+
+
+def test_cfg1_host_solver_selection_agrees():
+    """cfg1 ("CPU geometry path"): --cpu_p3p 1 selects the reference's host instantiation lambdatwist_p4p<double>
+    (geometry.cpp:112); --lambdatwist 0 selects AP3P.  All three back ends must find the same mode."""
+    from voldor_amd import pyvoldor, synth, kernels
+    sc = synth.make_scene(w=640, h=480, n_flows=5, fx=320, fy=320, cx=320, cy=240, seed=233)
+    fx, fy, cx, cy = sc["K"]
+    outs = []
+    for extra in ("", " --cpu_p3p 1", " --lambdatwist 0"):
+        kernels.set_rand_epoch(0)
+        outs.append(pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config="--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 3" + extra))
+    for o in outs[1:]:
+        assert o["n_registered"] == outs[0]["n_registered"] == 5
+        rot, tr = synth.pose_errors(o["poses"], outs[0]["poses"])
+        assert rot.max() < 1e-3 and tr.max() < 3e-2, (rot, tr)
