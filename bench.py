@@ -36,10 +36,19 @@ import numpy as np
 import torch  # noqa: E402  (first: shares its HIP runtime with libvoldor_hip.so)
 import torch.distributed as dist  # noqa: E402
 
-W, H, N_FLOW, EM_ITERS = 640, 480, 5, 8
-FX = FY = 320.0
-CX, CY = 320.0, 240.0
-CONFIG = f"--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters {EM_ITERS}"  # mono mode of voldor_slam.py:153
+# BASELINE.json configs; cfg2 (configs[1]) is the one the metric is quoted on and the default.  cfg3 / cfg5 are extra
+# measurement points (--workload), never the headline value.
+WORKLOADS = {
+    "cfg2": dict(w=640, h=480, n=5, iters=8, fx=320.0, cx=320.0, cy=240.0, mode="mono",
+                 cfg="--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 8",  # mono mode of voldor_slam.py:153
+                 name="BASELINE cfg2: 640x480, N_flow=5, monocular, 8 EM iterations"),
+    "cfg3": dict(w=1241, h=376, n=8, iters=8, fx=718.0, cx=607.0, cy=185.0, mode="stereo",
+                 cfg="--silent --meanshift_kernel_var 0.1 --disp_delta 1 --delta 0.2 --max_iters 8",  # stereo mode, voldor_slam.py:145-151
+                 name="BASELINE cfg3: 1241x376, N_flow=8, stereo disparity prior, 8 EM iterations"),
+    "cfg5": dict(w=1920, h=1080, n=10, iters=12, fx=1000.0, cx=960.0, cy=540.0, mode="rgbd",
+                 cfg="--silent --meanshift_kernel_var 0.1 --delta 0.2 --max_iters 12",
+                 name="BASELINE cfg5: 1920x1080, N_flow=10, depth-prior (RGB-D) init, 12 EM iterations"),
+}
 HBM_PEAK_GBS = 8000.0
 
 
@@ -50,7 +59,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-windows", type=int, default=2)
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    W, H, N_FLOW, EM_ITERS = wl["w"], wl["h"], wl["n"], wl["iters"]
+    FX = FY = wl["fx"]
+    CX, CY = wl["cx"], wl["cy"]
+    CONFIG = wl["cfg"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -67,8 +82,17 @@ def main():
     from voldor_amd import dist as vdist
 
     lib = capi.lib()
-    sc = synth.make_scene(w=W, h=H, n_flows=N_FLOW, fx=FX, fy=FY, cx=CX, cy=CY, seed=233 + rank)
+    basefocal = 0.54 * FX if wl["mode"] != "mono" else 0.0
+    sc = synth.make_scene(w=W, h=H, n_flows=N_FLOW, fx=FX, fy=FY, cx=CX, cy=CY, seed=233 + rank, basefocal=basefocal)
     flows = torch.from_numpy(sc["flows"]).cuda()
+    extra = {}
+    if wl["mode"] == "stereo":
+        extra = dict(basefocal=basefocal, disparity=torch.from_numpy(sc["disparity"]).cuda())
+    elif wl["mode"] == "rgbd":
+        prior = (sc["depth_gt"] * (1 + np.random.default_rng(3).normal(0, 0.01, sc["depth_gt"].shape))).astype(np.float32)[None]
+        extra = dict(basefocal=basefocal, depth_priors=torch.from_numpy(prior).cuda(), depth_prior_poses=np.zeros((1, 6), np.float32),
+                     depth_prior_pconfs=torch.full((1, H, W), 0.9, device="cuda"))
+    n_dp = {"mono": 0, "stereo": 1, "rgbd": 1}[wl["mode"]]
     depth = torch.empty(H, W, device="cuda")
     conf = torch.empty(H, W, device="cuda")
     blk = vdist.block_len(N_FLOW)
@@ -76,7 +100,7 @@ def main():
     recv = torch.zeros(world * blk, device="cuda")
 
     def step():
-        out = pyvoldor.voldor_device(flows, FX, FY, CX, CY, config=CONFIG, depth_out=depth, depth_conf_out=conf)
+        out = pyvoldor.voldor_device(flows, FX, FY, CX, CY, config=CONFIG, depth_out=depth, depth_conf_out=conf, **extra)
         if world > 1:  # pose exchange: [n_registered | poses N x 6 | covar N x 36] per rank
             send.copy_(torch.from_numpy(vdist.pack_pose_block(out, N_FLOW)), non_blocking=True)
             dist.all_gather_into_tensor(recv, send)
@@ -117,13 +141,14 @@ def main():
             if lib.vk_profile_get(name.encode(), C.byref(tot), C.byref(cnt)) == 0 and cnt.value > 0:
                 groups[name] = {"avg_us": tot.value / cnt.value * 1e3, "calls_per_window": cnt.value / nprof}
         lib.vk_profile_enable(0)
-        b_od = W * H * (40 * N_FLOW + 36 * 0 + 12)  # bytes per optimize_depth call
+        b_od = W * H * (40 * N_FLOW + 36 * n_dp + 12)  # bytes per optimize_depth call
         # Dominant streaming kernel of the path: k_cost_rand (cost map + 10 random depth hypotheses per pixel, one launch
         # per optimize_depth call).  Algorithmic bytes of one launch = every map it must touch once: flows 8N + rigidness
         # 4N read, depth and cost read 8 + written 8  ->  w*h*(12N+16)  (DESIGN.md section 3).
-        b_cr = W * H * (12 * N_FLOW + 16)
+        b_cr = W * H * (12 * N_FLOW + 12 * n_dp + 16)
         traffic = None
         try:
+            if args.workload != "cfg2": raise KeyError("PMC traffic was collected on cfg2 only")
             pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
             ks = pmc["kernels"]
             traffic = sum(ks[k]["hbm_bytes_per_launch"] for k in ks if "k_cost_rand" in k) or None
@@ -151,25 +176,26 @@ def main():
             orc.voldor(sc["flows"][:, :60, :80].copy(), 40.0, 40.0, 40.0, 30.0, config="--silent --max_iters 1")  # warm-up
             t0 = time.perf_counter()
             for _ in range(args.cpu_windows):
-                ref = orc.voldor(sc["flows"], FX, FY, CX, CY, config=CONFIG)
+                ref = orc.voldor(sc["flows"], FX, FY, CX, CY, config=CONFIG,
+                                 **{k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in extra.items()})
             tc = time.perf_counter() - t0
             rot, tr = synth.pose_errors(out["poses"], ref["poses"])
             cpu = {"value": round(args.cpu_windows / tc, 4), "unit": "frames/s", "cores": cores, "kind": "port",
-                   "sample": f"{args.cpu_windows} windows of the same 640x480 N_flow=5 8-iteration workload, oracle/liborc.so (C restatement, OpenMP {cores} threads)",
+                   "sample": f"{args.cpu_windows} windows of the same {W}x{H} N_flow={N_FLOW} {EM_ITERS}-iteration workload, oracle/liborc.so (C restatement, OpenMP {cores} threads)",
                    "pose_vs_gpu": {"rot_rad_max": float(rot.max()) if len(rot) else None, "rel_trans_max": float(tr.max()) if len(tr) else None}}
         except Exception as e:  # the baseline is a reported number, never a reason to fail the bench
             cpu = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
 
     if rank == 0:
         gt = sc["poses_gt"].copy()
-        s = np.mean(np.linalg.norm(gt[:, 3:], axis=1))
-        gt[:, 3:] /= s
+        if wl["mode"] == "mono":  # monocular windows are normalised to mean |t| = 1 (voldor.cpp:309-317)
+            gt[:, 3:] /= np.mean(np.linalg.norm(gt[:, 3:], axis=1))
         rot, tr = synth.pose_errors(out["poses"], gt)
         line = {
-            "metric": "VO frames/s (640x480, N_flow=5, 8 EM iters)", "value": round(value, 3), "unit": "frames/s",
+            "metric": f"VO frames/s ({W}x{H}, N_flow={N_FLOW}, {EM_ITERS} EM iters)", "value": round(value, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE cfg2: 640x480, N_flow=5, monocular, 8 EM iterations, scene S seed 233+rank, flows resident in HBM",
+            "config": {"workload": wl["name"] + ", scene S seed 233+rank, inputs resident in HBM",
                        "voldor_config": CONFIG, "parallelism": f"one sequence per GPU x{world}, RCCL all-gather of pose blocks"},
             "n_registered": int(out["n_registered"]),
             "pose_rpe_vs_gt": {"rot_rad_max": float(rot.max()) if len(rot) else None, "rel_trans_max": float(tr.max()) if len(tr) else None},
