@@ -329,6 +329,39 @@ static void svd3(const double* E, double* U, double* s, double* V) {
     for (int c = 0; c < 3; c++) for (int r = 0; r < 3; r++) U[r * 3 + c] = u[c][r];
 }
 
+/* Null vector of the 8x9 epipolar constraint matrix (8 correspondences -> the 9 entries of E up to scale) by
+ * Gaussian elimination with complete pivoting in double: after 8 pivots the remaining column is the free one, it is
+ * set to 1 and the others follow by back substitution.  A is destroyed.  (A minimal sample has an exact null space,
+ * so this is the same vector as the smallest eigenvector of A^T A at a fraction of the work; a rank-deficient
+ * sample gives a finite but meaningless vector that the LMedS score discards.) */
+static void null9(double* A, double* f) {
+    int perm[9];
+    for (int c = 0; c < 9; c++) perm[c] = c;
+    for (int k = 0; k < 8; k++) {
+        int pr = k, pc = k; double best = -1.0;
+        for (int r = k; r < 8; r++) for (int c = k; c < 9; c++) { double v = fabs(A[r * 9 + c]); if (v > best) { best = v; pr = r; pc = c; } }
+        if (pr != k) for (int c = 0; c < 9; c++) { double t = A[k * 9 + c]; A[k * 9 + c] = A[pr * 9 + c]; A[pr * 9 + c] = t; }
+        if (pc != k) { for (int r = 0; r < 8; r++) { double t = A[r * 9 + k]; A[r * 9 + k] = A[r * 9 + pc]; A[r * 9 + pc] = t; } int t = perm[k]; perm[k] = perm[pc]; perm[pc] = t; }
+        double piv = A[k * 9 + k];
+        if (!(fabs(piv) > 1e-300)) piv = 1e-300; /* rank deficient sample */
+        for (int r = k + 1; r < 8; r++) {
+            const double m = A[r * 9 + k] / piv;
+            for (int c = k + 1; c < 9; c++) A[r * 9 + c] -= m * A[k * 9 + c];
+        }
+        A[k * 9 + k] = piv;
+    }
+    double x[9]; x[8] = 1.0;
+    for (int k = 7; k >= 0; k--) {
+        double sacc = 0;
+        for (int c = k + 1; c < 9; c++) sacc += A[k * 9 + c] * x[c];
+        x[k] = -sacc / A[k * 9 + k];
+    }
+    double nrm = 0;
+    for (int c = 0; c < 9; c++) nrm += x[c] * x[c];
+    nrm = sqrt(nrm);
+    for (int c = 0; c < 9; c++) f[perm[c]] = x[c] / nrm;
+}
+
 static int cmp_double(const void* a, const void* b) { double x = *(const double*)a, y = *(const double*)b; return (x > y) - (x < y); }
 
 /* geometry.cpp:288-332 estimate_camera_pose_epipolar.  The reference calls OpenCV 3.4
@@ -357,18 +390,16 @@ int orc_estimate_pose_epipolar(const float* flow, const float* K, int w, int h, 
     double best_med = INFINITY, bestE[9] = { 0 };
     double* errs = malloc(sizeof(double) * ns);
     for (int hy = 0; hy < BOOT_HYPS; hy++) {
-        double AtA[81] = { 0 };
+        double A[72];
         for (int k = 0; k < 8; k++) {
             int i = (int)(orc_rng(233u, (uint32_t)hy, 0x100u + (uint32_t)k) % (uint32_t)n);
             double a[9] = { q2[i * 2] * q1[i * 2], q2[i * 2] * q1[i * 2 + 1], q2[i * 2],
                             q2[i * 2 + 1] * q1[i * 2], q2[i * 2 + 1] * q1[i * 2 + 1], q2[i * 2 + 1],
                             q1[i * 2], q1[i * 2 + 1], 1.0 };
-            for (int r = 0; r < 9; r++) for (int c = 0; c < 9; c++) AtA[r * 9 + c] += a[r] * a[c];
+            for (int c = 0; c < 9; c++) A[k * 9 + c] = a[c];
         }
-        double V[81], ev[9];
-        jacobi_eig(AtA, 9, V, ev);
         double E0[9];
-        for (int r = 0; r < 9; r++) E0[r] = V[r * 9 + 0]; /* smallest eigenvalue */
+        null9(A, E0);
         double U[9], s[3], Vt[9], E[9];
         svd3(E0, U, s, Vt);
         for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) /* E = U diag(1,1,0) V^T */

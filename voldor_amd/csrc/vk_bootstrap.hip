@@ -114,24 +114,78 @@ VK_HD inline void boot_corr(const BootGeom& g, const float* p2, int i, double* q
     q1[0] = (x - g.cx) / g.fx; q1[1] = (y - g.cy) / g.fy;
     q2[0] = (p2[i * 2] - g.cx) / g.fx; q2[1] = (p2[i * 2 + 1] - g.cy) / g.fy;
 }
-// 9x9 normal matrix of hypothesis `hy` (8 correspondences drawn with rng3), element stride S
+// 8x9 epipolar constraint matrix of hypothesis `hy` (8 correspondences drawn with rng3), element stride S
 template <int S>
-VK_HD void boot_normal_matrix(const BootGeom& g, const float* p2, int hy, double* AtA) {
-    for (int r = 0; r < 81; r++) AtA[r * S] = 0.0;
+VK_HD void boot_constraint_matrix(const BootGeom& g, const float* p2, int hy, double* A) {
     for (int k = 0; k < 8; k++) {
         const int i = (int)(rng3(RAND_SEED, (uint32_t)hy, 0x100u + (uint32_t)k) % (uint32_t)g.n);
         double q1[2], q2[2];
         boot_corr(g, p2, i, q1, q2);
         const double a[9] = { q2[0] * q1[0], q2[0] * q1[1], q2[0], q2[1] * q1[0], q2[1] * q1[1], q2[1], q1[0], q1[1], 1.0 };
-        for (int r = 0; r < 9; r++) for (int c = 0; c < 9; c++) AtA[(r * 9 + c) * S] += a[r] * a[c];
+        for (int c = 0; c < 9; c++) A[(k * 9 + c) * S] = a[c];
     }
 }
-// null vector (smallest eigenvalue) -> nearest essential matrix U diag(1,1,0) V^T
+// Null vector of the 8x9 matrix by Gaussian elimination with complete pivoting (double): after 8 pivots the remaining
+// column is free, set to 1, the rest follows by back substitution.  ~600 operations instead of the ~30k of a cyclic
+// Jacobi eigen-decomposition of A^T A; a minimal sample has an exact null space, so it is the same vector.
 template <int S>
-VK_HD void boot_essential(double* AtA, double* V, double* E) {
-    double ev[9], E0[9], U[9], s[3], Vt[9];
-    sym_eig<9, S>(AtA, V, ev);
-    for (int r = 0; r < 9; r++) E0[r] = V[(r * 9) * S];
+VK_HD void boot_null9(double* A, double* f) {
+#define AA(r, c) A[((r) * 9 + (c)) * S]
+    int perm[9];
+    for (int c = 0; c < 9; c++) perm[c] = c;
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        int pr = k, pc = k; double best = -1.0;
+#pragma unroll 1
+        for (int r = k; r < 8; r++)
+#pragma unroll 1
+            for (int c = k; c < 9; c++) { const double v = vk_abs(AA(r, c)); if (v > best) { best = v; pr = r; pc = c; } }
+        if (pr != k) for (int c = 0; c < 9; c++) { const double t = AA(k, c); AA(k, c) = AA(pr, c); AA(pr, c) = t; }
+        if (pc != k) {
+            for (int r = 0; r < 8; r++) { const double t = AA(r, k); AA(r, k) = AA(r, pc); AA(r, pc) = t; }
+            // perm[] is indexed dynamically: swap through selects so that it stays in registers on the device
+            int pk = 0, ppc = 0;
+#pragma unroll
+            for (int c = 0; c < 9; c++) { if (c == k) pk = perm[c]; if (c == pc) ppc = perm[c]; }
+#pragma unroll
+            for (int c = 0; c < 9; c++) { if (c == k) perm[c] = ppc; else if (c == pc) perm[c] = pk; }
+        }
+        double piv = AA(k, k);
+        if (!(vk_abs(piv) > 1e-300)) piv = 1e-300;  // rank deficient sample
+#pragma unroll 1
+        for (int r = k + 1; r < 8; r++) {
+            const double m = AA(r, k) / piv;
+#pragma unroll 1
+            for (int c = k + 1; c < 9; c++) AA(r, c) -= m * AA(k, c);
+        }
+        AA(k, k) = piv;
+    }
+    double x[9];
+    x[8] = 1.0;
+#pragma unroll
+    for (int k = 7; k >= 0; k--) {
+        double sacc = 0;
+#pragma unroll
+        for (int c = k + 1; c < 9; c++) sacc += AA(k, c) * x[c];
+        x[k] = -sacc / AA(k, k);
+    }
+    double nrm = 0;
+#pragma unroll
+    for (int c = 0; c < 9; c++) nrm += x[c] * x[c];
+    nrm = vk_sqrt(nrm);
+#pragma unroll
+    for (int c = 0; c < 9; c++) {
+        const double v = x[c] / nrm;
+#pragma unroll
+        for (int d = 0; d < 9; d++) if (perm[c] == d) f[d] = v;
+    }
+#undef AA
+}
+// null vector -> nearest essential matrix U diag(1,1,0) V^T
+template <int S>
+VK_HD void boot_essential(double* A, double* E) {
+    double E0[9], U[9], s[3], Vt[9];
+    boot_null9<S>(A, E0);
     svd_3x3(E0, U, s, Vt);
     for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) E[r * 3 + c] = U[r * 3] * Vt[c * 3] + U[r * 3 + 1] * Vt[c * 3 + 1];
 }
@@ -190,9 +244,9 @@ int lmeds_essential_host(const float* p2, int w, int h, float fx, float fy, floa
     std::vector<double> errs(g.ns);
     double best_med = INFINITY, bestE[9] = { 0 };
     for (int hy = 0; hy < BOOT_HYPS; hy++) {
-        double AtA[81], V[81], E[9];
-        boot_normal_matrix<1>(g, p2, hy, AtA);
-        boot_essential<1>(AtA, V, E);
+        double A[72], E[9];
+        boot_constraint_matrix<1>(g, p2, hy, A);
+        boot_essential<1>(A, E);
         for (int j = 0; j < g.ns; j++) {
             double q1[2], q2[2];
             boot_corr(g, p2, j * g.sstride, q1, q2);
@@ -229,16 +283,15 @@ __global__ static void k_extract_corr(const float2* __restrict__ flow, float* __
     out[i * 2 + 1] = (float)y + f.y;
 }
 
-// one lane per hypothesis; AtA and V of 64 hypotheses in LDS, [element][lane]
+// one lane per hypothesis; the 8x9 constraint matrices of 64 hypotheses in LDS, [element][lane] (rows and columns are
+// swapped with run-time indices during pivoting)
 __global__ __launch_bounds__(64) static void k_boot_hyp(const float* __restrict__ p2, BootGeom g, double* __restrict__ Es) {
-    __shared__ double sA[81 * 64];
-    __shared__ double sV[81 * 64];
+    __shared__ double sA[72 * 64];
     const int hy = blockIdx.x * 64 + threadIdx.x;
     double* A = sA + threadIdx.x;
-    double* V = sV + threadIdx.x;
     double E[9];
-    boot_normal_matrix<64>(g, p2, hy, A);
-    boot_essential<64>(A, V, E);
+    boot_constraint_matrix<64>(g, p2, hy, A);
+    boot_essential<64>(A, E);
     for (int k = 0; k < 9; k++) Es[(size_t)hy * 9 + k] = E[k];
 }
 
