@@ -66,6 +66,17 @@ int vk_voldor_device(const float* flows, const float* disparity, const float* di
                      int* n_registered, float* poses, float* poses_covar, float* depth,
                      float* depth_conf);
 /* per-camera statistics of the last window (voldor/utils.h:41-45): arrays of length >= N */
+/* n_windows independent windows of the same geometry and config IN FLIGHT TOGETHER on the current device (no reference
+ * counterpart: voldor/py_export.cpp processes one window per call).  Argument b of every pointer array belongs to window b
+ * (arrays may be NULL where the single call takes NULL); images may be host or device pointers; n_registered[n_windows],
+ * poses[n_windows][N][6], poses_covar[n_windows][N][36] are host arrays.  Each window runs on its own stream and buffers
+ * and gives the result of the one-at-a-time call. */
+int vk_voldor_device_batch(int n_windows, const float* const* flows, const float* const* disparity,
+                           const float* const* disparity_pconf, const float* const* depth_priors,
+                           const float* const* depth_prior_poses, const float* const* depth_prior_pconfs,
+                           float fx, float fy, float cx, float cy, float basefocal, int N, int N_dp, int w, int h,
+                           const char* config, int* n_registered, float* poses, float* poses_covar,
+                           float* const* depth, float* const* depth_conf);
 int vk_last_camera_stats(int* pose_sample_count, float* pose_density, float* pose_rigidness_density,
                          int* ms_iters, int* gu_iters, int n);
 /* bootstrap pieces (voldor/geometry.cpp:267-332) exposed for parity tests; host pointers */

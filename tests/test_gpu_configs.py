@@ -100,3 +100,29 @@ def test_cfg1_host_solver_selection_agrees():
         assert o["n_registered"] == outs[0]["n_registered"] == 5
         rot, tr = synth.pose_errors(o["poses"], outs[0]["poses"])
         assert rot.max() < 1e-3 and tr.max() < 3e-2, (rot, tr)
+
+
+def test_cfg4_windows_in_flight_match_one_at_a_time():
+    """cfg4 shards independent sequences; on ONE device the same independence lets several windows run concurrently
+    (vk_voldor_device_batch: own stream + buffers per window).  Each window must give exactly the one-at-a-time result."""
+    import torch
+    from voldor_amd import pyvoldor, synth, kernels
+    scs = [synth.make_scene(w=320, h=240, n_flows=4, fx=160, fy=160, cx=160, cy=120, seed=300 + b) for b in range(4)]
+    fx, fy, cx, cy = scs[0]["K"]
+    fl = [torch.from_numpy(s["flows"]).cuda() for s in scs]
+    cfg = "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 4"
+    single = []
+    for b in range(4):
+        kernels.set_rand_epoch(0)
+        d = torch.empty(240, 320, device="cuda")
+        single.append((pyvoldor.voldor_device(fl[b], fx, fy, cx, cy, config=cfg, depth_out=d), d.cpu().numpy()))
+    for rep in range(2):  # second round: pooled contexts and workers are reused
+        kernels.set_rand_epoch(0)  # also re-seeds the pooled contexts
+        dout = [torch.empty(240, 320, device="cuda") for _ in range(4)]
+        outs = pyvoldor.voldor_device_batch(fl, fx, fy, cx, cy, config=cfg, depth_out=dout)
+        torch.cuda.synchronize()
+        for b in range(4):
+            assert outs[b]["n_registered"] == single[b][0]["n_registered"] == 4
+            np.testing.assert_array_equal(outs[b]["poses"], single[b][0]["poses"])
+            np.testing.assert_array_equal(outs[b]["poses_covar"], single[b][0]["poses_covar"])
+            np.testing.assert_array_equal(dout[b].cpu().numpy(), single[b][1])

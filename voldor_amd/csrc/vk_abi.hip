@@ -54,6 +54,28 @@ Context* default_context() {
     return c;
 }
 
+// extra contexts of a device (own stream, own buffers) for windows in flight next to each other (vk_voldor_device_batch)
+static std::map<int, std::vector<Context*>> g_pool_ctx;
+Context* pool_context(int idx) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    std::lock_guard<std::mutex> lk(g_mu);
+    std::vector<Context*>& v = g_pool_ctx[dev];
+    while ((int)v.size() <= idx) {
+        Context* c = new Context();
+        if (c->init(dev) != 0) { delete c; return nullptr; }
+        v.push_back(c);
+    }
+    return v[(size_t)idx];
+}
+int pool_set_rand_epoch(unsigned epoch) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorNoDevice;
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (Context* c : g_pool_ctx[dev]) { c->rand_epoch = epoch; c->rand_w = c->rand_h = -1; }
+    return 0;
+}
+
 int prof_begin(Context* c) { return (int)hipEventRecord(c->ev0, c->stream); }
 int prof_end(Context* c, const char* name) {
     VK_CHECK(hipEventRecord(c->ev1, c->stream));
@@ -378,7 +400,7 @@ int vk_set_rand_epoch(unsigned epoch) {
     if (!c) return (int)hipErrorNoDevice;
     c->rand_epoch = epoch;
     c->rand_w = c->rand_h = -1;  // explicit seed: the next call adopts its size without resetting
-    return 0;
+    return pool_set_rand_epoch(epoch);  // and the contexts of vk_voldor_device_batch
 }
 unsigned vk_get_rand_epoch(void) {
     Context* c = default_context();

@@ -17,6 +17,10 @@
 #include <iostream>
 #include <cmath>
 #include <cstddef>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <vector>
 
 namespace vk {
 
@@ -251,11 +255,10 @@ struct Voldor {
 
 static thread_local Voldor g_last;  // stats of the last window (vk_last_camera_stats)
 
-static int voldor_run(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
-                      const float* depth_prior_poses, const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
-                      float basefocal, int N, int N_dp, int w, int h, const char* config, int* n_registered, float* poses,
-                      float* poses_covar, float* depth, float* depth_conf) {
-    Context* c = default_context();
+static int voldor_run_on(Context* c, const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
+                         const float* depth_prior_poses, const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+                         float basefocal, int N, int N_dp, int w, int h, const char* config, int* n_registered, float* poses,
+                         float* poses_covar, float* depth, float* depth_conf) {
     if (!c) return (int)hipErrorNoDevice;
     Voldor& v = g_last;
     v = Voldor();
@@ -279,6 +282,65 @@ static int voldor_run(const float* flows, const float* disparity, const float* d
         if (poses) { memcpy(poses + i * 6, v.hcams[i].rvec, 12); memcpy(poses + i * 6 + 3, v.hcams[i].t, 12); }
         if (poses_covar) memcpy(poses_covar + i * 36, v.hcams[i].covar, sizeof(float) * 36);
     }
+    return 0;
+}
+static int voldor_run(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
+                      const float* depth_prior_poses, const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+                      float basefocal, int N, int N_dp, int w, int h, const char* config, int* n_registered, float* poses,
+                      float* poses_covar, float* depth, float* depth_conf) {
+    return voldor_run_on(default_context(), flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, fx, fy,
+                         cx, cy, basefocal, N, N_dp, w, h, config, n_registered, poses, poses_covar, depth, depth_conf);
+}
+
+// ---- several independent windows in flight on ONE device ------------------------------------------------------------
+// Half of a window's GPU time is spent in single-workgroup kernels (mean-shift, robust-Gaussian refit) and 128-wave
+// kernels (P3P) that cannot be batched across the cameras of a window (camera i+1 needs the pose of camera i,
+// voldor.cpp:169-195): one CU of 256 is busy.  Independent windows (other sequences, or other windows of an offline
+// sequence) have no such dependence, so a batch runs window b on its own context = own HIP stream + own buffers, driven
+// by its own host thread (each window needs one host decision per EM iteration), and the hardware queues overlap the
+// narrow kernels of one window with the wide per-pixel kernels of the others.  Results are those of the one-at-a-time
+// call (same kernels, per-context depth-sampling counter).
+struct BatchJob {
+    const float *flows, *disparity, *disparity_pconf, *depth_priors, *depth_prior_poses, *depth_prior_pconfs;
+    float fx, fy, cx, cy, basefocal; int N, N_dp, w, h; const char* config;
+    int* n_registered; float *poses, *poses_covar, *depth, *depth_conf;
+    int rc;
+};
+class WindowPool {  // persistent workers: worker i owns pool context i of the device it was started on
+    std::mutex mu; std::condition_variable cv_work, cv_done;
+    std::vector<std::thread> workers; std::vector<BatchJob*> slot; int pending = 0, device = 0; bool stop = false;
+    void loop(int i) {
+        (void)hipSetDevice(device);
+        for (;;) {
+            BatchJob* j;
+            { std::unique_lock<std::mutex> lk(mu); cv_work.wait(lk, [&] { return stop || slot[i]; }); if (stop) return; j = slot[i]; }
+            j->rc = voldor_run_on(pool_context(i), j->flows, j->disparity, j->disparity_pconf, j->depth_priors, j->depth_prior_poses,
+                                  j->depth_prior_pconfs, j->fx, j->fy, j->cx, j->cy, j->basefocal, j->N, j->N_dp, j->w, j->h, j->config,
+                                  j->n_registered, j->poses, j->poses_covar, j->depth, j->depth_conf);
+            { std::lock_guard<std::mutex> lk(mu); slot[i] = nullptr; if (--pending == 0) cv_done.notify_all(); }
+        }
+    }
+public:
+    explicit WindowPool(int dev) : device(dev) {}
+    ~WindowPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv_work.notify_all(); for (auto& t : workers) t.join(); }
+    void run(std::vector<BatchJob>& jobs) {
+        std::unique_lock<std::mutex> lk(mu);
+        while (workers.size() < jobs.size()) { slot.push_back(nullptr); const int i = (int)workers.size(); workers.emplace_back([this, i] { loop(i); }); }
+        for (size_t i = 0; i < jobs.size(); i++) slot[i] = &jobs[i];
+        pending = (int)jobs.size();
+        cv_work.notify_all();
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+};
+static std::mutex g_pool_mu;
+static std::map<int, WindowPool*> g_pools;  // per device; intentionally never destroyed (worker threads outlive static teardown order)
+static int voldor_run_batch(std::vector<BatchJob>& jobs) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorNoDevice;
+    WindowPool* p;
+    { std::lock_guard<std::mutex> lk(g_pool_mu); auto& q = g_pools[dev]; if (!q) q = new WindowPool(dev); p = q; }
+    p->run(jobs);
+    for (auto& j : jobs) if (j.rc) return j.rc;
     return 0;
 }
 
@@ -307,6 +369,25 @@ int vk_voldor_device(const float* flows, const float* disparity, const float* di
                      float* poses_covar, float* depth, float* depth_conf) {
     return vk::voldor_run(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, fx, fy, cx, cy,
                           basefocal, N, N_dp, w, h, config, n_registered, poses, poses_covar, depth, depth_conf);
+}
+int vk_voldor_device_batch(int n_windows, const float* const* flows, const float* const* disparity, const float* const* disparity_pconf,
+                           const float* const* depth_priors, const float* const* depth_prior_poses,
+                           const float* const* depth_prior_pconfs, float fx, float fy, float cx, float cy, float basefocal, int N, int N_dp,
+                           int w, int h, const char* config, int* n_registered, float* poses, float* poses_covar, float* const* depth,
+                           float* const* depth_conf) {
+    if (n_windows <= 0 || !flows || !n_registered) return (int)hipErrorInvalidValue;
+    std::vector<vk::BatchJob> jobs((size_t)n_windows);
+    for (int b = 0; b < n_windows; b++) {
+        vk::BatchJob& j = jobs[(size_t)b];
+        j.flows = flows[b]; j.disparity = disparity ? disparity[b] : nullptr; j.disparity_pconf = disparity_pconf ? disparity_pconf[b] : nullptr;
+        j.depth_priors = depth_priors ? depth_priors[b] : nullptr; j.depth_prior_poses = depth_prior_poses ? depth_prior_poses[b] : nullptr;
+        j.depth_prior_pconfs = depth_prior_pconfs ? depth_prior_pconfs[b] : nullptr;
+        j.fx = fx; j.fy = fy; j.cx = cx; j.cy = cy; j.basefocal = basefocal; j.N = N; j.N_dp = N_dp; j.w = w; j.h = h; j.config = config;
+        j.n_registered = n_registered + b; j.poses = poses ? poses + (size_t)b * N * 6 : nullptr;
+        j.poses_covar = poses_covar ? poses_covar + (size_t)b * N * 36 : nullptr;
+        j.depth = depth ? depth[b] : nullptr; j.depth_conf = depth_conf ? depth_conf[b] : nullptr; j.rc = 0;
+    }
+    return vk::voldor_run_batch(jobs);
 }
 int vk_last_camera_stats(int* pose_sample_count, float* pose_density, float* pose_rigidness_density, int* ms_iters, int* gu_iters, int n) {
     for (int i = 0; i < n && i < vk::MAX_FRAMES; i++) {

@@ -80,3 +80,35 @@ def voldor_device(flows, fx, fy, cx, cy, basefocal=0, disparity=None, disparity_
     capi.check(rc, "vk_voldor_device")
     n = n_registered.value
     return {"n_registered": n, "poses": poses[:n], "poses_covar": poses_covar[:n], "depth": depth_out, "depth_conf": depth_conf_out}
+
+
+def voldor_device_batch(flows_list, fx, fy, cx, cy, basefocal=0, disparity_list=None, config="", depth_out=None, depth_conf_out=None):
+    """Several independent windows (same geometry / config) in flight together on the current device
+    (vk_voldor_device_batch): flows_list[b] is a torch float32 CUDA(HIP) tensor [N,h,w,2]; depth_out / depth_conf_out are
+    optional lists of [h,w] device tensors.  Returns one result dict per window, as voldor_device does."""
+    import torch
+
+    B = len(flows_list)
+    N, h, w = flows_list[0].shape[0], flows_list[0].shape[1], flows_list[0].shape[2]
+    PF = C.POINTER(C.c_float)
+
+    def arr(ts):
+        if ts is None:
+            return None
+        for t in ts:
+            assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        return (PF * B)(*[C.cast(t.data_ptr(), PF) for t in ts])
+
+    for t in flows_list:
+        assert tuple(t.shape) == (N, h, w, 2)
+    poses = np.zeros((B, N, 6), dtype=np.float32)
+    covar = np.zeros((B, N, 6, 6), dtype=np.float32)
+    nreg = (C.c_int * B)()
+    rc = capi.lib().vk_voldor_device_batch(
+        C.c_int(B), arr(flows_list), arr(disparity_list), None, None, None, None, C.c_float(fx), C.c_float(fy), C.c_float(cx),
+        C.c_float(cy), C.c_float(basefocal), C.c_int(N), C.c_int(0), C.c_int(w), C.c_int(h), str(config).encode(), nreg,
+        capi.fp(poses), capi.fp(covar), arr(depth_out), arr(depth_conf_out))
+    capi.check(rc, "vk_voldor_device_batch")
+    return [{"n_registered": nreg[b], "poses": poses[b, :nreg[b]], "poses_covar": covar[b, :nreg[b]],
+             "depth": None if depth_out is None else depth_out[b], "depth_conf": None if depth_conf_out is None else depth_conf_out[b]}
+            for b in range(B)]
