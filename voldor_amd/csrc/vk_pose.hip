@@ -452,70 +452,92 @@ __device__ static bool rg_prepare_wave(float* covar_half, float* cinv_half, int 
 // a handful of registers instead of ~100, for kernels whose register budget is pinned elsewhere.
 // Element updates are independent within a step -> still bit-identical to the serial LU.
 __device__ __forceinline__ bool rg_prepare_lds(float* covar_half, float* cinv_half, float lambda, bool regularise, double* lds72) {
-    const int n = 6;
+    // One lane per element (r,c); the lane keeps its own A and B element in registers, LDS is the exchange medium.
+    // This runs on ONE wave while the other 15 wait, so what counts is the number of dependent LDS round trips:
+    // every step issues its reads as one batch (pivot column; then both candidate rows), 3 trips per pivot instead
+    // of one per element touched.
+    constexpr int n = 6;
     const int lane = threadIdx.x & 63;
     const bool act = lane < n * n;
     const int r = act ? lane / n : 0, c = act ? lane % n : 0;
     double* A = lds72; double* B = lds72 + 36;
+    double a, b;
     {
         const int hi = r >= c ? r : c, lo = r >= c ? c : r;
         double full = (double)covar_half[(hi * hi + hi) / 2 + lo];
         if (regularise) {
             double tr = 0;
-#pragma unroll 1
+#pragma unroll
             for (int d = 0; d < n; d++) tr += (double)covar_half[(d * d + d) / 2 + d];
             const double m = tr / (double)n, lam = (double)lambda;
             full = lam * m * (r == c ? 1.0 : 0.0) + (1 - lam) * full;
         }
+        a = full; b = (r == c) ? 1.0 : 0.0;
         __builtin_amdgcn_wave_barrier();
-        if (act) { A[lane] = full; B[lane] = (r == c) ? 1.0 : 0.0; }
+        if (act) { A[lane] = a; B[lane] = b; }
         if (act && r >= c) covar_half[(r * r + r) / 2 + c] = (float)full;
         __builtin_amdgcn_wave_barrier();
     }
     double det = 1.0;
-    bool ok = true;
 #pragma unroll 1
-    for (int i = 0; i < n && ok; i++) {
+    for (int i = 0; i < n; i++) {
+        double col[n];
+#pragma unroll
+        for (int j = 0; j < n; j++) col[j] = A[j * n + i];  // one batch
+        const double mycol = A[r * n + i];
         int k = i;
-        double best = fabs(A[i * n + i]);
-#pragma unroll 1
-        for (int j = i + 1; j < n; j++) {
-            const double v = fabs(A[j * n + i]);
-            if (v > best) { best = v; k = j; }
+        double best = -1.0, piv = 0.0;
+#pragma unroll
+        for (int j = 0; j < n; j++) {
+            const double v = fabs(col[j]);
+            if (j >= i && (j == i ? true : v > best)) { best = v; k = j; piv = col[j]; }
         }
-        if (best < 2.220446049250313e-16) { ok = false; break; }
-        if (k != i) {
-            double ta = 0, tb = 0;
-            const int other = (r == i) ? k * n + c : i * n + c;
-            if (act && (r == i || r == k)) { ta = A[other]; tb = B[other]; }
-            __builtin_amdgcn_wave_barrier();
-            if (act && (r == i || r == k)) { A[lane] = ta; B[lane] = tb; }
-            __builtin_amdgcn_wave_barrier();
-            det = -det;
-        }
-        const double piv = A[i * n + i];
+        if (best < 2.220446049250313e-16) return false;
+        // rows i and k swap (k == i: both reads hit row i); everybody needs the new pivot row = old row k
+        const double ak = A[k * n + c], bk = B[k * n + c], ai = A[i * n + c], bi = B[i * n + c];
+        if (k != i) det = -det;
         det *= piv;
         const double d = -1.0 / piv;
-        if (act && r > i) {
-            const double alpha = A[r * n + i] * d;
-            const double air = A[i * n + c], bir = B[i * n + c];
-            if (c > i) A[lane] += alpha * air;
-            B[lane] += alpha * bir;
+        double old_ii = 0.0;  // A_old[i][i] = column element of the row that moves to position k
+#pragma unroll
+        for (int j = 0; j < n; j++) if (j == i) old_ii = col[j];
+        if (act) {
+            if (r == i) { a = ak; b = bk; }
+            else if (r > i) {
+                double ra = a, rb = b, rc = mycol;
+                if (r == k) { ra = ai; rb = bi; rc = old_ii; }  // this lane's row now holds old row i
+                const double alpha = rc * d;
+                a = (c > i) ? ra + alpha * ak : ra;
+                b = rb + alpha * bk;
+            }
         }
         __builtin_amdgcn_wave_barrier();
+        if (act) { A[lane] = a; B[lane] = b; }
+        __builtin_amdgcn_wave_barrier();
     }
-    if (!ok || det <= 0.0) return false;
+    if (det <= 0.0) return false;
+    // back substitution: row i of the inverse from rows > i; U's row and the reciprocal pivot are fetched once
+    double urow[n];
+#pragma unroll
+    for (int k = 0; k < n; k++) urow[k] = A[r * n + k];
+    double rdiag = 1.0;
+#pragma unroll
+    for (int k = 0; k < n; k++) if (k == r) rdiag = 1.0 / urow[k];
 #pragma unroll 1
     for (int i = n - 1; i >= 0; i--) {
+        double below[n];
+#pragma unroll
+        for (int k = 0; k < n; k++) below[k] = B[k * n + c];  // one batch; rows > i are final
         if (act && r == i) {
-            double sacc = B[lane];
-#pragma unroll 1
-            for (int k = i + 1; k < n; k++) sacc -= A[i * n + k] * B[k * n + c];
-            B[lane] = sacc / A[i * n + i];
+            double sacc = b;
+#pragma unroll
+            for (int k = 0; k < n; k++) if (k > i) sacc -= urow[k] * below[k];
+            b = sacc * rdiag;
+            B[lane] = b;
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (act && r >= c) cinv_half[(r * r + r) / 2 + c] = (float)B[lane];
+    if (act && r >= c) cinv_half[(r * r + r) / 2 + c] = (float)b;
     return true;
 }
 
@@ -525,6 +547,7 @@ __device__ static bool robust_gaussian_block(const float* __restrict__ space, in
                                              float* mean /*LDS[6]*/, float* covar_half /*LDS[21]*/, float* cinv_half /*LDS[21]*/,
                                              BlockRed& br, float* o_density, int* o_iters) {
     __shared__ int s_flag;  // 0 continue, 2 unreliable
+    __shared__ double s_lu[72];
     const int tid = threadIdx.x;
     const int dc = (dims * dims + dims) / 2;
     float weight = 0.f;
@@ -532,7 +555,9 @@ __device__ static bool robust_gaussian_block(const float* __restrict__ space, in
     bool reliable = true;
     for (iter = 0; iter < mp.rg_max_iters; iter++) {
         if (tid < 64) {
-            const bool ok = rg_prepare_wave(covar_half, cinv_half, dims, iter > 0 && mp.rg_covar_reg_lambda > 0.f, mp.rg_covar_reg_lambda);
+            // 6-D (poses): the LDS variant, the same code k_pose_refit runs; other dimensions: the register variant
+            const bool ok = dims == 6 ? rg_prepare_lds(covar_half, cinv_half, mp.rg_covar_reg_lambda, iter > 0 && mp.rg_covar_reg_lambda > 0.f, s_lu)
+                                      : rg_prepare_wave(covar_half, cinv_half, dims, iter > 0 && mp.rg_covar_reg_lambda > 0.f, mp.rg_covar_reg_lambda);
             if (tid == 0) s_flag = ok ? 0 : 2;
         }
         __syncthreads();
