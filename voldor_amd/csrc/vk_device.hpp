@@ -215,4 +215,53 @@ __device__ __forceinline__ float wave_sum(float v) {
     return (r0 + r1) + (r2 + r3);
 }
 
+// Transposing wave reduction: NV (<= P = 32 or 8) per-lane values -> lane L returns the 64-lane total of value
+// wave_slot<P>(L).  Stage with lane distance d halves the number of values a lane holds: the lane with bit d clear
+// keeps the lower half, its partner the upper half, each adds what the other one sends (2 selects + 1 DPP add per kept
+// value).  ~3.4 instructions per value instead of the 11 of an all-lanes wave_sum per value; with 28 values x 16 waves
+// per refit iteration on ONE compute unit that is the difference between 310 and ~110 issue slots per wave.
+template <int CTRL, int BANK = 0xf>
+__device__ __forceinline__ float dpp_get(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, 0xf, BANK, false));
+}
+template <int D>
+__device__ __forceinline__ float lane_xor(float v) {  // value of lane (L ^ D)
+    if (D == 1) return dpp_mov<0xB1>(v);
+    if (D == 2) return dpp_mov<0x4E>(v);
+    // row_ror:n hands lane i the value of lane (i - n) mod 16: banks 0,2 (bit 2 clear) read i+4 via ror:12, banks 1,3 read i-4 via ror:4
+    if (D == 4) { float t = dpp_get<0x12C, 0x5>(v, v); return dpp_get<0x124, 0xa>(t, v); }
+    if (D == 8) return dpp_mov<0x128>(v);                                                    // row_ror:8
+    return __shfl_xor(v, D, 64);
+}
+template <int P> __device__ __forceinline__ int wave_slot(int lane) {
+    int idx = 0;
+#pragma unroll
+    for (int s = 0, half = P / 2; half >= 1; s++, half >>= 1) idx += ((lane >> s) & 1) * half;
+    return idx;
+}
+template <int P, int D, int HALF>
+__device__ __forceinline__ void wave_transpose_stage(float (&v)[P], int lane) {
+    const bool up = (lane & D) != 0;
+#pragma unroll
+    for (int j = 0; j < HALF; j++) {
+        const float keep = up ? v[j + HALF] : v[j], send = up ? v[j] : v[j + HALF];
+        v[j] = keep + lane_xor<D>(send);
+    }
+}
+template <int P>
+__device__ __forceinline__ float wave_reduce_transpose(float (&v)[P]) {
+    static_assert(P == 32 || P == 8, "padded value count");
+    const int lane = threadIdx.x & 63;
+    if (P == 32) {
+        wave_transpose_stage<P, 1, 16>(v, lane); wave_transpose_stage<P, 2, 8>(v, lane); wave_transpose_stage<P, 4, 4>(v, lane);
+        wave_transpose_stage<P, 8, 2>(v, lane); wave_transpose_stage<P, 16, 1>(v, lane);
+        return v[0] + lane_xor<32>(v[0]);
+    } else {
+        wave_transpose_stage<P, 1, 4>(v, lane); wave_transpose_stage<P, 2, 2>(v, lane); wave_transpose_stage<P, 4, 1>(v, lane);
+        float t = v[0];
+        t += lane_xor<8>(t); t += lane_xor<16>(t); t += lane_xor<32>(t);
+        return t;
+    }
+}
+
 }  // namespace vk

@@ -624,12 +624,14 @@ struct RedBuf { float w[2][16][28]; };
 // second barrier for a shared total costs more than the redundant 16-term sums.)
 template <int NV, int NW = 16>
 __device__ __forceinline__ void allreduce_regs(float* v, RedBuf& rb, int parity) {
+    constexpr int P = NV <= 8 ? 8 : 32;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float pv[P];
 #pragma unroll
-    for (int k = 0; k < NV; k++) {
-        float s = wave_sum(v[k]);
-        if (lane == 0) rb.w[parity][wv][k] = s;
-    }
+    for (int k = 0; k < P; k++) pv[k] = k < NV ? v[k] : 0.f;
+    const float mine = wave_reduce_transpose<P>(pv);  // wave total of value wave_slot<P>(lane)
+    const int slot = wave_slot<P>(lane);
+    if (lane < P && slot < NV) rb.w[parity][wv][slot] = mine;
     __syncthreads();
     float tot = 0.f;
     if (lane < NV) {
