@@ -196,9 +196,12 @@ VK_HD __forceinline__ void consider(BestPose<S>& B, V3<S> L, S a12, S a13, S a23
 }
 
 // y: 4 pixel observations (u,v), x: 4 3-D points. Returns false if P3P has no solution.
+// `only` >= 0 evaluates just candidate root (block only>>1, root only&1) and reports its 4th-point error through
+// `err_out` (k_solve spreads the up-to-four candidates of one hypothesis over four lanes and folds them afterwards
+// with the same "first one, then strictly better" rule); only < 0 walks all candidates like the reference.
 template <typename S>
 VK_HD static bool lambdatwist_p4p(const float* yu, const float* yv, const float (*xp)[3], float fxf, float fyf,
-                                       float cxf, float cyf, float* Rout, float* tout) {
+                                       float cxf, float cyf, float* Rout, float* tout, int only = -1, S* err_out = nullptr) {
 #pragma clang fp contract(off)
     // bearings are formed in float and then widened (lambdatwist_p4p.h:13-15)
     V3<S> y1 = normalized<S>({ (S)((yu[0] - cxf) / fxf), (S)((yv[0] - cyf) / fyf), S(1.0) });
@@ -241,6 +244,30 @@ VK_HD static bool lambdatwist_p4p(const float* yu, const float* yv, const float 
     }
     BestPose<S> B;
     B.n = 0; B.err = S(0);
+    if (only >= 0) {  // one candidate, straight-line: the lanes of a hypothesis differ in data only
+        const S s = (only >> 1) == 0 ? v : -v;
+        S w2 = S(1.0) / (s * v2.x - v1.x);
+        S w0 = (v1.y - s * v2.y) * w2;
+        S w1 = (v1.z - s * v2.z) * w2;
+        S a = S(1.0) / ((a13 - a12) * w1 * w1 - a12 * b13 * w1 - a12);
+        S b = (a13 * b12 * w1 - a12 * b13 * w0 - S(2.0) * w0 * w1 * (a12 - a13)) * a;
+        S c = ((a13 - a12) * w0 * w0 + a13 * b12 * w0 + a13) * a;
+        if (b * b - 4.0 * c >= 0) {
+            S tau1, tau2;
+            root2real(b, c, tau1, tau2);
+            const S tau = (only & 1) == 0 ? tau1 : tau2;
+            if (tau > 0) {
+                S d = a23 / (tau * (b23 + tau) + S(1.0));
+                if (d > 0) {
+                    S l2 = vk_sqrt(d), l3 = tau * l2, l1 = w0 * l2 + w1 * l3;
+                    if (l1 >= 0)
+                        consider<S>(B, { l1, l2, l3 }, a12, a13, a23, b12, b13, b23, y1, y2, y3, x1, Xi, xp[3], yu[3], yv[3],
+                                    fxf, fyf, cxf, cyf);
+                }
+            }
+        }
+        if (err_out) *err_out = B.err;
+    } else
 #pragma unroll 1
     for (int blk = 0; blk < 2; blk++) {  // s = +v, then s = -v (lambdatwist_p3p.h:140-240)
         S s = blk == 0 ? v : -v;

@@ -147,7 +147,11 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                                                       float* __restrict__ rvecs, float* __restrict__ tvecs,
                                                       int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk,
                                                       CamState* cam, int npx, float fx, float fy, float cx, float cy, int n_poses) {
-    const int idx = blockIdx.x * 64 + threadIdx.x;
+    // LambdaTwist: four lanes per hypothesis, one candidate root each (the candidates are independent once the
+    // shared cubic / eigen-decomposition is done; a lane per hypothesis walks them one after the other and the wave
+    // waits for its slowest lane).  AP3P keeps one lane per hypothesis.
+    constexpr int LPH = (SOLVER == 1) ? 1 : 4;
+    const int gtid = blockIdx.x * 64 + threadIdx.x, idx = gtid / LPH, sub = gtid % LPH;
     int n_pts;
     if (FROM_MAP) {
         // number of valid correspondences = sum of k_collect's per-workgroup counts; every wave adds them up itself
@@ -163,13 +167,14 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
         n_pts = part;
-        if (idx == 0) { *n_pts_dev = n_pts; if (cam) cam->n_points = n_pts; }
+        if (gtid == 0) { *n_pts_dev = n_pts; if (cam) cam->n_points = n_pts; }
     } else
         n_pts = *n_pts_dev;
     if (idx >= n_poses) return;
     const float qnan = __builtin_nanf("");
     float R[9], t[3];
     bool ok = false;
+    float errf = 0.f; double errd = 0.0;
     if (n_pts >= (FROM_MAP ? 4 : 1)) {
         float yu[4], yv[4], xp[4][3];
         bool drawn = true;
@@ -219,15 +224,32 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
             xp[k][0] = pts3[(size_t)i * 3]; xp[k][1] = pts3[(size_t)i * 3 + 1]; xp[k][2] = pts3[(size_t)i * 3 + 2];
         }
         if (drawn) {
-            if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t);
-            else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t);
+            if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf);
+            else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errd);
             else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t);
         }
     }
     float aa[3] = { qnan, qnan, qnan };
     if (ok) { nearest_rotation(R); rotmat_to_angle_axis(R, aa); }
-    rvecs[(size_t)idx * 3] = aa[0]; rvecs[(size_t)idx * 3 + 1] = aa[1]; rvecs[(size_t)idx * 3 + 2] = aa[2];
-    tvecs[(size_t)idx * 3] = ok ? t[0] : qnan; tvecs[(size_t)idx * 3 + 1] = ok ? t[1] : qnan; tvecs[(size_t)idx * 3 + 2] = ok ? t[2] : qnan;
+    bool writer = true;
+    if (LPH == 4) {
+        // fold the four candidates in root order: the first valid one, then any later one with a strictly smaller
+        // 4th-point error (lambdatwist_p4p.h:43-58); every lane of the group evaluates the same fold
+        const int base = (threadIdx.x & 63) & ~3;
+        int win = -1;
+        double werr = 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const int okc = __shfl((int)ok, base + c, 64);
+            const double ec = (SOLVER == 2) ? __shfl(errd, base + c, 64) : (double)__shfl(errf, base + c, 64);
+            if (okc && (win < 0 || werr > ec)) { win = c; werr = ec; }
+        }
+        writer = (win < 0) ? (sub == 0) : (sub == win);  // no candidate: lane 0 writes the NaN marker
+    }
+    if (writer) {
+        rvecs[(size_t)idx * 3] = aa[0]; rvecs[(size_t)idx * 3 + 1] = aa[1]; rvecs[(size_t)idx * 3 + 2] = aa[2];
+        tvecs[(size_t)idx * 3] = ok ? t[0] : qnan; tvecs[(size_t)idx * 3 + 1] = ok ? t[1] : qnan; tvecs[(size_t)idx * 3 + 2] = ok ? t[2] : qnan;
+    }
 }
 
 // ---- single-workgroup mode finding ---------------------------------------------------------------
@@ -1030,7 +1052,8 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
                         float cx, float cy, int n_poses, int solver) {
     if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
-    dim3 g((n_poses + 63) / 64), b(64);
+    const int lph = (solver == 1) ? 1 : 4;  // lanes per hypothesis (k_solve)
+    dim3 g((n_poses * lph + 63) / 64), b(64);
     float* rv = c->rvecs.as<float>(); float* tv = c->tvecs.as<float>();
     const int* bc = c->blk_counts.as<int>(); const int nb = c->n_map_blocks;
     if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses);
