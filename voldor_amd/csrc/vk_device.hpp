@@ -107,20 +107,6 @@ __device__ __forceinline__ P3 transform(const float* R, const float* t, P3 o) {
              o.x * R[6] + o.y * R[7] + o.z * R[8] + t[2] };
 }
 
-// Hypothesis evaluation (pixel_cost, ~15x per pixel per EM iteration) uses v_rcp_f32 instead of
-// the two IEEE divisions: a 1-ulp change of a sampling position moves a cost by ~1e-7 relative,
-// the same class of difference as the transcendental implementations.
-__device__ __forceinline__ void project_fast(const PoseBlock* P, P3 o, float& px, float& py) {
-    const float iz = fast_rcp(o.z);
-    px = (P->K4[0] * o.x + P->K4[1] * o.z) * iz;
-    py = (P->K4[2] * o.y + P->K4[3] * o.z) * iz;
-}
-__device__ __forceinline__ P3 transform_fast(const float* R, const float* t, P3 o) {
-    return { fmaf(o.x, R[0], fmaf(o.y, R[1], fmaf(o.z, R[2], t[0]))),
-             fmaf(o.x, R[3], fmaf(o.y, R[4], fmaf(o.z, R[5], t[1]))),
-             fmaf(o.x, R[6], fmaf(o.y, R[7], fmaf(o.z, R[8], t[2]))) };
-}
-
 // ---- bilinear fetch, clamp-to-edge per layer, exact fp32 weights ------------------------
 struct BilIdx { int i00, i10, i01, i11; float a, b; };
 __device__ __forceinline__ BilIdx bil_index(float x, float y, int w, int h) {
@@ -171,14 +157,6 @@ __device__ __forceinline__ float bilinear1(const float* __restrict__ img, int w,
     BilIdx k = bil_index(x, y, w, h);
     float w00 = (1.f - k.a) * (1.f - k.b), w10 = k.a * (1.f - k.b), w01 = (1.f - k.a) * k.b, w11 = k.a * k.b;
     return w00 * img[k.i00] + w10 * img[k.i10] + w01 * img[k.i01] + w11 * img[k.i11];
-}
-
-__device__ __forceinline__ float2 bilinear2_fast(const float2* __restrict__ img, int w, int h, float x, float y) {
-    BilIdx k = bil_index(x, y, w, h);
-    float2 t00 = img[k.i00], t10 = img[k.i10], t01 = img[k.i01], t11 = img[k.i11];
-    float tx = fmaf(k.a, t10.x - t00.x, t00.x), ty = fmaf(k.a, t10.y - t00.y, t00.y);
-    float bx = fmaf(k.a, t11.x - t01.x, t01.x), by = fmaf(k.a, t11.y - t01.y, t01.y);
-    return make_float2(fmaf(k.b, bx - tx, tx), fmaf(k.b, by - ty, ty));
 }
 
 // ---- XCD-aware workgroup order ---------------------------------------------------------------
