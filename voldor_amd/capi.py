@@ -46,6 +46,12 @@ class VoldorHipError(RuntimeError):
 def lib() -> C.CDLL:
     global _lib
     if _lib is None:
+        path = os.environ.get("VOLDOR_HIP_LIB", LIB_PATH)  # A/B runs of two builds on one box (scripts/ab.sh)
+        if path != LIB_PATH:
+            _lib = C.CDLL(path)
+            _lib.vk_version.restype = C.c_char_p
+            _lib.vk_get_rand_epoch.restype = C.c_uint
+            return _lib
         if not os.path.exists(LIB_PATH):
             raise VoldorHipError(
                 f"{LIB_PATH} not found: build it with `python -m voldor_amd.build` (needs hipcc). "
