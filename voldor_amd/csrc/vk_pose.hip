@@ -722,6 +722,7 @@ template <bool DEFER>
 __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
                                                                   int n_poses, ModeParams mp, CamState* cam, PoseBlock* P, int cam_idx,
                                                                   const int* __restrict__ n_points_dev, float* __restrict__ handoff) {
+#pragma clang fp contract(fast)  // kernel-weighted sums: not part of the solver's exact-rounding contract (file-wide: off)
     __shared__ RedBuf rb;
     __shared__ int s_cnt[SPT_MAX][16];
     __shared__ float s_pick[6];
