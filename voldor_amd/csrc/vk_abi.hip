@@ -19,6 +19,8 @@ int Context::init(int dev) {
     VK_CHECK(hipEventCreate(&ev1));
     VK_CHECK(hipEventCreate(&ev2));
     VK_CHECK(hipEventCreate(&ev3));
+    VK_CHECK(hipEventCreateWithFlags(&ev_cams, hipEventDisableTiming));
+    VK_CHECK(hipHostMalloc((void**)&h_cams, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
     return 0;
 }
 void Context::destroy() {
@@ -31,8 +33,11 @@ void Context::destroy() {
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev2) (void)hipEventDestroy(ev2);
     if (ev3) (void)hipEventDestroy(ev3);
+    if (ev_cams) (void)hipEventDestroy(ev_cams);
+    if (h_cams) (void)hipHostFree(h_cams);
+    h_cams = nullptr;
     if (stream) (void)hipStreamDestroy(stream);
-    stream = nullptr; ev0 = ev1 = ev2 = ev3 = nullptr;
+    stream = nullptr; ev0 = ev1 = ev2 = ev3 = ev_cams = nullptr;
     od.pose_init = cp.pose_init = false;
 }
 

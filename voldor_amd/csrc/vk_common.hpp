@@ -44,6 +44,11 @@ struct PoseBlock {
     float ts[MAX_FRAMES][3];
     float dpRs[MAX_DISP_FRAMES][9];
     float dpts[MAX_DISP_FRAMES][3];
+    // number of flow frames still registered, decided ON THE DEVICE after the cameras of an EM iteration
+    // (k_decide_active, voldor.cpp:187-194): the depth kernels clamp their frame count to it, so the host can enqueue them
+    // before it has seen the decision itself.  B-inner callers pass the count by argument: MAX_FRAMES here.
+    int n_active;
+    int pad_[3];
 };
 
 // Per-camera state kept on the device (voldor/utils.h:31-45 Camera, minus OpenCV).
@@ -102,6 +107,8 @@ struct ImageSet {
         if (e) return e;
         if (!pose_init) {
             if (hipMemset(pose.p, 0, sizeof(PoseBlock)) != hipSuccess) return 1;
+            const int all = MAX_FRAMES;
+            if (hipMemcpy(&pb()->n_active, &all, sizeof(int), hipMemcpyHostToDevice) != hipSuccess) return 1;
             pose_init = true;
         }
         return 0;
@@ -146,6 +153,8 @@ struct Context {
     bool prof = false;
     std::map<std::string, ProfEntry> prof_acc;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // outer / inner scope
+    hipEvent_t ev_cams = nullptr;  // "camera records of this EM iteration are on the host"
+    CamState* h_cams = nullptr;    // pinned staging for that copy (a pageable destination would make the copy synchronous)
     int ensure_n_points() { return n_points.reserve(sizeof(int) * 4); }
     int init(int dev);
     void destroy();

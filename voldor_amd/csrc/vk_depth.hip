@@ -26,6 +26,12 @@ struct Img {
     int N, N_dp, w, h;
     float lambda, omega, inv_arf, basefocal, disp_delta, delta;
 };
+// Frames still registered: the launch-time count clamped by the device-side decision of this EM iteration
+// (PoseBlock::n_active).  Returns false when nothing is left to evaluate (window lost, no priors).
+__device__ __forceinline__ bool clamp_active(Img& I) {
+    I.N = min(I.N, I.P->n_active);
+    return I.N + I.N_dp > 0;
+}
 
 // compute_pixel_cost, optimize_depth.cu:140-198.
 // Three phases so that the N bilinear gathers of one hypothesis are all in flight together instead
@@ -99,6 +105,7 @@ __device__ __forceinline__ static float pixel_cost(const Img& I, int px, int py,
 // ---- cost map + all random samples, fused (optimize_depth.cu:279-284 + :269-277 x n_rand) ----
 template <int NMAX>
 __global__ __launch_bounds__(256) static void k_cost_rand(Img I, int n_rand, uint32_t epoch0, float range_factor) {
+    if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
     const int y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
@@ -129,6 +136,7 @@ __device__ __forceinline__ static void try_depth(const Img& I, int x, int y, flo
 // 1 T2B, 2 R2L, 3 B2T.
 template <int NMAX>
 __global__ __launch_bounds__(256) static void k_global_prop_sites(Img I, int dir, int step, int nsites) {
+    if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int s = (tile % gridDim.x) * blockDim.x + threadIdx.x;  // site index along the pass direction
     const int l = tile / gridDim.x;                               // line (row for 0/2, column for 1/3)
@@ -141,6 +149,7 @@ __global__ __launch_bounds__(256) static void k_global_prop_sites(Img I, int dir
 // step==1: a true serial chain per line (not used by any shipped config; kept for parity)
 template <int NMAX>
 __global__ static void k_global_prop_serial(Img I, int dir) {
+    if (!clamp_active(I)) return;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (dir == 0 || dir == 2) {
         if (l >= I.h) return;
@@ -246,6 +255,7 @@ __device__ __forceinline__ ChainGeom chain_geom(int w, int h, int dir, int width
 // Fallback for segments longer than one wave can hold (width > 65): one thread walks one chain.
 template <int NMAX>
 __global__ __launch_bounds__(64) static void k_local_serial(Img I, int dir, int width) {
+    if (!clamp_active(I)) return;
     const int line = blockIdx.x * 64 + threadIdx.x;
     if (line >= ((dir == 0 || dir == 2) ? I.h : I.w)) return;
     const ChainGeom cg = chain_geom(I.w, I.h, dir, width, line, blockIdx.y);
@@ -263,6 +273,7 @@ __global__ __launch_bounds__(64) static void k_local_serial(Img I, int dir, int 
 // exactly the cost step p evaluates whenever its predecessor was NOT replaced in this pass.
 template <int NMAX>
 __global__ __launch_bounds__(256) static void k_local_table(Img I, int dir, int width, float* __restrict__ tbl) {
+    if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63), y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
     if (x >= I.w || y >= I.h) return;
@@ -284,6 +295,7 @@ __global__ __launch_bounds__(256) static void k_local_table(Img I, int dir, int 
 // step-by-step chain, but the dependent latency is one evaluation per RUN instead of one per STEP
 // (measured replacement rates: ~40 % of the steps in the first EM iteration, ~6 % later).
 __global__ __launch_bounds__(64) static void k_local_runs(Img I, int dir, int width, const float* __restrict__ tbl) {
+    if (!clamp_active(I)) return;
     const int lane = threadIdx.x, g = lane >> 3, sub = lane & 7;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);  // (line, segment), segment-major
     const ChainGeom cg = chain_geom(I.w, I.h, dir, width, tile % gridDim.x, tile / gridDim.x);
@@ -329,6 +341,7 @@ __global__ __launch_bounds__(64) static void k_local_runs(Img I, int dir, int wi
 // test of voldor.cpp:171 then needs no D2H of the maps).  Same three-phase structure as pixel_cost.
 template <int NMAX>
 __global__ __launch_bounds__(256) static void k_update_rigidness(Img I, float* __restrict__ partial) {
+    if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
     const int y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
@@ -393,8 +406,9 @@ __global__ __launch_bounds__(256) static void k_update_rigidness(Img I, float* _
     }
 }
 // fixed-order second stage: cams[f].pose_rigidness_density = sum(partial[f][:]) / npx
-__global__ static void k_reduce_density(const float* __restrict__ partial, int nblk, int npx, CamState* cams) {
+__global__ static void k_reduce_density(const float* __restrict__ partial, int nblk, int npx, CamState* cams, const PoseBlock* P) {
     const int f = blockIdx.x;
+    if (f >= P->n_active) return;
     __shared__ float s[4];
     float acc = 0.f;
     for (int i = threadIdx.x; i < nblk; i += 256) acc += partial[(size_t)f * nblk + i];
@@ -493,8 +507,9 @@ __device__ __forceinline__ void fb_incoming(const FbMat* sF, const FbMat* sB, in
 // Row pass: thread = (row, segment), segments of a row on adjacent lanes -> a wave reads whole contiguous row
 // pieces (160 bytes per lane).  256 threads = floor(256/S) rows.
 template <bool VEC4>
-__global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps, int w, int h, int S, float e0, float p) {
+__global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps, int w, int h, int S, float e0, float p, const int* __restrict__ n_dev) {
     __shared__ FbMat sF[256], sB[256];
+    if (n_dev && (int)blockIdx.y >= *n_dev) return;  // map of a frame the device-side decision has dropped
     const int lpb = 256 / S, tid = threadIdx.x;
     const int ll = tid / S, seg = tid - ll * S, row = blockIdx.x * lpb + ll;
     const bool live = ll < lpb && row < h;
@@ -534,8 +549,9 @@ __global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps
 // Column pass: thread = (segment, column); FB_CW adjacent columns share a workgroup, so every access is a
 // contiguous 64-byte row piece and a workgroup is FB_CW * S threads (S <= 64).
 constexpr int FB_CW = 16;
-__global__ __launch_bounds__(1024) static void k_fb_cols(float* __restrict__ maps, int w, int h, int S, float e0, float p) {
+__global__ __launch_bounds__(1024) static void k_fb_cols(float* __restrict__ maps, int w, int h, int S, float e0, float p, const int* __restrict__ n_dev) {
     __shared__ FbMat sF[1024], sB[1024];
+    if (n_dev && (int)blockIdx.y >= *n_dev) return;
     const int tid = threadIdx.x, seg = tid / FB_CW, cl = tid - seg * FB_CW, col = blockIdx.x * FB_CW + cl;
     const bool live = col < w;
     const int r0 = seg * FB_SEG, n = live ? min(FB_SEG, h - r0) : 0;
@@ -557,7 +573,7 @@ __global__ __launch_bounds__(1024) static void k_fb_cols(float* __restrict__ map
     for (int k = 0; k < FB_SEG; k++) if (k < n) m[(size_t)(r0 + k) * w] = e[k];
 }
 
-int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob) {
+int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev) {
     if (n_maps <= 0) return 0;
     const int Sr = (w + FB_SEG - 1) / FB_SEG, Sc = (h + FB_SEG - 1) / FB_SEG;
     if (Sr > 256 || Sc * FB_CW > 1024) {
@@ -566,9 +582,9 @@ int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0
     }
     const int lpb = 256 / Sr;
     const bool vec4 = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(maps) % 16) == 0;
-    if (vec4) hipLaunchKernelGGL(k_fb_rows<true>, dim3((h + lpb - 1) / lpb, n_maps), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob);
-    else hipLaunchKernelGGL(k_fb_rows<false>, dim3((h + lpb - 1) / lpb, n_maps), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob);
-    hipLaunchKernelGGL(k_fb_cols, dim3((w + FB_CW - 1) / FB_CW, n_maps), dim3(FB_CW * Sc), 0, c->stream, maps, w, h, Sc, s0_ems_prob, no_change_prob);
+    if (vec4) hipLaunchKernelGGL(k_fb_rows<true>, dim3((h + lpb - 1) / lpb, n_maps), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob, n_dev);
+    else hipLaunchKernelGGL(k_fb_rows<false>, dim3((h + lpb - 1) / lpb, n_maps), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob, n_dev);
+    hipLaunchKernelGGL(k_fb_cols, dim3((w + FB_CW - 1) / FB_CW, n_maps), dim3(FB_CW * Sc), 0, c->stream, maps, w, h, Sc, s0_ems_prob, no_change_prob, n_dev);
     VK_CHECK_LAST();
     return 0;
 }
@@ -597,8 +613,8 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
     }
     if (!p.update_rigidness_only) {
         if (p.fb_smooth) {
-            if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob)) return e;
-            if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob)) return e;
+            if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active)) return e;
+            if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e;
         }
         if (c->prof) prof_begin_inner(c);
         hipLaunchKernelGGL(k_cost_rand<NMAX>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
@@ -641,7 +657,7 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
     hipLaunchKernelGGL(k_update_rigidness<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
     if (p.N > 0)
         hipLaunchKernelGGL(k_reduce_density, dim3(p.N), dim3(256), 0, c->stream, c->rig_partial.as<float>(), nblk, w * h,
-                           c->cams.as<CamState>());
+                           c->cams.as<CamState>(), S.pb());
     VK_CHECK_LAST();
     return 0;
 }

@@ -15,7 +15,7 @@ struct ModeParams {
 // vk_depth.hip
 int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p);
 int cost_map_device(Context* c, ImageSet& S, const OdParams& p);
-int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob);
+int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr);
 int fill_device(Context* c, float* p, float v, size_t n);
 int scale_device(Context* c, float* p, const float* s_dev, size_t n);
 int disp_to_depth_device(Context* c, const float* disp, float* out, float bf, size_t n);
@@ -32,6 +32,8 @@ int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* ca
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int world_scale_device(Context* c, PoseBlock* P, CamState* cams, int n_flows, float* scale_dev);
+int decide_active_device(Context* c, PoseBlock* P, const CamState* cams, int n_flows, int allow_trunc, float trunc_rigidness_density,
+                         float trunc_sample_density);
 
 // vk_bootstrap.hip
 int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, float cx, float cy, CamState* cam0_dev);

@@ -1106,6 +1106,8 @@ int robust_gaussian_device(Context* c, const float* space_dev, int N, const Mode
 // normalize_world_scale on the device (voldor.cpp:309-317): scale = n_flows / sum ||t_i||
 __global__ static void k_world_scale(PoseBlock* P, CamState* cams, int n_flows, float* scale_out) {
     if (threadIdx.x != 0) return;
+    n_flows = min(n_flows, P->n_active);  // frames dropped by this iteration's decision do not count
+    if (n_flows <= 0) { *scale_out = 1.f; return; }  // window lost: nothing to normalise (deviation D6)
     float ws = 0.f;
     for (int i = 0; i < n_flows; i++) {
         const float* t = P->ts[i];
@@ -1115,6 +1117,26 @@ __global__ static void k_world_scale(PoseBlock* P, CamState* cams, int n_flows, 
     for (int i = 0; i < n_flows; i++)
         for (int d = 0; d < 3; d++) { P->ts[i][d] *= s; cams[i].t[d] = P->ts[i][d]; }
     *scale_out = s;
+}
+// voldor.cpp:171-194 on the device: the first camera that failed, was not allowed to run (rigidness density) or is not
+// confident enough truncates the window at its index.  The host applies the same rule to its copy of the records.
+__global__ static void k_decide_active(PoseBlock* P, const CamState* cams, int n_flows, int allow_trunc, float trunc_rigidness_density,
+                                       float trunc_sample_density) {
+    if (threadIdx.x != 0) return;
+    int n = n_flows;
+    for (int i = 0; i < n_flows; i++) {
+        int ok = 0;
+        if (!allow_trunc || cams[i].pose_rigidness_density > trunc_rigidness_density) ok = cams[i].success;
+        if (!ok || (allow_trunc && cams[i].pose_density < trunc_sample_density)) { n = i; break; }
+    }
+    P->n_active = n;
+}
+int decide_active_device(Context* c, PoseBlock* P, const CamState* cams, int n_flows, int allow_trunc, float trunc_rigidness_density,
+                         float trunc_sample_density) {
+    hipLaunchKernelGGL(k_decide_active, dim3(1), dim3(64), 0, c->stream, P, cams, n_flows, allow_trunc, trunc_rigidness_density,
+                       trunc_sample_density);
+    VK_CHECK_LAST();
+    return 0;
 }
 int world_scale_device(Context* c, PoseBlock* P, CamState* cams, int n_flows, float* scale_dev) {
     hipLaunchKernelGGL(k_world_scale, dim3(1), dim3(64), 0, c->stream, P, cams, n_flows, scale_dev);

@@ -120,6 +120,7 @@ struct Voldor {
         if (int e = fill_device(c, S.rig.as<float>(), 1.f, npx * N)) return e;
         PoseBlock pb;
         memset(&pb, 0, sizeof pb);
+        pb.n_active = N;
         pb.K4[0] = cfg.fx; pb.K4[1] = cfg.cx; pb.K4[2] = cfg.fy; pb.K4[3] = cfg.cy;
         pb.K4i[0] = 1.f / cfg.fx; pb.K4i[1] = -cfg.cx / cfg.fx; pb.K4i[2] = 1.f / cfg.fy; pb.K4i[3] = -cfg.cy / cfg.fy;
         for (int i = 0; i < MAX_FRAMES; i++) { pb.Rs[i][0] = pb.Rs[i][4] = pb.Rs[i][8] = 1.f; pb.dpRs[i][0] = pb.dpRs[i][4] = pb.dpRs[i][8] = 1.f; }
@@ -193,19 +194,29 @@ struct Voldor {
         return 0;
     }
 
-    // voldor.cpp:164-201.  The reference decides after every camera (on the host) whether to go on; here
-    // all cameras of the iteration are enqueued back to back and the host looks at the per-camera
-    // records once.  That is equivalent: a camera that fails or is skipped truncates the window at
-    // its index, so whatever the speculatively executed later cameras wrote (their own pose slots
-    // only) is never read again.
-    int optimize_cameras() {
+    // voldor.cpp:164-201.  The reference decides after every camera (on the host) whether to go on; here all cameras of
+    // the iteration are enqueued back to back, the truncation rule runs ON THE DEVICE (k_decide_active -> PoseBlock::
+    // n_active, which the depth kernels clamp to), and the host applies the same rule to its copy of the records only
+    // after it has already enqueued this iteration's depth half: the GPU never waits for the host decision.
+    // Equivalent to the reference order: a camera that fails or is skipped truncates the window at its index, so whatever
+    // the speculatively executed later cameras wrote (their own pose slots only) is never read again.
+    int enqueue_cameras() {
         const bool allow_trunc = iters_cur > cfg.no_trunc_iters;
         const bool rg = cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0);
         for (int i = 0; i < n_flows; i++)
             if (int e = optimize_camera_pose(i, rg)) return e;
+        if (int e = decide_active_device(c, c->od.pb(), dcams(), n_flows, allow_trunc ? 1 : 0, cfg.trunc_rigidness_density,
+                                         cfg.trunc_sample_density))
+            return e;
         // rigidness densities (reduced on the device by the last optimize_depth, voldor.cpp:171) and results
-        VK_CHECK(hipMemcpyAsync(hcams, c->cams.p, sizeof(CamState) * n_flows, hipMemcpyDeviceToHost, c->stream));
-        VK_CHECK(hipStreamSynchronize(c->stream));
+        VK_CHECK(hipMemcpyAsync(c->h_cams, c->cams.p, sizeof(CamState) * n_flows, hipMemcpyDeviceToHost, c->stream));
+        VK_CHECK(hipEventRecord(c->ev_cams, c->stream));
+        return 0;
+    }
+    int finish_cameras() {
+        const bool allow_trunc = iters_cur > cfg.no_trunc_iters;
+        VK_CHECK(hipEventSynchronize(c->ev_cams));
+        memcpy(hcams, c->h_cams, sizeof(CamState) * n_flows);
         for (int i = 0; i < n_flows; i++) {
             int ok = 0;
             if (!allow_trunc || hcams[i].pose_rigidness_density > cfg.trunc_rigidness_density) ok = hcams[i].success;
@@ -245,9 +256,11 @@ struct Voldor {
         }
         while (iters_remain > 0 && n_flows > 0) {
             iters_cur++; iters_remain--;
-            if (int e = optimize_cameras()) return e;
+            if (int e = enqueue_cameras()) return e;
+            // the depth half is enqueued with the pre-decision frame count; on the device it runs with n_active
             if (int e = optimize_depth(cfg.optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY)) return e;
-            if (cfg.norm_world_scale && n_dp == 0 && n_flows > 0) { if (int e = normalize_world_scale()) return e; }
+            if (cfg.norm_world_scale && n_dp == 0) { if (int e = normalize_world_scale()) return e; }
+            if (int e = finish_cameras()) return e;
         }
         return 0;
     }
