@@ -473,7 +473,15 @@ __device__ static bool rg_prepare_wave(float* covar_half, float* cinv_half, int 
 // The same prepare step with the matrices in LDS (A, B: 36 doubles each) and one lane per element:
 // a handful of registers instead of ~100, for kernels whose register budget is pinned elsewhere.
 // Element updates are independent within a step -> still bit-identical to the serial LU.
-__device__ __forceinline__ bool rg_prepare_lds(float* covar_half, float* cinv_half, float lambda, bool regularise, double* lds72) {
+// `warm`: lds72[36..71] still holds the inverse this function produced for the previous iteration's covariance.  The
+// gate tightens by a few percent per iteration, so that inverse X is a good start for the Newton-Schulz iteration
+// X <- X + X (I - A X): every lane forms one element of each 6x6 product (6 multiply-adds, reads in one LDS batch), the
+// residual shrinks quadratically, ~4 updates reach 1e-12.  ~2.5k cycles against ~9k for the LU, whose pivot steps and
+// divisions are a serial fp64 chain.  The result is the same inverse to ~1e-13 relative (it is rounded to float
+// afterwards); if the residual of the start value is not small (first iterations) the LU runs instead.  ||I - A X|| < 1
+// with X positive definite implies det A > 0, the condition the LU path checks explicitly.
+__device__ __forceinline__ bool rg_prepare_lds(float* covar_half, float* cinv_half, float lambda, bool regularise, double* lds72,
+                                               bool warm = false) {
     // One lane per element (r,c); the lane keeps its own A and B element in registers, LDS is the exchange medium.
     // This runs on ONE wave while the other 15 wait, so what counts is the number of dependent LDS round trips:
     // every step issues its reads as one batch (pivot column; then both candidate rows), 3 trips per pivot instead
@@ -496,10 +504,47 @@ __device__ __forceinline__ bool rg_prepare_lds(float* covar_half, float* cinv_ha
         }
         a = full; b = (r == c) ? 1.0 : 0.0;
         __builtin_amdgcn_wave_barrier();
-        if (act) { A[lane] = a; B[lane] = b; }
+        if (act) A[lane] = a;
         if (act && r >= c) covar_half[(r * r + r) / 2 + c] = (float)full;
         __builtin_amdgcn_wave_barrier();
     }
+    if (warm) {
+        double* E = lds72 + 72;
+        double x = act ? B[lane] : 0.0;
+        bool done = false, fallback = false;
+#pragma unroll 1
+        for (int step = 0; step < 8 && !done; step++) {
+            double ar[n], xc[n];
+#pragma unroll
+            for (int k = 0; k < n; k++) { ar[k] = A[r * n + k]; xc[k] = B[k * n + c]; }  // one batch
+            double y = 0.0;
+#pragma unroll
+            for (int k = 0; k < n; k++) y += ar[k] * xc[k];
+            const double e = (r == c ? 1.0 : 0.0) - y;
+            const double ae = act ? fabs(e) : 0.0;
+            if (step == 0 && __ballot(!(ae < 0.3)) != 0ull) { fallback = true; break; }  // also catches NaN
+            done = __ballot(ae > 1e-6) == 0ull;  // the update below squares the residual
+            __builtin_amdgcn_wave_barrier();
+            if (act) E[lane] = e;
+            __builtin_amdgcn_wave_barrier();
+            double xr[n], ec[n];
+#pragma unroll
+            for (int k = 0; k < n; k++) { xr[k] = B[r * n + k]; ec[k] = E[k * n + c]; }
+            double u = 0.0;
+#pragma unroll
+            for (int k = 0; k < n; k++) u += xr[k] * ec[k];
+            x += u;
+            __builtin_amdgcn_wave_barrier();
+            if (act) B[lane] = x;
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (!fallback && done) {
+            if (act && r >= c) cinv_half[(r * r + r) / 2 + c] = (float)x;
+            return true;
+        }
+    }
+    if (act) B[lane] = b;
+    __builtin_amdgcn_wave_barrier();
     double det = 1.0;
 #pragma unroll 1
     for (int i = 0; i < n; i++) {
@@ -569,7 +614,7 @@ __device__ static bool robust_gaussian_block(const float* __restrict__ space, in
                                              float* mean /*LDS[6]*/, float* covar_half /*LDS[21]*/, float* cinv_half /*LDS[21]*/,
                                              BlockRed& br, float* o_density, int* o_iters) {
     __shared__ int s_flag;  // 0 continue, 2 unreliable
-    __shared__ double s_lu[72];
+    __shared__ double s_lu[108];
     const int tid = threadIdx.x;
     const int dc = (dims * dims + dims) / 2;
     float weight = 0.f;
@@ -578,7 +623,7 @@ __device__ static bool robust_gaussian_block(const float* __restrict__ space, in
     for (iter = 0; iter < mp.rg_max_iters; iter++) {
         if (tid < 64) {
             // 6-D (poses): the LDS variant, the same code k_pose_refit runs; other dimensions: the register variant
-            const bool ok = dims == 6 ? rg_prepare_lds(covar_half, cinv_half, mp.rg_covar_reg_lambda, iter > 0 && mp.rg_covar_reg_lambda > 0.f, s_lu)
+            const bool ok = dims == 6 ? rg_prepare_lds(covar_half, cinv_half, mp.rg_covar_reg_lambda, iter > 0 && mp.rg_covar_reg_lambda > 0.f, s_lu, iter > 0)
                                       : rg_prepare_wave(covar_half, cinv_half, dims, iter > 0 && mp.rg_covar_reg_lambda > 0.f, mp.rg_covar_reg_lambda);
             if (tid == 0) s_flag = ok ? 0 : 2;
         }
@@ -853,7 +898,7 @@ __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* _
     __shared__ int s_cnt[16];
     __shared__ float s_cinv[21], s_cov[21];
     __shared__ int s_flag;
-    __shared__ double s_lu[72];
+    __shared__ double s_lu[108];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (handoff[8] == 0.f) return;  // the mean-shift stage already reported failure
     const float sc = mp.rg_pose_scaling;
@@ -900,7 +945,7 @@ __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* _
     bool reliable = true;
     for (iter = 0; iter < mp.rg_max_iters; iter++) {
         if (tid < 64) {
-            const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, iter > 0 && mp.rg_covar_reg_lambda > 0.f, s_lu);
+            const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, iter > 0 && mp.rg_covar_reg_lambda > 0.f, s_lu, iter > 0);
             if (tid == 0) s_flag = ok ? 0 : 2;
         }
         __syncthreads();
