@@ -689,8 +689,9 @@ struct RedBuf { float w[2][16][28]; };
 // totals are broadcast inside the wave with v_readlane.  (Summing all NV*NW partials in every thread
 // makes the compiler batch NV*NW LDS loads into registers: 400+ VGPR spills in the refit kernel; a
 // second barrier for a shared total costs more than the redundant 16-term sums.)
+// allreduce_lanes: in every wave, lane k (< NV) returns the workgroup total of value k (other lanes 0)
 template <int NV, int NW = 16>
-__device__ __forceinline__ void allreduce_regs(float* v, RedBuf& rb, int parity) {
+__device__ __forceinline__ float allreduce_lanes(const float* v, RedBuf& rb, int parity) {
     constexpr int P = NV <= 8 ? 8 : 32;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float pv[P];
@@ -705,8 +706,16 @@ __device__ __forceinline__ void allreduce_regs(float* v, RedBuf& rb, int parity)
 #pragma unroll
         for (int j = 0; j < NW; j++) tot += rb.w[parity][j][lane];
     }
+    return tot;
+}
+__device__ __forceinline__ float lane_value(float v, int k) {  // wave-uniform k
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+template <int NV, int NW = 16>
+__device__ __forceinline__ void allreduce_regs(float* v, RedBuf& rb, int parity) {
+    const float tot = allreduce_lanes<NV, NW>(v, rb, parity);
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), k));
+    for (int k = 0; k < NV; k++) v[k] = lane_value(tot, k);
 }
 
 // hypotheses -> registers; returns the number of finite ones (geometry.cpp:156-165), rvec pre-scaled (:191)
@@ -896,7 +905,7 @@ __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* _
     __shared__ float xs[4][RF_N];
     __shared__ RedBuf rb;
     __shared__ int s_cnt[16];
-    __shared__ float s_cinv[21], s_cov[21];
+    __shared__ float s_cinv[21], s_cov[21], s_mean[6];
     __shared__ int s_flag;
     __shared__ double s_lu[108];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -989,18 +998,19 @@ __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* _
                 }
             }
         }
-        allreduce_regs<28>(acc, rb, parity); parity ^= 1;
-        weight = acc[0];
+        const float tot = allreduce_lanes<28>(acc, rb, parity); parity ^= 1;  // lane k of every wave: total of sum k
+        weight = lane_value(tot, 0);
         if (!isfinite(weight)) { reliable = false; break; }
         if (fabsf(weight / (float)used - prev_density) < mp.rg_epsilon) { reliable = true; break; }
-        // M-step (:234-246): mean and covariance of the gated set (no -1: it is regularised next)
-#pragma unroll
-        for (int d = 0; d < 6; d++) rg_mean[d] = acc[1 + d] / weight;
-        if (tid == 0) {  // s_cov was last read before the all-reduce barriers
-#pragma unroll
-            for (int k = 0; k < 21; k++) s_cov[k] = acc[7 + k] / weight;
+        // M-step (:234-246): mean and covariance of the gated set (no -1: it is regularised next).  One division per lane,
+        // where the totals sit (lanes 1..27 of wave 0), published through LDS with the barrier that ends the iteration.
+        if (wv == 0 && lane >= 1 && lane < 28) {
+            const float q = tot / weight;
+            if (lane < 7) s_mean[lane - 1] = q; else s_cov[lane - 7] = q;  // s_cov was last read before the all-reduce barrier
         }
         __syncthreads();
+#pragma unroll
+        for (int d = 0; d < 6; d++) rg_mean[d] = s_mean[d];
     }
     __syncthreads();
     if (tid == 0) {
