@@ -870,13 +870,15 @@ __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __
                 for (int d = 0; d < 6; d++) acc[1 + d] += wgt * x[k][d];
             }
         }
-        allreduce_regs<7>(acc, rb, parity); parity ^= 1;
-        conf = acc[0] / (float)used;
+        const float tot = allreduce_lanes<7>(acc, rb, parity); parity ^= 1;  // lane k: total of sum k
+        const float wsum = lane_value(tot, 0);
+        conf = wsum / (float)used;
         ms_iters = iter + 1;
+        const float quot = tot / wsum;  // lanes 1..6: the new mean, one division per wave instead of six per thread
         float disp = 0.f;
 #pragma unroll
         for (int d = 0; d < 6; d++) {
-            float m = acc[1 + d] / acc[0];
+            const float m = lane_value(quot, 1 + d);
             disp += (io_mean[d] - m) * (io_mean[d] - m);  // vs. the stale io mean on the first pass (SURVEY B-6)
             io_mean[d] = m; c_mean[d] = m;
         }
