@@ -962,9 +962,11 @@ __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* _
         __syncthreads();
         if (s_flag == 2) { reliable = false; break; }
         const float prev_density = weight / (float)used;
-        float ci[21];
+        float cs[21];
 #pragma unroll
-        for (int k = 0; k < 21; k++) ci[k] = s_cinv[k];
+        for (int d1 = 0; d1 < 6; d1++)
+#pragma unroll
+            for (int d2 = 0; d2 <= d1; d2++) cs[(d1 * d1 + d1) / 2 + d2] = (d1 == d2 ? 1.f : 2.f) * s_cinv[(d1 * d1 + d1) / 2 + d2];
         // e_step (fit_robust_gaussian.cu:56-97): gate, weight, weighted sample and weighted scatter about
         // the CURRENT mean in one pass -> one 28-value all-reduce per iteration
         float acc[28];
@@ -978,15 +980,13 @@ __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* _
                 float diff[6];
 #pragma unroll
                 for (int d = 0; d < 6; d++) diff[d] = xv[d] - rg_mean[d];
+                // z = d^T C d over the lower triangle (off-diagonal coefficients doubled in cs): 27 multiply-adds, not 42
                 float z = 0.f;
 #pragma unroll
                 for (int d1 = 0; d1 < 6; d1++) {
-                    float tmp = 0.f;
+                    float tmp = cs[(d1 * d1 + d1) / 2 + d1] * diff[d1];
 #pragma unroll
-                    for (int d2 = 0; d2 < 6; d2++) {
-                        const int hi = d1 >= d2 ? d1 : d2, lo = d1 >= d2 ? d2 : d1;
-                        tmp += ci[(hi * hi + hi) / 2 + lo] * diff[d2];
-                    }
+                    for (int d2 = 0; d2 < d1; d2++) tmp += cs[(d1 * d1 + d1) / 2 + d2] * diff[d2];
                     z += tmp * diff[d1];
                 }
                 if (sqrtf(z) < mp.rg_trunc_sigma) {
