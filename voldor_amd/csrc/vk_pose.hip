@@ -780,6 +780,7 @@ __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __
     __shared__ RedBuf rb;
     __shared__ int s_cnt[SPT_MAX][16];
     __shared__ float s_pick[6];
+    __shared__ int s_rank[SPT_MAX][MS_THREADS];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // successive pose? (voldor.cpp:177: pose_sample_count != 0), decided on the device
     const bool external_init = mp.use_external_init_mean < 0 ? (cam->pose_sample_count != 0) : (mp.use_external_init_mean != 0);
@@ -807,23 +808,26 @@ __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __
         float best = 0.f;
         float bestx[6] = { 0, 0, 0, 0, 0, 0 };
         bool have = false;
-        for (int trial = 0; trial < mp.ms_max_init_trials; trial++) {
-            const int target = (int)(rng3(RAND_SEED, (uint32_t)trial, 0x4D53u) % (uint32_t)used);
-            // locate the target-th finite hypothesis in index order (slot-major, then thread)
+        // rank of each of this thread's finite hypotheses in index order (slot-major, then thread), once
+        // (kept in LDS, own column: registers held across the trial loop would raise the pressure of the whole kernel)
+        {
             int base = 0;
 #pragma unroll
             for (int k = 0; k < SPT_MAX; k++) {
                 int wbase = base;
                 for (int j = 0; j < 16; j++) { if (j < wv) wbase += s_cnt[k][j]; base += s_cnt[k][j]; }
                 const unsigned long long b = __ballot((finmask >> k) & 1u);
-                if ((finmask >> k) & 1u) {
-                    int r = wbase + __popcll(b & ((1ull << lane) - 1ull));
-                    if (r == target) {
-#pragma unroll
-                        for (int d = 0; d < 6; d++) s_pick[d] = x[k][d];
-                    }
-                }
+                s_rank[k][tid] = ((finmask >> k) & 1u) ? wbase + __popcll(b & ((1ull << lane) - 1ull)) : -1;
             }
+        }
+        for (int trial = 0; trial < mp.ms_max_init_trials; trial++) {
+            const int target = (int)(rng3(RAND_SEED, (uint32_t)trial, 0x4D53u) % (uint32_t)used);
+#pragma unroll
+            for (int k = 0; k < SPT_MAX; k++)
+                if (s_rank[k][tid] == target) {  // the target-th finite hypothesis
+#pragma unroll
+                    for (int d = 0; d < 6; d++) s_pick[d] = x[k][d];
+                }
             __syncthreads();
             float c[6];
 #pragma unroll
