@@ -9,8 +9,9 @@
 //
 // Everything runs on the GPU, in the window's stream, with no host round trip:
 //   k_extract_corr   stride-4 correspondences
-//   k_boot_hyp       one lane per hypothesis: 9x9 normal matrix -> cyclic Jacobi (matrices in LDS,
-//                    [element][lane] so a wave touches consecutive banks) -> rank-2 projection
+//   k_boot_hyp       one lane per hypothesis: 8x9 constraint matrix -> null vector by complete-pivoting
+//                    elimination (matrices in LDS, [element][lane] so a wave touches consecutive banks)
+//                    -> rank-2 projection (3x3 Jacobi)
 //   k_boot_score     one workgroup per hypothesis: Sampson distances -> bitonic sort in LDS -> median
 //   k_boot_select    argmin, E -> (R,t) candidates, cheirality vote, pose -> PoseBlock / CamState
 //   k_depth_closed_form

@@ -4,11 +4,15 @@
 //
 // Launch structure per optimize_depth call (reference: 20+ launches, 10 of them streaming a
 // 48-byte RNG state per pixel):
-//   fb_rows / fb_cols           2 launches per map set (reference: 6), LDS-transposed rows
+//   fb_rows / fb_cols           2 launches per map set (reference: 6): one lane per 40-step line segment,
+//                               segment maps composed as 2x2 projective matrices, chained through LDS
 //   cost_rand                   1 launch: cost map + all n_rand samples, depth/cost in regs
 //   global_prop x4              1 launch each, one thread per candidate site (step>=2)
-//   local_prop  x4              1 launch each, one thread per (segment, line) chain
+//   local_table + local_runs x4 2 launches per pass: per-pixel candidate-cost table, then one wave per chain
+//                               resolving the serial chain run by run
 //   update_rigidness            1 launch (+ per-block rigidness sums for the density test)
+// Every per-pixel kernel clamps its frame count to PoseBlock::n_active (device-side truncation decision) and
+// remaps its workgroup id so that an XCD works on one band of the image (xcd_band_tile).
 #include "vk_common.hpp"
 #include "vk_device.hpp"
 

@@ -6,10 +6,11 @@
 //
 // Reference flow per camera per EM iteration: D2H of 6 MB of NaN-sparse maps, a 307k-iteration
 // host scan, H2D of the compacted list, 5 cudaMalloc/cudaFree, ~3 launches + 2 blocking D2H per
-// mean-shift iteration.  Here: collect -> wave-ballot ordered compaction -> one lane per pose
-// hypothesis -> ONE single-workgroup kernel that runs the whole mean-shift (and robust
-// Gaussian) iteration loop with shuffle/LDS reductions and writes the new pose straight into
-// the device PoseBlock.  Only a CamState record is ever read back.
+// mean-shift iteration.  Here: collect (NaN-marked correspondence maps, no compaction in the pipeline) -> four
+// lanes per pose hypothesis draw 4 valid pixels by rejection and solve P3P, one candidate root per lane -> ONE
+// single-workgroup kernel that runs the whole mean-shift (and, on the last EM iteration, a second one for the robust
+// Gaussian) iteration loop with DPP/LDS reductions and writes the new pose straight into the device PoseBlock.
+// Only a CamState record per camera is ever read back, once per EM iteration.
 #include "vk_common.hpp"
 #include "vk_device.hpp"
 #include "vk_p3p.hpp"
