@@ -11,6 +11,7 @@
  */
 #ifndef VOLDOR_HIP_H
 #define VOLDOR_HIP_H
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -77,6 +78,15 @@ int vk_voldor_device_batch(int n_windows, const float* const* flows, const float
                            float fx, float fy, float cx, float cy, float basefocal, int N, int N_dp, int w, int h,
                            const char* config, int* n_registered, float* poses, float* poses_covar,
                            float* const* depth, float* const* depth_conf);
+/* eval_covisibility (slam_py/slam_utils.py:18-53; the step after every VO call, voldor_slam.py:496-504) on the
+ * device: depth[h][w] and the optional 0/1 byte mask[h][w] (depth_conf > thresh) may be host or device pointers, T44 is
+ * the row-major 4x4 Tc1c2, K9 the row-major intrinsics.  o_counts (optional) receives {visible samples, occupied cells}. */
+int vk_eval_covisibility(const float* depth, const unsigned char* mask, const float* T44, const float* K9,
+                         int w, int h, int stride, float* o_score, int* o_counts);
+/* Middlebury .flo files (voldor/utils.cpp:23-41 load_flow; slam_py/flow_utils.py:10-34): out == NULL only reports
+ * the size.  0 ok, 1 cannot open, 2 bad magic / arguments, 3 buffer too small, 4 truncated. */
+int vk_read_flo(const char* path, int* w, int* h, float* out, size_t cap_floats);
+int vk_write_flo(const char* path, const float* flow, int w, int h);
 int vk_last_camera_stats(int* pose_sample_count, float* pose_density, float* pose_rigidness_density,
                          int* ms_iters, int* gu_iters, int n);
 /* bootstrap pieces (voldor/geometry.cpp:267-332) exposed for parity tests; host pointers */

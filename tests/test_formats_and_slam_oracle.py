@@ -1,0 +1,117 @@
+"""SURVEY.md 8(f)-3/4, CPU side: disk formats at the boundary and the oracle of the post-VO covisibility step, against
+vectors produced by the reference's own Python functions (tests/golden/gen_golden_slam.py)."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+GOLD = os.path.join(HERE, "golden")
+
+
+def _covis_cases():
+    z = np.load(os.path.join(GOLD, "ref_covis.npz"))
+    for i in range(int(z["n"])):
+        mask = z[f"mask_{i}"]
+        yield dict(w=int(z[f"w_{i}"]), h=int(z[f"h_{i}"]), stride=int(z[f"stride_{i}"]), depth=z[f"depth_{i}"], T=z[f"T_{i}"],
+                   K=z[f"K_{i}"], mask=None if mask.size == 0 else mask.astype(bool), score=float(z[f"score_{i}"]))
+
+
+def test_oracle_covisibility_reproduces_reference():
+    from oracle import orc_slam
+    n = 0
+    for c in _covis_cases():
+        s = orc_slam.eval_covisibility(c["depth"], c["T"], c["K"], c["mask"], c["stride"])
+        assert s == pytest.approx(c["score"], abs=1e-12), (n, s, c["score"])
+        n += 1
+    assert n == 24
+
+
+def test_flo_reader_matches_reference_bytes(tmp_path):
+    from voldor_amd import formats
+    want = np.load(os.path.join(GOLD, "ref_flo_values.npy"))
+    got = formats.load_flow(os.path.join(GOLD, "ref_flo.bin"))
+    np.testing.assert_array_equal(got, want)
+    p = str(tmp_path / "mine.flo")
+    formats.save_flow(p, want)
+    assert open(p, "rb").read() == open(os.path.join(GOLD, "ref_flo.bin"), "rb").read()  # byte-identical to flow_utils.save_flow
+    # header layout: float32 202021.25, int32 w, int32 h, little endian
+    assert struct.unpack("<fii", open(p, "rb").read(12)) == (202021.25, 9, 6)
+    bad = str(tmp_path / "bad.flo")
+    open(bad, "wb").write(struct.pack("<fii", 1.0, 9, 6) + b"\0" * 432)
+    assert formats.load_flow(bad) is None  # flow_utils.py:14-21
+    trunc = str(tmp_path / "trunc.flo")
+    open(trunc, "wb").write(open(p, "rb").read()[:100])
+    with pytest.raises(ValueError):
+        formats.load_flow(trunc)
+
+
+def test_flo_c_entry_points(tmp_path):
+    from voldor_amd import capi, formats
+    lib = capi.lib()
+    want = np.load(os.path.join(GOLD, "ref_flo_values.npy"))
+    w, h = C.c_int(0), C.c_int(0)
+    path = os.path.join(GOLD, "ref_flo.bin").encode()
+    assert lib.vk_read_flo(path, C.byref(w), C.byref(h), None, C.c_size_t(0)) == 0 and (w.value, h.value) == (9, 6)
+    buf = np.zeros((6, 9, 2), np.float32)
+    assert lib.vk_read_flo(path, C.byref(w), C.byref(h), buf.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(buf.size)) == 0
+    np.testing.assert_array_equal(buf, want)
+    assert lib.vk_read_flo(path, C.byref(w), C.byref(h), buf.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(10)) == 3
+    assert lib.vk_read_flo(b"/nonexistent/x.flo", C.byref(w), C.byref(h), None, C.c_size_t(0)) == 1
+    out = str(tmp_path / "c.flo")
+    assert lib.vk_write_flo(out.encode(), want.ctypes.data_as(C.POINTER(C.c_float)), 9, 6) == 0
+    assert open(out, "rb").read() == open(os.path.join(GOLD, "ref_flo.bin"), "rb").read()
+    bad = str(tmp_path / "bad.flo")
+    open(bad, "wb").write(struct.pack("<fii", 7.0, 9, 6))
+    assert lib.vk_read_flo(bad.encode(), C.byref(w), C.byref(h), None, C.c_size_t(0)) == 2
+
+
+def test_png_and_disparity_round_trip(tmp_path):
+    from voldor_amd import formats
+    rng = np.random.default_rng(5)
+    img16 = rng.integers(0, 65536, (13, 17)).astype(np.uint16)
+    img8 = rng.integers(0, 256, (5, 31)).astype(np.uint8)
+    for ft in range(5):  # every PNG scanline filter
+        p = str(tmp_path / f"f{ft}.png")
+        formats.write_png_gray(p, img16, ft)
+        np.testing.assert_array_equal(formats.read_png_gray(p), img16)
+        formats.write_png_gray(p, img8, ft)
+        np.testing.assert_array_equal(formats.read_png_gray(p), img8)
+    disp = rng.uniform(0, 200, (10, 12)).astype(np.float32)
+    p = str(tmp_path / "d.png")
+    formats.save_disparity_png(p, disp)
+    got = formats.load_disparity(p)  # voldor_slam.py:305-307: uint16 / 256
+    assert got.dtype == np.float32 and np.abs(got - disp).max() <= 0.5 / 256 + 1e-6
+    fl = np.stack([-disp, np.zeros_like(disp)], -1)
+    formats.save_flow(str(tmp_path / "d.flo"), fl)
+    np.testing.assert_array_equal(formats.load_disparity(str(tmp_path / "d.flo")), disp)  # :302-304
+    with pytest.raises(ValueError):
+        formats.load_disparity(str(tmp_path / "d.tiff"))
+
+
+def test_pose_text_formats(tmp_path):
+    from voldor_amd import formats, synth
+    rng = np.random.default_rng(9)
+    Ts = []
+    for _ in range(5):
+        T = np.eye(4)
+        T[:3, :3] = synth.rodrigues(rng.normal(0, 1.0, 3))
+        T[:3, 3] = rng.normal(0, 2, 3)
+        Ts.append(T)
+    p = str(tmp_path / "kitti.txt")
+    formats.save_poses(p, Ts, "KITTI")
+    np.testing.assert_allclose(formats.load_poses_kitti(p), np.stack(Ts), rtol=0, atol=0)  # str(float) round-trips exactly
+    p = str(tmp_path / "ta.txt")
+    formats.save_poses(p, Ts, "TartanAir")
+    rows = np.loadtxt(p)
+    assert rows.shape == (5, 7)
+    for T, r in zip(Ts, rows):  # tz tx ty qz qx qy qw (voldor_slam.py:327)
+        np.testing.assert_allclose(r[:3], [T[2, 3], T[0, 3], T[1, 3]])
+        qx, qy, qz, qw = r[4], r[5], r[3], r[6]
+        assert abs(qx * qx + qy * qy + qz * qz + qw * qw - 1) < 1e-12
+        R = np.array([[1 - 2 * (qy * qy + qz * qz), 2 * (qx * qy - qz * qw), 2 * (qx * qz + qy * qw)],
+                      [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
+                      [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
+        np.testing.assert_allclose(R, T[:3, :3], atol=1e-12)

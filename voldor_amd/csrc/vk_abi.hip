@@ -400,6 +400,37 @@ int vk_get_compacted_points(float* h_o_pts2, float* h_o_pts3, int max_points) {
     }
     return n;
 }
+// ---- Middlebury .flo at the boundary (voldor/utils.cpp:23-41 load_flow, slam_py/flow_utils.py:10-34) --------------
+// float32 magic 202021.25, int32 width, int32 height, float32 [h][w][2].  vk_read_flo: out == NULL only reports the size;
+// returns 0, or 1 cannot open, 2 bad magic, 3 buffer too small (cap_floats), 4 truncated file.
+int vk_read_flo(const char* path, int* w, int* h, float* out, size_t cap_floats) {
+    FILE* fs = fopen(path, "rb");
+    if (!fs) return 1;
+    float magic = 0.f; int ww = 0, hh = 0;
+    const bool head = fread(&magic, sizeof(float), 1, fs) == 1 && fread(&ww, sizeof(int), 1, fs) == 1 && fread(&hh, sizeof(int), 1, fs) == 1;
+    if (!head || magic != 202021.25f || ww <= 0 || hh <= 0) { fclose(fs); return head ? 2 : 4; }
+    if (w) *w = ww;
+    if (h) *h = hh;
+    int rc = 0;
+    if (out) {
+        const size_t n = (size_t)ww * hh * 2;
+        if (cap_floats < n) rc = 3;
+        else if (fread(out, sizeof(float), n, fs) != n) rc = 4;
+    }
+    fclose(fs);
+    return rc;
+}
+int vk_write_flo(const char* path, const float* flow, int w, int h) {
+    if (!flow || w <= 0 || h <= 0) return 2;
+    FILE* fs = fopen(path, "wb");
+    if (!fs) return 1;
+    const float magic = 202021.25f;
+    const size_t n = (size_t)w * h * 2;
+    const bool ok = fwrite(&magic, sizeof(float), 1, fs) == 1 && fwrite(&w, sizeof(int), 1, fs) == 1 && fwrite(&h, sizeof(int), 1, fs) == 1 &&
+                    fwrite(flow, sizeof(float), n, fs) == n;
+    fclose(fs);
+    return ok ? 0 : 4;
+}
 int vk_set_rand_epoch(unsigned epoch) {
     Context* c = default_context();
     if (!c) return (int)hipErrorNoDevice;
