@@ -74,3 +74,24 @@ DLL_EXPORT int optimize_depth_gpu(
 	bool fb_smooth, float s0_ems_prob, float no_change_prob,
 	float range_factor,
 	bool update_rigidness_only);
+
+// replaces gpu-kernels/align_frame.cu:443-554 (decl. gpu_kernels.h:60-66): uploads N key-frames (images optional:
+// NULL or crw <= 0 = geometry only), derives normals and image gradients on the device
+DLL_EXPORT int align_frame_init_gpu(
+	float* h_images[],
+	float* h_depths[],
+	float* h_weights[],
+	float* h_K,
+	float vbf, float crw,
+	int N, int w, int h);
+
+// replaces gpu-kernels/align_frame.cu:414-441 (decl. gpu_kernels.h:68-74): residual [h][w] and Jacobian [h][w*9]
+// (rvec, tvec, depth scale, colour scale, colour offset of the reference frame) of frame ref_fid against tar_fid
+DLL_EXPORT int align_frame_eval_gpu(
+	int ref_fid,
+	int tar_fid,
+	const float* h_params_ref,
+	const float* h_params_tar,
+	float* h_o_residual, float* h_o_jacobian,
+	const bool apply_weights = true);
+

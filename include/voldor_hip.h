@@ -78,6 +78,12 @@ int vk_voldor_device_batch(int n_windows, const float* const* flows, const float
                            float fx, float fy, float cx, float cy, float basefocal, int N, int N_dp, int w, int h,
                            const char* config, int* n_registered, float* poses, float* poses_covar,
                            float* const* depth, float* const* depth_conf);
+/* align_frame_init_gpu / align_frame_eval_gpu (gpu-kernels/gpu_kernels.h:60-74; the mapping back-end's residual and
+ * Jacobian maps), `bool` -> `int`. */
+int vk_align_frame_init_gpu(float** h_images, float** h_depths, float** h_weights, float* h_K, float vbf, float crw,
+                            int N, int w, int h);
+int vk_align_frame_eval_gpu(int ref_fid, int tar_fid, const float* h_params_ref, const float* h_params_tar,
+                            float* h_o_residual, float* h_o_jacobian, int apply_weights);
 /* eval_covisibility (slam_py/slam_utils.py:18-53; the step after every VO call, voldor_slam.py:496-504) on the
  * device: depth[h][w] and the optional 0/1 byte mask[h][w] (depth_conf > thresh) may be host or device pointers, T44 is
  * the row-major 4x4 Tc1c2, K9 the row-major intrinsics.  o_counts (optional) receives {visible samples, occupied cells}. */

@@ -132,4 +132,12 @@ int orc_get_max_threads(void);
 #ifdef __cplusplus
 }
 #endif
+/* ---- frame alignment maps (gpu-kernels/align_frame.cu), orc_align.c ---- */
+typedef struct orc_align orc_align;
+void orc_rot_with_rvec(const float* p3, const float* rvec, float* out3, float* J_rvec9, float* J_p39);
+orc_align* orc_align_init(const float* images, const float* depths, const float* weights, const float* K9, float vbf, float crw, int N, int w, int h);
+void orc_align_eval(const orc_align* A, int ref_fid, int tar_fid, const float* params_ref9, const float* params_tar9, float* residual,
+                    float* jacobian, int apply_weights);
+void orc_align_free(orc_align* A);
+
 #endif

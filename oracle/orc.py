@@ -306,3 +306,38 @@ def voldor(flows, fx, fy, cx, cy, basefocal=0.0, disparity=None, disparity_pconf
         raise RuntimeError(f"orc_voldor failed rc={rc}")
     n = nreg.value
     return {"n_registered": n, "poses": poses[:n], "poses_covar": covar[:n], "depth": depth, "depth_conf": conf}
+
+
+# ---- frame alignment maps (orc_align.c; gpu-kernels/align_frame.cu) ----
+def rot_with_rvec(p3, rvec):
+    p3 = f32(p3); rvec = f32(rvec)
+    out = np.zeros(3, np.float32); jw = np.zeros((3, 3), np.float32); jp = np.zeros((3, 3), np.float32)
+    lib().orc_rot_with_rvec(_fp(p3), _fp(rvec), _fp(out), _fp(jw), _fp(jp))
+    return out, jw, jp
+
+
+class Align:
+    """orc_align_init / orc_align_eval (align_frame_init_gpu / align_frame_eval_gpu of gpu_kernels.h:60-74)."""
+
+    def __init__(self, images, depths, weights, K, vbf, crw):
+        depths = f32(depths); weights = f32(weights)
+        self.shape = depths.shape
+        N, h, w = depths.shape
+        images = None if images is None else f32(images)
+        L = lib()
+        L.orc_align_init.restype = C.c_void_p
+        self._h = C.c_void_p(L.orc_align_init(_fp(images), _fp(depths), _fp(weights), _fp(f32(np.asarray(K, np.float32).reshape(9))),
+                                               C.c_float(vbf), C.c_float(crw), N, w, h))
+
+    def eval(self, ref_fid, tar_fid, params_ref, params_tar, want_jacobian=True, apply_weights=True):
+        _, h, w = self.shape
+        res = np.zeros((h, w), np.float32)
+        jac = np.zeros((h, w, 9), np.float32) if want_jacobian else None
+        lib().orc_align_eval(self._h, int(ref_fid), int(tar_fid), _fp(f32(params_ref)), _fp(f32(params_tar)), _fp(res), _fp(jac), int(bool(apply_weights)))
+        return res, jac
+
+    def __del__(self):
+        try:
+            lib().orc_align_free(self._h)
+        except Exception:
+            pass

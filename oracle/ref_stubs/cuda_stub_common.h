@@ -22,3 +22,11 @@ static inline float __fmul_rn(float a, float b) { volatile float r = a * b; retu
 static inline float __frsqrt_rn(float x) { return (float)(1.0 / sqrt((double)x)); }
 using std::max;
 using std::min;
+
+/* CUDA vector types used by gpu-kernels/vops.h and the host/device helpers of align_frame.cu */
+struct float2 { float x, y; };
+struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
+static inline float2 make_float2(float x, float y) { float2 r = { x, y }; return r; }
+static inline float3 make_float3(float x, float y, float z) { float3 r = { x, y, z }; return r; }
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r = { x, y, z, w }; return r; }

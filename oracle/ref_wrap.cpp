@@ -18,6 +18,10 @@
 #include "lambdatwist/lambdatwist_p4p.h"   // -I/root/reference
 #include "gpu-kernels/residual_model.h"
 #include "gpu-kernels/rodrigues.h"
+#ifdef REF_ROT_INC   // rot_with_rvec of gpu-kernels/align_frame.cu:47-137, cut out of the .cu at build time into a temp file
+#include "gpu-kernels/vops.h"
+#include REF_ROT_INC
+#endif
 
 extern "C" {
 
@@ -69,4 +73,13 @@ void ref_rotmat_to_angle_axis(const float* R9, float* rvec3) {
     float R[3][3]; memcpy(R, R9, sizeof R);
     RotationMatrixToAngleAxis(R, rvec3);
 }
+#ifdef REF_ROT_INC
+// rot_with_rvec (align_frame.cu:47-137): rotated point, d/d rvec and d/d point (row-major 3x3 each)
+void ref_rot_with_rvec(const float* p3, const float* rvec, float* out3, float* J_rvec9, float* J_p39) {
+    float Jr[3][3], Jp[3][3];
+    float3 q = rot_with_rvec(make_float3(p3[0], p3[1], p3[2]), make_float3(rvec[0], rvec[1], rvec[2]), Jr, Jp);
+    out3[0] = q.x; out3[1] = q.y; out3[2] = q.z;
+    memcpy(J_rvec9, Jr, sizeof Jr); memcpy(J_p39, Jp, sizeof Jp);
+}
+#endif
 }

@@ -56,5 +56,25 @@ def main():
     print("wrote", len(cases), "covisibility cases and ref_flo.bin (", os.path.getsize(path), "bytes )")
 
 
+
+
+def gen_rot():
+    """rot_with_rvec of gpu-kernels/align_frame.cu:47-137 through oracle/_ref (built in place by `make -C oracle ref`)."""
+    import ctypes as C
+    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libvoldor_ref.so"))
+    F = C.POINTER(C.c_float)
+    rng = np.random.default_rng(4242)
+    n = 2000
+    p = rng.normal(0, 3, (n, 3)).astype(np.float32)
+    w = (rng.normal(0, 1, (n, 3)) * rng.choice([1e-5, 1e-3, 0.05, 0.5, 2.0], (n, 1))).astype(np.float32)
+    w[:20] = 0  # first-order branch
+    out = np.zeros((n, 3), np.float32); jw = np.zeros((n, 9), np.float32); jp = np.zeros((n, 9), np.float32)
+    for i in range(n):
+        ref.ref_rot_with_rvec(p[i].ctypes.data_as(F), w[i].ctypes.data_as(F), out[i].ctypes.data_as(F), jw[i].ctypes.data_as(F), jp[i].ctypes.data_as(F))
+    np.savez_compressed(os.path.join(HERE, "ref_rot.npz"), p=p, rvec=w, out=out, J_rvec=jw, J_p3=jp)
+    print("wrote ref_rot.npz", n)
+
+
 if __name__ == "__main__":
     main()
+    gen_rot()

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvoldor_hip.so")
-SOURCES = ["vk_abi.hip", "vk_depth.hip", "vk_pose.hip", "vk_bootstrap.hip", "vk_voldor.hip", "vk_hostcheck.hip", "vk_slam.hip"]
+SOURCES = ["vk_abi.hip", "vk_depth.hip", "vk_pose.hip", "vk_bootstrap.hip", "vk_voldor.hip", "vk_hostcheck.hip", "vk_slam.hip", "vk_align.hip"]
 # The pose half (one hypothesis per lane) must reproduce the reference's fp32/fp64 rounding
 # sequence to stay inside the pose tolerance (vk_p3p.hpp NUMERICS NOTE): no fma contraction there.
 # It is a few hundred microseconds of work per window, so this costs nothing measurable; the

@@ -127,6 +127,31 @@ def fb_smooth_gpu(maps, s0_ems_prob=0.5, no_change_prob=0.9):
     return rc, m
 
 
+def align_frame_init_gpu(images, depths, weights, K, vbf, crw):
+    """gpu_kernels.h:60-66.  images [N,h,w] or None, depths / weights [N,h,w], K 3x3."""
+    depths = f32(depths); weights = f32(weights)
+    N, h, w = depths.shape
+    images = None if images is None else f32(images)
+    PF = C.POINTER(C.c_float)
+
+    def table(a):
+        return None if a is None else (PF * N)(*[a[i].ctypes.data_as(PF) for i in range(N)])
+
+    Kf = f32(np.asarray(K, np.float32).reshape(9))
+    return capi.lib().vk_align_frame_init_gpu(table(images), table(depths), table(weights), fp(Kf), C.c_float(vbf), C.c_float(crw), N, w, h), (N, h, w)
+
+
+def align_frame_eval_gpu(shape, ref_fid, tar_fid, params_ref, params_tar, want_jacobian=True, apply_weights=True):
+    """gpu_kernels.h:68-74 -> rc, residual [h,w], jacobian [h,w,9] (None if not wanted)."""
+    _, h, w = shape
+    res = np.zeros((h, w), np.float32)
+    jac = np.zeros((h, w, 9), np.float32) if want_jacobian else None
+    pr = None if params_ref is None else f32(params_ref)
+    pt = None if params_tar is None else f32(params_tar)
+    rc = capi.lib().vk_align_frame_eval_gpu(int(ref_fid), int(tar_fid), fp(pr), fp(pt), fp(res), fp(jac), int(bool(apply_weights)))
+    return rc, res, jac
+
+
 def gblur_gpu(src, sigma, ksize=0):
     src = f32(src)
     d, h, w = src.shape
