@@ -154,3 +154,36 @@ def test_device_resident_call_matches_host_call():
     rot, tr = s.pose_errors(a["poses"], b["poses"])
     assert rot.max() < 1e-3 and tr.max() < 2e-2
     assert torch.isfinite(d).all()
+
+
+def test_slam_driver_call_replayed_verbatim():
+    """slam_py/voldor_slam.py:447-457 builds these kwargs and calls pyvoldor.voldor through functools.partial; the driver
+    itself needs cv2 / sklearn (absent here), so its call is replayed with the same keys, including the explicit Nones of
+    the monocular mode, and its result handling (:460-504) is applied to the returned dict."""
+    from functools import partial
+    from voldor_amd import pyvoldor, synth, slam_utils
+    sc = synth.make_scene(w=320, h=240, n_flows=4, fx=160, fy=160, cx=160, cy=120, seed=250)
+    fx, fy, cx, cy = sc["K"]
+    flows = [sc["flows"][i] for i in range(4)]  # the driver keeps a list of per-frame flows and stacks a window
+    py_voldor_kwargs = {
+        'flows': np.stack(flows[0:4], axis=0),
+        'fx': fx, 'fy': fy, 'cx': cx, 'cy': cy, 'basefocal': 0.5 * fx,
+        'disparity': None,
+        'depth_priors': None,
+        'depth_prior_pconfs': None,
+        'depth_prior_poses': None,
+        'config': '--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 4' + ' ' + ''}
+    vo_ret = partial(pyvoldor.voldor, **py_voldor_kwargs)()
+    assert set(vo_ret) >= {"n_registered", "poses", "poses_covar", "depth", "depth_conf"}
+    assert vo_ret["n_registered"] == 4 and vo_ret["poses"].shape == (4, 6) and vo_ret["poses_covar"].shape == (4, 6, 6)
+    assert vo_ret["depth"].dtype == np.float32 and vo_ret["depth"].shape == (240, 320)
+    # :496-504: accumulate Tc1c2 and stop when covisibility drops
+    K = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+    T_tmp = np.eye(4, dtype=np.float32)
+    scores = []
+    for i in range(vo_ret["n_registered"]):
+        Ti = np.eye(4, dtype=np.float32)
+        Ti[:3, :3] = synth.rodrigues(vo_ret["poses"][i, :3]); Ti[:3, 3] = vo_ret["poses"][i, 3:]
+        T_tmp = Ti @ T_tmp
+        scores.append(slam_utils.eval_covisibility(vo_ret["depth"], T_tmp, K, vo_ret["depth_conf"] > 0.5))
+    assert all(0.0 < s <= 1.0 for s in scores) and scores[0] >= scores[-1] - 1e-3  # the view drifts away monotonically
