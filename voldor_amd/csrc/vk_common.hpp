@@ -45,7 +45,7 @@ struct PoseBlock {
     float dpRs[MAX_DISP_FRAMES][9];
     float dpts[MAX_DISP_FRAMES][3];
     // number of flow frames still registered, decided ON THE DEVICE after the cameras of an EM iteration
-    // (k_decide_active, voldor.cpp:187-194): the depth kernels clamp their frame count to it, so the host can enqueue them
+    // (decide_active in vk_pose.hip, voldor.cpp:187-194): the depth kernels clamp their frame count to it, so the host can enqueue them
     // before it has seen the decision itself.  B-inner callers pass the count by argument: MAX_FRAMES here.
     int n_active;
     int pad_[3];
@@ -125,6 +125,7 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
     bool fb_smooth = true;
     float s0_ems_prob = 0.5f, no_change_prob = 0.9f, range_factor = 1.f;
     bool update_rigidness_only = false;
+    float* world_scale_out = nullptr;  // device float: also run normalize_world_scale's pose half (voldor.cpp:309-317) in the last launch
 };
 
 struct ProfEntry { double ms = 0; long count = 0; };

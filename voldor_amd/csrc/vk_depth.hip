@@ -410,8 +410,26 @@ __global__ __launch_bounds__(256) static void k_update_rigidness(Img I, float* _
     }
 }
 // fixed-order second stage: cams[f].pose_rigidness_density = sum(partial[f][:]) / npx
-__global__ static void k_reduce_density(const float* __restrict__ partial, int nblk, int npx, CamState* cams, const PoseBlock* P) {
+// blocks 0..n_launch-1: rigidness density of one frame; block n_launch (only launched when scale_out != NULL): the pose half
+// of normalize_world_scale (voldor.cpp:309-317), scale = n / sum ||t_i|| over the registered frames -- one launch for both
+__global__ static void k_reduce_density(const float* __restrict__ partial, int nblk, int npx, CamState* cams, PoseBlock* P, int n_launch,
+                                        float* scale_out) {
     const int f = blockIdx.x;
+    if (f == n_launch) {
+        if (threadIdx.x != 0) return;
+        const int n = min(n_launch, P->n_active);  // frames dropped by this iteration's decision do not count
+        if (n <= 0) { *scale_out = 1.f; return; }   // window lost: nothing to normalise (deviation D6)
+        float ws = 0.f;
+        for (int i = 0; i < n; i++) {
+            const float* t = P->ts[i];
+            ws += (float)sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2]);
+        }
+        const float s = (float)n / ws;
+        for (int i = 0; i < n; i++)
+            for (int d = 0; d < 3; d++) { P->ts[i][d] *= s; cams[i].t[d] = P->ts[i][d]; }
+        *scale_out = s;
+        return;
+    }
     if (f >= P->n_active) return;
     __shared__ float s[4];
     float acc = 0.f;
@@ -660,8 +678,8 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
     const int nblk = gpx.x * gpx.y;
     hipLaunchKernelGGL(k_update_rigidness<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
     if (p.N > 0)
-        hipLaunchKernelGGL(k_reduce_density, dim3(p.N), dim3(256), 0, c->stream, c->rig_partial.as<float>(), nblk, w * h,
-                           c->cams.as<CamState>(), S.pb());
+        hipLaunchKernelGGL(k_reduce_density, dim3(p.N + (p.world_scale_out ? 1 : 0)), dim3(256), 0, c->stream, c->rig_partial.as<float>(), nblk,
+                           w * h, c->cams.as<CamState>(), S.pb(), p.N, p.world_scale_out);
     VK_CHECK_LAST();
     return 0;
 }

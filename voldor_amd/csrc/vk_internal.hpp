@@ -10,6 +10,9 @@ struct ModeParams {
     int use_external_init_mean;  // -1: derive from CamState.pose_sample_count on the device
     float rvec_scale, rg_pose_scaling;
     int do_rg; float rg_trunc_sigma, rg_covar_reg_lambda, rg_epsilon; int rg_max_iters;
+    // > 0 on the LAST camera of an EM iteration: the kernel that finishes it also takes the truncation decision for the
+    // decide_n cameras (voldor.cpp:171-194 -> PoseBlock::n_active) instead of a separate one-thread launch
+    int decide_n = 0, decide_allow_trunc = 0; float decide_trunc_rigidness_density = 0.f, decide_trunc_sample_density = 0.f;
 };
 
 // vk_depth.hip
@@ -31,9 +34,6 @@ int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, fl
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
-int world_scale_device(Context* c, PoseBlock* P, CamState* cams, int n_flows, float* scale_dev);
-int decide_active_device(Context* c, PoseBlock* P, const CamState* cams, int n_flows, int allow_trunc, float trunc_rigidness_density,
-                         float trunc_sample_density);
 
 // vk_bootstrap.hip
 int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, float cx, float cy, CamState* cam0_dev);

@@ -750,6 +750,23 @@ __device__ __forceinline__ int load_hypotheses(const float* __restrict__ rvecs, 
     return used;
 }
 
+// voldor.cpp:171-194 on the device: the first camera that failed, was not allowed to run (rigidness density) or is not
+// confident enough truncates the window at its index.  The host applies the same rule to its copy of the records.
+// `cams` = record of camera 0.  Called by ONE thread, after it has written the last camera's record.
+__device__ __forceinline__ void decide_active(PoseBlock* P, const CamState* cams, int n_flows, int allow_trunc, float trunc_rigidness_density,
+                                              float trunc_sample_density) {
+    int n = n_flows;
+    for (int i = 0; i < n_flows; i++) {
+        int ok = 0;
+        if (!allow_trunc || cams[i].pose_rigidness_density > trunc_rigidness_density) ok = cams[i].success;
+        if (!ok || (allow_trunc && cams[i].pose_density < trunc_sample_density)) { n = i; break; }
+    }
+    P->n_active = n;
+}
+__device__ __forceinline__ void maybe_decide(const ModeParams& mp, PoseBlock* P, const CamState* cam, int cam_idx) {
+    if (mp.decide_n > 0)
+        decide_active(P, cam - cam_idx, mp.decide_n, mp.decide_allow_trunc, mp.decide_trunc_rigidness_density, mp.decide_trunc_sample_density);
+}
 // geometry.cpp:249-263: unscale, checkRange, write the pose into CamState and the PoseBlock (thread 0)
 __device__ __forceinline__ void finalize_pose(const float* mean6 /*scaled space*/, float rvec_scale, int used, float density, int ms_iters,
                                               int gu_iters, CamState* cam, PoseBlock* P, int cam_idx) {
@@ -786,14 +803,14 @@ __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __
     // successive pose? (voldor.cpp:177: pose_sample_count != 0), decided on the device
     const bool external_init = mp.use_external_init_mean < 0 ? (cam->pose_sample_count != 0) : (mp.use_external_init_mean != 0);
     if (*n_points_dev < 4) {  // geometry.cpp:84-88
-        if (tid == 0) { cam->success = 0; if (DEFER) handoff[8] = 0.f; }
+        if (tid == 0) { cam->success = 0; if (DEFER) handoff[8] = 0.f; else maybe_decide(mp, P, cam, cam_idx); }
         return;
     }
     float x[SPT_MAX][6];
     unsigned finmask;
     const int used = load_hypotheses<MS_THREADS, SPT_MAX>(rvecs, tvecs, n_poses, mp.rvec_scale, x, finmask, s_cnt);
     if (used == 0) {
-        if (tid == 0) { cam->success = 0; if (DEFER) handoff[8] = 0.f; }
+        if (tid == 0) { cam->success = 0; if (DEFER) handoff[8] = 0.f; else maybe_decide(mp, P, cam, cam_idx); }
         return;
     }
     // ---- mean-shift (meanshift.cu:34-150)
@@ -893,8 +910,10 @@ __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __
         if (DEFER) {
             for (int d = 0; d < 6; d++) handoff[d] = io_mean[d];
             handoff[6] = conf; handoff[7] = (float)ms_iters; handoff[8] = (float)used;
-        } else
+        } else {
             finalize_pose(io_mean, mp.rvec_scale, used, conf, ms_iters, cam->last_used_gu_iters, cam, P, cam_idx);
+            maybe_decide(mp, P, cam, cam_idx);
+        }
     }
 }
 
@@ -916,7 +935,10 @@ __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* _
     __shared__ int s_flag;
     __shared__ double s_lu[108];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (handoff[8] == 0.f) return;  // the mean-shift stage already reported failure
+    if (handoff[8] == 0.f) {  // the mean-shift stage already reported failure
+        if (tid == 0) maybe_decide(mp, P, cam, cam_idx);
+        return;
+    }
     const float sc = mp.rg_pose_scaling;
     // stage: x = [rvec * rvec_scale | t] * rg_pose_scaling (geometry.cpp:191,211); non-finite -> masked out
     float xr[RF_SPT][2];
@@ -1040,6 +1062,7 @@ __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* _
             for (int d = 0; d < 6; d++) mean6[d] = (handoff[d] * sc) / sc;  // pose_opm *= sc; /= sc (:210,:238)
         }
         finalize_pose(mean6, mp.rvec_scale, used, density, (int)handoff[7], gu_iters, cam, P, cam_idx);
+        maybe_decide(mp, P, cam, cam_idx);
     }
 }
 
@@ -1161,47 +1184,6 @@ int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams
 }
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev) {
     hipLaunchKernelGGL(k_robust_gaussian_only, dim3(1), dim3(MS_THREADS), 0, c->stream, space_dev, N, mp, io_dev, ioi_dev);
-    VK_CHECK_LAST();
-    return 0;
-}
-
-// normalize_world_scale on the device (voldor.cpp:309-317): scale = n_flows / sum ||t_i||
-__global__ static void k_world_scale(PoseBlock* P, CamState* cams, int n_flows, float* scale_out) {
-    if (threadIdx.x != 0) return;
-    n_flows = min(n_flows, P->n_active);  // frames dropped by this iteration's decision do not count
-    if (n_flows <= 0) { *scale_out = 1.f; return; }  // window lost: nothing to normalise (deviation D6)
-    float ws = 0.f;
-    for (int i = 0; i < n_flows; i++) {
-        const float* t = P->ts[i];
-        ws += (float)sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2]);
-    }
-    const float s = (float)n_flows / ws;
-    for (int i = 0; i < n_flows; i++)
-        for (int d = 0; d < 3; d++) { P->ts[i][d] *= s; cams[i].t[d] = P->ts[i][d]; }
-    *scale_out = s;
-}
-// voldor.cpp:171-194 on the device: the first camera that failed, was not allowed to run (rigidness density) or is not
-// confident enough truncates the window at its index.  The host applies the same rule to its copy of the records.
-__global__ static void k_decide_active(PoseBlock* P, const CamState* cams, int n_flows, int allow_trunc, float trunc_rigidness_density,
-                                       float trunc_sample_density) {
-    if (threadIdx.x != 0) return;
-    int n = n_flows;
-    for (int i = 0; i < n_flows; i++) {
-        int ok = 0;
-        if (!allow_trunc || cams[i].pose_rigidness_density > trunc_rigidness_density) ok = cams[i].success;
-        if (!ok || (allow_trunc && cams[i].pose_density < trunc_sample_density)) { n = i; break; }
-    }
-    P->n_active = n;
-}
-int decide_active_device(Context* c, PoseBlock* P, const CamState* cams, int n_flows, int allow_trunc, float trunc_rigidness_density,
-                         float trunc_sample_density) {
-    hipLaunchKernelGGL(k_decide_active, dim3(1), dim3(64), 0, c->stream, P, cams, n_flows, allow_trunc, trunc_rigidness_density,
-                       trunc_sample_density);
-    VK_CHECK_LAST();
-    return 0;
-}
-int world_scale_device(Context* c, PoseBlock* P, CamState* cams, int n_flows, float* scale_dev) {
-    hipLaunchKernelGGL(k_world_scale, dim3(1), dim3(64), 0, c->stream, P, cams, n_flows, scale_dev);
     VK_CHECK_LAST();
     return 0;
 }

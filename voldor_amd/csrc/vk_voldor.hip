@@ -160,7 +160,7 @@ struct Voldor {
     }
 
     // voldor.cpp:203-307 (the upload / "minimal cache" branches collapse: everything is resident)
-    int optimize_depth(OdFlag flag) {
+    int optimize_depth(OdFlag flag, bool with_world_scale = false) {
         if (n_flows == 0 && n_dp == 0) return 0;
         OdParams p;
         p.abs_resize_factor = cfg.abs_resize_factor;
@@ -169,11 +169,17 @@ struct Voldor {
         p.lambda = cfg.lambda; p.omega = cfg.omega; p.disp_delta = has_disparity ? cfg.disp_delta : -1.f; p.delta = cfg.delta;
         p.fb_smooth = cfg.fb_smooth != 0; p.s0_ems_prob = cfg.fb_emm; p.no_change_prob = cfg.fb_no_change_prob;
         p.range_factor = cfg.depth_range_factor; p.update_rigidness_only = (flag == OD_UPDATE_RIGIDNESS_ONLY);
-        return optimize_depth_device(c, c->od, p);
+        if (with_world_scale) {  // voldor.cpp:309-317: the pose half rides on the density launch, the depth half follows
+            if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
+            p.world_scale_out = c->ms_io.as<float>() + 48;
+        }
+        if (int e = optimize_depth_device(c, c->od, p)) return e;
+        if (with_world_scale) return scale_device(c, c->od.depth.as<float>(), p.world_scale_out, (size_t)w * h);
+        return 0;
     }
 
     // voldor/geometry.cpp:5-265, all on the device; success / density come back in CamState
-    int optimize_camera_pose(int i, bool rg_refine) {
+    int optimize_camera_pose(int i, bool rg_refine, bool last = false) {
         ImageSet& S = c->od;
         if (c->prof) prof_begin(c);
         if (int e = collect_device(c, S, n_flows, w, h, i, cfg.rigidness_threshold, cfg.rigidness_sum_threshold,
@@ -189,13 +195,17 @@ struct Voldor {
         mp.rvec_scale = cfg.meanshift_rvec_scale; mp.rg_pose_scaling = cfg.rg_pose_scaling; mp.do_rg = rg_refine ? 1 : 0;
         mp.rg_trunc_sigma = cfg.rg_trunc_sigma; mp.rg_covar_reg_lambda = cfg.rg_covar_reg_lambda; mp.rg_epsilon = cfg.rg_epsilon;
         mp.rg_max_iters = cfg.rg_max_iters;
+        if (last) {  // the kernel that finishes the last camera also takes the truncation decision (PoseBlock::n_active)
+            mp.decide_n = n_flows; mp.decide_allow_trunc = iters_cur > cfg.no_trunc_iters ? 1 : 0;
+            mp.decide_trunc_rigidness_density = cfg.trunc_rigidness_density; mp.decide_trunc_sample_density = cfg.trunc_sample_density;
+        }
         if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e;
         if (c->prof) prof_end(c, "optimize_camera_pose");
         return 0;
     }
 
     // voldor.cpp:164-201.  The reference decides after every camera (on the host) whether to go on; here all cameras of
-    // the iteration are enqueued back to back, the truncation rule runs ON THE DEVICE (k_decide_active -> PoseBlock::
+    // the iteration are enqueued back to back, the truncation rule runs ON THE DEVICE (decide_active, at the end of the last camera's pose kernel -> PoseBlock::
     // n_active, which the depth kernels clamp to), and the host applies the same rule to its copy of the records only
     // after it has already enqueued this iteration's depth half: the GPU never waits for the host decision.
     // Equivalent to the reference order: a camera that fails or is skipped truncates the window at its index, so whatever
@@ -204,10 +214,8 @@ struct Voldor {
         const bool allow_trunc = iters_cur > cfg.no_trunc_iters;
         const bool rg = cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0);
         for (int i = 0; i < n_flows; i++)
-            if (int e = optimize_camera_pose(i, rg)) return e;
-        if (int e = decide_active_device(c, c->od.pb(), dcams(), n_flows, allow_trunc ? 1 : 0, cfg.trunc_rigidness_density,
-                                         cfg.trunc_sample_density))
-            return e;
+            if (int e = optimize_camera_pose(i, rg, i == n_flows - 1)) return e;
+        (void)allow_trunc;
         // rigidness densities (reduced on the device by the last optimize_depth, voldor.cpp:171) and results
         VK_CHECK(hipMemcpyAsync(c->h_cams, c->cams.p, sizeof(CamState) * n_flows, hipMemcpyDeviceToHost, c->stream));
         VK_CHECK(hipEventRecord(c->ev_cams, c->stream));
@@ -239,14 +247,6 @@ struct Voldor {
                   << "last used gu iters = " << s.last_used_gu_iters << std::endl << std::endl;
     }
 
-    // voldor.cpp:309-317, on the device: no host round trip of depth or translations
-    int normalize_world_scale() {
-        if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
-        float* s_dev = c->ms_io.as<float>() + 48;
-        if (int e = world_scale_device(c, c->od.pb(), dcams(), n_flows, s_dev)) return e;
-        return scale_device(c, c->od.depth.as<float>(), s_dev, (size_t)w * h);
-    }
-
     // voldor.cpp:130-149
     int solve() {
         if (n_dp == 0) {  // bootstrap :151-162
@@ -258,8 +258,7 @@ struct Voldor {
             iters_cur++; iters_remain--;
             if (int e = enqueue_cameras()) return e;
             // the depth half is enqueued with the pre-decision frame count; on the device it runs with n_active
-            if (int e = optimize_depth(cfg.optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY)) return e;
-            if (cfg.norm_world_scale && n_dp == 0) { if (int e = normalize_world_scale()) return e; }
+            if (int e = optimize_depth(cfg.optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY, cfg.norm_world_scale && n_dp == 0)) return e;
             if (int e = finish_cameras()) return e;
         }
         return 0;
