@@ -187,3 +187,25 @@ def test_slam_driver_call_replayed_verbatim():
         T_tmp = Ti @ T_tmp
         scores.append(slam_utils.eval_covisibility(vo_ret["depth"], T_tmp, K, vo_ret["depth_conf"] > 0.5))
     assert all(0.0 < s <= 1.0 for s in scores) and scores[0] >= scores[-1] - 1e-3  # the view drifts away monotonically
+
+
+@pytest.mark.parametrize("w,h,n", [(161, 123, 3), (66, 50, 1), (96, 72, 16)])
+def test_ragged_sizes_and_frame_count_limits(orc, w, h, n):
+    """Whole windows at sizes that are no multiple of any tile (row pitch not 16-byte aligned, partial 64x4 tiles, partial
+    fb_smooth segments), with a single flow and with MAX_FRAMES = 16 flows (optimize_depth.cu:20)."""
+    from voldor_amd import pyvoldor, synth, kernels, capi
+    sc = synth.make_scene(w=w, h=h, n_flows=n, fx=w / 2, fy=w / 2, cx=w / 2, cy=h / 2, seed=260 + n)
+    fx, fy, cx, cy = sc["K"]
+    cfg = "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 3"
+    kernels.set_rand_epoch(0)
+    g = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config=cfg)
+    o = orc.voldor(sc["flows"], fx, fy, cx, cy, config=cfg)
+    assert g["n_registered"] == o["n_registered"]
+    assert g["depth"].shape == (h, w) and np.isfinite(g["depth"]).all() and np.isfinite(g["depth_conf"]).all()
+    k = g["n_registered"]
+    if k > 0:
+        rot, tr = synth.pose_errors(g["poses"][:min(k, 4)], o["poses"][:min(k, 4)])
+        assert rot.max() < 2e-3 and tr.max() < 8e-2, (rot, tr)  # tiny images: few hundred useful pixels per camera
+    if n == 16:
+        with pytest.raises(capi.VoldorHipError):  # N > 16 is rejected, not silently truncated
+            pyvoldor.voldor(np.concatenate([sc["flows"], sc["flows"][:1]]), fx, fy, cx, cy, config=cfg)
