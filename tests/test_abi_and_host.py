@@ -30,6 +30,8 @@ def test_library_exports_every_declared_symbol():
                "collect_p3p_instances(float**, float**, float*, float*, float**, float**, float*, float*, int, int, int, int, float, float, float, float, int)",
                "solve_batch_p3p_ap3p_gpu(float*, float*, float*, float*, float*, int, int)",
                "solve_batch_p3p_lambdatwist_gpu(float*, float*, float*, float*, float*, int, int)",
+               "align_frame_init_gpu(float**, float**, float**, float*, float, float, int, int, int)",           # gpu_kernels.h:60-66
+               "align_frame_eval_gpu(int, int, float const*, float const*, float*, float*, bool)",               # gpu_kernels.h:68-74
                "py_voldor_wrapper(float const*, float const*, float const*, float const*, float const*, float const*, float, float, float, float, float, int, int, int, int, char const*, int&, float*, float*, float*, float*)"):
         assert fn in sigs, fn
     assert any(s.startswith("optimize_depth_gpu(float**, float**, float**, float**, float**, float**, float**, float*, float*, float*, float**, float**, float**, float**, float, int, int, int, int, float, int, int, int, float, float, float, float, bool, float, float, float, bool)") for s in sigs)
@@ -38,7 +40,7 @@ def test_library_exports_every_declared_symbol():
 def test_headers_mirror_reference_boundary():
     g = open(os.path.join(ROOT, "include", "gpu_kernels.h")).read()
     for name in ("meanshift_gpu", "fit_robust_gaussian", "collect_p3p_instances", "solve_batch_p3p_ap3p_gpu",
-                 "solve_batch_p3p_lambdatwist_gpu", "optimize_depth_gpu"):
+                 "solve_batch_p3p_lambdatwist_gpu", "optimize_depth_gpu", "align_frame_init_gpu", "align_frame_eval_gpu"):
         assert re.search(r"DLL_EXPORT int " + name + r"\(", g), name
     assert "float epsilon = 1e-5f, int max_iters = 100" in g and "float good_init_confidence = 0.5f" in g  # default args
     assert "int& n_registered" in open(os.path.join(ROOT, "include", "py_export.h")).read()
