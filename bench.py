@@ -173,23 +173,26 @@ def main():
     conc = None
     if rank == 0 and world == 1 and args.in_flight > 1 and wl["mode"] == "mono":
         B = args.in_flight
+        os.environ["VOLDOR_HIP_INFLIGHT"] = str(B)  # read by vk_voldor_device_batch at every call
+        NW = 4 * B  # windows per batch call: the tail of a batch (the last windows finishing alone) is amortised over 4 rounds
         scs = [sc] + [synth.make_scene(w=W, h=H, n_flows=N_FLOW, fx=FX, fy=FY, cx=CX, cy=CY, seed=1000 + b) for b in range(1, B)]
-        fls = [flows] + [torch.from_numpy(s["flows"]).cuda() for s in scs[1:]]
-        douts = [torch.empty(H, W, device="cuda") for _ in range(B)]
-        couts = [torch.empty(H, W, device="cuda") for _ in range(B)]
-        for _ in range(max(1, args.warmup)):
+        fl_b = [flows] + [torch.from_numpy(s["flows"]).cuda() for s in scs[1:]]
+        fls = [fl_b[i % B] for i in range(NW)]  # B distinct sequences, each submitted 4 times per batch
+        douts = [torch.empty(H, W, device="cuda") for _ in range(NW)]
+        couts = [torch.empty(H, W, device="cuda") for _ in range(NW)]
+        for _ in range(max(1, args.warmup // 2)):
             outs = pyvoldor.voldor_device_batch(fls, FX, FY, CX, CY, config=CONFIG, depth_out=douts, depth_conf_out=couts)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        nb = max(2, args.steps // 2)
+        nb = max(2, args.steps // 4)
         for _ in range(nb):
             outs = pyvoldor.voldor_device_batch(fls, FX, FY, CX, CY, config=CONFIG, depth_out=douts, depth_conf_out=couts)
         torch.cuda.synchronize()
         tb = time.perf_counter() - t0
-        conc = {"windows_in_flight": B, "value": round(B * nb / tb, 3), "unit": "frames/s", "ms_per_batch": round(tb / nb * 1e3, 3),
-                "n_registered": [int(o["n_registered"]) for o in outs],
-                "note": "B independent sequences, one window each in flight on its own stream/context (vk_voldor_device_batch); "
-                        "the single-workgroup pose kernels of one window overlap the per-pixel kernels of the others"}
+        conc = {"windows_in_flight": B, "windows_per_batch": NW, "value": round(NW * nb / tb, 3), "unit": "frames/s",
+                "ms_per_window": round(tb / nb / NW * 1e3, 3), "n_registered_min": int(min(o["n_registered"] for o in outs)),
+                "note": "independent windows, at most B in flight, each on its own stream/context (vk_voldor_device_batch); the "
+                        "single-workgroup pose kernels of one window overlap the per-pixel kernels of the others"}
 
     # ---- CPU baseline: the oracle on the host cores (rank 0, N=1 only, bounded sample) ----
     cpu = None

@@ -71,7 +71,8 @@ int vk_voldor_device(const float* flows, const float* disparity, const float* di
  * counterpart: voldor/py_export.cpp processes one window per call).  Argument b of every pointer array belongs to window b
  * (arrays may be NULL where the single call takes NULL); images may be host or device pointers; n_registered[n_windows],
  * poses[n_windows][N][6], poses_covar[n_windows][N][36] are host arrays.  Each window runs on its own stream and buffers
- * and gives the result of the one-at-a-time call. */
+ * and gives the result of the one-at-a-time call.  At most VOLDOR_HIP_INFLIGHT (environment, default 4) windows are in
+ * flight at a time; a longer batch queues behind them (a worker that finishes a window takes the next one). */
 int vk_voldor_device_batch(int n_windows, const float* const* flows, const float* const* disparity,
                            const float* const* disparity_pconf, const float* const* depth_priors,
                            const float* const* depth_prior_poses, const float* const* depth_prior_pconfs,

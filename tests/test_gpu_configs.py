@@ -123,21 +123,22 @@ def test_cfg4_windows_in_flight_match_one_at_a_time():
     (vk_voldor_device_batch: own stream + buffers per window).  Each window must give exactly the one-at-a-time result."""
     import torch
     from voldor_amd import pyvoldor, synth, kernels
-    scs = [synth.make_scene(w=320, h=240, n_flows=4, fx=160, fy=160, cx=160, cy=120, seed=300 + b) for b in range(4)]
+    NB = 6  # more windows than the 4 that are in flight at a time: the rest queues, workers pick windows dynamically
+    scs = [synth.make_scene(w=320, h=240, n_flows=4, fx=160, fy=160, cx=160, cy=120, seed=300 + b) for b in range(NB)]
     fx, fy, cx, cy = scs[0]["K"]
     fl = [torch.from_numpy(s["flows"]).cuda() for s in scs]
     cfg = "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 4"
     single = []
-    for b in range(4):
+    for b in range(NB):
         kernels.set_rand_epoch(0)
         d = torch.empty(240, 320, device="cuda")
         single.append((pyvoldor.voldor_device(fl[b], fx, fy, cx, cy, config=cfg, depth_out=d), d.cpu().numpy()))
     for rep in range(2):  # second round: pooled contexts and workers are reused
-        kernels.set_rand_epoch(0)  # also re-seeds the pooled contexts
-        dout = [torch.empty(240, 320, device="cuda") for _ in range(4)]
+        kernels.set_rand_epoch(0)  # also the epoch every window of the next batch starts from
+        dout = [torch.empty(240, 320, device="cuda") for _ in range(NB)]
         outs = pyvoldor.voldor_device_batch(fl, fx, fy, cx, cy, config=cfg, depth_out=dout)
         torch.cuda.synchronize()
-        for b in range(4):
+        for b in range(NB):
             assert outs[b]["n_registered"] == single[b][0]["n_registered"] == 4
             np.testing.assert_array_equal(outs[b]["poses"], single[b][0]["poses"])
             np.testing.assert_array_equal(outs[b]["poses_covar"], single[b][0]["poses_covar"])

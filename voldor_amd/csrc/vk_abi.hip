@@ -73,11 +73,18 @@ Context* pool_context(int idx) {
     }
     return v[(size_t)idx];
 }
+// depth-sampling epoch that the windows of the next vk_voldor_device_batch start from (per device); set != NULL stores
+static std::map<int, uint32_t> g_batch_epoch;
+uint32_t batch_rand_epoch(int dev, const uint32_t* set) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (set) g_batch_epoch[dev] = *set;
+    return g_batch_epoch[dev];
+}
 int pool_set_rand_epoch(unsigned epoch) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorNoDevice;
-    std::lock_guard<std::mutex> lk(g_mu);
-    for (Context* c : g_pool_ctx[dev]) { c->rand_epoch = epoch; c->rand_w = c->rand_h = -1; }
+    const uint32_t e = epoch;
+    batch_rand_epoch(dev, &e);
     return 0;
 }
 

@@ -164,6 +164,7 @@ struct Context {
 Context* default_context();          // lazily created on the current HIP device
 Context* pool_context(int idx);      // idx-th extra context of the current device (windows in flight next to each other)
 int pool_set_rand_epoch(unsigned epoch);
+uint32_t batch_rand_epoch(int dev, const uint32_t* set);  // epoch the windows of the next batch start from
 int prof_begin(Context* c);
 int prof_end(Context* c, const char* name);
 int prof_begin_inner(Context* c);

@@ -17,6 +17,7 @@
 #include <iostream>
 #include <cmath>
 #include <cstddef>
+#include <cstdlib>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -317,41 +318,55 @@ struct BatchJob {
     float fx, fy, cx, cy, basefocal; int N, N_dp, w, h; const char* config;
     int* n_registered; float *poses, *poses_covar, *depth, *depth_conf;
     int rc;
+    uint32_t epoch0, epoch_end;  // depth-sampling counter the window starts from / ends at
 };
 class WindowPool {  // persistent workers: worker i owns pool context i of the device it was started on
     std::mutex mu; std::condition_variable cv_work, cv_done;
-    std::vector<std::thread> workers; std::vector<BatchJob*> slot; int pending = 0, device = 0; bool stop = false;
+    std::vector<std::thread> workers; std::vector<BatchJob>* jobs = nullptr; size_t next = 0; int pending = 0, device = 0; bool stop = false;
     void loop(int i) {
         (void)hipSetDevice(device);
         for (;;) {
             BatchJob* j;
-            { std::unique_lock<std::mutex> lk(mu); cv_work.wait(lk, [&] { return stop || slot[i]; }); if (stop) return; j = slot[i]; }
+            {   // windows are handed out one at a time: a worker that finishes early starts the next one, no static split
+                std::unique_lock<std::mutex> lk(mu);
+                cv_work.wait(lk, [&] { return stop || (jobs && next < jobs->size()); });
+                if (stop) return;
+                j = &(*jobs)[next++];
+            }
+            // every window of a batch starts from the batch's epoch, whichever worker / context picks it up: the result of a
+            // window does not depend on how the batch was scheduled
+            if (Context* pc = pool_context(i)) { pc->rand_epoch = j->epoch0; pc->rand_w = pc->rand_h = -1; }
             j->rc = voldor_run_on(pool_context(i), j->flows, j->disparity, j->disparity_pconf, j->depth_priors, j->depth_prior_poses,
                                   j->depth_prior_pconfs, j->fx, j->fy, j->cx, j->cy, j->basefocal, j->N, j->N_dp, j->w, j->h, j->config,
                                   j->n_registered, j->poses, j->poses_covar, j->depth, j->depth_conf);
-            { std::lock_guard<std::mutex> lk(mu); slot[i] = nullptr; if (--pending == 0) cv_done.notify_all(); }
+            if (Context* pc = pool_context(i)) j->epoch_end = pc->rand_epoch;
+            { std::lock_guard<std::mutex> lk(mu); if (--pending == 0) { jobs = nullptr; cv_done.notify_all(); } }
         }
     }
 public:
     explicit WindowPool(int dev) : device(dev) {}
     ~WindowPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv_work.notify_all(); for (auto& t : workers) t.join(); }
-    void run(std::vector<BatchJob>& jobs) {
+    void run(std::vector<BatchJob>& js, int width) {
         std::unique_lock<std::mutex> lk(mu);
-        while (workers.size() < jobs.size()) { slot.push_back(nullptr); const int i = (int)workers.size(); workers.emplace_back([this, i] { loop(i); }); }
-        for (size_t i = 0; i < jobs.size(); i++) slot[i] = &jobs[i];
-        pending = (int)jobs.size();
+        const size_t want = std::min(js.size(), (size_t)std::max(1, width));
+        while (workers.size() < want) { const int i = (int)workers.size(); workers.emplace_back([this, i] { loop(i); }); }
+        // more workers than `width` may exist from an earlier, wider call: they simply take windows too (each has its own context)
+        jobs = &js; next = 0; pending = (int)js.size();
         cv_work.notify_all();
         cv_done.wait(lk, [&] { return pending == 0; });
     }
 };
 static std::mutex g_pool_mu;
 static std::map<int, WindowPool*> g_pools;  // per device; intentionally never destroyed (worker threads outlive static teardown order)
-static int voldor_run_batch(std::vector<BatchJob>& jobs) {
+static int voldor_run_batch(std::vector<BatchJob>& jobs, int width) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return (int)hipErrorNoDevice;
     WindowPool* p;
     { std::lock_guard<std::mutex> lk(g_pool_mu); auto& q = g_pools[dev]; if (!q) q = new WindowPool(dev); p = q; }
-    p->run(jobs);
+    const uint32_t e0 = batch_rand_epoch(dev, nullptr);
+    for (auto& j : jobs) { j.epoch0 = e0; j.epoch_end = e0; }
+    p->run(jobs, width);
+    batch_rand_epoch(dev, &jobs[0].epoch_end);  // the next batch continues where window 0 of this one stopped
     for (auto& j : jobs) if (j.rc) return j.rc;
     return 0;
 }
@@ -399,7 +414,10 @@ int vk_voldor_device_batch(int n_windows, const float* const* flows, const float
         j.poses_covar = poses_covar ? poses_covar + (size_t)b * N * 36 : nullptr;
         j.depth = depth ? depth[b] : nullptr; j.depth_conf = depth_conf ? depth_conf[b] : nullptr; j.rc = 0;
     }
-    return vk::voldor_run_batch(jobs);
+    // at most VOLDOR_HIP_INFLIGHT (default 4) windows in flight at a time; the rest of the batch queues behind them
+    int width = 4;
+    if (const char* e = getenv("VOLDOR_HIP_INFLIGHT")) { const int v = atoi(e); if (v > 0) width = v; }
+    return vk::voldor_run_batch(jobs, width);
 }
 int vk_last_camera_stats(int* pose_sample_count, float* pose_density, float* pose_rigidness_density, int* ms_iters, int* gu_iters, int n) {
     for (int i = 0; i < n && i < vk::MAX_FRAMES; i++) {
