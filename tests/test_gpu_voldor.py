@@ -209,3 +209,19 @@ def test_ragged_sizes_and_frame_count_limits(orc, w, h, n):
     if n == 16:
         with pytest.raises(capi.VoldorHipError):  # N > 16 is rejected, not silently truncated
             pyvoldor.voldor(np.concatenate([sc["flows"], sc["flows"][:1]]), fx, fy, cx, cy, config=cfg)
+
+
+def test_cxx_client_links_and_runs_against_the_b_inner_boundary(tmp_path):
+    """The reference's C++ host code links libgpu-kernels by name (setup_linux_vo.py:16-27).  A C++ translation unit that
+    includes OUR include/gpu_kernels.h + py_export.h is built with the system g++ and linked against libvoldor_hip.so."""
+    import os, shutil, subprocess
+    from voldor_amd import capi
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "binner_client")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cxx", "binner_client.cpp"),
+                           "-L", libdir, "-lvoldor_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=120)
+    assert out.returncode == 0 and b"CLIENT OK" in out.stdout, out.stdout.decode()[-2000:]
