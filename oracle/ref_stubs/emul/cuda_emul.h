@@ -1,0 +1,81 @@
+/* oracle/ref_stubs/emul/cuda_emul.h -- a few lines of CUDA execution model on the CPU, so that the DEVICE code of the
+ * reference's .cu files (kernels and device functions, cut out of the files at build time, never copied into the repo) can
+ * be compiled by g++ and run thread by thread.  TEST INFRASTRUCTURE ONLY (oracle/_ref).  Nothing here is reference code.
+ *
+ * What is emulated: threadIdx / blockIdx / blockDim / gridDim, a launcher that walks the grid sequentially, GMat (the
+ * reference's device array, gmat.h) backed by host memory, cuRAND state.  Two deliberate substitutions, the same ones the
+ * oracle documents: D1 curand_uniform draws from the counter-based generator of oracle/orc_model.c instead of XORWOW;
+ * D2 at_tex is an exact-weight clamp-to-edge bilinear fetch per layer instead of the 8-bit texture filter. */
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <cmath>
+#include "../cuda_stub_common.h"
+
+struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
+struct emul_idx3 { unsigned x, y, z; };
+static emul_idx3 threadIdx, blockIdx;
+static dim3 blockDim, gridDim;
+template <class F> static void emul_launch(dim3 grid, dim3 block, F kernel) {
+    gridDim = grid; blockDim = block;
+    for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++)
+        for (unsigned tz = 0; tz < block.z; tz++) for (unsigned ty = 0; ty < block.y; ty++) for (unsigned tx = 0; tx < block.x; tx++) {
+            blockIdx = { bx, by, bz }; threadIdx = { tx, ty, tz };
+            kernel();
+        }
+}
+#define DIV_CEIL_EMUL(a, b) (((a) + (b) - 1) / (b))
+
+/* D1: counter-based generator (orc_model.c orc_rng / orc_u01): murmur3 finaliser over (seed, stream, counter) */
+static inline uint32_t emul_fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+static inline uint32_t emul_rng3(uint32_t seed, uint32_t stream, uint32_t counter) {
+    uint32_t h = emul_fmix32(seed ^ 0x9E3779B9u);
+    h = emul_fmix32(h ^ stream);
+    h = emul_fmix32(h + counter * 0x9E3779B1u + 0x7F4A7C15u);
+    return h;
+}
+struct curandState { uint32_t seed, stream, counter; };
+static inline void curand_init(unsigned long long seed, unsigned long long sequence, unsigned long long offset, curandState* s) {
+    s->seed = (uint32_t)seed; s->stream = (uint32_t)sequence; s->counter = (uint32_t)offset;
+}
+static inline float curand_uniform(curandState* s) {  /* (0, 1] like cuRAND */
+    const uint32_t r = emul_rng3(s->seed, s->stream, s->counter++);
+    return (float)((r >> 8) + 1u) * (1.0f / 16777216.0f);
+}
+
+/* the reference's GMat<T> (gmat.h:4-204): 3-D array, x fastest; here dense host memory, no pitch */
+template <typename T> struct GMat {
+    T* ptr = nullptr; int _width = 0, _height = 0, _depth = 0;
+    void bind(T* p, int w, int h, int d) { ptr = p; _width = w; _height = h; _depth = d; }
+    T& at(const size_t x, const size_t y, const size_t d = 0) { return ptr[(d * (size_t)_height + y) * (size_t)_width + x]; }
+    T at_tex(const float x, const float y, const int d = 0) const;  /* D2 */
+};
+static inline void emul_bil_idx(float x, float y, int w, int h, int& x0, int& x1, int& y0, int& y1, float& a, float& b) {
+    const float fx = floorf(x), fy = floorf(y);
+    a = x - fx; b = y - fy;
+    int ix = (int)fx, iy = (int)fy, ix1 = ix + 1, iy1 = iy + 1;
+    ix = ix < 0 ? 0 : (ix > w - 1 ? w - 1 : ix); ix1 = ix1 < 0 ? 0 : (ix1 > w - 1 ? w - 1 : ix1);
+    iy = iy < 0 ? 0 : (iy > h - 1 ? h - 1 : iy); iy1 = iy1 < 0 ? 0 : (iy1 > h - 1 ? h - 1 : iy1);
+    x0 = ix; x1 = ix1; y0 = iy; y1 = iy1;
+}
+template <> inline float GMat<float>::at_tex(const float x, const float y, const int d) const {
+    int x0, x1, y0, y1; float a, b;
+    emul_bil_idx(x, y, _width, _height, x0, x1, y0, y1, a, b);
+    const float* m = ptr + (size_t)d * _height * _width;
+    return (1.f - a) * (1.f - b) * m[y0 * _width + x0] + a * (1.f - b) * m[y0 * _width + x1] + (1.f - a) * b * m[y1 * _width + x0] + a * b * m[y1 * _width + x1];
+}
+template <> inline float2 GMat<float2>::at_tex(const float x, const float y, const int d) const {
+    int x0, x1, y0, y1; float a, b;
+    emul_bil_idx(x, y, _width, _height, x0, x1, y0, y1, a, b);
+    const float2* m = ptr + (size_t)d * _height * _width;
+    const float2 t00 = m[y0 * _width + x0], t10 = m[y0 * _width + x1], t01 = m[y1 * _width + x0], t11 = m[y1 * _width + x1];
+    const float w00 = (1.f - a) * (1.f - b), w10 = a * (1.f - b), w01 = (1.f - a) * b, w11 = a * b;
+    float2 r;
+    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
+    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
+    return r;
+}
+typedef GMat<float> GMatf;
+typedef GMat<float2> GMatf2;
+typedef GMat<float4> GMatf4;
+typedef GMat<curandState> GMatRnd;
