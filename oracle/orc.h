@@ -6,12 +6,21 @@
  * cpu_baseline leg of bench.py may load this library.  The product never does.
  *
  * PARITY PINNING: the reference ships no tests / golden vectors for this path
- *  and its CUDA+OpenCV build cannot run here.  The pieces of
- * the reference that DO compile on the host (lambdatwist/*.h, residual_model.h,
- * rodrigues.h+svd3_cuda.h) are built in place into oracle/_ref and this oracle is
- * checked against them (tests/test_oracle_vs_ref.py, tests/golden/ref_*.npz).
- * Everything else (pixel passes, fb_smooth, collect, mean-shift, robust Gaussian,
- * EM schedule) is "parity unpinned": restated from the cited source lines only.
+ *  and its CUDA+OpenCV build cannot run here.  Two levels of pinning
+ * against the reference's own code stand in for them:
+ *  1. the headers that compile on the host (lambdatwist/*.h, residual_model.h,
+ *     rodrigues.h+svd3_cuda.h) are built in place into oracle/_ref (ref_wrap.cpp;
+ *     tests/test_oracle_vs_golden.py, tests/golden/ref_{lambdatwist,residual,rodrigues}.npz);
+ *  2. the CUDA kernel files themselves (optimize_depth.cu, fb_smooth.h, collect_p3p_instances.cu,
+ *     solve_batch_{lambdatwist,ap3p}.cu, meanshift.cu, fit_robust_gaussian.cu), host entry points
+ *     included, are compiled for the CPU on a small launch-emulation layer (ref_prep.pl,
+ *     ref_stubs/emul/, ref_wrap_kernels.cpp) and run thread by thread with the D1/D2
+ *     substitutions below; this oracle reproduces their outputs bit for bit (pixel passes,
+ *     fb_smooth, correspondence maps, solver translations) or to float summation order
+ *     (mean-shift, robust Gaussian) -- tests/test_oracle_vs_ref_kernels.py,
+ *     tests/golden/ref_kernels.npz.
+ * Still "parity unpinned" (needs OpenCV): the host schedule of voldor/voldor.cpp and
+ * voldor/geometry.cpp (orc_voldor.c), restated from the cited source lines only.
  *
  * Deliberate, documented deviations from the reference:
  *  D1 random numbers: counter-based hash (orc_rng) instead of cuRAND XORWOW.

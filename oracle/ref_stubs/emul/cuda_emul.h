@@ -1,13 +1,18 @@
-/* oracle/ref_stubs/emul/cuda_emul.h -- a few lines of CUDA execution model on the CPU, so that the DEVICE code of the
- * reference's .cu files (kernels and device functions, cut out of the files at build time, never copied into the repo) can
- * be compiled by g++ and run thread by thread.  TEST INFRASTRUCTURE ONLY (oracle/_ref).  Nothing here is reference code.
+/* oracle/ref_stubs/emul/cuda_emul.h -- a few lines of CUDA execution model on the CPU, so that the reference's .cu files
+ * (kernels, device functions AND their host entry points; rewritten at build time by oracle/ref_prep.pl into temp files,
+ * never copied into the repo) can be compiled by g++ and run thread by thread.  TEST INFRASTRUCTURE ONLY (oracle/_ref).
+ * Nothing here is reference code.
  *
- * What is emulated: threadIdx / blockIdx / blockDim / gridDim, a launcher that walks the grid sequentially, GMat (the
- * reference's device array, gmat.h) backed by host memory, cuRAND state.  Two deliberate substitutions, the same ones the
- * oracle documents: D1 curand_uniform draws from the counter-based generator of oracle/orc_model.c instead of XORWOW;
- * D2 at_tex is an exact-weight clamp-to-edge bilinear fetch per layer instead of the 8-bit texture filter. */
+ * What is emulated: threadIdx / blockIdx / blockDim / gridDim, a launcher that walks the grid sequentially (the only
+ * source rewrite is `kernel<<<grid, block>>>(args);` -> `emul_launch(emul_cfg(grid, block), [&]{ kernel(args); });`),
+ * cudaMalloc / cudaMemcpy / cudaMemcpyToSymbol on host memory, GMat (the reference's device array, gmat.h) backed by
+ * host memory, cuRAND state.  Two deliberate substitutions, the same ones the oracle documents: D1 curand_uniform draws
+ * from the counter-based generator of oracle/orc_model.c instead of XORWOW; D2 at_tex is an exact-weight clamp-to-edge
+ * bilinear fetch per layer instead of the 8-bit texture filter.  Kernels that need __syncthreads / warp lock-step
+ * (reduce_vector_sum.h only) are replaced by a stand-in header that restates their summation order. */
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <cmath>
 #include "../cuda_stub_common.h"
@@ -16,6 +21,7 @@ struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c 
 struct emul_idx3 { unsigned x, y, z; };
 static emul_idx3 threadIdx, blockIdx;
 static dim3 blockDim, gridDim;
+struct emul_cfg { dim3 grid, block; emul_cfg(dim3 g, dim3 b, size_t = 0) : grid(g), block(b) {} };
 template <class F> static void emul_launch(dim3 grid, dim3 block, F kernel) {
     gridDim = grid; blockDim = block;
     for (unsigned bz = 0; bz < grid.z; bz++) for (unsigned by = 0; by < grid.y; by++) for (unsigned bx = 0; bx < grid.x; bx++)
@@ -24,7 +30,25 @@ template <class F> static void emul_launch(dim3 grid, dim3 block, F kernel) {
             kernel();
         }
 }
+template <class F> static void emul_launch(const emul_cfg& c, F kernel) { emul_launch(c.grid, c.block, kernel); }
 #define DIV_CEIL_EMUL(a, b) (((a) + (b) - 1) / (b))
+
+/* ---- runtime API on host memory.  Allocations are padded: the reference's `int i = curand_uniform() * N` indexes one
+ * past the end when the draw is exactly 1.0 (solve_batch_lambdatwist.cu:16-19). */
+enum { cudaSuccess = 0 };
+enum cudaMemcpyKind { cudaMemcpyHostToHost, cudaMemcpyHostToDevice, cudaMemcpyDeviceToHost, cudaMemcpyDeviceToDevice };
+template <class T> static inline cudaError_t cudaMalloc(T** p, size_t n) { *p = (T*)calloc(n + 64, 1); return cudaSuccess; }
+static inline cudaError_t cudaFree(void* p) { free(p); return cudaSuccess; }
+static inline cudaError_t cudaMemcpy(void* d, const void* s, size_t n, cudaMemcpyKind) { memcpy(d, s, n); return cudaSuccess; }
+template <class S> static inline cudaError_t cudaMemcpyToSymbol(S& sym, const void* s, size_t n) { memcpy((void*)&sym, s, n); return cudaSuccess; }
+static inline cudaError_t cudaGetLastError() { return cudaSuccess; }
+static inline const char* cudaGetErrorString(cudaError_t) { return "emulated"; }
+struct cudaPos { size_t x, y, z; };
+static inline cudaPos make_cudaPos(size_t x, size_t y, size_t z) { cudaPos p = { x, y, z }; return p; }
+
+/* host rand() of meanshift.cu:76 (ref_wrap_kernels.cpp maps rand to emul_host_rand around that file): the wrapper sets
+ * the modulus so that `rand() % N` equals the oracle's draw */
+static uint32_t emul_rand_trial = 0, emul_rand_mod = 1;
 
 /* D1: counter-based generator (orc_model.c orc_rng / orc_u01): murmur3 finaliser over (seed, stream, counter) */
 static inline uint32_t emul_fmix32(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
@@ -34,19 +58,38 @@ static inline uint32_t emul_rng3(uint32_t seed, uint32_t stream, uint32_t counte
     h = emul_fmix32(h + counter * 0x9E3779B1u + 0x7F4A7C15u);
     return h;
 }
+static inline int emul_host_rand() { return (int)(emul_rng3(233u, emul_rand_trial++, 0x4D53u) % emul_rand_mod); }
 struct curandState { uint32_t seed, stream, counter; };
+static uint32_t emul_curand_epoch = 0;  /* the wrapper's stand-in for "states persist across calls": added to the offset */
 static inline void curand_init(unsigned long long seed, unsigned long long sequence, unsigned long long offset, curandState* s) {
-    s->seed = (uint32_t)seed; s->stream = (uint32_t)sequence; s->counter = (uint32_t)offset;
+    s->seed = (uint32_t)seed; s->stream = (uint32_t)sequence; s->counter = (uint32_t)offset + emul_curand_epoch;
 }
 static inline float curand_uniform(curandState* s) {  /* (0, 1] like cuRAND */
     const uint32_t r = emul_rng3(s->seed, s->stream, s->counter++);
     return (float)((r >> 8) + 1u) * (1.0f / 16777216.0f);
 }
 
-/* the reference's GMat<T> (gmat.h:4-204): 3-D array, x fastest; here dense host memory, no pitch */
+/* the reference's GMat<T> (gmat.h:4-204): 3-D array, x fastest; here dense host memory, no pitch.  create() keeps the
+ * reference's reuse rule (gmat.h:19-32: reallocate unless the size matches, or only the depth shrank with lazy_depth). */
 template <typename T> struct GMat {
-    T* ptr = nullptr; int _width = 0, _height = 0, _depth = 0;
-    void bind(T* p, int w, int h, int d) { ptr = p; _width = w; _height = h; _depth = d; }
+    T* ptr = nullptr; int _width = 0, _height = 0, _depth = 0; bool owned = false;
+    void bind(T* p, int w, int h, int d) { ptr = p; _width = w; _height = h; _depth = d; owned = false; }
+    int create(size_t w, size_t h, size_t d, bool lazy_depth = false) {
+        if (((int)w == _width && (int)h == _height && (int)d == _depth) || (lazy_depth && (int)w == _width && (int)h == _height && (int)d <= _depth)) return 0;
+        if (owned) free(ptr);
+        ptr = (T*)calloc(w * h * (d ? d : 1) + 16, sizeof(T)); owned = true;
+        _width = (int)w; _height = (int)h; _depth = (int)d;
+        return 1;
+    }
+    int bind_tex() { return 1; }
+    int copy_from_host(const T* src, cudaPos pos, size_t w, size_t h, size_t d) {
+        for (size_t z = 0; z < d; z++) for (size_t y = 0; y < h; y++) memcpy(&at(pos.x, pos.y + y, pos.z + z), src + (z * h + y) * w, w * sizeof(T));
+        return cudaSuccess;
+    }
+    int copy_to_host(const T* dst, cudaPos pos, size_t w, size_t h, size_t d) {
+        for (size_t z = 0; z < d; z++) for (size_t y = 0; y < h; y++) memcpy(const_cast<T*>(dst) + (z * h + y) * w, &at(pos.x, pos.y + y, pos.z + z), w * sizeof(T));
+        return cudaSuccess;
+    }
     T& at(const size_t x, const size_t y, const size_t d = 0) { return ptr[(d * (size_t)_height + y) * (size_t)_width + x]; }
     T at_tex(const float x, const float y, const int d = 0) const;  /* D2 */
 };
@@ -77,5 +120,6 @@ template <> inline float2 GMat<float2>::at_tex(const float x, const float y, con
 }
 typedef GMat<float> GMatf;
 typedef GMat<float2> GMatf2;
+typedef GMat<float3> GMatf3;
 typedef GMat<float4> GMatf4;
 typedef GMat<curandState> GMatRnd;

@@ -1,94 +1,169 @@
-// oracle/_ref builder, part 2: the DEVICE code of the reference's CUDA files executed on the CPU.
-// The Makefile cuts the device prefix of gpu-kernels/optimize_depth.cu (everything before the host entry point, lines 1-291)
-// and the kernel of gpu-kernels/fb_smooth.h (lines 17-70) out of the files into temp files outside the repo and passes
-// their paths as REF_OD_INC / REF_FB_INC; ref_stubs/emul/cuda_emul.h supplies threadIdx & co, a sequential launcher, a
-// host-backed GMat and the two documented substitutions (D1 RNG, D2 bilinear).  The launch geometry and stage order
-// below restate optimize_depth.cu:314-325,462-494 and fb_smooth.h:72-108 (host code that cannot be compiled: <<< >>>).
-// TEST INFRASTRUCTURE ONLY: pins oracle/orc_model.c (tests/golden/ref_depth.npz, ref_fb.npz).
-#if defined(REF_OD_INC) && defined(REF_FB_INC)
+// oracle/_ref builder, part 2: the reference's CUDA kernel files -- kernels, device functions AND host entry points --
+// compiled for the CPU and executed thread by thread.
+//
+// oracle/ref_prep.pl rewrites the <<< >>> launch statements of gpu-kernels/{optimize_depth,collect_p3p_instances,
+// meanshift,fit_robust_gaussian,solve_batch_ap3p,solve_batch_lambdatwist}.cu and fb_smooth.h into a temp directory
+// outside the repo (REF_PREP_DIR, deleted after the build); each file is included below in its own namespace (they all
+// define file-static __constant__ symbols with the same names).  ref_stubs/emul/ supplies threadIdx & co, a sequential
+// launcher, cudaMalloc/cudaMemcpy on host memory, a host-backed GMat, and stand-ins for the three pieces that cannot be
+// run as they are: the RNG (D1), the texture filter (D2), the __syncthreads tree reduction (summation order restated)
+// and aux_funs.cpp (OpenCV Matx66d: LU in double, defined at the bottom of this file).
+//
+// TEST INFRASTRUCTURE ONLY: pins oracle/orc_model.c + oracle/orc_pose.c (tests/golden/ref_kernels.npz).
+#ifdef REF_PREP_DIR
 #include <vector>
 #include "ref_stubs/emul/cuda_emul.h"
 #include "gpu-kernels/utils.h"
+#include "gpu-kernels/gpu_kernels.h"
 #include "gpu-kernels/residual_model.h"
+#include "gpu-kernels/rodrigues.h"
+#include "lambdatwist/lambdatwist_p4p.h"
+#include "ref_stubs/emul/gmat.h"
+#include "ref_stubs/emul/reduce_vector_sum.h"
+#include "ref_stubs/emul/aux_funs.h"
 
-namespace ref_fb {
-#define FB_MSG_L2R 0
-#define FB_MSG_T2B 1
-#define FB_MSG_R2L 2
-#define FB_MSG_B2T 3
-#define FB_POSTERIOR 4
-#include REF_FB_INC
-}  // namespace ref_fb
-
+#define EMUL_STR2(x) #x
+#define EMUL_STR(x) EMUL_STR2(x)
 namespace ref_od {
-#include REF_OD_INC
-}  // namespace ref_od
+#include EMUL_STR(REF_PREP_DIR/optimize_depth.cu)
+}
+#undef BLOCK_WIDTH
+#undef MAX_FRAMES
+#undef RAND_SEED
+namespace ref_collect {
+#include EMUL_STR(REF_PREP_DIR/collect_p3p_instances.cu)
+}
+#undef BLOCK_WIDTH
+#undef MAX_FRAMES
+#undef RAND_SEED
+#define RAND_SEED 233  /* utils.h:18, dropped by the #undef above */
+#define rand emul_host_rand
+namespace ref_ms {
+#include EMUL_STR(REF_PREP_DIR/meanshift.cu)
+}
+#undef rand
+#undef MAX_DIMS
+#undef N_THREADS
+namespace ref_rg {
+#include EMUL_STR(REF_PREP_DIR/fit_robust_gaussian.cu)
+}
+#undef MAX_DIMS
+#undef N_THREADS
+namespace ref_ap3p {
+#include EMUL_STR(REF_PREP_DIR/solve_batch_ap3p.cu)
+}
+#undef N_THREADS
+namespace ref_lt {
+#include EMUL_STR(REF_PREP_DIR/solve_batch_lambdatwist.cu)
+}
 
 extern "C" {
 
-// fb_smooth_batch_inplace (fb_smooth.h:72-108): rows (L2R, R2L, posterior), then columns (T2B, B2T, posterior)
+// fb_smooth_batch_inplace (fb_smooth.h:72-108) on caller memory: maps [N][h][w], smoothed in place
 void ref_fb_smooth(float* maps, int N, int w, int h, float s0_ems_prob, float no_change_prob) {
-    std::vector<float> fwd((size_t)N * w * h), bwd((size_t)N * w * h);
-    GMatf m, f, b;
-    m.bind(maps, w, h, N); f.bind(fwd.data(), w, h, N); b.bind(bwd.data(), w, h, N);
-    const dim3 blk(16, 16, 1), grid(DIV_CEIL_EMUL(w, 16), DIV_CEIL_EMUL(h, 16), N);
-    const dim3 blk_row(1, 128, 1), grid_row(1, DIV_CEIL_EMUL(h, 128), N), blk_col(128, 1, 1), grid_col(DIV_CEIL_EMUL(w, 128), 1, N);
-    using namespace ref_fb;
-    emul_launch(grid_row, blk_row, [&] { fb_smooth_inplace_kernel<FB_MSG_L2R>(m, f, b, s0_ems_prob, no_change_prob, N, w, h); });
-    emul_launch(grid_row, blk_row, [&] { fb_smooth_inplace_kernel<FB_MSG_R2L>(m, f, b, s0_ems_prob, no_change_prob, N, w, h); });
-    emul_launch(grid, blk, [&] { fb_smooth_inplace_kernel<FB_POSTERIOR>(m, f, b, s0_ems_prob, no_change_prob, N, w, h); });
-    emul_launch(grid_col, blk_col, [&] { fb_smooth_inplace_kernel<FB_MSG_T2B>(m, f, b, s0_ems_prob, no_change_prob, N, w, h); });
-    emul_launch(grid_col, blk_col, [&] { fb_smooth_inplace_kernel<FB_MSG_B2T>(m, f, b, s0_ems_prob, no_change_prob, N, w, h); });
-    emul_launch(grid, blk, [&] { fb_smooth_inplace_kernel<FB_POSTERIOR>(m, f, b, s0_ems_prob, no_change_prob, N, w, h); });
+    GMatf m; m.bind(maps, w, h, N);
+    ref_od::fb_smooth_batch_inplace(m, s0_ems_prob, no_change_prob, N, w, h);
 }
 
-// optimize_depth_gpu without the uploads (optimize_depth.cu:293-520): binds the "device" arrays to the caller's host arrays,
-// fills the __constant__ block, then runs the kernels in the order of :462-494.  flows [N][h][w][2], rig [N][h][w],
-// priors/pconfs/confs [N_dp][h][w], depth [h][w] (in/out), cost [h][w] (out), K4 = fx,cx,fy,cy, Rs [N][9], ts [N][3].
-// rand_epoch: counter value the random-sample kernels start from (the reference keeps cuRAND states across calls).
-// stage mask: 1 cost map, 2 random samples, 4 global propagation, 8 local propagation, 16 rigidness update, 32 fb_smooth.
-void ref_optimize_depth(float* flows, float* rig, float* priors, float* pconfs, float* confs, float* depth, float* cost, const float* K4,
-                        const float* Rs, const float* ts, const float* dpRs, const float* dpts, float abs_resize_factor, int N, int N_dp, int w,
-                        int h, float basefocal, int n_rand_samples, int global_prop_step, int local_prop_width, float lambda, float omega,
-                        float disp_delta, float delta, float s0_ems_prob, float no_change_prob, float range_factor, unsigned rand_epoch,
-                        int stages) {
-    using namespace ref_od;
-    for (int k = 0; k < 4; k++) _K4[k] = K4[k];
-    _K4_inv[0] = 1.f / K4[0]; _K4_inv[1] = -K4[1] / K4[0]; _K4_inv[2] = 1.f / K4[2]; _K4_inv[3] = -K4[3] / K4[2];  // :343-347
-    if (N > 0) { memcpy(_Rs, Rs, sizeof(float) * 9 * N); memcpy(_ts, ts, sizeof(float) * 3 * N); }
-    if (N_dp > 0) { memcpy(_dp_Rs, dpRs, sizeof(float) * 9 * N_dp); memcpy(_dp_ts, dpts, sizeof(float) * 3 * N_dp); }
-    _N = N; _N_dp = N_dp; _w = w; _h = h; _abs_resize_factor = abs_resize_factor; _basefocal = basefocal;
-    _lambda = lambda; _omega = omega; _delta = delta; _disp_delta = disp_delta; _range_factor = range_factor;
-    std::vector<curandState> states((size_t)w * h);
-    _d_rand_states.bind(states.data(), w, h, 1);
-    _d_flows.bind(reinterpret_cast<float2*>(flows), w, h, N);
-    _d_rigidnesses.bind(rig, w, h, N);
-    _d_depth_priors.bind(priors, w, h, N_dp); _d_depth_prior_pconfs.bind(pconfs, w, h, N_dp); _d_depth_prior_confs.bind(confs, w, h, N_dp);
-    _d_depth.bind(depth, w, h, 1); _d_cost_map.bind(cost, w, h, 1);
-    const dim3 blk(16, 16), grid(DIV_CEIL_EMUL(w, 16), DIV_CEIL_EMUL(h, 16));                                     // :311-312
-    const dim3 blk_rc(1, 64), grid_rc(1, DIV_CEIL_EMUL(h, 64)), blk_cc(64, 1), grid_cc(DIV_CEIL_EMUL(w, 64), 1);  // :314-318
-    emul_launch(grid, blk, [&] { init_rand_states(); });
-    for (auto& s : states) s.counter = rand_epoch;
-    if (stages & 32) {
-        if (N > 0) ref_fb_smooth(rig, N, w, h, s0_ems_prob, no_change_prob);
-        if (N_dp > 0) ref_fb_smooth(confs, N_dp, w, h, s0_ems_prob, no_change_prob);
-    }
-    if (stages & 1) emul_launch(grid, blk, [&] { compute_cost_map(); });
-    if (stages & 2) for (int it = 0; it < n_rand_samples; it++) emul_launch(grid, blk, [&] { optimize_depth_with_rand_inplace(); });
-    if ((stages & 4) && global_prop_step > 0) {
-        emul_launch(grid_rc, blk_rc, [&] { optimize_depth_with_global_propagation_inplace<PROPAGATE_L2R>(global_prop_step); });
-        emul_launch(grid_cc, blk_cc, [&] { optimize_depth_with_global_propagation_inplace<PROPAGATE_B2T>(global_prop_step); });
-        emul_launch(grid_rc, blk_rc, [&] { optimize_depth_with_global_propagation_inplace<PROPAGATE_R2L>(global_prop_step); });
-        emul_launch(grid_cc, blk_cc, [&] { optimize_depth_with_global_propagation_inplace<PROPAGATE_T2B>(global_prop_step); });
-    }
-    if ((stages & 8) && local_prop_width > 0) {
-        const dim3 grid_rs(DIV_CEIL_EMUL(w, 16 * local_prop_width), DIV_CEIL_EMUL(h, 16)), grid_cs(DIV_CEIL_EMUL(w, 16), DIV_CEIL_EMUL(h, 16 * local_prop_width));  // :321-325
-        emul_launch(grid_rs, blk, [&] { optimize_depth_with_local_propagation_inplace<PROPAGATE_L2R>(local_prop_width); });
-        emul_launch(grid_cs, blk, [&] { optimize_depth_with_local_propagation_inplace<PROPAGATE_B2T>(local_prop_width); });
-        emul_launch(grid_rs, blk, [&] { optimize_depth_with_local_propagation_inplace<PROPAGATE_R2L>(local_prop_width); });
-        emul_launch(grid_cs, blk, [&] { optimize_depth_with_local_propagation_inplace<PROPAGATE_T2B>(local_prop_width); });
-    }
-    if (stages & 16) emul_launch(grid, blk, [&] { update_rigidnesses(); });
+// optimize_depth_gpu (optimize_depth.cu:293-520), the reference's own host function.  flows [N][h][w][2], rig [N][h][w]
+// (in/out), priors/pconfs [N_dp][h][w], confs [N_dp][h][w] (in/out), depth [h][w] (in/out), cost [h][w] (out: the
+// reference keeps it on the device), K = 3x3 row-major, Rs [N][9], ts [N][3].  rand_epoch: counter value the cuRAND
+// states start from (the reference keeps its states across calls; here they are re-created for every call).
+int ref_optimize_depth(float* flows, float* rig, float* priors, float* pconfs, float* confs, float* depth, float* cost, float* K, float* Rs,
+                       float* ts, float* dpRs, float* dpts, float abs_resize_factor, int N, int N_dp, int w, int h, float basefocal,
+                       int n_rand_samples, int global_prop_step, int local_prop_width, float lambda, float omega, float disp_delta, float delta,
+                       int fb_smooth, float s0_ems_prob, float no_change_prob, float range_factor, int update_rigidness_only,
+                       unsigned rand_epoch) {
+    const size_t px = (size_t)w * h;
+    std::vector<float*> f(N), r(N), R(N), t(N), p(N_dp), pc(N_dp), c(N_dp), dR(N_dp), dt(N_dp);
+    for (int i = 0; i < N; i++) { f[i] = flows + i * px * 2; r[i] = rig + i * px; R[i] = Rs + i * 9; t[i] = ts + i * 3; }
+    for (int i = 0; i < N_dp; i++) { p[i] = priors + i * px; pc[i] = pconfs + i * px; c[i] = confs + i * px; dR[i] = dpRs + i * 9; dt[i] = dpts + i * 3; }
+    ref_od::d_rand_states.create(1, 1, 1);  // force optimize_depth.cu:357-362 to re-create and re-seed the states
+    emul_curand_epoch = rand_epoch;
+    const int rc = ref_od::optimize_depth_gpu(f.data(), r.data(), r.data(), N_dp ? p.data() : nullptr, N_dp ? pc.data() : nullptr,
+                                              N_dp ? c.data() : nullptr, N_dp ? c.data() : nullptr, depth, depth, K, R.data(), t.data(),
+                                              N_dp ? dR.data() : nullptr, N_dp ? dt.data() : nullptr, abs_resize_factor, N, N_dp, w, h, basefocal,
+                                              n_rand_samples, global_prop_step, local_prop_width, lambda, omega, disp_delta, delta, fb_smooth != 0,
+                                              s0_ems_prob, no_change_prob, range_factor, update_rigidness_only != 0);
+    emul_curand_epoch = 0;
+    if (cost) ref_od::d_cost_map.copy_to_host(cost, make_cudaPos(0, 0, 0), w, h, 1);
+    return rc;
 }
+
+// collect_p3p_instances (collect_p3p_instances.cu:147-250): p2_map [h][w][2], p3_map [h][w][3], NaN where rejected
+int ref_collect_p3p(float* flows, float* rig, float* depth, float* K, float* Rs, float* ts, float* o_p2_map, float* o_p3_map, int N, int w, int h,
+                    int active_idx, float rigidness_thresh, float rigidness_sum_thresh, float sample_min_depth, float sample_max_depth,
+                    int max_trace_on_flow) {
+    const size_t px = (size_t)w * h;
+    std::vector<float*> f(N), r(N), R(N), t(N);
+    for (int i = 0; i < N; i++) { f[i] = flows + i * px * 2; r[i] = rig + i * px; R[i] = Rs + i * 9; t[i] = ts + i * 3; }
+    return ref_collect::collect_p3p_instances(f.data(), r.data(), depth, K, R.data(), t.data(), o_p2_map, o_p3_map, N, w, h, active_idx,
+                                              rigidness_thresh, rigidness_sum_thresh, sample_min_depth, sample_max_depth, max_trace_on_flow);
+}
+
+// solve_batch_p3p_{lambdatwist,ap3p}_gpu (solve_batch_lambdatwist.cu:51-102, solve_batch_ap3p.cu:387-437)
+int ref_solve_batch_p3p(float* p3s, float* p2s, float* o_rvecs, float* o_tvecs, float* K, int N_pts, int N_poses, int use_ap3p) {
+    return use_ap3p ? ref_ap3p::solve_batch_p3p_ap3p_gpu(p3s, p2s, o_rvecs, o_tvecs, K, N_pts, N_poses)
+                    : ref_lt::solve_batch_p3p_lambdatwist_gpu(p3s, p2s, o_rvecs, o_tvecs, K, N_pts, N_poses);
+}
+
+// meanshift_gpu (meanshift.cu:34-150)
+int ref_meanshift(float* space, float kernel_var, float* io_mean, float* o_confidence, int* used_iters, int use_external_init_mean, int N, int dims,
+                  float epsilon, int max_iters, int max_init_trials, float good_init_confidence) {
+    emul_rand_trial = 0; emul_rand_mod = (uint32_t)N;
+    return ref_ms::meanshift_gpu(space, kernel_var, io_mean, o_confidence, used_iters, use_external_init_mean != 0, N, dims, epsilon, max_iters,
+                                 max_init_trials, good_init_confidence);
+}
+
+// fit_robust_gaussian (fit_robust_gaussian.cu:101-286)
+int ref_fit_robust_gaussian(float* space, float* io_mean, float* io_covar, float trunc_sigma, float covar_reg_lambda, float* o_density,
+                            int* used_iters, int N, int dims, float epsilon, int max_iters) {
+    return ref_rg::fit_robust_gaussian(space, io_mean, io_covar, trunc_sigma, covar_reg_lambda, o_density, used_iters, N, dims, epsilon, max_iters);
+}
+}  // extern "C"
+
+// ---- stand-in for gpu-kernels/aux_funs.cpp:97-141 (cv::Matx66d): partial-pivot Gauss-Jordan in double, N <= 6
+static double emul_lu(const double* A, double* Ainv, int n) {  // returns det(A); Ainv (may be null) only valid when det != 0
+    double a[36], b[36];
+    for (int i = 0; i < n * n; i++) { a[i] = A[i]; b[i] = (i / n == i % n) ? 1.0 : 0.0; }
+    double det = 1.0;
+    for (int i = 0; i < n; i++) {
+        int k = i;
+        for (int j = i + 1; j < n; j++) if (fabs(a[j * n + i]) > fabs(a[k * n + i])) k = j;
+        if (fabs(a[k * n + i]) < DBL_EPSILON) return 0.0;
+        if (k != i) { for (int j = 0; j < n; j++) { std::swap(a[i * n + j], a[k * n + j]); std::swap(b[i * n + j], b[k * n + j]); } det = -det; }
+        const double d = -1.0 / a[i * n + i];
+        for (int j = i + 1; j < n; j++) {
+            const double alpha = a[j * n + i] * d;
+            for (int c = i + 1; c < n; c++) a[j * n + c] += alpha * a[i * n + c];
+            for (int c = 0; c < n; c++) b[j * n + c] += alpha * b[i * n + c];
+        }
+        det *= a[i * n + i];
+    }
+    if (Ainv) {
+        for (int i = n - 1; i >= 0; i--) for (int c = 0; c < n; c++) {
+            double s = b[i * n + c];
+            for (int k = i + 1; k < n; k++) s -= a[i * n + k] * b[k * n + c];
+            b[i * n + c] = s / a[i * n + i];
+        }
+        for (int i = 0; i < n * n; i++) Ainv[i] = b[i];
+    }
+    return det;
+}
+double determinant(double* mat, int N) { return emul_lu(mat, nullptr, N); }
+double inverse(double* mat, double* mat_inv, int N) {
+    double inv[36];
+    const double det = emul_lu(mat, inv, N);
+    if (det > 0) for (int i = 0; i < N * N; i++) mat_inv[i] = inv[i];
+    return det;
+}
+double regularize_covar_LW_given_lambda(double* mat, double* mat_ret, double lambda, int dims) {
+    double m = 0;
+    for (int i = 0; i < dims; i++) m += mat[i * dims + i];
+    m /= (double)dims;
+    double S[36];
+    for (int i = 0; i < dims; i++) for (int j = 0; j < dims; j++) S[i * dims + j] = lambda * m * (i == j ? 1.0 : 0.0) + (1 - lambda) * mat[i * dims + j];
+    for (int i = 0; i < dims * dims; i++) mat_ret[i] = S[i];
+    return emul_lu(S, nullptr, dims);
 }
 #endif
