@@ -2,9 +2,11 @@
  * back-end: gpu-kernels/align_frame.cu:47-137 (rot_with_rvec), :140-162 (pin-hole helpers),
  * :153-205 (normals and image gradients), :207-388 (compute_residual), :390-417 (weighted sqrt-Cauchy loss),
  * :414-554 (host entry points), with the GMat access rules of gpu-kernels/gmat.h:171-186.
- * TEST INFRASTRUCTURE ONLY (tests/ link it through oracle/orc.py).  rot_with_rvec is pinned against the reference's own
- * function compiled in place (oracle/_ref, tests/golden/ref_rot.npz); the rest is restated from source ("parity
- * unpinned": no reference vectors exist for it and the .cu cannot be built here).
+ * TEST INFRASTRUCTURE ONLY (tests/ link it through oracle/orc.py).  PINNED against the reference's own code: rot_with_rvec
+ * against the function compiled in place (oracle/_ref, tests/golden/ref_rot.npz), and the whole pair of entry points against
+ * align_frame.cu itself compiled for the CPU on the launch-emulation layer (oracle/ref_wrap_kernels.cpp,
+ * tests/golden/ref_kernels.npz "align/..."): residual maps bit-exact incl. the NaN mask, Jacobian maps to 1e-6 of each
+ * parameter's scale (tests/test_oracle_vs_ref_kernels.py::test_align_frame_matches_reference).
  *
  * Same deviation as the VO path: D2, bilinear fetches use exact fp32 weights per layer with clamp-to-edge instead of the
  * 8-bit CUDA texture filter over vertically stacked layers.

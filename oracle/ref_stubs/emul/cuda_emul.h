@@ -82,6 +82,7 @@ template <typename T> struct GMat {
         return 1;
     }
     int bind_tex() { return 1; }
+    int zeros() { memset(ptr, 0, (size_t)_width * _height * (_depth ? _depth : 1) * sizeof(T)); return cudaSuccess; }
     int copy_from_host(const T* src, cudaPos pos, size_t w, size_t h, size_t d) {
         for (size_t z = 0; z < d; z++) for (size_t y = 0; y < h; y++) memcpy(&at(pos.x, pos.y + y, pos.z + z), src + (z * h + y) * w, w * sizeof(T));
         return cudaSuccess;
@@ -92,6 +93,13 @@ template <typename T> struct GMat {
     }
     T& at(const size_t x, const size_t y, const size_t d = 0) { return ptr[(d * (size_t)_height + y) * (size_t)_width + x]; }
     T at_tex(const float x, const float y, const int d = 0) const;  /* D2 */
+    /* gmat.h:181-186: the indices are size_t, so -1 wraps and min() sends it to the LAST row / column / layer */
+    T& at_safe(const size_t x, const size_t y, const size_t d = 0) {
+        return at(std::min(x, (size_t)(_width - 1)), std::min(y, (size_t)(_height - 1)), std::min(d, (size_t)(_depth - 1)));
+    }
+    T at_tex_safe(const float x, const float y, const int d = 0) const {  /* gmat.h:188-195 */
+        return at_tex(std::max(std::min(x, (float)(_width - 1)), 0.f), std::max(std::min(y, (float)(_height - 1)), 0.f), std::max(std::min(d, _depth - 1), 0));
+    }
 };
 static inline void emul_bil_idx(float x, float y, int w, int h, int& x0, int& x1, int& y0, int& y1, float& a, float& b) {
     const float fx = floorf(x), fy = floorf(y);
@@ -116,6 +124,19 @@ template <> inline float2 GMat<float2>::at_tex(const float x, const float y, con
     float2 r;
     r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
     r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
+    return r;
+}
+template <> inline float4 GMat<float4>::at_tex(const float x, const float y, const int d) const {
+    int x0, x1, y0, y1; float a, b;
+    emul_bil_idx(x, y, _width, _height, x0, x1, y0, y1, a, b);
+    const float4* m = ptr + (size_t)d * _height * _width;
+    const float4 t00 = m[y0 * _width + x0], t10 = m[y0 * _width + x1], t01 = m[y1 * _width + x0], t11 = m[y1 * _width + x1];
+    const float w00 = (1.f - a) * (1.f - b), w10 = a * (1.f - b), w01 = (1.f - a) * b, w11 = a * b;
+    float4 r;
+    r.x = w00 * t00.x + w10 * t10.x + w01 * t01.x + w11 * t11.x;
+    r.y = w00 * t00.y + w10 * t10.y + w01 * t01.y + w11 * t11.y;
+    r.z = w00 * t00.z + w10 * t10.z + w01 * t01.z + w11 * t11.z;
+    r.w = w00 * t00.w + w10 * t10.w + w01 * t01.w + w11 * t11.w;
     return r;
 }
 typedef GMat<float> GMatf;

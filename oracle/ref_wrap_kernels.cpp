@@ -2,7 +2,7 @@
 // compiled for the CPU and executed thread by thread.
 //
 // oracle/ref_prep.pl rewrites the <<< >>> launch statements of gpu-kernels/{optimize_depth,collect_p3p_instances,
-// meanshift,fit_robust_gaussian,solve_batch_ap3p,solve_batch_lambdatwist}.cu and fb_smooth.h into a temp directory
+// meanshift,fit_robust_gaussian,solve_batch_ap3p,solve_batch_lambdatwist,align_frame}.cu and fb_smooth.h into a temp directory
 // outside the repo (REF_PREP_DIR, deleted after the build); each file is included below in its own namespace (they all
 // define file-static __constant__ symbols with the same names).  ref_stubs/emul/ supplies threadIdx & co, a sequential
 // launcher, cudaMalloc/cudaMemcpy on host memory, a host-backed GMat, and stand-ins for the three pieces that cannot be
@@ -21,6 +21,8 @@
 #include "ref_stubs/emul/gmat.h"
 #include "ref_stubs/emul/reduce_vector_sum.h"
 #include "ref_stubs/emul/aux_funs.h"
+#include "ref_stubs/emul/gblur.h"
+#include "gpu-kernels/vops.h"
 
 #define EMUL_STR2(x) #x
 #define EMUL_STR(x) EMUL_STR2(x)
@@ -55,6 +57,12 @@ namespace ref_ap3p {
 #undef N_THREADS
 namespace ref_lt {
 #include EMUL_STR(REF_PREP_DIR/solve_batch_lambdatwist.cu)
+}
+#undef N_THREADS
+#undef MAX_FRAMES
+#undef BLOCK_WIDTH
+namespace ref_align {
+#include EMUL_STR(REF_PREP_DIR/align_frame.cu)
 }
 
 extern "C" {
@@ -119,6 +127,18 @@ int ref_meanshift(float* space, float kernel_var, float* io_mean, float* o_confi
 int ref_fit_robust_gaussian(float* space, float* io_mean, float* io_covar, float trunc_sigma, float covar_reg_lambda, float* o_density,
                             int* used_iters, int N, int dims, float epsilon, int max_iters) {
     return ref_rg::fit_robust_gaussian(space, io_mean, io_covar, trunc_sigma, covar_reg_lambda, o_density, used_iters, N, dims, epsilon, max_iters);
+}
+
+// align_frame_init_gpu / align_frame_eval_gpu (align_frame.cu:414-554): images/depths/weights [N][h][w], K 3x3 row-major
+int ref_align_init(float* images, float* depths, float* weights, float* K, float vbf, float crw, int N, int w, int h) {
+    const size_t px = (size_t)w * h;
+    std::vector<float*> im(N), d(N), wt(N);
+    for (int i = 0; i < N; i++) { im[i] = images ? images + i * px : nullptr; d[i] = depths + i * px; wt[i] = weights + i * px; }
+    return ref_align::align_frame_init_gpu(images ? im.data() : nullptr, d.data(), wt.data(), K, vbf, crw, N, w, h);
+}
+int ref_align_eval(int ref_fid, int tar_fid, const float* params_ref, const float* params_tar, float* o_residual, float* o_jacobian,
+                   int apply_weights) {
+    return ref_align::align_frame_eval_gpu(ref_fid, tar_fid, params_ref, params_tar, o_residual, o_jacobian, apply_weights != 0);
 }
 }  // extern "C"
 

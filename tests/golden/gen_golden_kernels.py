@@ -2,11 +2,12 @@
 
 Run in the build container only (needs /root/reference): `python tests/golden/gen_golden_kernels.py`.
 oracle/_ref/libvoldor_ref.so is built by `make -C oracle ref`: oracle/ref_prep.pl rewrites the <<< >>> launches of
-gpu-kernels/{optimize_depth,collect_p3p_instances,meanshift,fit_robust_gaussian,solve_batch_ap3p,solve_batch_lambdatwist}.cu
+gpu-kernels/{optimize_depth,collect_p3p_instances,meanshift,fit_robust_gaussian,solve_batch_ap3p,solve_batch_lambdatwist,
+align_frame}.cu
 and fb_smooth.h into a temp directory, oracle/ref_wrap_kernels.cpp compiles them on top of oracle/ref_stubs/emul/ (sequential
 launcher, host-backed GMat; substitutions: D1 counter RNG, D2 exact bilinear, tree reduction order restated, aux_funs LU).
 The functions called here are the reference's host entry points themselves (optimize_depth_gpu, collect_p3p_instances,
-solve_batch_p3p_*_gpu, meanshift_gpu, fit_robust_gaussian, fb_smooth_batch_inplace).
+solve_batch_p3p_*_gpu, meanshift_gpu, fit_robust_gaussian, fb_smooth_batch_inplace, align_frame_init_gpu / align_frame_eval_gpu).
 
 Inputs are re-derived from seeds by tests/ref_kernel_cases.py (shared with the tests), only outputs are stored.
 """
@@ -105,9 +106,29 @@ def ref_rg(ref, space, mean, covar, a):
     return rc, mean, covar, np.float32(dens.value), it.value
 
 
+def ref_align(ref, kf, photo, evals):
+    depths = np.ascontiguousarray(kf["depths"], np.float32)
+    N, h, w = depths.shape
+    images = np.ascontiguousarray(kf["images"], np.float32) if photo else None
+    weights = np.ascontiguousarray(kf["weights"], np.float32)
+    K = np.ascontiguousarray(kf["K"], np.float32).reshape(9)
+    assert ref.ref_align_init(fp(images), fp(depths), fp(weights), fp(K), C.c_float(kf["vbf"]), C.c_float(kf["crw"] if photo else 0.0), N, w, h) == 0
+    for name, rf, tf, pr, pt, want_j, apply_w in evals:
+        res = np.zeros((h, w), np.float32)
+        jac = np.zeros((h, w, 9), np.float32) if want_j else None
+        pr, pt = np.ascontiguousarray(pr, np.float32), np.ascontiguousarray(pt, np.float32)
+        assert ref.ref_align_eval(rf, tf, fp(pr), fp(pt), fp(res), fp(jac), int(apply_w)) == 0
+        yield name, res, jac
+
+
 def main():
     ref = load_ref()
     out = {}
+    for name, kf, photo, evals in cases.align_cases():
+        for ename, res, jac in ref_align(ref, kf, photo, evals):
+            out[f"align/{name}/{ename}/residual"] = res
+            if jac is not None:
+                out[f"align/{name}/{ename}/jacobian"] = jac
     for name, maps, s0, p in cases.fb_cases():
         out[f"fb/{name}"] = ref_fb(ref, maps, s0, p)
     for name, c in cases.depth_cases():

@@ -5,6 +5,8 @@ import numpy as np
 
 from voldor_amd import synth
 
+import align_scene
+
 OD_DEFAULTS = dict(abs_resize_factor=1.0, basefocal=0.0, n_rand_samples=10, global_prop_step=8, local_prop_width=32,
                    lambda_=0.15, omega=0.15, disp_delta=-1.0, delta=0.5, fb_smooth=1, s0_ems_prob=0.5,
                    no_change_prob=0.9, range_factor=1.0, update_rigidness_only=0)
@@ -139,3 +141,20 @@ def rg_cases():
     yield "n1000_cap2", pool2, c2, (np.eye(6) * 4e-2).astype(np.float32), dict(RG_DEFAULTS, max_iters=2)
     flat = np.tile(centre, (600, 1)).astype(np.float32)  # zero spread: singular covariance after the first M-step
     yield "singular", flat, centre, cov, dict(RG_DEFAULTS, covar_reg_lambda=0.0)
+
+
+def align_cases():
+    """(name, keyframe set, photometric?, [(eval name, ref_fid, tar_fid, params_ref, params_tar, want_jacobian, apply_weights)])"""
+    kf = align_scene.keyframes(w=64, h=48, n=3, seed=2)
+    rng = np.random.default_rng(8)
+    P = kf["params"].copy()
+    pert = P + rng.normal(0, 1, P.shape).astype(np.float32) * np.array([2e-3] * 3 + [2e-2] * 3 + [0, 0, 0], np.float32)
+    scaled = pert.copy()
+    scaled[:, 6] = [0.02, -0.03, 0.01]   # log depth scale
+    scaled[:, 7] = [0.05, 0.0, -0.04]    # log colour scale
+    scaled[:, 8] = [0.01, -0.02, 0.0]    # colour offset
+    yield "photo", kf, True, [("f0_f1_jac", 0, 1, pert[0], pert[1], True, True),
+                              ("f2_f0_scaled_jac", 2, 0, scaled[2], scaled[0], True, True),
+                              ("f1_f2_truth_res", 1, 2, P[1], P[2], False, False)]
+    yield "depth_only", kf, False, [("f1_f0_jac", 1, 0, scaled[1], scaled[0], True, False),
+                                    ("f0_f2_res", 0, 2, pert[0], pert[2], False, True)]

@@ -2,7 +2,7 @@
 
 tests/golden/ref_kernels.npz holds the outputs of the reference's host entry points (optimize_depth_gpu,
 fb_smooth_batch_inplace, collect_p3p_instances, solve_batch_p3p_{lambdatwist,ap3p}_gpu, meanshift_gpu,
-fit_robust_gaussian) compiled for the CPU by oracle/ref_wrap_kernels.cpp and run thread by thread on the seeded inputs of
+fit_robust_gaussian, align_frame_init_gpu / align_frame_eval_gpu) compiled for the CPU by oracle/ref_wrap_kernels.cpp and run thread by thread on the seeded inputs of
 tests/ref_kernel_cases.py (generator: tests/golden/gen_golden_kernels.py; substitutions D1 RNG / D2 bilinear).
 
 Bars: the per-pixel passes, fb_smooth, the correspondence maps and the minimal solvers (index draw + LambdaTwist / AP3P +
@@ -127,3 +127,24 @@ def test_fit_robust_gaussian_matches_reference(gold, name, space, mean0, cov0, a
     assert abs(dens - float(gold[f"rg/{name}/density"])) <= 1.0 / space.shape[0] + 1e-7
     np.testing.assert_allclose(mean, gold[f"rg/{name}/mean"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(covar, gold[f"rg/{name}/covar"], rtol=2e-4, atol=1e-8)
+
+
+@pytest.mark.parametrize("name,kf,photo,evals", list(cases.align_cases()), ids=[c[0] for c in cases.align_cases()])
+def test_align_frame_matches_reference(gold, name, kf, photo, evals):
+    """align_frame_init_gpu + align_frame_eval_gpu of the reference (normals / gradients at init, residual, sqrt-Cauchy loss,
+    Jacobian) vs oracle/orc_align.c: residual maps bit-exact including the NaN mask; Jacobian maps to 1e-6 of each
+    parameter's scale (the 27-term d/d(rvec) expressions of rot_with_rvec are regrouped in the restatement: 1-2 ulp)."""
+    A = orc.Align(kf["images"] if photo else None, kf["depths"], kf["weights"], kf["K"], kf["vbf"], kf["crw"] if photo else 0.0)
+    for en, rf, tf, pr, pt, want_j, apply_w in evals:
+        res, jac = A.eval(rf, tf, pr, pt, want_j, apply_w)
+        g_res = gold[f"align/{name}/{en}/residual"]
+        assert 0.5 < np.isfinite(g_res).mean() <= 1.0
+        assert same_values(res, g_res), en
+        if want_j:
+            g_jac = gold[f"align/{name}/{en}/jacobian"]
+            scale = np.nanmax(np.abs(g_jac), axis=(0, 1))
+            assert np.array_equal(np.isnan(jac), np.isnan(g_jac))
+            err = np.nanmax(np.abs(jac - g_jac), axis=(0, 1))
+            assert np.all(err <= 1e-6 * np.maximum(scale, 1.0)), (en, err, scale)
+            if not photo:
+                assert scale[7] == 0 and scale[8] == 0  # no colour parameters without the photometric term
