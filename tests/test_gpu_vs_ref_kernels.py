@@ -1,0 +1,149 @@
+"""The HIP kernels against the REFERENCE's own kernel outputs (tests/golden/ref_kernels.npz: the reference's .cu files run
+on the CPU by oracle/ref_wrap_kernels.cpp, see tests/golden/gen_golden_kernels.py), through the C-ABI, on the seeded inputs
+of tests/ref_kernel_cases.py.  No oracle in between: this is product vs reference code.
+
+Bars (same rules as the oracle-mediated stage tests in test_gpu_kernels.py): geometry / validity decisions /
+correspondence maps identical up to border rounding; Fisk-model values (rigidness, cost-driven decisions) to the accuracy
+of the hardware log/exp against glibc powf -- a depth search is a chain of argmin decisions, so the share of pixels taking
+the same branch is asserted, and values are compared on those pixels; solver translations on the bulk of the hypotheses
+(minimal solvers are ill-conditioned on some 4-tuples); iterative estimators to float summation order.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import ref_kernel_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_kernels.npz")
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(GOLD)
+
+
+@pytest.mark.parametrize("name,maps,s0,p", list(cases.fb_cases()), ids=[c[0] for c in cases.fb_cases()])
+def test_fb_smooth_vs_reference_kernel(gold, name, maps, s0, p):
+    from voldor_amd import kernels
+    rc, out = kernels.fb_smooth_gpu(maps, s0, p)
+    assert rc == 0
+    # D7: same recurrence evaluated as composed projective maps with v_rcp_f32; contractive, a few ulp per step
+    assert np.abs(out - gold[f"fb/{name}"]).max() < 2e-5
+
+
+def _run_depth(c):
+    from voldor_amd import kernels
+    kw = c["kw"]
+    N, h, w, _ = c["flows"].shape
+    N_dp = 0 if c["priors"] is None else c["priors"].shape[0]
+    K = np.asarray(c["K"], np.float32).reshape(3, 3)
+    kernels.set_rand_epoch(c["rand_epoch"])
+    return kernels.optimize_depth_gpu(
+        c["flows"], c["rig"], c["priors"], c["pconfs"], c["confs"], c["depth"], K, c["Rs"], c["ts"], c["dpRs"], c["dpts"],
+        kw["abs_resize_factor"], N, N_dp, w, h, kw["basefocal"], kw["n_rand_samples"], kw["global_prop_step"],
+        kw["local_prop_width"], kw["lambda_"], kw["omega"], kw["disp_delta"], kw["delta"], kw["fb_smooth"], kw["s0_ems_prob"],
+        kw["no_change_prob"], kw["range_factor"], kw["update_rigidness_only"])
+
+
+@pytest.mark.parametrize("name,c", list(cases.depth_cases()), ids=[c[0] for c in cases.depth_cases()])
+def test_optimize_depth_vs_reference_kernels(gold, name, c):
+    g_depth, g_rig = gold[f"od/{name}/depth"], gold[f"od/{name}/rig"]
+    depth, rig, confs = _run_depth(c)
+    same = np.abs(depth - g_depth) <= 1e-5 * np.abs(g_depth)
+    if name in ("cost", "update_only"):  # no search: the depth map must come back untouched
+        np.testing.assert_array_equal(depth, g_depth)
+    else:
+        need = 0.97 if name == "ragged_all" else 0.99
+        assert same.mean() >= need, f"{name}: only {same.mean():.4f} of the depth pixels take the reference's branch"
+    # E-step on the pixels whose depth agrees (another depth means another residual, legitimately)
+    assert np.abs(rig - g_rig)[:, same].max() < 5e-4
+    if confs is not None and confs.shape[0]:
+        assert np.abs(confs - gold[f"od/{name}/confs"])[:, same].max() < 5e-4
+
+
+@pytest.mark.parametrize("name,c,active_idx,a", list(cases.collect_cases()), ids=[c[0] for c in cases.collect_cases()])
+def test_collect_p3p_vs_reference_kernel(gold, name, c, active_idx, a):
+    from voldor_amd import kernels
+    N, h, w, _ = c["flows"].shape
+    K = np.asarray(c["K"], np.float32).reshape(3, 3)
+    p2, p3 = kernels.collect_p3p_instances(c["flows"], c["rig"], c["depth"], K, c["Rs"], c["ts"], N, w, h, active_idx, **a)
+    g2, g3 = gold[f"collect/{name}/p2"], gold[f"collect/{name}/p3"]
+    fg, fo = np.isfinite(g2[..., 0]), np.isfinite(p2[..., 0])
+    assert np.mean(fg != fo) < 1e-3
+    both = fg & fo
+    if name == "cam2_sumthresh":
+        assert not fo.any()  # the reference's inert / all-rejecting sum threshold (collect_p3p_instances.cu:91-93)
+        return
+    assert both.sum() > 100
+    assert np.abs(p2[both] - g2[both]).max() < 2e-3
+    assert np.abs(p3[both] - g3[both]).max() < 1e-4 * max(1.0, np.abs(g3[both]).max())
+
+
+@pytest.mark.parametrize("name,X,uv,K,n_poses,use_ap3p", list(cases.solve_cases()), ids=[c[0] for c in cases.solve_cases()])
+def test_solve_batch_p3p_vs_reference_kernel(gold, name, X, uv, K, n_poses, use_ap3p):
+    from voldor_amd import kernels
+    fn = kernels.solve_batch_p3p_ap3p_gpu if use_ap3p else kernels.solve_batch_p3p_lambdatwist_gpu
+    rv, tv = fn(X, uv, K, n_poses)
+    g_rv, g_tv = gold[f"solve/{name}/rvecs"], gold[f"solve/{name}/tvecs"]
+    fg = np.isfinite(g_rv.sum(1) + g_tv.sum(1))
+    fo = np.isfinite(rv.sum(1) + tv.sum(1))
+    assert np.mean(fg != fo) < 0.02
+    both = fg & fo
+    err = np.maximum(np.abs(rv - g_rv).max(1), np.abs(tv - g_tv).max(1))[both]
+    assert np.mean(err < 2e-3) > 0.93, np.percentile(err, [50, 90, 99])
+    if not use_ap3p:  # LambdaTwist is written with the reference's literal types and no fma contraction
+        exact = np.mean(np.all(tv[both] == g_tv[both], axis=1))
+        assert exact > 0.5, f"only {exact:.3f} of the translations are bit-identical"
+
+
+@pytest.mark.parametrize("name,space,kernel_var,init_mean,ext,a", list(cases.meanshift_cases()), ids=[c[0] for c in cases.meanshift_cases()])
+def test_meanshift_vs_reference(gold, name, space, kernel_var, init_mean, ext, a):
+    from voldor_amd import kernels
+    mean, conf, iters = kernels.meanshift_gpu(space, kernel_var, init_mean, ext, **a)
+    g_mean, g_conf, g_iters = gold[f"ms/{name}/mean"], float(gold[f"ms/{name}/conf"]), int(gold[f"ms/{name}/iters"])
+    assert np.abs(mean - g_mean).max() < 2e-4
+    assert abs(conf - g_conf) < 1e-4 * max(1.0, g_conf)
+    assert abs(iters - g_iters) <= 2
+
+
+@pytest.mark.parametrize("name,space,mean0,cov0,a", list(cases.rg_cases()), ids=[c[0] for c in cases.rg_cases()])
+def test_fit_robust_gaussian_vs_reference(gold, name, space, mean0, cov0, a):
+    from voldor_amd import kernels
+    rc, mean, covar, dens, iters = kernels.fit_robust_gaussian(space, mean0, cov0, **a)
+    g_rc = int(gold[f"rg/{name}/rc"])
+    assert (rc == 0) == (g_rc == 0)
+    if g_rc != 0:
+        np.testing.assert_array_equal(mean, mean0)  # unreliable fit leaves the inputs untouched
+        np.testing.assert_array_equal(covar, cov0)
+        return
+    g_mean, g_cov = gold[f"rg/{name}/mean"], gold[f"rg/{name}/covar"]
+    assert abs(dens - float(gold[f"rg/{name}/density"])) < 2e-3
+    assert np.abs(mean - g_mean).max() < 5e-4
+    assert np.abs(covar - g_cov).max() < 2e-2 * np.abs(g_cov).max()
+
+
+@pytest.mark.parametrize("name,kf,photo,evals", list(cases.align_cases()), ids=[c[0] for c in cases.align_cases()])
+def test_align_frame_vs_reference_kernels(gold, name, kf, photo, evals):
+    from voldor_amd import kernels
+    rc, shape = kernels.align_frame_init_gpu(kf["images"] if photo else None, kf["depths"], kf["weights"], kf["K"], kf["vbf"],
+                                             kf["crw"] if photo else 0.0)
+    assert rc == 0
+    for en, rf, tf, pr, pt, want_j, apply_w in evals:
+        rc, res, jac = kernels.align_frame_eval_gpu(shape, rf, tf, pr, pt, want_j, apply_w)
+        assert rc == 0
+        g_res = gold[f"align/{name}/{en}/residual"]
+        fg, fo = np.isfinite(g_res), np.isfinite(res)
+        assert np.mean(fg != fo) < 5e-3, en
+        m = fg & fo
+        assert np.abs(res[m] - g_res[m]).max() < 5e-4 * max(1.0, np.abs(g_res[m]).max()), en
+        if want_j:
+            g_jac = gold[f"align/{name}/{en}/jacobian"]
+            scale = np.abs(g_jac[m]).max(axis=0) + 1e-12
+            big = m & (g_res > 0.02)  # away from the r -> 0 amplification of the sqrt-Cauchy factor (see test_gpu_align.py)
+            if big.sum() > 50:
+                assert (np.abs(jac[big] - g_jac[big]).max(axis=0) / scale).max() < 2e-3, en
+            bad = (np.abs(jac[m] - g_jac[m]) / scale).max(axis=1) > 3e-2
+            assert bad.mean() < 2e-2, en
