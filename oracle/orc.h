@@ -109,6 +109,8 @@ void orc_rodrigues(const float* R9, float* rvec3);
 void orc_rotmat_to_angle_axis(const float* R9, float* rvec3);
 void orc_rvec_to_rotmat(const float* rvec3, float* R9); /* cv::Rodrigues(vec->mat), OpenCV 3.4 */
 /* gpu-kernels/solve_batch_lambdatwist.cu:51-102 / solve_batch_ap3p.cu:387-437 */
+void orc_last_two_view_translation(float* t3); /* test hook: recoverPose-style t of the last orc_estimate_pose_epipolar call */
+void orc_set_rodrigues_hook(void (*fn)(const float* R9, float* rvec3, float* Rproj9)); /* test hook, see orc_pose.c */
 void orc_solve_batch_p3p(const float* pts3, const float* pts2, float* rvecs, float* tvecs,
                          const float* K, int n_pts, int n_poses, int use_ap3p, int use_double);
 /* gpu-kernels/meanshift.cu:34-150 */

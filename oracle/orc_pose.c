@@ -192,7 +192,12 @@ static void polar_rotation(const float* R9, float* Q9) {
     }
     for (int i = 0; i < 9; i++) Q9[i] = (float)X[i];
 }
+/* Test hook: tests/test_oracle_vs_ref_window.py installs the reference's own rodrigues() (oracle/_ref, ref_rodrigues) here
+ * to take the approximate-SVD difference out of a whole-window comparison with the reference pipeline.  NULL = the oracle's. */
+static void (*g_rodrigues_hook)(const float* R9, float* rvec3, float* Rproj9) = NULL;
+void orc_set_rodrigues_hook(void (*fn)(const float*, float*, float*)) { g_rodrigues_hook = fn; }
 void orc_rodrigues(const float* R9, float* rvec3) {
+    if (g_rodrigues_hook) { g_rodrigues_hook(R9, rvec3, NULL); return; }
     float Q[9];
     polar_rotation(R9, Q);
     orc_rotmat_to_angle_axis(Q, rvec3);
@@ -450,32 +455,62 @@ void orc_solve_batch_p3p_maps(const float* p2_map, const float* p3_map, int npx,
 }
 
 /* ------------------------------------------------------------------ mean-shift
- * meanshift.cu:12-31 kernel, :34-150 host loop.  Sums are accumulated in double (the
- * reference uses a float shared-memory tree, reduce_vector_sum.h:12-42; both are within
- * float rounding of the exact sum). Init trials use orc_rng instead of host rand() (:76). */
-static double ms_weights(const float* space, const float* mean, float kernel_var, int N, int dims, double* wsum_x) {
-    double wsum = 0;
-    if (wsum_x) for (int d = 0; d < dims; d++) wsum_x[d] = 0;
+ * meanshift.cu:12-31 kernel, :34-150 host loop.  Sums follow the reference's float shared-memory tree
+ * (reduce_vector_sum.h:12-61) term by term -- per level, blocks of 512 rows: thread t starts from x[t] + x[t+256], then a
+ * binary tree over strides 128..1; the block sums form the next level -- so that the fixed point, the iteration count and
+ * the confidence are the reference's bit for bit (tests/test_oracle_vs_ref_kernels.py).  Init trials use orc_rng instead
+ * of host rand() (:76). */
+#define ORC_RED_BLOCK 256
+static void ref_tree_sum(const float* x, int N, int dims, float* out) { /* x: [N][dims] */
+    float* cur = malloc(sizeof(float) * (size_t)(N > 0 ? N : 1) * dims);
+    memcpy(cur, x, sizeof(float) * (size_t)N * dims);
+    int n = N;
+    float s[ORC_RED_BLOCK];
+    while (n > 1) {
+        const int nb = (n + 2 * ORC_RED_BLOCK - 1) / (2 * ORC_RED_BLOCK);
+        float* nxt = malloc(sizeof(float) * (size_t)nb * dims);
+        for (int b = 0; b < nb; b++)
+            for (int d = 0; d < dims; d++) {
+                for (int t = 0; t < ORC_RED_BLOCK; t++) {
+                    const int idx = b * 2 * ORC_RED_BLOCK + t;
+                    s[t] = 0;
+                    if (idx < n) { s[t] = cur[(size_t)idx * dims + d]; if (idx + ORC_RED_BLOCK < n) s[t] += cur[(size_t)(idx + ORC_RED_BLOCK) * dims + d]; }
+                }
+                for (int stride = ORC_RED_BLOCK / 2; stride >= 1; stride >>= 1)
+                    for (int t = 0; t < stride; t++) s[t] += s[t + stride];
+                nxt[(size_t)b * dims + d] = s[0];
+            }
+        free(cur); cur = nxt; n = nb;
+    }
+    for (int d = 0; d < dims; d++) out[d] = cur[d];
+    free(cur);
+}
+static float ms_weights(const float* space, const float* mean, float kernel_var, int N, int dims, float* wsum_x) {
+    float* wgt = malloc(sizeof(float) * (size_t)N);
+    float* wx = wsum_x ? malloc(sizeof(float) * (size_t)N * dims) : NULL;
     for (int i = 0; i < N; i++) {
         float l2 = 0;
         for (int d = 0; d < dims; d++) { float df = space[i * dims + d] - mean[d]; l2 += df * df; }
-        float wgt = expf(-l2 / (2 * kernel_var));
-        wsum += wgt;
-        if (wsum_x) for (int d = 0; d < dims; d++) wsum_x[d] += (double)(space[i * dims + d] * wgt);
+        wgt[i] = expf(-l2 / (2 * kernel_var));
+        if (wx) for (int d = 0; d < dims; d++) wx[(size_t)i * dims + d] = space[i * dims + d] * wgt[i];
     }
+    float wsum;
+    ref_tree_sum(wgt, N, 1, &wsum);
+    if (wx) { ref_tree_sum(wx, N, dims, wsum_x); free(wx); }
+    free(wgt);
     return wsum;
 }
 void orc_meanshift(const float* space, float kernel_var, float* io_mean, float* o_confidence,
                    int* used_iters, int use_external_init_mean, int N, int dims, float epsilon,
                    int max_iters, int max_init_trials, float good_init_confidence) {
     float c_mean[16];
-    double sx[16];
+    float sx[16];
     if (use_external_init_mean) memcpy(c_mean, io_mean, sizeof(float) * dims);
     else {
         float best = 0; int best_idx = -1;
         for (int trial = 0; trial < max_init_trials; trial++) { /* :75-95 */
             int idx_rand = (int)(orc_rng(233u, (uint32_t)trial, 0x4D53u) % (uint32_t)N);
-            float wsum = (float)ms_weights(space, space + idx_rand * dims, kernel_var, N, dims, NULL);
+            float wsum = ms_weights(space, space + idx_rand * dims, kernel_var, N, dims, NULL);
             if (wsum > best) { best = wsum; best_idx = idx_rand; }
             if (best > good_init_confidence * N) break;
         }
@@ -484,9 +519,9 @@ void orc_meanshift(const float* space, float kernel_var, float* io_mean, float* 
     }
     if (used_iters) *used_iters = 0;
     for (int iter = 0; iter < max_iters; iter++) { /* :103-134 */
-        float wsum = (float)ms_weights(space, c_mean, kernel_var, N, dims, sx);
+        float wsum = ms_weights(space, c_mean, kernel_var, N, dims, sx);
         float m[16];
-        for (int d = 0; d < dims; d++) m[d] = (float)sx[d] / wsum;
+        for (int d = 0; d < dims; d++) m[d] = sx[d] / wsum;
         if (o_confidence) *o_confidence = wsum / N;
         if (used_iters) *used_iters = iter + 1;
         float disp = 0;
@@ -569,7 +604,9 @@ int orc_fit_robust_gaussian(const float* space, float* io_mean, float* io_covar,
                 ht_covar_inv[(d1 * d1 + d1) / 2 + d2] = (float)inv_full[d1 * dims + d2];
             }
         float prev_density = ht_weight / N;
-        double sw = 0, sx[6] = { 0 }, sc[21] = { 0 };
+        float* e_w = malloc(sizeof(float) * (size_t)N);
+        float* e_x = malloc(sizeof(float) * (size_t)N * dims);
+        float* e_c = malloc(sizeof(float) * (size_t)N * dc);
         for (int i = 0; i < N; i++) { /* e_step :56-97 */
             float diff[6];
             for (int d = 0; d < dims; d++) diff[d] = space[i * dims + d] - ht_mean[d];
@@ -584,17 +621,23 @@ int orc_fit_robust_gaussian(const float* space, float* io_mean, float* io_covar,
             }
             z = sqrtf(z);
             const float wgt = z < trunc_sigma ? 1 : 0;
-            sw += wgt;
-            for (int d = 0; d < dims; d++) sx[d] += (double)(wgt * space[i * dims + d]);
+            e_w[i] = wgt;
+            for (int d = 0; d < dims; d++) e_x[(size_t)i * dims + d] = wgt * space[i * dims + d];
             for (int d1 = 0; d1 < dims; d1++)
-                for (int d2 = 0; d2 <= d1; d2++) sc[(d1 * d1 + d1) / 2 + d2] += (double)(wgt * diff[d1] * diff[d2]);
+                for (int d2 = 0; d2 <= d1; d2++) e_c[(size_t)i * dc + (d1 * d1 + d1) / 2 + d2] = wgt * diff[d1] * diff[d2];
         }
-        ht_weight = (float)sw;
-        if (!isfinite(ht_weight)) { reliable = 0; break; }
-        float density_change = fabsf(ht_weight / N - prev_density);
-        if (density_change < epsilon) { reliable = 1; break; }
-        for (int d = 0; d < dims; d++) ht_mean[d] = (float)sx[d] / ht_weight;
-        for (int k = 0; k < dc; k++) ht_covar[k] = (float)sc[k] / ht_weight;
+        ref_tree_sum(e_w, N, 1, &ht_weight); /* m step :213-243, sums in the reference's tree order */
+        int stop = 0;
+        if (!isfinite(ht_weight)) { reliable = 0; stop = 1; }
+        else if (fabsf(ht_weight / N - prev_density) < epsilon) { reliable = 1; stop = 1; }
+        if (!stop) {
+            ref_tree_sum(e_x, N, dims, ht_mean);
+            ref_tree_sum(e_c, N, dc, ht_covar);
+            for (int d = 0; d < dims; d++) ht_mean[d] /= ht_weight;
+            for (int k = 0; k < dc; k++) ht_covar[k] /= ht_weight;
+        }
+        free(e_w); free(e_x); free(e_c);
+        if (stop) break;
     }
     if (reliable) {
         if (o_density) *o_density = ht_weight / N;

@@ -105,6 +105,7 @@ typedef struct {
     float* priors; float* pconfs; float* confs; orc_cam dp_poses[ORC_MAX_FRAMES];
     const float* flows; float* rig; orc_cam cams[ORC_MAX_FRAMES];
     uint32_t rand_epoch;
+    float* od_depth; /* ORC_EMULATE_B1 only: the depth map as optimize_depth.cu's device copy holds it */
 } orc_voldor_t;
 
 enum { OD_DEFAULT = 0, OD_ONLY_USE_DEPTH_PRIOR = 1, OD_UPDATE_RIGIDNESS_ONLY = 2 };
@@ -126,8 +127,26 @@ static void v_optimize_depth(orc_voldor_t* v, int flag) {
     p.lambda = c->lambda; p.omega = c->omega; p.disp_delta = v->has_disparity ? c->disp_delta : -1; p.delta = c->delta;
     p.fb_smooth = c->fb_smooth; p.s0_ems_prob = c->fb_emm; p.no_change_prob = c->fb_no_change_prob;
     p.range_factor = c->depth_range_factor; p.update_rigidness_only = (flag == OD_UPDATE_RIGIDNESS_ONLY);
+    /* D4 vs SURVEY Appendix B-1: with exclusive_gpu_context the reference stops uploading the depth map after iteration 1
+     * (voldor.cpp:275-291 passes NULL), so optimize_depth.cu keeps searching from ITS copy, which never saw
+     * normalize_world_scale().  The oracle (and the product) use the one normalised map.  ORC_EMULATE_B1=1 reproduces the
+     * reference's behaviour instead, for the whole-window comparison with the reference pipeline run on the CPU. */
+    const char* b1 = getenv("ORC_EMULATE_B1");
+    const size_t bytes = sizeof(float) * (size_t)v->w * v->h;
+    if (b1 && b1[0] == '1') {
+        const int stale = c->exclusive_gpu_context && v->iters_cur >= 2 && v->od_depth != NULL;
+        if (!v->od_depth) v->od_depth = malloc(bytes);
+        if (!stale) memcpy(v->od_depth, v->depth, bytes);
+        orc_optimize_depth(&p, v->flows, v->rig, v->priors, v->pconfs, v->confs, v->od_depth, v->cost, &v->rand_epoch);
+        memcpy(v->depth, v->od_depth, bytes);
+        return;
+    }
     orc_optimize_depth(&p, v->flows, v->rig, v->priors, v->pconfs, v->confs, v->depth, v->cost, &v->rand_epoch);
 }
+
+/* cv::Mat /= double is a.convertTo(a, -1, 1./b) (OpenCV core/mat.inl.hpp, CV_MAT_AUG_OPERATOR): float data are MULTIPLIED
+ * by (float)(1./b), not divided -- one ulp apart for most b.  The element-wise at<float>() /= of :233-236 is a true division. */
+static inline float cv_div_scale(float b) { return (float)(1.0 / (double)b); }
 
 /* geometry.cpp:5-265 */
 static int v_optimize_camera_pose(orc_voldor_t* v, int active_idx, int successive_pose, int rg_refine) {
@@ -150,8 +169,18 @@ static int v_optimize_camera_pose(orc_voldor_t* v, int active_idx, int successiv
     const int np = c->n_poses_to_sample;
     float* rv = malloc(sizeof(float) * np * 3); float* tv = malloc(sizeof(float) * np * 3);
     float* pool = malloc(sizeof(float) * np * 6);
-    /* :99-170. cpu_p3p=1 is the reference's CPU path: lambdatwist_p4p<double,...> (:112). Draws: D3b. */
-    orc_solve_batch_p3p_maps(p2m, p3m, npx, n_points, rv, tv, K, np, !c->lambdatwist, c->cpu_p3p ? 1 : 0);
+    /* :99-170. cpu_p3p=1 is the reference's CPU path: lambdatwist_p4p<double,...> (:112). Draws: D3b by default;
+     * ORC_REFERENCE_DRAW=1 switches to the reference's own draw (index into the compacted list, geometry.cpp:68-80 +
+     * solve_batch_lambdatwist.cu:16-19, clamp D3) so that a whole window can be compared with the reference pipeline
+     * executed on the CPU (oracle/ref_wrap_host.cpp, tests/test_oracle_vs_ref_window.py). */
+    const char* ref_draw = getenv("ORC_REFERENCE_DRAW");
+    if (ref_draw && ref_draw[0] == '1') {
+        float* c2 = malloc(sizeof(float) * npx * 2); float* c3 = malloc(sizeof(float) * npx * 3);
+        const int nc = orc_compact_p3p(p2m, p3m, npx, c2, c3);
+        orc_solve_batch_p3p(c3, c2, rv, tv, K, nc, np, !c->lambdatwist, c->cpu_p3p ? 1 : 0);
+        free(c2); free(c3);
+    } else
+        orc_solve_batch_p3p_maps(p2m, p3m, npx, n_points, rv, tv, K, np, !c->lambdatwist, c->cpu_p3p ? 1 : 0);
     free(p2m); free(p3m);
     int used = 0;
     for (int i = 0; i < np; i++) {
@@ -181,16 +210,16 @@ static int v_optimize_camera_pose(orc_voldor_t* v, int active_idx, int successiv
         int ret = orc_fit_robust_gaussian(pool, pose_opm, cam->pose_covar, c->rg_trunc_sigma, c->rg_covar_reg_lambda,
                                           &cam->pose_density, &cam->last_used_gu_iters, used, 6, c->rg_epsilon, c->rg_max_iters);
         if (ret == 0) {
-            for (int d = 0; d < 36; d++) cam->pose_covar[d] /= (sc * sc);
+            { const float isc2 = cv_div_scale(sc * sc); for (int d = 0; d < 36; d++) cam->pose_covar[d] *= isc2; }
             for (int i1 = 0; i1 < 6; i1++)
                 for (int i2 = 0; i2 < 6; i2++) {
                     if (i1 < 3 || i2 < 3) cam->pose_covar[i1 * 6 + i2] /= c->meanshift_rvec_scale;
                     if (i1 < 3 && i2 < 3) cam->pose_covar[i1 * 6 + i2] /= c->meanshift_rvec_scale;
                 }
         } else memset(cam->pose_covar, 0, sizeof cam->pose_covar);
-        for (int d = 0; d < 6; d++) pose_opm[d] /= sc;
+        { const float isc = cv_div_scale(sc); for (int d = 0; d < 6; d++) pose_opm[d] *= isc; }
     }
-    for (int d = 0; d < 3; d++) pose_opm[d] /= c->meanshift_rvec_scale;
+    { const float irs = cv_div_scale(c->meanshift_rvec_scale); for (int d = 0; d < 3; d++) pose_opm[d] *= irs; }
     free(pool);
     int ok = 1; /* checkRange :256 */
     for (int d = 0; d < 6; d++) if (!isfinite(pose_opm[d])) ok = 0;
@@ -227,7 +256,7 @@ static void v_normalize_world_scale(orc_voldor_t* v) {
     float world_scale = 0;
     for (int i = 0; i < v->n_flows; i++) {
         const float* t = v->cams[i].t;
-        world_scale += (float)sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2]);
+        world_scale = (float)((double)world_scale + sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2])); /* float += double (cv::norm) */
     }
     const float s = v->n_flows / world_scale;
     for (int i = 0; i < v->n_flows; i++) for (int d = 0; d < 3; d++) v->cams[i].t[d] *= s;
@@ -241,7 +270,17 @@ void orc_estimate_depth_closed_form(const float* flow, float* depth, const float
                                     const float* R, const float* t, int w, int h,
                                     float min_depth, float max_depth) {
     /* b = K t ; KRKinv = K R K^-1 (float, cv::Mat products) */
-    float Kinv[9] = { 1.f / K[0], 0, -K[2] / K[0], 0, 1.f / K[4], -K[5] / K[4], 0, 0, 1 };
+    /* K.inv() (voldor.cpp:101): cv::invert of a 3x3 CV_32F goes through the adjugate with the determinant in double */
+    float Kinv[9];
+    {
+        double m[9]; for (int i = 0; i < 9; i++) m[i] = K[i];
+        const double det = m[0] * (m[4] * m[8] - m[5] * m[7]) - m[1] * (m[3] * m[8] - m[5] * m[6]) + m[2] * (m[3] * m[7] - m[4] * m[6]);
+        const double id = 1. / det;
+        const double a[9] = { (m[4] * m[8] - m[5] * m[7]) * id, (m[2] * m[7] - m[1] * m[8]) * id, (m[1] * m[5] - m[2] * m[4]) * id,
+                              (m[5] * m[6] - m[3] * m[8]) * id, (m[0] * m[8] - m[2] * m[6]) * id, (m[2] * m[3] - m[0] * m[5]) * id,
+                              (m[3] * m[7] - m[4] * m[6]) * id, (m[1] * m[6] - m[0] * m[7]) * id, (m[0] * m[4] - m[1] * m[3]) * id };
+        for (int i = 0; i < 9; i++) Kinv[i] = (float)a[i];
+    }
     float KR[9], M[9];
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { float s = 0; for (int k = 0; k < 3; k++) s += K[i * 3 + k] * R[k * 3 + j]; KR[i * 3 + j] = s; }
     for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { float s = 0; for (int k = 0; k < 3; k++) s += KR[i * 3 + k] * Kinv[k * 3 + j]; M[i * 3 + j] = s; }
@@ -372,6 +411,8 @@ static int cmp_double(const void* a, const void* b) { double x = *(const double*
  * cheirality vote of recoverPose, then cam.t = R*t (:330).  Returns 1 on success. */
 #define BOOT_HYPS 256
 #define BOOT_SCORE_MAX 2048
+static float g_last_two_view_t[3]; /* unit translation of the last call BEFORE cam.t = R*t, read by orc_last_two_view_translation() */
+void orc_last_two_view_translation(float* t3) { memcpy(t3, g_last_two_view_t, sizeof g_last_two_view_t); }
 int orc_estimate_pose_epipolar(const float* flow, const float* K, int w, int h, int step, float* R9, float* t3) {
     const int nx = (w + step - 1) / step, ny = (h + step - 1) / step, n = nx * ny;
     double* q1 = malloc(sizeof(double) * n * 2); double* q2 = malloc(sizeof(double) * n * 2);
@@ -455,6 +496,7 @@ int orc_estimate_pose_epipolar(const float* flow, const float* K, int w, int h, 
     float Rf[9], tf[3] = { (float)(sg * tc[0]), (float)(sg * tc[1]), (float)(sg * tc[2]) };
     for (int i = 0; i < 9; i++) Rf[i] = (float)R[i];
     memcpy(R9, Rf, sizeof Rf);
+    memcpy(g_last_two_view_t, tf, sizeof tf);
     for (int r = 0; r < 3; r++) t3[r] = Rf[r * 3] * tf[0] + Rf[r * 3 + 1] * tf[1] + Rf[r * 3 + 2] * tf[2]; /* cam.t = R*t :330 */
     free(q1); free(q2);
     return 1;
@@ -539,9 +581,9 @@ int orc_voldor(const float* flows, const float* disparity, const float* disparit
             float s = 0;
             for (int i = 0; i < v->n_flows; i++) s += v->rig[(size_t)i * npx + k];
             for (int i = 0; i < v->n_dp; i++) s += v->confs[(size_t)i * npx + k];
-            depth_conf[k] = s / (float)(v->n_flows + v->n_dp);
+            depth_conf[k] = s * cv_div_scale((float)(v->n_flows + v->n_dp)); /* Mat /= : py_export.cpp:74 */
         }
     }
-    free(v->depth); free(v->cost); free(v->rig); free(v->priors); free(v->pconfs); free(v->confs); free(v);
+    free(v->od_depth); free(v->depth); free(v->cost); free(v->rig); free(v->priors); free(v->pconfs); free(v->confs); free(v);
     return 0;
 }

@@ -1,0 +1,31 @@
+// oracle/_ref builder, part 3: the reference's HOST pipeline.  voldor/voldor.cpp, geometry.cpp, utils.cpp and py_export.cpp
+// are compiled in place from /root/reference (no rewriting at all) against oracle/ref_stubs/minicv (a stand-in for the slice
+// of OpenCV they use) and linked to the CPU-emulated kernels of ref_wrap_kernels.cpp: what runs behind ref_py_voldor_wrapper
+// is the reference's own py_voldor_wrapper (voldor/py_export.cpp:5-79) -> VOLDOR::init / solve -> optimize_camera_pose ->
+// the reference's kernels.  TEST INFRASTRUCTURE ONLY: pins oracle/orc_voldor.c (tests/golden/ref_window.npz).
+#ifdef REF_PREP_DIR
+#include "ref_stubs/minicv/minicv.hpp"
+#include "voldor/py_export.h"
+
+double minicv_two_view_R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, minicv_two_view_t[3] = { 0, 0, 1 };
+extern "C" void ref_reset_window_state(unsigned rand_epoch);
+
+extern "C" {
+// what cv::recoverPose will hand to estimate_camera_pose_epipolar (geometry.cpp:288-332); deviation D5
+void ref_set_two_view_pose(const double* R9, const double* t3) {
+    memcpy(minicv_two_view_R, R9, sizeof minicv_two_view_R);
+    memcpy(minicv_two_view_t, t3, sizeof minicv_two_view_t);
+}
+int ref_py_voldor_wrapper(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
+                          const float* depth_prior_poses, const float* depth_prior_pconfs, float fx, float fy, float cx, float cy, float basefocal,
+                          int N, int N_dp, int w, int h, const char* config, unsigned rand_epoch, int* n_registered, float* poses,
+                          float* poses_covar, float* depth, float* depth_conf) {
+    ref_reset_window_state(rand_epoch);
+    int n = 0;
+    const int rc = py_voldor_wrapper(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, fx, fy, cx, cy, basefocal,
+                                     N, N_dp, w, h, config, n, poses, poses_covar, depth, depth_conf);
+    *n_registered = n;
+    return rc;
+}
+}
+#endif

@@ -140,7 +140,48 @@ int ref_align_eval(int ref_fid, int tar_fid, const float* params_ref, const floa
                    int apply_weights) {
     return ref_align::align_frame_eval_gpu(ref_fid, tar_fid, params_ref, params_tar, o_residual, o_jacobian, apply_weights != 0);
 }
+
+// a new window: the next optimize_depth_gpu call re-creates its cuRAND states, starting from counter value `rand_epoch`
+void ref_reset_window_state(unsigned rand_epoch) {
+    ref_od::d_rand_states.create(1, 1, 1);
+    emul_curand_epoch = rand_epoch;
+}
 }  // extern "C"
+
+// ---- the entry points of gpu_kernels.h at global scope, for the reference's host pipeline (voldor/*.cpp compiled in place,
+// ref_wrap_host.cpp): plain forwards into the namespaces above
+int meanshift_gpu(float* h_space, float kernel_var, float* h_io_mean, float* h_o_confidence, int* used_iters, bool use_external_init_mean, int N,
+                  int dims, float epsilon, int max_iters, int max_init_trials, float good_init_confidence) {
+    emul_rand_trial = 0; emul_rand_mod = (uint32_t)N;
+    return ref_ms::meanshift_gpu(h_space, kernel_var, h_io_mean, h_o_confidence, used_iters, use_external_init_mean, N, dims, epsilon, max_iters,
+                                 max_init_trials, good_init_confidence);
+}
+int fit_robust_gaussian(float* h_space, float* h_io_mean, float* h_io_covar, float trunc_sigma, float covar_reg_lambda, float* h_o_density,
+                        int* used_iters, int N, int dims, float epsilon, int max_iters) {
+    return ref_rg::fit_robust_gaussian(h_space, h_io_mean, h_io_covar, trunc_sigma, covar_reg_lambda, h_o_density, used_iters, N, dims, epsilon, max_iters);
+}
+int collect_p3p_instances(float* h_flows[], float* h_rigidnesses[], float* h_depth, float* h_K, float* h_Rs[], float* h_ts[], float* h_o_p2_map,
+                          float* h_o_p3_map, int N, int w, int h, int active_idx, float rigidness_thresh, float rigidness_sum_thresh,
+                          float sample_min_depth, float sample_max_depth, int max_trace_on_flow) {
+    return ref_collect::collect_p3p_instances(h_flows, h_rigidnesses, h_depth, h_K, h_Rs, h_ts, h_o_p2_map, h_o_p3_map, N, w, h, active_idx,
+                                              rigidness_thresh, rigidness_sum_thresh, sample_min_depth, sample_max_depth, max_trace_on_flow);
+}
+int solve_batch_p3p_ap3p_gpu(float* h_p3s, float* h_p2s, float* h_o_rvecs, float* h_o_tvecs, float* h_K, int N_pts, int N_poses) {
+    return ref_ap3p::solve_batch_p3p_ap3p_gpu(h_p3s, h_p2s, h_o_rvecs, h_o_tvecs, h_K, N_pts, N_poses);
+}
+int solve_batch_p3p_lambdatwist_gpu(float* h_p3s, float* h_p2s, float* h_o_rvecs, float* h_o_tvecs, float* h_K, int N_pts, int N_poses) {
+    return ref_lt::solve_batch_p3p_lambdatwist_gpu(h_p3s, h_p2s, h_o_rvecs, h_o_tvecs, h_K, N_pts, N_poses);
+}
+int optimize_depth_gpu(float* h_flows[], float* h_rigidnesses[], float* h_o_rigidnesses[], float* h_depth_priors[], float* h_depth_prior_pconfs[],
+                       float* h_depth_prior_confs[], float* h_o_depth_prior_confs[], float* h_depth, float* h_o_depth, float* h_K, float* h_Rs[],
+                       float* h_ts[], float* h_dp_Rs[], float* h_dp_ts[], float abs_resize_factor, int N, int N_dp, int w, int h, float basefocal,
+                       int n_rand_samples, int global_prop_step, int local_prop_width, float lambda, float omega, float disp_delta, float delta,
+                       bool fb_smooth, float s0_ems_prob, float no_change_prob, float range_factor, bool update_rigidness_only) {
+    return ref_od::optimize_depth_gpu(h_flows, h_rigidnesses, h_o_rigidnesses, h_depth_priors, h_depth_prior_pconfs, h_depth_prior_confs,
+                                      h_o_depth_prior_confs, h_depth, h_o_depth, h_K, h_Rs, h_ts, h_dp_Rs, h_dp_ts, abs_resize_factor, N, N_dp, w, h,
+                                      basefocal, n_rand_samples, global_prop_step, local_prop_width, lambda, omega, disp_delta, delta, fb_smooth,
+                                      s0_ems_prob, no_change_prob, range_factor, update_rigidness_only);
+}
 
 // ---- stand-in for gpu-kernels/aux_funs.cpp:97-141 (cv::Matx66d): partial-pivot Gauss-Jordan in double, N <= 6
 static double emul_lu(const double* A, double* Ainv, int n) {  // returns det(A); Ainv (may be null) only valid when det != 0

@@ -1,0 +1,46 @@
+"""Seeded whole-window inputs shared by tests/golden/gen_golden_window.py (the reference's own py_voldor_wrapper executed on
+the CPU -> tests/golden/ref_window.npz) and the tests that compare the oracle / the HIP path with those outputs."""
+import numpy as np
+
+from voldor_amd import synth
+
+MONO = "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 8"
+STEREO = "--silent --meanshift_kernel_var 0.1 --disp_delta 1 --delta 0.2 --max_iters 8"
+
+
+def _small():
+    return synth.make_scene(w=128, h=96, n_flows=4, fx=64, fy=64, cx=64, cy=48, seed=5, basefocal=30.0)
+
+
+def _case(sc, config, basefocal=0.0, disparity=False, priors=None, flows=None, b1=False, exact=True, ref_config=None):
+    """b1: the reference run shows SURVEY Appendix B-1 (stale device depth), which the oracle only reproduces with
+    ORC_EMULATE_B1=1.  exact: small enough for the bit-exact oracle comparison on the CPU.  ref_config: what the reference
+    is run with when it differs from what the oracle / product get (the big cases switch B-1 off in the reference)."""
+    c = dict(flows=np.ascontiguousarray(sc["flows"] if flows is None else flows, np.float32), K=tuple(float(v) for v in sc["K"]),
+             basefocal=float(basefocal), disparity=np.ascontiguousarray(sc["disparity"], np.float32) if disparity else None,
+             depth_priors=None, depth_prior_poses=None, depth_prior_pconfs=None, config=config, b1=b1, exact=exact,
+             ref_config=ref_config or config, poses_gt=sc["poses_gt"])
+    if priors is not None:
+        c["depth_priors"], c["depth_prior_poses"], c["depth_prior_pconfs"] = priors
+    return c
+
+
+def window_cases():
+    sm = _small()
+    yield "stereo_default", _case(sm, "--silent", basefocal=30.0, disparity=True)
+    yield "stereo_ap3p", _case(sm, "--silent --lambdatwist 0 --max_iters 3", basefocal=30.0, disparity=True)
+    yield "mono_nonexclusive", _case(sm, "--silent --exclusive_gpu_context 0 --max_iters 3")
+    yield "mono_default_b1", _case(sm, "--silent --max_iters 3", b1=True)
+    sp = synth.make_scene(w=160, h=120, n_flows=3, fx=80, fy=80, cx=80, cy=60, seed=237)
+    pri = np.stack([sp["depth_gt"], sp["depth_gt"] * 1.01]).astype(np.float32)
+    pposes = np.array([[0, 0, 0, 0, 0, 0], [0.001, 0, 0, 0.01, 0, 0]], np.float32)
+    yield "depth_priors", _case(sp, "--silent --max_iters 4 --delta 0.5", basefocal=40.0, priors=(pri, pposes, np.full_like(pri, 0.8)))
+    st = synth.make_scene(w=160, h=120, n_flows=5, fx=80, fy=80, cx=80, cy=60, seed=238)
+    fl = st["flows"].copy()
+    fl[3:] = np.random.default_rng(0).uniform(-40, 40, fl[3:].shape).astype(np.float32)
+    yield "truncated_b1", _case(st, MONO, flows=fl, b1=True)
+    # the sizes of tests/test_gpu_voldor.py: reference run with the stale-depth bug switched off (D4), statistical comparison only
+    big = synth.make_scene(w=320, h=240, n_flows=5, fx=160, fy=160, cx=160, cy=120, seed=233)
+    yield "mono_320x240", _case(big, MONO, exact=False, ref_config=MONO + " --exclusive_gpu_context 0")
+    bs = synth.make_scene(w=312, h=96, n_flows=4, fx=180, fy=180, cx=152, cy=46, seed=236, basefocal=97.0)
+    yield "stereo_312x96", _case(bs, STEREO, basefocal=97.0, disparity=True, exact=False)
