@@ -19,8 +19,15 @@
  *     fb_smooth, correspondence maps, solver translations) or to float summation order
  *     (mean-shift, robust Gaussian) -- tests/test_oracle_vs_ref_kernels.py,
  *     tests/golden/ref_kernels.npz.
- * Still "parity unpinned" (needs OpenCV): the host schedule of voldor/voldor.cpp and
- * voldor/geometry.cpp (orc_voldor.c), restated from the cited source lines only.
+ *  3. the host pipeline (voldor/py_export.cpp, voldor.cpp, geometry.cpp, utils.cpp) is compiled in
+ *     place against ref_stubs/minicv (stand-in for the OpenCV calls) and linked to 2.
+ *     (ref_wrap_host.cpp): the reference's own py_voldor_wrapper runs end to end.  With
+ *     ORC_REFERENCE_DRAW=1, the reference rodrigues() installed via orc_set_rodrigues_hook and,
+ *     for the reference's default exclusive mode, ORC_EMULATE_B1=1, orc_voldor reproduces every
+ *     output of 6 windows bit for bit -- tests/test_oracle_vs_ref_window.py,
+ *     tests/golden/ref_window.npz.  These three switches exist for that test only.
+ * Still unpinned: OpenCV's own numerics (5-point bootstrap replaced by D5; Rodrigues / inv / gemm
+ * restated in minicv from documented behaviour).
  *
  * Deliberate, documented deviations from the reference:
  *  D1 random numbers: counter-based hash (orc_rng) instead of cuRAND XORWOW.

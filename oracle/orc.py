@@ -22,12 +22,17 @@ def _fp(a):
 def build(force: bool = False) -> None:
     """Compile liborc.so (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "liborc.so")
-    srcs = [os.path.join(_HERE, f) for f in ("orc_model.c", "orc_pose.c", "orc_voldor.c", "orc_lambdatwist_impl.h", "orc.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("orc_model.c", "orc_pose.c", "orc_voldor.c", "orc_align.c", "orc_lambdatwist_impl.h", "orc.h")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     ref_so = os.path.join(_HERE, "_ref", "libvoldor_ref.so")
-    want_ref = os.path.isdir("/root/reference/lambdatwist") and (force or not os.path.exists(ref_so))
+    want_ref = False
+    if os.path.isdir("/root/reference/lambdatwist"):  # only where the reference checkout exists; the built .so travels
+        ref_srcs = [os.path.join(_HERE, f) for f in ("ref_wrap.cpp", "ref_wrap_kernels.cpp", "ref_wrap_host.cpp", "ref_prep.pl", "Makefile")]
+        for d, _, files in os.walk(os.path.join(_HERE, "ref_stubs")):
+            ref_srcs += [os.path.join(d, f) for f in files]
+        want_ref = force or not os.path.exists(ref_so) or any(os.path.getmtime(s) > os.path.getmtime(ref_so) for s in ref_srcs)
     if stale or want_ref:
-        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []) + (["liborc.so", "ref"] if want_ref else ["liborc.so"]))
 
 
 class OdParams(C.Structure):
