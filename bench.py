@@ -19,6 +19,8 @@ Extra objects in the line:
                BASELINE.md §4) is reported next to it.
   cpu_baseline the oracle (C restatement of the reference path, OpenMP) timed on this box's host
                cores on the same workload, a bounded number of windows (rank 0, N=1 only).
+  cpu_reference  the reference's own code on one host core (oracle/_ref: voldor/*.cpp + gpu-kernels/*.cu compiled for the
+               CPU, BASELINE configs[0] "--cpu_p3p 1"), 2 of the 8 EM iterations of one window, scaled.
 """
 from __future__ import annotations
 
@@ -220,6 +222,23 @@ def main():
         except Exception as e:  # the baseline is a reported number, never a reason to fail the bench
             cpu = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port", "sample": f"unavailable: {e}"}
 
+    # ---- the reference itself on one host core (BASELINE configs[0], "CPU geometry path": --cpu_p3p 1), bounded sample ----
+    cpu_ref = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and wl["mode"] == "mono":
+        try:
+            from oracle import orc
+            sample_iters = 2
+            cfg_ref = CONFIG.replace(f"--max_iters {EM_ITERS}", f"--max_iters {sample_iters}") + " --cpu_p3p 1"
+            t0 = time.perf_counter()
+            orc.ref_voldor(sc["flows"], FX, FY, CX, CY, config=cfg_ref)
+            tr_s = time.perf_counter() - t0
+            cpu_ref = {"value": round(1.0 / (tr_s * EM_ITERS / sample_iters), 5), "unit": "frames/s", "cores": 1, "kind": "reference",
+                       "sample": f"{sample_iters} of the {EM_ITERS} EM iterations of one {W}x{H} N_flow={N_FLOW} window ({tr_s:.1f} s), scaled to the full window; "
+                                 "the reference's own voldor/*.cpp + gpu-kernels/*.cu compiled for the host (oracle/_ref: CPU geometry path "
+                                 "--cpu_p3p 1, per-pixel kernels run thread by thread on one core)"}
+        except Exception as e:
+            cpu_ref = {"value": None, "unit": "frames/s", "cores": 0, "kind": "reference", "sample": f"unavailable: {e}"}
+
     if rank == 0:
         gt = sc["poses_gt"].copy()
         if wl["mode"] == "mono":  # monocular windows are normalised to mean |t| = 1 (voldor.cpp:309-317)
@@ -233,7 +252,7 @@ def main():
                        "voldor_config": CONFIG, "parallelism": f"one sequence per GPU x{world}, RCCL all-gather of pose blocks"},
             "n_registered": int(out["n_registered"]),
             "pose_rpe_vs_gt": {"rot_rad_max": float(rot.max()) if len(rot) else None, "rel_trans_max": float(tr.max()) if len(tr) else None},
-            "roofline": roof, "cpu_baseline": cpu, "concurrent": conc,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_reference": cpu_ref, "concurrent": conc,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -313,6 +313,48 @@ def voldor(flows, fx, fy, cx, cy, basefocal=0.0, disparity=None, disparity_pconf
     return {"n_registered": n, "poses": poses[:n], "poses_covar": covar[:n], "depth": depth, "depth_conf": conf}
 
 
+
+def two_view_pose(flow0, K):
+    """(R float32 3x3, t float32 3) of the oracle's 8-point LMedS bootstrap BEFORE the reference's cam.t = R * t
+    (geometry.cpp:330): what ref_voldor() injects in place of cv::recoverPose (deviation D5)."""
+    ok, R, _ = estimate_pose_epipolar(flow0, K)
+    if not ok:
+        raise RuntimeError("two-view bootstrap failed")
+    t = np.zeros(3, np.float32)
+    lib().orc_last_two_view_translation(_fp(t))
+    return np.ascontiguousarray(R, np.float32), t
+
+
+def ref_voldor(flows, fx, fy, cx, cy, basefocal=0.0, disparity=None, depth_priors=None, depth_prior_poses=None,
+               depth_prior_pconfs=None, config="", rand_epoch=0):
+    """The REFERENCE's own py_voldor_wrapper (voldor/py_export.cpp) executed on the CPU through oracle/_ref
+    (ref_wrap_host.cpp: voldor/*.cpp compiled in place on minicv + the reference's kernel files on the launch emulation).
+    Single-threaded.  Monocular windows get the oracle's two-view pose injected.  Raises if oracle/_ref is not built."""
+    r = ref()
+    if r is None or not hasattr(r, "ref_py_voldor_wrapper"):
+        raise RuntimeError("oracle/_ref with the host pipeline is not built on this box")
+    flows = f32(flows)
+    N, h, w, _ = flows.shape
+    if disparity is None and depth_priors is None:
+        R, t = two_view_pose(flows[0], np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], np.float32))
+        D = C.POINTER(C.c_double)
+        R64, t64 = R.astype(np.float64), t.astype(np.float64)
+        r.ref_set_two_view_pose(R64.ctypes.data_as(D), t64.ctypes.data_as(D))
+    a = [None if x is None else f32(x) for x in (disparity, depth_priors, depth_prior_poses, depth_prior_pconfs)]
+    N_dp = 0 if a[1] is None else a[1].shape[0]
+    poses = np.zeros((N, 6), np.float32)
+    covar = np.zeros((N, 6, 6), np.float32)
+    depth = np.zeros((h, w), np.float32)
+    conf = np.zeros((h, w), np.float32)
+    nreg = C.c_int(0)
+    rc = r.ref_py_voldor_wrapper(_fp(flows), _fp(a[0]), None, _fp(a[1]), _fp(a[2]), _fp(a[3]), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                                 C.c_float(cy), C.c_float(basefocal), N, N_dp, w, h, config.encode(), C.c_uint(rand_epoch), C.byref(nreg),
+                                 _fp(poses), _fp(covar), _fp(depth), _fp(conf))
+    if rc != 0:
+        raise RuntimeError(f"ref_py_voldor_wrapper failed rc={rc}")
+    n = nreg.value
+    return {"n_registered": n, "poses": poses[:n], "poses_covar": covar[:n], "depth": depth, "depth_conf": conf}
+
 # ---- frame alignment maps (orc_align.c; gpu-kernels/align_frame.cu) ----
 def rot_with_rvec(p3, rvec):
     p3 = f32(p3); rvec = f32(rvec)

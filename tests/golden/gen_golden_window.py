@@ -10,7 +10,6 @@ recoverPose, which minicv does not have: the two-view pose is injected from the 
 Stored per case: n_registered, poses, poses_covar, depth, depth_conf (full maps for the small cases, sha256 + a 2x2
 subsample for the large ones) and the injected two-view pose.
 """
-import ctypes as C
 import hashlib
 import os
 import sys
@@ -25,53 +24,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_window_cases as cases  # noqa: E402
 from oracle import orc  # noqa: E402
 
-F = C.POINTER(C.c_float)
-D = C.POINTER(C.c_double)
-
-
-def fp(a):
-    return None if a is None else a.ctypes.data_as(F)
-
-
-def two_view_pose(flow0, K4):
-    """(R float32 3x3, t float32 3): the oracle's bootstrap pose BEFORE the reference's cam.t = R * t (geometry.cpp:330)."""
-    fx, fy, cx, cy = K4
-    K = np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], np.float32)
-    ok, R, _ = orc.estimate_pose_epipolar(flow0, K)
-    assert ok
-    t = np.zeros(3, np.float32)
-    orc.lib().orc_last_two_view_translation(fp(t))
-    return np.ascontiguousarray(R, np.float32), t
-
-
-def run_reference(ref, c, rand_epoch=0):
-    flows = c["flows"]
-    N, h, w, _ = flows.shape
+def run_reference(c, rand_epoch=0):
     fx, fy, cx, cy = c["K"]
     injected = None
-    if c["disparity"] is None and c["depth_priors"] is None:
-        R, t = two_view_pose(flows[0], c["K"])
-        ref.ref_set_two_view_pose(R.astype(np.float64).ctypes.data_as(D), t.astype(np.float64).ctypes.data_as(D))
+    if c["disparity"] is None and c["depth_priors"] is None:  # monocular: orc.ref_voldor injects this two-view pose (D5)
+        R, t = orc.two_view_pose(c["flows"][0], np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], np.float32))
         injected = np.concatenate([R.reshape(9), t])
-    pri = c["depth_priors"]
-    N_dp = 0 if pri is None else pri.shape[0]
-    poses = np.zeros((N, 6), np.float32)
-    cov = np.zeros((N, 6, 6), np.float32)
-    depth = np.zeros((h, w), np.float32)
-    conf = np.zeros((h, w), np.float32)
-    n = C.c_int(0)
-    rc = ref.ref_py_voldor_wrapper(fp(flows), fp(c["disparity"]), None, fp(pri), fp(c["depth_prior_poses"]), fp(c["depth_prior_pconfs"]),
-                                   C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_float(c["basefocal"]), N, N_dp, w, h,
-                                   c["ref_config"].encode(), C.c_uint(rand_epoch), C.byref(n), fp(poses), fp(cov), fp(depth), fp(conf))
-    assert rc == 0
-    return dict(n_registered=n.value, poses=poses[:n.value], poses_covar=cov[:n.value], depth=depth, depth_conf=conf, injected=injected)
+    r = orc.ref_voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"], depth_priors=c["depth_priors"],
+                       depth_prior_poses=c["depth_prior_poses"], depth_prior_pconfs=c["depth_prior_pconfs"], config=c["ref_config"],
+                       rand_epoch=rand_epoch)
+    r["injected"] = injected
+    return r
 
 
 def main():
-    ref = C.CDLL(os.path.join(ROOT, "oracle", "_ref", "libvoldor_ref.so"))
     out = {}
     for name, c in cases.window_cases():
-        r = run_reference(ref, c)
+        r = run_reference(c)
         out[f"{name}/n_registered"] = np.int32(r["n_registered"])
         out[f"{name}/poses"], out[f"{name}/poses_covar"] = r["poses"], r["poses_covar"]
         if r["injected"] is not None:

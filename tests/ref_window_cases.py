@@ -12,14 +12,14 @@ def _small():
     return synth.make_scene(w=128, h=96, n_flows=4, fx=64, fy=64, cx=64, cy=48, seed=5, basefocal=30.0)
 
 
-def _case(sc, config, basefocal=0.0, disparity=False, priors=None, flows=None, b1=False, exact=True, ref_config=None):
+def _case(sc, config, basefocal=0.0, disparity=False, priors=None, flows=None, b1=False, exact=True, ref_config=None, stat_only=False):
     """b1: the reference run shows SURVEY Appendix B-1 (stale device depth), which the oracle only reproduces with
     ORC_EMULATE_B1=1.  exact: small enough for the bit-exact oracle comparison on the CPU.  ref_config: what the reference
     is run with when it differs from what the oracle / product get (the big cases switch B-1 off in the reference)."""
     c = dict(flows=np.ascontiguousarray(sc["flows"] if flows is None else flows, np.float32), K=tuple(float(v) for v in sc["K"]),
              basefocal=float(basefocal), disparity=np.ascontiguousarray(sc["disparity"], np.float32) if disparity else None,
              depth_priors=None, depth_prior_poses=None, depth_prior_pconfs=None, config=config, b1=b1, exact=exact,
-             ref_config=ref_config or config, poses_gt=sc["poses_gt"])
+             ref_config=ref_config or config, poses_gt=sc["poses_gt"], stat_only=stat_only)
     if priors is not None:
         c["depth_priors"], c["depth_prior_poses"], c["depth_prior_pconfs"] = priors
     return c
@@ -39,6 +39,9 @@ def window_cases():
     fl = st["flows"].copy()
     fl[3:] = np.random.default_rng(0).uniform(-40, 40, fl[3:].shape).astype(np.float32)
     yield "truncated_b1", _case(st, MONO, flows=fl, b1=True)
+    # BASELINE configs[0]: the reference's CPU geometry path (geometry.cpp:99-143, lambdatwist_p4p<double> on the host with
+    # libc rand() draws, which no other implementation can replay): statistical comparison only
+    yield "cfg1_cpu_p3p", _case(sp, "--silent --max_iters 8 --cpu_p3p 1 --exclusive_gpu_context 0", stat_only=True)
     # the sizes of tests/test_gpu_voldor.py: reference run with the stale-depth bug switched off (D4), statistical comparison only
     big = synth.make_scene(w=320, h=240, n_flows=5, fx=160, fy=160, cx=160, cy=120, seed=233)
     yield "mono_320x240", _case(big, MONO, exact=False, ref_config=MONO + " --exclusive_gpu_context 0")

@@ -55,7 +55,10 @@ def bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("name,c", [(n, c) for n, c in CASES if c["exact"]], ids=[n for n, c in CASES if c["exact"]])
+EXACT = [(n, c) for n, c in CASES if c["exact"] and not c["stat_only"]]
+
+
+@pytest.mark.parametrize("name,c", EXACT, ids=[n for n, _ in EXACT])
 def test_window_bit_identical_in_reference_mode(gold, reference_mode, name, c):
     if c["b1"]:
         reference_mode.setenv("ORC_EMULATE_B1", "1")
@@ -82,7 +85,7 @@ def test_b1_is_the_only_difference_of_the_default_exclusive_mode(gold, reference
     assert np.array_equal(bits(o2["depth"]), bits(gold["mono_nonexclusive/depth"]))
 
 
-@pytest.mark.parametrize("name", ["stereo_default", "mono_nonexclusive", "depth_priors", "truncated_b1"])
+@pytest.mark.parametrize("name", ["stereo_default", "mono_nonexclusive", "depth_priors", "truncated_b1", "cfg1_cpu_p3p"])
 def test_default_oracle_within_sampling_noise_of_the_reference(gold, name):
     c = dict(CASES)[name]
     o = run_oracle(c)
