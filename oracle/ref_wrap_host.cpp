@@ -3,12 +3,23 @@
 // of OpenCV they use) and linked to the CPU-emulated kernels of ref_wrap_kernels.cpp: what runs behind ref_py_voldor_wrapper
 // is the reference's own py_voldor_wrapper (voldor/py_export.cpp:5-79) -> VOLDOR::init / solve -> optimize_camera_pose ->
 // the reference's kernels.  TEST INFRASTRUCTURE ONLY: pins oracle/orc_voldor.c (tests/golden/ref_window.npz).
-#ifdef REF_PREP_DIR
+//
+// Second build of the same file (-DREF_HOST_ON_HIP, oracle/_ref/libvoldor_refhost_hip.so): the SAME reference host objects
+// linked against voldor_amd/lib/libvoldor_hip.so instead of the emulated kernels -- the reference's voldor.cpp / geometry.cpp
+// then call optimize_depth_gpu, collect_p3p_instances, solve_batch_p3p_*_gpu, meanshift_gpu and fit_robust_gaussian of the
+// HIP library through the mangled gpu_kernels.h symbols, i.e. the drop-in a maintainer gets by swapping -lgpu-kernels for
+// -lvoldor_hip.  tests/test_gpu_reference_host_on_hip.py runs it on the GPU.
+#if defined(REF_PREP_DIR) || defined(REF_HOST_ON_HIP)
 #include "ref_stubs/minicv/minicv.hpp"
 #include "voldor/py_export.h"
 
 double minicv_two_view_R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, minicv_two_view_t[3] = { 0, 0, 1 };
+#ifdef REF_HOST_ON_HIP
+extern "C" int vk_set_rand_epoch(unsigned epoch);  // include/voldor_hip.h:108
+static void ref_reset_window_state(unsigned rand_epoch) { vk_set_rand_epoch(rand_epoch); }
+#else
 extern "C" void ref_reset_window_state(unsigned rand_epoch);
+#endif
 
 extern "C" {
 // what cv::recoverPose will hand to estimate_camera_pose_epipolar (geometry.cpp:288-332); deviation D5

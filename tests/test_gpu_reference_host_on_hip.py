@@ -1,0 +1,121 @@
+"""Drop-in proof: the REFERENCE's own host pipeline driving the HIP kernels.
+
+oracle/_ref/libvoldor_refhost_hip.so (built by `make -C oracle ref` in the authoring container, travels with the snapshot) is
+voldor/py_export.cpp + voldor.cpp + geometry.cpp + utils.cpp of the reference, compiled in place and unmodified (OpenCV calls
+served by oracle/ref_stubs/minicv), LINKED AGAINST voldor_amd/lib/libvoldor_hip.so: its calls to optimize_depth_gpu,
+collect_p3p_instances, solve_batch_p3p_{lambdatwist,ap3p}_gpu, meanshift_gpu and fit_robust_gaussian resolve to the HIP
+library's mangled gpu_kernels.h symbols -- exactly what a maintainer gets by swapping -lgpu-kernels for -lvoldor_hip
+(INTEGRATION.md).  Host pointers, pointer tables, the NULL "keep the device copy" protocol of exclusive_gpu_context, bool and
+default arguments all go through the real call sites of voldor.cpp:254-291 and geometry.cpp:36-58,150-153,193,221.
+
+Checked against the same host code running on the reference's own kernels (CPU emulation): tests/golden/ref_window.npz for
+whole windows, and a live one-iteration run for a tight comparison (identical host code, identical draws: the only
+difference left is the kernels' floating point).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import ref_window_cases as cases
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "oracle", "_ref", "libvoldor_refhost_hip.so")
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_window.npz")
+F = C.POINTER(C.c_float)
+CASES = dict(cases.window_cases())
+
+
+def fp(a):
+    return None if a is None else a.ctypes.data_as(F)
+
+
+@pytest.fixture(scope="module")
+def refhost():
+    from voldor_amd import capi
+    capi.lib()  # the HIP library first: the reference host binds to this very instance
+    if not os.path.exists(LIB):
+        pytest.skip("oracle/_ref/libvoldor_refhost_hip.so not built (needs /root/reference at build time)")
+    return C.CDLL(LIB)
+
+
+def run(refhost, orc, c, config=None, rand_epoch=0):
+    flows = np.ascontiguousarray(c["flows"], np.float32)
+    N, h, w, _ = flows.shape
+    fx, fy, cx, cy = c["K"]
+    if c["disparity"] is None and c["depth_priors"] is None:  # same injected two-view pose as the goldens (D5)
+        R, t = orc.two_view_pose(flows[0], np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], np.float32))
+        D = C.POINTER(C.c_double)
+        R64, t64 = R.astype(np.float64), t.astype(np.float64)
+        refhost.ref_set_two_view_pose(R64.ctypes.data_as(D), t64.ctypes.data_as(D))
+    a = [None if x is None else np.ascontiguousarray(x, np.float32) for x in (c["disparity"], c["depth_priors"], c["depth_prior_poses"], c["depth_prior_pconfs"])]
+    N_dp = 0 if a[1] is None else a[1].shape[0]
+    poses = np.zeros((N, 6), np.float32); covar = np.zeros((N, 6, 6), np.float32)
+    depth = np.zeros((h, w), np.float32); conf = np.zeros((h, w), np.float32)
+    n = C.c_int(0)
+    rc = refhost.ref_py_voldor_wrapper(fp(flows), fp(a[0]), None, fp(a[1]), fp(a[2]), fp(a[3]), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                                       C.c_float(c["basefocal"]), N, N_dp, w, h, (config or c["ref_config"]).encode(), C.c_uint(rand_epoch), C.byref(n),
+                                       fp(poses), fp(covar), fp(depth), fp(conf))
+    assert rc == 0
+    return {"n_registered": n.value, "poses": poses[:n.value], "poses_covar": covar[:n.value], "depth": depth, "depth_conf": conf}
+
+
+@pytest.mark.parametrize("name,config,rot_tol,tr_tol", [
+    ("stereo_default", "--silent --max_iters 1 --rg_refine 0", 1e-4, 3e-3),
+    ("stereo_default", "--silent --max_iters 2 --rg_refine 0", 5e-4, 2e-2),
+    ("mono_nonexclusive", "--silent --max_iters 1 --rg_refine 0", 1e-4, 3e-3),
+])
+def test_reference_host_same_draws_tight(refhost, orc, name, config, rot_tol, tr_tol):
+    """Identical host code and identical random draws on both sides; only the kernels differ (HIP vs the reference's on the
+    CPU).  Camera 0 of the first iteration sees identical inputs on both sides and must agree tightly; after that the
+    reference's index draw re-draws EVERY hypothesis of a camera as soon as one correspondence toggles (Gauss-Seidel cameras,
+    128x96 images), so the bars widen along the chain and with the iteration count -- that sensitivity is the reference's
+    own, it is why the product's pipeline draws by rejection over the map instead (D3b).  Measured: camera 0 rot 0, rel-trans
+    3e-4; camera 3 rot 4e-5, rel-trans 1.6e-3 (1 iteration); 8.5e-3 after 2 iterations."""
+    from voldor_amd import synth
+    c = dict(CASES[name])
+    g = run(refhost, orc, c, config)
+    fx, fy, cx, cy = c["K"]
+    r = orc.ref_voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"], config=config)
+    assert g["n_registered"] == r["n_registered"] == c["flows"].shape[0]
+    rot, tr = synth.pose_errors(g["poses"], r["poses"])
+    assert rot.max() < rot_tol and tr.max() < tr_tol, (rot, tr)
+    if "--max_iters 1 " in config:
+        assert rot[0] < 1e-5 and tr[0] < 1e-3, (rot, tr)
+    m = (g["depth_conf"] > 0.5) & (r["depth_conf"] > 0.5)
+    rel = np.abs(g["depth"][m] - r["depth"][m]) / r["depth"][m]
+    assert np.mean(rel < 1e-3) > 0.9
+
+
+@pytest.mark.parametrize("name", ["stereo_default", "stereo_ap3p", "mono_nonexclusive", "mono_default_b1", "depth_priors", "truncated_b1",
+                                  "mono_320x240", "stereo_312x96"])
+def test_reference_host_on_hip_whole_windows(refhost, orc, name):
+    from voldor_amd import synth
+    gold = np.load(GOLD)
+    c = CASES[name]
+    g = run(refhost, orc, c)
+    n = int(gold[f"{name}/n_registered"])
+    assert g["n_registered"] == n
+    rot, tr = synth.pose_errors(g["poses"], gold[f"{name}/poses"])
+    big = not c["exact"]
+    rot_tol, tr_tol = (1e-3, 3e-2) if big else (2e-3, 8e-2)
+    assert rot.max() < rot_tol and tr.max() < tr_tol, (rot, tr)
+    assert np.isfinite(g["depth"]).all() and np.isfinite(g["depth_conf"]).all()
+    if c["config"].find("--rg_refine 0") < 0:
+        assert np.all(np.diagonal(g["poses_covar"], axis1=1, axis2=2) > 0)  # fit_robust_gaussian ran and returned reliable fits
+
+
+def test_reference_host_and_native_host_agree(refhost, orc):
+    """The library's own B-outer (vk_voldor.hip) against the reference's B-outer on the same kernels."""
+    from voldor_amd import kernels, pyvoldor, synth
+    c = CASES["stereo_312x96"]
+    fx, fy, cx, cy = c["K"]
+    g_ref = run(refhost, orc, c)
+    kernels.set_rand_epoch(0)
+    g_nat = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"], config=c["config"])
+    assert g_ref["n_registered"] == g_nat["n_registered"]
+    rot, tr = synth.pose_errors(g_ref["poses"], g_nat["poses"])
+    assert rot.max() < 1e-3 and tr.max() < 3e-2, (rot, tr)
