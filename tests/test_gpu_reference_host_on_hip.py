@@ -119,3 +119,43 @@ def test_reference_host_and_native_host_agree(refhost, orc):
     assert g_ref["n_registered"] == g_nat["n_registered"]
     rot, tr = synth.pose_errors(g_ref["poses"], g_nat["poses"])
     assert rot.max() < 1e-3 and tr.max() < 3e-2, (rot, tr)
+
+
+def test_reference_cython_module_on_hip(refhost, orc):
+    """One layer further out: slam_py/install/pyvoldor_vo.pyx -- the module voldor_slam.py:21 imports -- cythonized from the
+    reference's own source and linked like the library above (oracle/_ref/pyvoldor_vo*.so).  voldor_slam.py:447-457 builds
+    these kwargs and calls pyvoldor.voldor through functools.partial; the driver itself needs cv2 / sklearn (absent here), so
+    its call is replayed verbatim, explicit Nones included, on the reference's own Python binding."""
+    import glob
+    import sys
+    from functools import partial
+    from voldor_amd import kernels, synth
+    mods = glob.glob(os.path.join(ROOT, "oracle", "_ref", "pyvoldor_vo*.so"))
+    if not mods:
+        pytest.skip("oracle/_ref/pyvoldor_vo*.so not built (needs /root/reference and Cython at build time)")
+    sys.path.insert(0, os.path.dirname(mods[0]))
+    try:
+        import pyvoldor_vo as pyvoldor  # voldor_slam.py:21
+    finally:
+        sys.path.pop(0)
+    c = CASES["stereo_312x96"]
+    fx, fy, cx, cy = c["K"]
+    flows = [c["flows"][i] for i in range(c["flows"].shape[0])]
+    py_voldor_kwargs = {
+        'flows': np.stack(flows[0:4], axis=0),
+        'fx': fx, 'fy': fy, 'cx': cx, 'cy': cy, 'basefocal': c["basefocal"],
+        'disparity': c["disparity"],
+        'depth_priors': None,
+        'depth_prior_pconfs': None,
+        'depth_prior_poses': None,
+        'config': cases.STEREO + ' ' + ''}
+    kernels.set_rand_epoch(0)
+    vo_ret = partial(pyvoldor.voldor, **py_voldor_kwargs)()
+    assert set(vo_ret) >= {"n_registered", "poses", "poses_covar", "depth", "depth_conf"}
+    assert vo_ret["n_registered"] == 4 and vo_ret["poses"].shape == (4, 6) and vo_ret["poses_covar"].shape == (4, 6, 6)
+    assert vo_ret["depth"].dtype == np.float32 and vo_ret["depth"].shape == c["flows"].shape[1:3]
+    gold = np.load(GOLD)
+    rot, tr = synth.pose_errors(vo_ret["poses"], gold["stereo_312x96/poses"])
+    assert rot.max() < 1e-3 and tr.max() < 3e-2, (rot, tr)
+    rot, tr = synth.pose_errors(vo_ret["poses"], c["poses_gt"])
+    assert rot.max() < 3e-3 and tr.max() < 5e-2, (rot, tr)
