@@ -52,6 +52,10 @@ def main():
                 out[f"{name}/{k}_sub2"] = r[k][::2, ::2].copy()
                 out[f"{name}/{k}_sha256"] = np.frombuffer(hashlib.sha256(r[k].tobytes()).digest(), np.uint8)
         print(f"{name:20s} n_registered {r['n_registered']}  |t| {np.linalg.norm(r['poses'][:, 3:], axis=1).round(4) if r['n_registered'] else ''}")
+    for name, c in cases.ensemble_cases():  # poses only
+        r = run_reference(c)
+        out[f"{name}/n_registered"], out[f"{name}/poses"] = np.int32(r["n_registered"]), r["poses"]
+        print(f"{name:20s} n_registered {r['n_registered']}")
     path = os.path.join(HERE, "ref_window.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")

@@ -47,3 +47,14 @@ def window_cases():
     yield "mono_320x240", _case(big, MONO, exact=False, ref_config=MONO + " --exclusive_gpu_context 0")
     bs = synth.make_scene(w=312, h=96, n_flows=4, fx=180, fy=180, cx=152, cy=46, seed=236, basefocal=97.0)
     yield "stereo_312x96", _case(bs, STEREO, basefocal=97.0, disparity=True, exact=False)
+
+
+ENSEMBLE_SEEDS = tuple(range(300, 308))
+
+
+def ensemble_cases():
+    """8 independent monocular 320x240 windows (BASELINE cfg2 at quarter size): poses only, for the accuracy-distribution
+    comparison of the estimators (reference vs HIP) against analytic ground truth."""
+    for seed in ENSEMBLE_SEEDS:
+        sc = synth.make_scene(w=320, h=240, n_flows=5, fx=160, fy=160, cx=160, cy=120, seed=seed)
+        yield f"ens{seed}", _case(sc, MONO, exact=False, ref_config=MONO + " --exclusive_gpu_context 0")

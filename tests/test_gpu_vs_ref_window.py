@@ -57,3 +57,34 @@ def test_window_vs_reference_pipeline(gold, name, c):
         r3, t3 = synth.pose_errors(gold[f"{name}/poses"], gt[:n])
         assert r2.max() < 3e-3 and t2.max() < 5e-2
         assert r3.max() < 3e-3 and t3.max() < 5e-2  # and so is the reference itself
+
+
+def test_accuracy_distribution_matches_the_reference(gold):
+    """Two samples of one estimator cannot be compared pose by pose below its sampling noise, but their ACCURACY can: over 8
+    independent 320x240 monocular windows (40 poses) the HIP path's error against analytic ground truth must have the same
+    size as the reference pipeline's (tests/golden/ref_window.npz "ens*").  Measured: RMS rotation error 6.41e-4 rad (HIP)
+    vs 6.42e-4 (reference), RMS relative translation error 1.62e-2 vs 1.44e-2; HIP vs reference pairwise 2.9e-4 rad /
+    1.2e-2 -- the two runs share the flow noise but not the hypothesis draws (D3b), so they are as far from each other as
+    each is from the truth."""
+    from voldor_amd import kernels, pyvoldor, synth
+    err = {"hip": [], "ref": [], "pair": []}
+    for name, c in cases.ensemble_cases():
+        fx, fy, cx, cy = c["K"]
+        kernels.set_rand_epoch(0)
+        g = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, config=c["config"])
+        ref_poses = gold[f"{name}/poses"]
+        assert g["n_registered"] == int(gold[f"{name}/n_registered"]) == 5
+        gt = c["poses_gt"].copy()
+        gt[:, 3:] /= np.mean(np.linalg.norm(gt[:, 3:], axis=1))  # monocular windows are normalised to mean |t| = 1
+        err["hip"].append(np.stack(synth.pose_errors(g["poses"], gt)))
+        err["ref"].append(np.stack(synth.pose_errors(ref_poses, gt)))
+        err["pair"].append(np.stack(synth.pose_errors(g["poses"], ref_poses)))
+    rms = {k: np.sqrt(np.mean(np.concatenate(v, axis=1) ** 2, axis=1)) for k, v in err.items()}  # [rot, rel-trans]
+    worst = {k: np.concatenate(v, axis=1).max(axis=1) for k, v in err.items()}
+    # same accuracy: RMS error within 25 % of the reference's, for rotation and translation
+    assert np.all(rms["hip"] < 1.25 * rms["ref"]), (rms["hip"], rms["ref"])
+    assert np.all(rms["hip"] > 0.6 * rms["ref"]), (rms["hip"], rms["ref"])  # and not suspiciously better either
+    assert worst["hip"][0] < 3e-3 and worst["hip"][1] < 5e-2 and worst["ref"][0] < 3e-3 and worst["ref"][1] < 5e-2
+    # pairwise: north_star's 1e-3 rad holds for every pose; translation sits at the estimator's noise floor
+    assert worst["pair"][0] < 1e-3 and worst["pair"][1] < 3e-2, worst["pair"]
+    print("rms rot/trans  hip", rms["hip"], " ref", rms["ref"], " hip-vs-ref", rms["pair"])
