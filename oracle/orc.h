@@ -40,6 +40,12 @@
  *     distribution; a 1-pixel change of the set no longer re-draws all 8192 hypotheses).
  *  D4 one depth buffer shared by the depth and the pose half (the reference keeps a
  *     stale un-normalised copy in optimize_depth.cu).
+ *  D5 8-point LMedS two-view bootstrap instead of OpenCV's 5-point findEssentialMat (not in the tree).
+ *  D6 world-scale normalisation skipped when the window is lost (reference: 0/0).
+ *  D8 rodrigues(): exact polar factor instead of the reference's approximate fp32 SVD (svd3_cuda.h).
+ *  (D7 is product-only: fb_smooth arithmetic, see DESIGN.md.)
+ *  Test-only switches that undo D3b / D4 / D8 for the whole-window comparison with the reference pipeline:
+ *  ORC_REFERENCE_DRAW=1, ORC_EMULATE_B1=1, orc_set_rodrigues_hook().
  *
  * All citations are file:line relative to /root/reference.
  */

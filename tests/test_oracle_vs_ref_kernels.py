@@ -94,7 +94,7 @@ def test_solve_batch_p3p_matches_reference(gold, name, X, uv, K, n_poses, use_ap
     # translation: bit-exact, which pins the index draw, the minimal solver and the 4th-point disambiguation.
     assert same_values(tv, g_tv)
     # rotation vector: the reference orthonormalises R with an approximate fp32 SVD (svd3_cuda.h, 4 Jacobi sweeps) before
-    # the angle-axis conversion, the oracle with the exact polar factor (DESIGN.md deviation D4): agreement to that SVD's
+    # the angle-axis conversion, the oracle with the exact polar factor (DESIGN.md deviation D8): agreement to that SVD's
     # own accuracy, the same bar as tests/test_oracle_vs_golden.py::test_rodrigues_vs_reference_svd.
     err = np.abs(rv[ok] - g_rv[ok]).max(axis=1)
     assert np.percentile(err, 99) < 2e-5 and err.max() < 2e-4, (np.percentile(err, [50, 99]), err.max())
