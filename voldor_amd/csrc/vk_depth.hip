@@ -127,6 +127,124 @@ __global__ __launch_bounds__(256) static void k_cost_rand(Img I, int n_rand, uin
     I.cost[pi] = c;
 }
 
+// Same pass for images whose flow layers do not fit the L2s (1080p: 10 layers x 16.6 MB against 4 MB of L2 per XCD).
+// k_cost_rand walks hypothesis-major: each of the 1 + n_rand hypotheses of a pixel touches all N layers in turn, and the
+// workgroups of an XCD are spread over all layers at any moment -- the per-pixel independent random depths scatter every
+// gather (measured at 1080p: 41 % TCC hit rate, 11.7 GB fetched per launch for 0.36 GB of algorithmic bytes).  Here the
+// loops are interchanged: FRAME-major, all hypotheses of the pixel advance together through layer f (rigid-chain state
+// per hypothesis kept in registers), so an XCD's workgroups, which own a band of rows, gather from the band of ONE layer at
+// a time (~2-3 MB).  Same expressions per hypothesis and the same first-wins order of the comparisons as k_cost_rand; the
+// two compile separately, so fma contraction may differ and a near-tie resolve the other way (measured: <= 1 pixel in
+// 76 800, tests/test_gpu_kernels.py::test_frame_major_cost_pass_matches_hypothesis_major).
+static size_t COST_RAND_FRAME_MAJOR_BYTES = (size_t)24 << 20;  // flow bytes above which the frame-major variant runs; vk_set_frame_major_threshold()
+void set_frame_major_threshold(size_t bytes) { COST_RAND_FRAME_MAJOR_BYTES = bytes; }
+constexpr int CR_NHYP = 11;  // incumbent + the reference's default 10 random samples per call; more samples run in batches
+// one frame step for hypotheses [K0, K1): rigid chain -> positions, gathers, residual model (the three phases of pixel_cost)
+template <int K0, int K1>
+__device__ __forceinline__ static void cr_frame_group(const Img& I, const PoseBlock* P, int f, int w, int h, const float2* __restrict__ layer, float2 obs0,
+                                                      float wgt, P3 (&o)[CR_NHYP], float (&px1)[CR_NHYP], float (&py1)[CR_NHYP], float (&cs)[CR_NHYP],
+                                                      float (&ws)[CR_NHYP]) {
+    float rdx[K1 - K0], rdy[K1 - K0];
+    float2 obs[K1 - K0];
+    unsigned valid = 0;
+#pragma unroll
+    for (int k = K0; k < K1; k++) {
+        o[k] = transform(P->Rs[f], P->ts[f], o[k]);
+        float px2, py2;
+        project(P, o[k], px2, py2);
+        float qx = 0.f, qy = 0.f;
+        rdx[k - K0] = 0.f; rdy[k - K0] = 0.f;
+        if (o[k].z > 0.f && px1[k] >= 0.f && px1[k] < (float)w && py1[k] >= 0.f && py1[k] < (float)h) {
+            valid |= 1u << k;
+            qx = px1[k]; qy = py1[k]; rdx[k - K0] = px2 - px1[k]; rdy[k - K0] = py2 - py1[k];
+            px1[k] = px2; py1[k] = py2;  // advances on contributing frames only (:162-164)
+        }
+        obs[k - K0] = (f == 0) ? obs0 : bilinear2(layer, w, h, qx, qy);  // unconditional (clamped) gather, as in pixel_cost
+    }
+#pragma unroll
+    for (int k = K0; k < K1; k++) {
+        if ((valid >> k) & 1u) {
+            cs[k] = __fadd_rn(cs[k], __fmul_rn(wgt, neglog_rigidness_from_flows(rdx[k - K0], rdy[k - K0], obs[k - K0].x, obs[k - K0].y, I.lambda, I.inv_arf)));
+            ws[k] += wgt;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) static void k_cost_rand_frame_major(Img I, int n_rand, uint32_t epoch0, float range_factor) {
+    if (!clamp_active(I)) return;
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
+    const int y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
+    if (x >= I.w || y >= I.h) return;
+    const int w = I.w, h = I.h, npx = w * h, pi = y * w + x;
+    const PoseBlock* P = I.P;
+    float d_best = I.depth[pi], c_best = 0.f;
+    bool first = true;
+    int it = 0;
+    while (first || it < n_rand) {
+        float dh[CR_NHYP];
+        int nh = 0;
+#pragma unroll
+        for (int k = 0; k < CR_NHYP; k++) {
+            dh[k] = 1.f;
+            if (k == 0 && first) { dh[0] = d_best; nh = 1; }
+            else if (it + (k - (first ? 1 : 0)) < n_rand) {
+                const float u = u01(rng3(RAND_SEED, (uint32_t)pi, epoch0 + (uint32_t)(it + k - (first ? 1 : 0))));
+                dh[k] = 1.0f / (range_factor * u + (1.0f / 1e5f));  // MAXIMUM_DEPTH, :15,:273
+                nh = k + 1;
+            }
+        }
+        P3 o[CR_NHYP];
+        float px1[CR_NHYP], py1[CR_NHYP], cs[CR_NHYP], ws[CR_NHYP];
+#pragma unroll
+        for (int k = 0; k < CR_NHYP; k++) {
+            o[k] = backproject(P, (float)x, (float)y, dh[k]);
+            px1[k] = (float)x; py1[k] = (float)y; cs[k] = 0.f; ws[k] = 0.f;
+        }
+        for (int f = 0; f < I.N; f++) {
+            const float wgt = I.rig[(size_t)f * npx + pi];
+            const float2* layer = I.flows + (size_t)f * npx;
+            float2 obs0 = make_float2(0.f, 0.f);
+            if (f == 0) obs0 = layer[pi];  // frame 0 is sampled at the pixel itself (weights 1,0,0,0)
+            cr_frame_group<0, 4>(I, P, f, w, h, layer, obs0, wgt, o, px1, py1, cs, ws);
+            __builtin_amdgcn_sched_barrier(0);  // keep the groups' gathers apart: a third of the registers in flight
+            cr_frame_group<4, 8>(I, P, f, w, h, layer, obs0, wgt, o, px1, py1, cs, ws);
+            __builtin_amdgcn_sched_barrier(0);
+            cr_frame_group<8, CR_NHYP>(I, P, f, w, h, layer, obs0, wgt, o, px1, py1, cs, ws);
+        }
+        for (int f = 0; f < I.N_dp; f++) {
+#pragma unroll
+            for (int k = 0; k < CR_NHYP; k++) {
+                P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)x, (float)y, dh[k]));
+                float qx2, qy2;
+                project(P, q, qx2, qy2);
+                if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
+                    float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+                    if (td > 0.f) {
+                        float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
+                        float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
+                        float wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
+                        cs[k] = __fadd_rn(cs[k], __fmul_rn(wg, 0.6931471805599453f * fast_log2(1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf))));
+                        ws[k] += wg;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CR_NHYP; k++) {
+            if (k < nh) {
+                const float cn = (ws[k] == 0.f) ? INFINITY : cs[k] / fmaxf(ws[k], 1.1920929e-07f);
+                if (k == 0 && first) c_best = cn;
+                else if (cn < c_best) { c_best = cn; d_best = dh[k]; }
+            }
+        }
+        it += nh - (first ? 1 : 0);
+        first = false;
+    }
+    I.depth[pi] = d_best;
+    I.cost[pi] = c_best;
+}
+
 // replace_if_better_depth, optimize_depth.cu:201-207
 template <int NMAX>
 __device__ __forceinline__ static void try_depth(const Img& I, int x, int y, float cand) {
@@ -639,7 +757,11 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
             if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e;
         }
         if (c->prof) prof_begin_inner(c);
-        hipLaunchKernelGGL(k_cost_rand<NMAX>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
+        // flow layers beyond what the eight 4 MB L2s hold: frame-major variant (see k_cost_rand_frame_major)
+        if ((size_t)p.N * w * h * sizeof(float2) > COST_RAND_FRAME_MAJOR_BYTES)
+            hipLaunchKernelGGL(k_cost_rand_frame_major, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
+        else
+            hipLaunchKernelGGL(k_cost_rand<NMAX>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
         if (c->prof) prof_end_inner(c, "cost_rand", 1);
         c->rand_epoch += (uint32_t)(p.n_rand_samples > 0 ? p.n_rand_samples : 0);
         if (p.global_prop_step > 0) {

@@ -195,3 +195,8 @@ def set_rand_epoch(e: int):
 
 def get_rand_epoch() -> int:
     return capi.lib().vk_get_rand_epoch()
+
+
+def set_frame_major_threshold(flow_bytes: int):
+    """Flow-layer size (bytes) above which optimize_depth uses the frame-major cost/random-sample kernel (default 24 MiB)."""
+    capi.lib().vk_set_frame_major_threshold(C.c_size_t(flow_bytes))
