@@ -56,6 +56,10 @@ def main():
         r = run_reference(c)
         out[f"{name}/n_registered"], out[f"{name}/poses"] = np.int32(r["n_registered"]), r["poses"]
         print(f"{name:20s} n_registered {r['n_registered']}")
+    name, c = cases.cfg2_case()  # ~35 s on one core
+    r = run_reference(c)
+    out[f"{name}/n_registered"], out[f"{name}/poses"], out[f"{name}/poses_covar"] = np.int32(r["n_registered"]), r["poses"], r["poses_covar"]
+    print(f"{name:20s} n_registered {r['n_registered']}")
     path = os.path.join(HERE, "ref_window.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")

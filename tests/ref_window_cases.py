@@ -49,6 +49,12 @@ def window_cases():
     yield "stereo_312x96", _case(bs, STEREO, basefocal=97.0, disparity=True, exact=False)
 
 
+def cfg2_case():
+    """BASELINE configs[1] at full size, the very window bench.py times on rank 0 (scene S, seed 233): poses only."""
+    sc = synth.make_scene(w=640, h=480, n_flows=5, fx=320.0, fy=320.0, cx=320.0, cy=240.0, seed=233)
+    return "cfg2_640x480", _case(sc, MONO, exact=False, ref_config=MONO + " --exclusive_gpu_context 0")
+
+
 ENSEMBLE_SEEDS = tuple(range(300, 308))
 
 

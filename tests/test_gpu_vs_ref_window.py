@@ -88,3 +88,21 @@ def test_accuracy_distribution_matches_the_reference(gold):
     # pairwise: north_star's 1e-3 rad holds for every pose; translation sits at the estimator's noise floor
     assert worst["pair"][0] < 1e-3 and worst["pair"][1] < 3e-2, worst["pair"]
     print("rms rot/trans  hip", rms["hip"], " ref", rms["ref"], " hip-vs-ref", rms["pair"])
+
+
+def test_baseline_cfg2_window_vs_reference_pipeline(gold):
+    """BASELINE configs[1] itself -- 640x480, N_flow=5, 8 EM iterations, monocular, the window bench.py times -- against the
+    reference pipeline's poses for the same flows (north_star: 1e-3 rad; translation at the estimator's noise floor)."""
+    from voldor_amd import kernels, pyvoldor, synth
+    name, c = cases.cfg2_case()
+    fx, fy, cx, cy = c["K"]
+    kernels.set_rand_epoch(0)
+    g = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, config=c["config"])
+    assert g["n_registered"] == int(gold[f"{name}/n_registered"]) == 5
+    rot, tr = synth.pose_errors(g["poses"], gold[f"{name}/poses"])
+    assert rot.max() < 1e-3 and tr.max() < 3e-2, (rot, tr)
+    gt = c["poses_gt"].copy()
+    gt[:, 3:] /= np.mean(np.linalg.norm(gt[:, 3:], axis=1))
+    for poses in (g["poses"], gold[f"{name}/poses"]):
+        r, t = synth.pose_errors(poses, gt)
+        assert r.max() < 2e-3 and t.max() < 4e-2, (r, t)
