@@ -93,7 +93,7 @@ def main():
 
     lib = capi.lib()
     if args.frame_major_mb >= 0:
-        lib.vk_set_frame_major_threshold(C.c_size_t(args.frame_major_mb << 20))
+        lib.vk_set_frame_major_threshold(C.c_size_t(args.frame_major_mb << 20), C.c_size_t(64 << 20))
     basefocal = wl["basefocal"]
     sc = synth.make_scene(w=W, h=H, n_flows=N_FLOW, fx=FX, fy=FY, cx=CX, cy=CY, seed=233 + rank,
                           basefocal=basefocal if wl["mode"] != "mono" else 0.0)

@@ -107,10 +107,11 @@ int vk_estimate_depth_closed_form(const float* h_flow, const float* h_K, const f
 int vk_get_compacted_points(float* h_o_pts2, float* h_o_pts3, int max_points); /* returns n_points (<0 error) */
 int vk_set_rand_epoch(unsigned epoch);   /* depth-sampling RNG counter of the current context */
 unsigned vk_get_rand_epoch(void);
-/* The cost-map + random-sample pass has two loop orders with the same results (up to fma-contraction ties, <= 1e-5 of the pixels): hypothesis-major (flow layers that fit
- * the L2s) and frame-major (larger windows, e.g. 1080p).  The switch is the size of the flow layers in bytes, default 24 MiB;
- * tests and A/B measurements force one variant with 0 / SIZE_MAX. */
-int vk_set_frame_major_threshold(size_t flow_bytes);
+/* The cost-map + random-sample pass has two loop orders with the same results (up to fma-contraction ties, <= 1e-5 of the
+ * pixels): hypothesis-major for flow layers that fit the L2s, frame-major above `flow_bytes` (default 24 MiB), and frame-major
+ * with the hypotheses of a pixel evaluated in depth order above `depth_order_bytes` (default 64 MiB; 1080p windows).  Tests and
+ * A/B measurements force a variant with 0 / SIZE_MAX. */
+int vk_set_frame_major_threshold(size_t flow_bytes, size_t depth_order_bytes);
 int vk_profile_enable(int on);           /* HIP-event timing of kernel groups on the library's stream */
 int vk_profile_get(const char* name, double* total_ms, long* count);
 int vk_device_count(void);

@@ -12,10 +12,11 @@ for (w,h,N,ndp) in ((640,360,10,1),(640,360,10,0),(640,360,6,1),(320,240,10,0)):
     if ndp:
         pri=((w/4)/sc['disparity'])[None].astype(np.float32); pc=np.ones_like(pri); cf=np.ones_like(pri); dR=np.eye(3,dtype=np.float32)[None]; dt=np.zeros((1,3),np.float32)
     out=[]
-    for thr in (1<<62,0):
-        kernels.set_frame_major_threshold(thr); kernels.set_rand_epoch(5)
+    for thr,order in ((1<<62,1<<62),(0,1<<62),(0,0)):
+        kernels.set_frame_major_threshold(thr,order); kernels.set_rand_epoch(5)
         out.append(kernels.optimize_depth_gpu(flows,rig,pri,pc,cf,depth,K9(w/2,w/2,w/2,h/2),Rs,ts,dR,dt,1.0,N,ndp,w,h,w/4 if ndp else 0.0,10,0,0,0.15,0.15,1.0 if ndp else -1.0,0.2,0,0.5,0.9,1.0,0))
-    d0,d1=out[0][0],out[1][0]
-    bad=np.argwhere(d0!=d1)
-    print((w,h,N,ndp),'depth mismatches',len(bad),'of',w*h, 'rig mismatches',int(np.sum(out[0][1]!=out[1][1])))
+    d0=out[0][0]
+    for o in out[1:]:
+      d1=o[0]; bad=np.argwhere(d0!=d1)
+      print((w,h,N,ndp),'depth mismatches',len(bad),'of',w*h, 'rig mismatches',int(np.sum(out[0][1]!=o[1])))
     for y,x in bad[:5]: print('   ',x,y,d0[y,x],d1[y,x])

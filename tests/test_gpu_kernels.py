@@ -342,18 +342,19 @@ def test_frame_major_cost_pass_matches_hypothesis_major(small_scene, with_priors
     kw = _od_kwargs(n_rand_samples=n_rand, basefocal=40.0 if with_priors else 0.0, disp_delta=1.0 if with_priors else -1.0)
     out = []
     try:
-        for thr in (1 << 62, 0):  # never / always frame-major
-            kernels.set_frame_major_threshold(thr)
+        for thr, order in ((1 << 62, 1 << 62), (0, 1 << 62), (0, 0)):  # hypothesis-major / frame-major / frame-major in depth order
+            kernels.set_frame_major_threshold(thr, order)
             kernels.set_rand_epoch(9)
             out.append(kernels.optimize_depth_gpu(flows, rig, pri, pc, cf, depth, K, Rs, ts, dR, dt, kw["abs_resize_factor"], N, 0 if pri is None else 2, w, h,
                                                   kw["basefocal"], kw["n_rand_samples"], kw["global_prop_step"], kw["local_prop_width"], kw["lambda_"],
                                                   kw["omega"], kw["disp_delta"], kw["delta"], kw["fb_smooth"], kw["s0_ems_prob"], kw["no_change_prob"],
                                                   kw["range_factor"], kw["update_rigidness_only"]))
     finally:
-        kernels.set_frame_major_threshold(24 << 20)
-    (d0, r0, c0), (d1, r1, c1) = out
-    same = d0 == d1
-    assert np.mean(~same) <= 1e-4, np.mean(~same)
-    np.testing.assert_array_equal(r0[:, same], r1[:, same])
-    np.testing.assert_array_equal(c0[:, same], c1[:, same])
+        kernels.set_frame_major_threshold()
+    d0, r0, c0 = out[0]
+    for d1, r1, c1 in out[1:]:
+        same = d0 == d1
+        assert np.mean(~same) <= 1e-4, np.mean(~same)
+        np.testing.assert_array_equal(r0[:, same], r1[:, same])
+        np.testing.assert_array_equal(c0[:, same], c1[:, same])
     assert np.mean(d0 != depth) > 0.3  # and the pass did something

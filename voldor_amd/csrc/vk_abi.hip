@@ -445,7 +445,7 @@ int vk_set_rand_epoch(unsigned epoch) {
     c->rand_w = c->rand_h = -1;  // explicit seed: the next call adopts its size without resetting
     return pool_set_rand_epoch(epoch);  // and the contexts of vk_voldor_device_batch
 }
-int vk_set_frame_major_threshold(size_t flow_bytes) { set_frame_major_threshold(flow_bytes); return 0; }
+int vk_set_frame_major_threshold(size_t flow_bytes, size_t depth_order_bytes) { set_frame_major_threshold(flow_bytes, depth_order_bytes); return 0; }
 unsigned vk_get_rand_epoch(void) {
     Context* c = default_context();
     return c ? c->rand_epoch : 0u;

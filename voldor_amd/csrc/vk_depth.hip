@@ -136,8 +136,9 @@ __global__ __launch_bounds__(256) static void k_cost_rand(Img I, int n_rand, uin
 // a time (~2-3 MB).  Same expressions per hypothesis and the same first-wins order of the comparisons as k_cost_rand; the
 // two compile separately, so fma contraction may differ and a near-tie resolve the other way (measured: <= 1 pixel in
 // 76 800, tests/test_gpu_kernels.py::test_frame_major_cost_pass_matches_hypothesis_major).
-static size_t COST_RAND_FRAME_MAJOR_BYTES = (size_t)24 << 20;  // flow bytes above which the frame-major variant runs; vk_set_frame_major_threshold()
-void set_frame_major_threshold(size_t bytes) { COST_RAND_FRAME_MAJOR_BYTES = bytes; }
+// flow-layer bytes above which the frame-major variant runs, and above which it also evaluates in depth order; vk_set_frame_major_threshold()
+static size_t COST_RAND_FRAME_MAJOR_BYTES = (size_t)24 << 20, COST_RAND_DEPTH_ORDER_BYTES = (size_t)64 << 20;
+void set_frame_major_threshold(size_t bytes, size_t depth_order_bytes) { COST_RAND_FRAME_MAJOR_BYTES = bytes; COST_RAND_DEPTH_ORDER_BYTES = depth_order_bytes; }
 constexpr int CR_NHYP = 11;  // incumbent + the reference's default 10 random samples per call; more samples run in batches
 // one frame step for hypotheses [K0, K1): rigid chain -> positions, gathers, residual model (the three phases of pixel_cost)
 template <int K0, int K1>
@@ -170,6 +171,7 @@ __device__ __forceinline__ static void cr_frame_group(const Img& I, const PoseBl
     }
 }
 
+template <bool DEPTH_ORDER>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) static void k_cost_rand_frame_major(Img I, int n_rand, uint32_t epoch0, float range_factor) {
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
@@ -192,6 +194,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) static
                 const float u = u01(rng3(RAND_SEED, (uint32_t)pi, epoch0 + (uint32_t)(it + k - (first ? 1 : 0))));
                 dh[k] = 1.0f / (range_factor * u + (1.0f / 1e5f));  // MAXIMUM_DEPTH, :15,:273
                 nh = k + 1;
+            }
+        }
+        // Evaluate the batch in depth order (odd-even transposition network on the 11 slots, original slot index carried
+        // along): the lanes of a wave then walk their hypotheses from far to near together, which narrows the spread of the
+        // gather positions of one step (1080p: -14 %; at KITTI size the sort costs more than it saves, hence the switch).
+        // The decision below restores the first-wins order of the sequential loop.
+        int ord[CR_NHYP];
+#pragma unroll
+        for (int k = 0; k < CR_NHYP; k++) ord[k] = k;
+#pragma unroll
+        for (int r = 0; r < (DEPTH_ORDER ? CR_NHYP : 0); r++) {
+#pragma unroll
+            for (int k = r & 1; k + 1 < CR_NHYP; k += 2) {
+                const bool sw = dh[k] < dh[k + 1];
+                const float a = sw ? dh[k + 1] : dh[k], b = sw ? dh[k] : dh[k + 1];
+                const int oa = sw ? ord[k + 1] : ord[k], ob = sw ? ord[k] : ord[k + 1];
+                dh[k] = a; dh[k + 1] = b; ord[k] = oa; ord[k + 1] = ob;
             }
         }
         P3 o[CR_NHYP];
@@ -230,14 +249,19 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) static
                 }
             }
         }
+        // sequential rule (:269-277): a sample replaces the running best only if strictly cheaper, i.e. the winner is the
+        // cheapest slot and, among equal costs, the earliest one (slot 0 of the first batch is the incumbent itself)
+        float cb = INFINITY, db = 0.f;
+        int ob = CR_NHYP;
 #pragma unroll
         for (int k = 0; k < CR_NHYP; k++) {
-            if (k < nh) {
+            if (ord[k] < nh) {
                 const float cn = (ws[k] == 0.f) ? INFINITY : cs[k] / fmaxf(ws[k], 1.1920929e-07f);
-                if (k == 0 && first) c_best = cn;
-                else if (cn < c_best) { c_best = cn; d_best = dh[k]; }
+                if (cn < cb || (cn == cb && ord[k] < ob) || ob == CR_NHYP) { cb = cn; db = dh[k]; ob = ord[k]; }
             }
         }
+        if (first) { c_best = cb; d_best = db; }   // the incumbent is slot 0 of this batch: it already won its ties
+        else if (cb < c_best) { c_best = cb; d_best = db; }
         it += nh - (first ? 1 : 0);
         first = false;
     }
@@ -758,8 +782,11 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
         }
         if (c->prof) prof_begin_inner(c);
         // flow layers beyond what the eight 4 MB L2s hold: frame-major variant (see k_cost_rand_frame_major)
-        if ((size_t)p.N * w * h * sizeof(float2) > COST_RAND_FRAME_MAJOR_BYTES)
-            hipLaunchKernelGGL(k_cost_rand_frame_major, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
+        const size_t flow_bytes = (size_t)p.N * w * h * sizeof(float2);
+        if (flow_bytes > COST_RAND_FRAME_MAJOR_BYTES && flow_bytes > COST_RAND_DEPTH_ORDER_BYTES)
+            hipLaunchKernelGGL(k_cost_rand_frame_major<true>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
+        else if (flow_bytes > COST_RAND_FRAME_MAJOR_BYTES)
+            hipLaunchKernelGGL(k_cost_rand_frame_major<false>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
         else
             hipLaunchKernelGGL(k_cost_rand<NMAX>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
         if (c->prof) prof_end_inner(c, "cost_rand", 1);
