@@ -7,7 +7,7 @@
 # are never copied into the repository.
 use strict; use warnings;
 my ($ref, $out) = @ARGV;
-my %expect = ('optimize_depth.cu' => 12, 'align_frame.cu' => 4, 'fb_smooth.h' => 6, 'collect_p3p_instances.cu' => 2, 'meanshift.cu' => 2,
+my %expect = ('optimize_depth.cu' => 12, 'align_frame.cu' => 4, 'gblur.cu' => 2, 'fb_smooth.h' => 6, 'collect_p3p_instances.cu' => 2, 'meanshift.cu' => 2,
               'fit_robust_gaussian.cu' => 2, 'solve_batch_ap3p.cu' => 2, 'solve_batch_lambdatwist.cu' => 2);
 for my $f (sort keys %expect) {
     open(my $in, '<', "$ref/gpu-kernels/$f") or die "$f: $!";

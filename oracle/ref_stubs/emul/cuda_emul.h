@@ -35,7 +35,7 @@ template <class F> static void emul_launch(const emul_cfg& c, F kernel) { emul_l
 
 /* ---- runtime API on host memory.  Allocations are padded: the reference's `int i = curand_uniform() * N` indexes one
  * past the end when the draw is exactly 1.0 (solve_batch_lambdatwist.cu:16-19). */
-enum { cudaSuccess = 0 };
+enum { cudaSuccess = 0, cudaErrorInvalidFilterSetting = 26 };
 enum cudaMemcpyKind { cudaMemcpyHostToHost, cudaMemcpyHostToDevice, cudaMemcpyDeviceToHost, cudaMemcpyDeviceToDevice };
 template <class T> static inline cudaError_t cudaMalloc(T** p, size_t n) { *p = (T*)calloc(n + 64, 1); return cudaSuccess; }
 static inline cudaError_t cudaFree(void* p) { free(p); return cudaSuccess; }
@@ -76,11 +76,15 @@ template <typename T> struct GMat {
     void bind(T* p, int w, int h, int d) { ptr = p; _width = w; _height = h; _depth = d; owned = false; }
     int create(size_t w, size_t h, size_t d, bool lazy_depth = false) {
         if (((int)w == _width && (int)h == _height && (int)d == _depth) || (lazy_depth && (int)w == _width && (int)h == _height && (int)d <= _depth)) return 0;
-        if (owned) free(ptr);
+        if (owned) ::free(ptr);
         ptr = (T*)calloc(w * h * (d ? d : 1) + 16, sizeof(T)); owned = true;
         _width = (int)w; _height = (int)h; _depth = (int)d;
         return 1;
     }
+    size_t width() const { return (size_t)_width; }
+    size_t height() const { return (size_t)_height; }
+    size_t depth() const { return (size_t)_depth; }
+    int free() { if (owned) ::free(ptr); ptr = nullptr; owned = false; _width = _height = _depth = 0; return cudaSuccess; }
     int bind_tex() { return 1; }
     int zeros() { memset(ptr, 0, (size_t)_width * _height * (_depth ? _depth : 1) * sizeof(T)); return cudaSuccess; }
     int copy_from_host(const T* src, cudaPos pos, size_t w, size_t h, size_t d) {

@@ -21,7 +21,18 @@ static void ref_reset_window_state(unsigned rand_epoch) { vk_set_rand_epoch(rand
 extern "C" void ref_reset_window_state(unsigned rand_epoch);
 #endif
 
+cv::Mat load_flow(const char* file_path);  // voldor/utils.cpp:23-41 (declared in voldor/utils.h, which py_export.h does not pull in)
+
 extern "C" {
+// the reference's Middlebury .flo reader on a file written by voldor_amd/formats.py / vk_write_flo
+int ref_load_flow(const char* path, int* w, int* h, float* out, size_t cap_floats) {
+    cv::Mat m = load_flow(path);
+    *w = m.cols; *h = m.rows;
+    const size_t n = (size_t)m.cols * m.rows * 2;
+    if (n > cap_floats) return 1;
+    memcpy(out, m.data, n * sizeof(float));
+    return 0;
+}
 // what cv::recoverPose will hand to estimate_camera_pose_epipolar (geometry.cpp:288-332); deviation D5
 void ref_set_two_view_pose(const double* R9, const double* t3) {
     memcpy(minicv_two_view_R, R9, sizeof minicv_two_view_R);

@@ -2,7 +2,7 @@
 // compiled for the CPU and executed thread by thread.
 //
 // oracle/ref_prep.pl rewrites the <<< >>> launch statements of gpu-kernels/{optimize_depth,collect_p3p_instances,
-// meanshift,fit_robust_gaussian,solve_batch_ap3p,solve_batch_lambdatwist,align_frame}.cu and fb_smooth.h into a temp directory
+// meanshift,fit_robust_gaussian,solve_batch_ap3p,solve_batch_lambdatwist,align_frame,gblur}.cu and fb_smooth.h into a temp directory
 // outside the repo (REF_PREP_DIR, deleted after the build); each file is included below in its own namespace (they all
 // define file-static __constant__ symbols with the same names).  ref_stubs/emul/ supplies threadIdx & co, a sequential
 // launcher, cudaMalloc/cudaMemcpy on host memory, a host-backed GMat, and stand-ins for the three pieces that cannot be
@@ -63,6 +63,10 @@ namespace ref_lt {
 #undef BLOCK_WIDTH
 namespace ref_align {
 #include EMUL_STR(REF_PREP_DIR/align_frame.cu)
+}
+namespace ref_gb {
+using ::GMatf;
+#include EMUL_STR(REF_PREP_DIR/gblur.cu)
 }
 
 extern "C" {
@@ -139,6 +143,15 @@ int ref_align_init(float* images, float* depths, float* weights, float* K, float
 int ref_align_eval(int ref_fid, int tar_fid, const float* params_ref, const float* params_tar, float* o_residual, float* o_jacobian,
                    int apply_weights) {
     return ref_align::align_frame_eval_gpu(ref_fid, tar_fid, params_ref, params_tar, o_residual, o_jacobian, apply_weights != 0);
+}
+
+// gblur_gpu (gblur.cu:47-72): src / dst [d][h][w]; returns the reference's error code (26 = kernel too wide)
+int ref_gblur(float* src, float* dst, int w, int h, int d, float sigma, int ksize) {
+    GMatf s, o;
+    s.bind(src, w, h, d);
+    const int rc = ref_gb::gblur_gpu(s, o, sigma, ksize);
+    if (rc == 0) { o.copy_to_host(dst, make_cudaPos(0, 0, 0), w, h, d); o.free(); }
+    return rc;
 }
 
 // a new window: the next optimize_depth_gpu call re-creates its cuRAND states, starting from counter value `rand_epoch`

@@ -149,6 +149,13 @@ def main():
         rc, m, cv, dens, it = ref_rg(ref, space, mean, covar, a)
         out[f"rg/{name}/rc"], out[f"rg/{name}/mean"], out[f"rg/{name}/covar"] = np.int32(rc), m, cv
         out[f"rg/{name}/density"], out[f"rg/{name}/iters"] = dens, np.int32(it)
+    for name, src, sigma, ksize in cases.gblur_cases():
+        dst = np.zeros_like(src)
+        d, h, w = src.shape
+        rc = ref.ref_gblur(fp(src), fp(dst), w, h, d, C.c_float(sigma), ksize)
+        out[f"gblur/{name}/rc"] = np.int32(rc)
+        if rc == 0:
+            out[f"gblur/{name}/dst"] = dst
     path = os.path.join(HERE, "ref_kernels.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")

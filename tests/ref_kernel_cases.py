@@ -158,3 +158,13 @@ def align_cases():
                               ("f1_f2_truth_res", 1, 2, P[1], P[2], False, False)]
     yield "depth_only", kf, False, [("f1_f0_jac", 1, 0, scaled[1], scaled[0], True, False),
                                     ("f0_f2_res", 0, 2, pert[0], pert[2], False, True)]
+
+
+def gblur_cases():
+    """(name, src [d,h,w], sigma, ksize): gblur_gpu (gblur.cu:47-72); ksize 0 = max(ceil(6 sigma), 3)"""
+    rng = np.random.default_rng(4)
+    yield "2x37x53_s1.5", rng.uniform(0, 5, (2, 37, 53)).astype(np.float32), 1.5, 0
+    yield "1x64x80_s3", rng.uniform(0, 5, (1, 64, 80)).astype(np.float32), 3.0, 0
+    yield "1x20x30_s0.4", rng.uniform(0, 5, (1, 20, 30)).astype(np.float32), 0.4, 0   # kernel clamps to 3 taps
+    yield "1x16x16_k9", rng.uniform(0, 5, (1, 16, 16)).astype(np.float32), 2.0, 9
+    yield "too_wide", rng.uniform(0, 5, (1, 8, 8)).astype(np.float32), 50.0, 0       # half kernel > 128 taps: error

@@ -115,3 +115,24 @@ def test_pose_text_formats(tmp_path):
                       [2 * (qx * qy + qz * qw), 1 - 2 * (qx * qx + qz * qz), 2 * (qy * qz - qx * qw)],
                       [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), 1 - 2 * (qx * qx + qy * qy)]])
         np.testing.assert_allclose(R, T[:3, :3], atol=1e-12)
+
+
+def test_flo_files_are_read_by_the_reference_cpp_loader(tmp_path):
+    """voldor/utils.cpp:23-41 load_flow -- the C++ reader the reference's main.cpp uses -- compiled in place into oracle/_ref
+    (ref_wrap_host.cpp) reads the files vk_write_flo and formats.save_flow write, value for value."""
+    from oracle import orc
+    from voldor_amd import capi, formats
+    ref = orc.ref()
+    if ref is None or not hasattr(ref, "ref_load_flow"):
+        pytest.skip("oracle/_ref with the host pipeline is not built on this box")
+    rng = np.random.default_rng(3)
+    flow = rng.normal(0, 7, (37, 53, 2)).astype(np.float32)
+    for k, write in enumerate((lambda p: formats.save_flow(p, flow),
+                               lambda p: capi.lib().vk_write_flo(p.encode(), flow.ctypes.data_as(C.POINTER(C.c_float)), 53, 37))):
+        p = str(tmp_path / f"f{k}.flo")
+        write(p)
+        w, h = C.c_int(0), C.c_int(0)
+        got = np.zeros_like(flow)
+        assert ref.ref_load_flow(p.encode(), C.byref(w), C.byref(h), got.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(got.size)) == 0
+        assert (w.value, h.value) == (53, 37)
+        np.testing.assert_array_equal(got, flow)

@@ -147,3 +147,13 @@ def test_align_frame_vs_reference_kernels(gold, name, kf, photo, evals):
                 assert (np.abs(jac[big] - g_jac[big]).max(axis=0) / scale).max() < 2e-3, en
             bad = (np.abs(jac[m] - g_jac[m]) / scale).max(axis=1) > 3e-2
             assert bad.mean() < 2e-2, en
+
+
+@pytest.mark.parametrize("name,src,sigma,ksize", list(cases.gblur_cases()), ids=[c[0] for c in cases.gblur_cases()])
+def test_gblur_vs_reference_kernel(gold, name, src, sigma, ksize):
+    from voldor_amd import kernels
+    rc, dst = kernels.gblur_gpu(src, sigma, ksize)
+    g_rc = int(gold[f"gblur/{name}/rc"])
+    assert (rc == 0) == (g_rc == 0)
+    if g_rc == 0:
+        assert np.abs(dst - gold[f"gblur/{name}/dst"]).max() < 1e-5 * max(1.0, np.abs(src).max())

@@ -148,3 +148,12 @@ def test_align_frame_matches_reference(gold, name, kf, photo, evals):
             assert np.all(err <= 1e-6 * np.maximum(scale, 1.0)), (en, err, scale)
             if not photo:
                 assert scale[7] == 0 and scale[8] == 0  # no colour parameters without the photometric term
+
+
+@pytest.mark.parametrize("name,src,sigma,ksize", list(cases.gblur_cases()), ids=[c[0] for c in cases.gblur_cases()])
+def test_gblur_bit_exact(gold, name, src, sigma, ksize):
+    rc, dst = orc.gblur(src, sigma, ksize)
+    g_rc = int(gold[f"gblur/{name}/rc"])
+    assert (rc == 0) == (g_rc == 0)
+    if g_rc == 0:
+        assert same_bits(dst, gold[f"gblur/{name}/dst"])
