@@ -136,3 +136,38 @@ def test_flo_files_are_read_by_the_reference_cpp_loader(tmp_path):
         assert ref.ref_load_flow(p.encode(), C.byref(w), C.byref(h), got.ctypes.data_as(C.POINTER(C.c_float)), C.c_size_t(got.size)) == 0
         assert (w.value, h.value) == (53, 37)
         np.testing.assert_array_equal(got, flow)
+
+
+def test_pose_conversions_either_side_of_the_vo_call():
+    """slam_py/slam_utils.py:55-93 (T44_to_T6 / T6_to_T44 / polish_T44; cv2.Rodrigues restated): round trips, the small-angle
+    and the pi branch, dtype and batch handling, and agreement with the oracle's restatement of the same OpenCV function."""
+    from oracle import orc
+    from voldor_amd import slam_utils as su
+    rng = np.random.default_rng(12)
+    for scale in (1e-9, 1e-3, 0.3, 2.5):
+        p6 = np.concatenate([rng.normal(0, scale, 3), rng.normal(0, 1, 3)]).astype(np.float32)
+        T = su.T6_to_T44(p6)
+        assert T.dtype == np.float32 and T.shape == (4, 4) and T[3, 3] == 1 and np.all(T[3, :3] == 0)
+        np.testing.assert_allclose(T[:3, :3] @ T[:3, :3].T, np.eye(3), atol=2e-6)
+        np.testing.assert_allclose(T[:3, :3], orc.rvec_to_rotmat(p6[:3]), atol=1e-7)  # same cvRodrigues2 restatement in C
+        back = su.T44_to_T6(T)
+        np.testing.assert_allclose(back, p6, atol=2e-6 * max(1.0, scale))
+    # rotation by pi about a tilted axis: the acos branch with s ~ 0
+    axis = np.array([0.6, -0.48, 0.64])
+    Rpi = 2 * np.outer(axis, axis) - np.eye(3)
+    Tpi = np.eye(4); Tpi[:3, :3] = Rpi
+    r = su.T44_to_T6(Tpi)[:3]
+    assert abs(np.linalg.norm(r) - np.pi) < 1e-9 and (np.allclose(r / np.pi, axis, atol=1e-9) or np.allclose(r / np.pi, -axis, atol=1e-9))
+    # batches, and the exact expression of voldor_slam.py:440 / :492
+    P = rng.normal(0, 0.1, (5, 6))
+    TT = su.T6_to_T44(P)
+    assert TT.shape == (5, 4, 4) and TT.dtype == np.float64
+    np.testing.assert_allclose(su.T44_to_T6(TT), P, atol=1e-12)
+    Twc_cur, Tcw = su.T6_to_T44(P[0]), np.linalg.inv(su.T6_to_T44(P[1]))
+    prior_pose = su.T44_to_T6(np.linalg.inv(Twc_cur @ Tcw))
+    np.testing.assert_allclose(su.T6_to_T44(prior_pose) @ (Twc_cur @ Tcw), np.eye(4), atol=1e-12)
+    noisy = TT[2].copy(); noisy[:3, :3] += rng.normal(0, 1e-3, (3, 3))
+    su.polish_T44(noisy)
+    np.testing.assert_allclose(noisy[:3, :3] @ noisy[:3, :3].T, np.eye(3), atol=1e-12)
+    with pytest.raises(ValueError):
+        su.T44_to_T6(np.zeros(4))
