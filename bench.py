@@ -182,22 +182,27 @@ def main():
 
     # ---- extra: several independent windows in flight on the one GPU (never the headline value) ----
     conc = None
-    if rank == 0 and world == 1 and args.in_flight > 1 and wl["mode"] == "mono":
+    if rank == 0 and world == 1 and args.in_flight > 1:
         B = args.in_flight
         os.environ["VOLDOR_HIP_INFLIGHT"] = str(B)  # read by vk_voldor_device_batch at every call
         NW = 4 * B  # windows per batch call: the tail of a batch (the last windows finishing alone) is amortised over 4 rounds
-        scs = [sc] + [synth.make_scene(w=W, h=H, n_flows=N_FLOW, fx=FX, fy=FY, cx=CX, cy=CY, seed=1000 + b) for b in range(1, B)]
+        scs = [sc] + [synth.make_scene(w=W, h=H, n_flows=N_FLOW, fx=FX, fy=FY, cx=CX, cy=CY, seed=1000 + b,
+                                       basefocal=basefocal if wl["mode"] != "mono" else 0.0) for b in range(1, B)]
         fl_b = [flows] + [torch.from_numpy(s["flows"]).cuda() for s in scs[1:]]
         fls = [fl_b[i % B] for i in range(NW)]  # B distinct sequences, each submitted 4 times per batch
+        bkw = {}
+        if wl["mode"] == "stereo":
+            dsp = [extra["disparity"]] + [torch.from_numpy(s["disparity"]).cuda() for s in scs[1:]]
+            bkw = dict(basefocal=basefocal, disparity_list=[dsp[i % B] for i in range(NW)])
         douts = [torch.empty(H, W, device="cuda") for _ in range(NW)]
         couts = [torch.empty(H, W, device="cuda") for _ in range(NW)]
         for _ in range(max(1, args.warmup // 2)):
-            outs = pyvoldor.voldor_device_batch(fls, FX, FY, CX, CY, config=CONFIG, depth_out=douts, depth_conf_out=couts)
+            outs = pyvoldor.voldor_device_batch(fls, FX, FY, CX, CY, config=CONFIG, depth_out=douts, depth_conf_out=couts, **bkw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         nb = max(2, args.steps // 4)
         for _ in range(nb):
-            outs = pyvoldor.voldor_device_batch(fls, FX, FY, CX, CY, config=CONFIG, depth_out=douts, depth_conf_out=couts)
+            outs = pyvoldor.voldor_device_batch(fls, FX, FY, CX, CY, config=CONFIG, depth_out=douts, depth_conf_out=couts, **bkw)
         torch.cuda.synchronize()
         tb = time.perf_counter() - t0
         conc = {"windows_in_flight": B, "windows_per_batch": NW, "value": round(NW * nb / tb, 3), "unit": "frames/s",
