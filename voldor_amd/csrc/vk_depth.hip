@@ -783,9 +783,10 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
         if (c->prof) prof_begin_inner(c);
         // flow layers beyond what the eight 4 MB L2s hold: frame-major variant (see k_cost_rand_frame_major)
         const size_t flow_bytes = (size_t)p.N * w * h * sizeof(float2);
-        if (flow_bytes > COST_RAND_FRAME_MAJOR_BYTES && flow_bytes > COST_RAND_DEPTH_ORDER_BYTES)
+        const bool frame_major = flow_bytes > COST_RAND_FRAME_MAJOR_BYTES && p.n_rand_samples > 0;  // without samples there is one hypothesis: nothing to interchange
+        if (frame_major && flow_bytes > COST_RAND_DEPTH_ORDER_BYTES)
             hipLaunchKernelGGL(k_cost_rand_frame_major<true>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
-        else if (flow_bytes > COST_RAND_FRAME_MAJOR_BYTES)
+        else if (frame_major)
             hipLaunchKernelGGL(k_cost_rand_frame_major<false>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
         else
             hipLaunchKernelGGL(k_cost_rand<NMAX>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
