@@ -37,6 +37,25 @@ __device__ __forceinline__ bool clamp_active(Img& I) {
     return I.N + I.N_dp > 0;
 }
 
+// depth-prior term of compute_pixel_cost (optimize_depth.cu:166-190): the hypothesis seen from prior f's camera against the
+// prior map, weighted by the prior's confidences (all three sampled bilinearly at the projected position)
+__device__ __forceinline__ static void prior_term(const Img& I, const PoseBlock* P, int f, int px, int py, float depth, float& cost_sum, float& wsum) {
+    const int w = I.w, h = I.h, npx = w * h;
+    P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
+    float qx2, qy2;
+    project(P, q, qx2, qy2);
+    if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
+        float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+        if (td > 0.f) {
+            float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
+            float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
+            float wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
+            cost_sum = __fadd_rn(cost_sum, __fmul_rn(wg, 0.6931471805599453f * fast_log2(1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf))));
+            wsum += wg;
+        }
+    }
+}
+
 // compute_pixel_cost, optimize_depth.cu:140-198.
 // Three phases so that the N bilinear gathers of one hypothesis are all in flight together instead
 // of one L2 round trip per frame (the sampling positions depend on depth and poses only, not on
@@ -87,21 +106,7 @@ __device__ __forceinline__ static float pixel_cost(const Img& I, int px, int py,
             wsum += wgt[f];
         }
     }
-    for (int f = 0; f < I.N_dp; f++) {
-        P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
-        float qx2, qy2;
-        project(P, q, qx2, qy2);
-        if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
-            float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
-            if (td > 0.f) {
-                float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
-                float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
-                float wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
-                cost_sum = __fadd_rn(cost_sum, __fmul_rn(wg, 0.6931471805599453f * fast_log2(1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf))));
-                wsum += wg;
-            }
-        }
-    }
+    for (int f = 0; f < I.N_dp; f++) prior_term(I, P, f, px, py, depth, cost_sum, wsum);
     if (wsum == 0.f) return INFINITY;
     return cost_sum / fmaxf(wsum, 1.1920929e-07f);
 }
@@ -233,21 +238,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) static
         }
         for (int f = 0; f < I.N_dp; f++) {
 #pragma unroll
-            for (int k = 0; k < CR_NHYP; k++) {
-                P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)x, (float)y, dh[k]));
-                float qx2, qy2;
-                project(P, q, qx2, qy2);
-                if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
-                    float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
-                    if (td > 0.f) {
-                        float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
-                        float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
-                        float wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
-                        cs[k] = __fadd_rn(cs[k], __fmul_rn(wg, 0.6931471805599453f * fast_log2(1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf))));
-                        ws[k] += wg;
-                    }
-                }
-            }
+            for (int k = 0; k < CR_NHYP; k++) prior_term(I, P, f, x, y, dh[k], cs[k], ws[k]);
         }
         // sequential rule (:269-277): a sample replaces the running best only if strictly cheaper, i.e. the winner is the
         // cheapest slot and, among equal costs, the earliest one (slot 0 of the first batch is the incumbent itself)
