@@ -81,9 +81,10 @@ def test_accuracy_distribution_matches_the_reference(gold):
         err["pair"].append(np.stack(synth.pose_errors(g["poses"], ref_poses)))
     rms = {k: np.sqrt(np.mean(np.concatenate(v, axis=1) ** 2, axis=1)) for k, v in err.items()}  # [rot, rel-trans]
     worst = {k: np.concatenate(v, axis=1).max(axis=1) for k, v in err.items()}
-    # same accuracy: RMS error within 25 % of the reference's, for rotation and translation
-    assert np.all(rms["hip"] < 1.25 * rms["ref"]), (rms["hip"], rms["ref"])
-    assert np.all(rms["hip"] > 0.6 * rms["ref"]), (rms["hip"], rms["ref"])  # and not suspiciously better either
+    # same accuracy: RMS error of 40 poses within a factor 1.5 of the reference's, for rotation and translation (measured 1.00
+    # and 1.13; the bar leaves room for the sampling noise of another 40-pose draw, ~ +-15 %)
+    assert np.all(rms["hip"] < 1.5 * rms["ref"]), (rms["hip"], rms["ref"])
+    assert np.all(rms["hip"] > 0.5 * rms["ref"]), (rms["hip"], rms["ref"])  # and not suspiciously better either
     assert worst["hip"][0] < 3e-3 and worst["hip"][1] < 5e-2 and worst["ref"][0] < 3e-3 and worst["ref"][1] < 5e-2
     # pairwise: north_star's 1e-3 rad holds for every pose; translation sits at the estimator's noise floor
     assert worst["pair"][0] < 1e-3 and worst["pair"][1] < 3e-2, worst["pair"]
