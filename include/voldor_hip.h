@@ -112,21 +112,17 @@ unsigned vk_get_rand_epoch(void);
  * with the hypotheses of a pixel evaluated in depth order above `depth_order_bytes` (default 64 MiB; 1080p windows).  Tests and
  * A/B measurements force a variant with 0 / SIZE_MAX. */
 int vk_set_frame_major_threshold(size_t flow_bytes, size_t depth_order_bytes);
+/* Strict-math mode (process-wide default; the window call also takes the config key --strict_math 0|1): every stage runs in
+ * the reference's operation order on software transcendentals (voldor_amd/csrc/vk_strict_math.h), a few times slower, so that
+ * results can be compared bit for bit with the CPU oracle in the same mode (parity pinning).  Unset, the
+ * default comes from the environment variable VOLDOR_HIP_STRICT_MATH. */
+int vk_set_strict_math(int on);
+int vk_get_strict_math(void);
 int vk_profile_enable(int on);           /* HIP-event timing of kernel groups on the library's stream */
 int vk_profile_get(const char* name, double* total_ms, long* count);
 int vk_device_count(void);
 int vk_set_device(int dev);
 const char* vk_version(void);
-
-/* ---- D. host builds of the per-lane solver math (same source as the device code), for CPU-only
- * verification against the oracle; not part of the product path ---- */
-int vk_host_lambdatwist_p4p(const float* y8, const float* x12, float fx, float fy, float cx, float cy,
-                            int use_double, float* R9, float* t3);
-int vk_host_ap3p_p4p(const float* y8, const float* x12, float fx, float fy, float cx, float cy, float* R9, float* t3);
-void vk_host_rodrigues(const float* R9, float* rvec3);
-void vk_host_rvec_to_rotmat(const float* rvec3, float* R9);
-unsigned vk_host_rng(unsigned seed, unsigned stream, unsigned counter);
-float vk_host_u01(unsigned r);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -4,6 +4,7 @@
  * Restated from gpu-kernels/{residual_model.h,optimize_depth.cu,fb_smooth.h,gblur.cu};
  * citations inline (file:line relative to /root/reference). */
 #include "orc.h"
+#include "orc_math.h"
 #include <math.h>
 #include <float.h>
 #include <stdlib.h>
@@ -13,6 +14,10 @@
 #endif
 
 #define ZDE FLT_EPSILON /* gpu-kernels/utils.h:19 */
+
+int orc_strict_math_flag = 0;
+void orc_set_strict_math(int on) { orc_strict_math_flag = on ? 1 : 0; }
+int orc_get_strict_math(void) { return orc_strict_math_flag; }
 
 void orc_set_threads(int n) {
 #ifdef _OPENMP
@@ -64,12 +69,12 @@ float orc_fun_fmag_c(float fmag) {
 /* residual_model.h:21-25 */
 float orc_fun_fmag_scale(float fmag) {
     fmag = fminf(fmaxf((float)(fmag * EST_RF), MIN_OBS_FMAG), MAX_OBS_FMAG);
-    return FISK_A1 * expf(FISK_A2 * fmag);
+    return FISK_A1 * om_expf(FISK_A2 * fmag);
 }
 /* residual_model.h:28-31 */
 float orc_fisk_dist_pdf(float x, float c, float scale) {
     x = fmaxf((float)(x * EST_RF), ZDE);
-    return (c * powf((x * x) / scale, -c - 1.f) * powf(1 + powf((x * x) / scale, -c), -2.f)) / scale;
+    return (c * om_powf((x * x) / scale, -c - 1.f) * om_powf(1 + om_powf((x * x) / scale, -c), -2.f)) / scale;
 }
 static inline float l2norm(float x, float y) { return sqrtf(x * x + y * y); }
 /* residual_model.h:34-42 */
@@ -85,7 +90,7 @@ float orc_fun_rigidness(float dx1, float dy1, float dx2, float dy2, float lambda
 /* residual_model.h:45-49 */
 static inline void fun_cost(float dx1, float dy1, float dx2, float dy2, float weight,
                             float* io_cost, float* io_wsum, float lambda, float abs_rf) {
-    *io_cost -= weight * logf(orc_fun_rigidness(dx1, dy1, dx2, dy2, lambda, abs_rf));
+    *io_cost -= weight * om_logf(orc_fun_rigidness(dx1, dy1, dx2, dy2, lambda, abs_rf));
     *io_wsum += weight;
 }
 /* residual_model.h:51-61 */
@@ -103,7 +108,7 @@ float orc_fun_depth_rigidness(float d1, float d2, float basefocal, float omega, 
 /* residual_model.h:64-68 */
 static inline void fun_depth_cost(float d1, float d2, float basefocal, float weight,
                                   float* io_cost, float* io_wsum, float omega, float abs_rf) {
-    *io_cost -= weight * logf(orc_fun_depth_rigidness(d1, d2, basefocal, omega, abs_rf));
+    *io_cost -= weight * om_logf(orc_fun_depth_rigidness(d1, d2, basefocal, omega, abs_rf));
     *io_wsum += weight;
 }
 

@@ -5,6 +5,7 @@
  * solve_batch_ap3p.cu,rodrigues.h,meanshift.cu,fit_robust_gaussian.cu,aux_funs.cpp},
  * lambdatwist/*.h and voldor/geometry.cpp; citations inline. */
 #include "orc.h"
+#include "orc_math.h"
 #include <tgmath.h>
 #include <float.h>
 #include <stdlib.h>
@@ -156,7 +157,7 @@ void orc_rotmat_to_angle_axis(const float* R9, float* aa) {
     aa[2] = R[1][0] - R[0][1];
     float costheta = fminf(fmaxf((R[0][0] + R[1][1] + R[2][2] - 1.f) * 0.5f, -1.f), 1.f);
     float sintheta = fminf(sqrtf(aa[0] * aa[0] + aa[1] * aa[1] + aa[2] * aa[2]) * 0.5f, 1.f);
-    const float theta = atan2f(sintheta, costheta);
+    const float theta = om_atan2f(sintheta, costheta);
     if ((sintheta > FLT_EPSILON) || (sintheta < -FLT_EPSILON)) {
         const float r = theta / (2.f * sintheta);
         aa[0] *= r; aa[1] *= r; aa[2] *= r;
@@ -213,7 +214,7 @@ void orc_rvec_to_rotmat(const float* rvec3, float* R9) {
         for (int i = 0; i < 9; i++) R9[i] = (i % 4 == 0) ? 1.f : 0.f;
         return;
     }
-    double c = cos(theta), s = sin(theta), c1 = 1. - c, it = 1. / theta;
+    double c = om_cos(theta), s = om_sin(theta), c1 = 1. - c, it = 1. / theta;
     rx *= it; ry *= it; rz *= it;
     double rrt[9] = { rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz };
     double rxm[9] = { 0, -rz, ry, rz, 0, -rx, -ry, rx, 0 };
@@ -248,8 +249,8 @@ static cplx c_sqrt(cplx x) { /* :9-15 */
     return o;
 }
 static cplx c_pow(cplx z, float p) { /* :17-20 */
-    float theta = atan2f(z.y, z.x);
-    cplx o = { powf(c_abs(z), p) * cosf(p * theta), powf(c_abs(z), p) * sinf(p * theta) };
+    float theta = om_atan2f(z.y, z.x);
+    cplx o = { om_powf(c_abs(z), p) * om_cosf(p * theta), om_powf(c_abs(z), p) * om_sinf(p * theta) };
     return o;
 }
 static void solve_quartic(const float* f, float* roots) { /* :28-82, literal incl. the double sqrt at :57 */
@@ -265,7 +266,7 @@ static void solve_quartic(const float* f, float* roots) { /* :28-82, literal inc
     w = c_sqrt(w);
     if (q3 >= 0) { w.x = -w.x - q3; w.y = -w.y; }
     else { w = c_sqrt(w); w.x = w.x - q3; }
-    if (w.y == 0.0f) { w.x = cbrtf(w.x); t = 2.0f * (w.x + p3 / w.x); }
+    if (w.y == 0.0f) { w.x = om_cbrtf(w.x); t = 2.0f * (w.x + p3 / w.x); }
     else { w = c_pow(w, (1.0f / 3.0f)); t = 4.0f * w.x; }
     cplx arg = { -2 * p4 / 3 + t, 0 };
     cplx sqrt_2m = c_sqrt(arg);
@@ -491,7 +492,7 @@ static float ms_weights(const float* space, const float* mean, float kernel_var,
     for (int i = 0; i < N; i++) {
         float l2 = 0;
         for (int d = 0; d < dims; d++) { float df = space[i * dims + d] - mean[d]; l2 += df * df; }
-        wgt[i] = expf(-l2 / (2 * kernel_var));
+        wgt[i] = om_expf(-l2 / (2 * kernel_var));
         if (wx) for (int d = 0; d < dims; d++) wx[(size_t)i * dims + d] = space[i * dims + d] * wgt[i];
     }
     float wsum;

@@ -1,0 +1,176 @@
+// tests/cxx/vk_testhooks.hip -- TEST LIBRARY (voldor_amd/lib/libvoldor_hip_test.so), not part of the product.
+//
+// (1) Host instantiations of the __host__ __device__ per-lane math of the product headers (vk_p3p.hpp, vk_device.hpp,
+//     vk_strict_model.hpp), so the CPU-only test tier can compare the exact source the GPU lanes run with the oracle and
+//     the reference's golden vectors.
+// (2) Device-vs-host probes: the same functions evaluated by a trivial kernel, one lane per element.  Strict mode rests on
+//     "IEEE + - * / sqrt and conversions give the same bits on gfx950 and on the host"; these probes test exactly that on
+//     the GPU box (tests/test_gpu_strict.py), and they locate where a device build starts to differ from the host build.
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+#include "../../voldor_amd/csrc/vk_p3p.hpp"
+#include "../../voldor_amd/csrc/vk_device.hpp"
+#include "../../voldor_amd/csrc/vk_strict_math.h"
+#include "../../voldor_amd/csrc/vk_strict_model.hpp"
+
+#define VKT_API extern "C" __attribute__((visibility("default")))
+
+// ---- (1) host instantiations ------------------------------------------------------------------------------------
+VKT_API int vk_host_lambdatwist_p4p(const float* y8, const float* x12, float fx, float fy, float cx, float cy, int use_double,
+                                    float* R9, float* t3) {
+    float yu[4], yv[4], xp[4][3];
+    for (int k = 0; k < 4; k++) { yu[k] = y8[k * 2]; yv[k] = y8[k * 2 + 1]; for (int d = 0; d < 3; d++) xp[k][d] = x12[k * 3 + d]; }
+    bool ok = use_double ? vk::lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R9, t3)
+                         : vk::lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R9, t3);
+    return ok ? 1 : 0;
+}
+VKT_API int vk_host_ap3p_p4p(const float* y8, const float* x12, float fx, float fy, float cx, float cy, float* R9, float* t3) {
+    float yu[4], yv[4], xp[4][3];
+    for (int k = 0; k < 4; k++) { yu[k] = y8[k * 2]; yv[k] = y8[k * 2 + 1]; for (int d = 0; d < 3; d++) xp[k][d] = x12[k * 3 + d]; }
+    return vk::ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R9, t3) ? 1 : 0;
+}
+VKT_API void vk_host_rodrigues(const float* R9, float* rvec3) {
+    float R[9];
+    for (int i = 0; i < 9; i++) R[i] = R9[i];
+    vk::nearest_rotation(R);
+    vk::rotmat_to_angle_axis(R, rvec3);
+}
+VKT_API void vk_host_rvec_to_rotmat(const float* rvec3, float* R9) { vk::angle_axis_to_rotmat(rvec3, R9); }
+VKT_API unsigned vk_host_rng(unsigned seed, unsigned stream, unsigned counter) { return vk::rng3(seed, stream, counter); }
+VKT_API float vk_host_u01(unsigned r) { return vk::u01(r); }
+
+// ---- (2) elementary probes: out[i] = op(a[i], b[i]) as double (float results widen exactly) ------------------------
+__host__ __device__ static double probe_op(int op, float a, float b) {
+#pragma clang fp contract(off)
+    const double da = (double)a, db = (double)b;
+    switch (op) {
+        case 0: return (double)(a / b);
+        case 1: return (double)sqrtf(fabsf(a));
+        case 2: return da / db;
+        case 3: return ::sqrt(fabs(da));
+        case 4: return (double)(float)(1.0 / ::sqrt(da * da + db * db + 1.0));
+        case 5: return (double)(a * b + a);
+        case 6: return (double)vsm_expf(a);
+        case 7: return (double)vsm_logf(fabsf(a));
+        case 8: return (double)vsm_powf(fabsf(a), b);
+        case 9: return (double)vsm_atan2f(a, b);
+        case 10: return (double)vsm_sinf(a);
+        case 11: return (double)vsm_cosf(a);
+        case 12: return (double)vsm_cbrtf(a);
+        case 13: return (double)floorf(a);
+        case 14: return (double)(float)(int)a;
+        case 15: return (double)(1.0f / a);
+        case 16: return vsm_exp(da);
+        case 17: return vsm_log(fabs(da));
+        case 18: return (double)(float)(da * db);                       // double product rounded to float
+        case 19: return (double)((float)(da) * 0.5);                    // float * double literal
+        case 20: return (double)vk::strict::rigidness(a, b, a * 0.9f + 0.1f, b * 1.1f - 0.05f, 0.15f, 1.f);
+        case 21: return (double)vk::strict::depth_rigidness(fabsf(a) + 0.1f, fabsf(b) + 0.1f, 160.f, 0.15f, 1.f);
+        case 22: return (double)(-1.5f * vsm_logf(vk::strict::rigidness(a, b, a * 0.9f + 0.1f, b * 1.1f - 0.05f, 0.15f, 1.f)));
+        case 23: return (double)(fabsf(a) / (2.f * fabsf(b) + 1e-3f));
+        case 24: return (double)sqrtf(a * a + b * b);
+        default: return 0.0;
+    }
+}
+__global__ static void k_probe(int op, const float* a, const float* b, double* out, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = probe_op(op, a[i], b[i]);
+}
+VKT_API int vkt_probe_ops_count(void) { return 25; }
+VKT_API void vkt_probe_host(int op, const float* a, const float* b, double* out, int n) {
+    for (int i = 0; i < n; i++) out[i] = probe_op(op, a[i], b[i]);
+}
+VKT_API int vkt_probe_device(int op, const float* a, const float* b, double* out, int n) {
+    float *da = nullptr, *db = nullptr; double* dout = nullptr;
+    if (hipMalloc(&da, sizeof(float) * n) != hipSuccess || hipMalloc(&db, sizeof(float) * n) != hipSuccess ||
+        hipMalloc(&dout, sizeof(double) * n) != hipSuccess) return 1;
+    (void)hipMemcpy(da, a, sizeof(float) * n, hipMemcpyHostToDevice);
+    (void)hipMemcpy(db, b, sizeof(float) * n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_probe, dim3((n + 255) / 256), dim3(256), 0, 0, op, da, db, dout, n);
+    const int rc = (int)hipMemcpy(out, dout, sizeof(double) * n, hipMemcpyDeviceToHost);
+    (void)hipFree(da); (void)hipFree(db); (void)hipFree(dout);
+    return rc;
+}
+
+// ---- LambdaTwist: sequential path (`only` = -1, what the host build runs) on the device, one lane per 4-tuple, with the
+// intermediate values of vk_p3p.hpp's debug taps.  y8[n][8], x12[n][12] -> ok[n], R9[n][9], t3[n][3], dbg[n][96]
+constexpr int VKT_DBG = 96;
+template <typename S>
+__host__ __device__ static void p4p_one(const float* y8, const float* x12, float fx, float fy, float cx, float cy, int* ok, float* R9, float* t3,
+                                        double* dbg) {
+    float yu[4], yv[4], xp[4][3];
+    for (int k = 0; k < 4; k++) { yu[k] = y8[k * 2]; yv[k] = y8[k * 2 + 1]; for (int d = 0; d < 3; d++) xp[k][d] = x12[k * 3 + d]; }
+    S d[VKT_DBG];
+    for (int i = 0; i < VKT_DBG; i++) d[i] = S(0);
+    float R[9] = { 0 }, t[3] = { 0 };
+    *ok = vk::lambdatwist_p4p<S>(yu, yv, xp, fx, fy, cx, cy, R, t, -1, (S*)nullptr, d) ? 1 : 0;
+    for (int i = 0; i < 9; i++) R9[i] = R[i];
+    for (int i = 0; i < 3; i++) t3[i] = t[i];
+    for (int i = 0; i < VKT_DBG; i++) dbg[i] = (double)d[i];
+}
+template <typename S>
+__global__ static void k_p4p(const float* y8, const float* x12, float fx, float fy, float cx, float cy, int* ok, float* R9, float* t3, double* dbg,
+                             int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p4p_one<S>(y8 + (size_t)i * 8, x12 + (size_t)i * 12, fx, fy, cx, cy, ok + i, R9 + (size_t)i * 9, t3 + (size_t)i * 3, dbg + (size_t)i * VKT_DBG);
+}
+VKT_API int vkt_p4p_dbg_len(void) { return VKT_DBG; }
+VKT_API void vkt_p4p_host(const float* y8, const float* x12, int n, float fx, float fy, float cx, float cy, int use_double, int* ok, float* R9,
+                          float* t3, double* dbg) {
+    for (int i = 0; i < n; i++) {
+        if (use_double) p4p_one<double>(y8 + (size_t)i * 8, x12 + (size_t)i * 12, fx, fy, cx, cy, ok + i, R9 + (size_t)i * 9, t3 + (size_t)i * 3, dbg + (size_t)i * VKT_DBG);
+        else p4p_one<float>(y8 + (size_t)i * 8, x12 + (size_t)i * 12, fx, fy, cx, cy, ok + i, R9 + (size_t)i * 9, t3 + (size_t)i * 3, dbg + (size_t)i * VKT_DBG);
+    }
+}
+VKT_API int vkt_p4p_device(const float* y8, const float* x12, int n, float fx, float fy, float cx, float cy, int use_double, int* ok, float* R9,
+                           float* t3, double* dbg) {
+    float *dy = nullptr, *dx = nullptr, *dR = nullptr, *dt = nullptr; int* dok = nullptr; double* dd = nullptr;
+    if (hipMalloc(&dy, sizeof(float) * 8 * n) || hipMalloc(&dx, sizeof(float) * 12 * n) || hipMalloc(&dR, sizeof(float) * 9 * n) ||
+        hipMalloc(&dt, sizeof(float) * 3 * n) || hipMalloc(&dok, sizeof(int) * n) || hipMalloc(&dd, sizeof(double) * VKT_DBG * n)) return 1;
+    (void)hipMemcpy(dy, y8, sizeof(float) * 8 * n, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dx, x12, sizeof(float) * 12 * n, hipMemcpyHostToDevice);
+    if (use_double) hipLaunchKernelGGL(k_p4p<double>, dim3((n + 63) / 64), dim3(64), 0, 0, dy, dx, fx, fy, cx, cy, dok, dR, dt, dd, n);
+    else hipLaunchKernelGGL(k_p4p<float>, dim3((n + 63) / 64), dim3(64), 0, 0, dy, dx, fx, fy, cx, cy, dok, dR, dt, dd, n);
+    int rc = (int)hipMemcpy(ok, dok, sizeof(int) * n, hipMemcpyDeviceToHost);
+    rc |= (int)hipMemcpy(R9, dR, sizeof(float) * 9 * n, hipMemcpyDeviceToHost);
+    rc |= (int)hipMemcpy(t3, dt, sizeof(float) * 3 * n, hipMemcpyDeviceToHost);
+    rc |= (int)hipMemcpy(dbg, dd, sizeof(double) * VKT_DBG * n, hipMemcpyDeviceToHost);
+    (void)hipFree(dy); (void)hipFree(dx); (void)hipFree(dR); (void)hipFree(dt); (void)hipFree(dok); (void)hipFree(dd);
+    return rc;
+}
+// rotation matrix -> nearest rotation -> angle axis (strict = software atan2), device vs host
+__global__ static void k_rodrigues(const float* R9, float* rv, int n, int strict) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float R[9];
+    for (int k = 0; k < 9; k++) R[k] = R9[(size_t)i * 9 + k];
+    vk::nearest_rotation(R);
+    vk::rotmat_to_angle_axis(R, rv + (size_t)i * 3, strict != 0);
+}
+VKT_API void vkt_rodrigues_host(const float* R9, float* rv, int n, int strict) {
+    for (int i = 0; i < n; i++) {
+        float R[9];
+        for (int k = 0; k < 9; k++) R[k] = R9[(size_t)i * 9 + k];
+        vk::nearest_rotation(R);
+        vk::rotmat_to_angle_axis(R, rv + (size_t)i * 3, strict != 0);
+    }
+}
+VKT_API int vkt_rodrigues_device(const float* R9, float* rv, int n, int strict) {
+    float *dR = nullptr, *dv = nullptr;
+    if (hipMalloc(&dR, sizeof(float) * 9 * n) || hipMalloc(&dv, sizeof(float) * 3 * n)) return 1;
+    (void)hipMemcpy(dR, R9, sizeof(float) * 9 * n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_rodrigues, dim3((n + 63) / 64), dim3(64), 0, 0, dR, dv, n, strict);
+    const int rc = (int)hipMemcpy(rv, dv, sizeof(float) * 3 * n, hipMemcpyDeviceToHost);
+    (void)hipFree(dR); (void)hipFree(dv);
+    return rc;
+}
+// strict residual model on the host (vs the oracle in strict mode, CPU tier)
+VKT_API float vkt_strict_rigidness(float dx1, float dy1, float dx2, float dy2, float lambda, float abs_rf) {
+    return vk::strict::rigidness(dx1, dy1, dx2, dy2, lambda, abs_rf);
+}
+VKT_API float vkt_strict_depth_rigidness(float d1, float d2, float basefocal, float omega, float abs_rf) {
+    return vk::strict::depth_rigidness(d1, d2, basefocal, omega, abs_rf);
+}
+VKT_API void vkt_strict_rvec_to_rotmat(const float* rv, float* R9) { vk::angle_axis_to_rotmat(rv, R9, true); }

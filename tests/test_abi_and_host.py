@@ -78,8 +78,8 @@ def _host_p4p(lib, y, x, fx, fy, cx, cy, dbl):
 @pytest.mark.parametrize("dbl", [0, 1])
 def test_device_solver_source_matches_reference_golden(dbl):
     """vk_p3p.hpp compiled for the host reproduces the REFERENCE's own lambdatwist bit for bit."""
-    from voldor_amd import capi
-    lib = capi.lib()
+    import hooks
+    lib = hooks.lib()
     g = np.load(os.path.join(G, "ref_lambdatwist.npz"))
     fx, fy, cx, cy = map(float, g["K"])
     sfx = "d" if dbl else "f"
@@ -92,8 +92,9 @@ def test_device_solver_source_matches_reference_golden(dbl):
 
 
 def test_host_ap3p_rodrigues_rng_match_oracle(orc):
+    import hooks
     from voldor_amd import capi, synth
-    lib = capi.lib()
+    lib = hooks.lib()
     lib.vk_host_u01.restype = C.c_float
     lib.vk_host_rng.restype = C.c_uint
     L = orc.lib()

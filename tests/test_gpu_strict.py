@@ -1,0 +1,185 @@
+"""Strict-math mode: the HIP path reproduces the CPU oracle BIT FOR BIT -- stages and whole windows, up to BASELINE cfg2.
+
+Chain of evidence: the oracle reproduces the reference's own code bit for bit (tests/test_oracle_vs_ref_*.py);
+strict mode swaps the transcendental library calls for voldor_amd/csrc/vk_strict_math.h on both sides (oracle: orc_set_strict_math,
+product: --strict_math 1) and runs every HIP stage in the reference's operation order (vk_strict.hip); `--reference_draw 1` /
+ORC_REFERENCE_DRAW=1 select the reference's index draw (geometry.cpp:68-88 + solve_batch_lambdatwist.cu:16-19) on both sides.
+What is asserted here is EQUALITY OF BITS, not a tolerance."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import K9
+import test_gpu_kernels as tk
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_bits(a, b):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    return (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+
+
+def assert_bits(a, b, what):
+    eq = _same_bits(a, b)
+    assert eq.all(), f"{what}: {(~eq).sum()} of {eq.size} values differ"
+
+
+@pytest.fixture()
+def strict(orc):
+    from voldor_amd import kernels
+    L = orc.lib()
+    L.orc_set_strict_math(1); kernels.set_strict_math(True)
+    old = os.environ.get("ORC_REFERENCE_DRAW")
+    os.environ["ORC_REFERENCE_DRAW"] = "1"
+    yield
+    L.orc_set_strict_math(0); kernels.set_strict_math(False)
+    if old is None:
+        os.environ.pop("ORC_REFERENCE_DRAW", None)
+    else:
+        os.environ["ORC_REFERENCE_DRAW"] = old
+
+
+def test_device_arithmetic_gives_the_host_bits():
+    """IEEE + - * / sqrt, conversions and every vk_strict_math.h function: gfx950 == host, on 2^18 inputs each."""
+    import hooks
+    rng = np.random.default_rng(1)
+    n = 1 << 18
+    a = (rng.choice([-1, 1], n) * np.exp(rng.uniform(-12, 12, n))).astype(np.float32)
+    b = (rng.choice([-1, 1], n) * np.exp(rng.uniform(-6, 6, n))).astype(np.float32)
+    a2 = rng.normal(0, 3, n).astype(np.float32); b2 = rng.normal(0, 3, n).astype(np.float32)
+    for op in range(hooks.lib().vkt_probe_ops_count()):
+        for x, y in ((a, b), (a2, b2)):
+            if op == 14:
+                x = np.clip(x, -1e9, 1e9)
+            h = hooks.probe(op, x, y, False); d = hooks.probe(op, x, y, True)
+            neq = (h.view(np.uint64) != d.view(np.uint64)) & ~(np.isnan(h) & np.isnan(d))
+            assert not neq.any(), (op, int(neq.sum()))
+
+
+def test_strict_fb_smooth_bits(orc, strict):
+    from voldor_amd import kernels
+    rng = np.random.default_rng(3)
+    for (n, h, w) in ((3, 120, 160), (1, 37, 101), (2, 240, 41)):
+        m = rng.uniform(0.02, 0.98, (n, h, w)).astype(np.float32)
+        rc, g = kernels.fb_smooth_gpu(m.copy())
+        assert rc == 0
+        assert_bits(orc.fb_smooth(m.copy()), g, f"fb_smooth {n}x{h}x{w}")
+
+
+@pytest.mark.parametrize("case", ["rigidness_only", "cost_rand", "global", "local", "full", "full_no_smooth_step4_width7"])
+def test_strict_optimize_depth_bits(orc, small_scene, strict, case):
+    over = {"rigidness_only": dict(update_rigidness_only=1), "cost_rand": dict(global_prop_step=0, local_prop_width=0, fb_smooth=0),
+            "global": dict(n_rand_samples=0, local_prop_width=0, fb_smooth=0), "local": dict(n_rand_samples=0, global_prop_step=0, fb_smooth=0),
+            "full": dict(), "full_no_smooth_step4_width7": dict(fb_smooth=0, global_prop_step=4, local_prop_width=7, n_rand_samples=3)}[case]
+    rng = np.random.default_rng(0)
+    K = K9(*small_scene["K"])
+    flows, Rs, ts, depth, rig = tk._state(small_scene, rng)
+    (od, orig, _), (gd, grig, _) = tk._run_both(orc, small_scene, K, flows, Rs, ts, depth, rig, **over)
+    assert_bits(od, gd, "depth"); assert_bits(orig, grig, "rigidness")
+
+
+def test_strict_optimize_depth_with_priors_and_ragged_size_bits(orc, strict):
+    from voldor_amd import synth
+    sc = synth.make_scene(w=157, h=93, n_flows=6, fx=80, fy=75, cx=77, cy=45, seed=21)
+    rng = np.random.default_rng(5)
+    K = K9(*sc["K"])
+    flows, Rs, ts, depth, rig = tk._state(sc, rng)
+    N, h, w, _ = flows.shape
+    pri = (sc["depth_gt"][None] * (1 + rng.normal(0, 0.05, (2, h, w)))).astype(np.float32)
+    pri[1, :5] = 0.0  # invalid prior pixels: confidence left untouched (optimize_depth.cu:129)
+    pc = rng.uniform(0.5, 1, (2, h, w)).astype(np.float32); cf = rng.uniform(0.5, 1, (2, h, w)).astype(np.float32)
+    dpR = np.stack([np.eye(3), synth.rodrigues([0.01, -0.02, 0.005])]).astype(np.float32)
+    dpt = np.array([[0, 0, 0], [0.05, 0.01, -0.1]], np.float32)
+    (od, orig, oc), (gd, grig, gc) = tk._run_both(orc, sc, K, flows, Rs, ts, depth, rig, priors=pri, pconfs=pc, confs=cf, dp_Rs=dpR, dp_ts=dpt,
+                                                   basefocal=40.0, disp_delta=1.0)
+    assert_bits(od, gd, "depth"); assert_bits(orig, grig, "rigidness"); assert_bits(oc, gc, "prior confidences")
+
+
+@pytest.mark.parametrize("solver", ["lambdatwist", "ap3p", "lambdatwist_f64"])
+def test_strict_pose_hypotheses_bits(orc, small_scene, strict, solver):
+    """index draw + minimal solver + 4th-point selection + nearest rotation + angle-axis: rotation vectors AND translations"""
+    from voldor_amd import kernels
+    pts2, pts3, K = tk._corr(orc, small_scene)
+    kw, fn = {"lambdatwist": ({}, kernels.solve_batch_p3p_lambdatwist_gpu), "ap3p": (dict(use_ap3p=True), kernels.solve_batch_p3p_ap3p_gpu),
+              "lambdatwist_f64": (dict(use_double=True), kernels.solve_batch_p3p_lambdatwist_f64_gpu)}[solver]
+    orv, otv = orc.solve_batch_p3p(pts3, pts2, K, 8192, **kw)
+    grv, gtv = fn(pts3, pts2, K, 8192)
+    assert np.isfinite(otv.sum(1)).mean() > 0.5
+    assert_bits(orv, grv, "rvecs"); assert_bits(otv, gtv, "tvecs")
+
+
+def _window_both(orc, sc, cfg, **extra):
+    from voldor_amd import kernels, pyvoldor
+    fx, fy, cx, cy = sc["K"]
+    o = orc.voldor(sc["flows"], fx, fy, cx, cy, config=cfg, **extra)
+    kernels.set_rand_epoch(0)
+    g = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config=cfg + " --strict_math 1 --reference_draw 1", **extra)
+    return o, g
+
+
+def _assert_window_bits(o, g):
+    assert o["n_registered"] == g["n_registered"]
+    n = o["n_registered"]
+    assert_bits(o["poses"][:n], g["poses"][:n], "poses")
+    assert_bits(o["poses_covar"][:n], g["poses_covar"][:n], "pose covariances")
+    assert_bits(o["depth"], g["depth"], "depth")
+    assert_bits(o["depth_conf"], g["depth_conf"], "depth confidence")
+
+
+WINDOWS = {
+    "mono_1iter_norefit": (dict(seed=11), "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 1 --rg_refine 0"),
+    "mono_3iters_refit": (dict(seed=11), "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 3"),
+    "mono_ap3p": (dict(seed=13), "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 2 --lambdatwist 0"),
+    "mono_cpu_p3p_f64": (dict(seed=14), "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 2 --cpu_p3p 1"),
+    "mono_refit_every_iteration": (dict(seed=15), "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 3 --rg_refine_last_only 0"),
+    "stereo": (dict(seed=12, basefocal=80.0), "--silent --meanshift_kernel_var 0.1 --disp_delta 1 --delta 0.2 --max_iters 3"),
+}
+
+
+@pytest.mark.parametrize("name", sorted(WINDOWS))
+def test_strict_window_bits(orc, strict, name):
+    from voldor_amd import synth
+    kw, cfg = WINDOWS[name]
+    sc = synth.make_scene(w=320, h=240, n_flows=4, fx=160, fy=160, cx=160, cy=120, **kw)
+    extra = dict(basefocal=kw["basefocal"], disparity=sc["disparity"]) if "basefocal" in kw else {}
+    o, g = _window_both(orc, sc, cfg, **extra)
+    assert o["n_registered"] == 4
+    _assert_window_bits(o, g)
+
+
+def test_strict_window_with_depth_priors_bits(orc, strict):
+    """the SLAM driver's call shape (voldor_slam.py:447-457): depth priors with poses and confidences from earlier windows"""
+    from voldor_amd import synth
+    sc = synth.make_scene(w=320, h=240, n_flows=4, fx=160, fy=160, cx=160, cy=120, seed=16)
+    rng = np.random.default_rng(2)
+    h, w = sc["depth_gt"].shape
+    pri = (sc["depth_gt"][None] * (1 + rng.normal(0, 0.03, (2, h, w)))).astype(np.float32)
+    poses = np.array([[0.002, -0.001, 0.0005, 0.01, 0.0, -0.02], [0, 0, 0, 0, 0, 0]], np.float32)
+    pconf = rng.uniform(0.3, 1.0, (2, h, w)).astype(np.float32)
+    o, g = _window_both(orc, sc, "--silent --meanshift_kernel_var 0.1 --delta 0.5 --max_iters 3", depth_priors=pri, depth_prior_poses=poses,
+                        depth_prior_pconfs=pconf)
+    _assert_window_bits(o, g)
+
+
+def test_strict_window_truncation_bits(orc, strict):
+    """a window that loses its last frames (voldor.cpp:187-194): same truncation point, same outputs"""
+    from voldor_amd import synth
+    sc = synth.make_scene(w=320, h=240, n_flows=5, fx=160, fy=160, cx=160, cy=120, seed=17)
+    fl = sc["flows"].copy()
+    rng = np.random.default_rng(4)
+    fl[3:] = rng.uniform(-25, 25, fl[3:].shape).astype(np.float32)  # frames 3.. carry no rigid motion at all
+    sc = dict(sc, flows=fl)
+    o, g = _window_both(orc, sc, "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 5")
+    assert o["n_registered"] < 5
+    _assert_window_bits(o, g)
+
+
+def test_strict_baseline_cfg2_window_bits(orc, strict):
+    """BASELINE cfg2 (640x480, N=5, 8 EM iterations, refit on): every output of the window, bit for bit"""
+    from voldor_amd import synth
+    sc = synth.make_scene(w=640, h=480, n_flows=5, fx=320, fy=320, cx=320, cy=240, seed=233)
+    o, g = _window_both(orc, sc, "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 8")
+    assert o["n_registered"] == 5
+    _assert_window_bits(o, g)

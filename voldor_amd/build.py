@@ -16,13 +16,17 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvoldor_hip.so")
-SOURCES = ["vk_abi.hip", "vk_depth.hip", "vk_pose.hip", "vk_bootstrap.hip", "vk_voldor.hip", "vk_hostcheck.hip", "vk_slam.hip", "vk_align.hip"]
+SOURCES = ["vk_abi.hip", "vk_depth.hip", "vk_pose.hip", "vk_strict.hip", "vk_bootstrap.hip", "vk_voldor.hip", "vk_slam.hip", "vk_align.hip"]
+# test-only library (host builds of the per-lane math + device-vs-host probes): tests/cxx/vk_testhooks.hip.  Built here because
+# it compiles the product headers with the product flags; nothing in the product loads it.
+TEST_LIB = os.path.join(LIBDIR, "libvoldor_hip_test.so")
+TEST_SRC = os.path.join(os.path.dirname(HERE), "tests", "cxx", "vk_testhooks.hip")
 # The pose half (one hypothesis per lane) must reproduce the reference's fp32/fp64 rounding
 # sequence to stay inside the pose tolerance (vk_p3p.hpp NUMERICS NOTE): no fma contraction there.
 # It is a few hundred microseconds of work per window, so this costs nothing measurable; the
 # per-pixel kernels of vk_depth.hip keep contraction (geometry there opts out via pragmas).
 PER_FILE_FLAGS = {"vk_pose.hip": ["-ffp-contract=off"], "vk_bootstrap.hip": ["-ffp-contract=off"],
-                  "vk_hostcheck.hip": ["-ffp-contract=off"]}
+                  "vk_strict.hip": ["-ffp-contract=off"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-Wall", "-Wno-unused-function",
          "-Wno-unused-result",
          # the SLP vectorizer packs scalar fp32 math into v_pk_* pairs and pays for it with ~30 % extra
@@ -42,7 +46,7 @@ def _deps():
     out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     inc = os.path.join(os.path.dirname(HERE), "include")
     out += [os.path.join(inc, f) for f in os.listdir(inc)]
-    return out
+    return out + [TEST_SRC]
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -50,7 +54,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     newest = max(os.path.getmtime(p) for p in _deps())
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest and os.path.exists(TEST_LIB) and os.path.getmtime(TEST_LIB) >= newest:
         return LIB
     hipcc = _hipcc()
 
@@ -64,8 +68,19 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.check_call(cmd)
         return obj
 
-    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+    def build_test_lib(_):
+        if not force and os.path.exists(TEST_LIB) and os.path.getmtime(TEST_LIB) >= newest:
+            return TEST_LIB
+        cmd = [hipcc] + FLAGS + ["-ffp-contract=off", "-shared", "-o", TEST_LIB, TEST_SRC]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        return TEST_LIB
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES) + 1) as ex:
+        test_future = ex.submit(build_test_lib, None)
         objs = list(ex.map(compile_one, SOURCES))
+        test_future.result()
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
     if verbose:
         print(" ".join(cmd))

@@ -8,8 +8,10 @@
 #include "../../include/gpu_kernels.h"
 #include "../../include/voldor_hip.h"
 #include <mutex>
+#include <cstdlib>
 
 namespace vk {
+void set_strict_math_default(int on);
 
 int Context::init(int dev) {
     device = dev;
@@ -27,7 +29,7 @@ void Context::destroy() {
     DevBuf* bufs[] = { &od.flows, &od.rig, &od.depth, &od.cost, &od.priors, &od.pconfs, &od.confs, &od.pose,
                        &cp.flows, &cp.rig, &cp.depth, &cp.cost, &cp.priors, &cp.pconfs, &cp.confs, &cp.pose,
                        &rig_partial, &local_tbl, &p2_map, &p3_map, &blk_counts, &blk_offsets, &pts2, &pts3, &n_points,
-                       &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp };
+                       &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp, &fb_scratch };
     for (DevBuf* b : bufs) b->release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -87,6 +89,15 @@ int pool_set_rand_epoch(unsigned epoch) {
     batch_rand_epoch(dev, &e);
     return 0;
 }
+
+// strict-math mode of entry points that carry no config string (B-inner) and the default of the window call
+static int g_strict_math = -1;  // -1: not set -> environment VOLDOR_HIP_STRICT_MATH
+bool strict_math_default() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_strict_math < 0) { const char* e = getenv("VOLDOR_HIP_STRICT_MATH"); g_strict_math = (e && e[0] == '1') ? 1 : 0; }
+    return g_strict_math != 0;
+}
+void set_strict_math_default(int on) { std::lock_guard<std::mutex> lk(g_mu); g_strict_math = on ? 1 : 0; }
 
 int prof_begin(Context* c) { return (int)hipEventRecord(c->ev0, c->stream); }
 int prof_end(Context* c, const char* name) {
@@ -186,6 +197,12 @@ int optimize_depth_gpu(float* h_flows[], float* h_rigidnesses[], float* h_o_rigi
     p.lambda = lambda; p.omega = omega; p.disp_delta = disp_delta; p.delta = delta; p.fb_smooth = fb_smooth;
     p.s0_ems_prob = s0_ems_prob; p.no_change_prob = no_change_prob; p.range_factor = range_factor;
     p.update_rigidness_only = update_rigidness_only;
+    p.strict = strict_math_default();
+    // the frame count comes by argument here: undo whatever a window call (py_voldor_wrapper: device-side truncation,
+    // PoseBlock::n_active) left in the shared pose block
+    const int all_frames = MAX_FRAMES;
+    VK_CHECK(hipMemcpyAsync(&S.pb()->n_active, &all_frames, sizeof(int), hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
     if (int e = optimize_depth_device(c, S, p)) return e;
     if (h_o_depth) VK_CHECK(hipMemcpyAsync(h_o_depth, S.depth.p, sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));
     if (h_o_rigidnesses && N > 0) { if (int e = download_layers(c, S.rig, h_o_rigidnesses, N, npx)) return e; }
@@ -236,7 +253,7 @@ static int solve_batch_host(float* h_p3s, float* h_p2s, float* h_o_rvecs, float*
     VK_CHECK(hipMemcpyAsync(c->n_points.p, &N_pts, sizeof(int), hipMemcpyHostToDevice, c->stream));
     VK_CHECK(hipStreamSynchronize(c->stream));
     if (int e = solve_device(c, c->pts2.as<float>(), c->pts3.as<float>(), c->n_points.as<int>(), h_K[0], h_K[4], h_K[2], h_K[5],
-                             N_poses, solver))
+                             N_poses, solver, strict_math_default()))
         return e;
     VK_CHECK(hipMemcpyAsync(h_o_rvecs, c->rvecs.p, sizeof(float) * 3 * (size_t)N_poses, hipMemcpyDeviceToHost, c->stream));
     VK_CHECK(hipMemcpyAsync(h_o_tvecs, c->tvecs.p, sizeof(float) * 3 * (size_t)N_poses, hipMemcpyDeviceToHost, c->stream));
@@ -388,7 +405,8 @@ int vk_fb_smooth(float* h_maps, int n_maps, int w, int h, float s0_ems_prob, flo
     const size_t bytes = sizeof(float) * (size_t)n_maps * w * h;
     if (int e = c->tmp.reserve(bytes)) return e;
     VK_CHECK(hipMemcpyAsync(c->tmp.p, h_maps, bytes, hipMemcpyHostToDevice, c->stream));
-    if (int e = fb_smooth_device(c, c->tmp.as<float>(), n_maps, w, h, s0_ems_prob, no_change_prob)) return e;
+    if (strict_math_default()) { if (int e = fb_smooth_strict_device(c, c->tmp.as<float>(), n_maps, w, h, s0_ems_prob, no_change_prob)) return e; }
+    else if (int e = fb_smooth_device(c, c->tmp.as<float>(), n_maps, w, h, s0_ems_prob, no_change_prob)) return e;
     VK_CHECK(hipMemcpyAsync(h_maps, c->tmp.p, bytes, hipMemcpyDeviceToHost, c->stream));
     VK_CHECK(hipStreamSynchronize(c->stream));
     return 0;
@@ -445,6 +463,8 @@ int vk_set_rand_epoch(unsigned epoch) {
     c->rand_w = c->rand_h = -1;  // explicit seed: the next call adopts its size without resetting
     return pool_set_rand_epoch(epoch);  // and the contexts of vk_voldor_device_batch
 }
+int vk_set_strict_math(int on) { set_strict_math_default(on); return 0; }
+int vk_get_strict_math(void) { return strict_math_default() ? 1 : 0; }
 int vk_set_frame_major_threshold(size_t flow_bytes, size_t depth_order_bytes) { set_frame_major_threshold(flow_bytes, depth_order_bytes); return 0; }
 unsigned vk_get_rand_epoch(void) {
     Context* c = default_context();

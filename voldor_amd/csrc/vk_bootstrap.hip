@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) static void k_boot_score(const float* __restri
 
 // argmin over hypotheses, decomposition, cheirality vote, pose write-back (single workgroup)
 __global__ __launch_bounds__(256) static void k_boot_select(const float* __restrict__ p2, BootGeom g, const double* __restrict__ Es,
-                                                             const double* __restrict__ med, PoseBlock* P, CamState* cam0, float* __restrict__ Mb) {
+                                                             const double* __restrict__ med, PoseBlock* P, CamState* cam0, float* __restrict__ Mb, int strict) {
     __shared__ double sRc[2][9], stc[3];
     __shared__ int s_cnt[4][4];
     const int tid = threadIdx.x;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(256) static void k_boot_select(const float* __restr
         }
         float R[9], t[3], rv[3];
         boot_finish(sRc[best >> 1], stc, (best & 1) ? -1.0 : 1.0, R, t);
-        rotmat_to_angle_axis(R, rv);
+        rotmat_to_angle_axis(R, rv, strict != 0);
         for (int k = 0; k < 9; k++) P->Rs[0][k] = R[k];
         for (int k = 0; k < 3; k++) { P->ts[0][k] = t[k]; cam0->rvec[k] = rv[k]; cam0->t[k] = t[k]; }
         const float K9[9] = { (float)g.fx, 0, (float)g.cx, 0, (float)g.fy, (float)g.cy, 0, 0, 1 };
@@ -392,7 +392,7 @@ __global__ __launch_bounds__(256) static void k_depth_closed_form(const float2* 
     depth[y * w + x] = fminf(fmaxf(zn / zd, min_depth), max_depth);
 }
 
-int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, float cx, float cy, CamState* cam0_dev) {
+int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, float cx, float cy, CamState* cam0_dev, bool strict) {
     const BootGeom g = boot_geom(w, h, fx, fy, cx, cy);
     const size_t bytes = sizeof(double) * (BOOT_HYPS * 10 + 4) + sizeof(float) * (2 * (size_t)g.n + 16) + 64;
     if (int e = c->tmp.reserve(bytes)) return e;
@@ -405,7 +405,7 @@ int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, 
         hipLaunchKernelGGL(k_extract_corr, dim3((g.n + 255) / 256), dim3(256), 0, c->stream, S.flows.as<float2>(), d_p2, w, h, g.step, g.nx, g.n);
         hipLaunchKernelGGL(k_boot_hyp, dim3(BOOT_HYPS / 64), dim3(64), 0, c->stream, d_p2, g, d_E);
         hipLaunchKernelGGL(k_boot_score, dim3(BOOT_HYPS), dim3(256), 0, c->stream, d_p2, g, d_E, d_med);
-        hipLaunchKernelGGL(k_boot_select, dim3(1), dim3(256), 0, c->stream, d_p2, g, d_E, d_med, S.pb(), cam0_dev, d_Mb);
+        hipLaunchKernelGGL(k_boot_select, dim3(1), dim3(256), 0, c->stream, d_p2, g, d_E, d_med, S.pb(), cam0_dev, d_Mb, strict ? 1 : 0);
     } else {  // too few correspondences: identity pose (the host path returns failure and keeps R=I, t=0)
         const float K9[9] = { fx, 0, cx, 0, fy, cy, 0, 0, 1 }, R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, t[3] = { 0, 0, 0 };
         float Mb[12];

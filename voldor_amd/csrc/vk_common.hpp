@@ -125,6 +125,7 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
     bool fb_smooth = true;
     float s0_ems_prob = 0.5f, no_change_prob = 0.9f, range_factor = 1.f;
     bool update_rigidness_only = false;
+    bool strict = false;  // strict-math mode: reference-order arithmetic on vk_strict_math.h (vk_strict.hip)
     float* world_scale_out = nullptr;  // device float: also run normalize_world_scale's pose half (voldor.cpp:309-317) in the last launch
 };
 
@@ -148,6 +149,8 @@ struct Context {
     DevBuf ms_io;                 // small float/int scratch for B-inner meanshift / robust fit
     DevBuf cams;                  // CamState[MAX_FRAMES]
     DevBuf tmp;                   // misc scratch (gblur, depth_conf ...)
+    DevBuf fb_scratch;            // strict fb_smooth: forward messages [n_maps][h][w]
+    bool strict = false;          // strict-math mode of the B-inner entry points that use this context (vk_set_strict_math)
     uint32_t rand_epoch = 0;      // persistent depth-sampling RNG counter (optimize_depth.cu:358-361)
     int rand_w = 0, rand_h = 0;
     // profiling (off by default): HIP events on ctx.stream around kernel groups

@@ -15,6 +15,8 @@
 // remaps its workgroup id so that an XCD works on one band of the image (xcd_band_tile).
 #include "vk_common.hpp"
 #include "vk_device.hpp"
+#include "vk_strict_model.hpp"
+#include "vk_internal.hpp"
 
 namespace vk {
 
@@ -28,7 +30,7 @@ struct Img {
     float* __restrict__ cost;
     const PoseBlock* __restrict__ P;
     int N, N_dp, w, h;
-    float lambda, omega, inv_arf, basefocal, disp_delta, delta;
+    float lambda, omega, inv_arf, arf, basefocal, disp_delta, delta;
 };
 // Frames still registered: the launch-time count clamped by the device-side decision of this EM iteration
 // (PoseBlock::n_active).  Returns false when nothing is left to evaluate (window lost, no priors).
@@ -39,6 +41,7 @@ __device__ __forceinline__ bool clamp_active(Img& I) {
 
 // depth-prior term of compute_pixel_cost (optimize_depth.cu:166-190): the hypothesis seen from prior f's camera against the
 // prior map, weighted by the prior's confidences (all three sampled bilinearly at the projected position)
+template <bool STRICT = false>
 __device__ __forceinline__ static void prior_term(const Img& I, const PoseBlock* P, int f, int px, int py, float depth, float& cost_sum, float& wsum) {
     const int w = I.w, h = I.h, npx = w * h;
     P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
@@ -50,7 +53,8 @@ __device__ __forceinline__ static void prior_term(const Img& I, const PoseBlock*
             float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
             float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
             float wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
-            cost_sum = __fadd_rn(cost_sum, __fmul_rn(wg, 0.6931471805599453f * fast_log2(1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf))));
+            if (STRICT) cost_sum = strict::cost_acc(cost_sum, wg, strict::depth_rigidness(q.z, td, I.basefocal, I.omega, I.arf));  // fun_depth_cost, residual_model.h:64-68
+            else cost_sum = __fadd_rn(cost_sum, __fmul_rn(wg, 0.6931471805599453f * fast_log2(1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf))));
             wsum += wg;
         }
     }
@@ -61,7 +65,9 @@ __device__ __forceinline__ static void prior_term(const Img& I, const PoseBlock*
 // of one L2 round trip per frame (the sampling positions depend on depth and poses only, not on
 // the flow values): (1) rigid chain -> positions + validity mask, (2) issue every gather,
 // (3) residual model.  NMAX is the compile-time frame bound (arrays stay in registers).
-template <int NMAX>
+// STRICT: the residual model in the reference's operation order on the software transcendentals (vk_strict_model.hpp); the
+// geometry, the gathers and the summation order are the same in both modes.
+template <int NMAX, bool STRICT = false>
 __device__ __forceinline__ static float pixel_cost(const Img& I, int px, int py, float depth) {
     const int w = I.w, h = I.h, npx = w * h, pi = py * w + px;
     const PoseBlock* P = I.P;
@@ -102,17 +108,18 @@ __device__ __forceinline__ static float pixel_cost(const Img& I, int px, int py,
     for (int f = 0; f < NMAX; f++) {
         if (f < I.N && ((valid >> f) & 1u)) {
             // product rounded before the add (no fma): same value as the lane-split evaluation cost_split8
-            cost_sum = __fadd_rn(cost_sum, __fmul_rn(wgt[f], neglog_rigidness_from_flows(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.inv_arf)));
+            if (STRICT) cost_sum = strict::cost_acc(cost_sum, wgt[f], strict::rigidness(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.arf));  // fun_cost :45-49
+            else cost_sum = __fadd_rn(cost_sum, __fmul_rn(wgt[f], neglog_rigidness_from_flows(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.inv_arf)));
             wsum += wgt[f];
         }
     }
-    for (int f = 0; f < I.N_dp; f++) prior_term(I, P, f, px, py, depth, cost_sum, wsum);
+    for (int f = 0; f < I.N_dp; f++) prior_term<STRICT>(I, P, f, px, py, depth, cost_sum, wsum);
     if (wsum == 0.f) return INFINITY;
     return cost_sum / fmaxf(wsum, 1.1920929e-07f);
 }
 
 // ---- cost map + all random samples, fused (optimize_depth.cu:279-284 + :269-277 x n_rand) ----
-template <int NMAX>
+template <int NMAX, bool STRICT = false>
 __global__ __launch_bounds__(256) static void k_cost_rand(Img I, int n_rand, uint32_t epoch0, float range_factor) {
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
@@ -121,11 +128,11 @@ __global__ __launch_bounds__(256) static void k_cost_rand(Img I, int n_rand, uin
     if (x >= I.w || y >= I.h) return;
     const int pi = y * I.w + x;
     float d = I.depth[pi];
-    float c = pixel_cost<NMAX>(I, x, y, d);
+    float c = pixel_cost<NMAX, STRICT>(I, x, y, d);
     for (int it = 0; it < n_rand; it++) {
         float u = u01(rng3(RAND_SEED, (uint32_t)pi, epoch0 + (uint32_t)it));
         float dn = 1.0f / (range_factor * u + (1.0f / 1e5f));  // MAXIMUM_DEPTH, :15,:273
-        float cn = pixel_cost<NMAX>(I, x, y, dn);
+        float cn = pixel_cost<NMAX, STRICT>(I, x, y, dn);
         if (cn < c) { c = cn; d = dn; }
     }
     I.depth[pi] = d;
@@ -261,41 +268,41 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) static
 }
 
 // replace_if_better_depth, optimize_depth.cu:201-207
-template <int NMAX>
+template <int NMAX, bool STRICT = false>
 __device__ __forceinline__ static void try_depth(const Img& I, int x, int y, float cand) {
     const int pi = y * I.w + x;
-    float c = pixel_cost<NMAX>(I, x, y, cand);
+    float c = pixel_cost<NMAX, STRICT>(I, x, y, cand);
     if (c < I.cost[pi]) { I.depth[pi] = cand; I.cost[pi] = c; }
 }
 
 // ---- global propagation (optimize_depth.cu:209-235). With step>=2 the sites of one pass are
 // independent (reads x-1, writes x): one thread per site.  dir: 0 L2R,
 // 1 T2B, 2 R2L, 3 B2T.
-template <int NMAX>
+template <int NMAX, bool STRICT = false>
 __global__ __launch_bounds__(256) static void k_global_prop_sites(Img I, int dir, int step, int nsites) {
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int s = (tile % gridDim.x) * blockDim.x + threadIdx.x;  // site index along the pass direction
     const int l = tile / gridDim.x;                               // line (row for 0/2, column for 1/3)
     if (s >= nsites) return;
-    if (dir == 0) { int x = 1 + s * step; try_depth<NMAX>(I, x, l, I.depth[l * I.w + x - 1]); }
-    else if (dir == 2) { int x = I.w - 2 - s * step; try_depth<NMAX>(I, x, l, I.depth[l * I.w + x + 1]); }
-    else if (dir == 1) { int y = 1 + s * step; try_depth<NMAX>(I, l, y, I.depth[(y - 1) * I.w + l]); }
-    else { int y = I.h - 2 - s * step; try_depth<NMAX>(I, l, y, I.depth[(y + 1) * I.w + l]); }
+    if (dir == 0) { int x = 1 + s * step; try_depth<NMAX, STRICT>(I, x, l, I.depth[l * I.w + x - 1]); }
+    else if (dir == 2) { int x = I.w - 2 - s * step; try_depth<NMAX, STRICT>(I, x, l, I.depth[l * I.w + x + 1]); }
+    else if (dir == 1) { int y = 1 + s * step; try_depth<NMAX, STRICT>(I, l, y, I.depth[(y - 1) * I.w + l]); }
+    else { int y = I.h - 2 - s * step; try_depth<NMAX, STRICT>(I, l, y, I.depth[(y + 1) * I.w + l]); }
 }
 // step==1: a true serial chain per line (not used by any shipped config; kept for parity)
-template <int NMAX>
+template <int NMAX, bool STRICT = false>
 __global__ static void k_global_prop_serial(Img I, int dir) {
     if (!clamp_active(I)) return;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     if (dir == 0 || dir == 2) {
         if (l >= I.h) return;
-        if (dir == 0) for (int x = 1; x < I.w; x++) try_depth<NMAX>(I, x, l, I.depth[l * I.w + x - 1]);
-        else for (int x = I.w - 2; x >= 0; x--) try_depth<NMAX>(I, x, l, I.depth[l * I.w + x + 1]);
+        if (dir == 0) for (int x = 1; x < I.w; x++) try_depth<NMAX, STRICT>(I, x, l, I.depth[l * I.w + x - 1]);
+        else for (int x = I.w - 2; x >= 0; x--) try_depth<NMAX, STRICT>(I, x, l, I.depth[l * I.w + x + 1]);
     } else {
         if (l >= I.w) return;
-        if (dir == 1) for (int y = 1; y < I.h; y++) try_depth<NMAX>(I, l, y, I.depth[(y - 1) * I.w + l]);
-        else for (int y = I.h - 2; y >= 0; y--) try_depth<NMAX>(I, l, y, I.depth[(y + 1) * I.w + l]);
+        if (dir == 1) for (int y = 1; y < I.h; y++) try_depth<NMAX, STRICT>(I, l, y, I.depth[(y - 1) * I.w + l]);
+        else for (int y = I.h - 2; y >= 0; y--) try_depth<NMAX, STRICT>(I, l, y, I.depth[(y + 1) * I.w + l]);
     }
 }
 
@@ -390,7 +397,7 @@ __device__ __forceinline__ ChainGeom chain_geom(int w, int h, int dir, int width
 }
 
 // Fallback for segments longer than one wave can hold (width > 65): one thread walks one chain.
-template <int NMAX>
+template <int NMAX, bool STRICT = false>
 __global__ __launch_bounds__(64) static void k_local_serial(Img I, int dir, int width) {
     if (!clamp_active(I)) return;
     const int line = blockIdx.x * 64 + threadIdx.x;
@@ -399,7 +406,7 @@ __global__ __launch_bounds__(64) static void k_local_serial(Img I, int dir, int 
     float cand = cg.n > 0 ? I.depth[cg.prev0] : 0.f;
     for (int k = 0; k < cg.n; k++) {
         const int pi = cg.pi0 + k * cg.stride;
-        const float c = pixel_cost<NMAX>(I, pi % I.w, pi / I.w, cand);
+        const float c = pixel_cost<NMAX, STRICT>(I, pi % I.w, pi / I.w, cand);
         if (c < I.cost[pi]) { I.depth[pi] = cand; I.cost[pi] = c; }
         else cand = I.depth[pi];
     }
@@ -476,7 +483,7 @@ __global__ __launch_bounds__(64) static void k_local_runs(Img I, int dir, int wi
 
 // ---- E-step (optimize_depth.cu:84-138) + per-block sums of each rigidness map (the density
 // test of voldor.cpp:171 then needs no D2H of the maps).  Same three-phase structure as pixel_cost.
-template <int NMAX>
+template <int NMAX, bool STRICT = false>
 __global__ __launch_bounds__(256) static void k_update_rigidness(Img I, float* __restrict__ partial) {
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
@@ -518,7 +525,8 @@ __global__ __launch_bounds__(256) static void k_update_rigidness(Img I, float* _
     for (int f = 0; f < NMAX; f++) {
         if (f < I.N) {
             float r = 0.f;
-            if ((valid >> f) & 1u) r = rigidness_from_flows(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.inv_arf);
+            if ((valid >> f) & 1u)
+                r = STRICT ? strict::rigidness(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.arf) : rigidness_from_flows(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.inv_arf);
             if (live) I.rig[(size_t)f * npx + pi] = r;
             float ws = wave_sum(live ? r : 0.f);
             if ((threadIdx.x & 63) == 0) s_part[f][threadIdx.x >> 6] = ws;
@@ -537,7 +545,7 @@ __global__ __launch_bounds__(256) static void k_update_rigidness(Img I, float* _
         if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
             float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
             if (td > 0.f)  // else: the confidence is left untouched (:129)
-                I.confs[(size_t)f * npx + pi] = 1.f / (1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf));
+                I.confs[(size_t)f * npx + pi] = STRICT ? strict::depth_rigidness(q.z, td, I.basefocal, I.omega, I.arf) : 1.f / (1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf));
         } else
             I.confs[(size_t)f * npx + pi] = 0.f;
     }
@@ -555,7 +563,7 @@ __global__ static void k_reduce_density(const float* __restrict__ partial, int n
         float ws = 0.f;
         for (int i = 0; i < n; i++) {
             const float* t = P->ts[i];
-            ws += (float)sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2]);
+            ws = (float)((double)ws + sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2]));  // float += double (cv::norm, voldor.cpp:312)
         }
         const float s = (float)n / ws;
         for (int i = 0; i < n; i++)
@@ -750,37 +758,42 @@ static Img make_img(const ImageSet& S, const OdParams& p) {
     I.priors = S.priors.as<float>(); I.pconfs = S.pconfs.as<float>(); I.confs = S.confs.as<float>();
     I.depth = S.depth.as<float>(); I.cost = S.cost.as<float>(); I.P = S.pb();
     I.N = p.N; I.N_dp = p.N_dp; I.w = p.w; I.h = p.h;
-    I.lambda = p.lambda; I.omega = p.omega; I.inv_arf = 1.f / p.abs_resize_factor;
+    I.lambda = p.lambda; I.omega = p.omega; I.inv_arf = 1.f / p.abs_resize_factor; I.arf = p.abs_resize_factor;
     I.basefocal = p.basefocal; I.disp_delta = p.disp_delta; I.delta = p.delta;
     return I;
 }
 
 // Device-resident optimize_depth: all inputs already in `S`. Stage order optimize_depth.cu:462-494.
-template <int NMAX>
+template <int NMAX, bool STRICT>
 static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_only) {
     const int w = p.w, h = p.h;
     Img I = make_img(S, p);
     const dim3 gpx((w + 63) / 64, (h + 3) / 4), bpx(256);
     if (cost_only) {
-        hipLaunchKernelGGL(k_cost_rand<NMAX>, gpx, bpx, 0, c->stream, I, 0, 0u, p.range_factor);
+        hipLaunchKernelGGL((k_cost_rand<NMAX, STRICT>), gpx, bpx, 0, c->stream, I, 0, 0u, p.range_factor);
         VK_CHECK_LAST();
         return 0;
     }
     if (!p.update_rigidness_only) {
         if (p.fb_smooth) {
-            if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active)) return e;
-            if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e;
+            if (STRICT) {
+                if (int e = fb_smooth_strict_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active)) return e;
+                if (int e = fb_smooth_strict_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e;
+            } else {
+                if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active)) return e;
+                if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e;
+            }
         }
         if (c->prof) prof_begin_inner(c);
         // flow layers beyond what the eight 4 MB L2s hold: frame-major variant (see k_cost_rand_frame_major)
         const size_t flow_bytes = (size_t)p.N * w * h * sizeof(float2);
-        const bool frame_major = flow_bytes > COST_RAND_FRAME_MAJOR_BYTES && p.n_rand_samples > 0;  // without samples there is one hypothesis: nothing to interchange
+        const bool frame_major = !STRICT && flow_bytes > COST_RAND_FRAME_MAJOR_BYTES && p.n_rand_samples > 0;  // without samples there is one hypothesis: nothing to interchange
         if (frame_major && flow_bytes > COST_RAND_DEPTH_ORDER_BYTES)
             hipLaunchKernelGGL(k_cost_rand_frame_major<true>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
         else if (frame_major)
             hipLaunchKernelGGL(k_cost_rand_frame_major<false>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
         else
-            hipLaunchKernelGGL(k_cost_rand<NMAX>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
+            hipLaunchKernelGGL((k_cost_rand<NMAX, STRICT>), gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
         if (c->prof) prof_end_inner(c, "cost_rand", 1);
         c->rand_epoch += (uint32_t)(p.n_rand_samples > 0 ? p.n_rand_samples : 0);
         if (p.global_prop_step > 0) {
@@ -792,10 +805,10 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                 if (p.global_prop_step >= 2) {
                     const int nsites = (len - 1 + p.global_prop_step - 1) / p.global_prop_step;
                     if (nsites > 0)
-                        hipLaunchKernelGGL(k_global_prop_sites<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir,
+                        hipLaunchKernelGGL((k_global_prop_sites<NMAX, STRICT>), dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir,
                                            p.global_prop_step, nsites);
                 } else
-                    hipLaunchKernelGGL(k_global_prop_serial<NMAX>, dim3((lines + 63) / 64), dim3(64), 0, c->stream, I, dir);
+                    hipLaunchKernelGGL((k_global_prop_serial<NMAX, STRICT>), dim3((lines + 63) / 64), dim3(64), 0, c->stream, I, dir);
             }
         }
         if (p.local_prop_width > 0) {
@@ -806,18 +819,18 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                 const bool rowpass = (dir == 0 || dir == 2);
                 const int len = rowpass ? w : h, lines = rowpass ? h : w;
                 const int nseg = (len + p.local_prop_width - 1) / p.local_prop_width;
-                if (p.local_prop_width <= 65) {  // chains of <= 64 steps: table + one wave per chain
+                if (!STRICT && p.local_prop_width <= 65) {  // chains of <= 64 steps: table + one wave per chain (strict: the plain serial chain)
                     hipLaunchKernelGGL(k_local_table<NMAX>, gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
                     hipLaunchKernelGGL(k_local_runs, dim3(lines, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width,
                                        c->local_tbl.as<float>());
                 } else
-                    hipLaunchKernelGGL(k_local_serial<NMAX>, dim3((lines + 63) / 64, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
+                    hipLaunchKernelGGL((k_local_serial<NMAX, STRICT>), dim3((lines + 63) / 64, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
             }
             if (c->prof) prof_end_inner(c, "local_pass", 4);
         }
     }
     const int nblk = gpx.x * gpx.y;
-    hipLaunchKernelGGL(k_update_rigidness<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
+    hipLaunchKernelGGL((k_update_rigidness<NMAX, STRICT>), gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
     if (p.N > 0)
         hipLaunchKernelGGL(k_reduce_density, dim3(p.N + (p.world_scale_out ? 1 : 0)), dim3(256), 0, c->stream, c->rig_partial.as<float>(), nblk,
                            w * h, c->cams.as<CamState>(), S.pb(), p.N, p.world_scale_out);
@@ -825,10 +838,14 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
     return 0;
 }
 static int optimize_depth_dispatch(Context* c, ImageSet& S, const OdParams& p, bool cost_only) {
-    if (p.N <= 4) return optimize_depth_launch<4>(c, S, p, cost_only);
-    if (p.N <= 6) return optimize_depth_launch<6>(c, S, p, cost_only);  // the SLAM driver's window is 5 flows (voldor_slam.py:85)
-    if (p.N <= 8) return optimize_depth_launch<8>(c, S, p, cost_only);
-    return optimize_depth_launch<16>(c, S, p, cost_only);
+    if (p.strict) {  // parity-pinning mode: two frame bounds are enough
+        if (p.N <= 8) return optimize_depth_launch<8, true>(c, S, p, cost_only);
+        return optimize_depth_launch<16, true>(c, S, p, cost_only);
+    }
+    if (p.N <= 4) return optimize_depth_launch<4, false>(c, S, p, cost_only);
+    if (p.N <= 6) return optimize_depth_launch<6, false>(c, S, p, cost_only);  // the SLAM driver's window is 5 flows (voldor_slam.py:85)
+    if (p.N <= 8) return optimize_depth_launch<8, false>(c, S, p, cost_only);
+    return optimize_depth_launch<16, false>(c, S, p, cost_only);
 }
 
 int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p) {
@@ -874,7 +891,7 @@ __global__ static void k_depth_conf(const float* rig, const float* confs, float*
     float s = 0.f;
     for (int f = 0; f < n_flows; f++) s += rig[(size_t)f * npx + i];
     for (int f = 0; f < n_dp; f++) s += confs[(size_t)f * npx + i];
-    out[i] = s / (float)(n_flows + n_dp);
+    out[i] = s * (float)(1.0 / (double)(float)(n_flows + n_dp));  // cv::Mat /= n multiplies by (float)(1./n) (py_export.cpp:74)
 }
 int fill_device(Context* c, float* p, float v, size_t n) {
     if (n == 0) return 0;

@@ -15,10 +15,33 @@ struct ModeParams {
     int decide_n = 0, decide_allow_trunc = 0; float decide_trunc_rigidness_density = 0.f, decide_trunc_sample_density = 0.f;
 };
 
+#ifdef __HIPCC__
+// voldor.cpp:171-194 on the device: the first camera that failed, was not allowed to run (rigidness density) or is not
+// confident enough truncates the window at its index.  The host applies the same rule to its copy of the records.
+// `cams` = record of camera 0.  Called by ONE thread, after it has written the last camera's record.
+__device__ __forceinline__ void decide_active(PoseBlock* P, const CamState* cams, int n_flows, int allow_trunc, float trunc_rigidness_density,
+                                              float trunc_sample_density) {
+    int n = n_flows;
+    for (int i = 0; i < n_flows; i++) {
+        int ok = 0;
+        if (!allow_trunc || cams[i].pose_rigidness_density > trunc_rigidness_density) ok = cams[i].success;
+        if (!ok || (allow_trunc && cams[i].pose_density < trunc_sample_density)) { n = i; break; }
+    }
+    P->n_active = n;
+}
+__device__ __forceinline__ void maybe_decide(const ModeParams& mp, PoseBlock* P, const CamState* cam, int cam_idx) {
+    if (mp.decide_n > 0)
+        decide_active(P, cam - cam_idx, mp.decide_n, mp.decide_allow_trunc, mp.decide_trunc_rigidness_density, mp.decide_trunc_sample_density);
+}
+#endif
+
 // vk_depth.hip
 int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p);
 int cost_map_device(Context* c, ImageSet& S, const OdParams& p);
 int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr);
+// vk_strict.hip
+int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr);
+int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
 int fill_device(Context* c, float* p, float v, size_t n);
 int scale_device(Context* c, float* p, const float* s_dev, size_t n);
 int disp_to_depth_device(Context* c, const float* disp, float* out, float bf, size_t n);
@@ -30,13 +53,19 @@ void set_frame_major_threshold(size_t bytes, size_t depth_order_bytes);  // vk_d
 int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
                    float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact);
 int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, float fx, float fy, float cx, float cy,
-                 int n_poses, int solver);
-int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev);
+                 int n_poses, int solver, bool strict = false, CamState* cam_dev = nullptr);
+// draw = 0: rejection over the map (D3b), falling back to the compacted list below DRAW_LIST_DENSITY; 1: always the reference's
+// index draw over the compacted list (geometry.cpp:68-88 + solve_batch_lambdatwist.cu:16-19); -1: rejection only (tests)
+int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev,
+                           int draw = 0, bool strict = false);
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 
 // vk_bootstrap.hip
-int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, float cx, float cy, CamState* cam0_dev);
+int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, float cx, float cy, CamState* cam0_dev, bool strict = false);
+
+// vk_abi.hip: process-wide default of the strict-math mode (vk_set_strict_math / VOLDOR_HIP_STRICT_MATH)
+bool strict_math_default();
 
 }  // namespace vk

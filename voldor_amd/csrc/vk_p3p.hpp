@@ -9,6 +9,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cmath>
+#include "vk_strict_math.h"
 // the solvers are plain arithmetic: compiled for host and device so the host build can be
 // checked against the oracle without a GPU (vk_host_* entry points, tests/test_host_math.py)
 #define VK_HD __host__ __device__
@@ -201,7 +202,8 @@ VK_HD __forceinline__ void consider(BestPose<S>& B, V3<S> L, S a12, S a13, S a23
 // with the same "first one, then strictly better" rule); only < 0 walks all candidates like the reference.
 template <typename S>
 VK_HD static bool lambdatwist_p4p(const float* yu, const float* yv, const float (*xp)[3], float fxf, float fyf,
-                                       float cxf, float cyf, float* Rout, float* tout, int only = -1, S* err_out = nullptr) {
+                                       float cxf, float cyf, float* Rout, float* tout, int only = -1, S* err_out = nullptr,
+                                       S* dbg = nullptr /* tests only: intermediate values of the sequential path (tests/cxx/vk_testhooks.hip) */) {
 #pragma clang fp contract(off)
     // bearings are formed in float and then widened (lambdatwist_p4p.h:13-15)
     V3<S> y1 = normalized<S>({ (S)((yu[0] - cxf) / fxf), (S)((yv[0] - cyf) / fyf), S(1.0) });
@@ -230,6 +232,11 @@ VK_HD static bool lambdatwist_p4p(const float* yu, const float* yv, const float 
     S e1, e2; V3<S> v1, v2;
     eig_known0<S>(A, e1, e2, v1, v2);
     S v = vk_sqrt(-e2 / e1 > 0 ? -e2 / e1 : S(0));
+    if (dbg) {
+        dbg[0] = p2; dbg[1] = p1; dbg[2] = p0; dbg[3] = g; dbg[4] = e1; dbg[5] = e2; dbg[6] = v1.x; dbg[7] = v1.y; dbg[8] = v1.z;
+        dbg[9] = v2.x; dbg[10] = v2.y; dbg[11] = v2.z; dbg[12] = v; dbg[13] = a12; dbg[14] = a13; dbg[15] = a23; dbg[16] = b12; dbg[17] = b13;
+        dbg[18] = b23; dbg[19] = y1.x; dbg[20] = y1.y; dbg[21] = y1.z;
+    }
 
     // X^-1 with X = [d12 d13 d12xd13] columns (matrix.h:636-656 adjugate form)
     S Xm[9] = { d12.x, d13.x, dc.x, d12.y, d13.y, dc.y, d12.z, d13.z, dc.z };
@@ -287,14 +294,18 @@ VK_HD static bool lambdatwist_p4p(const float* yu, const float* yv, const float 
                     S d = a23 / (tau * (b23 + tau) + S(1.0));
                     if (d > 0) {  // the +v block relies on vk_sqrt(NaN) failing l1>=0: same outcome
                         S l2 = vk_sqrt(d), l3 = tau * l2, l1 = w0 * l2 + w1 * l3;
-                        if (l1 >= 0)
+                        if (dbg) { S* q = dbg + 32 + (blk * 2 + k) * 16; q[0] = w0; q[1] = w1; q[2] = a; q[3] = b; q[4] = c; q[5] = tau; q[6] = d; q[7] = l1; q[8] = l2; q[9] = l3; }
+                        if (l1 >= 0) {
                             consider<S>(B, { l1, l2, l3 }, a12, a13, a23, b12, b13, b23, y1, y2, y3, x1, Xi, xp[3], yu[3], yv[3],
                                         fxf, fyf, cxf, cyf);
+                            if (dbg) { S* q = dbg + 32 + (blk * 2 + k) * 16; q[10] = B.err; q[11] = B.t[0]; q[12] = B.t[1]; q[13] = B.t[2]; q[14] = (S)B.n; }
+                        }
                     }
                 }
             }
         }
     }
+    if (dbg) { for (int i = 0; i < 9; i++) dbg[22 + i] = Xi[i]; }
     if (B.n == 0) return false;
 #pragma unroll
     for (int k = 0; k < 9; k++) Rout[k] = (float)B.R[k];
@@ -331,11 +342,12 @@ VK_HD __forceinline__ void nearest_rotation(float* Rf) {
 #pragma unroll
     for (int i = 0; i < 9; i++) Rf[i] = (float)X[i];
 }
-VK_HD __forceinline__ void rotmat_to_angle_axis(const float* R, float* aa) {
+// `strict`: software atan2 / sin / cos (vk_strict_math.h) -- the same bits on the host and on the device (strict-math mode)
+VK_HD __forceinline__ void rotmat_to_angle_axis(const float* R, float* aa, bool strict = false) {
     float a0 = R[7] - R[5], a1 = R[2] - R[6], a2 = R[3] - R[1];
     float costheta = fminf(fmaxf((R[0] + R[4] + R[8] - 1.f) * 0.5f, -1.f), 1.f);
     float sintheta = fminf(sqrtf(a0 * a0 + a1 * a1 + a2 * a2) * 0.5f, 1.f);
-    const float theta = atan2f(sintheta, costheta);
+    const float theta = strict ? vsm_atan2f(sintheta, costheta) : atan2f(sintheta, costheta);
     if (sintheta > 1.1920929e-07f) {
         const float r = theta / (2.f * sintheta);
         aa[0] = a0 * r; aa[1] = a1 * r; aa[2] = a2 * r;
@@ -351,14 +363,17 @@ VK_HD __forceinline__ void rotmat_to_angle_axis(const float* R, float* aa) {
     aa[0] = b0; aa[1] = b1; aa[2] = b2;
 }
 // angle-axis -> rotation matrix (cv::Rodrigues vec->mat as used at voldor/geometry.cpp:258)
-VK_HD __forceinline__ void angle_axis_to_rotmat(const float* rv, float* R) {
+VK_HD __forceinline__ void angle_axis_to_rotmat(const float* rv, float* R, bool strict = false) {
     double rx = rv[0], ry = rv[1], rz = rv[2];
     double th = sqrt(rx * rx + ry * ry + rz * rz);
     if (th < 2.220446049250313e-16) {
         R[0] = 1; R[1] = 0; R[2] = 0; R[3] = 0; R[4] = 1; R[5] = 0; R[6] = 0; R[7] = 0; R[8] = 1;
         return;
     }
-    double c = cos(th), s = sin(th), c1 = 1. - c, it = 1. / th;
+    double c, s;
+    if (strict) vsm_sincos(th, &s, &c);
+    else { c = cos(th); s = sin(th); }
+    const double c1 = 1. - c, it = 1. / th;
     rx *= it; ry *= it; rz *= it;
     R[0] = (float)(c + c1 * rx * rx);      R[1] = (float)(c1 * rx * ry - s * rz); R[2] = (float)(c1 * rx * rz + s * ry);
     R[3] = (float)(c1 * rx * ry + s * rz); R[4] = (float)(c + c1 * ry * ry);      R[5] = (float)(c1 * ry * rz - s * rx);
@@ -388,7 +403,7 @@ VK_HD __forceinline__ Cx cx_sqrt(Cx x) {  // solve_batch_ap3p.cu:9-15 (principal
 // Ferrari quartic as written at solve_batch_ap3p.cu:28-82, INCLUDING the double square root
 // in the q3<0 branch (:57, differs from OpenCV's ap3p.cpp): result parity with the reference
 // wins over fixing it; the two Newton polish steps (:85-98) follow.
-VK_HD static void ap3p_quartic(float a4, float a3, float a2, float a1, float a0, float& r0, float& r1, float& r2, float& r3) {
+VK_HD static void ap3p_quartic(float a4, float a3, float a2, float a1, float a0, float& r0, float& r1, float& r2, float& r3, bool strict = false) {
     float a4_2 = a4 * a4, a3_2 = a3 * a3, a4_3 = a4_2 * a4, a2a4 = a2 * a4;
     float p4 = (8 * a2a4 - 3 * a3_2) / (8 * a4_2);
     float q4 = (a3_2 * a3 - 4 * a2a4 * a3 + 8 * a1 * a4_2) / (8 * a4_3);
@@ -399,10 +414,10 @@ VK_HD static void ap3p_quartic(float a4, float a3, float a2, float a1, float a0,
     Cx w = cx_sqrt({ q3 * q3 - p3 * p3 * p3, 0.f });
     if (q3 >= 0) { w.x = -w.x - q3; w.y = -w.y; }
     else { w = cx_sqrt(w); w.x = w.x - q3; }
-    if (w.y == 0.0f) { w.x = cbrtf(w.x); t = 2.0f * (w.x + p3 / w.x); }
+    if (w.y == 0.0f) { w.x = strict ? vsm_cbrtf(w.x) : cbrtf(w.x); t = 2.0f * (w.x + p3 / w.x); }
     else {
-        float theta = atan2f(w.y, w.x), mag = powf(cx_abs(w), 1.0f / 3.0f);
-        t = 4.0f * (mag * cosf(theta * (1.0f / 3.0f)));
+        float theta = strict ? vsm_atan2f(w.y, w.x) : atan2f(w.y, w.x), mag = strict ? vsm_powf(cx_abs(w), 1.0f / 3.0f) : powf(cx_abs(w), 1.0f / 3.0f);
+        t = 4.0f * (mag * (strict ? vsm_cosf((1.0f / 3.0f) * theta) : cosf(theta * (1.0f / 3.0f))));
     }
     Cx sq2m = cx_sqrt({ -2 * p4 / 3 + t, 0.f });
     float B_4A = -a3 / (4 * a4);
@@ -427,7 +442,7 @@ VK_HD __forceinline__ V3<float> vcross(V3<float> a, V3<float> b) {
     return { a.y * b.z - a.z * b.y, -(a.x * b.z - a.z * b.x), a.x * b.y - a.y * b.x };
 }
 VK_HD static bool ap3p_p4p(const float* yu, const float* yv, const float (*xp)[3], float fx, float fy, float cx,
-                                float cy, float* Rout, float* tout) {
+                                float cy, float* Rout, float* tout, bool strict = false) {
     typedef V3<float> F3;
     F3 bv[3];
 #pragma unroll
@@ -465,7 +480,7 @@ VK_HD static bool ap3p_p4p(const float* yu, const float* yv, const float (*xp)[3
     float q3 = 2 * (g6 * g7 - g1 * g2 - g3 * g4);
     float q4 = g7 * g7 - g2 * g2 - g4 * g4;
     float s0, s1, s2, s3;
-    ap3p_quartic(q0, q1, q2, q3, q4, s0, s1, s2, s3);
+    ap3p_quartic(q0, q1, q2, q3, q4, s0, s1, s2, s3, strict);
     // polishQuarticRoots interleaves the 4 roots per iteration but roots are independent
     s0 = ap3p_polish(s0, q0, q1, q2, q3, q4); s1 = ap3p_polish(s1, q0, q1, q2, q3, q4);
     s2 = ap3p_polish(s2, q0, q1, q2, q3, q4); s3 = ap3p_polish(s3, q0, q1, q2, q3, q4);

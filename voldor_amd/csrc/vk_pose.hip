@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) static void k_compact(const float* __restrict_
 }
 
 // ---- batched pose hypotheses: one lane each (solve_batch_lambdatwist.cu:11-42, solve_batch_ap3p.cu:331-378)
-// Two ways to draw the 4 correspondences of a hypothesis, both uniform over the valid set:
+// Three ways to draw the 4 correspondences of a hypothesis, all uniform over the valid set:
 //  FROM_MAP=false  index into the compacted list, (int)(u*N_pts) like the reference kernel -- used by
 //                  the host-pointer API solve_batch_p3p_*_gpu, which receives that list;
 //  FROM_MAP=true   rejection sampling over the NaN-marked correspondence maps -- used by the
@@ -142,16 +142,26 @@ __global__ __launch_bounds__(256) static void k_compact(const float* __restrict_
 //                  one-pixel change of the valid set only changes the hypotheses that hit that
 //                  pixel instead of re-drawing all of them (with list indices a single insertion
 //                  shifts every later index; DESIGN.md "sampling stability").
+//  FROM_MAP=true, rank select: the reference's own draw WITHOUT materialising its list.  Entry i of the compacted list
+//                  (geometry.cpp:68-80) is the i-th valid pixel in row-major order: the per-workgroup counts of k_collect
+//                  (row-major blocks of 256 pixels) are prefix-summed in LDS, the block that holds rank i is found by
+//                  bisection and the pixel by a scan of that block.  Taken (a) when the valid density is below
+//                  1/DRAW_RANK_INV_DENSITY, where rejection within DRAW_MAX_TRIES probes starts to lose hypotheses
+//                  (a hypothesis survives with probability (1-(1-rho)^256)^4: 73 % at rho = 1 %), so that the pool has the
+//                  reference's size at ANY density >= 4 points; (b) always in reference-draw mode (--reference_draw 1).
 constexpr int DRAW_MAX_TRIES = 256;
+constexpr int DRAW_RANK_INV_DENSITY = 20;  // rank select below 5 % valid pixels (rejection then needs > 90 tries for 1 % of the points)
 template <int SOLVER, bool FROM_MAP>  // SOLVER: 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>
 __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ pts2, const float* __restrict__ pts3,
                                                       float* __restrict__ rvecs, float* __restrict__ tvecs,
                                                       int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk,
-                                                      CamState* cam, int npx, float fx, float fy, float cx, float cy, int n_poses) {
+                                                      CamState* cam, int npx, float fx, float fy, float cx, float cy, int n_poses,
+                                                      int draw /* 0 auto, 1 rank select (reference draw), -1 rejection only */, int strict) {
     // LambdaTwist: four lanes per hypothesis, one candidate root each (the candidates are independent once the
     // shared cubic / eigen-decomposition is done; a lane per hypothesis walks them one after the other and the wave
     // waits for its slowest lane).  AP3P keeps one lane per hypothesis.
     constexpr int LPH = (SOLVER == 1) ? 1 : 4;
+    extern __shared__ int s_pref[];  // FROM_MAP: inclusive prefix of blk_counts (rank select only)
     const int gtid = blockIdx.x * 64 + threadIdx.x, idx = gtid / LPH, sub = gtid % LPH;
     int n_pts;
     if (FROM_MAP) {
@@ -171,6 +181,19 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
         if (gtid == 0) { *n_pts_dev = n_pts; if (cam) cam->n_points = n_pts; }
     } else
         n_pts = *n_pts_dev;
+    const bool rank_draw = FROM_MAP && n_pts >= 4 && (draw > 0 || (draw == 0 && (long long)n_pts * DRAW_RANK_INV_DENSITY < (long long)npx));
+    if (rank_draw) {  // wave-uniform: inclusive prefix sums of the block counts
+        int carry = 0;
+        for (int i0 = 0; i0 < nblk; i0 += 64) {
+            const int i = i0 + (int)threadIdx.x;
+            int incl = i < nblk ? blk_counts[i] : 0;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += t; }
+            if (i < nblk) s_pref[i] = carry + incl;
+            carry += __shfl(incl, 63, 64);
+        }
+        __syncthreads();
+    }
     if (idx >= n_poses) return;
     const float qnan = __builtin_nanf("");
     float R[9], t[3];
@@ -180,7 +203,28 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
         float yu[4], yv[4], xp[4][3];
         bool drawn = true;
         int sel[4];
-        if (FROM_MAP) {
+        if (FROM_MAP && rank_draw) {
+#pragma unroll 1
+            for (int k = 0; k < 4; k++) {
+                // (int)(curand_uniform * N_pts), clamped (D3): solve_batch_lambdatwist.cu:16-19
+                const int r = min((int)(u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)k)) * (float)n_pts), n_pts - 1);
+                int lo = 0, hi = nblk - 1;  // first block whose inclusive prefix exceeds r
+                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid] > r) hi = mid; else lo = mid + 1; }
+                int want = r - (lo > 0 ? s_pref[lo - 1] : 0);  // rank inside the block
+                int pix = lo * 256, found = -1;
+                const int end = min(pix + 256, npx);
+                for (; pix < end && found < 0; pix += 4) {
+                    float pr[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) pr[u] = pix + u < end ? pts2[(size_t)(pix + u) * 2] : qnan;
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (found < 0 && isfinite(pr[u])) { if (want == 0) found = pix + u; else want--; }
+                }
+                sel[k] = found;
+                if (found < 0) { drawn = false; sel[k] = 0; }  // cannot happen: the counts come from the same map
+            }
+        } else if (FROM_MAP) {
             // Rejection draw over the NaN-marked correspondence map: point k takes the first valid pixel of its
             // own candidate sequence j = 0,1,2,...  A probe is a random read (one L2/HBM round trip), so the
             // probes are issued DRAW_BATCH tries x 4 points at a time instead of one dependent read per try;
@@ -227,11 +271,11 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
         if (drawn) {
             if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf);
             else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errd);
-            else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t);
+            else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t, strict != 0);
         }
     }
     float aa[3] = { qnan, qnan, qnan };
-    if (ok) { nearest_rotation(R); rotmat_to_angle_axis(R, aa); }
+    if (ok) { nearest_rotation(R); rotmat_to_angle_axis(R, aa, strict != 0); }
     bool writer = true;
     if (LPH == 4) {
         // fold the four candidates in root order: the first valid one, then any later one with a strictly smaller
@@ -750,23 +794,6 @@ __device__ __forceinline__ int load_hypotheses(const float* __restrict__ rvecs, 
     return used;
 }
 
-// voldor.cpp:171-194 on the device: the first camera that failed, was not allowed to run (rigidness density) or is not
-// confident enough truncates the window at its index.  The host applies the same rule to its copy of the records.
-// `cams` = record of camera 0.  Called by ONE thread, after it has written the last camera's record.
-__device__ __forceinline__ void decide_active(PoseBlock* P, const CamState* cams, int n_flows, int allow_trunc, float trunc_rigidness_density,
-                                              float trunc_sample_density) {
-    int n = n_flows;
-    for (int i = 0; i < n_flows; i++) {
-        int ok = 0;
-        if (!allow_trunc || cams[i].pose_rigidness_density > trunc_rigidness_density) ok = cams[i].success;
-        if (!ok || (allow_trunc && cams[i].pose_density < trunc_sample_density)) { n = i; break; }
-    }
-    P->n_active = n;
-}
-__device__ __forceinline__ void maybe_decide(const ModeParams& mp, PoseBlock* P, const CamState* cam, int cam_idx) {
-    if (mp.decide_n > 0)
-        decide_active(P, cam - cam_idx, mp.decide_n, mp.decide_allow_trunc, mp.decide_trunc_rigidness_density, mp.decide_trunc_sample_density);
-}
 // geometry.cpp:249-263: unscale, checkRange, write the pose into CamState and the PoseBlock (thread 0)
 __device__ __forceinline__ void finalize_pose(const float* mean6 /*scaled space*/, float rvec_scale, int used, float density, int ms_iters,
                                               int gu_iters, CamState* cam, PoseBlock* P, int cam_idx) {
@@ -1135,26 +1162,30 @@ int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int activ
 
 template <bool FROM_MAP>
 static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, CamState* cam, int npx, float fx, float fy,
-                        float cx, float cy, int n_poses, int solver) {
+                        float cx, float cy, int n_poses, int solver, int draw, bool strict) {
     if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     const int lph = (solver == 1) ? 1 : 4;  // lanes per hypothesis (k_solve)
     dim3 g((n_poses * lph + 63) / 64), b(64);
     float* rv = c->rvecs.as<float>(); float* tv = c->tvecs.as<float>();
-    const int* bc = c->blk_counts.as<int>(); const int nb = c->n_map_blocks;
-    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses);
-    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses);
-    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, 0, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses);
+    const int* bc = c->blk_counts.as<int>(); const int nb = FROM_MAP ? c->n_map_blocks : 0;
+    const size_t lds = FROM_MAP ? sizeof(int) * (size_t)nb : 0;  // prefix of the block counts (rank-select draw)
+    if (lds > 60 * 1024) { fprintf(stderr, "voldor_hip: image too large for the rank-select draw (%d blocks)\n", nb); return (int)hipErrorInvalidValue; }
+    const int st = strict ? 1 : 0;
+    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st);
+    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st);
+    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st);
     VK_CHECK_LAST();
     return 0;
 }
 int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, float fx, float fy, float cx, float cy,
-                 int n_poses, int solver) {
-    return solve_launch<false>(c, pts2, pts3, n_pts_dev, nullptr, 0, fx, fy, cx, cy, n_poses, solver);
+                 int n_poses, int solver, bool strict, CamState* cam_dev) {
+    return solve_launch<false>(c, pts2, pts3, n_pts_dev, cam_dev, 0, fx, fy, cx, cy, n_poses, solver, 0, strict);
 }
-int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev) {
+int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev, int draw,
+                           bool strict) {
     return solve_launch<true>(c, c->p2_map.as<float>(), c->p3_map.as<float>(), c->n_points.as<int>(), cam_dev, npx, fx, fy, cx, cy, n_poses,
-                              solver);
+                              solver, draw, strict);
 }
 
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx) {

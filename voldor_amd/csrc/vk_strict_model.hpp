@@ -1,0 +1,61 @@
+// voldor_amd/csrc/vk_strict_model.hpp -- the residual model in the REFERENCE's operation order on the software
+// transcendentals of vk_strict_math.h ("strict math" mode).
+//
+// The fast kernels use an algebraically re-derived form on v_log_f32 / v_exp_f32 (vk_device.hpp: 5 transcendental
+// instructions per rigidness).  Here the formulas of gpu-kernels/residual_model.h:15-68 are evaluated as written there --
+// fun_fmag_c, fun_fmag_scale, fisk_dist_pdf, fun_rigidness, fun_depth_rigidness, one rounding per operation, no fma -- with
+// vsm_expf / vsm_powf / vsm_logf in place of the library calls.  The oracle in strict mode (oracle/orc_math.h) evaluates the
+// same expressions with the same functions, so both produce the same bits; host-compiled, these functions are checked against
+// it on the CPU (tests/test_strict_host.py), on the GPU they are checked against their own host build (tests/test_gpu_strict.py).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "vk_strict_math.h"
+
+namespace vk { namespace strict {
+
+#define VK_SHD __host__ __device__ __forceinline__
+
+// residual_model.h:6-13: EST_RF 0.5 is a DOUBLE literal there (fmag * EST_RF widens), the rest are floats
+VK_SHD float clamp_fmag(float fmag) {
+#pragma clang fp contract(off)
+    return fminf(fmaxf((float)((double)fmag * 0.5), 2.f), 100.f);  // :16 / :22
+}
+VK_SHD float fmag_c(float fmag) {
+#pragma clang fp contract(off)
+    return 1.0f + -0.0022f * clamp_fmag(fmag);  // FISK_B1 + FISK_B2 * fmag (:17)
+}
+VK_SHD float fmag_scale(float fmag) {
+#pragma clang fp contract(off)
+    return 0.01f * vsm_expf(0.09f * clamp_fmag(fmag));  // FISK_A1 * expf(FISK_A2 * fmag) (:23)
+}
+VK_SHD float fisk_pdf(float x, float c, float scale) {  // :28-31
+#pragma clang fp contract(off)
+    x = fmaxf((float)((double)x * 0.5), 1.1920929e-07f);
+    const float r = (x * x) / scale;
+    return (c * vsm_powf(r, -c - 1.f) * vsm_powf(1.f + vsm_powf(r, -c), -2.f)) / scale;
+}
+VK_SHD float rigidness(float dx1, float dy1, float dx2, float dy2, float lambda, float abs_rf) {  // fun_rigidness :34-42
+#pragma clang fp contract(off)
+    const float obs_fmag = sqrtf(dx2 * dx2 + dy2 * dy2) / abs_rf;
+    const float ex = dx1 - dx2, ey = dy1 - dy2;
+    const float diff_fmag = sqrtf(ex * ex + ey * ey) / abs_rf;
+    const float c = fmag_c(obs_fmag), s = fmag_scale(obs_fmag);
+    const float p = fisk_pdf(diff_fmag, c, s), mu = fisk_pdf(lambda * obs_fmag, c, s);
+    return p / (p + mu);
+}
+VK_SHD float depth_rigidness(float d1, float d2, float basefocal, float omega, float abs_rf) {  // fun_depth_rigidness :51-61
+#pragma clang fp contract(off)
+    const float disp1 = (basefocal / d1) / abs_rf, disp2 = (basefocal / d2) / abs_rf;
+    const float diff = fabsf(disp1 - disp2);
+    const float c = fmag_c(disp2), s = fmag_scale(disp2);
+    const float p = fisk_pdf(diff, c, s), mu = fisk_pdf(omega * disp2, c, s);
+    return p / (p + mu);
+}
+// fun_cost / fun_depth_cost (:45-49, :64-68): io_cost -= weight * logf(rigidness)
+VK_SHD float cost_acc(float cost_sum, float weight, float rig) {
+#pragma clang fp contract(off)
+    return cost_sum - weight * vsm_logf(rig);
+}
+
+#undef VK_SHD
+}}  // namespace vk::strict

@@ -40,6 +40,13 @@ struct Config {
     int optimize_depth = 1, depth_rand_samples = 10, depth_global_prop_step = 8, depth_local_prop_width = 32; float depth_range_factor = 1.f;
     int meanshift_max_iters = 100, meanshift_max_init_trials = 20; float meanshift_good_init_confidence = 0.5f, meanshift_epsilon = 1e-5f;
     int kitti_estimate_ground = 0, kitti_ground_holo_width = 5; float kitti_ground_roi = 0.4f, kitti_ground_meanshift_kernel_var = 0.01f;
+    // Extensions (not in config.h; they select how results are COMPUTED, not what is computed; parity pinning):
+    //  strict_math     1: every stage in the reference's operation order on software transcendentals (vk_strict.hip) -- the window then
+    //                  reproduces the CPU oracle in strict mode bit for bit; -1 (default) = the process-wide setting of vk_set_strict_math
+    //  reference_draw  1: pose hypotheses index the row-major list of valid correspondences like geometry.cpp:68-88 +
+    //                  solve_batch_lambdatwist.cu:16-19 (rank select over the map); 0: rejection draw (D3b) with that draw as the
+    //                  low-density fallback
+    int strict_math = -1, reference_draw = 0;
 
     // Returns 0, or non-zero where the reference prints and calls exit(1) (config.h:101-108,245-248):
     // a library must not exit its host process, so the error is reported to the caller instead.
@@ -58,6 +65,7 @@ struct Config {
             KI(depth_global_prop_step), KI(depth_local_prop_width), KF(depth_range_factor), KI(meanshift_max_iters),
             KI(meanshift_max_init_trials), KF(meanshift_good_init_confidence), KF(meanshift_epsilon), KI(kitti_estimate_ground),
             KI(kitti_ground_holo_width), KF(kitti_ground_roi), KF(kitti_ground_meanshift_kernel_var),
+            KI(strict_math), KI(reference_draw),
         };
 #undef KF
 #undef KI
@@ -89,7 +97,7 @@ struct Voldor {
     Context* c = nullptr;
     Config cfg;
     int n_flows = 0, n_flows_init = 0, n_dp = 0, w = 0, h = 0, iters_cur = 0, iters_remain = 0;
-    bool has_disparity = false;
+    bool has_disparity = false, strict = false;
     CamState hcams[MAX_FRAMES];
 
     CamState* dcams() { return c->cams.as<CamState>(); }
@@ -98,6 +106,7 @@ struct Voldor {
     int init(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
              const float* depth_prior_poses, const float* depth_prior_pconfs, int N, int N_dp_in, int w_, int h_) {
         w = w_; h = h_;
+        strict = cfg.strict_math < 0 ? strict_math_default() : cfg.strict_math != 0;
         n_flows = n_flows_init = N;
         iters_cur = 0; iters_remain = cfg.max_iters;
         n_dp = N_dp_in + (disparity ? 1 : 0);
@@ -143,7 +152,7 @@ struct Voldor {
                 if (depth_prior_pconfs)
                     VK_CHECK(hipMemcpyAsync(S.pconfs.as<float>() + (size_t)(o + i) * npx, depth_prior_pconfs + (size_t)i * npx, sizeof(float) * npx, hipMemcpyDefault, st));
                 else if (int e = fill_device(c, S.pconfs.as<float>() + (size_t)(o + i) * npx, 1.f, npx)) return e;
-                angle_axis_to_rotmat(depth_prior_poses + i * 6, pb.dpRs[o + i]);
+                angle_axis_to_rotmat(depth_prior_poses + i * 6, pb.dpRs[o + i], strict);
                 for (int d = 0; d < 3; d++) pb.dpts[o + i][d] = depth_prior_poses[i * 6 + 3 + d];
             }
             if (int e = fill_device(c, S.confs.as<float>(), 1.f, npx * n_dp)) return e;
@@ -170,6 +179,7 @@ struct Voldor {
         p.lambda = cfg.lambda; p.omega = cfg.omega; p.disp_delta = has_disparity ? cfg.disp_delta : -1.f; p.delta = cfg.delta;
         p.fb_smooth = cfg.fb_smooth != 0; p.s0_ems_prob = cfg.fb_emm; p.no_change_prob = cfg.fb_no_change_prob;
         p.range_factor = cfg.depth_range_factor; p.update_rigidness_only = (flag == OD_UPDATE_RIGIDNESS_ONLY);
+        p.strict = strict;
         if (with_world_scale) {  // voldor.cpp:309-317: the pose half rides on the density launch, the depth half follows
             if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
             p.world_scale_out = c->ms_io.as<float>() + 48;
@@ -188,7 +198,9 @@ struct Voldor {
             return e;
         // cpu_p3p=1 selects the reference's CPU instantiation lambdatwist_p4p<double,...> (geometry.cpp:112)
         const int solver = cfg.lambdatwist ? (cfg.cpu_p3p ? 2 : 0) : 1;
-        if (int e = solve_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i)) return e;
+        if (int e = solve_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i,
+                                           cfg.reference_draw ? 1 : 0, strict))
+            return e;
         ModeParams mp{};
         mp.dims = 6; mp.kernel_var = cfg.meanshift_kernel_var; mp.ms_epsilon = cfg.meanshift_epsilon;
         mp.ms_max_iters = cfg.meanshift_max_iters; mp.ms_max_init_trials = cfg.meanshift_max_init_trials;
@@ -200,7 +212,8 @@ struct Voldor {
             mp.decide_n = n_flows; mp.decide_allow_trunc = iters_cur > cfg.no_trunc_iters ? 1 : 0;
             mp.decide_trunc_rigidness_density = cfg.trunc_rigidness_density; mp.decide_trunc_sample_density = cfg.trunc_sample_density;
         }
-        if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e;
+        if (strict) { if (int e = pose_mode_strict_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e; }
+        else if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e;
         if (c->prof) prof_end(c, "optimize_camera_pose");
         return 0;
     }
@@ -252,7 +265,7 @@ struct Voldor {
     int solve() {
         if (n_dp == 0) {  // bootstrap :151-162
             if (c->prof) prof_begin(c);
-            if (int e = bootstrap_device(c, c->od, w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, dcams())) return e;
+            if (int e = bootstrap_device(c, c->od, w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, dcams(), strict)) return e;
             if (c->prof) prof_end(c, "bootstrap");
         }
         while (iters_remain > 0 && n_flows > 0) {
