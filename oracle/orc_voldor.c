@@ -164,6 +164,7 @@ static int v_optimize_camera_pose(orc_voldor_t* v, int active_idx, int successiv
     int n_points = 0; /* geometry.cpp:68-80: number of finite correspondences */
     for (int i = 0; i < npx; i++) if (isfinite(p2m[i * 2])) n_points++;
     free(Rs); free(ts);
+    if (getenv("ORC_PRINT_POINTS")) fprintf(stderr, "orc: iter %d camera %d: %d valid correspondences of %d pixels\n", v->iters_cur, active_idx, n_points, npx);
     if (n_points < 4) { free(p2m); free(p3m); return 0; } /* :84 */
 
     const int np = c->n_poses_to_sample;
@@ -174,7 +175,10 @@ static int v_optimize_camera_pose(orc_voldor_t* v, int active_idx, int successiv
      * solve_batch_lambdatwist.cu:16-19, clamp D3) so that a whole window can be compared with the reference pipeline
      * executed on the CPU (oracle/ref_wrap_host.cpp, tests/test_oracle_vs_ref_window.py). */
     const char* ref_draw = getenv("ORC_REFERENCE_DRAW");
-    if (ref_draw && ref_draw[0] == '1') {
+    /* D3b keeps a fallback: below 5 % valid pixels the rejection draw (256 probes per point) starts to lose hypotheses, so the
+     * reference's own draw is used there (product: rank select in k_solve, DRAW_RANK_INV_DENSITY) and the pool keeps the
+     * reference's size at any density */
+    if ((ref_draw && ref_draw[0] == '1') || (long long)n_points * 20 < (long long)npx) {
         float* c2 = malloc(sizeof(float) * npx * 2); float* c3 = malloc(sizeof(float) * npx * 3);
         const int nc = orc_compact_p3p(p2m, p3m, npx, c2, c3);
         orc_solve_batch_p3p(c3, c2, rv, tv, K, nc, np, !c->lambdatwist, c->cpu_p3p ? 1 : 0);

@@ -17,6 +17,37 @@
 #include <cmath>
 #include "../cuda_stub_common.h"
 
+/* ---- the C library's transcendentals, switchable at run time (ref_set_math_mode, defined in ref_wrap_kernels.cpp):
+ *  0  libm, as the reference calls it;
+ *  1  voldor_amd/csrc/vk_strict_math.h -- what the oracle (orc_set_strict_math) and the product (--strict_math 1) use in
+ *     strict mode, so the reference's own code can be run in strict mode too (tests/golden/ref_window_strict.npz);
+ *  2  libm with every expf / powf / logf result moved by -1 / 0 / +1 ulp (a hash of the argument bits decides): a stand-in
+ *     for "some other correctly-behaving libm / GPU math library", used to MEASURE how far two runs of the reference's own
+ *     pipeline drift apart when only the last bit of the transcendentals differs (tests/golden/ref_selfnoise.npz). */
+#include "../../../voldor_amd/csrc/vk_strict_math.h"
+extern "C" int ref_math_mode;
+static inline float ref_ulp_jitter(float r, float x, float y) {
+    uint32_t a, b; memcpy(&a, &x, 4); memcpy(&b, &y, 4);
+    uint32_t h = (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u); h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    const int k = (int)(h % 3u) - 1;
+    if (k == 0 || !(r == r) || std::isinf(r)) return r;
+    return std::nextafterf(r, k > 0 ? INFINITY : -INFINITY);
+}
+static inline float ref_expf(float x) { return ref_math_mode == 1 ? vsm_expf(x) : (ref_math_mode == 2 ? ref_ulp_jitter(::expf(x), x, 1.f) : ::expf(x)); }
+static inline float ref_logf(float x) { return ref_math_mode == 1 ? vsm_logf(x) : (ref_math_mode == 2 ? ref_ulp_jitter(::logf(x), x, 2.f) : ::logf(x)); }
+static inline float ref_powf(float x, float y) { return ref_math_mode == 1 ? vsm_powf(x, y) : (ref_math_mode == 2 ? ref_ulp_jitter(::powf(x, y), x, y) : ::powf(x, y)); }
+static inline float ref_atan2f(float y, float x) { return ref_math_mode == 1 ? vsm_atan2f(y, x) : ::atan2f(y, x); }
+static inline float ref_sinf(float x) { return ref_math_mode == 1 ? vsm_sinf(x) : ::sinf(x); }
+static inline float ref_cosf(float x) { return ref_math_mode == 1 ? vsm_cosf(x) : ::cosf(x); }
+static inline float ref_cbrtf(float x) { return ref_math_mode == 1 ? vsm_cbrtf(x) : ::cbrtf(x); }
+#define expf ref_expf
+#define logf ref_logf
+#define powf ref_powf
+#define atan2f ref_atan2f
+#define sinf ref_sinf
+#define cosf ref_cosf
+#define cbrtf ref_cbrtf
+
 struct dim3 { unsigned x, y, z; dim3(unsigned a = 1, unsigned b = 1, unsigned c = 1) : x(a), y(b), z(c) {} };
 struct emul_idx3 { unsigned x, y, z; };
 static emul_idx3 threadIdx, blockIdx;

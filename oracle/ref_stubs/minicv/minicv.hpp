@@ -24,6 +24,9 @@
 #include <string>
 #include <vector>
 
+#include "../../../voldor_amd/csrc/vk_strict_math.h"
+extern "C" int ref_math_mode;  /* ref_wrap_kernels.cpp; 1 = strict math (ref_stubs/emul/cuda_emul.h) */
+
 #define CV_32F 5
 #define CV_64F 6
 #define CV_MAKETYPE(depth, cn) ((depth) + (((cn) - 1) << 3))
@@ -245,7 +248,7 @@ static inline void minicv_rvec_to_R(const double r_in[3], double R[9]) {
     double rx = r_in[0], ry = r_in[1], rz = r_in[2];
     const double theta = std::sqrt(rx * rx + ry * ry + rz * rz);
     if (theta < DBL_EPSILON) { for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0); return; }
-    const double c = std::cos(theta), s = std::sin(theta), c1 = 1. - c, it = 1. / theta;
+    const double c = ref_math_mode == 1 ? vsm_cos(theta) : std::cos(theta), s = ref_math_mode == 1 ? vsm_sin(theta) : std::sin(theta), c1 = 1. - c, it = 1. / theta;  /* strict mode: oracle/ref_stubs/emul/cuda_emul.h */
     rx *= it; ry *= it; rz *= it;
     const double rrt[9] = { rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz };
     const double rxm[9] = { 0, -rz, ry, rz, 0, -rx, -ry, rx, 0 };

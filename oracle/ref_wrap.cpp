@@ -14,7 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
-#include "ref_stubs/cuda_stub_common.h"
+#include "ref_stubs/emul/cuda_emul.h"   // (includes cuda_stub_common.h) the libm switch ref_set_math_mode also governs these headers
 #include "lambdatwist/lambdatwist_p4p.h"   // -I/root/reference
 #include "gpu-kernels/residual_model.h"
 #include "gpu-kernels/rodrigues.h"

@@ -15,6 +15,7 @@
 
 double minicv_two_view_R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, minicv_two_view_t[3] = { 0, 0, 1 };
 #ifdef REF_HOST_ON_HIP
+extern "C" { int ref_math_mode = 0; }  // minicv's Rodrigues switch (the kernels come from libvoldor_hip.so here, which has its own strict mode)
 extern "C" int vk_set_rand_epoch(unsigned epoch);  // include/voldor_hip.h:108
 static void ref_reset_window_state(unsigned rand_epoch) { vk_set_rand_epoch(rand_epoch); }
 #else

@@ -1,0 +1,59 @@
+"""Generates tests/golden/ref_big.npz: BASELINE cfg3 (1241x376, N=8, stereo) and cfg5 (1920x1080, N=10, 12 iterations,
+RGB-D style disparity prior) windows -- the sizes bench.py --workload cfg3/cfg5 measures.  Build container only; takes
+~20-30 minutes (the reference pipeline runs on one core):  python tests/golden/gen_golden_big.py [cfg3] [cfg5]
+
+Two records per window:
+  ref/...     the REFERENCE's own py_voldor_wrapper executed on the CPU (oracle/_ref, as tests/golden/gen_golden_window.py): poses,
+              covariances, depth / confidence sub-sampled 4x4.  The HIP path is compared with it statistically (the reference's
+              approximate-SVD rodrigues and its draw differ from the product's).
+  strict/...  the oracle in strict-math mode (orc_set_strict_math(1), default draw): sha256 of the full depth and confidence maps,
+              poses, covariances.  The HIP path in --strict_math 1 must reproduce these BIT FOR BIT at full size
+              (tests/test_gpu_configs.py)."""
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import orc  # noqa: E402
+import big_window_cases as big  # noqa: E402
+
+
+def main():
+    which = [a for a in sys.argv[1:] if a in big.CASES] or list(big.CASES)
+    path = os.path.join(HERE, "ref_big.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    for name in which:
+        c = big.make(name)
+        fx, fy, cx, cy = c["K"]
+        kw = dict(basefocal=c["basefocal"], disparity=c["disparity"])
+        t0 = time.time()
+        orc.lib().orc_set_strict_math(1)
+        try:
+            s = orc.voldor(c["flows"], fx, fy, cx, cy, config=c["config"], **kw)
+        finally:
+            orc.lib().orc_set_strict_math(0)
+        print(f"{name}: strict oracle {time.time() - t0:.0f} s, n_registered {s['n_registered']}", flush=True)
+        out[f"{name}/strict/n_registered"] = np.int32(s["n_registered"])
+        out[f"{name}/strict/poses"], out[f"{name}/strict/poses_covar"] = s["poses"], s["poses_covar"]
+        for k in ("depth", "depth_conf"):
+            out[f"{name}/strict/{k}_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(s[k]).tobytes()).digest(), np.uint8)
+            out[f"{name}/strict/{k}_sub8"] = s[k][::8, ::8].copy()
+        t0 = time.time()
+        r = orc.ref_voldor(c["flows"], fx, fy, cx, cy, config=c["config"], **kw)
+        print(f"{name}: reference pipeline {time.time() - t0:.0f} s, n_registered {r['n_registered']}", flush=True)
+        out[f"{name}/ref/n_registered"] = np.int32(r["n_registered"])
+        out[f"{name}/ref/poses"], out[f"{name}/ref/poses_covar"] = r["poses"], r["poses_covar"]
+        for k in ("depth", "depth_conf"):
+            out[f"{name}/ref/{k}_sub4"] = r[k][::4, ::4].copy()
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -8,6 +8,18 @@ MONO = "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 8"
 STEREO = "--silent --meanshift_kernel_var 0.1 --disp_delta 1 --delta 0.2 --max_iters 8"
 
 
+# A window whose valid-correspondence density collapses after the first EM iteration: only pixels with rigidness > 0.9995 are
+# sampled (config.h:59 rigidness_threshold), i.e. ~1 % of the image for camera 0, a few dozen pixels for camera 1, none for
+# camera 2 (the window truncates there).  The reference still forms all n_poses_to_sample hypotheses from those few points
+# (index draw over the compacted list, geometry.cpp:68-88 + solve_batch_lambdatwist.cu:16-19); a rejection draw with a probe
+# budget would lose camera 1.
+LOW_DENSITY_CFG = "--silent --meanshift_kernel_var 0.1 --disp_delta 1 --delta 0.2 --max_iters 3 --rigidness_threshold 0.9995 --trunc_sample_density 0"
+
+
+def low_density_scene():
+    return synth.make_scene(w=256, h=192, n_flows=4, fx=128, fy=128, cx=128, cy=96, seed=239, basefocal=64.0)
+
+
 def _small():
     return synth.make_scene(w=128, h=96, n_flows=4, fx=64, fy=64, cx=64, cy=48, seed=5, basefocal=30.0)
 
@@ -39,6 +51,7 @@ def window_cases():
     fl = st["flows"].copy()
     fl[3:] = np.random.default_rng(0).uniform(-40, 40, fl[3:].shape).astype(np.float32)
     yield "truncated_b1", _case(st, MONO, flows=fl, b1=True)
+    yield "low_density", _case(low_density_scene(), LOW_DENSITY_CFG, basefocal=64.0, disparity=True)
     # BASELINE configs[0]: the reference's CPU geometry path (geometry.cpp:99-143, lambdatwist_p4p<double> on the host with
     # libc rand() draws, which no other implementation can replay): statistical comparison only
     yield "cfg1_cpu_p3p", _case(sp, "--silent --max_iters 8 --cpu_p3p 1 --exclusive_gpu_context 0", stat_only=True)

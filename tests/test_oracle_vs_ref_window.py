@@ -98,3 +98,30 @@ def test_default_oracle_within_sampling_noise_of_the_reference(gold, name):
     s = np.mean(np.linalg.norm(o["poses"][:, 3:], axis=1)) / np.mean(np.linalg.norm(gold[f"{name}/poses"][:, 3:], axis=1))
     rel = np.abs(o["depth"][m] / s - gold[f"{name}/depth"][m]) / gold[f"{name}/depth"][m]
     assert m.mean() > 0.3 and np.median(rel) < 3e-2, (m.mean(), np.median(rel))
+
+
+# ---- strict math on the reference's own code --------------------------------------------------------------------------------
+STRICT_GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_window_strict.npz")
+
+
+@pytest.mark.parametrize("name", ["mono_nonexclusive", "stereo_default", "stereo_ap3p", "depth_priors"])
+def test_strict_oracle_bit_identical_to_the_reference_in_strict_math(reference_mode, name):
+    """tests/golden/ref_window_strict.npz = the reference pipeline with its libm calls served by vk_strict_math.h (oracle/ref_stubs/emul/
+    cuda_emul.h, ref_set_math_mode(1)).  The oracle with orc_set_strict_math(1) must give the same bits: "strict math" is nothing but
+    a libm swap in the reference's own code, and the HIP path is held to this oracle bit for bit on the GPU (tests/test_gpu_strict.py)."""
+    g = np.load(STRICT_GOLD)
+    c = dict(CASES)[name]
+    orc.lib().orc_set_strict_math(1)
+    orc.ref().ref_set_math_mode(1)  # the hooked rodrigues() is the reference's own code: its atan2f must be the strict one too
+    try:
+        o = run_oracle(c)
+    finally:
+        orc.lib().orc_set_strict_math(0)
+        orc.ref().ref_set_math_mode(0)
+    assert o["n_registered"] == int(g[f"{name}/n_registered"])
+    assert np.array_equal(bits(o["depth"]), bits(g[f"{name}/depth"]))
+    assert np.array_equal(bits(o["depth_conf"]), bits(g[f"{name}/depth_conf"]))
+    assert np.array_equal(bits(o["poses_covar"]), bits(g[f"{name}/poses_covar"]))
+    assert np.abs(o["poses"] - g[f"{name}/poses"]).max() < 1e-9
+    # and it is a different rounding of the same window than the glibc run
+    assert not np.array_equal(bits(g[f"{name}/depth"]), bits(np.load(GOLD)[f"{name}/depth"]))

@@ -49,6 +49,14 @@ struct PoseBlock {
     // before it has seen the decision itself.  B-inner callers pass the count by argument: MAX_FRAMES here.
     int n_active;
     int pad_[3];
+    // Fast path only (k_cum_poses, vk_depth.hip): the rigid chain of optimize_depth.cu:54-81 folded into one projective map per
+    // frame.  With (Rc_f, tc_f) = the pose that takes frame-0 coordinates to frame f+1 (Rc_f = R_f Rc_{f-1}, tc_f = R_f tc_{f-1} + t_f)
+    // the homogeneous pixel of (x, y, depth d) in frame f+1 is  d * cumM[f] (x, y, 1)^T + cumT[f],  cumM = K Rc K^-1, cumT = K tc;
+    // its third component is the camera-space depth.  dpM / dpT: the same for the depth-prior poses (each relative to frame 0).
+    float cumM[MAX_FRAMES][9];
+    float cumT[MAX_FRAMES][4];
+    float dpM[MAX_DISP_FRAMES][9];
+    float dpT[MAX_DISP_FRAMES][4];
 };
 
 // Per-camera state kept on the device (voldor/utils.h:31-45 Camera, minus OpenCV).

@@ -85,6 +85,52 @@ __device__ __forceinline__ float depth_ratio(float d1, float d2, float basefocal
     return fisk_ratio_sq(dd * dd, om * om, fisk_params(disp2));
 }
 
+// ---- fast path: the same model with the observation-only part split off ---------------------------------------------------
+// Everything that depends on the OBSERVED flow alone (c, log2(1/s), the strictness term mu) is computed once per gather
+// (and once per pixel for frame 0, whose observation does not depend on the depth hypothesis); a residual then costs
+// 2 v_log + 2 v_exp.  log2(1/s) = log2(100) - 0.09 log2(e) g needs no exp at all, and the eps clamp of the strictness term
+// moves into the log domain: log2(max(x, eps^2)) = max(log2 x, log2 eps^2).
+struct __attribute__((aligned(8))) TexPair { float ax, ay, bx, by; };  // two horizontally adjacent flow texels
+struct ObsTerms { float c, c1, ls, lm, rqm; };
+__device__ __forceinline__ ObsTerms obs_terms(float ox, float oy, float ia2, float log2_qlam2 /* log2(0.25 lambda^2) */) {
+    const float obs2 = (ox * ox + oy * oy) * ia2;
+    const float g = __builtin_amdgcn_fmed3f(0.5f * fast_sqrt(obs2), 2.f, 100.f);  // residual_model.h:16
+    ObsTerms t;
+    t.c = fmaf(-0.0022f, g, 1.0f);
+    t.c1 = t.c + 1.f;
+    t.ls = fmaf(-0.12984255368000671f, g, 6.643856189774724f);  // log2(100 / exp(0.09 g))
+    t.lm = fmaxf(fast_log2(obs2) + log2_qlam2, -45.99999998912693f) + t.ls;  // log2(ZDE^2), ZDE = FLT_EPSILON (utils.h:19)
+    t.rqm = fast_rcp(1.f + fast_exp2(-t.c * t.lm));
+    return t;
+}
+// mu/p for an end-point error (ex, ey)
+__device__ __forceinline__ float obs_ratio(const ObsTerms& t, float ex, float ey, float qia2 /* 0.25 / abs_rf^2 */) {
+    const float l = fast_log2(fmaxf((ex * ex + ey * ey) * qia2, 1.4210854822304103e-14f)) + t.ls;
+    const float a = (1.f + fast_exp2(-t.c * l)) * t.rqm;
+    return fast_exp2(t.c1 * (l - t.lm)) * a * a;
+}
+
+// bilinear flow fetch at a position that is known to lie inside [0,w) x [0,h): two 16-byte texel-pair loads (rows yb, yb+1 at
+// column xb).  At the last column / row the pair is shifted inwards and the weight pinned to 1: the same value as clamping.
+__device__ __forceinline__ float2 bilinear2_inside(const float2* __restrict__ img, int w, int h, float x, float y) {
+    const float fx = floorf(x), fy = floorf(y);
+    const int x0 = (int)fx, y0 = (int)fy;
+    const int xb = min(x0, w - 2), yb = min(y0, h - 2);
+    const float a = x0 > xb ? 1.f : x - fx, b = y0 > yb ? 1.f : y - fy;
+    const char* base = reinterpret_cast<const char*>(img);
+    const unsigned off = (unsigned)(yb * w + xb) * 8u;
+    const TexPair r0 = *reinterpret_cast<const TexPair*>(base + off);
+    const TexPair r1 = *reinterpret_cast<const TexPair*>(base + off + (unsigned)w * 8u);
+    const float tx = fmaf(a, r0.bx - r0.ax, r0.ax), ty = fmaf(a, r0.by - r0.ay, r0.ay);
+    const float ux = fmaf(a, r1.bx - r1.ax, r1.ax), uy = fmaf(a, r1.by - r1.ay, r1.ay);
+    return make_float2(fmaf(b, ux - tx, tx), fmaf(b, uy - ty, ty));
+}
+// homogeneous pixel of (x, y, d) under one projective map (PoseBlock::cumM / cumT)
+struct H3 { float x, y, z; };
+__device__ __forceinline__ H3 hom_dir(const float* __restrict__ M, float x, float y) {
+    return { fmaf(M[0], x, fmaf(M[1], y, M[2])), fmaf(M[3], x, fmaf(M[4], y, M[5])), fmaf(M[6], x, fmaf(M[7], y, M[8])) };
+}
+
 // ---- geometry (optimize_depth.cu:54-81) -------------------------------------------------
 struct P3 { float x, y, z; };
 // Geometry and bilinear weights are evaluated with the reference's operation order, true
@@ -125,7 +171,6 @@ __device__ __forceinline__ BilIdx bil_index(float x, float y, int w, int h) {
 // uncoalesced gathers touch per wave instruction, not by bytes: a bilinear fetch is 2 line accesses
 // instead of 4.  Border handling picks the clamped texels out of the pair, so the values are the same
 // as four clamped single-texel fetches.
-struct __attribute__((aligned(8))) TexPair { float ax, ay, bx, by; };
 __device__ __forceinline__ float2 bilinear2(const float2* __restrict__ img, int w, int h, float x, float y) {
 #pragma clang fp contract(off)
     float fx = floorf(x), fy = floorf(y);

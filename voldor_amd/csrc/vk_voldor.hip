@@ -334,7 +334,7 @@ struct BatchJob {
     uint32_t epoch0, epoch_end;  // depth-sampling counter the window starts from / ends at
 };
 class WindowPool {  // persistent workers: worker i owns pool context i of the device it was started on
-    std::mutex mu; std::condition_variable cv_work, cv_done;
+    std::mutex mu, run_mu; std::condition_variable cv_work, cv_done;  // run_mu: one batch at a time per device (callers queue)
     std::vector<std::thread> workers; std::vector<BatchJob>* jobs = nullptr; size_t next = 0; int pending = 0, device = 0; bool stop = false;
     void loop(int i) {
         (void)hipSetDevice(device);
@@ -360,6 +360,7 @@ public:
     explicit WindowPool(int dev) : device(dev) {}
     ~WindowPool() { { std::lock_guard<std::mutex> lk(mu); stop = true; } cv_work.notify_all(); for (auto& t : workers) t.join(); }
     void run(std::vector<BatchJob>& js, int width) {
+        std::lock_guard<std::mutex> serial(run_mu);  // cv_done.wait releases `mu`: without this a second caller could overwrite jobs / next / pending
         std::unique_lock<std::mutex> lk(mu);
         const size_t want = std::min(js.size(), (size_t)std::max(1, width));
         while (workers.size() < want) { const int i = (int)workers.size(); workers.emplace_back([this, i] { loop(i); }); }

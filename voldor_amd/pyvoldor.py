@@ -26,6 +26,40 @@ def _arr(a, ndim, name):
     return a
 
 
+def _check_shapes(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs):
+    """The C side reads w*h*N (resp. N_dp) floats from every buffer: a mismatch must be a Python error, not an overrun."""
+    if len(flows) != 4 or flows[3] != 2:
+        raise ValueError(f"flows must be [N, h, w, 2], got {tuple(flows)}")
+    N, h, w = flows[0], flows[1], flows[2]
+    if N < 1 or N > 16:
+        raise ValueError(f"1 <= N <= 16 flows per window (gpu-kernels/optimize_depth.cu:20), got {N}")
+    for name, shp in (("disparity", disparity), ("disparity_pconf", disparity_pconf)):
+        if shp is not None and tuple(shp) != (h, w):
+            raise ValueError(f"{name} must be [h, w] = {(h, w)}, got {tuple(shp)}")
+    if disparity_pconf is not None and disparity is None:
+        raise ValueError("disparity_pconf without disparity")
+    if depth_priors is not None:
+        if len(depth_priors) != 3 or tuple(depth_priors[1:]) != (h, w):
+            raise ValueError(f"depth_priors must be [N_dp, h, w] with (h, w) = {(h, w)}, got {tuple(depth_priors)}")
+        n_dp = depth_priors[0]
+        if depth_prior_poses is None or tuple(depth_prior_poses) != (n_dp, 6):
+            raise ValueError(f"depth_prior_poses must be [N_dp, 6] = {(n_dp, 6)}, got {None if depth_prior_poses is None else tuple(depth_prior_poses)}")
+        if depth_prior_pconfs is not None and tuple(depth_prior_pconfs) != (n_dp, h, w):
+            raise ValueError(f"depth_prior_pconfs must be [N_dp, h, w] = {(n_dp, h, w)}, got {tuple(depth_prior_pconfs)}")
+    elif depth_prior_poses is not None or depth_prior_pconfs is not None:
+        raise ValueError("depth_prior_poses / depth_prior_pconfs without depth_priors")
+
+
+def last_camera_stats(n):
+    """Per-camera statistics of the last window of this thread (voldor/utils.h:41-45): pose_sample_count, pose_density,
+    pose_rigidness_density, last_used_ms_iters, last_used_gu_iters."""
+    cnt = np.zeros(n, np.int32); dens = np.zeros(n, np.float32); rdens = np.zeros(n, np.float32); ms = np.zeros(n, np.int32); gu = np.zeros(n, np.int32)
+    I = C.POINTER(C.c_int)
+    capi.check(capi.lib().vk_last_camera_stats(cnt.ctypes.data_as(I), capi.fp(dens), capi.fp(rdens), ms.ctypes.data_as(I), gu.ctypes.data_as(I), int(n)),
+               "vk_last_camera_stats")
+    return {"pose_sample_count": cnt, "pose_density": dens, "pose_rigidness_density": rdens, "ms_iters": ms, "gu_iters": gu}
+
+
 def voldor(flows, fx, fy, cx, cy, basefocal=0, disparity=None, disparity_pconf=None, depth_priors=None,
            depth_prior_poses=None, depth_prior_pconfs=None, config=""):
     if flows is None:
@@ -38,6 +72,9 @@ def voldor(flows, fx, fy, cx, cy, basefocal=0, disparity=None, disparity_pconf=N
     depth_prior_pconfs = _arr(depth_prior_pconfs, 3, "depth_prior_pconfs")
     N, h, w = flows.shape[0], flows.shape[1], flows.shape[2]
     N_dp = 0 if depth_priors is None else depth_priors.shape[0]
+    _check_shapes(flows.shape, None if disparity is None else disparity.shape, None if disparity_pconf is None else disparity_pconf.shape,
+                  None if depth_priors is None else depth_priors.shape, None if depth_prior_poses is None else depth_prior_poses.shape,
+                  None if depth_prior_pconfs is None else depth_prior_pconfs.shape)
 
     poses = np.zeros((N, 6), dtype=np.float32)
     poses_covar = np.zeros((N, 6, 6), dtype=np.float32)
@@ -68,6 +105,14 @@ def voldor_device(flows, fx, fy, cx, cy, basefocal=0, disparity=None, disparity_
 
     N, h, w = flows.shape[0], flows.shape[1], flows.shape[2]
     N_dp = 0 if depth_priors is None else depth_priors.shape[0]
+    shp = lambda t: None if t is None else tuple(t.shape)  # noqa: E731
+    _check_shapes(shp(flows), shp(disparity), shp(disparity_pconf), shp(depth_priors), shp(depth_prior_poses), shp(depth_prior_pconfs))
+    for name, t in (("depth_out", depth_out), ("depth_conf_out", depth_conf_out)):
+        if t is not None and tuple(t.shape) != (h, w):
+            raise ValueError(f"{name} must be [h, w] = {(h, w)}, got {tuple(t.shape)}")
+    # The library works on its own (non-blocking) stream: whatever torch still has in flight on the caller's stream (the kernels
+    # or H2D copies that produce these tensors) must have finished before it reads them.  Outputs are complete on return.
+    torch.cuda.current_stream().synchronize()
     poses = np.zeros((N, 6), dtype=np.float32)
     poses_covar = np.zeros((N, 6, 6), dtype=np.float32)
     dpp = None if depth_prior_poses is None else capi.f32(depth_prior_poses)
@@ -101,6 +146,11 @@ def voldor_device_batch(flows_list, fx, fy, cx, cy, basefocal=0, disparity_list=
 
     for t in flows_list:
         assert tuple(t.shape) == (N, h, w, 2)
+    for lst, shape in ((disparity_list, (h, w)), (depth_out, (h, w)), (depth_conf_out, (h, w))):
+        if lst is not None:
+            if len(lst) != B or any(tuple(t.shape) != shape for t in lst):
+                raise ValueError(f"per-window lists must hold {B} tensors of shape {shape}")
+    torch.cuda.current_stream().synchronize()  # see voldor_device: the library's streams do not order with torch's
     poses = np.zeros((B, N, 6), dtype=np.float32)
     covar = np.zeros((B, N, 6, 6), dtype=np.float32)
     nreg = (C.c_int * B)()

@@ -27,6 +27,9 @@ def eval_covisibility(depth, Tc1c2, K, mask=None, stride=4, return_counts=False)
         import torch
         mask = mask.to(torch.uint8)
     mp, _m = ptr(mask, C.c_ubyte, np.uint8)
+    if hasattr(depth, "data_ptr") or hasattr(mask, "data_ptr"):  # the library's stream does not order with torch's (pyvoldor.voldor_device)
+        import torch
+        torch.cuda.current_stream().synchronize()
     T = capi.f32(np.asarray(Tc1c2, np.float32).reshape(4, 4))
     Kf = capi.f32(np.asarray(K, np.float32).reshape(3, 3))
     score = C.c_float(0)
