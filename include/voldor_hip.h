@@ -117,6 +117,8 @@ int vk_set_frame_major_threshold(size_t flow_bytes, size_t depth_order_bytes);
  * results can be compared bit for bit with the CPU oracle in the same mode (parity pinning).  Unset, the
  * default comes from the environment variable VOLDOR_HIP_STRICT_MATH. */
 int vk_set_strict_math(int on);
+/* A/B switch of the fast depth kernels: 1 = lean kernels (default), 0 = the round-1 kernels with the reference's un-fused geometry */
+int vk_set_fast_variant(int v);
 int vk_get_strict_math(void);
 int vk_profile_enable(int on);           /* HIP-event timing of kernel groups on the library's stream */
 int vk_profile_get(const char* name, double* total_ms, long* count);

@@ -1,9 +1,11 @@
-"""Parity of every HIP stage against the CPU oracle, through the C-ABI (B-inner).
+"""Parity of every FAST HIP stage against the CPU oracle (glibc), through the C-ABI (B-inner).
 
-Tolerances: the per-pixel model is fp32 with different transcendental implementations on the
-two sides (glibc powf/expf/logf vs. v_log/v_exp), so maps are compared at 2e-4 relative; the
-discrete `cost < best` decisions of the depth search can flip on near-ties, so depth maps are
-compared on the fraction of pixels that agree (>= 99 %).
+Bit-exact parity is the strict mode's job (tests/test_gpu_strict.py: every stage and whole windows equal the oracle bit for bit).
+The fast kernels differ from the oracle by fp32 rounding: hardware v_log/v_exp/v_rcp instead of glibc powf/expf/logf and IEEE
+division, the rigid chain folded into one projective map per frame (positions move by ~1e-5 px), fused multiply-adds.  A rigidness
+is a steep function of a small end-point error, so a map agrees to ~1e-5 typically and to ~1e-3 at its worst pixel; the discrete
+`cost < best` decisions of the depth search can flip on near-ties, so depth maps are compared on the fraction of pixels that agree
+(>= 99 %).
 """
 import numpy as np
 import pytest
@@ -50,13 +52,18 @@ def _run_both(orc, scene, K, flows, Rs, ts, depth, rig, priors=None, pconfs=None
     return (o_depth, o_rig, o_confs), (g_depth, g_rig, g_confs)
 
 
+def _assert_map_close(a, b, typical=2e-5, worst=3e-3):
+    d = np.abs(a - b)
+    assert np.percentile(d, 99) < 10 * typical and np.median(d) < typical and d.max() < worst, (np.median(d), np.percentile(d, 99), d.max())
+
+
 def test_update_rigidness_only_matches_oracle(orc, small_scene):
     rng = np.random.default_rng(0)
     K = K9(*small_scene["K"])
     flows, Rs, ts, depth, rig = _state(small_scene, rng)
     (od, orig, _), (gd, grig, _) = _run_both(orc, small_scene, K, flows, Rs, ts, depth, rig, update_rigidness_only=1)
     np.testing.assert_array_equal(od, gd)  # depth untouched
-    assert np.abs(orig - grig).max() < 2e-4
+    _assert_map_close(orig, grig)
 
 
 def test_fb_smooth_and_cost_path(orc, small_scene):
@@ -67,7 +74,7 @@ def test_fb_smooth_and_cost_path(orc, small_scene):
     (od, orig, _), (gd, grig, _) = _run_both(orc, small_scene, K, flows, Rs, ts, depth, rig, n_rand_samples=0,
                                              global_prop_step=0, local_prop_width=0)
     np.testing.assert_array_equal(od, gd)
-    assert np.abs(orig - grig).max() < 2e-4
+    _assert_map_close(orig, grig)
 
 
 @pytest.mark.parametrize("stage", ["rand", "global", "local", "all"])
@@ -84,7 +91,7 @@ def test_depth_search_stages(orc, small_scene, stage):
     agree = np.mean(np.abs(od - gd) <= 1e-5 * np.abs(od))
     assert agree >= 0.99, f"{stage}: only {agree:.4f} of depth pixels agree"
     same = np.abs(od - gd) <= 1e-5 * np.abs(od)
-    assert np.abs(orig - grig)[:, same].max() < 5e-4
+    _assert_map_close(orig[:, same], grig[:, same])
 
 
 def test_ragged_size_and_small_segments(orc):
@@ -127,8 +134,8 @@ def test_depth_priors_and_disparity(orc):
     agree = np.mean(np.abs(od - gd) <= 1e-5 * np.abs(od))
     assert agree >= 0.99
     same = np.abs(od - gd) <= 1e-5 * np.abs(od)
-    assert np.abs(orig - grig)[:, same].max() < 5e-4
-    assert np.abs(ocf - gcf)[:, same].max() < 5e-4
+    _assert_map_close(orig[:, same], grig[:, same])
+    _assert_map_close(ocf[:, same], gcf[:, same])
 
 
 def test_only_depth_priors_N0(orc):

@@ -17,6 +17,7 @@
 #include "vk_device.hpp"
 #include "vk_strict_model.hpp"
 #include "vk_internal.hpp"
+#include <cstdlib>
 
 namespace vk {
 
@@ -481,6 +482,471 @@ __global__ __launch_bounds__(64) static void k_local_runs(Img I, int dir, int wi
     }
 }
 
+// =================================================================================================================================
+// LEAN fast path.  Same algorithm, same decisions up to rounding, ~half the VALU instructions of the kernels above (which keep the
+// reference's un-fused fp32 geometry so that they agree bit for bit with the oracle's geometry; that job now belongs to the strict
+// mode, and these are held to the strict kernels by measured distances, tests/test_gpu_strict.py, tests/test_gpu_kernels.py):
+//   * the rigid chain of a hypothesis is ONE projective map per frame (PoseBlock::cumM / cumT, k_cum_poses): the homogeneous
+//     pixel in frame f+1 is d * (cumM[f] (x,y,1)) + cumT[f] -- 3 fma + 1 v_rcp + 2 mul per hypothesis and frame instead of a 3x3
+//     transform, two IEEE divisions and a re-projection; cumM[f] (x,y,1) is shared by all hypotheses of a pixel
+//   * a bilinear fetch at a position known to be inside the image needs no clamps (bilinear2_inside)
+//   * the observation-only half of the residual model is split off (obs_terms: once per gather, once per PIXEL for frame 0)
+// The validity rules (z > 0, previous position inside the image, position advanced on contributing frames only) are unchanged.
+__global__ __launch_bounds__(64) static void k_cum_poses(PoseBlock* P, int N, int N_dp) {
+    __shared__ double Rc[9], tc[3];
+    const int l = threadIdx.x;
+    const double fx = P->K4[0], cx = P->K4[1], fy = P->K4[2], cy = P->K4[3];
+    auto emit = [&](const double* R, const double* t, float* M, float* T) {  // K R K^-1 and K t
+        if (l < 9) {
+            const int r = l / 3, c = l % 3;
+            double kr[3];
+            for (int j = 0; j < 3; j++) kr[j] = r == 0 ? fx * R[j] + cx * R[6 + j] : (r == 1 ? fy * R[3 + j] + cy * R[6 + j] : R[6 + j]);
+            M[l] = (float)(c == 0 ? kr[0] / fx : (c == 1 ? kr[1] / fy : kr[2] - kr[0] * cx / fx - kr[1] * cy / fy));
+        } else if (l < 12) {
+            const int r = l - 9;
+            T[r] = (float)(r == 0 ? fx * t[0] + cx * t[2] : (r == 1 ? fy * t[1] + cy * t[2] : t[2]));
+        }
+    };
+    for (int f = 0; f < N; f++) {
+        const float* R = P->Rs[f]; const float* t = P->ts[f];
+        double nv = 0.0;
+        if (l < 9) {
+            const int r = l / 3, c = l % 3;
+            nv = f == 0 ? (double)R[l] : (double)R[r * 3] * Rc[c] + (double)R[r * 3 + 1] * Rc[3 + c] + (double)R[r * 3 + 2] * Rc[6 + c];
+        } else if (l < 12) {
+            const int r = l - 9;
+            nv = f == 0 ? (double)t[r] : (double)R[r * 3] * tc[0] + (double)R[r * 3 + 1] * tc[1] + (double)R[r * 3 + 2] * tc[2] + (double)t[r];
+        }
+        __syncthreads();
+        if (l < 9) Rc[l] = nv; else if (l < 12) tc[l - 9] = nv;
+        __syncthreads();
+        emit(Rc, tc, P->cumM[f], P->cumT[f]);
+    }
+    for (int f = 0; f < N_dp; f++) {
+        double R[9], t[3];
+        for (int k = 0; k < 9; k++) R[k] = P->dpRs[f][k];
+        for (int k = 0; k < 3; k++) t[k] = P->dpts[f][k];
+        emit(R, t, P->dpM[f], P->dpT[f]);
+    }
+}
+
+struct LeanK { float ia2, qia2, l2q; };  // 1/arf^2, 0.25/arf^2, log2(0.25 lambda^2)
+__device__ __forceinline__ LeanK lean_consts(const Img& I) {
+    LeanK k;
+    k.ia2 = I.inv_arf * I.inv_arf; k.qia2 = 0.25f * k.ia2; k.l2q = fast_log2(0.25f * I.lambda * I.lambda);
+    return k;
+}
+// ONE ARITHMETIC FOR EVERY KERNEL.  The depth search compares the cost a kernel computes now with the cost another kernel stored
+// earlier (`cost < io_cost`, optimize_depth.cu:201-207).  Large regions of a converged map share one depth value, so "the neighbour's
+// depth" is often the pixel's own: if two kernels round the same cost differently, the comparison fires on the last bit, nothing
+// changes but a run starts in k_local_runs (measured at 1080p: 2x the time of that kernel).  Hence a single operation sequence --
+// lean_head (frame 0, then the depth priors), lean_rest (frames 1.. summed in log2 units), cs = head + ln2 * rest, cost = cs * rcp(ws)
+// -- with explicit fma and no compiler contraction, used verbatim by the cost map, the samples, both propagations, and reproduced
+// term by term by the lane-split evaluation of k_local_runs.
+// depth-prior term (optimize_depth.cu:166-190), the prior pose as one projective map: weight and -log(confidence) of the hypothesis
+__device__ __forceinline__ static bool prior_parts(const Img& I, const PoseBlock* P, int f, float x, float y, float depth, float& wg, float& term) {
+#pragma clang fp contract(off)
+    const int w = I.w, h = I.h, npx = w * h;
+    const H3 a = hom_dir(P->dpM[f], x, y);
+    // true divisions here (one per prior, not per frame): the usual prior pose is the identity (disparity of the reference frame),
+    // where the sample must land on the pixel itself and not 1e-5 px beside it
+    const float hz = fmaf(depth, a.z, P->dpT[f][2]);
+    const float qx2 = fmaf(depth, a.x, P->dpT[f][0]) / hz, qy2 = fmaf(depth, a.y, P->dpT[f][1]) / hz;
+    wg = 0.f; term = 0.f;
+    if (!(hz > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h)) return false;
+    const float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+    if (!(td > 0.f)) return false;
+    const float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
+    const float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
+    wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
+    term = 0.6931471805599453f * fast_log2(1.f + depth_ratio(hz, td, I.basefocal, I.omega, I.inv_arf));
+    return true;
+}
+__device__ __forceinline__ static void prior_term_lean(const Img& I, const PoseBlock* P, int f, float x, float y, float depth, float& cost_sum, float& wsum) {
+    float wg, term;
+    if (prior_parts(I, P, f, x, y, depth, wg, term)) { cost_sum = fmaf(wg, term, cost_sum); wsum += wg; }
+}
+// one frame step of the chain: homogeneous pixel -> position in the next frame; returns z > 0
+__device__ __forceinline__ static bool lean_step(const PoseBlock* P, int f, float x, float y, float d, float& px2, float& py2) {
+#pragma clang fp contract(off)
+    const H3 a = hom_dir(P->cumM[f], x, y);
+    const float hz = fmaf(d, a.z, P->cumT[f][2]), iz = fast_rcp(hz);
+    px2 = fmaf(d, a.x, P->cumT[f][0]) * iz; py2 = fmaf(d, a.y, P->cumT[f][1]) * iz;
+    return hz > 0.f;
+}
+// frame 0 (observed at the pixel itself) + depth priors of one hypothesis; leaves the position the chain continues from
+__device__ __forceinline__ static void lean_head(const Img& I, const LeanK& K, const PoseBlock* P, float x, float y, float d, float2 o0, const ObsTerms& T0,
+                                                 float wgt0, float& cs, float& ws, float& px1, float& py1) {
+#pragma clang fp contract(off)
+    cs = 0.f; ws = 0.f; px1 = x; py1 = y;
+    if (I.N > 0) {
+        float px2, py2;
+        if (lean_step(P, 0, x, y, d, px2, py2)) {  // the pixel itself is always inside the image
+            cs = wgt0 * (0.6931471805599453f * fast_log2(1.f + obs_ratio(T0, (px2 - x) - o0.x, (py2 - y) - o0.y, K.qia2)));
+            ws = wgt0;
+            px1 = px2; py1 = py2;
+        }
+    }
+    for (int f = 0; f < I.N_dp; f++) prior_term_lean(I, P, f, x, y, d, cs, ws);
+}
+// frames 1.. of compute_pixel_cost (optimize_depth.cu:140-198): positions of all frames, then all gathers, then the model
+template <int NMAX>
+__device__ __forceinline__ static void lean_rest(const Img& I, const LeanK& K, const PoseBlock* P, int pi, float x, float y, float d, float px1, float py1,
+                                                 float& cs, float& ws) {
+#pragma clang fp contract(off)
+    const int w = I.w, h = I.h, npx = w * h;
+    const float fw = (float)w, fh = (float)h;
+    float qx[NMAX], qy[NMAX], ex[NMAX], ey[NMAX];
+    unsigned valid = 0;
+#pragma unroll
+    for (int f = 1; f < NMAX; f++) {
+        qx[f] = 0.f; qy[f] = 0.f; ex[f] = 0.f; ey[f] = 0.f;
+        if (f < I.N) {
+            float px2, py2;
+            const bool zok = lean_step(P, f, x, y, d, px2, py2);
+            if (zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh) {
+                valid |= 1u << f;
+                qx[f] = px1; qy[f] = py1; ex[f] = px2 - px1; ey[f] = py2 - py1;
+                px1 = px2; py1 = py2;  // advances on contributing frames only (:162-164)
+            }
+        }
+    }
+    float2 obs[NMAX];
+    float wgt[NMAX];
+#pragma unroll
+    for (int f = 1; f < NMAX; f++) {
+        obs[f] = make_float2(0.f, 0.f); wgt[f] = 0.f;
+        if (f < I.N) { obs[f] = bilinear2_inside(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]); wgt[f] = I.rig[(size_t)f * npx + pi]; }
+    }
+    float cl = 0.f;
+#pragma unroll
+    for (int f = 1; f < NMAX; f++) {
+        if (f < I.N && ((valid >> f) & 1u)) {
+            const ObsTerms T = obs_terms(obs[f].x, obs[f].y, K.ia2, K.l2q);
+            cl = fmaf(wgt[f], fast_log2(1.f + obs_ratio(T, ex[f] - obs[f].x, ey[f] - obs[f].y, K.qia2)), cl);
+            ws += wgt[f];
+        }
+    }
+    cs = fmaf(0.6931471805599453f, cl, cs);
+}
+__device__ __forceinline__ float lean_final(float cs, float ws) {
+#pragma clang fp contract(off)
+    return ws == 0.f ? INFINITY : cs * fast_rcp(fmaxf(ws, 1.1920929e-07f));
+}
+// the whole cost of one hypothesis at pixel (px, py)
+template <int NMAX>
+__device__ __forceinline__ static float pixel_cost_lean(const Img& I, const LeanK& K, int px, int py, float depth) {
+    const int pi = py * I.w + px;
+    const float x = (float)px, y = (float)py;
+    const float2 o0 = I.N > 0 ? I.flows[pi] : make_float2(0.f, 0.f);
+    const ObsTerms T0 = obs_terms(o0.x, o0.y, K.ia2, K.l2q);
+    const float wgt0 = I.N > 0 ? I.rig[pi] : 0.f;
+    float cs, ws, px1, py1;
+    lean_head(I, K, I.P, x, y, depth, o0, T0, wgt0, cs, ws, px1, py1);
+    lean_rest<NMAX>(I, K, I.P, pi, x, y, depth, px1, py1, cs, ws);
+    return lean_final(cs, ws);
+}
+
+// ---- cost map + random samples with EXACT EARLY REJECTION and SURVIVOR COMPACTION ---------------------------------------------------
+// (a) The cost is sum(w_f c_f) / sum(w_f) over the contributing frames with every c_f >= 0, so after the part that needs no divergent
+// gather (lean_head: frame 0 and the depth priors) the final cost is at least cs / (ws + wrest), wrest = the weight frames 1.. can
+// add at most.  A random sample is only ever compared with the running best (`cost < best`, optimize_depth.cu:201-207): once that
+// lower bound exceeds the incumbent's cost the outcome is decided.  Most random depths are far off and die here, before the gathers at
+// positions that differ from lane to lane (64 distinct cache lines per load instruction: what the round-1 kernel was bound by).  The
+// 1e-5 margin keeps the float rounding of the final quotient on the safe side: near-ties are evaluated in full.
+// (b) Rejection alone spares the loads of a dead sample, not its VALU slots: a wave keeps issuing frames 1.. of sample k as long as ONE
+// of its 64 lanes has it alive (measured: same instruction count as without rejection).  So the survivors of a workgroup's 64x4 pixel
+// tile are appended to a queue in LDS and frames 1.. are evaluated over the QUEUE, one entry per lane, dense: ~2 full evaluations per
+// pixel instead of 10.
+//   1. every lane evaluates its pixel's incumbent depth in full (its cost is the rejection bound)
+//   2. per round of CRQ_NS samples: lean_head of each sample -> survivors into the queue
+//   3. queue entries (pixel, sample, depth, partial sums) are evaluated by whichever lane picks them up; the result goes into the
+//      pixel's 64-bit LDS slot with atomicMin on (cost bits << 32 | sample index): the cheapest sample, the earliest among equals --
+//      the one the sequential rule of optimize_depth.cu:269-277 would end up with
+//   4. the pixel takes the winner if it is strictly cheaper than its running best
+// The result does not depend on the order in which entries enter or leave the queue.
+constexpr int CRQ_NS = 5;  // samples per round: queue capacity 256 * CRQ_NS entries (20 KB of LDS)
+struct CrqEntry { unsigned id; float d, cs, ws; };  // id = lane-in-workgroup | sample << 8
+__device__ __forceinline__ float sample_depth(int pi, uint32_t epoch, float range_factor) {
+    const float u = u01(rng3(RAND_SEED, (uint32_t)pi, epoch));
+    return 1.0f / (range_factor * u + (1.0f / 1e5f));  // MAXIMUM_DEPTH, optimize_depth.cu:15,:273 (exact: the depth VALUES are outputs)
+}
+template <int NMAX>
+__global__ __launch_bounds__(256) static void k_cost_rand_q(Img I, int n_rand, uint32_t epoch0, float range_factor) {
+    __shared__ unsigned long long s_best[256];
+    __shared__ CrqEntry s_q[256 * CRQ_NS];
+    __shared__ int s_qn;
+    if (!clamp_active(I)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int x0 = (tile % gridDim.x) * 64, y0 = (tile / gridDim.x) * 4;
+    const int xi = x0 + lane, yi = y0 + (tid >> 6);
+    const bool live = xi < I.w && yi < I.h;
+    const int w = I.w, npx = w * I.h, pi = live ? yi * w + xi : 0;
+    const PoseBlock* P = I.P;
+    const LeanK K = lean_consts(I);
+    const float x = (float)(live ? xi : 0), y = (float)(live ? yi : 0);
+    const float2 o0 = I.N > 0 ? I.flows[pi] : make_float2(0.f, 0.f);
+    const ObsTerms T0 = obs_terms(o0.x, o0.y, K.ia2, K.l2q);
+    const float wgt0 = I.N > 0 ? I.rig[pi] : 0.f;
+    float wrest = 0.f;
+    for (int f = 1; f < I.N; f++) wrest += I.rig[(size_t)f * npx + pi];
+    // 1. the incumbent
+    float d_best = I.depth[pi], c_best;
+    {
+        float cs, ws, px1, py1;
+        lean_head(I, K, P, x, y, d_best, o0, T0, wgt0, cs, ws, px1, py1);
+        lean_rest<NMAX>(I, K, P, pi, x, y, d_best, px1, py1, cs, ws);
+        c_best = lean_final(cs, ws);
+    }
+    for (int it = 0; it < n_rand; it += CRQ_NS) {
+        const int nh = min(CRQ_NS, n_rand - it);
+        s_best[tid] = ~0ull;
+        if (tid == 0) s_qn = 0;
+        __syncthreads();
+        // 2. heads of this round's samples; survivors enter the queue (one LDS atomic per wave and sample)
+        for (int k = 0; k < nh; k++) {
+            const float d = sample_depth(pi, epoch0 + (uint32_t)(it + k), range_factor);
+            float cs, ws, px1, py1;
+            lean_head(I, K, P, x, y, d, o0, T0, wgt0, cs, ws, px1, py1);
+            const bool alive = live && !(cs > c_best * (ws + wrest) * 1.00001f);
+            const unsigned long long m = __ballot(alive);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_qn, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (alive) s_q[base + __popcll(m & ((1ull << lane) - 1ull))] = { (unsigned)tid | ((unsigned)k << 8), d, cs, ws };
+        }
+        __syncthreads();
+        // 3. frames 1.. over the queue
+        const int qn = s_qn;
+        for (int e = tid; e < qn; e += 256) {
+            const CrqEntry q = s_q[e];
+            const int t = (int)(q.id & 255u), k = (int)(q.id >> 8);
+            const int ex_ = x0 + (t & 63), ey_ = y0 + (t >> 6), epi = ey_ * w + ex_;
+            const float fx_ = (float)ex_, fy_ = (float)ey_;
+            float px1 = fx_, py1 = fy_;
+            if (I.N > 0) {  // where the chain stands after frame 0 (the same step lean_head took)
+                float px2, py2;
+                if (lean_step(P, 0, fx_, fy_, q.d, px2, py2)) { px1 = px2; py1 = py2; }
+            }
+            float cs = q.cs, ws = q.ws;
+            lean_rest<NMAX>(I, K, P, epi, fx_, fy_, q.d, px1, py1, cs, ws);
+            const float c = lean_final(cs, ws);
+            if (c == c)  // costs are >= 0: their bit patterns order like the values
+                atomicMin(&s_best[t], ((unsigned long long)__float_as_uint(fmaxf(c, 0.f)) << 32) | (unsigned)k);
+        }
+        __syncthreads();
+        // 4. the cheapest survivor against the running best
+        const unsigned long long key = s_best[tid];
+        if (key != ~0ull) {
+            const float c = __uint_as_float((unsigned)(key >> 32));
+            if (c < c_best) { c_best = c; d_best = sample_depth(pi, epoch0 + (uint32_t)(it + (int)(key & 0xffu)), range_factor); }
+        }
+        __syncthreads();
+    }
+    if (live) { I.depth[pi] = d_best; I.cost[pi] = c_best; }
+}
+
+template <int NMAX>
+__device__ __forceinline__ static void try_depth_lean(const Img& I, const LeanK& K, int x, int y, float cand) {
+    const int pi = y * I.w + x;
+    const float c = pixel_cost_lean<NMAX>(I, K, x, y, cand);
+    if (c < I.cost[pi]) { I.depth[pi] = cand; I.cost[pi] = c; }
+}
+template <int NMAX>
+__global__ __launch_bounds__(256) static void k_global_prop_sites_lean(Img I, int dir, int step, int nsites) {
+    if (!clamp_active(I)) return;
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int s = (tile % gridDim.x) * blockDim.x + threadIdx.x;
+    const int l = tile / gridDim.x;
+    if (s >= nsites) return;
+    const LeanK K = lean_consts(I);
+    if (dir == 0) { int x = 1 + s * step; try_depth_lean<NMAX>(I, K, x, l, I.depth[l * I.w + x - 1]); }
+    else if (dir == 2) { int x = I.w - 2 - s * step; try_depth_lean<NMAX>(I, K, x, l, I.depth[l * I.w + x + 1]); }
+    else if (dir == 1) { int y = 1 + s * step; try_depth_lean<NMAX>(I, K, l, y, I.depth[(y - 1) * I.w + l]); }
+    else { int y = I.h - 2 - s * step; try_depth_lean<NMAX>(I, K, l, y, I.depth[(y + 1) * I.w + l]); }
+}
+template <int NMAX>
+__global__ __launch_bounds__(256) static void k_local_table_lean(Img I, int dir, int width, float* __restrict__ tbl) {
+    if (!clamp_active(I)) return;
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63), y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
+    if (x >= I.w || y >= I.h) return;
+    const int w = I.w, h = I.h;
+    bool member; int nb;
+    if (dir == 0) { member = x >= 1 && (x % width) != 0; nb = y * w + x - 1; }
+    else if (dir == 2) { member = x <= w - 2 && (x % width) != width - 1; nb = y * w + x + 1; }
+    else if (dir == 1) { member = y >= 1 && (y % width) != 0; nb = (y - 1) * w + x; }
+    else { member = y <= h - 2 && (y % width) != width - 1; nb = (y + 1) * w + x; }
+    if (!member) return;
+    tbl[y * w + x] = pixel_cost_lean<NMAX>(I, lean_consts(I), x, y, I.depth[nb]);
+}
+// Lane-split evaluation for k_local_runs_lean (8 lanes per pixel, lane g owns frames g and g+8 and priors g, g+8): every lane walks the
+// (cheap) chain of positions, evaluates the gathers and residuals of its own frames, and the terms are combined through 8-wide
+// shuffles in exactly the order of lean_head / lean_rest -- frame 0, priors, frames 1.. in log2 units, one scale by ln 2 -- so the value
+// has the bits pixel_cost_lean gives for the same pixel and depth.
+__device__ __forceinline__ static float cost_split8_lean(const Img& I, const LeanK& K, int px, int py, float depth, int g) {
+#pragma clang fp contract(off)
+    const int w = I.w, h = I.h, npx = w * h, pi = py * w + px;
+    const PoseBlock* P = I.P;
+    const float x = (float)px, y = (float)py, fw = (float)w, fh = (float)h;
+    float qx0 = 0.f, qy0 = 0.f, ex0 = 0.f, ey0 = 0.f, qx1 = 0.f, qy1 = 0.f, ex1 = 0.f, ey1 = 0.f;
+    bool v0 = false, v1 = false;
+    {
+        float px1 = x, py1 = y;
+        for (int f = 0; f < I.N; f++) {  // uniform trip count: no divergence inside the group
+            float px2, py2;
+            const bool zok = lean_step(P, f, x, y, depth, px2, py2);
+            const bool valid = f == 0 ? zok : (zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh);
+            if (f == g) { v0 = valid; qx0 = px1; qy0 = py1; ex0 = px2 - px1; ey0 = py2 - py1; }
+            if (f == g + 8) { v1 = valid; qx1 = px1; qy1 = py1; ex1 = px2 - px1; ey1 = py2 - py1; }
+            if (valid) { px1 = px2; py1 = py2; }
+        }
+    }
+    // own terms: frame g -> (weight, log2(1 + ratio)); the owner of frame 0 applies ln 2 and the weight like lean_head
+    float wt0 = 0.f, lt0 = 0.f, wt1 = 0.f, lt1 = 0.f;
+    if (v0) {
+        const float2 ob = g == 0 ? I.flows[pi] : bilinear2_inside(I.flows + (size_t)g * npx, w, h, qx0, qy0);
+        wt0 = I.rig[(size_t)g * npx + pi];
+        const ObsTerms T = obs_terms(ob.x, ob.y, K.ia2, K.l2q);
+        lt0 = fast_log2(1.f + obs_ratio(T, ex0 - ob.x, ey0 - ob.y, K.qia2));
+        if (g == 0) lt0 = wt0 * (0.6931471805599453f * lt0);  // = the cs lean_head starts from
+    }
+    if (I.N > 8 && v1) {
+        const float2 ob = bilinear2_inside(I.flows + (size_t)(g + 8) * npx, w, h, qx1, qy1);
+        wt1 = I.rig[(size_t)(g + 8) * npx + pi];
+        const ObsTerms T = obs_terms(ob.x, ob.y, K.ia2, K.l2q);
+        lt1 = fast_log2(1.f + obs_ratio(T, ex1 - ob.x, ey1 - ob.y, K.qia2));
+    }
+    float pw0 = 0.f, pt0 = 0.f, pw1 = 0.f, pt1 = 0.f;
+    bool pk0 = false, pk1 = false;
+    if (g < I.N_dp) pk0 = prior_parts(I, P, g, x, y, depth, pw0, pt0);
+    if (g + 8 < I.N_dp) pk1 = prior_parts(I, P, g + 8, x, y, depth, pw1, pt1);
+    // combine in the order of lean_head / lean_rest
+    float cs = 0.f, ws = 0.f;
+    if (I.N > 0 && __shfl((int)v0, 0, 8)) { cs = __shfl(lt0, 0, 8); ws = __shfl(wt0, 0, 8); }
+    for (int f = 0; f < I.N_dp; f++) {
+        const int ok = __shfl((int)((f & 8) ? pk1 : pk0), f & 7, 8);
+        const float wg = __shfl((f & 8) ? pw1 : pw0, f & 7, 8), term = __shfl((f & 8) ? pt1 : pt0, f & 7, 8);
+        if (ok) { cs = fmaf(wg, term, cs); ws += wg; }
+    }
+    float cl = 0.f;
+    for (int f = 1; f < I.N; f++) {
+        const int ok = __shfl((int)((f & 8) ? v1 : v0), f & 7, 8);
+        const float wg = __shfl((f & 8) ? wt1 : wt0, f & 7, 8), lt = __shfl((f & 8) ? lt1 : lt0, f & 7, 8);
+        if (ok) { cl = fmaf(wg, lt, cl); ws += wg; }
+    }
+    cs = fmaf(0.6931471805599453f, cl, cs);
+    return lean_final(cs, ws);
+}
+__global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, int width, const float* __restrict__ tbl) {
+    if (!clamp_active(I)) return;
+    const int lane = threadIdx.x, g = lane >> 3, sub = lane & 7;
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const ChainGeom cg = chain_geom(I.w, I.h, dir, width, tile % gridDim.x, tile / gridDim.x);
+    const int n = cg.n;
+    if (n <= 0) return;
+    const LeanK K = lean_consts(I);
+    const bool has = lane < n;
+    const int mypi = has ? cg.pi0 + lane * cg.stride : cg.pi0;
+    const float d0 = has ? I.depth[mypi] : 0.f, c0 = has ? I.cost[mypi] : 0.f, t0 = has ? tbl[mypi] : INFINITY;
+    const float first_cand = I.depth[cg.prev0];
+    int x = 0;
+    while (x < n) {  // see k_local_runs
+        const unsigned long long am = __ballot(has && lane >= x && t0 < c0);
+        if (am == 0ull) break;
+        const int xa = __ffsll((long long)am) - 1;
+        const float dprev = __shfl(d0, max(xa - 1, 0), 64);
+        const float v = xa == 0 ? first_cand : dprev;
+        if (lane == xa) { I.depth[mypi] = v; I.cost[mypi] = t0; }
+        x = xa + 1;
+        bool running = true;
+        while (running && x < n) {
+            const int px = x + g;
+            const bool act = px < n;
+            const int pi = act ? cg.pi0 + px * cg.stride : cg.pi0;
+            const float c = cost_split8_lean(I, K, pi % I.w, pi / I.w, v, sub);
+            const float c0p = __shfl(c0, min(px, 63), 64);
+            const bool acc = act && c < c0p;
+            const unsigned long long rej = __ballot(!acc);
+            const int L = (__ffsll((long long)rej) - 1) >> 3;
+            const int Lacc = rej == 0ull ? 8 : L;
+            if (g < Lacc && sub == 0) { I.depth[pi] = v; I.cost[pi] = c; }
+            x += Lacc;
+            if (Lacc < 8) { running = false; x += 1; }
+        }
+    }
+}
+// E-step (optimize_depth.cu:84-138), lean geometry and model; per-block rigidness sums as k_update_rigidness
+template <int NMAX>
+__global__ __launch_bounds__(256) static void k_update_rigidness_lean(Img I, float* __restrict__ partial) {
+    if (!clamp_active(I)) return;
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int xi = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
+    const int yi = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
+    const bool live = xi < I.w && yi < I.h;
+    const int w = I.w, h = I.h, npx = w * h, pi = live ? yi * w + xi : 0;
+    const PoseBlock* P = I.P;
+    const LeanK K = lean_consts(I);
+    __shared__ float s_part[NMAX][4];
+    const int blk = tile, nblk = gridDim.x * gridDim.y;
+    const float d = live ? I.depth[pi] : 1.f;
+    const float x = (float)(live ? xi : 0), y = (float)(live ? yi : 0), fw = (float)w, fh = (float)h;
+    float qx[NMAX], qy[NMAX], rdx[NMAX], rdy[NMAX];
+    unsigned valid = 0;
+    {
+        float px1 = x, py1 = y;
+#pragma unroll
+        for (int f = 0; f < NMAX; f++) {
+            qx[f] = 0.f; qy[f] = 0.f; rdx[f] = 0.f; rdy[f] = 0.f;
+            if (f < I.N) {
+                float px2, py2;
+                const bool zok = lean_step(P, f, x, y, d, px2, py2);
+                if (live && zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh) {
+                    valid |= 1u << f;
+                    qx[f] = px1; qy[f] = py1; rdx[f] = px2 - px1; rdy[f] = py2 - py1;
+                    px1 = px2; py1 = py2;  // NOT advanced on invalid frames
+                }
+            }
+        }
+    }
+    float2 obs[NMAX];
+#pragma unroll
+    for (int f = 0; f < NMAX; f++) {
+        obs[f] = make_float2(0.f, 0.f);
+        if (f < I.N) obs[f] = (f == 0) ? I.flows[pi] : bilinear2_inside(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < NMAX; f++) {
+        if (f < I.N) {
+            float r = 0.f;
+            if ((valid >> f) & 1u) {
+                const ObsTerms T = obs_terms(obs[f].x, obs[f].y, K.ia2, K.l2q);
+                r = fast_rcp(1.f + obs_ratio(T, rdx[f] - obs[f].x, rdy[f] - obs[f].y, K.qia2));
+            }
+            if (live) I.rig[(size_t)f * npx + pi] = r;
+            const float ws = wave_sum(live ? r : 0.f);
+            if ((threadIdx.x & 63) == 0) s_part[f][threadIdx.x >> 6] = ws;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NMAX && (int)threadIdx.x < I.N) {
+        const int f = threadIdx.x;
+        partial[(size_t)f * nblk + blk] = (s_part[f][0] + s_part[f][1]) + (s_part[f][2] + s_part[f][3]);
+    }
+    if (!live) return;
+    for (int f = 0; f < I.N_dp; f++) {
+        const H3 a = hom_dir(P->dpM[f], x, y);
+        const float hz = fmaf(d, a.z, P->dpT[f][2]);
+        const float qx2 = fmaf(d, a.x, P->dpT[f][0]) / hz, qy2 = fmaf(d, a.y, P->dpT[f][1]) / hz;  // see prior_parts
+        if (hz > 0.f && qx2 >= 0.f && qx2 < fw && qy2 >= 0.f && qy2 < fh) {
+            const float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+            if (td > 0.f) I.confs[(size_t)f * npx + pi] = fast_rcp(1.f + depth_ratio(hz, td, I.basefocal, I.omega, I.inv_arf));
+        } else
+            I.confs[(size_t)f * npx + pi] = 0.f;
+    }
+}
+
 // ---- E-step (optimize_depth.cu:84-138) + per-block sums of each rigidness map (the density
 // test of voldor.cpp:171 then needs no D2H of the maps).  Same three-phase structure as pixel_cost.
 template <int NMAX, bool STRICT = false>
@@ -837,10 +1303,81 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
     VK_CHECK_LAST();
     return 0;
 }
+// the lean fast path: same stage order, lean kernels (see k_cum_poses)
+static int g_fast_variant = -1;  // 1 lean (default), 0 legacy kernels (A/B measurements: VOLDOR_HIP_LEAN=0 / vk_set_fast_variant)
+void set_fast_variant(int v) { g_fast_variant = v; }
+static bool lean_enabled() {
+    if (g_fast_variant < 0) { const char* e = getenv("VOLDOR_HIP_LEAN"); g_fast_variant = e ? atoi(e) : 1; }
+    return g_fast_variant != 0;
+}
+template <int NMAX>
+static int optimize_depth_launch_lean(Context* c, ImageSet& S, const OdParams& p, bool cost_only) {
+    const int w = p.w, h = p.h;
+    Img I = make_img(S, p);
+    const dim3 gpx((w + 63) / 64, (h + 3) / 4), bpx(256);
+    hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, S.pb(), p.N, p.N_dp);
+    if (cost_only) {
+        hipLaunchKernelGGL(k_cost_rand_q<NMAX>, gpx, bpx, 0, c->stream, I, 0, 0u, p.range_factor);
+        VK_CHECK_LAST();
+        return 0;
+    }
+    if (!p.update_rigidness_only) {
+        if (p.fb_smooth) {
+            if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active)) return e;
+            if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e;
+        }
+        if (c->prof) prof_begin_inner(c);
+        hipLaunchKernelGGL(k_cost_rand_q<NMAX>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
+        if (c->prof) prof_end_inner(c, "cost_rand", 1);
+        c->rand_epoch += (uint32_t)(p.n_rand_samples > 0 ? p.n_rand_samples : 0);
+        const int order[4] = { 0, 3, 2, 1 };  // L2R, B2T, R2L, T2B (:481-484, :487-490)
+        if (p.global_prop_step > 0) {
+            for (int k = 0; k < 4; k++) {
+                const int dir = order[k];
+                const bool rowpass = (dir == 0 || dir == 2);
+                const int len = rowpass ? w : h, lines = rowpass ? h : w;
+                if (p.global_prop_step >= 2) {
+                    const int nsites = (len - 1 + p.global_prop_step - 1) / p.global_prop_step;
+                    if (nsites > 0)
+                        hipLaunchKernelGGL(k_global_prop_sites_lean<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
+                } else  // step 1 is a true serial chain: not used by any shipped config, served by the legacy kernel
+                    hipLaunchKernelGGL((k_global_prop_serial<NMAX, false>), dim3((lines + 63) / 64), dim3(64), 0, c->stream, I, dir);
+            }
+        }
+        if (p.local_prop_width > 0) {
+            if (c->prof) prof_begin_inner(c);
+            for (int k = 0; k < 4; k++) {
+                const int dir = order[k];
+                const bool rowpass = (dir == 0 || dir == 2);
+                const int len = rowpass ? w : h, lines = rowpass ? h : w;
+                const int nseg = (len + p.local_prop_width - 1) / p.local_prop_width;
+                if (p.local_prop_width <= 65) {
+                    hipLaunchKernelGGL(k_local_table_lean<NMAX>, gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
+                    hipLaunchKernelGGL(k_local_runs_lean, dim3(lines, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
+                } else
+                    hipLaunchKernelGGL((k_local_serial<NMAX, false>), dim3((lines + 63) / 64, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
+            }
+            if (c->prof) prof_end_inner(c, "local_pass", 4);
+        }
+    }
+    const int nblk = gpx.x * gpx.y;
+    hipLaunchKernelGGL(k_update_rigidness_lean<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
+    if (p.N > 0)
+        hipLaunchKernelGGL(k_reduce_density, dim3(p.N + (p.world_scale_out ? 1 : 0)), dim3(256), 0, c->stream, c->rig_partial.as<float>(), nblk,
+                           w * h, c->cams.as<CamState>(), S.pb(), p.N, p.world_scale_out);
+    VK_CHECK_LAST();
+    return 0;
+}
 static int optimize_depth_dispatch(Context* c, ImageSet& S, const OdParams& p, bool cost_only) {
     if (p.strict) {  // parity-pinning mode: two frame bounds are enough
         if (p.N <= 8) return optimize_depth_launch<8, true>(c, S, p, cost_only);
         return optimize_depth_launch<16, true>(c, S, p, cost_only);
+    }
+    if (lean_enabled() && p.w >= 2 && p.h >= 2) {
+        if (p.N <= 4) return optimize_depth_launch_lean<4>(c, S, p, cost_only);
+        if (p.N <= 6) return optimize_depth_launch_lean<6>(c, S, p, cost_only);
+        if (p.N <= 8) return optimize_depth_launch_lean<8>(c, S, p, cost_only);
+        return optimize_depth_launch_lean<16>(c, S, p, cost_only);
     }
     if (p.N <= 4) return optimize_depth_launch<4, false>(c, S, p, cost_only);
     if (p.N <= 6) return optimize_depth_launch<6, false>(c, S, p, cost_only);  // the SLAM driver's window is 5 flows (voldor_slam.py:85)

@@ -93,7 +93,8 @@ __device__ __forceinline__ float depth_ratio(float d1, float d2, float basefocal
 struct __attribute__((aligned(8))) TexPair { float ax, ay, bx, by; };  // two horizontally adjacent flow texels
 struct ObsTerms { float c, c1, ls, lm, rqm; };
 __device__ __forceinline__ ObsTerms obs_terms(float ox, float oy, float ia2, float log2_qlam2 /* log2(0.25 lambda^2) */) {
-    const float obs2 = (ox * ox + oy * oy) * ia2;
+#pragma clang fp contract(off)  // explicit fma only: every kernel must get the same bits (vk_depth.hip "one arithmetic")
+    const float obs2 = fmaf(ox, ox, oy * oy) * ia2;
     const float g = __builtin_amdgcn_fmed3f(0.5f * fast_sqrt(obs2), 2.f, 100.f);  // residual_model.h:16
     ObsTerms t;
     t.c = fmaf(-0.0022f, g, 1.0f);
@@ -105,7 +106,8 @@ __device__ __forceinline__ ObsTerms obs_terms(float ox, float oy, float ia2, flo
 }
 // mu/p for an end-point error (ex, ey)
 __device__ __forceinline__ float obs_ratio(const ObsTerms& t, float ex, float ey, float qia2 /* 0.25 / abs_rf^2 */) {
-    const float l = fast_log2(fmaxf((ex * ex + ey * ey) * qia2, 1.4210854822304103e-14f)) + t.ls;
+#pragma clang fp contract(off)
+    const float l = fast_log2(fmaxf(fmaf(ex, ex, ey * ey) * qia2, 1.4210854822304103e-14f)) + t.ls;
     const float a = (1.f + fast_exp2(-t.c * l)) * t.rqm;
     return fast_exp2(t.c1 * (l - t.lm)) * a * a;
 }
@@ -113,6 +115,7 @@ __device__ __forceinline__ float obs_ratio(const ObsTerms& t, float ex, float ey
 // bilinear flow fetch at a position that is known to lie inside [0,w) x [0,h): two 16-byte texel-pair loads (rows yb, yb+1 at
 // column xb).  At the last column / row the pair is shifted inwards and the weight pinned to 1: the same value as clamping.
 __device__ __forceinline__ float2 bilinear2_inside(const float2* __restrict__ img, int w, int h, float x, float y) {
+#pragma clang fp contract(off)
     const float fx = floorf(x), fy = floorf(y);
     const int x0 = (int)fx, y0 = (int)fy;
     const int xb = min(x0, w - 2), yb = min(y0, h - 2);
@@ -128,6 +131,7 @@ __device__ __forceinline__ float2 bilinear2_inside(const float2* __restrict__ im
 // homogeneous pixel of (x, y, d) under one projective map (PoseBlock::cumM / cumT)
 struct H3 { float x, y, z; };
 __device__ __forceinline__ H3 hom_dir(const float* __restrict__ M, float x, float y) {
+#pragma clang fp contract(off)
     return { fmaf(M[0], x, fmaf(M[1], y, M[2])), fmaf(M[3], x, fmaf(M[4], y, M[5])), fmaf(M[6], x, fmaf(M[7], y, M[8])) };
 }
 

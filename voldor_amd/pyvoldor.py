@@ -31,8 +31,6 @@ def _check_shapes(flows, disparity, disparity_pconf, depth_priors, depth_prior_p
     if len(flows) != 4 or flows[3] != 2:
         raise ValueError(f"flows must be [N, h, w, 2], got {tuple(flows)}")
     N, h, w = flows[0], flows[1], flows[2]
-    if N < 1 or N > 16:
-        raise ValueError(f"1 <= N <= 16 flows per window (gpu-kernels/optimize_depth.cu:20), got {N}")
     for name, shp in (("disparity", disparity), ("disparity_pconf", disparity_pconf)):
         if shp is not None and tuple(shp) != (h, w):
             raise ValueError(f"{name} must be [h, w] = {(h, w)}, got {tuple(shp)}")
