@@ -68,7 +68,6 @@ def main():
     ap.add_argument("--cpu-windows", type=int, default=2)
     ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed seconds of windows before the warm-up steps (GPU clock ramp-up)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
-    ap.add_argument("--frame-major-mb", type=int, default=-1, help="A/B only: flow-layer size above which the frame-major cost pass runs (library default 24)")
     ap.add_argument("--in-flight", type=int, default=4, help="windows in flight for the extra 'concurrent' measurement (0 = skip)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -92,8 +91,6 @@ def main():
     from voldor_amd import dist as vdist
 
     lib = capi.lib()
-    if args.frame_major_mb >= 0:
-        lib.vk_set_frame_major_threshold(C.c_size_t(args.frame_major_mb << 20), C.c_size_t(64 << 20))
     basefocal = wl["basefocal"]
     sc = synth.make_scene(w=W, h=H, n_flows=N_FLOW, fx=FX, fy=FY, cx=CX, cy=CY, seed=233 + rank,
                           basefocal=basefocal if wl["mode"] != "mono" else 0.0)

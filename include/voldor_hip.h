@@ -107,18 +107,11 @@ int vk_estimate_depth_closed_form(const float* h_flow, const float* h_K, const f
 int vk_get_compacted_points(float* h_o_pts2, float* h_o_pts3, int max_points); /* returns n_points (<0 error) */
 int vk_set_rand_epoch(unsigned epoch);   /* depth-sampling RNG counter of the current context */
 unsigned vk_get_rand_epoch(void);
-/* The cost-map + random-sample pass has two loop orders with the same results (up to fma-contraction ties, <= 1e-5 of the
- * pixels): hypothesis-major for flow layers that fit the L2s, frame-major above `flow_bytes` (default 24 MiB), and frame-major
- * with the hypotheses of a pixel evaluated in depth order above `depth_order_bytes` (default 64 MiB; 1080p windows).  Tests and
- * A/B measurements force a variant with 0 / SIZE_MAX. */
-int vk_set_frame_major_threshold(size_t flow_bytes, size_t depth_order_bytes);
 /* Strict-math mode (process-wide default; the window call also takes the config key --strict_math 0|1): every stage runs in
  * the reference's operation order on software transcendentals (voldor_amd/csrc/vk_strict_math.h), a few times slower, so that
  * results can be compared bit for bit with the CPU oracle in the same mode (parity pinning).  Unset, the
  * default comes from the environment variable VOLDOR_HIP_STRICT_MATH. */
 int vk_set_strict_math(int on);
-/* A/B switch of the fast depth kernels: 1 = lean kernels (default), 0 = the round-1 kernels with the reference's un-fused geometry */
-int vk_set_fast_variant(int v);
 int vk_get_strict_math(void);
 int vk_profile_enable(int on);           /* HIP-event timing of kernel groups on the library's stream */
 int vk_profile_get(const char* name, double* total_ms, long* count);

@@ -155,9 +155,12 @@ def test_only_depth_priors_N0(orc):
     (od, _, ocf), (gd, _, gcf) = _run_both(orc, sc, K, flows, None, None, depth, rig, priors, pconfs, confs, dp_Rs, dp_ts, delta=0.5,
                                            basefocal=24.0)  # basefocal 0 would make every prior cost tie exactly
     agree = np.mean(np.abs(od - gd) <= 1e-5 * np.abs(od))
-    # two priors that agree to 5 %: flat cost valleys, i.e. many near-ties between candidates
-    assert agree >= 0.97
-    assert np.abs(ocf - gcf)[:, np.abs(od - gd) <= 1e-5 * np.abs(od)].max() < 5e-4
+    # two priors that agree to 5 %: flat cost valleys, i.e. many near-ties between candidates, decided by the last bits of the
+    # projection (fast path: one projective map + v_rcp; oracle: un-fused chain + IEEE division).  Strict mode has no such slack
+    # (tests/test_gpu_strict.py::test_strict_optimize_depth_with_priors_and_ragged_size_bits).
+    assert agree >= 0.94
+    same = np.abs(od - gd) <= 1e-5 * np.abs(od)
+    _assert_map_close(ocf[:, same], gcf[:, same])
 
 
 def test_null_protocol_reuses_device_copies(orc, small_scene):
@@ -327,14 +330,13 @@ def test_fb_smooth_alone_matches_oracle(orc, w, h):
     assert np.abs(o - g).max() < 2e-5
 
 
-@pytest.mark.parametrize("with_priors,n_rand", [(False, 10), (True, 10), (False, 23), (False, 3)])
-def test_frame_major_cost_pass_matches_hypothesis_major(small_scene, with_priors, n_rand):
-    """optimize_depth has two loop orders for the cost map + random samples (k_cost_rand: hypothesis-major,
-    k_cost_rand_frame_major: frame-major, chosen by the size of the flow layers): same arithmetic per hypothesis, same
-    first-wins comparison order -- also when the samples do not fill the 11-hypothesis batches (3) or need several (23).
-    The two are separate compilations of the same expressions, and the compiler's fma contraction is free to differ between
-    the loop orders: a cost can then differ in its last bit and a near-tie between two hypotheses resolve the other way
-    (measured: 0 pixels in most cases, 1 in 76 800 at 320x240 N=10, scripts/fm_check.py).  Everything else is identical."""
+@pytest.mark.parametrize("with_priors,n_rand", [(False, 10), (True, 10), (False, 23), (False, 3), (False, 0)])
+def test_sample_pass_with_survivor_queue_matches_strict(small_scene, with_priors, n_rand):
+    """The fast cost-map + random-sample pass (k_cost_rand_q: exact early rejection after frame 0 / the priors, survivors compacted
+    into an LDS queue, winner per pixel by a 64-bit atomicMin on (cost, sample index)) against the strict kernel, which walks the
+    samples one by one like optimize_depth.cu:269-277: the same depth on all but the near-ties that fp32 rounding decides
+    (measured: 4-6 pixels in 100 000) -- also when the samples do not fill a round of the queue (3) or need several (23) -- and the
+    same result on every run (the queue order is whatever the LDS atomics make it)."""
     from voldor_amd import kernels
     rng = np.random.default_rng(21)
     K = K9(*small_scene["K"])
@@ -346,22 +348,23 @@ def test_frame_major_cost_pass_matches_hypothesis_major(small_scene, with_priors
         pri[1, :7] = 0
         pc = rng.uniform(0.5, 1, pri.shape).astype(np.float32); cf = rng.uniform(0.5, 1, pri.shape).astype(np.float32)
         dR = np.stack([np.eye(3), np.eye(3)]).astype(np.float32); dt = np.array([[0, 0, 0], [0.01, 0, -0.02]], np.float32)
-    kw = _od_kwargs(n_rand_samples=n_rand, basefocal=40.0 if with_priors else 0.0, disp_delta=1.0 if with_priors else -1.0)
+    kw = _od_kwargs(n_rand_samples=n_rand, basefocal=40.0 if with_priors else 0.0, disp_delta=1.0 if with_priors else -1.0, global_prop_step=0,
+                    local_prop_width=0, fb_smooth=0)
     out = []
     try:
-        for thr, order in ((1 << 62, 1 << 62), (0, 1 << 62), (0, 0)):  # hypothesis-major / frame-major / frame-major in depth order
-            kernels.set_frame_major_threshold(thr, order)
+        for strict in (True, False, False):
+            kernels.set_strict_math(strict)
             kernels.set_rand_epoch(9)
             out.append(kernels.optimize_depth_gpu(flows, rig, pri, pc, cf, depth, K, Rs, ts, dR, dt, kw["abs_resize_factor"], N, 0 if pri is None else 2, w, h,
                                                   kw["basefocal"], kw["n_rand_samples"], kw["global_prop_step"], kw["local_prop_width"], kw["lambda_"],
                                                   kw["omega"], kw["disp_delta"], kw["delta"], kw["fb_smooth"], kw["s0_ems_prob"], kw["no_change_prob"],
                                                   kw["range_factor"], kw["update_rigidness_only"]))
     finally:
-        kernels.set_frame_major_threshold()
-    d0, r0, c0 = out[0]
-    for d1, r1, c1 in out[1:]:
-        same = d0 == d1
-        assert np.mean(~same) <= 1e-4, np.mean(~same)
-        np.testing.assert_array_equal(r0[:, same], r1[:, same])
-        np.testing.assert_array_equal(c0[:, same], c1[:, same])
-    assert np.mean(d0 != depth) > 0.3  # and the pass did something
+        kernels.set_strict_math(False)
+    (sd, sr, _), (fd, fr, _), (fd2, fr2, _) = out
+    np.testing.assert_array_equal(fd, fd2); np.testing.assert_array_equal(fr, fr2)
+    if n_rand > 0:
+        assert np.mean(sd != depth) > 0.05  # the samples do replace depths
+    assert np.mean(fd != sd) <= 5e-4, np.mean(fd != sd)
+    same = fd == sd
+    _assert_map_close(sr[:, same], fr[:, same])

@@ -256,7 +256,11 @@ def test_fast_vs_strict_within_the_reference_self_noise(orc, name):
     for r in (s, f):
         rr, tt = synth.pose_errors(r["poses"], gold[f"{name}/m0/poses"])
         assert rr.max() <= max(2 * nr, 1e-3) and tt.max() <= 2 * nt, (rr.max(), tt.max())
-    # covariance: an output of the boundary the SLAM driver feeds to its pose graph -- within 2x of each other and of the reference
+    # covariance (an output of the boundary: the SLAM driver feeds it to its pose graph).  It comes from the hard-gated robust Gaussian,
+    # which keeps ~0.3 % of the samples: between the reference's own three runs its trace moves by up to 1.8x (cfg2).  Same yardstick:
+    # twice the largest log-ratio of the reference pairs, against the strict run and against the reference's glibc run.
+    tr_ = lambda c: np.trace(c, axis1=1, axis2=2)  # noqa: E731
+    spread = max(np.abs(np.log(tr_(gold[f"{name}/m{a}/poses_covar"]) / tr_(gold[f"{name}/m{b}/poses_covar"]))).max() for a, b in ((0, 1), (0, 2), (1, 2)))
     for other in (s["poses_covar"], gold[f"{name}/m0/poses_covar"]):
-        ratio = np.trace(f["poses_covar"], axis1=1, axis2=2) / np.trace(other, axis1=1, axis2=2)
-        assert np.all((ratio > 0.5) & (ratio < 2.0)), ratio
+        lr = np.abs(np.log(tr_(f["poses_covar"]) / tr_(other)))
+        assert lr.max() <= 2 * spread, (lr, spread)

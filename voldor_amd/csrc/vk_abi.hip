@@ -463,10 +463,8 @@ int vk_set_rand_epoch(unsigned epoch) {
     c->rand_w = c->rand_h = -1;  // explicit seed: the next call adopts its size without resetting
     return pool_set_rand_epoch(epoch);  // and the contexts of vk_voldor_device_batch
 }
-int vk_set_fast_variant(int v) { set_fast_variant(v); return 0; }
 int vk_set_strict_math(int on) { set_strict_math_default(on); return 0; }
 int vk_get_strict_math(void) { return strict_math_default() ? 1 : 0; }
-int vk_set_frame_major_threshold(size_t flow_bytes, size_t depth_order_bytes) { set_frame_major_threshold(flow_bytes, depth_order_bytes); return 0; }
 unsigned vk_get_rand_epoch(void) {
     Context* c = default_context();
     return c ? c->rand_epoch : 0u;

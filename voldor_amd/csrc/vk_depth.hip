@@ -42,8 +42,7 @@ __device__ __forceinline__ bool clamp_active(Img& I) {
 
 // depth-prior term of compute_pixel_cost (optimize_depth.cu:166-190): the hypothesis seen from prior f's camera against the
 // prior map, weighted by the prior's confidences (all three sampled bilinearly at the projected position)
-template <bool STRICT = false>
-__device__ __forceinline__ static void prior_term(const Img& I, const PoseBlock* P, int f, int px, int py, float depth, float& cost_sum, float& wsum) {
+__device__ __forceinline__ static void prior_term_strict(const Img& I, const PoseBlock* P, int f, int px, int py, float depth, float& cost_sum, float& wsum) {
     const int w = I.w, h = I.h, npx = w * h;
     P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
     float qx2, qy2;
@@ -54,8 +53,7 @@ __device__ __forceinline__ static void prior_term(const Img& I, const PoseBlock*
             float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
             float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
             float wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
-            if (STRICT) cost_sum = strict::cost_acc(cost_sum, wg, strict::depth_rigidness(q.z, td, I.basefocal, I.omega, I.arf));  // fun_depth_cost, residual_model.h:64-68
-            else cost_sum = __fadd_rn(cost_sum, __fmul_rn(wg, 0.6931471805599453f * fast_log2(1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf))));
+            cost_sum = strict::cost_acc(cost_sum, wg, strict::depth_rigidness(q.z, td, I.basefocal, I.omega, I.arf));  // fun_depth_cost, residual_model.h:64-68
             wsum += wg;
         }
     }
@@ -66,10 +64,11 @@ __device__ __forceinline__ static void prior_term(const Img& I, const PoseBlock*
 // of one L2 round trip per frame (the sampling positions depend on depth and poses only, not on
 // the flow values): (1) rigid chain -> positions + validity mask, (2) issue every gather,
 // (3) residual model.  NMAX is the compile-time frame bound (arrays stay in registers).
-// STRICT: the residual model in the reference's operation order on the software transcendentals (vk_strict_model.hpp); the
-// geometry, the gathers and the summation order are the same in both modes.
-template <int NMAX, bool STRICT = false>
-__device__ __forceinline__ static float pixel_cost(const Img& I, int px, int py, float depth) {
+// STRICT kernels: the reference's un-fused fp32 geometry (vk_device.hpp backproject / transform / project, true divisions) and the
+// residual model in the reference's operation order on the software transcendentals (vk_strict_model.hpp): bit-identical to the
+// oracle in strict mode.  The fast ("lean") kernels further down share the structure, not the arithmetic.
+template <int NMAX>
+__device__ __forceinline__ static float pixel_cost_strict(const Img& I, int px, int py, float depth) {
     const int w = I.w, h = I.h, npx = w * h, pi = py * w + px;
     const PoseBlock* P = I.P;
     float qx[NMAX], qy[NMAX], rdx[NMAX], rdy[NMAX];
@@ -109,19 +108,18 @@ __device__ __forceinline__ static float pixel_cost(const Img& I, int px, int py,
     for (int f = 0; f < NMAX; f++) {
         if (f < I.N && ((valid >> f) & 1u)) {
             // product rounded before the add (no fma): same value as the lane-split evaluation cost_split8
-            if (STRICT) cost_sum = strict::cost_acc(cost_sum, wgt[f], strict::rigidness(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.arf));  // fun_cost :45-49
-            else cost_sum = __fadd_rn(cost_sum, __fmul_rn(wgt[f], neglog_rigidness_from_flows(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.inv_arf)));
+            cost_sum = strict::cost_acc(cost_sum, wgt[f], strict::rigidness(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.arf));  // fun_cost :45-49
             wsum += wgt[f];
         }
     }
-    for (int f = 0; f < I.N_dp; f++) prior_term<STRICT>(I, P, f, px, py, depth, cost_sum, wsum);
+    for (int f = 0; f < I.N_dp; f++) prior_term_strict(I, P, f, px, py, depth, cost_sum, wsum);
     if (wsum == 0.f) return INFINITY;
     return cost_sum / fmaxf(wsum, 1.1920929e-07f);
 }
 
 // ---- cost map + all random samples, fused (optimize_depth.cu:279-284 + :269-277 x n_rand) ----
-template <int NMAX, bool STRICT = false>
-__global__ __launch_bounds__(256) static void k_cost_rand(Img I, int n_rand, uint32_t epoch0, float range_factor) {
+template <int NMAX>
+__global__ __launch_bounds__(256) static void k_cost_rand_strict(Img I, int n_rand, uint32_t epoch0, float range_factor) {
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
@@ -129,252 +127,41 @@ __global__ __launch_bounds__(256) static void k_cost_rand(Img I, int n_rand, uin
     if (x >= I.w || y >= I.h) return;
     const int pi = y * I.w + x;
     float d = I.depth[pi];
-    float c = pixel_cost<NMAX, STRICT>(I, x, y, d);
+    float c = pixel_cost_strict<NMAX>(I, x, y, d);
     for (int it = 0; it < n_rand; it++) {
         float u = u01(rng3(RAND_SEED, (uint32_t)pi, epoch0 + (uint32_t)it));
         float dn = 1.0f / (range_factor * u + (1.0f / 1e5f));  // MAXIMUM_DEPTH, :15,:273
-        float cn = pixel_cost<NMAX, STRICT>(I, x, y, dn);
+        float cn = pixel_cost_strict<NMAX>(I, x, y, dn);
         if (cn < c) { c = cn; d = dn; }
     }
     I.depth[pi] = d;
     I.cost[pi] = c;
 }
 
-// Same pass for images whose flow layers do not fit the L2s (1080p: 10 layers x 16.6 MB against 4 MB of L2 per XCD).
-// k_cost_rand walks hypothesis-major: each of the 1 + n_rand hypotheses of a pixel touches all N layers in turn, and the
-// workgroups of an XCD are spread over all layers at any moment -- the per-pixel independent random depths scatter every
-// gather (measured at 1080p: 41 % TCC hit rate, 11.7 GB fetched per launch for 0.36 GB of algorithmic bytes).  Here the
-// loops are interchanged: FRAME-major, all hypotheses of the pixel advance together through layer f (rigid-chain state
-// per hypothesis kept in registers), so an XCD's workgroups, which own a band of rows, gather from the band of ONE layer at
-// a time (~2-3 MB).  Same expressions per hypothesis and the same first-wins order of the comparisons as k_cost_rand; the
-// two compile separately, so fma contraction may differ and a near-tie resolve the other way (measured: <= 1 pixel in
-// 76 800, tests/test_gpu_kernels.py::test_frame_major_cost_pass_matches_hypothesis_major).
-// flow-layer bytes above which the frame-major variant runs, and above which it also evaluates in depth order; vk_set_frame_major_threshold()
-static size_t COST_RAND_FRAME_MAJOR_BYTES = (size_t)24 << 20, COST_RAND_DEPTH_ORDER_BYTES = (size_t)64 << 20;
-void set_frame_major_threshold(size_t bytes, size_t depth_order_bytes) { COST_RAND_FRAME_MAJOR_BYTES = bytes; COST_RAND_DEPTH_ORDER_BYTES = depth_order_bytes; }
-constexpr int CR_NHYP = 11;  // incumbent + the reference's default 10 random samples per call; more samples run in batches
-// one frame step for hypotheses [K0, K1): rigid chain -> positions, gathers, residual model (the three phases of pixel_cost)
-template <int K0, int K1>
-__device__ __forceinline__ static void cr_frame_group(const Img& I, const PoseBlock* P, int f, int w, int h, const float2* __restrict__ layer, float2 obs0,
-                                                      float wgt, P3 (&o)[CR_NHYP], float (&px1)[CR_NHYP], float (&py1)[CR_NHYP], float (&cs)[CR_NHYP],
-                                                      float (&ws)[CR_NHYP]) {
-    float rdx[K1 - K0], rdy[K1 - K0];
-    float2 obs[K1 - K0];
-    unsigned valid = 0;
-#pragma unroll
-    for (int k = K0; k < K1; k++) {
-        o[k] = transform(P->Rs[f], P->ts[f], o[k]);
-        float px2, py2;
-        project(P, o[k], px2, py2);
-        float qx = 0.f, qy = 0.f;
-        rdx[k - K0] = 0.f; rdy[k - K0] = 0.f;
-        if (o[k].z > 0.f && px1[k] >= 0.f && px1[k] < (float)w && py1[k] >= 0.f && py1[k] < (float)h) {
-            valid |= 1u << k;
-            qx = px1[k]; qy = py1[k]; rdx[k - K0] = px2 - px1[k]; rdy[k - K0] = py2 - py1[k];
-            px1[k] = px2; py1[k] = py2;  // advances on contributing frames only (:162-164)
-        }
-        obs[k - K0] = (f == 0) ? obs0 : bilinear2(layer, w, h, qx, qy);  // unconditional (clamped) gather, as in pixel_cost
-    }
-#pragma unroll
-    for (int k = K0; k < K1; k++) {
-        if ((valid >> k) & 1u) {
-            cs[k] = __fadd_rn(cs[k], __fmul_rn(wgt, neglog_rigidness_from_flows(rdx[k - K0], rdy[k - K0], obs[k - K0].x, obs[k - K0].y, I.lambda, I.inv_arf)));
-            ws[k] += wgt;
-        }
-    }
-}
-
-template <bool DEPTH_ORDER>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3))) static void k_cost_rand_frame_major(Img I, int n_rand, uint32_t epoch0, float range_factor) {
-    if (!clamp_active(I)) return;
-    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
-    const int y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
-    if (x >= I.w || y >= I.h) return;
-    const int w = I.w, h = I.h, npx = w * h, pi = y * w + x;
-    const PoseBlock* P = I.P;
-    float d_best = I.depth[pi], c_best = 0.f;
-    bool first = true;
-    int it = 0;
-    while (first || it < n_rand) {
-        float dh[CR_NHYP];
-        int nh = 0;
-#pragma unroll
-        for (int k = 0; k < CR_NHYP; k++) {
-            dh[k] = 1.f;
-            if (k == 0 && first) { dh[0] = d_best; nh = 1; }
-            else if (it + (k - (first ? 1 : 0)) < n_rand) {
-                const float u = u01(rng3(RAND_SEED, (uint32_t)pi, epoch0 + (uint32_t)(it + k - (first ? 1 : 0))));
-                dh[k] = 1.0f / (range_factor * u + (1.0f / 1e5f));  // MAXIMUM_DEPTH, :15,:273
-                nh = k + 1;
-            }
-        }
-        // Evaluate the batch in depth order (odd-even transposition network on the 11 slots, original slot index carried
-        // along): the lanes of a wave then walk their hypotheses from far to near together, which narrows the spread of the
-        // gather positions of one step (1080p: -14 %; at KITTI size the sort costs more than it saves, hence the switch).
-        // The decision below restores the first-wins order of the sequential loop.
-        int ord[CR_NHYP];
-#pragma unroll
-        for (int k = 0; k < CR_NHYP; k++) ord[k] = k;
-#pragma unroll
-        for (int r = 0; r < (DEPTH_ORDER ? CR_NHYP : 0); r++) {
-#pragma unroll
-            for (int k = r & 1; k + 1 < CR_NHYP; k += 2) {
-                const bool sw = dh[k] < dh[k + 1];
-                const float a = sw ? dh[k + 1] : dh[k], b = sw ? dh[k] : dh[k + 1];
-                const int oa = sw ? ord[k + 1] : ord[k], ob = sw ? ord[k] : ord[k + 1];
-                dh[k] = a; dh[k + 1] = b; ord[k] = oa; ord[k + 1] = ob;
-            }
-        }
-        P3 o[CR_NHYP];
-        float px1[CR_NHYP], py1[CR_NHYP], cs[CR_NHYP], ws[CR_NHYP];
-#pragma unroll
-        for (int k = 0; k < CR_NHYP; k++) {
-            o[k] = backproject(P, (float)x, (float)y, dh[k]);
-            px1[k] = (float)x; py1[k] = (float)y; cs[k] = 0.f; ws[k] = 0.f;
-        }
-        for (int f = 0; f < I.N; f++) {
-            const float wgt = I.rig[(size_t)f * npx + pi];
-            const float2* layer = I.flows + (size_t)f * npx;
-            float2 obs0 = make_float2(0.f, 0.f);
-            if (f == 0) obs0 = layer[pi];  // frame 0 is sampled at the pixel itself (weights 1,0,0,0)
-            cr_frame_group<0, 4>(I, P, f, w, h, layer, obs0, wgt, o, px1, py1, cs, ws);
-            __builtin_amdgcn_sched_barrier(0);  // keep the groups' gathers apart: a third of the registers in flight
-            cr_frame_group<4, 8>(I, P, f, w, h, layer, obs0, wgt, o, px1, py1, cs, ws);
-            __builtin_amdgcn_sched_barrier(0);
-            cr_frame_group<8, CR_NHYP>(I, P, f, w, h, layer, obs0, wgt, o, px1, py1, cs, ws);
-        }
-        for (int f = 0; f < I.N_dp; f++) {
-#pragma unroll
-            for (int k = 0; k < CR_NHYP; k++) prior_term(I, P, f, x, y, dh[k], cs[k], ws[k]);
-        }
-        // sequential rule (:269-277): a sample replaces the running best only if strictly cheaper, i.e. the winner is the
-        // cheapest slot and, among equal costs, the earliest one (slot 0 of the first batch is the incumbent itself)
-        float cb = INFINITY, db = 0.f;
-        int ob = CR_NHYP;
-#pragma unroll
-        for (int k = 0; k < CR_NHYP; k++) {
-            if (ord[k] < nh) {
-                const float cn = (ws[k] == 0.f) ? INFINITY : cs[k] / fmaxf(ws[k], 1.1920929e-07f);
-                if (cn < cb || (cn == cb && ord[k] < ob) || ob == CR_NHYP) { cb = cn; db = dh[k]; ob = ord[k]; }
-            }
-        }
-        if (first) { c_best = cb; d_best = db; }   // the incumbent is slot 0 of this batch: it already won its ties
-        else if (cb < c_best) { c_best = cb; d_best = db; }
-        it += nh - (first ? 1 : 0);
-        first = false;
-    }
-    I.depth[pi] = d_best;
-    I.cost[pi] = c_best;
-}
-
 // replace_if_better_depth, optimize_depth.cu:201-207
-template <int NMAX, bool STRICT = false>
-__device__ __forceinline__ static void try_depth(const Img& I, int x, int y, float cand) {
+template <int NMAX>
+__device__ __forceinline__ static void try_depth_strict(const Img& I, int x, int y, float cand) {
     const int pi = y * I.w + x;
-    float c = pixel_cost<NMAX, STRICT>(I, x, y, cand);
+    float c = pixel_cost_strict<NMAX>(I, x, y, cand);
     if (c < I.cost[pi]) { I.depth[pi] = cand; I.cost[pi] = c; }
 }
 
 // ---- global propagation (optimize_depth.cu:209-235). With step>=2 the sites of one pass are
 // independent (reads x-1, writes x): one thread per site.  dir: 0 L2R,
 // 1 T2B, 2 R2L, 3 B2T.
-template <int NMAX, bool STRICT = false>
-__global__ __launch_bounds__(256) static void k_global_prop_sites(Img I, int dir, int step, int nsites) {
+template <int NMAX>
+__global__ __launch_bounds__(256) static void k_global_prop_sites_strict(Img I, int dir, int step, int nsites) {
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int s = (tile % gridDim.x) * blockDim.x + threadIdx.x;  // site index along the pass direction
     const int l = tile / gridDim.x;                               // line (row for 0/2, column for 1/3)
     if (s >= nsites) return;
-    if (dir == 0) { int x = 1 + s * step; try_depth<NMAX, STRICT>(I, x, l, I.depth[l * I.w + x - 1]); }
-    else if (dir == 2) { int x = I.w - 2 - s * step; try_depth<NMAX, STRICT>(I, x, l, I.depth[l * I.w + x + 1]); }
-    else if (dir == 1) { int y = 1 + s * step; try_depth<NMAX, STRICT>(I, l, y, I.depth[(y - 1) * I.w + l]); }
-    else { int y = I.h - 2 - s * step; try_depth<NMAX, STRICT>(I, l, y, I.depth[(y + 1) * I.w + l]); }
-}
-// step==1: a true serial chain per line (not used by any shipped config; kept for parity)
-template <int NMAX, bool STRICT = false>
-__global__ static void k_global_prop_serial(Img I, int dir) {
-    if (!clamp_active(I)) return;
-    const int l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (dir == 0 || dir == 2) {
-        if (l >= I.h) return;
-        if (dir == 0) for (int x = 1; x < I.w; x++) try_depth<NMAX, STRICT>(I, x, l, I.depth[l * I.w + x - 1]);
-        else for (int x = I.w - 2; x >= 0; x--) try_depth<NMAX, STRICT>(I, x, l, I.depth[l * I.w + x + 1]);
-    } else {
-        if (l >= I.w) return;
-        if (dir == 1) for (int y = 1; y < I.h; y++) try_depth<NMAX, STRICT>(I, l, y, I.depth[(y - 1) * I.w + l]);
-        else for (int y = I.h - 2; y >= 0; y--) try_depth<NMAX, STRICT>(I, l, y, I.depth[(y + 1) * I.w + l]);
-    }
+    if (dir == 0) { int x = 1 + s * step; try_depth_strict<NMAX>(I, x, l, I.depth[l * I.w + x - 1]); }
+    else if (dir == 2) { int x = I.w - 2 - s * step; try_depth_strict<NMAX>(I, x, l, I.depth[l * I.w + x + 1]); }
+    else if (dir == 1) { int y = 1 + s * step; try_depth_strict<NMAX>(I, l, y, I.depth[(y - 1) * I.w + l]); }
+    else { int y = I.h - 2 - s * step; try_depth_strict<NMAX>(I, l, y, I.depth[(y + 1) * I.w + l]); }
 }
 
-// ---- local propagation (optimize_depth.cu:237-267): a true serial chain inside each `width`
-// segment -- the candidate of step k+1 is the (possibly replaced) depth of step k -- so the pass is
-// bound by the latency of ONE cost evaluation times (width-1).  To shorten that critical path a
-// chain is driven by a group of 8 adjacent lanes: every lane walks the (cheap, ALU-only) rigid
-// chain, then evaluates only the frames it owns (f = g, g+8: gather + residual model), and the
-// per-frame terms are summed in frame order through 8-wide shuffles, so the cost has the same
-// summation order as the one-thread evaluation.  640x480: 9600 chains x 8 lanes = 1200 waves
-// (the reference runs 9600 threads, one full evaluation per step each).
-__device__ __forceinline__ static float cost_split8(const Img& I, int px, int py, float depth, int g) {
-    const int w = I.w, h = I.h, npx = w * h, pi = py * w + px;
-    const PoseBlock* P = I.P;
-    float qx0 = 0.f, qy0 = 0.f, rx0 = 0.f, ry0 = 0.f, qx1 = 0.f, qy1 = 0.f, rx1 = 0.f, ry1 = 0.f;
-    bool v0 = false, v1 = false;
-    {
-        P3 o = backproject(P, (float)px, (float)py, depth);
-        float px1 = (float)px, py1 = (float)py;
-        for (int f = 0; f < I.N; f++) {  // uniform trip count: no divergence inside the group
-            o = transform(P->Rs[f], P->ts[f], o);
-            float px2, py2;
-            project(P, o, px2, py2);
-            const bool valid = o.z > 0.f && px1 >= 0.f && px1 < (float)w && py1 >= 0.f && py1 < (float)h;
-            if (f == g) { v0 = valid; qx0 = px1; qy0 = py1; rx0 = px2 - px1; ry0 = py2 - py1; }
-            if (f == g + 8) { v1 = valid; qx1 = px1; qy1 = py1; rx1 = px2 - px1; ry1 = py2 - py1; }
-            if (valid) { px1 = px2; py1 = py2; }
-        }
-    }
-    float ct0 = 0.f, wt0 = 0.f, ct1 = 0.f, wt1 = 0.f;
-    if (v0) {
-        float2 ob = bilinear2(I.flows + (size_t)g * npx, w, h, qx0, qy0);
-        wt0 = I.rig[(size_t)g * npx + pi];
-        ct0 = __fmul_rn(wt0, neglog_rigidness_from_flows(rx0, ry0, ob.x, ob.y, I.lambda, I.inv_arf));
-    }
-    if (I.N > 8 && v1) {
-        float2 ob = bilinear2(I.flows + (size_t)(g + 8) * npx, w, h, qx1, qy1);
-        wt1 = I.rig[(size_t)(g + 8) * npx + pi];
-        ct1 = __fmul_rn(wt1, neglog_rigidness_from_flows(rx1, ry1, ob.x, ob.y, I.lambda, I.inv_arf));
-    }
-    float cp0 = 0.f, wp0 = 0.f, cp1 = 0.f, wp1 = 0.f;
-    for (int s = 0; s < 2; s++) {  // depth priors owned by this lane: f = g, g+8 (optimize_depth.cu:170-190)
-        const int f = g + 8 * s;
-        if (f < I.N_dp) {
-            P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
-            float qx2, qy2;
-            project(P, q, qx2, qy2);
-            if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
-                float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
-                if (td > 0.f) {
-                    float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
-                    float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
-                    float wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
-                    float cc = __fmul_rn(wg, 0.6931471805599453f * fast_log2(1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf)));
-                    if (s == 0) { cp0 = cc; wp0 = wg; } else { cp1 = cc; wp1 = wg; }
-                }
-            }
-        }
-    }
-    float cost_sum = 0.f, wsum = 0.f;
-    for (int f = 0; f < I.N; f++) {  // frame order, like the serial loop (adding an exact 0 for skipped frames)
-        const float c = __shfl((f & 8) ? ct1 : ct0, f & 7, 8), wg = __shfl((f & 8) ? wt1 : wt0, f & 7, 8);
-        cost_sum = __fadd_rn(cost_sum, c); wsum += wg;
-    }
-    for (int f = 0; f < I.N_dp; f++) {
-        const float c = __shfl((f & 8) ? cp1 : cp0, f & 7, 8), wg = __shfl((f & 8) ? wp1 : wp0, f & 7, 8);
-        cost_sum = __fadd_rn(cost_sum, c); wsum += wg;
-    }
-    if (wsum == 0.f) return INFINITY;
-    return cost_sum / fmaxf(wsum, 1.1920929e-07f);
-}
 // Segment geometry of one local pass (optimize_depth.cu:242-265): chain `seg` of `line` visits n
 // pixels pi0, pi0+stride, ...; the first candidate is the depth of the pixel before pi0.
 struct ChainGeom { int pi0, stride, n, prev0; };
@@ -397,95 +184,79 @@ __device__ __forceinline__ ChainGeom chain_geom(int w, int h, int dir, int width
     return g;
 }
 
-// Fallback for segments longer than one wave can hold (width > 65): one thread walks one chain.
-template <int NMAX, bool STRICT = false>
-__global__ __launch_bounds__(64) static void k_local_serial(Img I, int dir, int width) {
-    if (!clamp_active(I)) return;
-    const int line = blockIdx.x * 64 + threadIdx.x;
-    if (line >= ((dir == 0 || dir == 2) ? I.h : I.w)) return;
-    const ChainGeom cg = chain_geom(I.w, I.h, dir, width, line, blockIdx.y);
-    float cand = cg.n > 0 ? I.depth[cg.prev0] : 0.f;
-    for (int k = 0; k < cg.n; k++) {
-        const int pi = cg.pi0 + k * cg.stride;
-        const float c = pixel_cost<NMAX, STRICT>(I, pi % I.w, pi / I.w, cand);
-        if (c < I.cost[pi]) { I.depth[pi] = cand; I.cost[pi] = c; }
-        else cand = I.depth[pi];
-    }
-}
-
-// Pass 1 of a local propagation: tbl[p] = cost of pixel p under its neighbour's CURRENT depth, for every
-// pixel that is a chain member.  Fully parallel (one evaluation per pixel).  In the serial algorithm this is
-// exactly the cost step p evaluates whenever its predecessor was NOT replaced in this pass.
+// ---- E-step (optimize_depth.cu:84-138) + per-block sums of each rigidness map (the density
+// test of voldor.cpp:171 then needs no D2H of the maps).  Same three-phase structure as pixel_cost.
 template <int NMAX>
-__global__ __launch_bounds__(256) static void k_local_table(Img I, int dir, int width, float* __restrict__ tbl) {
+__global__ __launch_bounds__(256) static void k_update_rigidness_strict(Img I, float* __restrict__ partial) {
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63), y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
-    if (x >= I.w || y >= I.h) return;
-    const int w = I.w, h = I.h;
-    bool member; int nb;
-    if (dir == 0) { member = x >= 1 && (x % width) != 0; nb = y * w + x - 1; }
-    else if (dir == 2) { member = x <= w - 2 && (x % width) != width - 1; nb = y * w + x + 1; }
-    else if (dir == 1) { member = y >= 1 && (y % width) != 0; nb = (y - 1) * w + x; }
-    else { member = y <= h - 2 && (y % width) != width - 1; nb = (y + 1) * w + x; }
-    if (!member) return;
-    tbl[y * w + x] = pixel_cost<NMAX>(I, x, y, I.depth[nb]);
-}
-
-// Pass 2: ONE WAVE per chain (n <= 64 steps).  Lane j holds pixel j's old depth, old cost and table value.
-// "fresh" steps (predecessor unchanged) are resolved from the table with one ballot: the first accepting
-// step starts a RUN in which one value v keeps propagating; the costs c(x+1..x+8, v) of a run are
-// independent given v, so they are evaluated as one batch (8 groups x 8 lanes, frame-split like
-// cost_split8) and the accept/reject scan over the batch is again a ballot.  The result is identical to the
-// step-by-step chain, but the dependent latency is one evaluation per RUN instead of one per STEP
-// (measured replacement rates: ~40 % of the steps in the first EM iteration, ~6 % later).
-__global__ __launch_bounds__(64) static void k_local_runs(Img I, int dir, int width, const float* __restrict__ tbl) {
-    if (!clamp_active(I)) return;
-    const int lane = threadIdx.x, g = lane >> 3, sub = lane & 7;
-    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);  // (line, segment), segment-major
-    const ChainGeom cg = chain_geom(I.w, I.h, dir, width, tile % gridDim.x, tile / gridDim.x);
-    const int n = cg.n;
-    if (n <= 0) return;
-    const bool has = lane < n;
-    const int mypi = has ? cg.pi0 + lane * cg.stride : cg.pi0;
-    const float d0 = has ? I.depth[mypi] : 0.f, c0 = has ? I.cost[mypi] : 0.f, t0 = has ? tbl[mypi] : INFINITY;
-    const float first_cand = I.depth[cg.prev0];
-    int x = 0;
-    while (x < n) {
-        // fresh mode: first step >= x whose table cost beats its current cost
-        const unsigned long long am = __ballot(has && lane >= x && t0 < c0);
-        if (am == 0ull) break;
-        const int xa = __ffsll((long long)am) - 1;
-        const float dprev = __shfl(d0, max(xa - 1, 0), 64);
-        const float v = xa == 0 ? first_cand : dprev;
-        if (lane == xa) { I.depth[mypi] = v; I.cost[mypi] = t0; }  // replace_if_better_depth (:201-207)
-        x = xa + 1;
-        bool running = true;
-        while (running && x < n) {
-            const int px = x + g;  // pixel evaluated by group g in this batch
-            const bool act = px < n;
-            const int pi = act ? cg.pi0 + px * cg.stride : cg.pi0;
-            const float c = cost_split8(I, pi % I.w, pi / I.w, v, sub);
-            const float c0p = __shfl(c0, min(px, 63), 64);
-            const bool acc = act && c < c0p;
-            // length of the accepted prefix over the groups (a group's 8 lanes agree)
-            const unsigned long long rej = __ballot(!acc);
-            const int L = (__ffsll((long long)rej) - 1) >> 3;  // rej != 0 unless all 8 groups accept
-            const int Lacc = rej == 0ull ? 8 : L;
-            if (g < Lacc && sub == 0) { I.depth[pi] = v; I.cost[pi] = c; }
-            x += Lacc;
-            if (Lacc < 8) {  // the step at x rejected v (or the chain ended): its successor is fresh again
-                running = false;
-                x += 1;
+    const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
+    const int y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
+    const bool live = x < I.w && y < I.h;
+    const int w = I.w, h = I.h, npx = w * h, pi = live ? y * w + x : 0;
+    const PoseBlock* P = I.P;
+    __shared__ float s_part[NMAX][4];
+    const int blk = tile, nblk = gridDim.x * gridDim.y;
+    const float d = live ? I.depth[pi] : 1.f;
+    float qx[NMAX], qy[NMAX], rdx[NMAX], rdy[NMAX];
+    unsigned valid = 0;
+    {
+        P3 o = backproject(P, (float)x, (float)y, d);
+        float px1 = (float)x, py1 = (float)y;
+#pragma unroll
+        for (int f = 0; f < NMAX; f++) {
+            qx[f] = 0.f; qy[f] = 0.f; rdx[f] = 0.f; rdy[f] = 0.f;
+            if (f < I.N) {
+                o = transform(P->Rs[f], P->ts[f], o);
+                float px2, py2;
+                project(P, o, px2, py2);
+                if (live && o.z > 0.f && px1 >= 0.f && px1 < (float)w && py1 >= 0.f && py1 < (float)h) {
+                    valid |= 1u << f;
+                    qx[f] = px1; qy[f] = py1; rdx[f] = px2 - px1; rdy[f] = py2 - py1;
+                    px1 = px2; py1 = py2;  // NOT advanced on invalid frames (SURVEY Appendix B-10)
+                }
             }
         }
     }
+    float2 obs[NMAX];
+#pragma unroll
+    for (int f = 0; f < NMAX; f++) {
+        obs[f] = make_float2(0.f, 0.f);
+        if (f < I.N) obs[f] = (f == 0) ? I.flows[pi] : bilinear2(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
+    }
+#pragma unroll
+    for (int f = 0; f < NMAX; f++) {
+        if (f < I.N) {
+            float r = 0.f;
+            if ((valid >> f) & 1u)
+                r = strict::rigidness(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.arf);
+            if (live) I.rig[(size_t)f * npx + pi] = r;
+            float ws = wave_sum(live ? r : 0.f);
+            if ((threadIdx.x & 63) == 0) s_part[f][threadIdx.x >> 6] = ws;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < NMAX && (int)threadIdx.x < I.N) {
+        const int f = threadIdx.x;
+        partial[(size_t)f * nblk + blk] = (s_part[f][0] + s_part[f][1]) + (s_part[f][2] + s_part[f][3]);
+    }
+    if (!live) return;
+    for (int f = 0; f < I.N_dp; f++) {
+        P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)x, (float)y, d));
+        float qx2, qy2;
+        project(P, q, qx2, qy2);
+        if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
+            float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+            if (td > 0.f)  // else: the confidence is left untouched (:129)
+                I.confs[(size_t)f * npx + pi] = strict::depth_rigidness(q.z, td, I.basefocal, I.omega, I.arf);
+        } else
+            I.confs[(size_t)f * npx + pi] = 0.f;
+    }
 }
-
 // =================================================================================================================================
-// LEAN fast path.  Same algorithm, same decisions up to rounding, ~half the VALU instructions of the kernels above (which keep the
-// reference's un-fused fp32 geometry so that they agree bit for bit with the oracle's geometry; that job now belongs to the strict
-// mode, and these are held to the strict kernels by measured distances, tests/test_gpu_strict.py, tests/test_gpu_kernels.py):
+// LEAN fast path.  Same algorithm, same decisions up to rounding as the strict kernels above (which keep the reference's un-fused
+// fp32 geometry and operation order: bit-identical to the oracle); the fast kernels are held to them by measured distances
+// (tests/test_gpu_strict.py, tests/test_gpu_kernels.py):
 //   * the rigid chain of a hypothesis is ONE projective map per frame (PoseBlock::cumM / cumT, k_cum_poses): the homogeneous
 //     pixel in frame f+1 is d * (cumM[f] (x,y,1)) + cumT[f] -- 3 fma + 1 v_rcp + 2 mul per hypothesis and frame instead of a 3x3
 //     transform, two IEEE divisions and a re-projection; cumM[f] (x,y,1) is shared by all hypotheses of a pixel
@@ -947,75 +718,43 @@ __global__ __launch_bounds__(256) static void k_update_rigidness_lean(Img I, flo
     }
 }
 
-// ---- E-step (optimize_depth.cu:84-138) + per-block sums of each rigidness map (the density
-// test of voldor.cpp:171 then needs no D2H of the maps).  Same three-phase structure as pixel_cost.
-template <int NMAX, bool STRICT = false>
-__global__ __launch_bounds__(256) static void k_update_rigidness(Img I, float* __restrict__ partial) {
+// ---- serial-chain fallbacks, both modes: global propagation with step 1, local segments longer than one wave
+// step==1: a true serial chain per line (not used by any shipped config; kept for parity)
+template <int NMAX, bool STRICT>
+__global__ static void k_global_prop_serial(Img I, int dir) {
     if (!clamp_active(I)) return;
-    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
-    const int y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
-    const bool live = x < I.w && y < I.h;
-    const int w = I.w, h = I.h, npx = w * h, pi = live ? y * w + x : 0;
-    const PoseBlock* P = I.P;
-    __shared__ float s_part[NMAX][4];
-    const int blk = tile, nblk = gridDim.x * gridDim.y;
-    const float d = live ? I.depth[pi] : 1.f;
-    float qx[NMAX], qy[NMAX], rdx[NMAX], rdy[NMAX];
-    unsigned valid = 0;
-    {
-        P3 o = backproject(P, (float)x, (float)y, d);
-        float px1 = (float)x, py1 = (float)y;
-#pragma unroll
-        for (int f = 0; f < NMAX; f++) {
-            qx[f] = 0.f; qy[f] = 0.f; rdx[f] = 0.f; rdy[f] = 0.f;
-            if (f < I.N) {
-                o = transform(P->Rs[f], P->ts[f], o);
-                float px2, py2;
-                project(P, o, px2, py2);
-                if (live && o.z > 0.f && px1 >= 0.f && px1 < (float)w && py1 >= 0.f && py1 < (float)h) {
-                    valid |= 1u << f;
-                    qx[f] = px1; qy[f] = py1; rdx[f] = px2 - px1; rdy[f] = py2 - py1;
-                    px1 = px2; py1 = py2;  // NOT advanced on invalid frames (SURVEY Appendix B-10)
-                }
-            }
-        }
-    }
-    float2 obs[NMAX];
-#pragma unroll
-    for (int f = 0; f < NMAX; f++) {
-        obs[f] = make_float2(0.f, 0.f);
-        if (f < I.N) obs[f] = (f == 0) ? I.flows[pi] : bilinear2(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
-    }
-#pragma unroll
-    for (int f = 0; f < NMAX; f++) {
-        if (f < I.N) {
-            float r = 0.f;
-            if ((valid >> f) & 1u)
-                r = STRICT ? strict::rigidness(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.arf) : rigidness_from_flows(rdx[f], rdy[f], obs[f].x, obs[f].y, I.lambda, I.inv_arf);
-            if (live) I.rig[(size_t)f * npx + pi] = r;
-            float ws = wave_sum(live ? r : 0.f);
-            if ((threadIdx.x & 63) == 0) s_part[f][threadIdx.x >> 6] = ws;
-        }
-    }
-    __syncthreads();
-    if (threadIdx.x < NMAX && (int)threadIdx.x < I.N) {
-        const int f = threadIdx.x;
-        partial[(size_t)f * nblk + blk] = (s_part[f][0] + s_part[f][1]) + (s_part[f][2] + s_part[f][3]);
-    }
-    if (!live) return;
-    for (int f = 0; f < I.N_dp; f++) {
-        P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)x, (float)y, d));
-        float qx2, qy2;
-        project(P, q, qx2, qy2);
-        if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
-            float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
-            if (td > 0.f)  // else: the confidence is left untouched (:129)
-                I.confs[(size_t)f * npx + pi] = STRICT ? strict::depth_rigidness(q.z, td, I.basefocal, I.omega, I.arf) : 1.f / (1.f + depth_ratio(q.z, td, I.basefocal, I.omega, I.inv_arf));
-        } else
-            I.confs[(size_t)f * npx + pi] = 0.f;
+    const LeanK K = lean_consts(I);
+    auto try_depth = [&](int x, int y, float cand) { if constexpr (STRICT) try_depth_strict<NMAX>(I, x, y, cand); else try_depth_lean<NMAX>(I, K, x, y, cand); };
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (dir == 0 || dir == 2) {
+        if (l >= I.h) return;
+        if (dir == 0) for (int x = 1; x < I.w; x++) try_depth(x, l, I.depth[l * I.w + x - 1]);
+        else for (int x = I.w - 2; x >= 0; x--) try_depth(x, l, I.depth[l * I.w + x + 1]);
+    } else {
+        if (l >= I.w) return;
+        if (dir == 1) for (int y = 1; y < I.h; y++) try_depth(l, y, I.depth[(y - 1) * I.w + l]);
+        else for (int y = I.h - 2; y >= 0; y--) try_depth(l, y, I.depth[(y + 1) * I.w + l]);
     }
 }
+
+// Fallback for segments longer than one wave can hold (width > 65): one thread walks one chain.
+template <int NMAX, bool STRICT>
+__global__ __launch_bounds__(64) static void k_local_serial(Img I, int dir, int width) {
+    if (!clamp_active(I)) return;
+    const int line = blockIdx.x * 64 + threadIdx.x;
+    if (line >= ((dir == 0 || dir == 2) ? I.h : I.w)) return;
+    const ChainGeom cg = chain_geom(I.w, I.h, dir, width, line, blockIdx.y);
+    const LeanK K = lean_consts(I);
+    float cand = cg.n > 0 ? I.depth[cg.prev0] : 0.f;
+    for (int k = 0; k < cg.n; k++) {
+        const int pi = cg.pi0 + k * cg.stride;
+        float c;
+        if constexpr (STRICT) c = pixel_cost_strict<NMAX>(I, pi % I.w, pi / I.w, cand); else c = pixel_cost_lean<NMAX>(I, K, pi % I.w, pi / I.w, cand);
+        if (c < I.cost[pi]) { I.depth[pi] = cand; I.cost[pi] = c; }
+        else cand = I.depth[pi];
+    }
+}
+
 // fixed-order second stage: cams[f].pose_rigidness_density = sum(partial[f][:]) / npx
 // blocks 0..n_launch-1: rigidness density of one frame; block n_launch (only launched when scale_out != NULL): the pose half
 // of normalize_world_scale (voldor.cpp:309-317), scale = n / sum ||t_i|| over the registered frames -- one launch for both
@@ -1229,14 +968,22 @@ static Img make_img(const ImageSet& S, const OdParams& p) {
     return I;
 }
 
+
 // Device-resident optimize_depth: all inputs already in `S`. Stage order optimize_depth.cu:462-494.
+// STRICT: the reference's operation order on software transcendentals, plain launch structure (one thread per serial chain).
+// Fast: k_cum_poses, then the lean kernels (cost + samples through the survivor queue, table + runs for the local passes).
 template <int NMAX, bool STRICT>
 static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_only) {
     const int w = p.w, h = p.h;
     Img I = make_img(S, p);
     const dim3 gpx((w + 63) / 64, (h + 3) / 4), bpx(256);
+    if constexpr (!STRICT) hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, S.pb(), p.N, p.N_dp);
+    auto cost_rand = [&](int n_rand, uint32_t epoch) {
+        if constexpr (STRICT) hipLaunchKernelGGL(k_cost_rand_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
+        else hipLaunchKernelGGL(k_cost_rand_q<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
+    };
     if (cost_only) {
-        hipLaunchKernelGGL((k_cost_rand<NMAX, STRICT>), gpx, bpx, 0, c->stream, I, 0, 0u, p.range_factor);
+        cost_rand(0, 0u);
         VK_CHECK_LAST();
         return 0;
     }
@@ -1251,83 +998,7 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
             }
         }
         if (c->prof) prof_begin_inner(c);
-        // flow layers beyond what the eight 4 MB L2s hold: frame-major variant (see k_cost_rand_frame_major)
-        const size_t flow_bytes = (size_t)p.N * w * h * sizeof(float2);
-        const bool frame_major = !STRICT && flow_bytes > COST_RAND_FRAME_MAJOR_BYTES && p.n_rand_samples > 0;  // without samples there is one hypothesis: nothing to interchange
-        if (frame_major && flow_bytes > COST_RAND_DEPTH_ORDER_BYTES)
-            hipLaunchKernelGGL(k_cost_rand_frame_major<true>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
-        else if (frame_major)
-            hipLaunchKernelGGL(k_cost_rand_frame_major<false>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
-        else
-            hipLaunchKernelGGL((k_cost_rand<NMAX, STRICT>), gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
-        if (c->prof) prof_end_inner(c, "cost_rand", 1);
-        c->rand_epoch += (uint32_t)(p.n_rand_samples > 0 ? p.n_rand_samples : 0);
-        if (p.global_prop_step > 0) {
-            const int order[4] = { 0, 3, 2, 1 };  // L2R, B2T, R2L, T2B (:481-484)
-            for (int k = 0; k < 4; k++) {
-                const int dir = order[k];
-                const bool rowpass = (dir == 0 || dir == 2);
-                const int len = rowpass ? w : h, lines = rowpass ? h : w;
-                if (p.global_prop_step >= 2) {
-                    const int nsites = (len - 1 + p.global_prop_step - 1) / p.global_prop_step;
-                    if (nsites > 0)
-                        hipLaunchKernelGGL((k_global_prop_sites<NMAX, STRICT>), dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir,
-                                           p.global_prop_step, nsites);
-                } else
-                    hipLaunchKernelGGL((k_global_prop_serial<NMAX, STRICT>), dim3((lines + 63) / 64), dim3(64), 0, c->stream, I, dir);
-            }
-        }
-        if (p.local_prop_width > 0) {
-            const int order[4] = { 0, 3, 2, 1 };  // (:487-490)
-            if (c->prof) prof_begin_inner(c);
-            for (int k = 0; k < 4; k++) {
-                const int dir = order[k];
-                const bool rowpass = (dir == 0 || dir == 2);
-                const int len = rowpass ? w : h, lines = rowpass ? h : w;
-                const int nseg = (len + p.local_prop_width - 1) / p.local_prop_width;
-                if (!STRICT && p.local_prop_width <= 65) {  // chains of <= 64 steps: table + one wave per chain (strict: the plain serial chain)
-                    hipLaunchKernelGGL(k_local_table<NMAX>, gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
-                    hipLaunchKernelGGL(k_local_runs, dim3(lines, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width,
-                                       c->local_tbl.as<float>());
-                } else
-                    hipLaunchKernelGGL((k_local_serial<NMAX, STRICT>), dim3((lines + 63) / 64, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
-            }
-            if (c->prof) prof_end_inner(c, "local_pass", 4);
-        }
-    }
-    const int nblk = gpx.x * gpx.y;
-    hipLaunchKernelGGL((k_update_rigidness<NMAX, STRICT>), gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
-    if (p.N > 0)
-        hipLaunchKernelGGL(k_reduce_density, dim3(p.N + (p.world_scale_out ? 1 : 0)), dim3(256), 0, c->stream, c->rig_partial.as<float>(), nblk,
-                           w * h, c->cams.as<CamState>(), S.pb(), p.N, p.world_scale_out);
-    VK_CHECK_LAST();
-    return 0;
-}
-// the lean fast path: same stage order, lean kernels (see k_cum_poses)
-static int g_fast_variant = -1;  // 1 lean (default), 0 legacy kernels (A/B measurements: VOLDOR_HIP_LEAN=0 / vk_set_fast_variant)
-void set_fast_variant(int v) { g_fast_variant = v; }
-static bool lean_enabled() {
-    if (g_fast_variant < 0) { const char* e = getenv("VOLDOR_HIP_LEAN"); g_fast_variant = e ? atoi(e) : 1; }
-    return g_fast_variant != 0;
-}
-template <int NMAX>
-static int optimize_depth_launch_lean(Context* c, ImageSet& S, const OdParams& p, bool cost_only) {
-    const int w = p.w, h = p.h;
-    Img I = make_img(S, p);
-    const dim3 gpx((w + 63) / 64, (h + 3) / 4), bpx(256);
-    hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, S.pb(), p.N, p.N_dp);
-    if (cost_only) {
-        hipLaunchKernelGGL(k_cost_rand_q<NMAX>, gpx, bpx, 0, c->stream, I, 0, 0u, p.range_factor);
-        VK_CHECK_LAST();
-        return 0;
-    }
-    if (!p.update_rigidness_only) {
-        if (p.fb_smooth) {
-            if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active)) return e;
-            if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e;
-        }
-        if (c->prof) prof_begin_inner(c);
-        hipLaunchKernelGGL(k_cost_rand_q<NMAX>, gpx, bpx, 0, c->stream, I, p.n_rand_samples, c->rand_epoch, p.range_factor);
+        cost_rand(p.n_rand_samples, c->rand_epoch);
         if (c->prof) prof_end_inner(c, "cost_rand", 1);
         c->rand_epoch += (uint32_t)(p.n_rand_samples > 0 ? p.n_rand_samples : 0);
         const int order[4] = { 0, 3, 2, 1 };  // L2R, B2T, R2L, T2B (:481-484, :487-490)
@@ -1338,10 +1009,11 @@ static int optimize_depth_launch_lean(Context* c, ImageSet& S, const OdParams& p
                 const int len = rowpass ? w : h, lines = rowpass ? h : w;
                 if (p.global_prop_step >= 2) {
                     const int nsites = (len - 1 + p.global_prop_step - 1) / p.global_prop_step;
-                    if (nsites > 0)
-                        hipLaunchKernelGGL(k_global_prop_sites_lean<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
-                } else  // step 1 is a true serial chain: not used by any shipped config, served by the legacy kernel
-                    hipLaunchKernelGGL((k_global_prop_serial<NMAX, false>), dim3((lines + 63) / 64), dim3(64), 0, c->stream, I, dir);
+                    if (nsites <= 0) continue;
+                    if constexpr (STRICT) hipLaunchKernelGGL(k_global_prop_sites_strict<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
+                    else hipLaunchKernelGGL(k_global_prop_sites_lean<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
+                } else  // step 1: a true serial chain per line (no shipped config uses it)
+                    hipLaunchKernelGGL((k_global_prop_serial<NMAX, STRICT>), dim3((lines + 63) / 64), dim3(64), 0, c->stream, I, dir);
             }
         }
         if (p.local_prop_width > 0) {
@@ -1351,17 +1023,18 @@ static int optimize_depth_launch_lean(Context* c, ImageSet& S, const OdParams& p
                 const bool rowpass = (dir == 0 || dir == 2);
                 const int len = rowpass ? w : h, lines = rowpass ? h : w;
                 const int nseg = (len + p.local_prop_width - 1) / p.local_prop_width;
-                if (p.local_prop_width <= 65) {
+                if (!STRICT && p.local_prop_width <= 65) {  // chains of <= 64 steps: table + one wave per chain
                     hipLaunchKernelGGL(k_local_table_lean<NMAX>, gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
                     hipLaunchKernelGGL(k_local_runs_lean, dim3(lines, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
                 } else
-                    hipLaunchKernelGGL((k_local_serial<NMAX, false>), dim3((lines + 63) / 64, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
+                    hipLaunchKernelGGL((k_local_serial<NMAX, STRICT>), dim3((lines + 63) / 64, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
             }
             if (c->prof) prof_end_inner(c, "local_pass", 4);
         }
     }
     const int nblk = gpx.x * gpx.y;
-    hipLaunchKernelGGL(k_update_rigidness_lean<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
+    if constexpr (STRICT) hipLaunchKernelGGL(k_update_rigidness_strict<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
+    else hipLaunchKernelGGL(k_update_rigidness_lean<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
     if (p.N > 0)
         hipLaunchKernelGGL(k_reduce_density, dim3(p.N + (p.world_scale_out ? 1 : 0)), dim3(256), 0, c->stream, c->rig_partial.as<float>(), nblk,
                            w * h, c->cams.as<CamState>(), S.pb(), p.N, p.world_scale_out);
@@ -1369,21 +1042,16 @@ static int optimize_depth_launch_lean(Context* c, ImageSet& S, const OdParams& p
     return 0;
 }
 static int optimize_depth_dispatch(Context* c, ImageSet& S, const OdParams& p, bool cost_only) {
-    if (p.strict) {  // parity-pinning mode: two frame bounds are enough
+    if (p.strict || p.w < 2 || p.h < 2) {  // parity-pinning mode (two frame bounds are enough); 1-pixel-wide images: the lean bilinear needs 2x2 texels
         if (p.N <= 8) return optimize_depth_launch<8, true>(c, S, p, cost_only);
         return optimize_depth_launch<16, true>(c, S, p, cost_only);
-    }
-    if (lean_enabled() && p.w >= 2 && p.h >= 2) {
-        if (p.N <= 4) return optimize_depth_launch_lean<4>(c, S, p, cost_only);
-        if (p.N <= 6) return optimize_depth_launch_lean<6>(c, S, p, cost_only);
-        if (p.N <= 8) return optimize_depth_launch_lean<8>(c, S, p, cost_only);
-        return optimize_depth_launch_lean<16>(c, S, p, cost_only);
     }
     if (p.N <= 4) return optimize_depth_launch<4, false>(c, S, p, cost_only);
     if (p.N <= 6) return optimize_depth_launch<6, false>(c, S, p, cost_only);  // the SLAM driver's window is 5 flows (voldor_slam.py:85)
     if (p.N <= 8) return optimize_depth_launch<8, false>(c, S, p, cost_only);
     return optimize_depth_launch<16, false>(c, S, p, cost_only);
 }
+
 
 int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p) {
     const int w = p.w, h = p.h;

@@ -49,8 +49,6 @@ int depth_conf_device(Context* c, const float* rig, const float* confs, float* o
 int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk_dev, int w, int h, int d, float sigma, int ksize);
 
 // vk_pose.hip
-void set_fast_variant(int v);  // vk_depth.hip: 1 lean kernels (default), 0 legacy kernels
-void set_frame_major_threshold(size_t bytes, size_t depth_order_bytes);  // vk_depth.hip: flow bytes above which k_cost_rand_frame_major is used
 int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
                    float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact);
 int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, float fx, float fy, float cx, float cy,

@@ -197,12 +197,6 @@ def get_rand_epoch() -> int:
     return capi.lib().vk_get_rand_epoch()
 
 
-def set_frame_major_threshold(flow_bytes: int = 24 << 20, depth_order_bytes: int = 64 << 20):
-    """Flow-layer sizes (bytes) above which optimize_depth uses the frame-major cost/random-sample kernel, and above which that
-    kernel evaluates each pixel's hypotheses in depth order.  No arguments = library defaults."""
-    capi.lib().vk_set_frame_major_threshold(C.c_size_t(flow_bytes), C.c_size_t(depth_order_bytes))
-
-
 def set_strict_math(on: bool):
     """Process-wide default of the strict-math mode (include/voldor_hip.h: vk_set_strict_math)."""
     capi.check(capi.lib().vk_set_strict_math(1 if on else 0), "vk_set_strict_math")
