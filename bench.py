@@ -12,11 +12,17 @@ HBM when the timed region starts (vk_voldor_device).  With N>1 every rank owns o
 per step.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     dominant streaming kernel k_cost_rand: algorithmic bytes w*h*(12N+16) / average launch
-               duration measured with HIP events on the library's stream (vk_profile_*), against the
-               8 TB/s HBM peak; `traffic` = PMC FETCH_SIZE/WRITE_SIZE bytes per launch
-               (profiles/r01_pmc_traffic.json).  The optimize_depth group (B_od = w*h*(40N+36N_dp+12),
+  roofline     dominant streaming kernel k_cost_rand_q (cost map + random depth samples): algorithmic bytes
+               w*h*(12N+12N_dp+16) / average launch duration measured with HIP events on the library's stream
+               (vk_profile_*), against the 8 TB/s HBM peak; `traffic` = PMC FETCH_SIZE/WRITE_SIZE bytes per
+               launch and `valu_issue_frac` from the raw SQ counters of the same kernel (profiles/r02c_pmc_*.json,
+               scripts/pmc_traffic.sh, scripts/pmc_sq.sh).  The optimize_depth group (B_od = w*h*(40N+36N_dp+12),
                BASELINE.md §4) is reported next to it.
+  host_inclusive  SURVEY.md §8(d)'s own definition of a frame: py_voldor_wrapper with the flows in pageable HOST memory
+               and depth / confidence returned to the host; median of 20 calls after 3 warm-ups (never `value`).
+  strict       one window in strict-math mode (--strict_math 1: bit-identical to the CPU oracle in the
+               same mode, tests/test_gpu_strict.py): its time, its pose distance from the fast window and from the
+               reference pipeline's own run of this window (tests/golden/ref_window.npz).
   cpu_baseline the oracle (C restatement of the reference path, OpenMP) timed on this box's host
                cores on the same workload, a bounded number of windows (rank 0, N=1 only).
   cpu_reference  the reference's own code on one host core (oracle/_ref: voldor/*.cpp + gpu-kernels/*.cu compiled for the
@@ -69,6 +75,8 @@ def main():
     ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed seconds of windows before the warm-up steps (GPU clock ramp-up)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--in-flight", type=int, default=4, help="windows in flight for the extra 'concurrent' measurement (0 = skip)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the pose all-gather also with one rank (tests)")
+    ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive / strict / concurrent / CPU legs (profiling runs)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     W, H, N_FLOW, EM_ITERS = wl["w"], wl["h"], wl["n"], wl["iters"]
@@ -84,13 +92,20 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # backend nccl == RCCL on ROCm
+    if args.no_extras:
+        args.no_cpu_baseline = True
+        args.in_flight = 0
 
     from voldor_amd import capi, pyvoldor, synth
     from voldor_amd import dist as vdist
 
     lib = capi.lib()
+    capi.check(lib.vk_set_device(local_rank), "vk_set_device")
     basefocal = wl["basefocal"]
     sc = synth.make_scene(w=W, h=H, n_flows=N_FLOW, fx=FX, fy=FY, cx=CX, cy=CY, seed=233 + rank,
                           basefocal=basefocal if wl["mode"] != "mono" else 0.0)
@@ -106,15 +121,15 @@ def main():
     recv = torch.zeros(world * blk, device="cuda")
 
     def step():
-        out = pyvoldor.voldor_device(flows, FX, FY, CX, CY, config=CONFIG, depth_out=depth, depth_conf_out=conf, **extra)
-        if world > 1:  # pose exchange: [n_registered | poses N x 6 | covar N x 36] per rank
-            send.copy_(torch.from_numpy(vdist.pack_pose_block(out, N_FLOW)), non_blocking=True)
+        # the library leaves [n_registered | poses N x 6 | covar N x 36] in `send` on the device (vk_voldor_device_block)
+        out = pyvoldor.voldor_device(flows, FX, FY, CX, CY, config=CONFIG, depth_out=depth, depth_conf_out=conf, pose_block_out=send, **extra)
+        if use_dist:  # pose exchange: one RCCL all-gather of 1 + 42 N floats per rank, device to device
             dist.all_gather_into_tensor(recv, send)
         return out
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -131,10 +146,12 @@ def main():
         out = step()
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        blocks = recv.view(world, -1).cpu().numpy()  # every rank holds every rank's result
+        assert int(round(float(blocks[rank, 0]))) == int(out["n_registered"]) and np.array_equal(blocks[rank, 1:1 + 6 * int(out["n_registered"])], out["poses"].reshape(-1))
     ms_per_step = dt / args.steps * 1e3
     value = world * args.steps / dt
 
@@ -153,29 +170,85 @@ def main():
                 groups[name] = {"avg_us": tot.value / cnt.value * 1e3, "calls_per_window": cnt.value / nprof}
         lib.vk_profile_enable(0)
         b_od = W * H * (40 * N_FLOW + 36 * n_dp + 12)  # bytes per optimize_depth call
-        # Dominant streaming kernel of the path: k_cost_rand (cost map + 10 random depth hypotheses per pixel, one launch
-        # per optimize_depth call).  Algorithmic bytes of one launch = every map it must touch once: flows 8N + rigidness
-        # 4N read, depth and cost read 8 + written 8  ->  w*h*(12N+16)  (DESIGN.md section 3).
+        # Dominant streaming kernel of the path: k_cost_rand_q (cost map + 10 random depth samples per pixel, one launch per
+        # optimize_depth call).  Algorithmic bytes of one launch = every map it must touch once: flows 8N + rigidness 4N read,
+        # priors 12 N_dp read, depth and cost read 8 + written 8  ->  w*h*(12N+12N_dp+16)  (DESIGN.md section 3).
         b_cr = W * H * (12 * N_FLOW + 12 * n_dp + 16)
-        traffic = None
+        nmax = 4 if N_FLOW <= 4 else 6 if N_FLOW <= 6 else 8 if N_FLOW <= 8 else 16
+        kname = f"vk::k_cost_rand_q<{nmax}>"
+        traffic = valu = None
+        sqc = {}
+        try:  # PMC passes of this workload (collected separately: rocprofv3 cannot time and count in one run)
+            ks = json.load(open(os.path.join(ROOT, "profiles", f"r02c_pmc_traffic_{args.workload}.json")))["kernels"]
+            traffic = ks[kname]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         try:
-            if args.workload != "cfg2": raise KeyError("PMC traffic was collected on cfg2 only")
-            pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            ks = pmc["kernels"]
-            traffic = sum(ks[k]["hbm_bytes_per_launch"] for k in ks if "k_cost_rand" in k) or None
+            sqc = json.load(open(os.path.join(ROOT, "profiles", f"r02c_pmc_sq_{args.workload}.json")))[kname]
+            # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves (MI355X_MICROARCH.md): x4 = cycles some SIMD spent issuing VALU;
+            # over 1024 SIMDs and the launch duration at the 2.4 GHz peak clock = the fraction of VALU issue slots used
+            valu = sqc["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sqc["avg_us_under_pmc"] * 1e-6 * 2.4e9)
         except Exception:
             pass
         if "cost_rand" in groups and "optimize_depth" in groups:
             t_cr = groups["cost_rand"]["avg_us"] * 1e-6
             ach = b_cr / t_cr / 1e9
             t_od = groups["optimize_depth"]["avg_us"] * 1e-6
-            roof = {"bound": "hbm", "kernel": "vk::k_cost_rand<6> (cost map + 10 random depth hypotheses per pixel; 1 launch per optimize_depth call)",
+            roof = {"bound": "hbm", "kernel": kname + " (cost map + random depth samples: exact early rejection, survivor queue in LDS; 1 launch per optimize_depth call)",
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                     "algorithmic_bytes": b_cr, "avg_us": round(groups["cost_rand"]["avg_us"], 2), "traffic": traffic,
-                    "note": "the kernel evaluates 11 hypotheses x N frames of the residual model per pixel: VALUBusy 70 % (PMC), i.e. ALU-issue bound, not HBM bound",
+                    "valu_issue_frac": None if valu is None else round(valu, 3),
+                    "sq_counters_per_launch": {k: sqc[k] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY") if k in sqc} or None,
                     "optimize_depth_group": {"algorithmic_bytes": b_od, "avg_us": round(groups["optimize_depth"]["avg_us"], 2),
                                              "achieved": round(b_od / t_od / 1e9, 2), "frac": round(b_od / t_od / 1e9 / HBM_PEAK_GBS, 5)},
                     "groups": {k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in groups.items()}}
+
+    # ---- SURVEY 8(d)'s frame: host buffers in, host results out (py_voldor_wrapper), median of 20 after 3 warm-ups ----
+    host_inc = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        hkw = dict(basefocal=basefocal, disparity=sc["disparity"]) if wl["mode"] == "stereo" else {}
+        ts = []
+        for i in range(23):
+            t0 = time.perf_counter()
+            ho = pyvoldor.voldor(sc["flows"], FX, FY, CX, CY, config=CONFIG, **hkw)
+            ts.append(time.perf_counter() - t0)
+        med = float(np.median(ts[3:]))
+        host_inc = {"value": round(1.0 / med, 3), "unit": "frames/s", "ms_median": round(med * 1e3, 3), "calls": 20, "warmup": 3,
+                    "h2d_bytes": int(sc["flows"].nbytes + (sc["disparity"].nbytes if wl["mode"] == "stereo" else 0)), "d2h_bytes": int(2 * W * H * 4),
+                    "n_registered": int(ho["n_registered"]),
+                    "note": "vk_py_voldor_wrapper: flows in pageable host memory, depth + confidence returned to the host (PCIe inclusive)"}
+
+    # ---- strict-math mode: the window that reproduces the CPU oracle bit for bit ----
+    strict = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        from voldor_amd import kernels
+        kernels.set_rand_epoch(0)
+        fo = pyvoldor.voldor_device(flows, FX, FY, CX, CY, config=CONFIG, depth_out=depth, depth_conf_out=conf, **extra)
+        kernels.set_rand_epoch(0)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        so = pyvoldor.voldor_device(flows, FX, FY, CX, CY, config=CONFIG + " --strict_math 1", depth_out=depth, depth_conf_out=conf, **extra)
+        torch.cuda.synchronize(); ts_ = time.perf_counter() - t0
+        strict = {"ms_per_window": round(ts_ * 1e3, 2), "n_registered": int(so["n_registered"]),
+                  "note": "--strict_math 1 (same hypothesis draw as the fast window): every stage in the reference's operation order on software transcendentals; "
+                          "bit-identical to the CPU oracle in the same mode (tests/test_gpu_strict.py)"}
+        if int(so["n_registered"]) == int(fo["n_registered"]) and int(so["n_registered"]) > 0:
+            r3, t3 = synth.pose_errors(fo["poses"], so["poses"])
+            strict["fast_vs_strict"] = {"rot_rad_max": float(r3.max()), "rel_trans_max": float(t3.max())}
+        gold_path = os.path.join(ROOT, "tests", "golden", "ref_window.npz")
+        if args.workload == "cfg2" and os.path.exists(gold_path):
+            ref_poses = np.load(gold_path)["cfg2_640x480/poses"]
+            if len(ref_poses) == int(so["n_registered"]):
+                r4, t4 = synth.pose_errors(so["poses"], ref_poses)
+                strict["pose_rpe_vs_reference"] = {"rot_rad_max": float(r4.max()), "rel_trans_max": float(t4.max())}
+        try:
+            noise = np.load(os.path.join(ROOT, "tests", "golden", "ref_selfnoise.npz"))
+            if args.workload == "cfg2":
+                pr = [synth.pose_errors(noise[f"cfg2_640x480/m{a}/poses"], noise[f"cfg2_640x480/m{b}/poses"]) for a, b in ((0, 1), (0, 2), (1, 2))]
+                strict["reference_self_noise"] = {"rot_rad_max": float(max(r.max() for r, _ in pr)), "rel_trans_max": float(max(t.max() for _, t in pr)),
+                                                  "note": "the reference's own pipeline run 3x on this window with different last bits of expf/powf/logf (tests/golden/ref_selfnoise.npz)"}
+        except Exception:
+            pass
+        out = fo
 
     # ---- extra: several independent windows in flight on the one GPU (never the headline value) ----
     conc = None
@@ -258,7 +331,7 @@ def main():
             if len(ref_poses) == int(out["n_registered"]):
                 r2, t2 = synth.pose_errors(out["poses"], ref_poses)
                 vs_ref = {"rot_rad_max": float(r2.max()), "rel_trans_max": float(t2.max()),
-                          "note": "two samples of one estimator (the hypothesis draws differ, D3b): rotation within north_star's 1e-3 rad, translation at the sampling-noise floor"}
+                          "note": "fast mode vs the reference pipeline's own run of this window: within the reference's self-noise under 1-ulp changes of its libm (strict.reference_self_noise)"}
         line = {
             "metric": f"VO frames/s ({W}x{H}, N_flow={N_FLOW}, {EM_ITERS} EM iters)", "value": round(value, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -268,10 +341,10 @@ def main():
             "n_registered": int(out["n_registered"]),
             "pose_rpe_vs_gt": {"rot_rad_max": float(rot.max()) if len(rot) else None, "rel_trans_max": float(tr.max()) if len(tr) else None},
             "pose_rpe_vs_reference": vs_ref,
-            "roofline": roof, "cpu_baseline": cpu, "cpu_reference": cpu_ref, "concurrent": conc,
+            "roofline": roof, "cpu_baseline": cpu, "cpu_reference": cpu_ref, "host_inclusive": host_inc, "strict": strict, "concurrent": conc,
         }
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

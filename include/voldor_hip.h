@@ -66,7 +66,15 @@ int vk_voldor_device(const float* flows, const float* disparity, const float* di
                      float basefocal, int N, int N_dp, int w, int h, const char* config,
                      int* n_registered, float* poses, float* poses_covar, float* depth,
                      float* depth_conf);
-/* per-camera statistics of the last window (voldor/utils.h:41-45): arrays of length >= N */
+/* vk_voldor_device plus the result as one DEVICE record pose_block_dev[1 + 6N + 36N] = { n_registered, poses[N][6],
+ * poses_covar[N][36] } (unregistered slots zero): the send buffer of the multi-GPU pose exchange (one ncclAllGather per batch
+ * step), packed on the device.  The host outputs may be NULL. */
+int vk_voldor_device_block(const float* flows, const float* disparity, const float* disparity_pconf,
+                           const float* depth_priors, const float* depth_prior_poses,
+                           const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+                           float basefocal, int N, int N_dp, int w, int h, const char* config,
+                           int* n_registered, float* poses, float* poses_covar, float* depth,
+                           float* depth_conf, float* pose_block_dev);
 /* n_windows independent windows of the same geometry and config IN FLIGHT TOGETHER on the current device (no reference
  * counterpart: voldor/py_export.cpp processes one window per call).  Argument b of every pointer array belongs to window b
  * (arrays may be NULL where the single call takes NULL); images may be host or device pointers; n_registered[n_windows],
@@ -94,6 +102,7 @@ int vk_eval_covisibility(const float* depth, const unsigned char* mask, const fl
  * the size.  0 ok, 1 cannot open, 2 bad magic / arguments, 3 buffer too small, 4 truncated. */
 int vk_read_flo(const char* path, int* w, int* h, float* out, size_t cap_floats);
 int vk_write_flo(const char* path, const float* flow, int w, int h);
+/* per-camera statistics of the last window (voldor/utils.h:41-45): arrays of length >= N */
 int vk_last_camera_stats(int* pose_sample_count, float* pose_density, float* pose_rigidness_density,
                          int* ms_iters, int* gu_iters, int n);
 /* bootstrap pieces (voldor/geometry.cpp:267-332) exposed for parity tests; host pointers */

@@ -1,15 +1,17 @@
 #!/bin/bash
 # HBM traffic per kernel launch from the PMC counters (MI355X_MICROARCH.md, HBM/rocprofv3 section): FETCH_SIZE and
 # WRITE_SIZE in SEPARATE rocprofv3 --pmc passes (kernel-trace only), per-launch averages, gfx950 correction
-# (FETCH_SIZE reports half of the bytes of coalesced reads).  Run on the GPU box:  bash scripts/pmc_traffic.sh
+# (FETCH_SIZE reports half of the bytes of coalesced reads).  Run on the GPU box:  WL=cfg2 bash scripts/pmc_traffic.sh <tag>
 cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
+tag=${1:-run}; WL=${WL:-cfg2}
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_$c -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${c}_$tag -- python bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --in-flight 0 > gpurun_out/pmc_${c}_$tag.log 2>&1
 done
-python - <<'PY'
-import csv, glob, json, collections
+python - "$tag" "$WL" <<'PY'
+import csv, glob, json, collections, sys
+tag, wl = sys.argv[1], sys.argv[2]
 def load(c):
-    f = glob.glob(f"gpurun_out/pmc_{c}/**/*counter_collection.csv", recursive=True)[0]
+    f = glob.glob(f"gpurun_out/pmc_{c}_{tag}/**/*counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(float); n = collections.Counter(); seen = set()
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
@@ -18,15 +20,14 @@ def load(c):
         if r["Dispatch_Id"] not in seen: seen.add(r["Dispatch_Id"]); n[k] += 1
     return {k: (acc[k] / n[k], n[k]) for k in acc}
 F, W = load("FETCH_SIZE"), load("WRITE_SIZE")
-out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --steps 2 --warmup 1 "
-                "--no-cpu-baseline; per-launch averages in KiB as reported.  gfx950: FETCH_SIZE reports 1/2 of the bytes of coalesced "
-                "reads (MI355X_MICROARCH.md; k_scale reads a 1200 KiB map and reports ~600), WRITE_SIZE is exact.  "
-                "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.",
-       "workload": "cfg2 640x480 N=5", "kernels": {}}
-for k in sorted(F, key=lambda k: -F[k][0]):
+out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --workload WL --steps 2 --warmup 1 "
+                "--no-cpu-baseline --in-flight 0; per-launch averages in KiB as reported.  gfx950: FETCH_SIZE reports 1/2 of the bytes of coalesced "
+                "reads (MI355X_MICROARCH.md), WRITE_SIZE is exact.  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.",
+       "workload": wl, "kernels": {}}
+for k in sorted(F, key=lambda k: -F[k][0] * F[k][1]):
     w = W.get(k, (0.0, 0))[0]
     out["kernels"][k] = {"launches": F[k][1], "FETCH_SIZE_KiB": round(F[k][0], 1), "WRITE_SIZE_KiB": round(w, 1),
                          "hbm_bytes_per_launch": int((2 * F[k][0] + w) * 1024)}
-json.dump(out, open("gpurun_out/pmc_traffic.json", "w"), indent=1)
-for k, v in out["kernels"].items(): print(k[:44].ljust(44), v)
+json.dump(out, open(f"gpurun_out/pmc_traffic_{tag}.json", "w"), indent=1)
+for k, v in list(out["kernels"].items())[:14]: print(k[:44].ljust(44), v)
 PY

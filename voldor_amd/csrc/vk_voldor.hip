@@ -281,10 +281,23 @@ struct Voldor {
 
 static thread_local Voldor g_last;  // stats of the last window (vk_last_camera_stats)
 
+// The result of a window as ONE device-resident record, [n_registered | poses N x 6 | covariances N x 36] floats (unregistered
+// slots zero): what a multi-GPU launcher all-gathers (sendcount 1 + 6N + 36N), packed where the data is
+// instead of a D2H -> numpy -> H2D hop around an 844-byte collective.
+__global__ static void k_pack_pose_block(const CamState* __restrict__ cams, int n_registered, int N, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x, len = 1 + 42 * N;
+    if (i >= len) return;
+    float v = 0.f;
+    if (i == 0) v = (float)n_registered;
+    else if (i < 1 + 6 * N) { const int c = (i - 1) / 6, d = (i - 1) % 6; if (c < n_registered) v = d < 3 ? cams[c].rvec[d] : cams[c].t[d - 3]; }
+    else { const int c = (i - 1 - 6 * N) / 36, k = (i - 1 - 6 * N) % 36; if (c < n_registered) v = cams[c].covar[k]; }
+    out[i] = v;
+}
+
 static int voldor_run_on(Context* c, const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
                          const float* depth_prior_poses, const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
                          float basefocal, int N, int N_dp, int w, int h, const char* config, int* n_registered, float* poses,
-                         float* poses_covar, float* depth, float* depth_conf) {
+                         float* poses_covar, float* depth, float* depth_conf, float* pose_block_dev = nullptr) {
     if (!c) return (int)hipErrorNoDevice;
     Voldor& v = g_last;
     v = Voldor();
@@ -301,6 +314,10 @@ static int voldor_run_on(Context* c, const float* flows, const float* disparity,
         if (int e = c->tmp.reserve(sizeof(float) * npx)) return e;
         if (int e = depth_conf_device(c, c->od.rig.as<float>(), c->od.confs.as<float>(), c->tmp.as<float>(), v.n_flows, v.n_dp, npx)) return e;
         VK_CHECK(hipMemcpyAsync(depth_conf, c->tmp.p, sizeof(float) * npx, hipMemcpyDefault, c->stream));
+    }
+    if (pose_block_dev) {
+        hipLaunchKernelGGL(k_pack_pose_block, dim3((1 + 42 * N + 255) / 256), dim3(256), 0, c->stream, c->cams.as<CamState>(), v.n_flows, N, pose_block_dev);
+        VK_CHECK_LAST();
     }
     VK_CHECK(hipStreamSynchronize(c->stream));
     *n_registered = v.n_flows;
@@ -410,6 +427,13 @@ int vk_voldor_device(const float* flows, const float* disparity, const float* di
                      float* poses_covar, float* depth, float* depth_conf) {
     return vk::voldor_run(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, fx, fy, cx, cy,
                           basefocal, N, N_dp, w, h, config, n_registered, poses, poses_covar, depth, depth_conf);
+}
+int vk_voldor_device_block(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
+                           const float* depth_prior_poses, const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+                           float basefocal, int N, int N_dp, int w, int h, const char* config, int* n_registered, float* poses,
+                           float* poses_covar, float* depth, float* depth_conf, float* pose_block_dev) {
+    return vk::voldor_run_on(vk::default_context(), flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, fx, fy,
+                             cx, cy, basefocal, N, N_dp, w, h, config, n_registered, poses, poses_covar, depth, depth_conf, pose_block_dev);
 }
 int vk_voldor_device_batch(int n_windows, const float* const* flows, const float* const* disparity, const float* const* disparity_pconf,
                            const float* const* depth_priors, const float* const* depth_prior_poses,

@@ -44,14 +44,18 @@ def unpack_pose_block(blk, n_flows: int) -> dict:
 
 def allgather_pose_blocks(blk, group=None, device=None):
     """All-gather one pose block per rank. Returns a [world, block_len] float32 numpy array on every rank.
-    `blk` is a numpy array; `device` selects where the collective runs ("cuda" for RCCL, None/"cpu" for gloo)."""
+    `blk` is a numpy array (`device` then selects where the collective runs: "cuda" for RCCL, None/"cpu" for gloo) or a torch
+    tensor that already lives there (no host hop: vk_voldor_device_block packs the record on the device)."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
-    send = torch.from_numpy(np.ascontiguousarray(blk, np.float32))
-    if device is not None and str(device) != "cpu":
-        send = send.to(device, non_blocking=True)
+    if torch.is_tensor(blk):  # already where the collective runs, e.g. the device record of pyvoldor.voldor_device(pose_block_out=...)
+        send = blk.reshape(-1)
+    else:
+        send = torch.from_numpy(np.ascontiguousarray(blk, np.float32))
+        if device is not None and str(device) != "cpu":
+            send = send.to(device, non_blocking=True)
     recv = torch.empty(world * send.numel(), dtype=torch.float32, device=send.device)
     dist.all_gather_into_tensor(recv, send, group=group)
     return recv.view(world, -1).cpu().numpy()

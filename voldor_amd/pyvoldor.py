@@ -90,9 +90,11 @@ def voldor(flows, fx, fy, cx, cy, basefocal=0, disparity=None, disparity_pconf=N
 
 
 def voldor_device(flows, fx, fy, cx, cy, basefocal=0, disparity=None, disparity_pconf=None, depth_priors=None,
-                  depth_prior_poses=None, depth_prior_pconfs=None, config="", depth_out=None, depth_conf_out=None):
+                  depth_prior_poses=None, depth_prior_pconfs=None, config="", depth_out=None, depth_conf_out=None, pose_block_out=None):
     """Same call for torch CUDA(HIP) tensors already resident in HBM (bench.py). Image-sized
-    arguments are torch float32 tensors on the current device; poses come back as numpy."""
+    arguments are torch float32 tensors on the current device; poses come back as numpy.
+    pose_block_out: optional float32 device tensor of voldor_amd.dist.block_len(N) elements that receives
+    [n_registered | poses | covariances] on the device (the send buffer of the multi-GPU pose all-gather)."""
     import torch
 
     def dp(t):
@@ -115,12 +117,14 @@ def voldor_device(flows, fx, fy, cx, cy, basefocal=0, disparity=None, disparity_
     poses_covar = np.zeros((N, 6, 6), dtype=np.float32)
     dpp = None if depth_prior_poses is None else capi.f32(depth_prior_poses)
     n_registered = C.c_int(0)
-    rc = capi.lib().vk_voldor_device(
+    if pose_block_out is not None and pose_block_out.numel() != 1 + 42 * N:
+        raise ValueError(f"pose_block_out must hold 1 + 42 N = {1 + 42 * N} floats, got {pose_block_out.numel()}")
+    rc = capi.lib().vk_voldor_device_block(
         dp(flows), dp(disparity), dp(disparity_pconf), dp(depth_priors), capi.fp(dpp), dp(depth_prior_pconfs),
         C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_float(basefocal), C.c_int(N), C.c_int(N_dp),
         C.c_int(w), C.c_int(h), str(config).encode(), C.byref(n_registered), capi.fp(poses), capi.fp(poses_covar),
-        dp(depth_out), dp(depth_conf_out))
-    capi.check(rc, "vk_voldor_device")
+        dp(depth_out), dp(depth_conf_out), dp(pose_block_out))
+    capi.check(rc, "vk_voldor_device_block")
     n = n_registered.value
     return {"n_registered": n, "poses": poses[:n], "poses_covar": poses_covar[:n], "depth": depth_out, "depth_conf": depth_conf_out}
 
