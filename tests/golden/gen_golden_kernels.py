@@ -121,8 +121,37 @@ def ref_align(ref, kf, photo, evals):
         yield name, res, jac
 
 
+def main_strict(ref):
+    """tests/golden/ref_kernels_strict.npz: the stages that call the C library's transcendentals (optimize_depth: expf / powf / logf;
+    the solvers: atan2f, AP3P's cbrtf / powf / cosf; mean-shift: expf) run again with those calls served by
+    voldor_amd/csrc/vk_strict_math.h (ref_set_math_mode(1), oracle/ref_stubs/emul/cuda_emul.h).  The HIP kernels in strict mode must
+    reproduce these bit for bit (tests/test_gpu_vs_ref_kernels.py); fb_smooth, collect and the robust Gaussian call no libm, their
+    strict-mode outputs are compared with ref_kernels.npz itself."""
+    out = {}
+    ref.ref_set_math_mode(1)
+    try:
+        for name, c in cases.depth_cases():
+            d, r, cf, cost = ref_depth(ref, c)
+            out[f"od/{name}/depth"], out[f"od/{name}/rig"], out[f"od/{name}/cost"] = d, r, cost
+            if cf is not None:
+                out[f"od/{name}/confs"] = cf
+        for name, p3s, p2s, K, n_poses, use_ap3p in cases.solve_cases():
+            rv, tv = ref_solve(ref, p3s, p2s, K, n_poses, use_ap3p)
+            out[f"solve/{name}/rvecs"], out[f"solve/{name}/tvecs"] = rv, tv
+        for name, space, kernel_var, init_mean, ext, a in cases.meanshift_cases():
+            mean, conf, it = ref_meanshift(ref, space, kernel_var, init_mean, ext, a)
+            out[f"ms/{name}/mean"], out[f"ms/{name}/conf"], out[f"ms/{name}/iters"] = mean, conf, np.int32(it)
+    finally:
+        ref.ref_set_math_mode(0)
+    path = os.path.join(HERE, "ref_kernels_strict.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
 def main():
     ref = load_ref()
+    if "--strict" in sys.argv:
+        return main_strict(ref)
     out = {}
     for name, kf, photo, evals in cases.align_cases():
         for ename, res, jac in ref_align(ref, kf, photo, evals):

@@ -157,3 +157,88 @@ def test_gblur_vs_reference_kernel(gold, name, src, sigma, ksize):
     assert (rc == 0) == (g_rc == 0)
     if g_rc == 0:
         assert np.abs(dst - gold[f"gblur/{name}/dst"]).max() < 1e-5 * max(1.0, np.abs(src).max())
+
+
+# ---- strict mode: the HIP kernels equal the REFERENCE's own kernel code, bit for bit ---------------------------------------------
+# Goldens: ref_kernels.npz for the stages that call no libm (fb_smooth, collect_p3p_instances, fit_robust_gaussian), and
+# ref_kernels_strict.npz (the reference's .cu files with their libm calls served by vk_strict_math.h, gen_golden_kernels.py --strict)
+# for optimize_depth, the solvers and mean-shift.  Not bit-exact by design: rotation vectors (D8: exact polar factor instead of the
+# reference's approximate SVD).
+GOLD_STRICT = os.path.join(os.path.dirname(__file__), "golden", "ref_kernels_strict.npz")
+
+
+@pytest.fixture()
+def strict_mode():
+    from voldor_amd import kernels
+    kernels.set_strict_math(True)
+    yield np.load(GOLD_STRICT)
+    kernels.set_strict_math(False)
+
+
+def _bits(a, b, what):
+    a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+    eq = (a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))
+    assert eq.all(), f"{what}: {(~eq).sum()} of {eq.size} values differ"
+
+
+@pytest.mark.parametrize("name,maps,s0,p", list(cases.fb_cases()), ids=[c[0] for c in cases.fb_cases()])
+def test_strict_fb_smooth_equals_reference_kernel(gold, strict_mode, name, maps, s0, p):
+    from voldor_amd import kernels
+    rc, out = kernels.fb_smooth_gpu(maps, s0, p)
+    assert rc == 0
+    _bits(out, gold[f"fb/{name}"], "smoothed maps")
+
+
+@pytest.mark.parametrize("name,c", list(cases.depth_cases()), ids=[c[0] for c in cases.depth_cases()])
+def test_strict_optimize_depth_equals_reference_kernels(strict_mode, name, c):
+    """cost map, random samples, both propagations (alone and chained), priors, ragged sizes, E-step, prior confidences"""
+    g = strict_mode
+    depth, rig, confs = _run_depth(c)
+    _bits(depth, g[f"od/{name}/depth"], "depth"); _bits(rig, g[f"od/{name}/rig"], "rigidness")
+    if confs is not None and confs.shape[0]:
+        _bits(confs, g[f"od/{name}/confs"], "prior confidences")
+
+
+@pytest.mark.parametrize("name,c,active_idx,a", list(cases.collect_cases()), ids=[c[0] for c in cases.collect_cases()])
+def test_strict_collect_equals_reference_kernel(gold, strict_mode, name, c, active_idx, a):
+    from voldor_amd import kernels
+    N, h, w, _ = c["flows"].shape
+    K = np.asarray(c["K"], np.float32).reshape(3, 3)
+    p2, p3 = kernels.collect_p3p_instances(c["flows"], c["rig"], c["depth"], K, c["Rs"], c["ts"], N, w, h, active_idx, **a)
+    _bits(p2, gold[f"collect/{name}/p2"], "p2 map"); _bits(p3, gold[f"collect/{name}/p3"], "p3 map")
+
+
+@pytest.mark.parametrize("name,X,uv,K,n_poses,use_ap3p", list(cases.solve_cases()), ids=[c[0] for c in cases.solve_cases()])
+def test_strict_solver_translations_equal_reference_kernel(strict_mode, name, X, uv, K, n_poses, use_ap3p):
+    """index draw + minimal solver + 4th-point selection: every translation bit-identical; rotation vectors to the accuracy of the
+    reference's approximate SVD (D8)"""
+    from voldor_amd import kernels
+    fn = kernels.solve_batch_p3p_ap3p_gpu if use_ap3p else kernels.solve_batch_p3p_lambdatwist_gpu
+    rv, tv = fn(X, uv, K, n_poses)
+    g_rv, g_tv = strict_mode[f"solve/{name}/rvecs"], strict_mode[f"solve/{name}/tvecs"]
+    _bits(tv, g_tv, "translations")
+    fin = np.isfinite(g_rv.sum(1))
+    assert np.percentile(np.abs(rv[fin] - g_rv[fin]).max(1), 99) < 2e-5
+
+
+@pytest.mark.parametrize("name,space,kernel_var,init_mean,ext,a", list(cases.meanshift_cases()), ids=[c[0] for c in cases.meanshift_cases()])
+def test_strict_meanshift_equals_reference(strict_mode, name, space, kernel_var, init_mean, ext, a):
+    from voldor_amd import kernels
+    mean, conf, iters = kernels.meanshift_gpu(space, kernel_var, init_mean, ext, **a)
+    g = strict_mode
+    _bits(mean, g[f"ms/{name}/mean"], "mode")
+    assert np.float32(conf).tobytes() == np.float32(g[f"ms/{name}/conf"]).tobytes() and iters == int(g[f"ms/{name}/iters"])
+
+
+@pytest.mark.parametrize("name,space,mean0,cov0,a", list(cases.rg_cases()), ids=[c[0] for c in cases.rg_cases()])
+def test_strict_fit_robust_gaussian_equals_reference(gold, strict_mode, name, space, mean0, cov0, a):
+    """mean, covariance, density, iteration count and verdict of fit_robust_gaussian.cu, bit for bit (covariance was 2e-2)"""
+    from voldor_amd import kernels
+    rc, mean, covar, dens, iters = kernels.fit_robust_gaussian(space, mean0, cov0, **a)
+    g_rc = int(gold[f"rg/{name}/rc"])
+    assert (rc == 0) == (g_rc == 0)
+    if g_rc != 0:
+        np.testing.assert_array_equal(mean, mean0); np.testing.assert_array_equal(covar, cov0)
+        return
+    _bits(mean, gold[f"rg/{name}/mean"], "mean"); _bits(covar, gold[f"rg/{name}/covar"], "covariance")
+    assert np.float32(dens).tobytes() == np.float32(gold[f"rg/{name}/density"]).tobytes() and iters == int(gold[f"rg/{name}/iters"])

@@ -289,7 +289,8 @@ int meanshift_gpu(float* h_space, float kernel_var, float* h_io_mean, float* h_o
     mp.use_external_init_mean = use_external_init_mean ? 1 : 0;
     if (used_iters) *used_iters = 0;
     int* ioi = reinterpret_cast<int*>(c->ms_io.as<float>() + 64);
-    if (int e = meanshift_device(c, c->pool.as<float>(), N, mp, c->ms_io.as<float>(), ioi)) return e;
+    if (strict_math_default() && N <= 32768) { if (int e = meanshift_strict_device(c, c->pool.as<float>(), N, mp, c->ms_io.as<float>(), ioi)) return e; }
+    else if (int e = meanshift_device(c, c->pool.as<float>(), N, mp, c->ms_io.as<float>(), ioi)) return e;
     int hi[2] = { 0, 0 };
     VK_CHECK(hipMemcpyAsync(io, c->ms_io.p, sizeof io, hipMemcpyDeviceToHost, c->stream));
     VK_CHECK(hipMemcpyAsync(hi, ioi, sizeof hi, hipMemcpyDeviceToHost, c->stream));
@@ -323,7 +324,8 @@ int fit_robust_gaussian(float* h_space, float* h_io_mean, float* h_io_covar, flo
     mp.rg_max_iters = max_iters;
     if (used_iters) *used_iters = 0;
     int* ioi = reinterpret_cast<int*>(c->ms_io.as<float>() + 64);
-    if (int e = robust_gaussian_device(c, c->pool.as<float>(), N, mp, c->ms_io.as<float>(), ioi)) return e;
+    if (strict_math_default() && N <= 32768) { if (int e = robust_gaussian_strict_device(c, c->pool.as<float>(), N, mp, c->ms_io.as<float>(), ioi)) return e; }
+    else if (int e = robust_gaussian_device(c, c->pool.as<float>(), N, mp, c->ms_io.as<float>(), ioi)) return e;
     int hi[2] = { 0, 0 };
     VK_CHECK(hipMemcpyAsync(io, c->ms_io.p, sizeof io, hipMemcpyDeviceToHost, c->stream));
     VK_CHECK(hipMemcpyAsync(hi, ioi, sizeof hi, hipMemcpyDeviceToHost, c->stream));

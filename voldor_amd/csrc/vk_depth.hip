@@ -43,6 +43,7 @@ __device__ __forceinline__ bool clamp_active(Img& I) {
 // depth-prior term of compute_pixel_cost (optimize_depth.cu:166-190): the hypothesis seen from prior f's camera against the
 // prior map, weighted by the prior's confidences (all three sampled bilinearly at the projected position)
 __device__ __forceinline__ static void prior_term_strict(const Img& I, const PoseBlock* P, int f, int px, int py, float depth, float& cost_sum, float& wsum) {
+#pragma clang fp contract(off)  // strict: one rounding per operation, also across statements (wsum += wg must not become an fma)
     const int w = I.w, h = I.h, npx = w * h;
     P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
     float qx2, qy2;
@@ -69,6 +70,7 @@ __device__ __forceinline__ static void prior_term_strict(const Img& I, const Pos
 // oracle in strict mode.  The fast ("lean") kernels further down share the structure, not the arithmetic.
 template <int NMAX>
 __device__ __forceinline__ static float pixel_cost_strict(const Img& I, int px, int py, float depth) {
+#pragma clang fp contract(off)
     const int w = I.w, h = I.h, npx = w * h, pi = py * w + px;
     const PoseBlock* P = I.P;
     float qx[NMAX], qy[NMAX], rdx[NMAX], rdy[NMAX];
@@ -120,6 +122,7 @@ __device__ __forceinline__ static float pixel_cost_strict(const Img& I, int px, 
 // ---- cost map + all random samples, fused (optimize_depth.cu:279-284 + :269-277 x n_rand) ----
 template <int NMAX>
 __global__ __launch_bounds__(256) static void k_cost_rand_strict(Img I, int n_rand, uint32_t epoch0, float range_factor) {
+#pragma clang fp contract(off)  // the random depth range_factor * u + 1/MAXIMUM_DEPTH is an output value: no fma
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
@@ -188,6 +191,7 @@ __device__ __forceinline__ ChainGeom chain_geom(int w, int h, int dir, int width
 // test of voldor.cpp:171 then needs no D2H of the maps).  Same three-phase structure as pixel_cost.
 template <int NMAX>
 __global__ __launch_bounds__(256) static void k_update_rigidness_strict(Img I, float* __restrict__ partial) {
+#pragma clang fp contract(off)
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
@@ -443,6 +447,7 @@ __device__ __forceinline__ static float pixel_cost_lean(const Img& I, const Lean
 constexpr int CRQ_NS = 5;  // samples per round: queue capacity 256 * CRQ_NS entries (20 KB of LDS)
 struct CrqEntry { unsigned id; float d, cs, ws; };  // id = lane-in-workgroup | sample << 8
 __device__ __forceinline__ float sample_depth(int pi, uint32_t epoch, float range_factor) {
+#pragma clang fp contract(off)
     const float u = u01(rng3(RAND_SEED, (uint32_t)pi, epoch));
     return 1.0f / (range_factor * u + (1.0f / 1e5f));  // MAXIMUM_DEPTH, optimize_depth.cu:15,:273 (exact: the depth VALUES are outputs)
 }

@@ -42,6 +42,8 @@ int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0
 // vk_strict.hip
 int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr);
 int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
+int meanshift_strict_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
+int robust_gaussian_strict_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int fill_device(Context* c, float* p, float v, size_t n);
 int scale_device(Context* c, float* p, const float* s_dev, size_t n);
 int disp_to_depth_device(Context* c, const float* disp, float* out, float bf, size_t n);

@@ -392,6 +392,170 @@ __global__ __launch_bounds__(ST_THREADS) static void k_pose_strict(const float* 
     }
 }
 
+// ---- B-inner, strict: meanshift_gpu / fit_robust_gaussian on a host-supplied sample matrix space[N][dims] ------------------------
+// Same arithmetic as k_pose_strict (the reference's tree-order sums, serial fp64 LU), generic in the dimension like the reference's
+// entry points (meanshift.cu:34-150: dims <= 16; fit_robust_gaussian.cu:101-286: dims <= 6).  io layout as k_meanshift_only /
+// k_robust_gaussian_only in vk_pose.hip.
+__global__ __launch_bounds__(ST_THREADS) static void k_meanshift_strict(const float* __restrict__ space, int N, ModeParams mp, float* __restrict__ io,
+                                                                         int* __restrict__ ioi) {
+#pragma clang fp contract(off)
+    __shared__ TreeBuf<17> tb;
+    const int dims = mp.dims;
+    float io_mean[16], c_mean[16];
+    for (int d = 0; d < 16; d++) { io_mean[d] = d < dims ? io[d] : 0.f; c_mean[d] = io_mean[d]; }
+    const float two_var = 2 * mp.kernel_var;
+    if (!mp.use_external_init_mean) {  // meanshift.cu:72-95
+        float best = 0;
+        int best_idx = -1;
+        for (int trial = 0; trial < mp.ms_max_init_trials; trial++) {
+            const int idx_rand = (int)(rng3(RAND_SEED, (uint32_t)trial, 0x4D53u) % (uint32_t)N);
+            auto elem = [&](int i, float* v) {
+                float l2 = 0;
+                for (int d = 0; d < dims; d++) { const float df = space[(size_t)i * dims + d] - space[(size_t)idx_rand * dims + d]; l2 += df * df; }
+                v[0] = vsm_expf(-l2 / two_var);
+                for (int k = 1; k < 17; k++) v[k] = 0.f;
+            };
+            tree_sum<17>(N, elem, tb);
+            const float wsum = tb.out[0];
+            __syncthreads();
+            if (wsum > best) { best = wsum; best_idx = idx_rand; }
+            if (best > mp.ms_good_init_confidence * (float)N) break;
+        }
+        if (best_idx < 0) best_idx = 0;
+        for (int d = 0; d < dims; d++) c_mean[d] = space[(size_t)best_idx * dims + d];
+    }
+    int iters = 0;
+    float conf = 0.f;
+    for (int iter = 0; iter < mp.ms_max_iters; iter++) {  // :103-134
+        auto elem = [&](int i, float* v) {
+            float l2 = 0;
+            for (int d = 0; d < dims; d++) { const float df = space[(size_t)i * dims + d] - c_mean[d]; l2 += df * df; }
+            const float wgt = vsm_expf(-l2 / two_var);
+            v[0] = wgt;
+            for (int d = 0; d < 16; d++) v[1 + d] = d < dims ? space[(size_t)i * dims + d] * wgt : 0.f;
+        };
+        tree_sum<17>(N, elem, tb);
+        const float wsum = tb.out[0];
+        float m[16];
+        for (int d = 0; d < 16; d++) m[d] = d < dims ? tb.out[1 + d] / wsum : 0.f;
+        __syncthreads();
+        conf = wsum / (float)N;
+        iters = iter + 1;
+        float disp = 0;
+        for (int d = 0; d < dims; d++) disp += (io_mean[d] - m[d]) * (io_mean[d] - m[d]);
+        disp = sqrtf(disp);
+        for (int d = 0; d < dims; d++) io_mean[d] = m[d];
+        if (disp < mp.ms_epsilon) break;
+        for (int d = 0; d < dims; d++) c_mean[d] = io_mean[d];
+    }
+    if (threadIdx.x == 0) {
+        for (int d = 0; d < dims; d++) io[d] = io_mean[d];
+        io[16] = conf; ioi[0] = iters; ioi[1] = 0;
+    }
+}
+// io: [0..5] mean in/out, [6..41] covar full (dims x dims) in/out, [42] density out ; ioi: [0] iters, [1] 0 reliable / 1 not
+__global__ __launch_bounds__(ST_THREADS) static void k_rg_strict(const float* __restrict__ space, int N, ModeParams mp, float* __restrict__ io,
+                                                                  int* __restrict__ ioi) {
+#pragma clang fp contract(off)
+    __shared__ TreeBuf<28> tb;
+    __shared__ double s_full[36], s_inv[36];
+    __shared__ float s_cov[21], s_cinv[21], s_mean[6];
+    __shared__ int s_flag;
+    const int dims = mp.dims, t = threadIdx.x, dc = (dims * dims + dims) / 2;
+    if (t < dims) s_mean[t] = io[t];
+    if (t == 0)
+        for (int d1 = 0; d1 < dims; d1++)
+            for (int d2 = 0; d2 <= d1; d2++) s_cov[(d1 * d1 + d1) / 2 + d2] = io[6 + d1 * dims + d2];
+    __syncthreads();
+    float weight = 0;
+    int iter = 0;
+    bool reliable = true;
+    for (iter = 0; iter < mp.rg_max_iters; iter++) {
+        if (t == 0) {
+            for (int d1 = 0; d1 < dims; d1++)
+                for (int d2 = 0; d2 <= d1; d2++) {
+                    s_full[d1 * dims + d2] = (double)s_cov[(d1 * d1 + d1) / 2 + d2];
+                    if (d1 != d2) s_full[d2 * dims + d1] = s_full[d1 * dims + d2];
+                }
+            if (iter > 0 && mp.rg_covar_reg_lambda > 0) {
+                double tr = 0;
+                for (int d = 0; d < dims; d++) tr += s_full[d * dims + d];
+                const double m = tr / (double)dims, lam = (double)mp.rg_covar_reg_lambda;
+                for (int i = 0; i < dims; i++)
+                    for (int j = 0; j < dims; j++) s_full[i * dims + j] = lam * m * (i == j ? 1.0 : 0.0) + (1 - lam) * s_full[i * dims + j];
+            }
+            const double det = lu_inverse_serial(s_full, s_inv, dims);
+            s_flag = det <= 0 ? 2 : 0;
+            if (det > 0)
+                for (int d1 = 0; d1 < dims; d1++)
+                    for (int d2 = 0; d2 <= d1; d2++) {
+                        s_cov[(d1 * d1 + d1) / 2 + d2] = (float)s_full[d1 * dims + d2];
+                        s_cinv[(d1 * d1 + d1) / 2 + d2] = (float)s_inv[d1 * dims + d2];
+                    }
+        }
+        __syncthreads();
+        if (s_flag == 2) { reliable = false; break; }
+        const float prev_density = weight / (float)N;
+        auto elem = [&](int i, float* v) {  // e_step (:56-97)
+            float x[6], diff[6];
+            for (int d = 0; d < 6; d++) { x[d] = d < dims ? space[(size_t)i * dims + d] : 0.f; diff[d] = d < dims ? x[d] - s_mean[d] : 0.f; }
+            float z = 0;
+            for (int d1 = 0; d1 < dims; d1++) {
+                float tmp = 0;
+                for (int d2 = 0; d2 < dims; d2++) {
+                    const int hi = d1 >= d2 ? d1 : d2, lo = d1 >= d2 ? d2 : d1;
+                    tmp += s_cinv[(hi * hi + hi) / 2 + lo] * diff[d2];
+                }
+                z += tmp * diff[d1];
+            }
+            z = sqrtf(z);
+            const float wgt = z < mp.rg_trunc_sigma ? 1.f : 0.f;
+            for (int k = 0; k < 28; k++) v[k] = 0.f;
+            v[0] = wgt;
+            for (int d = 0; d < dims; d++) v[1 + d] = wgt * x[d];
+            for (int d1 = 0; d1 < dims; d1++)
+                for (int d2 = 0; d2 <= d1; d2++) v[7 + (d1 * d1 + d1) / 2 + d2] = wgt * diff[d1] * diff[d2];
+        };
+        tree_sum<28>(N, elem, tb);
+        weight = tb.out[0];
+        float nm[6], nc[21];
+        for (int d = 0; d < 6; d++) nm[d] = tb.out[1 + d] / weight;
+        for (int k = 0; k < 21; k++) nc[k] = tb.out[7 + k] / weight;
+        __syncthreads();
+        if (!isfinite(weight)) { reliable = false; break; }
+        if (fabsf(weight / (float)N - prev_density) < mp.rg_epsilon) { reliable = true; break; }
+        if (t < dims) s_mean[t] = nm[t];
+        if (t < dc) s_cov[t] = nc[t];
+        __syncthreads();
+    }
+    __syncthreads();
+    if (t == 0) {
+        ioi[1] = reliable ? 0 : 1;
+        if (reliable) {
+            ioi[0] = iter;
+            io[42] = weight / (float)N;
+            for (int d = 0; d < dims; d++) io[d] = s_mean[d];
+            for (int d1 = 0; d1 < dims; d1++)
+                for (int d2 = 0; d2 <= d1; d2++) {
+                    io[6 + d1 * dims + d2] = s_cov[(d1 * d1 + d1) / 2 + d2];
+                    io[6 + d2 * dims + d1] = s_cov[(d1 * d1 + d1) / 2 + d2];
+                }
+        }
+    }
+}
+int meanshift_strict_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev) {
+    if (N > 2 * ST_THREADS * ST_MAXBLK) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_meanshift_strict, dim3(1), dim3(ST_THREADS), 0, c->stream, space_dev, N, mp, io_dev, ioi_dev);
+    VK_CHECK_LAST();
+    return 0;
+}
+int robust_gaussian_strict_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev) {
+    if (N > 2 * ST_THREADS * ST_MAXBLK) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_rg_strict, dim3(1), dim3(ST_THREADS), 0, c->stream, space_dev, N, mp, io_dev, ioi_dev);
+    VK_CHECK_LAST();
+    return 0;
+}
+
 int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx) {
     if (n_poses > 2 * ST_THREADS * ST_MAXBLK) {
         fprintf(stderr, "voldor_hip: strict mode supports up to %d pose hypotheses\n", 2 * ST_THREADS * ST_MAXBLK);
