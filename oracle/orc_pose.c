@@ -8,6 +8,7 @@
 #include "orc_math.h"
 #include <tgmath.h>
 #include <float.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -628,6 +629,7 @@ int orc_fit_robust_gaussian(const float* space, float* io_mean, float* io_covar,
                 for (int d2 = 0; d2 <= d1; d2++) e_c[(size_t)i * dc + (d1 * d1 + d1) / 2 + d2] = wgt * diff[d1] * diff[d2];
         }
         ref_tree_sum(e_w, N, 1, &ht_weight); /* m step :213-243, sums in the reference's tree order */
+        if (getenv("ORC_PRINT_RG")) fprintf(stderr, "orc rg: iter %d gated %.0f of %d\n", iter, ht_weight, N);
         int stop = 0;
         if (!isfinite(ht_weight)) { reliable = 0; stop = 1; }
         else if (fabsf(ht_weight / N - prev_density) < epsilon) { reliable = 1; stop = 1; }
