@@ -14,8 +14,8 @@
 //  * return value: 0 on success, otherwise the HIP runtime error code as int (message on stderr);
 //    fit_robust_gaussian additionally returns non-zero for an unreliable fit;
 //  * N <= 16 flows, N_dp <= 16 depth priors; not thread-safe (one caller thread per device).
-// The two frame-alignment symbols of the reference header (gpu_kernels.h:60-74) belong to the
-// mapping back-end and are out of scope.
+// The two frame-alignment symbols of the reference header (gpu_kernels.h:60-74, the mapping
+// back-end's residual / Jacobian maps) are declared at the end of this file.
 #pragma once
 
 #define DLL_EXPORT __attribute__((visibility("default")))

@@ -2,7 +2,7 @@
 # per-kernel time of one bench run: scripts/kstats.sh <tag>   (env WL, VOLDOR_HIP_LEAN as in bench/ab scripts)
 cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
 tag=$1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$tag -- python bench.py --workload ${WL:-cfg2} --steps 5 --warmup 2 --no-cpu-baseline --in-flight 0 > gpurun_out/ks_$tag.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ks_$tag -- python bench.py --workload ${WL:-cfg2} --steps 5 --warmup 2 --no-extras > gpurun_out/ks_$tag.log 2>&1
 f=$(ls -t $(find gpurun_out/ks_$tag -name "*kernel_stats.csv") | head -1)
 cp "$f" gpurun_out/ks_$tag.csv
 python - "$f" <<'PY'

@@ -4,7 +4,7 @@
 cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
 tag=$1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_BUSY_CYCLES \
-  --output-format csv -d gpurun_out/pmc_sq_$tag -- python bench.py --workload ${WL:-cfg2} --steps 3 --warmup 1 --no-cpu-baseline --in-flight 0 > gpurun_out/pmc_sq_$tag.log 2>&1
+  --output-format csv -d gpurun_out/pmc_sq_$tag -- python bench.py --workload ${WL:-cfg2} --steps 3 --warmup 1 --no-extras > gpurun_out/pmc_sq_$tag.log 2>&1
 f=$(ls -t $(find gpurun_out/pmc_sq_$tag -name "*counter_collection.csv") | head -1)
 k=$(ls -t $(find gpurun_out/pmc_sq_$tag -name "*kernel_trace.csv") | head -1)
 python - "$f" "$k" "gpurun_out/pmc_sq_$tag.json" <<'PY'

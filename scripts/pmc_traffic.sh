@@ -5,7 +5,7 @@
 cd "$GRAFT_REPO_ROOT" && export TMPDIR=/tmp
 tag=${1:-run}; WL=${WL:-cfg2}
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${c}_$tag -- python bench.py --workload $WL --steps 2 --warmup 1 --no-cpu-baseline --in-flight 0 > gpurun_out/pmc_${c}_$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${c}_$tag -- python bench.py --workload $WL --steps 2 --warmup 1 --no-extras > gpurun_out/pmc_${c}_$tag.log 2>&1
 done
 python - "$tag" "$WL" <<'PY'
 import csv, glob, json, collections, sys
