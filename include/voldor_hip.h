@@ -122,6 +122,10 @@ unsigned vk_get_rand_epoch(void);
  * default comes from the environment variable VOLDOR_HIP_STRICT_MATH. */
 int vk_set_strict_math(int on);
 int vk_get_strict_math(void);
+/* Verification aid: 1 = the local-propagation pass of the fast mode walks every chain step by step (one lane per chain, the literal
+ * optimize_depth.cu:320-396 order) instead of the table + speculative-run kernel; both must give identical maps
+ * (tests/test_gpu_kernels.py::test_local_runs_equal_the_step_by_step_chain). */
+int vk_set_local_serial(int on);
 int vk_profile_enable(int on);           /* HIP-event timing of kernel groups on the library's stream */
 int vk_profile_get(const char* name, double* total_ms, long* count);
 int vk_device_count(void);

@@ -8,7 +8,12 @@ Two records per window:
               approximate-SVD rodrigues and its draw differ from the product's).
   strict/...  the oracle in strict-math mode (orc_set_strict_math(1), default draw): sha256 of the full depth and confidence maps,
               poses, covariances.  The HIP path in --strict_math 1 must reproduce these BIT FOR BIT at full size
-              (tests/test_gpu_configs.py)."""
+              (tests/test_gpu_configs.py).
+
+python tests/golden/gen_golden_big.py --noise cfg3   writes tests/golden/ref_big_noise_cfg3.npz: the reference pipeline run twice more on the
+same window, with strict-math transcendentals (ref_set_math_mode(1)) and with the last bit of every expf/powf/logf result jittered
+(mode 2), poses and covariances only: the reference's own sensitivity to the last bit of its libm at this size, which is what the
+fast-mode comparison is held to (as tests/golden/gen_golden_strict.py does for cfg2)."""
 import hashlib
 import os
 import sys
@@ -24,8 +29,31 @@ from oracle import orc  # noqa: E402
 import big_window_cases as big  # noqa: E402
 
 
+def noise(which):
+    ref = orc.ref()
+    for name in which:
+        c = big.make(name)
+        fx, fy, cx, cy = c["K"]
+        out = {}
+        for mode in (1, 2):
+            t0 = time.time()
+            ref.ref_set_math_mode(mode)
+            try:
+                r = orc.ref_voldor(c["flows"], fx, fy, cx, cy, config=c["config"], basefocal=c["basefocal"], disparity=c["disparity"])
+            finally:
+                ref.ref_set_math_mode(0)
+            print(f"{name}: reference pipeline, math mode {mode}: {time.time() - t0:.0f} s, n_registered {r['n_registered']}", flush=True)
+            out[f"{name}/m{mode}/n_registered"] = np.int32(r["n_registered"])
+            out[f"{name}/m{mode}/poses"], out[f"{name}/m{mode}/poses_covar"] = r["poses"], r["poses_covar"]
+        path = os.path.join(HERE, f"ref_big_noise_{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}", flush=True)
+
+
 def main():
     which = [a for a in sys.argv[1:] if a in big.CASES] or list(big.CASES)
+    if "--noise" in sys.argv:
+        return noise(which)
     path = os.path.join(HERE, "ref_big.npz")
     out = dict(np.load(path)) if os.path.exists(path) else {}
     for name in which:

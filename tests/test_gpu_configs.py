@@ -191,7 +191,14 @@ def test_big_window_fast_mode_vs_the_reference_pipeline(name):
     o = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"], config=c["config"])
     assert o["n_registered"] == int(g[f"{name}/ref/n_registered"])
     rot, tr = synth.pose_errors(o["poses"], g[f"{name}/ref/poses"])
-    assert rot.max() < 1e-3 and tr.max() < 3e-2, (rot, tr)
+    # the bar: twice the largest distance between the reference's OWN runs of this window under three libms that differ in the last
+    # bit (glibc / strict / 1-ulp jitter: tests/golden/gen_golden_big.py --noise; cfg3: 3.6e-4 rad, 2.0e-2), the rule of
+    # test_fast_vs_strict_within_the_reference_self_noise; rotation additionally inside north_star's 1e-3 rad
+    nz = np.load(os.path.join(os.path.dirname(BIG_GOLD), f"ref_big_noise_{name}.npz"))
+    runs = [g[f"{name}/ref/poses"], nz[f"{name}/m1/poses"], nz[f"{name}/m2/poses"]]
+    pairs = [synth.pose_errors(runs[a], runs[b]) for a, b in ((0, 1), (0, 2), (1, 2))]
+    rot_noise, tr_noise = max(r.max() for r, _ in pairs), max(t.max() for _, t in pairs)
+    assert rot.max() < min(1e-3, 2 * rot_noise + 2e-4) and tr.max() < 2 * tr_noise, (rot, tr, rot_noise, tr_noise)
     d, cf = o["depth"][::4, ::4], o["depth_conf"][::4, ::4]
     rd, rcf = g[f"{name}/ref/depth_sub4"], g[f"{name}/ref/depth_conf_sub4"]
     m = (cf > 0.5) & (rcf > 0.5)

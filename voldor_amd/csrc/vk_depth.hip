@@ -13,6 +13,7 @@
 //   update_rigidness            1 launch (+ per-block rigidness sums for the density test)
 // Every per-pixel kernel clamps its frame count to PoseBlock::n_active (device-side truncation decision) and
 // remaps its workgroup id so that an XCD works on one band of the image (xcd_band_tile).
+#include <atomic>
 #include "vk_common.hpp"
 #include "vk_device.hpp"
 #include "vk_strict_model.hpp"
@@ -20,6 +21,8 @@
 #include <cstdlib>
 
 namespace vk {
+
+static std::atomic<int> g_local_serial{0};  // vk_set_local_serial (verification aid)
 
 struct Img {
     const float2* __restrict__ flows;  // [N][h][w]
@@ -622,15 +625,23 @@ __device__ __forceinline__ static float cost_split8_lean(const Img& I, const Lea
 // Pass 2 of a local propagation: one chain per HALF lanes (HALF = 64: one chain per wave, up to 64 steps; HALF = 32: two chains
 // of up to 32 steps share a wave -- the default width 32 gives chains of 31 steps, so a wave per chain leaves half the lanes idle
 // and needs two rounds of waves at 640x480; with two chains per wave the whole pass is resident at once).  Lane j of a half holds
-// pixel j's old depth, old cost and table value.  "Fresh" steps (predecessor unchanged) are resolved from the table with one ballot:
-// the first accepting step starts a RUN in which one value v keeps propagating; the costs c(x+1.., v) of a run are independent
-// given v, so they are evaluated as one batch (HALF/8 pixels x 8 lanes, frames split over the lanes, cost_split8_lean) and the
-// accept / reject scan over the batch is again a ballot.  Identical to the step-by-step chain; the dependent latency is one
-// evaluation per RUN instead of one per STEP (replacement rates: ~40 % of the steps in the first EM iteration, ~6 % later).
+// pixel j's old depth, old cost and table value.  A chain is an automaton with two states:
+//   fresh   the predecessor kept its depth, so the step's candidate cost is the table value: the next ACCEPT is found with a ballot;
+//   run     an accepted value v keeps propagating; c(x, v) has to be evaluated (8 lanes per pixel, frames split over the lanes,
+//           cost_split8_lean) until a step rejects it -- the step after the rejecting one is fresh again.
+// What costs time is the dependent latency of an evaluation (~1 us), so every evaluation round is filled with HALF/8 pixels:
+//   in a run     the next HALF/8 pixels with v (the costs of a run are independent given v), accept / reject scanned with a ballot;
+//   when fresh   the FIRST run pixel of each of the next HALF/8 accepts, under the guess that each value is rejected right away (the
+//                common case after the first EM iteration: ~6 % of the steps are replaced, mostly one at a time).  If accept s_j is
+//                rejected at s_j + 1, the next accept is the first table accept >= s_j + 2 -- exactly the one slot j + 1 evaluated, with
+//                the value it evaluated (the predecessor of s_j+1 is untouched).  The slots are replayed in order and the first
+//                one whose value IS accepted turns into a run and discards the rest.
+// Every cost that is used was evaluated for exactly the (pixel, value) the step-by-step chain would evaluate: identical results.
+// Both chains of a wave share one evaluation per round whatever state each is in; only the cheap bookkeeping diverges.
 template <int HALF>
 __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, int width, const float* __restrict__ tbl, int lines, int nchains) {
     if (!clamp_active(I)) return;
-    constexpr int NH = 64 / HALF, NG = HALF / 8;  // chains per wave, pixels per batch
+    constexpr int NH = 64 / HALF, NG = HALF / 8;  // chains per wave, pixels per evaluation round
     const int lane = threadIdx.x, half = lane / HALF, hl = lane % HALF, g = hl >> 3, sub = hl & 7;
     const int tile = xcd_band_tile(blockIdx.x, gridDim.x);
     const int chain = tile * NH + half;
@@ -645,24 +656,36 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
     const int mypi = has ? cg.pi0 + hl * cg.stride : cg.pi0;
     const float d0 = has ? I.depth[mypi] : 0.f, c0 = has ? I.cost[mypi] : 0.f, t0 = has ? tbl[mypi] : INFINITY;
     const float first_cand = I.depth[cg.prev0];
+    const unsigned long long tacc = (__ballot(has && t0 < c0) & hmask) >> hshift;  // steps whose table cost beats their current cost
     int x = 0;
-    while (x < n) {
-        // fresh mode: first step >= x whose table cost beats its current cost
-        const unsigned long long am = (__ballot(has && hl >= x && t0 < c0) & hmask) >> hshift;
-        if (am == 0ull) break;
-        const int xa = __ffsll((long long)am) - 1;
-        const float dprev = __shfl(d0, max(xa - 1, 0), HALF);
-        const float v = xa == 0 ? first_cand : dprev;
-        if (hl == xa) { I.depth[mypi] = v; I.cost[mypi] = t0; }  // replace_if_better_depth (:201-207)
-        x = xa + 1;
-        bool running = true;
-        while (running && x < n) {
-            const int px = x + g;  // pixel evaluated by group g in this batch
-            const bool act = px < n;
-            const int pi = act ? cg.pi0 + px * cg.stride : cg.pi0;
-            const float c = cost_split8_lean(I, K, pi % I.w, pi / I.w, v, sub);
-            const float c0p = __shfl(c0, min(px, HALF - 1), HALF);
-            const bool acc = act && c < c0p;
+    bool running = false;
+    float vrun = 0.f;
+    for (;;) {
+        // ---- this round's pixel and value of my group
+        int s = -1, px;
+        float v;
+        bool act;
+        if (running) { px = x + g; v = vrun; act = px < n; }
+        else {
+            unsigned long long m = (tacc >> x) << x;  // accepts at steps >= x (x < n <= 64)
+            if (m == 0ull) break;  // no accept left: the rest of the chain keeps its values
+#pragma unroll
+            for (int j = 0; j < NG; j++) {
+                const int sj = m != 0ull ? __ffsll((long long)m) - 1 : -1;
+                if (j == g) s = sj;
+                m = (sj >= 0 && sj + 2 < 64) ? (m >> (sj + 2)) << (sj + 2) : 0ull;
+            }
+            px = s + 1; act = s >= 0 && px < n;
+            const float dprev = __shfl(d0, max(s - 1, 0), HALF);
+            v = s == 0 ? first_cand : dprev;
+        }
+        // ---- one evaluation for the whole wave
+        const int pi = cg.pi0 + (act ? px : 0) * cg.stride;
+        const float c = cost_split8_lean(I, K, pi % I.w, pi / I.w, v, sub);
+        const float c0p = __shfl(c0, min(max(px, 0), HALF - 1), HALF);
+        const bool acc = act && c < c0p;
+        // ---- bookkeeping
+        if (running) {
             // length of the accepted prefix over the groups (a group's 8 lanes agree)
             const unsigned long long rej = (__ballot(!acc) & hmask) >> hshift;
             const int L = (__ffsll((long long)rej) - 1) >> 3;  // rej != 0 unless all groups accept
@@ -673,7 +696,28 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
                 running = false;
                 x += 1;
             }
+        } else {
+            const unsigned long long accm = (__ballot(acc) & hmask) >> hshift;  // bit 8 j: slot j's value is accepted by its first run pixel
+            bool stop = false;
+#pragma unroll
+            for (int j = 0; j < NG; j++) {
+                if (!stop) {
+                    const int sj = __shfl(s, j * 8, HALF);
+                    const float vj = __shfl(v, j * 8, HALF);
+                    if (sj < 0) { x = n; stop = true; }  // no further accept
+                    else {
+                        if (hl == sj) { I.depth[mypi] = vj; I.cost[mypi] = t0; }  // replace_if_better_depth (:201-207)
+                        if (sj + 1 >= n) { x = n; stop = true; }
+                        else if ((accm >> (j * 8)) & 1ull) {  // v_j goes on: a run
+                            if (g == j && sub == 0) { I.depth[pi] = v; I.cost[pi] = c; }
+                            running = true; vrun = vj; x = sj + 2; stop = true;
+                        } else
+                            x = sj + 2;  // rejected at s_j + 1: s_j + 2 is fresh, and slot j + 1 holds the first accept from there
+                    }
+                }
+            }
         }
+        if (x >= n) break;
     }
 }
 // E-step (optimize_depth.cu:84-138), lean geometry and model; per-block rigidness sums as k_update_rigidness
@@ -1051,7 +1095,7 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                 const bool rowpass = (dir == 0 || dir == 2);
                 const int len = rowpass ? w : h, lines = rowpass ? h : w;
                 const int nseg = (len + p.local_prop_width - 1) / p.local_prop_width;
-                if (!STRICT && p.local_prop_width <= 65) {  // chains of <= 64 steps: table + one wave per chain
+                if (!STRICT && p.local_prop_width <= 65 && !g_local_serial.load(std::memory_order_relaxed)) {  // chains of <= 64 steps: table + one wave per chain
                     hipLaunchKernelGGL(k_local_table_lean<NMAX>, gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
                     const int nchains = lines * nseg;
                     if (p.local_prop_width <= 33)  // chains of <= 32 steps: two per wave
@@ -1186,3 +1230,5 @@ int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk
 }
 
 }  // namespace vk
+
+extern "C" __attribute__((visibility("default"))) int vk_set_local_serial(int on) { vk::g_local_serial.store(on ? 1 : 0); return 0; }

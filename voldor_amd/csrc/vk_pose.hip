@@ -18,6 +18,18 @@
 
 namespace vk {
 
+// phase clocks of the pose kernels (profiling builds only: scripts/phase_clocks.sh compiles a second library with -DVK_PHASE_CLOCKS)
+#ifdef VK_PHASE_CLOCKS
+__device__ unsigned long long g_phase[64];
+#define PH_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime()
+#define PH_MARK(slot) do { if (threadIdx.x == 0 && blockIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_phase[slot], n_ - ph_t); ph_t = n_; } } while (0)
+#define PH_ADD(slot, v) do { if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_phase[slot], (unsigned long long)(v)); } while (0)
+#else
+#define PH_DECL do {} while (0)
+#define PH_MARK(slot) do {} while (0)
+#define PH_ADD(slot, v) do {} while (0)
+#endif
+
 // ---- collect_p3p_instances.cu:70-145, 1-D pixel indexing so that block order == row-major order
 __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict__ flows, const float* __restrict__ rig,
                                                          const float* __restrict__ depth, const PoseBlock* __restrict__ P,
@@ -25,6 +37,7 @@ __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict
                                                          int* __restrict__ blk_counts, int N, int w, int h, int active_idx,
                                                          float rig_thresh, float rig_sum_thresh, float min_depth,
                                                          float max_depth, int max_trace) {
+    PH_DECL;
     const int npx = w * h;
     const int tile = xcd_band_tile(blockIdx.x, gridDim.x);  // XCD k works on the k-th band of rows (vk_device.hpp)
     const int pi = tile * 256 + threadIdx.x;
@@ -78,6 +91,7 @@ __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict
     if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
     __syncthreads();
     if (threadIdx.x == 0) blk_counts[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    PH_MARK(0); PH_ADD(1, 1);
 }
 
 // exclusive scan of the per-block counts (single workgroup), total -> *n_points
@@ -160,6 +174,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
     // LambdaTwist: four lanes per hypothesis, one candidate root each (the candidates are independent once the
     // shared cubic / eigen-decomposition is done; a lane per hypothesis walks them one after the other and the wave
     // waits for its slowest lane).  AP3P keeps one lane per hypothesis.
+    PH_DECL;
     constexpr int LPH = (SOLVER == 1) ? 1 : 4;
     extern __shared__ int s_pref[];  // FROM_MAP: inclusive prefix of blk_counts (rank select only)
     const int gtid = blockIdx.x * 64 + threadIdx.x, idx = gtid / LPH, sub = gtid % LPH;
@@ -181,6 +196,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
         if (gtid == 0) { *n_pts_dev = n_pts; if (cam) cam->n_points = n_pts; }
     } else
         n_pts = *n_pts_dev;
+    PH_MARK(8);
     const bool rank_draw = FROM_MAP && n_pts >= 4 && (draw > 0 || (draw == 0 && (long long)n_pts * DRAW_RANK_INV_DENSITY < (long long)npx));
     if (rank_draw) {  // wave-uniform: inclusive prefix sums of the block counts
         int carry = 0;
@@ -262,20 +278,27 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                 sel[k] = min(i, n_pts - 1);
             }
         }
+        PH_MARK(9);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int i = sel[k];
             yu[k] = pts2[(size_t)i * 2]; yv[k] = pts2[(size_t)i * 2 + 1];
             xp[k][0] = pts3[(size_t)i * 3]; xp[k][1] = pts3[(size_t)i * 3 + 1]; xp[k][2] = pts3[(size_t)i * 3 + 2];
         }
+#ifdef VK_PHASE_CLOCKS
+        if (yu[0] + xp[3][2] == 123456.f) return;  // forces the loads to complete before the mark
+#endif
+        PH_MARK(10);
         if (drawn) {
             if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf);
             else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errd);
             else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t, strict != 0);
         }
     }
+    PH_MARK(11);
     float aa[3] = { qnan, qnan, qnan };
     if (ok) { nearest_rotation(R); rotmat_to_angle_axis(R, aa, strict != 0); }
+    PH_MARK(12);
     bool writer = true;
     if (LPH == 4) {
         // fold the four candidates in root order: the first valid one, then any later one with a strictly smaller
@@ -292,9 +315,15 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
         writer = (win < 0) ? (sub == 0) : (sub == win);  // no candidate: lane 0 writes the NaN marker
     }
     if (writer) {
-        rvecs[(size_t)idx * 3] = aa[0]; rvecs[(size_t)idx * 3 + 1] = aa[1]; rvecs[(size_t)idx * 3 + 2] = aa[2];
-        tvecs[(size_t)idx * 3] = ok ? t[0] : qnan; tvecs[(size_t)idx * 3 + 1] = ok ? t[1] : qnan; tvecs[(size_t)idx * 3 + 2] = ok ? t[2] : qnan;
+        if (FROM_MAP) {  // device pipeline: coordinate planes [3][n_poses], what the single-workgroup mode kernels read coalesced
+            rvecs[idx] = aa[0]; rvecs[(size_t)n_poses + idx] = aa[1]; rvecs[(size_t)2 * n_poses + idx] = aa[2];
+            tvecs[idx] = ok ? t[0] : qnan; tvecs[(size_t)n_poses + idx] = ok ? t[1] : qnan; tvecs[(size_t)2 * n_poses + idx] = ok ? t[2] : qnan;
+        } else {  // host-pointer API: [n_poses][3] like the reference's output arrays
+            rvecs[(size_t)idx * 3] = aa[0]; rvecs[(size_t)idx * 3 + 1] = aa[1]; rvecs[(size_t)idx * 3 + 2] = aa[2];
+            tvecs[(size_t)idx * 3] = ok ? t[0] : qnan; tvecs[(size_t)idx * 3 + 1] = ok ? t[1] : qnan; tvecs[(size_t)idx * 3 + 2] = ok ? t[2] : qnan;
+        }
     }
+    PH_MARK(13); PH_ADD(14, 1);
 }
 
 // ---- single-workgroup mode finding ---------------------------------------------------------------
@@ -521,8 +550,8 @@ __device__ static bool rg_prepare_wave(float* covar_half, float* cinv_half, int 
 // `warm`: lds72[36..71] still holds the inverse this function produced for the previous iteration's covariance.  The
 // gate tightens by a few percent per iteration, so that inverse X is a good start for the Newton-Schulz iteration
 // X <- X + X (I - A X): every lane forms one element of each 6x6 product (6 multiply-adds, reads in one LDS batch), the
-// residual shrinks quadratically, ~4 updates reach 1e-12.  ~2.5k cycles against ~9k for the LU, whose pivot steps and
-// divisions are a serial fp64 chain.  The result is the same inverse to ~1e-13 relative (it is rounded to float
+// residual shrinks quadratically, ~3 updates reach 1e-8.  ~2k cycles against ~9k for the LU, whose pivot steps and
+// divisions are a serial fp64 chain.  The result is the same inverse to ~1e-8 relative (it is rounded to float
 // afterwards); if the residual of the start value is not small (first iterations) the LU runs instead.  ||I - A X|| < 1
 // with X positive definite implies det A > 0, the condition the LU path checks explicitly.
 __device__ __forceinline__ bool rg_prepare_lds(float* covar_half, float* cinv_half, float lambda, bool regularise, double* lds72,
@@ -568,7 +597,9 @@ __device__ __forceinline__ bool rg_prepare_lds(float* covar_half, float* cinv_ha
             const double e = (r == c ? 1.0 : 0.0) - y;
             const double ae = act ? fabs(e) : 0.0;
             if (step == 0 && __ballot(!(ae < 0.3)) != 0ull) { fallback = true; break; }  // also catches NaN
-            done = __ballot(ae > 1e-6) == 0ull;  // the update below squares the residual
+            // the update below squares the residual, E <- E^2 exactly, so max|E| <= 4e-5 now means <= 6 * 1.6e-9 = 1e-8 after it:
+            // below the float rounding of the result; no further product is spent on verifying that
+            done = __ballot(ae > 4e-5) == 0ull;
             __builtin_amdgcn_wave_barrier();
             if (act) E[lane] = e;
             __builtin_amdgcn_wave_barrier();
@@ -723,11 +754,9 @@ __device__ static bool robust_gaussian_block(const float* __restrict__ space, in
 }
 
 // ---- the per-camera mode kernel of the device-resident pipeline (voldor/geometry.cpp:156-263)
-// One 1024-thread workgroup; every thread keeps SPT hypotheses (6 floats each) in registers for
-// the whole mean-shift / robust-Gaussian iteration, so an iteration is ~200 VALU ops + one
-// shuffle/LDS all-reduce with a single barrier (the reference does 3 launches + 2 blocking D2H per
-// iteration, meanshift.cu:103-134).  Sample i lives in thread i%1024, slot i/1024.
-constexpr int SPT_MAX = 8;  // 8 * 1024 = 8192 hypotheses (cfg.n_poses_to_sample default)
+// One workgroup; every thread keeps its share of the hypotheses (6 floats each) in registers for the whole mean-shift /
+// robust-Gaussian iteration, so an iteration is a pass over registers + one shuffle/LDS all-reduce with a single barrier (the
+// reference does 3 launches + 2 blocking D2H per iteration, meanshift.cu:103-134).
 struct RedBuf { float w[2][16][28]; };
 // All-reduce of NV per-thread partial sums over the workgroup, fixed summation order, ONE barrier:
 // wave partials -> LDS -> barrier -> in every wave lane k (< NV) sums the NW partials of value k, and the
@@ -763,37 +792,6 @@ __device__ __forceinline__ void allreduce_regs(float* v, RedBuf& rb, int parity)
     for (int k = 0; k < NV; k++) v[k] = lane_value(tot, k);
 }
 
-// hypotheses -> registers; returns the number of finite ones (geometry.cpp:156-165), rvec pre-scaled (:191)
-template <int THREADS, int SPT>
-__device__ __forceinline__ int load_hypotheses(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses,
-                                               float rvec_scale, float (&x)[SPT][6], unsigned& finmask, int (*s_cnt)[16]) {
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    finmask = 0;
-#pragma unroll
-    for (int k = 0; k < SPT; k++) {
-        const int i = k * THREADS + tid;
-        bool fin = false;
-#pragma unroll
-        for (int d = 0; d < 6; d++) x[k][d] = 0.f;
-        if (i < n_poses) {
-            float r0 = rvecs[(size_t)i * 3], r1 = rvecs[(size_t)i * 3 + 1], r2 = rvecs[(size_t)i * 3 + 2];
-            float t0 = tvecs[(size_t)i * 3], t1 = tvecs[(size_t)i * 3 + 1], t2 = tvecs[(size_t)i * 3 + 2];
-            fin = isfinite(r0 + r1 + r2 + t0 + t1 + t2);
-            if (fin) { x[k][0] = r0 * rvec_scale; x[k][1] = r1 * rvec_scale; x[k][2] = r2 * rvec_scale; x[k][3] = t0; x[k][4] = t1; x[k][5] = t2; }
-        }
-        const unsigned long long b = __ballot(fin);
-        if (fin) finmask |= 1u << k;
-        if (lane == 0) s_cnt[k][wv] = __popcll(b);
-    }
-    __syncthreads();
-    int used = 0;
-#pragma unroll
-    for (int k = 0; k < SPT; k++)
-#pragma unroll
-        for (int j = 0; j < THREADS / 64; j++) used += s_cnt[k][j];
-    return used;
-}
-
 // geometry.cpp:249-263: unscale, checkRange, write the pose into CamState and the PoseBlock (thread 0)
 __device__ __forceinline__ void finalize_pose(const float* mean6 /*scaled space*/, float rvec_scale, int used, float density, int ms_iters,
                                               int gu_iters, CamState* cam, PoseBlock* P, int cam_idx) {
@@ -817,15 +815,33 @@ __device__ __forceinline__ void finalize_pose(const float* mean6 /*scaled space*
 
 // mean-shift stage. DEFER=false: also finalises the pose. DEFER=true (robust-Gaussian refit follows,
 // geometry.cpp:201): leaves {mean[6], confidence, iters, used} in `handoff` for k_pose_refit.
-template <bool DEFER>
-__global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
+//
+// One compute unit does all of it, and its passes over the pool are VALU-issue bound (16 waves on 4 SIMDs), so the pool is
+// held as PAIRS of hypotheses per lane and the arithmetic is written on float2: gfx950 issues v_pk_{add,mul,fma}_f32 at the
+// rate of the scalar forms, two hypotheses per instruction.  Hypothesis i lives in thread i % 1024, pair (i / 1024) / 2,
+// half (i / 1024) % 2.  A non-finite hypothesis (geometry.cpp:156-165 drops those) is stored as MS_FAR in every coordinate:
+// its squared distance to anything is ~6e36, its kernel weight exp(-6e36 / 2 var) is exactly 0 and 0 * MS_FAR = 0, so it
+// contributes exactly nothing to any sum -- no mask in the loops.
+typedef float f2 __attribute__((ext_vector_type(2)));
+#ifndef VK_PM_THREADS
+#define VK_PM_THREADS 512
+#endif
+constexpr int PM_THREADS = VK_PM_THREADS;
+constexpr int PM_POOL = 8192;   // hypotheses the mode kernels keep on chip (cfg.n_poses_to_sample default)
+constexpr float MS_FAR = 1e18f;
+constexpr int MS_TRIAL_BATCH = 5;  // initial-mode trials evaluated per pass (meanshift.cu:72-95 runs them one at a time)
+// THREADS: the per-iteration all-reduce, the mean update and the convergence test are executed by every wave (~100 instructions next
+// to ~30 per pair of hypotheses), so fewer, fatter waves do less redundant work: THREADS * SPT = PM_POOL.
+template <bool DEFER, int THREADS>
+__global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
                                                                   int n_poses, ModeParams mp, CamState* cam, PoseBlock* P, int cam_idx,
                                                                   const int* __restrict__ n_points_dev, float* __restrict__ handoff) {
 #pragma clang fp contract(fast)  // kernel-weighted sums: not part of the solver's exact-rounding contract (file-wide: off)
+    constexpr int SPT = PM_POOL / THREADS, MS_PAIRS = SPT / 2, NW = THREADS / 64;
     __shared__ RedBuf rb;
-    __shared__ int s_cnt[SPT_MAX][16];
-    __shared__ float s_pick[6];
-    __shared__ int s_rank[SPT_MAX][MS_THREADS];
+    __shared__ int s_cnt[SPT][NW];
+    __shared__ float s_pick[MS_TRIAL_BATCH][6];
+    PH_DECL;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // successive pose? (voldor.cpp:177: pose_sample_count != 0), decided on the device
     const bool external_init = mp.use_external_init_mean < 0 ? (cam->pose_sample_count != 0) : (mp.use_external_init_mean != 0);
@@ -833,18 +849,51 @@ __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __
         if (tid == 0) { cam->success = 0; if (DEFER) handoff[8] = 0.f; else maybe_decide(mp, P, cam, cam_idx); }
         return;
     }
-    float x[SPT_MAX][6];
-    unsigned finmask;
-    const int used = load_hypotheses<MS_THREADS, SPT_MAX>(rvecs, tvecs, n_poses, mp.rvec_scale, x, finmask, s_cnt);
+    // ---- pool -> registers (coordinate planes [3][n_poses] written by k_solve: every load of a wave is one 256-byte run);
+    // rvec pre-scaled (:191); number of finite hypotheses (geometry.cpp:156-165)
+    f2 X[MS_PAIRS][6];
+    unsigned finmask = 0;
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {  // all 48 loads first, straight into their registers
+        const int i = min(k * THREADS + tid, n_poses - 1);  // slots past the pool read a valid address and are dropped below
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            const float v = d < 3 ? rvecs[(size_t)d * n_poses + i] : tvecs[(size_t)(d - 3) * n_poses + i];
+            if (k & 1) X[k >> 1][d].y = v; else X[k >> 1][d].x = v;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        float v[6];
+#pragma unroll
+        for (int d = 0; d < 6; d++) v[d] = (k & 1) ? X[k >> 1][d].y : X[k >> 1][d].x;
+        const bool fin = k * THREADS + tid < n_poses && isfinite(v[0] + v[1] + v[2] + v[3] + v[4] + v[5]);
+        const unsigned long long b = __ballot(fin);
+        if (fin) finmask |= 1u << k;
+        if (lane == 0) s_cnt[k][wv] = __popcll(b);
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            const float u = fin ? (d < 3 ? v[d] * mp.rvec_scale : v[d]) : MS_FAR;
+            if (k & 1) X[k >> 1][d].y = u; else X[k >> 1][d].x = u;
+        }
+    }
+    __syncthreads();
+    int used = 0;
+#pragma unroll
+    for (int k = 0; k < SPT; k++)
+#pragma unroll
+        for (int j = 0; j < NW; j++) used += s_cnt[k][j];
     if (used == 0) {
         if (tid == 0) { cam->success = 0; if (DEFER) handoff[8] = 0.f; else maybe_decide(mp, P, cam, cam_idx); }
         return;
     }
+    PH_MARK(16);
     // ---- mean-shift (meanshift.cu:34-150)
     float io_mean[6], c_mean[6];
 #pragma unroll
     for (int d = 0; d < 3; d++) { io_mean[d] = cam->rvec[d] * mp.rvec_scale; io_mean[3 + d] = cam->t[d]; }
     const float inv2v = 1.f / (2.f * mp.kernel_var);
+    const f2 ninv2v = { -inv2v, -inv2v };
     int parity = 0;
     if (external_init) {
 #pragma unroll
@@ -853,48 +902,80 @@ __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __
         float best = 0.f;
         float bestx[6] = { 0, 0, 0, 0, 0, 0 };
         bool have = false;
-        // rank of each of this thread's finite hypotheses in index order (slot-major, then thread), once
-        // (kept in LDS, own column: registers held across the trial loop would raise the pressure of the whole kernel)
+        // rank of each of this thread's finite hypotheses in index order (slot-major, then thread), in registers for the
+        // duration of the trials
+        int rank[SPT];
         {
             int base = 0;
 #pragma unroll
-            for (int k = 0; k < SPT_MAX; k++) {
+            for (int k = 0; k < SPT; k++) {
                 int wbase = base;
-                for (int j = 0; j < 16; j++) { if (j < wv) wbase += s_cnt[k][j]; base += s_cnt[k][j]; }
+#pragma unroll
+                for (int j = 0; j < NW; j++) { if (j < wv) wbase += s_cnt[k][j]; base += s_cnt[k][j]; }
                 const unsigned long long b = __ballot((finmask >> k) & 1u);
-                s_rank[k][tid] = ((finmask >> k) & 1u) ? wbase + __popcll(b & ((1ull << lane) - 1ull)) : -1;
+                rank[k] = ((finmask >> k) & 1u) ? wbase + __popcll(b & ((1ull << lane) - 1ull)) : -1;
             }
         }
-        for (int trial = 0; trial < mp.ms_max_init_trials; trial++) {
-            const int target = (int)(rng3(RAND_SEED, (uint32_t)trial, 0x4D53u) % (uint32_t)used);
+        // The trials do not depend on one another (trial t looks at the (rng(t) % used)-th finite hypothesis); only the
+        // "good enough, stop" test is sequential.  MS_TRIAL_BATCH of them share one pass over the pool and one all-reduce,
+        // and the reference's sequential rule is replayed on the totals in trial order: same picks, same early stop.
+        bool stop = false;
+        for (int t0 = 0; t0 < mp.ms_max_init_trials && !stop; t0 += MS_TRIAL_BATCH) {
+            const int nb = min(MS_TRIAL_BATCH, mp.ms_max_init_trials - t0);
 #pragma unroll
-            for (int k = 0; k < SPT_MAX; k++)
-                if (s_rank[k][tid] == target) {  // the target-th finite hypothesis
+            for (int b = 0; b < MS_TRIAL_BATCH; b++) {
+                if (b < nb) {
+                    const int target = (int)(rng3(RAND_SEED, (uint32_t)(t0 + b), 0x4D53u) % (uint32_t)used);
+                    int kk = -1;  // which of my slots holds the target-th finite hypothesis (at most one thread has one)
 #pragma unroll
-                    for (int d = 0; d < 6; d++) s_pick[d] = x[k][d];
+                    for (int k = 0; k < SPT; k++) kk = rank[k] == target ? k : kk;
+                    if (kk >= 0) {
+                        float v[6] = { 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+                        for (int k = 0; k < SPT; k++)
+#pragma unroll
+                            for (int d = 0; d < 6; d++) v[d] = k == kk ? ((k & 1) ? X[k >> 1][d].y : X[k >> 1][d].x) : v[d];
+#pragma unroll
+                        for (int d = 0; d < 6; d++) s_pick[b][d] = v[d];
+                    }
                 }
+            }
             __syncthreads();
-            float c[6];
+            f2 acc2[MS_TRIAL_BATCH];
 #pragma unroll
-            for (int d = 0; d < 6; d++) c[d] = s_pick[d];
-            float acc[1] = { 0.f };
+            for (int b = 0; b < MS_TRIAL_BATCH; b++) {
+                acc2[b] = f2{ 0.f, 0.f };
+                if (b < nb) {  // uniform
+                    f2 c[6];
 #pragma unroll
-            for (int k = 0; k < SPT_MAX; k++) {
-                if ((finmask >> k) & 1u) {
-                    float l2 = 0.f;
+                    for (int d = 0; d < 6; d++) { const float v = s_pick[b][d]; c[d] = f2{ v, v }; }
 #pragma unroll
-                    for (int d = 0; d < 6; d++) { float df = x[k][d] - c[d]; l2 += df * df; }
-                    acc[0] += __expf(-l2 * inv2v);
+                    for (int p = 0; p < MS_PAIRS; p++) {
+                        f2 l2 = { 0.f, 0.f };
+#pragma unroll
+                        for (int d = 0; d < 6; d++) { const f2 df = X[p][d] - c[d]; l2 += df * df; }
+                        const f2 a = l2 * ninv2v;
+                        acc2[b] += f2{ __expf(a.x), __expf(a.y) };
+                    }
                 }
             }
-            allreduce_regs<1>(acc, rb, parity); parity ^= 1;
-            if (acc[0] > best) {
-                best = acc[0];
+            float acc[MS_TRIAL_BATCH];
 #pragma unroll
-                for (int d = 0; d < 6; d++) bestx[d] = c[d];
-                have = true;
+            for (int b = 0; b < MS_TRIAL_BATCH; b++) acc[b] = acc2[b].x + acc2[b].y;
+            allreduce_regs<MS_TRIAL_BATCH, NW>(acc, rb, parity); parity ^= 1;
+#pragma unroll
+            for (int b = 0; b < MS_TRIAL_BATCH; b++) {
+                if (b < nb && !stop) {
+                    if (acc[b] > best) {
+                        best = acc[b];
+#pragma unroll
+                        for (int d = 0; d < 6; d++) bestx[d] = s_pick[b][d];
+                        have = true;
+                    }
+                    if (best > mp.ms_good_init_confidence * (float)used) stop = true;
+                }
             }
-            if (best > mp.ms_good_init_confidence * (float)used) break;
+            __syncthreads();  // s_pick is rewritten by the next batch
         }
         if (!have) {  // no trial had positive weight (the reference would index element -1)
 #pragma unroll
@@ -903,23 +984,35 @@ __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __
 #pragma unroll
         for (int d = 0; d < 6; d++) c_mean[d] = bestx[d];
     }
+    PH_MARK(17);
     int ms_iters = 0;
     float conf = 0.f;
     for (int iter = 0; iter < mp.ms_max_iters; iter++) {  // meanshift.cu:103-134
-        float acc[7] = { 0, 0, 0, 0, 0, 0, 0 };
+        f2 c[6];
 #pragma unroll
-        for (int k = 0; k < SPT_MAX; k++) {
-            if ((finmask >> k) & 1u) {
-                float l2 = 0.f;
+        for (int d = 0; d < 6; d++) c[d] = f2{ c_mean[d], c_mean[d] };
+        f2 acc2[7];
 #pragma unroll
-                for (int d = 0; d < 6; d++) { float df = x[k][d] - c_mean[d]; l2 += df * df; }
-                float wgt = __expf(-l2 * inv2v);
-                acc[0] += wgt;
+        for (int k = 0; k < 7; k++) acc2[k] = f2{ 0.f, 0.f };
 #pragma unroll
-                for (int d = 0; d < 6; d++) acc[1 + d] += wgt * x[k][d];
-            }
+        for (int p = 0; p < MS_PAIRS; p++) {
+            f2 l2 = { 0.f, 0.f };
+#pragma unroll
+            for (int d = 0; d < 6; d++) { const f2 df = X[p][d] - c[d]; l2 += df * df; }
+            const f2 a = l2 * ninv2v;
+            const f2 wgt = { __expf(a.x), __expf(a.y) };
+            acc2[0] += wgt;
+#pragma unroll
+            for (int d = 0; d < 6; d++) acc2[1 + d] += wgt * X[p][d];
         }
-        const float tot = allreduce_lanes<7>(acc, rb, parity); parity ^= 1;  // lane k: total of sum k
+        float acc[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) acc[k] = acc2[k].x + acc2[k].y;
+#ifdef VK_PHASE_CLOCKS
+        if (acc[0] == 123456.f) return;
+#endif
+        PH_MARK(32);
+        const float tot = allreduce_lanes<7, NW>(acc, rb, parity); parity ^= 1;  // lane k: total of sum k
         const float wsum = lane_value(tot, 0);
         conf = wsum / (float)used;
         ms_iters = iter + 1;
@@ -932,62 +1025,71 @@ __global__ __launch_bounds__(MS_THREADS) static void k_pose_mode(const float* __
             io_mean[d] = m; c_mean[d] = m;
         }
         if (sqrtf(disp) < mp.ms_epsilon) break;  // uniform: every thread holds the same totals
+        PH_MARK(33);
     }
+    PH_MARK(33); PH_ADD(19, ms_iters); PH_ADD(20, 1);
     if (tid == 0) {
         if (DEFER) {
             for (int d = 0; d < 6; d++) handoff[d] = io_mean[d];
             handoff[6] = conf; handoff[7] = (float)ms_iters; handoff[8] = (float)used;
         } else {
             finalize_pose(io_mean, mp.rvec_scale, used, conf, ms_iters, cam->last_used_gu_iters, cam, P, cam_idx);
+            PH_MARK(21);
             maybe_decide(mp, P, cam, cam_idx);
         }
     }
+    PH_MARK(22);
 }
 
 // robust-Gaussian refit + finalisation (geometry.cpp:201-263, fit_robust_gaussian.cu:131-263); runs
-// on the last EM iteration only, ~30-50 gate/refit iterations per camera.  The 8192 scaled
-// hypotheses stay on chip for the whole loop: coordinates 0-3 in LDS (128 KiB, [dim][sample] so
-// that a wave reads consecutive addresses), coordinates 4-5 in registers.  (All six in registers
-// does not fit the 128-VGPR budget of a 1024-thread workgroup next to the fp64 6x6 inverse; all
-// six in LDS would need 192 KiB.)
-constexpr int RF_THREADS = 1024, RF_SPT = 8, RF_N = RF_THREADS * RF_SPT;
+// on the last EM iteration only, ~30-50 gate/refit iterations per camera, each of them three dependent phases on ONE
+// compute unit: the fp64 inverse of the 6x6 covariance (one wave), the gate + moment pass over the pool (VALU-issue bound),
+// a 28-value all-reduce.  The 8192 scaled hypotheses stay in registers for the whole loop as pairs (two per lane, packed
+// fp32 arithmetic as in k_pose_mode); 512 threads, because everything that is not the pass is executed by every wave.  The gate
+// weight multiplies instead of branching (a wave practically always holds a gated sample).  Wave 0 turns the totals into the
+// new mean / covariance and inverts it right away, so an iteration has two workgroup barriers.
+constexpr int RF_THREADS = 512, RF_SPT = PM_POOL / RF_THREADS, RF_PAIRS = RF_SPT / 2, RF_NW = RF_THREADS / 64;
 __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
                                                                    int n_poses, ModeParams mp, CamState* cam, PoseBlock* P, int cam_idx,
                                                                    const float* __restrict__ handoff) {
 #pragma clang fp contract(fast)  // the gate / scatter sums are not part of the solver's exact-rounding contract
-    __shared__ float xs[4][RF_N];
     __shared__ RedBuf rb;
-    __shared__ int s_cnt[16];
+    __shared__ int s_cnt[RF_NW];
     __shared__ float s_cinv[21], s_cov[21], s_mean[6];
     __shared__ int s_flag;
     __shared__ double s_lu[108];
+    PH_DECL;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (handoff[8] == 0.f) {  // the mean-shift stage already reported failure
         if (tid == 0) maybe_decide(mp, P, cam, cam_idx);
         return;
     }
     const float sc = mp.rg_pose_scaling;
-    // stage: x = [rvec * rvec_scale | t] * rg_pose_scaling (geometry.cpp:191,211); non-finite -> masked out
-    float xr[RF_SPT][2];
-    unsigned finmask = 0;
+    // stage: x = [rvec * rvec_scale | t] * rg_pose_scaling (geometry.cpp:191,211); a non-finite hypothesis becomes MS_FAR in every
+    // coordinate: its Mahalanobis distance is huge, infinite or NaN, never inside the gate, and 0 * MS_FAR = 0 in the sums
+    f2 X[RF_PAIRS][6];
+#pragma unroll
+    for (int k = 0; k < RF_SPT; k++) {
+        const int i = min(k * RF_THREADS + tid, n_poses - 1);
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            const float v = d < 3 ? rvecs[(size_t)d * n_poses + i] : tvecs[(size_t)(d - 3) * n_poses + i];  // planes [3][n_poses]
+            if (k & 1) X[k >> 1][d].y = v; else X[k >> 1][d].x = v;
+        }
+    }
     int mycnt = 0;
 #pragma unroll
     for (int k = 0; k < RF_SPT; k++) {
-        const int i = k * RF_THREADS + tid;
-        float v[6] = { 0, 0, 0, 0, 0, 0 };
-        bool fin = false;
-        if (i < n_poses) {
-            v[0] = rvecs[(size_t)i * 3]; v[1] = rvecs[(size_t)i * 3 + 1]; v[2] = rvecs[(size_t)i * 3 + 2];
-            v[3] = tvecs[(size_t)i * 3]; v[4] = tvecs[(size_t)i * 3 + 1]; v[5] = tvecs[(size_t)i * 3 + 2];
-            fin = isfinite(v[0] + v[1] + v[2] + v[3] + v[4] + v[5]);
+        float v[6];
+#pragma unroll
+        for (int d = 0; d < 6; d++) v[d] = (k & 1) ? X[k >> 1][d].y : X[k >> 1][d].x;
+        const bool fin = k * RF_THREADS + tid < n_poses && isfinite(v[0] + v[1] + v[2] + v[3] + v[4] + v[5]);
+        mycnt += fin ? 1 : 0;
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            const float u = fin ? (d < 3 ? (v[d] * mp.rvec_scale) * sc : v[d] * sc) : MS_FAR;
+            if (k & 1) X[k >> 1][d].y = u; else X[k >> 1][d].x = u;
         }
-        if (fin) { finmask |= 1u << k; mycnt++; }
-        xs[0][i] = fin ? (v[0] * mp.rvec_scale) * sc : 0.f;
-        xs[1][i] = fin ? (v[1] * mp.rvec_scale) * sc : 0.f;
-        xs[2][i] = fin ? (v[2] * mp.rvec_scale) * sc : 0.f;
-        xs[3][i] = fin ? v[3] * sc : 0.f;
-        xr[k][0] = fin ? v[4] * sc : 0.f;
-        xr[k][1] = fin ? v[5] * sc : 0.f;
     }
     {
         int c = mycnt;
@@ -996,79 +1098,96 @@ __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* _
         if (lane == 0) s_cnt[wv] = c;
     }
     if (tid < 21) s_cov[tid] = 0.f;
+    if (tid < 6) s_mean[tid] = handoff[tid] * sc;
     __syncthreads();
     int used = 0;
 #pragma unroll
-    for (int j = 0; j < 16; j++) used += s_cnt[j];
+    for (int j = 0; j < RF_NW; j++) used += s_cnt[j];
     if (tid < 6) s_cov[(tid * tid + tid) / 2 + tid] = mp.kernel_var * (sc * sc);  // :203-206
-    float rg_mean[6];
-#pragma unroll
-    for (int d = 0; d < 6; d++) rg_mean[d] = handoff[d] * sc;
     __syncthreads();
+    const bool regularise = mp.rg_covar_reg_lambda > 0.f;
+    if (wv == 0) {  // inverse for iteration 0 (not regularised, fit_robust_gaussian.cu:180)
+        const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, false, s_lu, false);
+        if (lane == 0) s_flag = ok ? 0 : 2;
+    }
+    __syncthreads();
+    const float sig2 = mp.rg_trunc_sigma * mp.rg_trunc_sigma;
     float weight = 0.f;
     int iter = 0, parity = 0;
     bool reliable = true;
+    PH_MARK(24);
     for (iter = 0; iter < mp.rg_max_iters; iter++) {
-        if (tid < 64) {
-            const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, iter > 0 && mp.rg_covar_reg_lambda > 0.f, s_lu, iter > 0);
-            if (tid == 0) s_flag = ok ? 0 : 2;
-        }
-        __syncthreads();
         if (s_flag == 2) { reliable = false; break; }
         const float prev_density = weight / (float)used;
-        float cs[21];
+        float cs[21], mean[6];
 #pragma unroll
         for (int d1 = 0; d1 < 6; d1++)
 #pragma unroll
             for (int d2 = 0; d2 <= d1; d2++) cs[(d1 * d1 + d1) / 2 + d2] = (d1 == d2 ? 1.f : 2.f) * s_cinv[(d1 * d1 + d1) / 2 + d2];
+#pragma unroll
+        for (int d = 0; d < 6; d++) mean[d] = s_mean[d];
         // e_step (fit_robust_gaussian.cu:56-97): gate, weight, weighted sample and weighted scatter about
         // the CURRENT mean in one pass -> one 28-value all-reduce per iteration
+        f2 acc2[28];
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc2[k] = f2{ 0.f, 0.f };
+#pragma unroll
+        for (int p = 0; p < RF_PAIRS; p++) {
+            f2 diff[6];
+#pragma unroll
+            for (int d = 0; d < 6; d++) diff[d] = X[p][d] - f2{ mean[d], mean[d] };
+            // z = d^T C d over the lower triangle (off-diagonal coefficients doubled in cs): 27 multiply-adds, not 42
+            f2 z = { 0.f, 0.f };
+#pragma unroll
+            for (int d1 = 0; d1 < 6; d1++) {
+                f2 tmp = diff[d1] * cs[(d1 * d1 + d1) / 2 + d1];
+#pragma unroll
+                for (int d2 = 0; d2 < d1; d2++) tmp += diff[d2] * cs[(d1 * d1 + d1) / 2 + d2];
+                z += tmp * diff[d1];
+            }
+            // sqrt(z) < sigma (fit_robust_gaussian.cu:80) as 0 <= z < sigma^2: a negative or NaN form stays outside
+            const f2 wgt = { (z.x >= 0.f && z.x < sig2) ? 1.f : 0.f, (z.y >= 0.f && z.y < sig2) ? 1.f : 0.f };
+            acc2[0] += wgt;
+#pragma unroll
+            for (int d = 0; d < 6; d++) acc2[1 + d] += wgt * X[p][d];
+            f2 wd[6];
+#pragma unroll
+            for (int d = 0; d < 6; d++) wd[d] = wgt * diff[d];
+#pragma unroll
+            for (int d1 = 0; d1 < 6; d1++)
+#pragma unroll
+                for (int d2 = 0; d2 <= d1; d2++) acc2[7 + (d1 * d1 + d1) / 2 + d2] += wd[d1] * diff[d2];
+        }
         float acc[28];
 #pragma unroll
-        for (int k = 0; k < 28; k++) acc[k] = 0.f;
-#pragma unroll
-        for (int k = 0; k < RF_SPT; k++) {
-            if ((finmask >> k) & 1u) {
-                const int i = k * RF_THREADS + tid;
-                const float xv[6] = { xs[0][i], xs[1][i], xs[2][i], xs[3][i], xr[k][0], xr[k][1] };
-                float diff[6];
-#pragma unroll
-                for (int d = 0; d < 6; d++) diff[d] = xv[d] - rg_mean[d];
-                // z = d^T C d over the lower triangle (off-diagonal coefficients doubled in cs): 27 multiply-adds, not 42
-                float z = 0.f;
-#pragma unroll
-                for (int d1 = 0; d1 < 6; d1++) {
-                    float tmp = cs[(d1 * d1 + d1) / 2 + d1] * diff[d1];
-#pragma unroll
-                    for (int d2 = 0; d2 < d1; d2++) tmp += cs[(d1 * d1 + d1) / 2 + d2] * diff[d2];
-                    z += tmp * diff[d1];
-                }
-                if (sqrtf(z) < mp.rg_trunc_sigma) {
-                    acc[0] += 1.f;
-#pragma unroll
-                    for (int d = 0; d < 6; d++) acc[1 + d] += xv[d];
-#pragma unroll
-                    for (int d1 = 0; d1 < 6; d1++)
-#pragma unroll
-                        for (int d2 = 0; d2 <= d1; d2++) acc[7 + (d1 * d1 + d1) / 2 + d2] += diff[d1] * diff[d2];
-                }
-            }
-        }
-        const float tot = allreduce_lanes<28>(acc, rb, parity); parity ^= 1;  // lane k of every wave: total of sum k
+        for (int k = 0; k < 28; k++) acc[k] = acc2[k].x + acc2[k].y;
+#ifdef VK_PHASE_CLOCKS
+        if (acc[0] == -123456.f) return;
+#endif
+        PH_MARK(26);
+        const float tot = allreduce_lanes<28, RF_NW>(acc, rb, parity); parity ^= 1;  // lane k of every wave: total of sum k
         weight = lane_value(tot, 0);
         if (!isfinite(weight)) { reliable = false; break; }
         if (fabsf(weight / (float)used - prev_density) < mp.rg_epsilon) { reliable = true; break; }
-        // M-step (:234-246): mean and covariance of the gated set (no -1: it is regularised next).  One division per lane,
-        // where the totals sit (lanes 1..27 of wave 0), published through LDS with the barrier that ends the iteration.
-        if (wv == 0 && lane >= 1 && lane < 28) {
-            const float q = tot / weight;
-            if (lane < 7) s_mean[lane - 1] = q; else s_cov[lane - 7] = q;  // s_cov was last read before the all-reduce barrier
+        PH_MARK(27);
+        if (wv == 0) {
+            // M-step (:234-246): mean and covariance of the gated set (no -1: it is regularised next), one division per lane where
+            // the totals sit, and -- unless this was the last iteration -- the regularised inverse of the next one
+            if (lane >= 1 && lane < 28) {
+                const float q = tot / weight;
+                if (lane < 7) s_mean[lane - 1] = q; else s_cov[lane - 7] = q;  // the other waves read both before the all-reduce barrier
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (iter + 1 < mp.rg_max_iters) {
+                const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, regularise, s_lu, true);
+                if (lane == 0) s_flag = ok ? 0 : 2;
+            }
         }
         __syncthreads();
-#pragma unroll
-        for (int d = 0; d < 6; d++) rg_mean[d] = s_mean[d];
+        PH_MARK(25);
     }
     __syncthreads();
+    PH_MARK(27); PH_ADD(28, iter); PH_ADD(29, 1);
     if (tid == 0) {
         float mean6[6];
         float density = handoff[6];
@@ -1083,7 +1202,7 @@ __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* _
                     if (i1 < 3 && i2 < 3) c /= mp.rvec_scale;
                     cam->covar[i1 * 6 + i2] = c;
                 }
-            for (int d = 0; d < 6; d++) mean6[d] = rg_mean[d] / sc;
+            for (int d = 0; d < 6; d++) mean6[d] = s_mean[d] / sc;
         } else {
             for (int k = 0; k < 36; k++) cam->covar[k] = 0.f;
             for (int d = 0; d < 6; d++) mean6[d] = (handoff[d] * sc) / sc;  // pose_opm *= sc; /= sc (:210,:238)
@@ -1091,6 +1210,7 @@ __global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* _
         finalize_pose(mean6, mp.rvec_scale, used, density, (int)handoff[7], gu_iters, cam, P, cam_idx);
         maybe_decide(mp, P, cam, cam_idx);
     }
+    PH_MARK(30);
 }
 
 // ---- stand-alone kernels behind the host-pointer API (B-inner) -------------------------------
@@ -1189,20 +1309,20 @@ int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, fl
 }
 
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx) {
-    if (n_poses > SPT_MAX * MS_THREADS) {
+    if (n_poses > PM_POOL) {
         fprintf(stderr, "voldor_hip: n_poses_to_sample=%d exceeds the %d hypotheses the mode kernel keeps in registers\n", n_poses,
-                SPT_MAX * MS_THREADS);
+                PM_POOL);
         return (int)hipErrorInvalidValue;
     }
     if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
     float* handoff = c->ms_io.as<float>() + 32;
     if (mp.do_rg) {
-        hipLaunchKernelGGL(k_pose_mode<true>, dim3(1), dim3(MS_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
+        hipLaunchKernelGGL((k_pose_mode<true, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
                            mp, cam_dev, P, cam_idx, c->n_points.as<int>(), handoff);
         hipLaunchKernelGGL(k_pose_refit, dim3(1), dim3(RF_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp,
                            cam_dev, P, cam_idx, handoff);
     } else
-        hipLaunchKernelGGL(k_pose_mode<false>, dim3(1), dim3(MS_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
+        hipLaunchKernelGGL((k_pose_mode<false, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
                            mp, cam_dev, P, cam_idx, c->n_points.as<int>(), handoff);
     VK_CHECK_LAST();
     return 0;
@@ -1220,3 +1340,12 @@ int robust_gaussian_device(Context* c, const float* space_dev, int N, const Mode
 }
 
 }  // namespace vk
+
+#ifdef VK_PHASE_CLOCKS
+extern "C" __attribute__((visibility("default"))) int vk_phase_read(unsigned long long* out, int n, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vk::g_phase), sizeof(unsigned long long) * (size_t)(n < 64 ? n : 64)) != hipSuccess) return 2;
+    if (reset) { unsigned long long z[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vk::g_phase), z, sizeof z) != hipSuccess) return 3; }
+    return 0;
+}
+#endif

@@ -190,8 +190,9 @@ __global__ __launch_bounds__(ST_THREADS) static void k_pose_strict(const float* 
         float v[6] = { 0, 0, 0, 0, 0, 0 };
         bool fin = false;
         if (i < n_poses) {
-            v[0] = rvecs[(size_t)i * 3]; v[1] = rvecs[(size_t)i * 3 + 1]; v[2] = rvecs[(size_t)i * 3 + 2];
-            v[3] = tvecs[(size_t)i * 3]; v[4] = tvecs[(size_t)i * 3 + 1]; v[5] = tvecs[(size_t)i * 3 + 2];
+            // k_solve<.., FROM_MAP> leaves the pool as coordinate planes [3][n_poses] (vk_pose.hip)
+            v[0] = rvecs[i]; v[1] = rvecs[(size_t)n_poses + i]; v[2] = rvecs[(size_t)2 * n_poses + i];
+            v[3] = tvecs[i]; v[4] = tvecs[(size_t)n_poses + i]; v[5] = tvecs[(size_t)2 * n_poses + i];
             fin = isfinite(v[0] + v[1] + v[2] + v[3] + v[4] + v[5]);
         }
         const unsigned long long m = __ballot(fin);

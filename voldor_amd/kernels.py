@@ -204,3 +204,8 @@ def set_strict_math(on: bool):
 
 def get_strict_math() -> bool:
     return bool(capi.lib().vk_get_strict_math())
+
+
+def set_local_serial(on: bool):
+    """Verification aid (include/voldor_hip.h: vk_set_local_serial): step-by-step local propagation in fast mode."""
+    capi.check(capi.lib().vk_set_local_serial(1 if on else 0), "vk_set_local_serial")
