@@ -24,6 +24,9 @@ buf = (C.c_ulonglong * 64)()
 for _ in range(3):
     pyvoldor.voldor_device(flows, wl["fx"], wl["fx"], wl["cx"], wl["cy"], config=wl["cfg"], **extra)
 assert lib.vk_phase_read(buf, 64, 1) == 0
+lib.vk_phase_read_depth.argtypes = [C.POINTER(C.c_ulonglong), C.c_int, C.c_int]
+bufd = (C.c_ulonglong * 64)()
+assert lib.vk_phase_read_depth(bufd, 64, 1) == 0
 NW = 10
 t0 = time.perf_counter()
 for _ in range(NW):
@@ -44,3 +47,10 @@ show("k_pose_mode", [("load hypotheses", 16), ("init / trials", 17), ("mean-shif
 print(f"   mean-shift iterations / call {v[19]/max(v[20],1):.2f}")
 show("k_pose_refit", [("stage", 24), ("prepare (inverse)", 25), ("sample pass", 26), ("all-reduce + M-step", 27), ("finalize", 30)], 29)
 print(f"   gate iterations / call {v[28]/max(v[29],1):.2f}")
+
+assert lib.vk_phase_read_depth(bufd, 64, 0) == 0
+v = np.array(list(bufd), dtype=np.float64)
+show("k_local_runs_lean (middle wave: two chains)", [("setup + loads", 0), ("evaluation rounds", 1), ("bookkeeping", 2), ("exit", 3)], 8)
+print(f"   rounds / call {v[6]/max(v[8],1):.2f}")
+h = v[16:48]
+print("   rounds histogram (chains per launch): " + " ".join(f"{i}:{h[i]/(NW*32):.1f}" for i in range(32) if h[i] > 0))

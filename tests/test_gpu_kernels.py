@@ -116,39 +116,51 @@ def test_global_step1_serial_chain(orc):
     assert agree >= 0.97  # one flipped decision propagates along a serial chain
 
 
-def _gpu_only(flows, Rs, ts, depth, rig, K, epoch=5, **over):
+def _gpu_only(flows, Rs, ts, depth, rig, K, epoch=5, priors=None, pconfs=None, confs=None, dp_Rs=None, dp_ts=None, **over):
     from voldor_amd import kernels
     N, h, w, _ = flows.shape
+    N_dp = 0 if priors is None else priors.shape[0]
     kw = _od_kwargs(**over)
     kernels.set_rand_epoch(epoch)
-    return kernels.optimize_depth_gpu(flows, rig, None, None, None, depth, K, Rs, ts, None, None, kw["abs_resize_factor"], N, 0, w, h,
+    return kernels.optimize_depth_gpu(flows, rig, priors, pconfs, confs, depth, K, Rs, ts, dp_Rs, dp_ts, kw["abs_resize_factor"], N, N_dp, w, h,
                                       kw["basefocal"], kw["n_rand_samples"], kw["global_prop_step"], kw["local_prop_width"], kw["lambda_"], kw["omega"],
                                       kw["disp_delta"], kw["delta"], kw["fb_smooth"], kw["s0_ems_prob"], kw["no_change_prob"], kw["range_factor"],
                                       kw["update_rigidness_only"])
 
 
-@pytest.mark.parametrize("width,noise", [(32, 0.3), (32, 0.02), (33, 0.1), (7, 0.3), (64, 0.3), (65, 0.05), (5, 0.0)])
-def test_local_runs_equal_the_step_by_step_chain(width, noise):
-    """The local-propagation kernel of the fast mode (cost table + runs, the first pixel of the next few runs evaluated speculatively in
-    one round, two chains per wave up to width 33) against the literal step-by-step chain of the same arithmetic
-    (vk_set_local_serial): identical depth and rigidness maps, bit for bit, at replacement rates from ~50 % (noisy start) to ~0."""
+@pytest.mark.parametrize("width,noise,n_flows,n_dp", [(32, 0.3, 4, 0), (32, 0.02, 5, 0), (33, 0.1, 5, 1), (7, 0.3, 3, 0), (64, 0.3, 9, 0),
+                                                        (65, 0.05, 13, 2), (5, 0.0, 2, 0), (32, 0.1, 16, 0), (32, 0.2, 6, 5)])
+def test_local_runs_equal_the_step_by_step_chain(width, noise, n_flows, n_dp):
+    """The local-propagation kernel of the fast mode (cost table + chain automata whose run evaluations are planned two runs ahead, four
+    lanes per pixel, two chains per wave up to width 33) against the literal step-by-step chain of the same arithmetic
+    (vk_set_local_serial): identical depth and rigidness maps, bit for bit, at replacement rates from ~50 % (noisy start) to ~0, for
+    every way the frames and depth priors fall onto the four lanes of a pixel."""
     from voldor_amd import kernels, synth
-    sc = synth.make_scene(w=211, h=97, n_flows=4, fx=100, fy=100, cx=105, cy=48, seed=21)  # ragged: 211 = 6 * 32 + 19
+    sc = synth.make_scene(w=211, h=97, n_flows=n_flows, fx=100, fy=100, cx=105, cy=48, seed=21, basefocal=40.0 if n_dp else 0.0)  # ragged: 211 = 6 * 32 + 19
     rng = np.random.default_rng(int(width * 100 + noise * 1000))
     K = K9(*sc["K"])
     flows, Rs, ts, depth, rig = _state(sc, rng, noise=noise)
     if noise == 0.0:
         depth = sc["depth_gt"].astype(np.float32).copy()
-    over = dict(n_rand_samples=3, global_prop_step=5, local_prop_width=width, fb_smooth=0)
+    h, w = depth.shape
+    extra = {}
+    if n_dp:
+        pri = np.stack([(sc["depth_gt"] * (1 + rng.normal(0, 0.05, (h, w)))).astype(np.float32) for _ in range(n_dp)])
+        pri[:, ::7, ::5] = 0.0  # holes
+        extra = dict(priors=pri, pconfs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32), confs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32),
+                     dp_Rs=np.tile(np.eye(3, dtype=np.float32), (n_dp, 1, 1)), dp_ts=(rng.normal(0, 0.02, (n_dp, 3)) * np.arange(n_dp)[:, None]).astype(np.float32))
+    over = dict(n_rand_samples=3, global_prop_step=5, local_prop_width=width, fb_smooth=0, basefocal=40.0 if n_dp else 0.0, disp_delta=1.0 if n_dp else -1.0)
     try:
         kernels.set_local_serial(True)
-        d1, r1, _ = _gpu_only(flows, Rs, ts, depth, rig, K, **over)
+        d1, r1, c1 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
     finally:
         kernels.set_local_serial(False)
-    d2, r2, _ = _gpu_only(flows, Rs, ts, depth, rig, K, **over)
+    d2, r2, c2 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
     assert np.mean(d1 != depth) > (0.05 if noise >= 0.1 else 0.0)  # the passes did replace depths
     np.testing.assert_array_equal(d1.view(np.uint32), d2.view(np.uint32))
     np.testing.assert_array_equal(r1.view(np.uint32), r2.view(np.uint32))
+    if n_dp:
+        np.testing.assert_array_equal(c1.view(np.uint32), c2.view(np.uint32))
 
 
 def test_depth_priors_and_disparity(orc):

@@ -24,6 +24,19 @@ namespace vk {
 
 static std::atomic<int> g_local_serial{0};  // vk_set_local_serial (verification aid)
 
+// phase clocks (profiling builds only, scripts/phase_clocks.sh): thread 0 of the middle workgroup of a launch
+#ifdef VK_PHASE_CLOCKS
+__device__ unsigned long long g_phase_d[64];
+#define PHD_ON (threadIdx.x == 0 && blockIdx.x == gridDim.x / 2)
+#define PHD_DECL unsigned long long ph_t = __builtin_amdgcn_s_memtime()
+#define PHD_MARK(slot) do { if (PHD_ON) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_phase_d[slot], n_ - ph_t); ph_t = n_; } } while (0)
+#define PHD_ADD(slot, v) do { if (PHD_ON) atomicAdd(&g_phase_d[slot], (unsigned long long)(v)); } while (0)
+#else
+#define PHD_DECL do {} while (0)
+#define PHD_MARK(slot) do {} while (0)
+#define PHD_ADD(slot, v) do {} while (0)
+#endif
+
 struct Img {
     const float2* __restrict__ flows;  // [N][h][w]
     float* __restrict__ rig;           // [N][h][w]
@@ -564,60 +577,85 @@ __global__ __launch_bounds__(256) static void k_local_table_lean(Img I, int dir,
     if (!member) return;
     tbl[y * w + x] = pixel_cost_lean<NMAX>(I, lean_consts(I), x, y, I.depth[nb]);
 }
-// Lane-split evaluation for k_local_runs_lean (8 lanes per pixel, lane g owns frames g and g+8 and priors g, g+8): every lane walks the
-// (cheap) chain of positions, evaluates the gathers and residuals of its own frames, and the terms are combined through 8-wide
-// shuffles in exactly the order of lean_head / lean_rest -- frame 0, priors, frames 1.. in log2 units, one scale by ln 2 -- so the value
-// has the bits pixel_cost_lean gives for the same pixel and depth.
-__device__ __forceinline__ static float cost_split8_lean(const Img& I, const LeanK& K, int px, int py, float depth, int g) {
+// Lane-split evaluation for k_local_runs_lean: 4 lanes per pixel, lane g owns frames g, g+4, .. and priors g, g+4, ..  Every lane walks
+// the (cheap) chain of positions, evaluates the gathers and residuals of its own frames, and the terms are combined in exactly the order
+// of lean_head / lean_rest -- frame 0, priors, frames 1.. in log2 units, one scale by ln 2 -- so the value has the bits pixel_cost_lean
+// gives for the same pixel and depth.  The combination reads the owner's term with a quad broadcast (DPP quad_perm: a VALU move, no trip
+// through the LDS crossbar) and every lane of the quad accumulates the same chain.
+__device__ __forceinline__ float quad_bcast(float v, int q) {  // quad_perm [q,q,q,q]; q is a constant after unrolling
+    switch (q & 3) { case 0: return dpp_mov<0x00>(v); case 1: return dpp_mov<0x55>(v); case 2: return dpp_mov<0xAA>(v); default: return dpp_mov<0xFF>(v); }
+}
+__device__ __forceinline__ bool quad_bcast(bool b, int q) { return quad_bcast(b ? 1.f : 0.f, q) != 0.f; }
+template <int NMAX>
+__device__ __forceinline__ static float cost_split4_lean(const Img& I, const LeanK& K, int px, int py, float depth, int g) {
 #pragma clang fp contract(off)
+    constexpr int S = (NMAX + 3) / 4, PS = (MAX_DISP_FRAMES + 3) / 4;
     const int w = I.w, h = I.h, npx = w * h, pi = py * w + px;
     const PoseBlock* P = I.P;
     const float x = (float)px, y = (float)py, fw = (float)w, fh = (float)h;
-    float qx0 = 0.f, qy0 = 0.f, ex0 = 0.f, ey0 = 0.f, qx1 = 0.f, qy1 = 0.f, ex1 = 0.f, ey1 = 0.f;
-    bool v0 = false, v1 = false;
+    float qx[S], qy[S], ex[S], ey[S];
+    bool vv[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) { qx[k] = 0.f; qy[k] = 0.f; ex[k] = 0.f; ey[k] = 0.f; vv[k] = false; }
     {
         float px1 = x, py1 = y;
-        for (int f = 0; f < I.N; f++) {  // uniform trip count: no divergence inside the group
-            float px2, py2;
-            const bool zok = lean_step(P, f, x, y, depth, px2, py2);
-            const bool valid = f == 0 ? zok : (zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh);
-            if (f == g) { v0 = valid; qx0 = px1; qy0 = py1; ex0 = px2 - px1; ey0 = py2 - py1; }
-            if (f == g + 8) { v1 = valid; qx1 = px1; qy1 = py1; ex1 = px2 - px1; ey1 = py2 - py1; }
-            if (valid) { px1 = px2; py1 = py2; }
+#pragma unroll
+        for (int f = 0; f < NMAX; f++) {
+            if (f < I.N) {  // uniform trip count: no divergence inside the quad
+                float px2, py2;
+                const bool zok = lean_step(P, f, x, y, depth, px2, py2);
+                const bool valid = f == 0 ? zok : (zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh);
+                if ((f & 3) == g) { vv[f >> 2] = valid; qx[f >> 2] = px1; qy[f >> 2] = py1; ex[f >> 2] = px2 - px1; ey[f >> 2] = py2 - py1; }
+                if (valid) { px1 = px2; py1 = py2; }
+            }
         }
     }
-    // own terms: frame g -> (weight, log2(1 + ratio)); the owner of frame 0 applies ln 2 and the weight like lean_head
-    float wt0 = 0.f, lt0 = 0.f, wt1 = 0.f, lt1 = 0.f;
-    if (v0) {
-        const float2 ob = g == 0 ? I.flows[pi] : bilinear2_inside(I.flows + (size_t)g * npx, w, h, qx0, qy0);
-        wt0 = I.rig[(size_t)g * npx + pi];
-        const ObsTerms T = obs_terms(ob.x, ob.y, K.ia2, K.l2q);
-        lt0 = fast_log2(1.f + obs_ratio(T, ex0 - ob.x, ey0 - ob.y, K.qia2));
-        if (g == 0) lt0 = wt0 * (0.6931471805599453f * lt0);  // = the cs lean_head starts from
+    // own terms: frame g + 4k -> (weight, log2(1 + ratio)); the owner of frame 0 applies ln 2 and the weight like lean_head.
+    // All gathers first (an unused slot reads texel (0,0) of its layer, or of layer 0), then the model.
+    float2 ob[S];
+    float wt[S], lt[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const int f = g + 4 * k, fl = f < I.N ? f : 0;
+        const bool use = f < I.N && vv[k];
+        ob[k] = (k == 0 && g == 0) ? I.flows[pi] : bilinear2_inside(I.flows + (size_t)fl * npx, w, h, use ? qx[k] : 0.f, use ? qy[k] : 0.f);
+        wt[k] = I.rig[(size_t)fl * npx + pi];
     }
-    if (I.N > 8 && v1) {
-        const float2 ob = bilinear2_inside(I.flows + (size_t)(g + 8) * npx, w, h, qx1, qy1);
-        wt1 = I.rig[(size_t)(g + 8) * npx + pi];
-        const ObsTerms T = obs_terms(ob.x, ob.y, K.ia2, K.l2q);
-        lt1 = fast_log2(1.f + obs_ratio(T, ex1 - ob.x, ey1 - ob.y, K.qia2));
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const int f = g + 4 * k;
+        const bool use = f < I.N && vv[k];
+        const ObsTerms T = obs_terms(ob[k].x, ob[k].y, K.ia2, K.l2q);
+        float l = fast_log2(1.f + obs_ratio(T, ex[k] - ob[k].x, ey[k] - ob[k].y, K.qia2));
+        if (k == 0 && g == 0) l = wt[k] * (0.6931471805599453f * l);  // = the cs lean_head starts from
+        lt[k] = use ? l : 0.f; wt[k] = use ? wt[k] : 0.f; vv[k] = use;
     }
-    float pw0 = 0.f, pt0 = 0.f, pw1 = 0.f, pt1 = 0.f;
-    bool pk0 = false, pk1 = false;
-    if (g < I.N_dp) pk0 = prior_parts(I, P, g, x, y, depth, pw0, pt0);
-    if (g + 8 < I.N_dp) pk1 = prior_parts(I, P, g + 8, x, y, depth, pw1, pt1);
+    float pw[PS], pt[PS];
+    bool pk[PS];
+#pragma unroll
+    for (int k = 0; k < PS; k++) {
+        pw[k] = 0.f; pt[k] = 0.f; pk[k] = false;
+        if (g + 4 * k < I.N_dp) pk[k] = prior_parts(I, P, g + 4 * k, x, y, depth, pw[k], pt[k]);
+    }
     // combine in the order of lean_head / lean_rest
     float cs = 0.f, ws = 0.f;
-    if (I.N > 0 && __shfl((int)v0, 0, 8)) { cs = __shfl(lt0, 0, 8); ws = __shfl(wt0, 0, 8); }
-    for (int f = 0; f < I.N_dp; f++) {
-        const int ok = __shfl((int)((f & 8) ? pk1 : pk0), f & 7, 8);
-        const float wg = __shfl((f & 8) ? pw1 : pw0, f & 7, 8), term = __shfl((f & 8) ? pt1 : pt0, f & 7, 8);
-        if (ok) { cs = fmaf(wg, term, cs); ws += wg; }
+    if (I.N > 0 && quad_bcast(vv[0], 0)) { cs = quad_bcast(lt[0], 0); ws = quad_bcast(wt[0], 0); }
+#pragma unroll
+    for (int f = 0; f < MAX_DISP_FRAMES; f++) {
+        if (f < I.N_dp) {
+            const bool ok = quad_bcast(pk[f >> 2], f & 3);
+            const float wg = quad_bcast(pw[f >> 2], f & 3), term = quad_bcast(pt[f >> 2], f & 3);
+            if (ok) { cs = fmaf(wg, term, cs); ws += wg; }
+        }
     }
     float cl = 0.f;
-    for (int f = 1; f < I.N; f++) {
-        const int ok = __shfl((int)((f & 8) ? v1 : v0), f & 7, 8);
-        const float wg = __shfl((f & 8) ? wt1 : wt0, f & 7, 8), lt = __shfl((f & 8) ? lt1 : lt0, f & 7, 8);
-        if (ok) { cl = fmaf(wg, lt, cl); ws += wg; }
+#pragma unroll
+    for (int f = 1; f < NMAX; f++) {
+        if (f < I.N) {
+            const bool ok = quad_bcast(vv[f >> 2], f & 3);
+            const float wg = quad_bcast(wt[f >> 2], f & 3), l = quad_bcast(lt[f >> 2], f & 3);
+            if (ok) { cl = fmaf(wg, l, cl); ws += wg; }
+        }
     }
     cs = fmaf(0.6931471805599453f, cl, cs);
     return lean_final(cs, ws);
@@ -627,22 +665,24 @@ __device__ __forceinline__ static float cost_split8_lean(const Img& I, const Lea
 // and needs two rounds of waves at 640x480; with two chains per wave the whole pass is resident at once).  Lane j of a half holds
 // pixel j's old depth, old cost and table value.  A chain is an automaton with two states:
 //   fresh   the predecessor kept its depth, so the step's candidate cost is the table value: the next ACCEPT is found with a ballot;
-//   run     an accepted value v keeps propagating; c(x, v) has to be evaluated (8 lanes per pixel, frames split over the lanes,
-//           cost_split8_lean) until a step rejects it -- the step after the rejecting one is fresh again.
-// What costs time is the dependent latency of an evaluation (~1 us), so every evaluation round is filled with HALF/8 pixels:
-//   in a run     the next HALF/8 pixels with v (the costs of a run are independent given v), accept / reject scanned with a ballot;
-//   when fresh   the FIRST run pixel of each of the next HALF/8 accepts, under the guess that each value is rejected right away (the
-//                common case after the first EM iteration: ~6 % of the steps are replaced, mostly one at a time).  If accept s_j is
-//                rejected at s_j + 1, the next accept is the first table accept >= s_j + 2 -- exactly the one slot j + 1 evaluated, with
-//                the value it evaluated (the predecessor of s_j+1 is untouched).  The slots are replayed in order and the first
-//                one whose value IS accepted turns into a run and discards the rest.
-// Every cost that is used was evaluated for exactly the (pixel, value) the step-by-step chain would evaluate: identical results.
-// Both chains of a wave share one evaluation per round whatever state each is in; only the cheap bookkeeping diverges.
-template <int HALF>
+//   run     an accepted value v keeps propagating; c(x, v) has to be evaluated (4 lanes per pixel, frames split over the lanes,
+//           cost_split4_lean) until a step rejects it -- the step after the rejecting one is fresh again.
+// What costs time is the dependent latency of an evaluation round (~3 us: position chain, gathers at positions that miss the L2, model),
+// and the pass ends with its slowest chain (measured: 80 % of the chains have no accept at all, a few per launch have 5-7 runs).  So a
+// round is filled with HALF/4 pixels that are LIKELY to be needed:
+//   in a run     the next HALF/4 pixels with v (the costs of a run are independent given v), accept / reject scanned with a ballot;
+//   when fresh   the next TWO accepts s_A < s_B of the table with the first HALF/8 pixels of the run each would start (measured: an accept
+//                is followed by a short run four times out of five).  Run B's evaluations are the right ones if run A ends before
+//                s_B - 1 -- then s_B is the first accept after it and its predecessor is untouched; otherwise they are dropped.
+// Every cost that is used was evaluated for exactly the (pixel, value) the step-by-step chain evaluates: identical maps (tests:
+// vk_set_local_serial).  Both chains of a wave share one evaluation per round whatever state each is in; only the cheap
+// bookkeeping diverges.
+template <int HALF, int NMAX>
 __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, int width, const float* __restrict__ tbl, int lines, int nchains) {
     if (!clamp_active(I)) return;
-    constexpr int NH = 64 / HALF, NG = HALF / 8;  // chains per wave, pixels per evaluation round
-    const int lane = threadIdx.x, half = lane / HALF, hl = lane % HALF, g = hl >> 3, sub = hl & 7;
+    PHD_DECL;
+    constexpr int NH = 64 / HALF, NG = HALF / 4, NP = NG / 2;  // chains per wave, pixels per round, pixels per planned run
+    const int lane = threadIdx.x, half = lane / HALF, hl = lane % HALF, g = hl >> 2, sub = hl & 3;
     const int tile = xcd_band_tile(blockIdx.x, gridDim.x);
     const int chain = tile * NH + half;
     const bool in_range = chain < nchains;
@@ -657,68 +697,76 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
     const float d0 = has ? I.depth[mypi] : 0.f, c0 = has ? I.cost[mypi] : 0.f, t0 = has ? tbl[mypi] : INFINITY;
     const float first_cand = I.depth[cg.prev0];
     const unsigned long long tacc = (__ballot(has && t0 < c0) & hmask) >> hshift;  // steps whose table cost beats their current cost
+    // number of leading groups of [g0, g0 + cnt) whose lanes are set in `m` (one bit per lane, a group's four lanes agree)
+    auto lead = [](unsigned long long m, int g0, int cnt) {
+        const unsigned long long r = (~m >> (4 * g0)) & (cnt * 4 >= 64 ? ~0ull : ((1ull << (4 * cnt)) - 1ull));
+        return r != 0ull ? (__ffsll((long long)r) - 1) >> 2 : cnt;
+    };
     int x = 0;
     bool running = false;
     float vrun = 0.f;
+#ifdef VK_PHASE_CLOCKS
+    if (d0 + c0 + t0 + first_cand == 123456.f) return;
+    int rounds_ = 0;
+#endif
+    PHD_MARK(0);
     for (;;) {
+#ifdef VK_PHASE_CLOCKS
+        rounds_++;
+#endif
         // ---- this round's pixel and value of my group
-        int s = -1, px;
-        float v;
+        int px, sA = -1, sB = -1;
+        float v, vA = 0.f, vB = 0.f;
         bool act;
         if (running) { px = x + g; v = vrun; act = px < n; }
         else {
             unsigned long long m = (tacc >> x) << x;  // accepts at steps >= x (x < n <= 64)
             if (m == 0ull) break;  // no accept left: the rest of the chain keeps its values
-#pragma unroll
-            for (int j = 0; j < NG; j++) {
-                const int sj = m != 0ull ? __ffsll((long long)m) - 1 : -1;
-                if (j == g) s = sj;
-                m = (sj >= 0 && sj + 2 < 64) ? (m >> (sj + 2)) << (sj + 2) : 0ull;
-            }
-            px = s + 1; act = s >= 0 && px < n;
-            const float dprev = __shfl(d0, max(s - 1, 0), HALF);
-            v = s == 0 ? first_cand : dprev;
+            sA = __ffsll((long long)m) - 1;
+            m = sA + 2 < 64 ? (m >> (sA + 2)) << (sA + 2) : 0ull;
+            sB = m != 0ull ? __ffsll((long long)m) - 1 : -1;
+            const float dA = __shfl(d0, max(sA - 1, 0), HALF), dB = __shfl(d0, max(sB - 1, 0), HALF);
+            vA = sA == 0 ? first_cand : dA; vB = dB;  // s_B >= 2
+            const bool inB = g >= NP;
+            const int s = inB ? sB : sA;
+            px = s + 1 + (inB ? g - NP : g); v = inB ? vB : vA; act = s >= 0 && px < n;
         }
         // ---- one evaluation for the whole wave
         const int pi = cg.pi0 + (act ? px : 0) * cg.stride;
-        const float c = cost_split8_lean(I, K, pi % I.w, pi / I.w, v, sub);
+        const float c = cost_split4_lean<NMAX>(I, K, pi % I.w, pi / I.w, v, sub);
         const float c0p = __shfl(c0, min(max(px, 0), HALF - 1), HALF);
         const bool acc = act && c < c0p;
-        // ---- bookkeeping
+        const unsigned long long accm = (__ballot(acc) & hmask) >> hshift;
+        PHD_MARK(1); PHD_ADD(6, 1);
+        // ---- bookkeeping (uniform within a half)
         if (running) {
-            // length of the accepted prefix over the groups (a group's 8 lanes agree)
-            const unsigned long long rej = (__ballot(!acc) & hmask) >> hshift;
-            const int L = (__ffsll((long long)rej) - 1) >> 3;  // rej != 0 unless all groups accept
-            const int Lacc = rej == 0ull ? NG : L;
-            if (g < Lacc && sub == 0) { I.depth[pi] = v; I.cost[pi] = c; }
-            x += Lacc;
-            if (Lacc < NG) {  // the step at x rejected v (or the chain ended): its successor is fresh again
-                running = false;
-                x += 1;
-            }
+            const int L = lead(accm, 0, NG);  // a step past the end of the chain counts as rejecting
+            if (g < L && sub == 0) { I.depth[pi] = v; I.cost[pi] = c; }
+            x += L;
+            if (L < NG) { running = false; x += 1; }  // the step at x rejected v: its successor is fresh again
         } else {
-            const unsigned long long accm = (__ballot(acc) & hmask) >> hshift;  // bit 8 j: slot j's value is accepted by its first run pixel
-            bool stop = false;
-#pragma unroll
-            for (int j = 0; j < NG; j++) {
-                if (!stop) {
-                    const int sj = __shfl(s, j * 8, HALF);
-                    const float vj = __shfl(v, j * 8, HALF);
-                    if (sj < 0) { x = n; stop = true; }  // no further accept
-                    else {
-                        if (hl == sj) { I.depth[mypi] = vj; I.cost[mypi] = t0; }  // replace_if_better_depth (:201-207)
-                        if (sj + 1 >= n) { x = n; stop = true; }
-                        else if ((accm >> (j * 8)) & 1ull) {  // v_j goes on: a run
-                            if (g == j && sub == 0) { I.depth[pi] = v; I.cost[pi] = c; }
-                            running = true; vrun = vj; x = sj + 2; stop = true;
-                        } else
-                            x = sj + 2;  // rejected at s_j + 1: s_j + 2 is fresh, and slot j + 1 holds the first accept from there
-                    }
+            if (hl == sA) { I.depth[mypi] = vA; I.cost[mypi] = t0; }  // replace_if_better_depth (:201-207)
+            const int LA = lead(accm, 0, NP);
+            if (g < LA && sub == 0) { I.depth[pi] = v; I.cost[pi] = c; }
+            if (LA == NP) { running = true; vrun = vA; x = sA + 1 + NP; }  // still going: a run in progress
+            else {
+                x = sA + LA + 2;  // rejected at s_A + 1 + LA (or the chain ended there)
+                if (sB >= x && x < n) {  // run A ended before s_B - 1: s_B is the first accept from x, evaluated with the right value
+                    if (hl == sB) { I.depth[mypi] = vB; I.cost[mypi] = t0; }
+                    const int LB = lead(accm, NP, NP);
+                    if (g >= NP && g < NP + LB && sub == 0) { I.depth[pi] = v; I.cost[pi] = c; }
+                    if (LB == NP) { running = true; vrun = vB; x = sB + 1 + NP; }
+                    else x = sB + LB + 2;
                 }
             }
         }
+        PHD_MARK(2);
         if (x >= n) break;
     }
+    PHD_MARK(3); PHD_ADD(8, 1);
+#ifdef VK_PHASE_CLOCKS
+    if (hl == 0) atomicAdd(&g_phase_d[16 + min(rounds_, 31)], 1ull);  // histogram of the rounds a chain's half took part in
+#endif
 }
 // E-step (optimize_depth.cu:84-138), lean geometry and model; per-block rigidness sums as k_update_rigidness
 template <int NMAX>
@@ -1099,9 +1147,9 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                     hipLaunchKernelGGL(k_local_table_lean<NMAX>, gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
                     const int nchains = lines * nseg;
                     if (p.local_prop_width <= 33)  // chains of <= 32 steps: two per wave
-                        hipLaunchKernelGGL(k_local_runs_lean<32>, dim3((nchains + 1) / 2), dim3(64), 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>(), lines, nchains);
+                        hipLaunchKernelGGL((k_local_runs_lean<32, NMAX>), dim3((nchains + 1) / 2), dim3(64), 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>(), lines, nchains);
                     else
-                        hipLaunchKernelGGL(k_local_runs_lean<64>, dim3(nchains), dim3(64), 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>(), lines, nchains);
+                        hipLaunchKernelGGL((k_local_runs_lean<64, NMAX>), dim3(nchains), dim3(64), 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>(), lines, nchains);
                 } else
                     hipLaunchKernelGGL((k_local_serial<NMAX, STRICT>), dim3((lines + 63) / 64, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
             }
@@ -1232,3 +1280,12 @@ int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk
 }  // namespace vk
 
 extern "C" __attribute__((visibility("default"))) int vk_set_local_serial(int on) { vk::g_local_serial.store(on ? 1 : 0); return 0; }
+
+#ifdef VK_PHASE_CLOCKS
+extern "C" __attribute__((visibility("default"))) int vk_phase_read_depth(unsigned long long* out, int n, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return 1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(vk::g_phase_d), sizeof(unsigned long long) * (size_t)(n < 64 ? n : 64)) != hipSuccess) return 2;
+    if (reset) { unsigned long long z[64] = {}; if (hipMemcpyToSymbol(HIP_SYMBOL(vk::g_phase_d), z, sizeof z) != hipSuccess) return 3; }
+    return 0;
+}
+#endif

@@ -208,4 +208,4 @@ def get_strict_math() -> bool:
 
 def set_local_serial(on: bool):
     """Verification aid (include/voldor_hip.h: vk_set_local_serial): step-by-step local propagation in fast mode."""
-    capi.check(capi.lib().vk_set_local_serial(1 if on else 0), "vk_set_local_serial")
+    capi.check(capi.lib().vk_set_local_serial(int(on)), "vk_set_local_serial")
