@@ -54,3 +54,4 @@ show("k_local_runs_lean (middle wave: two chains)", [("setup + loads", 0), ("eva
 print(f"   rounds / call {v[6]/max(v[8],1):.2f}")
 h = v[16:48]
 print("   rounds histogram (chains per launch): " + " ".join(f"{i}:{h[i]/(NW*32):.1f}" for i in range(32) if h[i] > 0))
+

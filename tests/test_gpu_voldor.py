@@ -31,7 +31,11 @@ def _cmp(out_g, out_o, rot_tol=1e-3, tr_tol=1e-3):
 
 
 @pytest.mark.parametrize("cfg,rot_tol,tr_tol", [
-    ("--max_iters 1 --rg_refine 0", 1e-4, 1e-3),
+    # translation: the picks of the initial-mode trials are rand() % (number of finite hypotheses) (meanshift.cu:72-95); a last-bit
+    # difference in camera 0's pose makes a handful of camera 1's 8192 P3P solutions (non-)finite, the count moves by a few, every pick
+    # changes, and the mean shift stops (step < 1e-5, contraction ~0.9) within ~1e-4 of the same mode from another side.  Measured with
+    # two summation orders of the mode kernel: 3.6e-4 and 1.04e-3 for the same window.
+    ("--max_iters 1 --rg_refine 0", 1e-4, 2e-3),
     ("--max_iters 2 --rg_refine 0", 2e-4, 2e-3),
 ])
 def test_mono_window_tight_with_identical_draws(orc, cfg, rot_tol, tr_tol):

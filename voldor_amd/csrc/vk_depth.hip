@@ -283,7 +283,20 @@ __global__ __launch_bounds__(256) static void k_update_rigidness_strict(Img I, f
 //   * a bilinear fetch at a position known to be inside the image needs no clamps (bilinear2_inside)
 //   * the observation-only half of the residual model is split off (obs_terms: once per gather, once per PIXEL for frame 0)
 // The validity rules (z > 0, previous position inside the image, position advanced on contributing frames only) are unchanged.
-__global__ __launch_bounds__(64) static void k_cum_poses(PoseBlock* P, int N, int N_dp) {
+// voldor.cpp:309-317: scale = n / sum ||t_i|| over the registered frames (frames dropped by this iteration's decision do not count)
+__device__ __forceinline__ static float world_scale_factor(const PoseBlock* P, int n_launch, const float (*ts)[3]) {
+    const int n = min(n_launch, P->n_active);
+    if (n <= 0) return 1.f;  // window lost: nothing to normalise (deviation D6)
+    float ws = 0.f;
+    for (int i = 0; i < n; i++) {
+        const float* t = ts[i];
+        ws = (float)((double)ws + sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2]));  // float += double (cv::norm, voldor.cpp:312)
+    }
+    return (float)n / ws;
+}
+// world_scale (may be NULL): the factor of normalize_world_scale (voldor.cpp:309-317), n / sum ||t_i|| over the registered frames, from
+// the poses this optimize_depth call runs with; the E-step kernel stores the scaled depth, k_reduce_density then scales the poses.
+__device__ __forceinline__ static void cum_poses_block(PoseBlock* P, int N, int N_dp, float* world_scale) {
     __shared__ double Rc[9], tc[3];
     __shared__ float sR[MAX_FRAMES][9], sT[MAX_FRAMES][3];  // one round trip to the pose block instead of one per frame of the chain
     const int l = threadIdx.x;
@@ -323,7 +336,9 @@ __global__ __launch_bounds__(64) static void k_cum_poses(PoseBlock* P, int N, in
         for (int k = 0; k < 3; k++) t[k] = P->dpts[f][k];
         emit(R, t, P->dpM[f], P->dpT[f]);
     }
+    if (world_scale && l == 0) *world_scale = world_scale_factor(P, N, sT);
 }
+__global__ __launch_bounds__(64) static void k_cum_poses(PoseBlock* P, int N, int N_dp, float* world_scale) { cum_poses_block(P, N, N_dp, world_scale); }
 
 struct LeanK { float ia2, qia2, l2q; };  // 1/arf^2, 0.25/arf^2, log2(0.25 lambda^2)
 __device__ __forceinline__ LeanK lean_consts(const Img& I) {
@@ -770,7 +785,7 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
 }
 // E-step (optimize_depth.cu:84-138), lean geometry and model; per-block rigidness sums as k_update_rigidness
 template <int NMAX>
-__global__ __launch_bounds__(256) static void k_update_rigidness_lean(Img I, float* __restrict__ partial) {
+__global__ __launch_bounds__(256) static void k_update_rigidness_lean(Img I, float* __restrict__ partial, const float* __restrict__ world_scale) {
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
     const int xi = (tile % gridDim.x) * 64 + (threadIdx.x & 63);
@@ -826,6 +841,7 @@ __global__ __launch_bounds__(256) static void k_update_rigidness_lean(Img I, flo
         partial[(size_t)f * nblk + blk] = (s_part[f][0] + s_part[f][1]) + (s_part[f][2] + s_part[f][3]);
     }
     if (!live) return;
+    if (world_scale) I.depth[pi] = d * *world_scale;  // normalize_world_scale's depth half (voldor.cpp:314): the E-step above saw the unscaled map
     for (int f = 0; f < I.N_dp; f++) {
         const H3 a = hom_dir(P->dpM[f], x, y);
         const float hz = fmaf(d, a.z, P->dpT[f][2]);
@@ -879,18 +895,14 @@ __global__ __launch_bounds__(64) static void k_local_serial(Img I, int dir, int 
 // blocks 0..n_launch-1: rigidness density of one frame; block n_launch (only launched when scale_out != NULL): the pose half
 // of normalize_world_scale (voldor.cpp:309-317), scale = n / sum ||t_i|| over the registered frames -- one launch for both
 __global__ static void k_reduce_density(const float* __restrict__ partial, int nblk, int npx, CamState* cams, PoseBlock* P, int n_launch,
-                                        float* scale_out) {
+                                        float* scale_out, int scale_ready) {
     const int f = blockIdx.x;
     if (f == n_launch) {
         if (threadIdx.x != 0) return;
         const int n = min(n_launch, P->n_active);  // frames dropped by this iteration's decision do not count
-        if (n <= 0) { *scale_out = 1.f; return; }   // window lost: nothing to normalise (deviation D6)
-        float ws = 0.f;
-        for (int i = 0; i < n; i++) {
-            const float* t = P->ts[i];
-            ws = (float)((double)ws + sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2]));  // float += double (cv::norm, voldor.cpp:312)
-        }
-        const float s = (float)n / ws;
+        // scale_ready: the factor was computed from these poses at the start of the call (cum_poses_block) and the depth map already
+        // carries it (k_update_rigidness_lean); otherwise it is computed here and k_scale follows
+        const float s = scale_ready ? *scale_out : world_scale_factor(P, n_launch, P->ts);
         for (int i = 0; i < n; i++)
             for (int d = 0; d < 3; d++) { P->ts[i][d] *= s; cams[i].t[d] = P->ts[i][d]; }
         *scale_out = s;
@@ -995,8 +1007,13 @@ __device__ __forceinline__ void fb_incoming(const FbMat* sF, const FbMat* sB, in
 // Row pass: thread = (row, segment), segments of a row on adjacent lanes -> a wave reads whole contiguous row
 // pieces (160 bytes per lane).  256 threads = floor(256/S) rows.
 template <bool VEC4>
-__global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps, int w, int h, int S, float e0, float p, const int* __restrict__ n_dev) {
+__global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps, int w, int h, int S, float e0, float p, const int* __restrict__ n_dev,
+                                                        int n_maps, PoseBlock* cumP, int cumN, int cumNdp, float* world_scale) {
     __shared__ FbMat sF[256], sB[256];
+    if ((int)blockIdx.y == n_maps) {  // extra layer (launched only with cumP): one workgroup prepares the projective maps the cost kernels need next
+        if (blockIdx.x == 0) cum_poses_block(cumP, cumN, cumNdp, world_scale);
+        return;
+    }
     if (n_dev && (int)blockIdx.y >= *n_dev) return;  // map of a frame the device-side decision has dropped
     const int lpb = 256 / S, tid = threadIdx.x;
     const int ll = tid / S, seg = tid - ll * S, row = blockIdx.x * lpb + ll;
@@ -1061,7 +1078,8 @@ __global__ __launch_bounds__(1024) static void k_fb_cols(float* __restrict__ map
     for (int k = 0; k < FB_SEG; k++) if (k < n) m[(size_t)(r0 + k) * w] = e[k];
 }
 
-int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev) {
+int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev, PoseBlock* cumP,
+                     int cumN, int cumNdp, float* world_scale) {
     if (n_maps <= 0) return 0;
     const int Sr = (w + FB_SEG - 1) / FB_SEG, Sc = (h + FB_SEG - 1) / FB_SEG;
     if (Sr > 256 || Sc * FB_CW > 1024) {
@@ -1070,8 +1088,9 @@ int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0
     }
     const int lpb = 256 / Sr;
     const bool vec4 = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(maps) % 16) == 0;
-    if (vec4) hipLaunchKernelGGL(k_fb_rows<true>, dim3((h + lpb - 1) / lpb, n_maps), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob, n_dev);
-    else hipLaunchKernelGGL(k_fb_rows<false>, dim3((h + lpb - 1) / lpb, n_maps), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob, n_dev);
+    const int layers = n_maps + (cumP ? 1 : 0);
+    if (vec4) hipLaunchKernelGGL(k_fb_rows<true>, dim3((h + lpb - 1) / lpb, layers), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob, n_dev, n_maps, cumP, cumN, cumNdp, world_scale);
+    else hipLaunchKernelGGL(k_fb_rows<false>, dim3((h + lpb - 1) / lpb, layers), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob, n_dev, n_maps, cumP, cumN, cumNdp, world_scale);
     hipLaunchKernelGGL(k_fb_cols, dim3((w + FB_CW - 1) / FB_CW, n_maps), dim3(FB_CW * Sc), 0, c->stream, maps, w, h, Sc, s0_ems_prob, no_change_prob, n_dev);
     VK_CHECK_LAST();
     return 0;
@@ -1089,6 +1108,11 @@ static Img make_img(const ImageSet& S, const OdParams& p) {
 }
 
 
+__global__ static void k_scale(float* p, const float* s_dev, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] *= *s_dev;
+}
+
 // Device-resident optimize_depth: all inputs already in `S`. Stage order optimize_depth.cu:462-494.
 // STRICT: the reference's operation order on software transcendentals, plain launch structure (one thread per serial chain).
 // Fast: k_cum_poses, then the lean kernels (cost + samples through the survivor queue, table + runs for the local passes).
@@ -1097,7 +1121,10 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
     const int w = p.w, h = p.h;
     Img I = make_img(S, p);
     const dim3 gpx((w + 63) / 64, (h + 3) / 4), bpx(256);
-    if constexpr (!STRICT) hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, S.pb(), p.N, p.N_dp);
+    // fast mode: the projective maps of the chain (and the world-scale factor) are prepared by an extra workgroup of the first fb_smooth
+    // launch when there is one, by their own small launch otherwise
+    const bool cum_in_fb = !STRICT && !cost_only && !p.update_rigidness_only && p.fb_smooth && p.N > 0;
+    if constexpr (!STRICT) { if (!cum_in_fb) hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, S.pb(), p.N, p.N_dp, p.world_scale_out); }
     auto cost_rand = [&](int n_rand, uint32_t epoch) {
         if constexpr (STRICT) hipLaunchKernelGGL(k_cost_rand_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
         else hipLaunchKernelGGL(k_cost_rand_q<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
@@ -1113,7 +1140,8 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                 if (int e = fb_smooth_strict_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active)) return e;
                 if (int e = fb_smooth_strict_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e;
             } else {
-                if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active)) return e;
+                if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active, cum_in_fb ? S.pb() : nullptr, p.N, p.N_dp,
+                                             p.world_scale_out)) return e;
                 if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e;
             }
         }
@@ -1158,10 +1186,12 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
     }
     const int nblk = gpx.x * gpx.y;
     if constexpr (STRICT) hipLaunchKernelGGL(k_update_rigidness_strict<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
-    else hipLaunchKernelGGL(k_update_rigidness_lean<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
+    else hipLaunchKernelGGL(k_update_rigidness_lean<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>(), p.N > 0 ? p.world_scale_out : nullptr);
     if (p.N > 0)
         hipLaunchKernelGGL(k_reduce_density, dim3(p.N + (p.world_scale_out ? 1 : 0)), dim3(256), 0, c->stream, c->rig_partial.as<float>(), nblk,
-                           w * h, c->cams.as<CamState>(), S.pb(), p.N, p.world_scale_out);
+                           w * h, c->cams.as<CamState>(), S.pb(), p.N, p.world_scale_out, STRICT ? 0 : 1);
+    // normalize_world_scale's depth half: strict mode as its own pass after the E-step; the fast E-step kernel has stored the scaled map
+    if (STRICT && p.N > 0 && p.world_scale_out) hipLaunchKernelGGL(k_scale, dim3((unsigned)(((size_t)w * h + 255) / 256)), dim3(256), 0, c->stream, I.depth, p.world_scale_out, (size_t)w * h);
     VK_CHECK_LAST();
     return 0;
 }
@@ -1204,10 +1234,6 @@ int cost_map_device(Context* c, ImageSet& S, const OdParams& p) {
 __global__ static void k_fill(float* p, float v, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
-}
-__global__ static void k_scale(float* p, const float* s_dev, size_t n) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] *= *s_dev;
 }
 __global__ static void k_disp_to_depth(const float* disp, float* out, float bf, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

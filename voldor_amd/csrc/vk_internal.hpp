@@ -38,7 +38,8 @@ __device__ __forceinline__ void maybe_decide(const ModeParams& mp, PoseBlock* P,
 // vk_depth.hip
 int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p);
 int cost_map_device(Context* c, ImageSet& S, const OdParams& p);
-int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr);
+int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr,
+                     PoseBlock* cumP = nullptr, int cumN = 0, int cumNdp = 0, float* world_scale = nullptr);
 // vk_strict.hip
 int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr);
 int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);

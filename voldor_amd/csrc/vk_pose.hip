@@ -829,7 +829,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr int PM_THREADS = VK_PM_THREADS;
 constexpr int PM_POOL = 8192;   // hypotheses the mode kernels keep on chip (cfg.n_poses_to_sample default)
 constexpr float MS_FAR = 1e18f;
-constexpr int MS_TRIAL_BATCH = 5;  // initial-mode trials evaluated per pass (meanshift.cu:72-95 runs them one at a time)
+#ifndef VK_MS_TRIAL_BATCH
+#define VK_MS_TRIAL_BATCH 5
+#endif
+constexpr int MS_TRIAL_BATCH = VK_MS_TRIAL_BATCH;  // initial-mode trials evaluated per pass (meanshift.cu:72-95 runs them one at a time)
 // THREADS: the per-iteration all-reduce, the mean update and the convergence test are executed by every wave (~100 instructions next
 // to ~30 per pair of hypotheses), so fewer, fatter waves do less redundant work: THREADS * SPT = PM_POOL.
 template <bool DEFER, int THREADS>

@@ -184,9 +184,7 @@ struct Voldor {
             if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
             p.world_scale_out = c->ms_io.as<float>() + 48;
         }
-        if (int e = optimize_depth_device(c, c->od, p)) return e;
-        if (with_world_scale) return scale_device(c, c->od.depth.as<float>(), p.world_scale_out, (size_t)w * h);
-        return 0;
+        return optimize_depth_device(c, c->od, p);  // with world_scale_out: depth and poses leave normalised (voldor.cpp:309-317)
     }
 
     // voldor/geometry.cpp:5-265, all on the device; success / density come back in CamState
