@@ -592,19 +592,23 @@ __global__ __launch_bounds__(256) static void k_local_table_lean(Img I, int dir,
     if (!member) return;
     tbl[y * w + x] = pixel_cost_lean<NMAX>(I, lean_consts(I), x, y, I.depth[nb]);
 }
-// Lane-split evaluation for k_local_runs_lean: 4 lanes per pixel, lane g owns frames g, g+4, .. and priors g, g+4, ..  Every lane walks
+// Lane-split evaluation for k_local_runs_lean: LPP (4 or 8) lanes per pixel, lane g owns frames g, g+LPP, .. and priors g, g+LPP, ..  Every lane walks
 // the (cheap) chain of positions, evaluates the gathers and residuals of its own frames, and the terms are combined in exactly the order
 // of lean_head / lean_rest -- frame 0, priors, frames 1.. in log2 units, one scale by ln 2 -- so the value has the bits pixel_cost_lean
-// gives for the same pixel and depth.  The combination reads the owner's term with a quad broadcast (DPP quad_perm: a VALU move, no trip
-// through the LDS crossbar) and every lane of the quad accumulates the same chain.
+// gives for the same pixel and depth.  The combination reads the owner's term with a group broadcast (LPP = 4: DPP quad_perm, a VALU move,
+// no trip through the LDS crossbar) and every lane of the group accumulates the same chain.  LPP = 4 halves the rounds a chain needs (twice
+// the pixels per round) and suits up to 8 frames (two per lane); beyond that the per-lane work doubles again and 8 lanes per pixel win.
 __device__ __forceinline__ float quad_bcast(float v, int q) {  // quad_perm [q,q,q,q]; q is a constant after unrolling
     switch (q & 3) { case 0: return dpp_mov<0x00>(v); case 1: return dpp_mov<0x55>(v); case 2: return dpp_mov<0xAA>(v); default: return dpp_mov<0xFF>(v); }
 }
 __device__ __forceinline__ bool quad_bcast(bool b, int q) { return quad_bcast(b ? 1.f : 0.f, q) != 0.f; }
-template <int NMAX>
-__device__ __forceinline__ static float cost_split4_lean(const Img& I, const LeanK& K, int px, int py, float depth, int g) {
+// lane q of every aligned group of LPP lanes: a DPP move for quads, the LDS crossbar for groups of eight
+template <int LPP> __device__ __forceinline__ float group_bcast(float v, int q) { return LPP == 4 ? quad_bcast(v, q) : __shfl(v, q, LPP); }
+template <int LPP> __device__ __forceinline__ bool group_bcast(bool b, int q) { return LPP == 4 ? quad_bcast(b, q) : (__shfl((int)b, q, LPP) != 0); }
+template <int NMAX, int LPP>
+__device__ __forceinline__ static float cost_split_lean(const Img& I, const LeanK& K, int px, int py, float depth, int g) {
 #pragma clang fp contract(off)
-    constexpr int S = (NMAX + 3) / 4, PS = (MAX_DISP_FRAMES + 3) / 4;
+    constexpr int S = (NMAX + LPP - 1) / LPP, PS = (MAX_DISP_FRAMES + LPP - 1) / LPP;
     const int w = I.w, h = I.h, npx = w * h, pi = py * w + px;
     const PoseBlock* P = I.P;
     const float x = (float)px, y = (float)py, fw = (float)w, fh = (float)h;
@@ -620,25 +624,25 @@ __device__ __forceinline__ static float cost_split4_lean(const Img& I, const Lea
                 float px2, py2;
                 const bool zok = lean_step(P, f, x, y, depth, px2, py2);
                 const bool valid = f == 0 ? zok : (zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh);
-                if ((f & 3) == g) { vv[f >> 2] = valid; qx[f >> 2] = px1; qy[f >> 2] = py1; ex[f >> 2] = px2 - px1; ey[f >> 2] = py2 - py1; }
+                if (f % LPP == g) { vv[f / LPP] = valid; qx[f / LPP] = px1; qy[f / LPP] = py1; ex[f / LPP] = px2 - px1; ey[f / LPP] = py2 - py1; }
                 if (valid) { px1 = px2; py1 = py2; }
             }
         }
     }
-    // own terms: frame g + 4k -> (weight, log2(1 + ratio)); the owner of frame 0 applies ln 2 and the weight like lean_head.
+    // own terms: frame g + LPP k -> (weight, log2(1 + ratio)); the owner of frame 0 applies ln 2 and the weight like lean_head.
     // All gathers first (an unused slot reads texel (0,0) of its layer, or of layer 0), then the model.
     float2 ob[S];
     float wt[S], lt[S];
 #pragma unroll
     for (int k = 0; k < S; k++) {
-        const int f = g + 4 * k, fl = f < I.N ? f : 0;
+        const int f = g + LPP * k, fl = f < I.N ? f : 0;
         const bool use = f < I.N && vv[k];
         ob[k] = (k == 0 && g == 0) ? I.flows[pi] : bilinear2_inside(I.flows + (size_t)fl * npx, w, h, use ? qx[k] : 0.f, use ? qy[k] : 0.f);
         wt[k] = I.rig[(size_t)fl * npx + pi];
     }
 #pragma unroll
     for (int k = 0; k < S; k++) {
-        const int f = g + 4 * k;
+        const int f = g + LPP * k;
         const bool use = f < I.N && vv[k];
         const ObsTerms T = obs_terms(ob[k].x, ob[k].y, K.ia2, K.l2q);
         float l = fast_log2(1.f + obs_ratio(T, ex[k] - ob[k].x, ey[k] - ob[k].y, K.qia2));
@@ -650,16 +654,16 @@ __device__ __forceinline__ static float cost_split4_lean(const Img& I, const Lea
 #pragma unroll
     for (int k = 0; k < PS; k++) {
         pw[k] = 0.f; pt[k] = 0.f; pk[k] = false;
-        if (g + 4 * k < I.N_dp) pk[k] = prior_parts(I, P, g + 4 * k, x, y, depth, pw[k], pt[k]);
+        if (g + LPP * k < I.N_dp) pk[k] = prior_parts(I, P, g + LPP * k, x, y, depth, pw[k], pt[k]);
     }
     // combine in the order of lean_head / lean_rest
     float cs = 0.f, ws = 0.f;
-    if (I.N > 0 && quad_bcast(vv[0], 0)) { cs = quad_bcast(lt[0], 0); ws = quad_bcast(wt[0], 0); }
+    if (I.N > 0 && group_bcast<LPP>(vv[0], 0)) { cs = group_bcast<LPP>(lt[0], 0); ws = group_bcast<LPP>(wt[0], 0); }
 #pragma unroll
     for (int f = 0; f < MAX_DISP_FRAMES; f++) {
         if (f < I.N_dp) {
-            const bool ok = quad_bcast(pk[f >> 2], f & 3);
-            const float wg = quad_bcast(pw[f >> 2], f & 3), term = quad_bcast(pt[f >> 2], f & 3);
+            const bool ok = group_bcast<LPP>(pk[f / LPP], f % LPP);
+            const float wg = group_bcast<LPP>(pw[f / LPP], f % LPP), term = group_bcast<LPP>(pt[f / LPP], f % LPP);
             if (ok) { cs = fmaf(wg, term, cs); ws += wg; }
         }
     }
@@ -667,8 +671,8 @@ __device__ __forceinline__ static float cost_split4_lean(const Img& I, const Lea
 #pragma unroll
     for (int f = 1; f < NMAX; f++) {
         if (f < I.N) {
-            const bool ok = quad_bcast(vv[f >> 2], f & 3);
-            const float wg = quad_bcast(wt[f >> 2], f & 3), l = quad_bcast(lt[f >> 2], f & 3);
+            const bool ok = group_bcast<LPP>(vv[f / LPP], f % LPP);
+            const float wg = group_bcast<LPP>(wt[f / LPP], f % LPP), l = group_bcast<LPP>(lt[f / LPP], f % LPP);
             if (ok) { cl = fmaf(wg, l, cl); ws += wg; }
         }
     }
@@ -680,24 +684,24 @@ __device__ __forceinline__ static float cost_split4_lean(const Img& I, const Lea
 // and needs two rounds of waves at 640x480; with two chains per wave the whole pass is resident at once).  Lane j of a half holds
 // pixel j's old depth, old cost and table value.  A chain is an automaton with two states:
 //   fresh   the predecessor kept its depth, so the step's candidate cost is the table value: the next ACCEPT is found with a ballot;
-//   run     an accepted value v keeps propagating; c(x, v) has to be evaluated (4 lanes per pixel, frames split over the lanes,
-//           cost_split4_lean) until a step rejects it -- the step after the rejecting one is fresh again.
+//   run     an accepted value v keeps propagating; c(x, v) has to be evaluated (LPP lanes per pixel, frames split over the lanes,
+//           cost_split_lean) until a step rejects it -- the step after the rejecting one is fresh again.
 // What costs time is the dependent latency of an evaluation round (~3 us: position chain, gathers at positions that miss the L2, model),
 // and the pass ends with its slowest chain (measured: 80 % of the chains have no accept at all, a few per launch have 5-7 runs).  So a
-// round is filled with HALF/4 pixels that are LIKELY to be needed:
-//   in a run     the next HALF/4 pixels with v (the costs of a run are independent given v), accept / reject scanned with a ballot;
-//   when fresh   the next TWO accepts s_A < s_B of the table with the first HALF/8 pixels of the run each would start (measured: an accept
+// round is filled with HALF/LPP pixels that are LIKELY to be needed:
+//   in a run     the next HALF/LPP pixels with v (the costs of a run are independent given v), accept / reject scanned with a ballot;
+//   when fresh   the next TWO accepts s_A < s_B of the table with the first HALF/(2 LPP) pixels of the run each would start (measured: an accept
 //                is followed by a short run four times out of five).  Run B's evaluations are the right ones if run A ends before
 //                s_B - 1 -- then s_B is the first accept after it and its predecessor is untouched; otherwise they are dropped.
 // Every cost that is used was evaluated for exactly the (pixel, value) the step-by-step chain evaluates: identical maps (tests:
 // vk_set_local_serial).  Both chains of a wave share one evaluation per round whatever state each is in; only the cheap
 // bookkeeping diverges.
-template <int HALF, int NMAX>
+template <int HALF, int NMAX, int LPP>
 __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, int width, const float* __restrict__ tbl, int lines, int nchains) {
     if (!clamp_active(I)) return;
     PHD_DECL;
-    constexpr int NH = 64 / HALF, NG = HALF / 4, NP = NG / 2;  // chains per wave, pixels per round, pixels per planned run
-    const int lane = threadIdx.x, half = lane / HALF, hl = lane % HALF, g = hl >> 2, sub = hl & 3;
+    constexpr int NH = 64 / HALF, NG = HALF / LPP, NP = NG / 2;  // chains per wave, pixels per round, pixels per planned run
+    const int lane = threadIdx.x, half = lane / HALF, hl = lane % HALF, g = hl / LPP, sub = hl % LPP;
     const int tile = xcd_band_tile(blockIdx.x, gridDim.x);
     const int chain = tile * NH + half;
     const bool in_range = chain < nchains;
@@ -712,10 +716,10 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
     const float d0 = has ? I.depth[mypi] : 0.f, c0 = has ? I.cost[mypi] : 0.f, t0 = has ? tbl[mypi] : INFINITY;
     const float first_cand = I.depth[cg.prev0];
     const unsigned long long tacc = (__ballot(has && t0 < c0) & hmask) >> hshift;  // steps whose table cost beats their current cost
-    // number of leading groups of [g0, g0 + cnt) whose lanes are set in `m` (one bit per lane, a group's four lanes agree)
+    // number of leading groups of [g0, g0 + cnt) whose lanes are set in `m` (one bit per lane, a group's lanes agree)
     auto lead = [](unsigned long long m, int g0, int cnt) {
-        const unsigned long long r = (~m >> (4 * g0)) & (cnt * 4 >= 64 ? ~0ull : ((1ull << (4 * cnt)) - 1ull));
-        return r != 0ull ? (__ffsll((long long)r) - 1) >> 2 : cnt;
+        const unsigned long long r = (~m >> (LPP * g0)) & (cnt * LPP >= 64 ? ~0ull : ((1ull << (LPP * cnt)) - 1ull));
+        return r != 0ull ? (__ffsll((long long)r) - 1) / LPP : cnt;
     };
     int x = 0;
     bool running = false;
@@ -748,7 +752,7 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
         }
         // ---- one evaluation for the whole wave
         const int pi = cg.pi0 + (act ? px : 0) * cg.stride;
-        const float c = cost_split4_lean<NMAX>(I, K, pi % I.w, pi / I.w, v, sub);
+        const float c = cost_split_lean<NMAX, LPP>(I, K, pi % I.w, pi / I.w, v, sub);
         const float c0p = __shfl(c0, min(max(px, 0), HALF - 1), HALF);
         const bool acc = act && c < c0p;
         const unsigned long long accm = (__ballot(acc) & hmask) >> hshift;
@@ -1174,10 +1178,11 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                 if (!STRICT && p.local_prop_width <= 65 && !g_local_serial.load(std::memory_order_relaxed)) {  // chains of <= 64 steps: table + one wave per chain
                     hipLaunchKernelGGL(k_local_table_lean<NMAX>, gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
                     const int nchains = lines * nseg;
+                    constexpr int LR_LPP = NMAX <= 8 ? 4 : 8;  // lanes per pixel of a run evaluation (cost_split_lean)
                     if (p.local_prop_width <= 33)  // chains of <= 32 steps: two per wave
-                        hipLaunchKernelGGL((k_local_runs_lean<32, NMAX>), dim3((nchains + 1) / 2), dim3(64), 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>(), lines, nchains);
+                        hipLaunchKernelGGL((k_local_runs_lean<32, NMAX, LR_LPP>), dim3((nchains + 1) / 2), dim3(64), 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>(), lines, nchains);
                     else
-                        hipLaunchKernelGGL((k_local_runs_lean<64, NMAX>), dim3(nchains), dim3(64), 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>(), lines, nchains);
+                        hipLaunchKernelGGL((k_local_runs_lean<64, NMAX, LR_LPP>), dim3(nchains), dim3(64), 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>(), lines, nchains);
                 } else
                     hipLaunchKernelGGL((k_local_serial<NMAX, STRICT>), dim3((lines + 63) / 64, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
             }
