@@ -23,6 +23,8 @@ int Context::init(int dev) {
     VK_CHECK(hipEventCreate(&ev3));
     VK_CHECK(hipEventCreateWithFlags(&ev_cams, hipEventDisableTiming));
     VK_CHECK(hipHostMalloc((void**)&h_cams, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
+    VK_CHECK(hipHostMalloc((void**)&h_brief, sizeof(CamBrief) * MAX_FRAMES, hipHostMallocMapped));
+    VK_CHECK(hipHostGetDevicePointer((void**)&h_brief_dev, h_brief, 0));
     return 0;
 }
 void Context::destroy() {
@@ -37,7 +39,8 @@ void Context::destroy() {
     if (ev3) (void)hipEventDestroy(ev3);
     if (ev_cams) (void)hipEventDestroy(ev_cams);
     if (h_cams) (void)hipHostFree(h_cams);
-    h_cams = nullptr;
+    if (h_brief) (void)hipHostFree(h_brief);
+    h_cams = nullptr; h_brief = h_brief_dev = nullptr;
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr; ev0 = ev1 = ev2 = ev3 = ev_cams = nullptr;
     od.pose_init = cp.pose_init = false;

@@ -74,6 +74,11 @@ struct CamState {
     int pad;
 };
 
+// What the host needs from a camera record to take the truncation decision of voldor.cpp:171-194 (and to print it): the kernel that
+// finishes the last camera of an EM iteration stores these straight into pinned host memory (no copy command between the pose
+// half and the depth half).
+struct CamBrief { int success, pose_sample_count, last_used_ms_iters, last_used_gu_iters; float pose_density, pose_rigidness_density; };
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -166,6 +171,8 @@ struct Context {
     std::map<std::string, ProfEntry> prof_acc;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // outer / inner scope
     hipEvent_t ev_cams = nullptr;  // "camera records of this EM iteration are on the host"
+    CamBrief* h_brief = nullptr;   // pinned, written by the device (CamBrief above); h_brief_dev = its device address
+    CamBrief* h_brief_dev = nullptr;
     CamState* h_cams = nullptr;    // pinned staging for that copy (a pageable destination would make the copy synchronous)
     int ensure_n_points() { return n_points.reserve(sizeof(int) * 4); }
     int init(int dev);

@@ -13,6 +13,7 @@ struct ModeParams {
     // > 0 on the LAST camera of an EM iteration: the kernel that finishes it also takes the truncation decision for the
     // decide_n cameras (voldor.cpp:171-194 -> PoseBlock::n_active) instead of a separate one-thread launch
     int decide_n = 0, decide_allow_trunc = 0; float decide_trunc_rigidness_density = 0.f, decide_trunc_sample_density = 0.f;
+    CamBrief* host_brief = nullptr;  // with decide_n: pinned host records the same thread fills for the host's copy of the decision
 };
 
 #ifdef __HIPCC__
@@ -30,8 +31,16 @@ __device__ __forceinline__ void decide_active(PoseBlock* P, const CamState* cams
     P->n_active = n;
 }
 __device__ __forceinline__ void maybe_decide(const ModeParams& mp, PoseBlock* P, const CamState* cam, int cam_idx) {
-    if (mp.decide_n > 0)
-        decide_active(P, cam - cam_idx, mp.decide_n, mp.decide_allow_trunc, mp.decide_trunc_rigidness_density, mp.decide_trunc_sample_density);
+    if (mp.decide_n > 0) {
+        const CamState* cams = cam - cam_idx;
+        decide_active(P, cams, mp.decide_n, mp.decide_allow_trunc, mp.decide_trunc_rigidness_density, mp.decide_trunc_sample_density);
+        if (mp.host_brief) {
+            for (int i = 0; i < mp.decide_n; i++)
+                mp.host_brief[i] = { cams[i].success, cams[i].pose_sample_count, cams[i].last_used_ms_iters, cams[i].last_used_gu_iters,
+                                     cams[i].pose_density, cams[i].pose_rigidness_density };
+            __threadfence_system();
+        }
+    }
 }
 #endif
 

@@ -183,12 +183,12 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
         // number of valid correspondences = sum of k_collect's per-workgroup counts; every wave adds them up itself
         // (a few coalesced loads) instead of a separate single-workgroup launch between collect and solve
         int part = 0;
-        for (int i0 = 0; i0 < nblk; i0 += 64 * 8) {  // 8 independent loads in flight per lane
-            int v[8];
+        for (int i0 = 0; i0 < nblk; i0 += 64 * 32) {  // 32 independent loads in flight per lane: one round trip up to 2048 blocks (1080p: 8100)
+            int v[32];
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const int i = i0 + u * 64 + (int)threadIdx.x; v[u] = i < nblk ? blk_counts[i] : 0; }
+            for (int u = 0; u < 32; u++) { const int i = i0 + u * 64 + (int)threadIdx.x; v[u] = i < nblk ? blk_counts[i] : 0; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) part += v[u];
+            for (int u = 0; u < 32; u++) part += v[u];
         }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);

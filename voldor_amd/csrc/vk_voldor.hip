@@ -209,6 +209,7 @@ struct Voldor {
         if (last) {  // the kernel that finishes the last camera also takes the truncation decision (PoseBlock::n_active)
             mp.decide_n = n_flows; mp.decide_allow_trunc = iters_cur > cfg.no_trunc_iters ? 1 : 0;
             mp.decide_trunc_rigidness_density = cfg.trunc_rigidness_density; mp.decide_trunc_sample_density = cfg.trunc_sample_density;
+            mp.host_brief = c->h_brief_dev;
         }
         if (strict) { if (int e = pose_mode_strict_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e; }
         else if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e;
@@ -228,15 +229,19 @@ struct Voldor {
         for (int i = 0; i < n_flows; i++)
             if (int e = optimize_camera_pose(i, rg, i == n_flows - 1)) return e;
         (void)allow_trunc;
-        // rigidness densities (reduced on the device by the last optimize_depth, voldor.cpp:171) and results
-        VK_CHECK(hipMemcpyAsync(c->h_cams, c->cams.p, sizeof(CamState) * n_flows, hipMemcpyDeviceToHost, c->stream));
+        // rigidness densities (reduced on the device by the last optimize_depth, voldor.cpp:171) and results: the last camera's kernel
+        // has stored what the host needs into pinned memory (CamBrief); the event marks it complete
         VK_CHECK(hipEventRecord(c->ev_cams, c->stream));
         return 0;
     }
     int finish_cameras() {
         const bool allow_trunc = iters_cur > cfg.no_trunc_iters;
         VK_CHECK(hipEventSynchronize(c->ev_cams));
-        memcpy(hcams, c->h_cams, sizeof(CamState) * n_flows);
+        for (int i = 0; i < n_flows; i++) {
+            const CamBrief& b = c->h_brief[i];
+            hcams[i].success = b.success; hcams[i].pose_sample_count = b.pose_sample_count; hcams[i].last_used_ms_iters = b.last_used_ms_iters;
+            hcams[i].last_used_gu_iters = b.last_used_gu_iters; hcams[i].pose_density = b.pose_density; hcams[i].pose_rigidness_density = b.pose_rigidness_density;
+        }
         for (int i = 0; i < n_flows; i++) {
             int ok = 0;
             if (!allow_trunc || hcams[i].pose_rigidness_density > cfg.trunc_rigidness_density) ok = hcams[i].success;
