@@ -296,14 +296,24 @@ __global__ __launch_bounds__(64) static void k_boot_hyp(const float* __restrict_
     for (int k = 0; k < 9; k++) Es[(size_t)hy * 9 + k] = E[k];
 }
 
-// one workgroup per hypothesis: squared Sampson distances of the scoring subset, bitonic sort, median
+// one workgroup per hypothesis: squared Sampson distances of the scoring subset and their median = the element of rank ns / 2 in
+// ascending order (what a full sort would leave at s[ns / 2]).  The distances are >= 0 (NaN counted as +inf), so their bit patterns
+// order like the values: a most-significant-digit-first radix SELECT finds that element in 8 passes of 8 bits over values that stay in
+// registers -- a histogram of the still-matching candidates, a scan to the bin that holds the rank -- instead of a 66-step bitonic
+// sort of 2048 doubles in LDS.
 __global__ __launch_bounds__(256) static void k_boot_score(const float* __restrict__ p2, BootGeom g, const double* __restrict__ Es,
                                                             double* __restrict__ med) {
-    __shared__ double s[BOOT_SCORE_MAX];
-    const int hy = blockIdx.x, tid = threadIdx.x;
+    constexpr int PER = BOOT_SCORE_MAX / 256;
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_wave[4];
+    __shared__ unsigned s_bin, s_rank;
+    const int hy = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double E[9];
     for (int k = 0; k < 9; k++) E[k] = Es[(size_t)hy * 9 + k];
-    for (int j = tid; j < BOOT_SCORE_MAX; j += 256) {
+    unsigned long long key[PER];
+#pragma unroll
+    for (int u = 0; u < PER; u++) {
+        const int j = tid + u * 256;
         double v = INFINITY;  // padding sorts to the end; NaN distances are ordered as +inf as well
         if (j < g.ns) {
             double q1[2], q2[2];
@@ -311,22 +321,35 @@ __global__ __launch_bounds__(256) static void k_boot_score(const float* __restri
             v = boot_sampson(E, q1, q2);
             if (!(v == v)) v = INFINITY;
         }
-        s[j] = v;
+        key[u] = (unsigned long long)__double_as_longlong(v);
     }
-    __syncthreads();
-    for (int k = 2; k <= BOOT_SCORE_MAX; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < BOOT_SCORE_MAX; i += 256) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const double a = s[i], b = s[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { s[i] = b; s[ixj] = a; }
-                }
-            }
-            __syncthreads();
-        }
-    if (tid == 0) med[hy] = s[g.ns / 2];
+    unsigned long long prefix = 0ull, mask = 0ull;
+    unsigned rank = (unsigned)(g.ns / 2);  // rank among the candidates that match `prefix` under `mask`
+#pragma unroll 1
+    for (int shift = 56; shift >= 0; shift -= 8) {
+        hist[tid] = 0u;
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if ((key[u] & mask) == prefix) atomicAdd(&hist[(unsigned)(key[u] >> shift) & 255u], 1u);
+        __syncthreads();
+        // inclusive scan of the 256 bins (thread = bin); the bin whose range contains `rank` is the next digit
+        const unsigned mine = hist[tid];
+        unsigned incl = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        unsigned base = 0u;
+        for (int k = 0; k < wv; k++) base += s_wave[k];
+        incl += base;
+        if (rank < incl && rank >= incl - mine) { s_bin = (unsigned)tid; s_rank = rank - (incl - mine); }  // exactly one bin
+        __syncthreads();
+        prefix |= (unsigned long long)s_bin << shift;
+        mask |= 0xffull << shift;
+        rank = s_rank;
+    }
+    if (tid == 0) med[hy] = __longlong_as_double((long long)prefix);
 }
 
 // argmin over hypotheses, decomposition, cheirality vote, pose write-back (single workgroup)
@@ -335,10 +358,28 @@ __global__ __launch_bounds__(256) static void k_boot_select(const float* __restr
     __shared__ double sRc[2][9], stc[3];
     __shared__ int s_cnt[4][4];
     const int tid = threadIdx.x;
+    // first strict minimum of the medians (hypothesis 0 if none is below +inf): every thread takes one, ties go to the lower index
+    __shared__ double s_bm[4];
+    __shared__ int s_bi[4];
+    {
+        static_assert(BOOT_HYPS == 256, "one hypothesis per thread");
+        double bm = med[tid];
+        int bi = tid;
+        if (!(bm < INFINITY)) { bm = INFINITY; bi = BOOT_HYPS; }  // never "below": loses against everything, like the sequential scan
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double om = __shfl_xor(bm, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
+            if (om < bm || (om == bm && oi < bi)) { bm = om; bi = oi; }
+        }
+        if ((tid & 63) == 0) { s_bm[tid >> 6] = bm; s_bi[tid >> 6] = bi; }
+    }
+    __syncthreads();
     if (tid == 0) {
-        int best = 0;
+        int best = BOOT_HYPS;
         double bm = INFINITY;
-        for (int hy = 0; hy < BOOT_HYPS; hy++) if (med[hy] < bm) { bm = med[hy]; best = hy; }  // first strict minimum
+        for (int k = 0; k < 4; k++) if (s_bm[k] < bm || (s_bm[k] == bm && s_bi[k] < best)) { bm = s_bm[k]; best = s_bi[k]; }
+        if (best >= BOOT_HYPS) best = 0;
         double E[9], Rc[2][9], tc[3];
         for (int k = 0; k < 9; k++) E[k] = Es[(size_t)best * 9 + k];
         boot_decompose(E, Rc, tc);

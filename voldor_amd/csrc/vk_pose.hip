@@ -698,7 +698,7 @@ __device__ static bool robust_gaussian_block(const float* __restrict__ space, in
     bool reliable = true;
     for (iter = 0; iter < mp.rg_max_iters; iter++) {
         if (tid < 64) {
-            // 6-D (poses): the LDS variant, the same code k_pose_refit runs; other dimensions: the register variant
+            // 6-D (poses): the LDS variant, the same code refit_block runs; other dimensions: the register variant
             const bool ok = dims == 6 ? rg_prepare_lds(covar_half, cinv_half, mp.rg_covar_reg_lambda, iter > 0 && mp.rg_covar_reg_lambda > 0.f, s_lu, iter > 0)
                                       : rg_prepare_wave(covar_half, cinv_half, dims, iter > 0 && mp.rg_covar_reg_lambda > 0.f, mp.rg_covar_reg_lambda);
             if (tid == 0) s_flag = ok ? 0 : 2;
@@ -813,8 +813,8 @@ __device__ __forceinline__ void finalize_pose(const float* mean6 /*scaled space*
     }
 }
 
-// mean-shift stage. DEFER=false: also finalises the pose. DEFER=true (robust-Gaussian refit follows,
-// geometry.cpp:201): leaves {mean[6], confidence, iters, used} in `handoff` for k_pose_refit.
+// mean-shift stage. DEFER=false: finalises the pose. DEFER=true (last EM iteration, geometry.cpp:201): the robust-Gaussian refit
+// (refit_block) runs on the same registers and finalises.
 //
 // One compute unit does all of it, and its passes over the pool are VALU-issue bound (16 waves on 4 SIMDs), so the pool is
 // held as PAIRS of hypotheses per lane and the arithmetic is written on float2: gfx950 issues v_pk_{add,mul,fma}_f32 at the
@@ -833,12 +833,151 @@ constexpr float MS_FAR = 1e18f;
 #define VK_MS_TRIAL_BATCH 5
 #endif
 constexpr int MS_TRIAL_BATCH = VK_MS_TRIAL_BATCH;  // initial-mode trials evaluated per pass (meanshift.cu:72-95 runs them one at a time)
+// robust-Gaussian refit + finalisation (geometry.cpp:201-263, fit_robust_gaussian.cu:131-263); runs
+// on the last EM iteration only, ~30-50 gate/refit iterations per camera, each of them three dependent phases on ONE
+// compute unit: the fp64 inverse of the 6x6 covariance (one wave), the gate + moment pass over the pool (VALU-issue bound),
+// a 28-value all-reduce.  The 8192 scaled hypotheses stay in registers for the whole loop as pairs (two per lane, packed
+// fp32 arithmetic as in k_pose_mode); 512 threads, because everything that is not the pass is executed by every wave.  The gate
+// weight multiplies instead of branching (a wave practically always holds a gated sample).  Wave 0 turns the totals into the
+// new mean / covariance and inverts it right away, so an iteration has two workgroup barriers.
+// It continues k_pose_mode<true> in the same kernel: the pool is already in registers (scaled for the mean-shift metric, non-finite
+// hypotheses as MS_FAR: their Mahalanobis distance is huge, infinite or NaN, never inside the gate, and 0 * MS_FAR = 0 in the sums).
+// ms_mean / ms_conf / ms_iters / used: the mean-shift result, the same in every thread.
+template <int THREADS>
+__device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], int used, const float (&ms_mean)[6], float ms_conf, int ms_iters,
+                                            const ModeParams& mp, CamState* cam, PoseBlock* P, int cam_idx, RedBuf& rb) {
+#pragma clang fp contract(fast)  // the gate / scatter sums are not part of the solver's exact-rounding contract
+    constexpr int RF_PAIRS = PM_POOL / THREADS / 2, RF_NW = THREADS / 64;
+    __shared__ float s_cinv[21], s_cov[21], s_mean[6];
+    __shared__ int s_flag;
+    __shared__ double s_lu[108];
+    PH_DECL;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float sc = mp.rg_pose_scaling;
+    // x = [rvec * rvec_scale | t] * rg_pose_scaling (geometry.cpp:191,211)
+#pragma unroll
+    for (int p = 0; p < RF_PAIRS; p++)
+#pragma unroll
+        for (int d = 0; d < 6; d++) X[p][d] *= f2{ sc, sc };
+    if (tid < 21) s_cov[tid] = 0.f;
+    if (tid < 6) s_mean[tid] = ms_mean[tid] * sc;
+    __syncthreads();
+    if (tid < 6) s_cov[(tid * tid + tid) / 2 + tid] = mp.kernel_var * (sc * sc);  // :203-206
+    __syncthreads();
+    const bool regularise = mp.rg_covar_reg_lambda > 0.f;
+    if (wv == 0) {  // inverse for iteration 0 (not regularised, fit_robust_gaussian.cu:180)
+        const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, false, s_lu, false);
+        if (lane == 0) s_flag = ok ? 0 : 2;
+    }
+    __syncthreads();
+    const float sig2 = mp.rg_trunc_sigma * mp.rg_trunc_sigma;
+    float weight = 0.f;
+    int iter = 0, parity = 0;
+    bool reliable = true;
+    PH_MARK(24);
+    for (iter = 0; iter < mp.rg_max_iters; iter++) {
+        if (s_flag == 2) { reliable = false; break; }
+        const float prev_density = weight / (float)used;
+        float cs[21], mean[6];
+#pragma unroll
+        for (int d1 = 0; d1 < 6; d1++)
+#pragma unroll
+            for (int d2 = 0; d2 <= d1; d2++) cs[(d1 * d1 + d1) / 2 + d2] = (d1 == d2 ? 1.f : 2.f) * s_cinv[(d1 * d1 + d1) / 2 + d2];
+#pragma unroll
+        for (int d = 0; d < 6; d++) mean[d] = s_mean[d];
+        // e_step (fit_robust_gaussian.cu:56-97): gate, weight, weighted sample and weighted scatter about
+        // the CURRENT mean in one pass -> one 28-value all-reduce per iteration
+        f2 acc2[28];
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc2[k] = f2{ 0.f, 0.f };
+#pragma unroll
+        for (int p = 0; p < RF_PAIRS; p++) {
+            f2 diff[6];
+#pragma unroll
+            for (int d = 0; d < 6; d++) diff[d] = X[p][d] - f2{ mean[d], mean[d] };
+            // z = d^T C d over the lower triangle (off-diagonal coefficients doubled in cs): 27 multiply-adds, not 42
+            f2 z = { 0.f, 0.f };
+#pragma unroll
+            for (int d1 = 0; d1 < 6; d1++) {
+                f2 tmp = diff[d1] * cs[(d1 * d1 + d1) / 2 + d1];
+#pragma unroll
+                for (int d2 = 0; d2 < d1; d2++) tmp += diff[d2] * cs[(d1 * d1 + d1) / 2 + d2];
+                z += tmp * diff[d1];
+            }
+            // sqrt(z) < sigma (fit_robust_gaussian.cu:80) as 0 <= z < sigma^2: a negative or NaN form stays outside
+            const f2 wgt = { (z.x >= 0.f && z.x < sig2) ? 1.f : 0.f, (z.y >= 0.f && z.y < sig2) ? 1.f : 0.f };
+            acc2[0] += wgt;
+#pragma unroll
+            for (int d = 0; d < 6; d++) acc2[1 + d] += wgt * X[p][d];
+            f2 wd[6];
+#pragma unroll
+            for (int d = 0; d < 6; d++) wd[d] = wgt * diff[d];
+#pragma unroll
+            for (int d1 = 0; d1 < 6; d1++)
+#pragma unroll
+                for (int d2 = 0; d2 <= d1; d2++) acc2[7 + (d1 * d1 + d1) / 2 + d2] += wd[d1] * diff[d2];
+        }
+        float acc[28];
+#pragma unroll
+        for (int k = 0; k < 28; k++) acc[k] = acc2[k].x + acc2[k].y;
+#ifdef VK_PHASE_CLOCKS
+        if (acc[0] == -123456.f) return;
+#endif
+        PH_MARK(26);
+        const float tot = allreduce_lanes<28, RF_NW>(acc, rb, parity); parity ^= 1;  // lane k of every wave: total of sum k
+        weight = lane_value(tot, 0);
+        if (!isfinite(weight)) { reliable = false; break; }
+        if (fabsf(weight / (float)used - prev_density) < mp.rg_epsilon) { reliable = true; break; }
+        PH_MARK(27);
+        if (wv == 0) {
+            // M-step (:234-246): mean and covariance of the gated set (no -1: it is regularised next), one division per lane where
+            // the totals sit, and -- unless this was the last iteration -- the regularised inverse of the next one
+            if (lane >= 1 && lane < 28) {
+                const float q = tot / weight;
+                if (lane < 7) s_mean[lane - 1] = q; else s_cov[lane - 7] = q;  // the other waves read both before the all-reduce barrier
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (iter + 1 < mp.rg_max_iters) {
+                const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, regularise, s_lu, true);
+                if (lane == 0) s_flag = ok ? 0 : 2;
+            }
+        }
+        __syncthreads();
+        PH_MARK(25);
+    }
+    __syncthreads();
+    PH_MARK(27); PH_ADD(28, iter); PH_ADD(29, 1);
+    if (tid == 0) {
+        float mean6[6];
+        float density = ms_conf;
+        int gu_iters = 0;  // fit_robust_gaussian.cu:158-159 resets *used_iters on entry
+        if (reliable) {
+            density = weight / (float)used; gu_iters = iter;
+            for (int i1 = 0; i1 < 6; i1++)
+                for (int i2 = 0; i2 < 6; i2++) {
+                    const int hi = i1 >= i2 ? i1 : i2, lo = i1 >= i2 ? i2 : i1;
+                    float c = s_cov[(hi * hi + hi) / 2 + lo] / (sc * sc);  // :224-233
+                    if (i1 < 3 || i2 < 3) c /= mp.rvec_scale;
+                    if (i1 < 3 && i2 < 3) c /= mp.rvec_scale;
+                    cam->covar[i1 * 6 + i2] = c;
+                }
+            for (int d = 0; d < 6; d++) mean6[d] = s_mean[d] / sc;
+        } else {
+            for (int k = 0; k < 36; k++) cam->covar[k] = 0.f;
+            for (int d = 0; d < 6; d++) mean6[d] = (ms_mean[d] * sc) / sc;  // pose_opm *= sc; /= sc (:210,:238)
+        }
+        finalize_pose(mean6, mp.rvec_scale, used, density, ms_iters, gu_iters, cam, P, cam_idx);
+        maybe_decide(mp, P, cam, cam_idx);
+    }
+    PH_MARK(30);
+}
+
 // THREADS: the per-iteration all-reduce, the mean update and the convergence test are executed by every wave (~100 instructions next
 // to ~30 per pair of hypotheses), so fewer, fatter waves do less redundant work: THREADS * SPT = PM_POOL.
 template <bool DEFER, int THREADS>
 __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
                                                                   int n_poses, ModeParams mp, CamState* cam, PoseBlock* P, int cam_idx,
-                                                                  const int* __restrict__ n_points_dev, float* __restrict__ handoff) {
+                                                                  const int* __restrict__ n_points_dev) {
 #pragma clang fp contract(fast)  // kernel-weighted sums: not part of the solver's exact-rounding contract (file-wide: off)
     constexpr int SPT = PM_POOL / THREADS, MS_PAIRS = SPT / 2, NW = THREADS / 64;
     __shared__ RedBuf rb;
@@ -849,7 +988,7 @@ __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __res
     // successive pose? (voldor.cpp:177: pose_sample_count != 0), decided on the device
     const bool external_init = mp.use_external_init_mean < 0 ? (cam->pose_sample_count != 0) : (mp.use_external_init_mean != 0);
     if (*n_points_dev < 4) {  // geometry.cpp:84-88
-        if (tid == 0) { cam->success = 0; if (DEFER) handoff[8] = 0.f; else maybe_decide(mp, P, cam, cam_idx); }
+        if (tid == 0) { cam->success = 0; maybe_decide(mp, P, cam, cam_idx); }
         return;
     }
     // ---- pool -> registers (coordinate planes [3][n_poses] written by k_solve: every load of a wave is one 256-byte run);
@@ -887,7 +1026,7 @@ __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __res
 #pragma unroll
         for (int j = 0; j < NW; j++) used += s_cnt[k][j];
     if (used == 0) {
-        if (tid == 0) { cam->success = 0; if (DEFER) handoff[8] = 0.f; else maybe_decide(mp, P, cam, cam_idx); }
+        if (tid == 0) { cam->success = 0; maybe_decide(mp, P, cam, cam_idx); }
         return;
     }
     PH_MARK(16);
@@ -1031,189 +1170,16 @@ __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __res
         PH_MARK(33);
     }
     PH_MARK(33); PH_ADD(19, ms_iters); PH_ADD(20, 1);
-    if (tid == 0) {
-        if (DEFER) {
-            for (int d = 0; d < 6; d++) handoff[d] = io_mean[d];
-            handoff[6] = conf; handoff[7] = (float)ms_iters; handoff[8] = (float)used;
-        } else {
-            finalize_pose(io_mean, mp.rvec_scale, used, conf, ms_iters, cam->last_used_gu_iters, cam, P, cam_idx);
-            PH_MARK(21);
-            maybe_decide(mp, P, cam, cam_idx);
-        }
-    }
-    PH_MARK(22);
-}
-
-// robust-Gaussian refit + finalisation (geometry.cpp:201-263, fit_robust_gaussian.cu:131-263); runs
-// on the last EM iteration only, ~30-50 gate/refit iterations per camera, each of them three dependent phases on ONE
-// compute unit: the fp64 inverse of the 6x6 covariance (one wave), the gate + moment pass over the pool (VALU-issue bound),
-// a 28-value all-reduce.  The 8192 scaled hypotheses stay in registers for the whole loop as pairs (two per lane, packed
-// fp32 arithmetic as in k_pose_mode); 512 threads, because everything that is not the pass is executed by every wave.  The gate
-// weight multiplies instead of branching (a wave practically always holds a gated sample).  Wave 0 turns the totals into the
-// new mean / covariance and inverts it right away, so an iteration has two workgroup barriers.
-constexpr int RF_THREADS = 512, RF_SPT = PM_POOL / RF_THREADS, RF_PAIRS = RF_SPT / 2, RF_NW = RF_THREADS / 64;
-__global__ __launch_bounds__(RF_THREADS) static void k_pose_refit(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
-                                                                   int n_poses, ModeParams mp, CamState* cam, PoseBlock* P, int cam_idx,
-                                                                   const float* __restrict__ handoff) {
-#pragma clang fp contract(fast)  // the gate / scatter sums are not part of the solver's exact-rounding contract
-    __shared__ RedBuf rb;
-    __shared__ int s_cnt[RF_NW];
-    __shared__ float s_cinv[21], s_cov[21], s_mean[6];
-    __shared__ int s_flag;
-    __shared__ double s_lu[108];
-    PH_DECL;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (handoff[8] == 0.f) {  // the mean-shift stage already reported failure
-        if (tid == 0) maybe_decide(mp, P, cam, cam_idx);
+    if (DEFER) {  // robust-Gaussian refit on the same registers (geometry.cpp:201-263), which finalises the pose itself
+        refit_block<THREADS>(X, used, io_mean, conf, ms_iters, mp, cam, P, cam_idx, rb);
         return;
     }
-    const float sc = mp.rg_pose_scaling;
-    // stage: x = [rvec * rvec_scale | t] * rg_pose_scaling (geometry.cpp:191,211); a non-finite hypothesis becomes MS_FAR in every
-    // coordinate: its Mahalanobis distance is huge, infinite or NaN, never inside the gate, and 0 * MS_FAR = 0 in the sums
-    f2 X[RF_PAIRS][6];
-#pragma unroll
-    for (int k = 0; k < RF_SPT; k++) {
-        const int i = min(k * RF_THREADS + tid, n_poses - 1);
-#pragma unroll
-        for (int d = 0; d < 6; d++) {
-            const float v = d < 3 ? rvecs[(size_t)d * n_poses + i] : tvecs[(size_t)(d - 3) * n_poses + i];  // planes [3][n_poses]
-            if (k & 1) X[k >> 1][d].y = v; else X[k >> 1][d].x = v;
-        }
-    }
-    int mycnt = 0;
-#pragma unroll
-    for (int k = 0; k < RF_SPT; k++) {
-        float v[6];
-#pragma unroll
-        for (int d = 0; d < 6; d++) v[d] = (k & 1) ? X[k >> 1][d].y : X[k >> 1][d].x;
-        const bool fin = k * RF_THREADS + tid < n_poses && isfinite(v[0] + v[1] + v[2] + v[3] + v[4] + v[5]);
-        mycnt += fin ? 1 : 0;
-#pragma unroll
-        for (int d = 0; d < 6; d++) {
-            const float u = fin ? (d < 3 ? (v[d] * mp.rvec_scale) * sc : v[d] * sc) : MS_FAR;
-            if (k & 1) X[k >> 1][d].y = u; else X[k >> 1][d].x = u;
-        }
-    }
-    {
-        int c = mycnt;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-        if (lane == 0) s_cnt[wv] = c;
-    }
-    if (tid < 21) s_cov[tid] = 0.f;
-    if (tid < 6) s_mean[tid] = handoff[tid] * sc;
-    __syncthreads();
-    int used = 0;
-#pragma unroll
-    for (int j = 0; j < RF_NW; j++) used += s_cnt[j];
-    if (tid < 6) s_cov[(tid * tid + tid) / 2 + tid] = mp.kernel_var * (sc * sc);  // :203-206
-    __syncthreads();
-    const bool regularise = mp.rg_covar_reg_lambda > 0.f;
-    if (wv == 0) {  // inverse for iteration 0 (not regularised, fit_robust_gaussian.cu:180)
-        const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, false, s_lu, false);
-        if (lane == 0) s_flag = ok ? 0 : 2;
-    }
-    __syncthreads();
-    const float sig2 = mp.rg_trunc_sigma * mp.rg_trunc_sigma;
-    float weight = 0.f;
-    int iter = 0, parity = 0;
-    bool reliable = true;
-    PH_MARK(24);
-    for (iter = 0; iter < mp.rg_max_iters; iter++) {
-        if (s_flag == 2) { reliable = false; break; }
-        const float prev_density = weight / (float)used;
-        float cs[21], mean[6];
-#pragma unroll
-        for (int d1 = 0; d1 < 6; d1++)
-#pragma unroll
-            for (int d2 = 0; d2 <= d1; d2++) cs[(d1 * d1 + d1) / 2 + d2] = (d1 == d2 ? 1.f : 2.f) * s_cinv[(d1 * d1 + d1) / 2 + d2];
-#pragma unroll
-        for (int d = 0; d < 6; d++) mean[d] = s_mean[d];
-        // e_step (fit_robust_gaussian.cu:56-97): gate, weight, weighted sample and weighted scatter about
-        // the CURRENT mean in one pass -> one 28-value all-reduce per iteration
-        f2 acc2[28];
-#pragma unroll
-        for (int k = 0; k < 28; k++) acc2[k] = f2{ 0.f, 0.f };
-#pragma unroll
-        for (int p = 0; p < RF_PAIRS; p++) {
-            f2 diff[6];
-#pragma unroll
-            for (int d = 0; d < 6; d++) diff[d] = X[p][d] - f2{ mean[d], mean[d] };
-            // z = d^T C d over the lower triangle (off-diagonal coefficients doubled in cs): 27 multiply-adds, not 42
-            f2 z = { 0.f, 0.f };
-#pragma unroll
-            for (int d1 = 0; d1 < 6; d1++) {
-                f2 tmp = diff[d1] * cs[(d1 * d1 + d1) / 2 + d1];
-#pragma unroll
-                for (int d2 = 0; d2 < d1; d2++) tmp += diff[d2] * cs[(d1 * d1 + d1) / 2 + d2];
-                z += tmp * diff[d1];
-            }
-            // sqrt(z) < sigma (fit_robust_gaussian.cu:80) as 0 <= z < sigma^2: a negative or NaN form stays outside
-            const f2 wgt = { (z.x >= 0.f && z.x < sig2) ? 1.f : 0.f, (z.y >= 0.f && z.y < sig2) ? 1.f : 0.f };
-            acc2[0] += wgt;
-#pragma unroll
-            for (int d = 0; d < 6; d++) acc2[1 + d] += wgt * X[p][d];
-            f2 wd[6];
-#pragma unroll
-            for (int d = 0; d < 6; d++) wd[d] = wgt * diff[d];
-#pragma unroll
-            for (int d1 = 0; d1 < 6; d1++)
-#pragma unroll
-                for (int d2 = 0; d2 <= d1; d2++) acc2[7 + (d1 * d1 + d1) / 2 + d2] += wd[d1] * diff[d2];
-        }
-        float acc[28];
-#pragma unroll
-        for (int k = 0; k < 28; k++) acc[k] = acc2[k].x + acc2[k].y;
-#ifdef VK_PHASE_CLOCKS
-        if (acc[0] == -123456.f) return;
-#endif
-        PH_MARK(26);
-        const float tot = allreduce_lanes<28, RF_NW>(acc, rb, parity); parity ^= 1;  // lane k of every wave: total of sum k
-        weight = lane_value(tot, 0);
-        if (!isfinite(weight)) { reliable = false; break; }
-        if (fabsf(weight / (float)used - prev_density) < mp.rg_epsilon) { reliable = true; break; }
-        PH_MARK(27);
-        if (wv == 0) {
-            // M-step (:234-246): mean and covariance of the gated set (no -1: it is regularised next), one division per lane where
-            // the totals sit, and -- unless this was the last iteration -- the regularised inverse of the next one
-            if (lane >= 1 && lane < 28) {
-                const float q = tot / weight;
-                if (lane < 7) s_mean[lane - 1] = q; else s_cov[lane - 7] = q;  // the other waves read both before the all-reduce barrier
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (iter + 1 < mp.rg_max_iters) {
-                const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, regularise, s_lu, true);
-                if (lane == 0) s_flag = ok ? 0 : 2;
-            }
-        }
-        __syncthreads();
-        PH_MARK(25);
-    }
-    __syncthreads();
-    PH_MARK(27); PH_ADD(28, iter); PH_ADD(29, 1);
     if (tid == 0) {
-        float mean6[6];
-        float density = handoff[6];
-        int gu_iters = 0;  // fit_robust_gaussian.cu:158-159 resets *used_iters on entry
-        if (reliable) {
-            density = weight / (float)used; gu_iters = iter;
-            for (int i1 = 0; i1 < 6; i1++)
-                for (int i2 = 0; i2 < 6; i2++) {
-                    const int hi = i1 >= i2 ? i1 : i2, lo = i1 >= i2 ? i2 : i1;
-                    float c = s_cov[(hi * hi + hi) / 2 + lo] / (sc * sc);  // :224-233
-                    if (i1 < 3 || i2 < 3) c /= mp.rvec_scale;
-                    if (i1 < 3 && i2 < 3) c /= mp.rvec_scale;
-                    cam->covar[i1 * 6 + i2] = c;
-                }
-            for (int d = 0; d < 6; d++) mean6[d] = s_mean[d] / sc;
-        } else {
-            for (int k = 0; k < 36; k++) cam->covar[k] = 0.f;
-            for (int d = 0; d < 6; d++) mean6[d] = (handoff[d] * sc) / sc;  // pose_opm *= sc; /= sc (:210,:238)
-        }
-        finalize_pose(mean6, mp.rvec_scale, used, density, (int)handoff[7], gu_iters, cam, P, cam_idx);
+        finalize_pose(io_mean, mp.rvec_scale, used, conf, ms_iters, cam->last_used_gu_iters, cam, P, cam_idx);
+        PH_MARK(21);
         maybe_decide(mp, P, cam, cam_idx);
     }
-    PH_MARK(30);
+    PH_MARK(22);
 }
 
 // ---- stand-alone kernels behind the host-pointer API (B-inner) -------------------------------
@@ -1317,16 +1283,12 @@ int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* ca
                 PM_POOL);
         return (int)hipErrorInvalidValue;
     }
-    if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
-    float* handoff = c->ms_io.as<float>() + 32;
-    if (mp.do_rg) {
+    if (mp.do_rg)
         hipLaunchKernelGGL((k_pose_mode<true, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
-                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), handoff);
-        hipLaunchKernelGGL(k_pose_refit, dim3(1), dim3(RF_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp,
-                           cam_dev, P, cam_idx, handoff);
-    } else
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>());
+    else
         hipLaunchKernelGGL((k_pose_mode<false, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
-                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), handoff);
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>());
     VK_CHECK_LAST();
     return 0;
 }
