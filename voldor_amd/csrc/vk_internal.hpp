@@ -69,7 +69,7 @@ int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_de
 // index draw over the compacted list (geometry.cpp:68-88 + solve_batch_lambdatwist.cu:16-19); -1: rejection only (tests)
 int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev,
                            int draw = 0, bool strict = false);
-int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
+int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first = false);
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 

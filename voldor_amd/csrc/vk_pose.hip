@@ -977,7 +977,7 @@ __device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], i
 template <bool DEFER, int THREADS>
 __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
                                                                   int n_poses, ModeParams mp, CamState* cam, PoseBlock* P, int cam_idx,
-                                                                  const int* __restrict__ n_points_dev) {
+                                                                  const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
 #pragma clang fp contract(fast)  // kernel-weighted sums: not part of the solver's exact-rounding contract (file-wide: off)
     constexpr int SPT = PM_POOL / THREADS, MS_PAIRS = SPT / 2, NW = THREADS / 64;
     __shared__ RedBuf rb;
@@ -1044,6 +1044,18 @@ __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __res
         float best = 0.f;
         float bestx[6] = { 0, 0, 0, 0, 0, 0 };
         bool have = false;
+        if (trials_in) {  // the densities of the trial hypotheses were evaluated by k_mode_trials, one workgroup per trial: replay the rule
+            for (int t = 0; t < mp.ms_max_init_trials; t++) {
+                const float dens = trials_in[t * 8];
+                if (dens > best) {
+                    best = dens;
+#pragma unroll
+                    for (int d = 0; d < 6; d++) bestx[d] = trials_in[t * 8 + 1 + d];
+                    have = true;
+                }
+                if (best > mp.ms_good_init_confidence * (float)used) break;
+            }
+        } else {
         // rank of each of this thread's finite hypotheses in index order (slot-major, then thread), in registers for the
         // duration of the trials
         int rank[SPT];
@@ -1119,6 +1131,7 @@ __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __res
             }
             __syncthreads();  // s_pick is rewritten by the next batch
         }
+        }
         if (!have) {  // no trial had positive weight (the reference would index element -1)
 #pragma unroll
             for (int d = 0; d < 6; d++) bestx[d] = io_mean[d];
@@ -1180,6 +1193,93 @@ __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __res
         maybe_decide(mp, P, cam, cam_idx);
     }
     PH_MARK(22);
+}
+
+// The initial-mode trials of a camera that has no pose yet (first EM iteration; meanshift.cu:72-95: the kernel density at up to
+// max_init_trials random hypotheses, the densest one starts the mean shift) are independent of one another and each is a full pass
+// over the pool: inside the single-workgroup mode kernel they cost 20 passes on one compute unit (~33 us).  Here trial b is
+// workgroup b: same pool, same pick ((rng(b) % used)-th finite hypothesis in index order), density and hypothesis to
+// out[b][0..6]; k_pose_mode replays the sequential "better than the best so far / good enough, stop" rule on them.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) static void k_mode_trials(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses,
+                                                                 ModeParams mp, const int* __restrict__ n_points_dev, float* __restrict__ out) {
+#pragma clang fp contract(fast)
+    constexpr int SPT = PM_POOL / THREADS, MS_PAIRS = SPT / 2, NW = THREADS / 64;
+    __shared__ RedBuf rb;
+    __shared__ int s_cnt[SPT][NW];
+    __shared__ float s_pick[6];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, trial = blockIdx.x;
+    if (*n_points_dev < 4) return;
+    f2 X[MS_PAIRS][6];
+    unsigned finmask = 0;
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        const int i = min(k * THREADS + tid, n_poses - 1);
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            const float v = d < 3 ? rvecs[(size_t)d * n_poses + i] : tvecs[(size_t)(d - 3) * n_poses + i];
+            if (k & 1) X[k >> 1][d].y = v; else X[k >> 1][d].x = v;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        float v[6];
+#pragma unroll
+        for (int d = 0; d < 6; d++) v[d] = (k & 1) ? X[k >> 1][d].y : X[k >> 1][d].x;
+        const bool fin = k * THREADS + tid < n_poses && isfinite(v[0] + v[1] + v[2] + v[3] + v[4] + v[5]);
+        const unsigned long long b = __ballot(fin);
+        if (fin) finmask |= 1u << k;
+        if (lane == 0) s_cnt[k][wv] = __popcll(b);
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+            const float u = fin ? (d < 3 ? v[d] * mp.rvec_scale : v[d]) : MS_FAR;
+            if (k & 1) X[k >> 1][d].y = u; else X[k >> 1][d].x = u;
+        }
+    }
+    __syncthreads();
+    int used = 0;
+#pragma unroll
+    for (int k = 0; k < SPT; k++)
+#pragma unroll
+        for (int j = 0; j < NW; j++) used += s_cnt[k][j];
+    if (used == 0) return;
+    const int target = (int)(rng3(RAND_SEED, (uint32_t)trial, 0x4D53u) % (uint32_t)used);
+    {
+        int base = 0;
+#pragma unroll
+        for (int k = 0; k < SPT; k++) {
+            int wbase = base;
+#pragma unroll
+            for (int j = 0; j < NW; j++) { if (j < wv) wbase += s_cnt[k][j]; base += s_cnt[k][j]; }
+            const unsigned long long b = __ballot((finmask >> k) & 1u);
+            const int rank = ((finmask >> k) & 1u) ? wbase + __popcll(b & ((1ull << lane) - 1ull)) : -1;
+            if (rank == target) {
+#pragma unroll
+                for (int d = 0; d < 6; d++) s_pick[d] = (k & 1) ? X[k >> 1][d].y : X[k >> 1][d].x;
+            }
+        }
+    }
+    __syncthreads();
+    const float inv2v = 1.f / (2.f * mp.kernel_var);
+    const f2 ninv2v = { -inv2v, -inv2v };
+    f2 c[6];
+#pragma unroll
+    for (int d = 0; d < 6; d++) { const float v = s_pick[d]; c[d] = f2{ v, v }; }
+    f2 acc2 = { 0.f, 0.f };
+#pragma unroll
+    for (int p = 0; p < MS_PAIRS; p++) {
+        f2 l2 = { 0.f, 0.f };
+#pragma unroll
+        for (int d = 0; d < 6; d++) { const f2 df = X[p][d] - c[d]; l2 += df * df; }
+        const f2 a = l2 * ninv2v;
+        acc2 += f2{ __expf(a.x), __expf(a.y) };
+    }
+    float acc[1] = { acc2.x + acc2.y };
+    allreduce_regs<1, NW>(acc, rb, 0);
+    if (tid == 0) {
+        out[trial * 8] = acc[0];
+        for (int d = 0; d < 6; d++) out[trial * 8 + 1 + d] = s_pick[d];
+    }
 }
 
 // ---- stand-alone kernels behind the host-pointer API (B-inner) -------------------------------
@@ -1277,18 +1377,30 @@ int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, fl
                               solver, draw, strict);
 }
 
-int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx) {
+int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first) {
     if (n_poses > PM_POOL) {
         fprintf(stderr, "voldor_hip: n_poses_to_sample=%d exceeds the %d hypotheses the mode kernel keeps in registers\n", n_poses,
                 PM_POOL);
         return (int)hipErrorInvalidValue;
     }
+    // trials_first: the camera has no pose yet (the caller's copy of pose_sample_count is 0), so the mode kernel will look for a start
+    // among random hypotheses: those trials run as their own workgroups first.  (If the device record disagrees the mode kernel ignores
+    // them -- external start -- or, without them, runs the trials itself.)
+    constexpr int MAX_SPLIT_TRIALS = 64;
+    const float* trials = nullptr;
+    if (trials_first && mp.use_external_init_mean <= 0 && mp.ms_max_init_trials > 0 && mp.ms_max_init_trials <= MAX_SPLIT_TRIALS) {
+        if (int e = c->ms_io.reserve(sizeof(float) * (64 + 8 * MAX_SPLIT_TRIALS) + sizeof(int) * 4)) return e;
+        float* out = c->ms_io.as<float>() + 64;
+        hipLaunchKernelGGL((k_mode_trials<PM_THREADS>), dim3(mp.ms_max_init_trials), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(),
+                           c->tvecs.as<float>(), n_poses, mp, c->n_points.as<int>(), out);
+        trials = out;
+    }
     if (mp.do_rg)
         hipLaunchKernelGGL((k_pose_mode<true, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
-                           mp, cam_dev, P, cam_idx, c->n_points.as<int>());
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials);
     else
         hipLaunchKernelGGL((k_pose_mode<false, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
-                           mp, cam_dev, P, cam_idx, c->n_points.as<int>());
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials);
     VK_CHECK_LAST();
     return 0;
 }

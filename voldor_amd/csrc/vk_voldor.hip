@@ -212,7 +212,7 @@ struct Voldor {
             mp.host_brief = c->h_brief_dev;
         }
         if (strict) { if (int e = pose_mode_strict_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e; }
-        else if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e;
+        else if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i, hcams[i].pose_sample_count == 0)) return e;
         if (c->prof) prof_end(c, "optimize_camera_pose");
         return 0;
     }
