@@ -15,7 +15,7 @@ Extra objects in the line:
   roofline     dominant streaming kernel k_cost_rand_q (cost map + random depth samples): algorithmic bytes
                w*h*(12N+12N_dp+16) / average launch duration measured with HIP events on the library's stream
                (vk_profile_*), against the 8 TB/s HBM peak; `traffic` = PMC FETCH_SIZE/WRITE_SIZE bytes per
-               launch and `valu_issue_frac` from the raw SQ counters of the same kernel (profiles/r02c_pmc_*.json,
+               launch and `valu_issue_frac` from the raw SQ counters of the same kernel (profiles/r02h_pmc_*.json / r02c_pmc_*.json,
                scripts/pmc_traffic.sh, scripts/pmc_sq.sh).  The optimize_depth group (B_od = w*h*(40N+36N_dp+12),
                BASELINE.md §4) is reported next to it.
   host_inclusive  SURVEY.md §8(d)'s own definition of a frame: py_voldor_wrapper with the flows in pageable HOST memory
@@ -178,13 +178,19 @@ def main():
         kname = f"vk::k_cost_rand_q<{nmax}>"
         traffic = valu = None
         sqc = {}
+        def pmc_file(kind):  # the latest PMC pass of this workload that is committed (r02h: final tree; r02c: same kernel, earlier)
+            for tag in ("r02h", "r02c"):
+                f = os.path.join(ROOT, "profiles", f"{tag}_pmc_{kind}_{args.workload}.json")
+                if os.path.exists(f):
+                    return f
+            raise FileNotFoundError(kind)
         try:  # PMC passes of this workload (collected separately: rocprofv3 cannot time and count in one run)
-            ks = json.load(open(os.path.join(ROOT, "profiles", f"r02c_pmc_traffic_{args.workload}.json")))["kernels"]
+            ks = json.load(open(pmc_file("traffic")))["kernels"]
             traffic = ks[kname]["hbm_bytes_per_launch"]
         except Exception:
             pass
         try:
-            sqc = json.load(open(os.path.join(ROOT, "profiles", f"r02c_pmc_sq_{args.workload}.json")))[kname]
+            sqc = json.load(open(pmc_file("sq")))[kname]
             # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves (MI355X_MICROARCH.md): x4 = cycles some SIMD spent issuing VALU;
             # over 1024 SIMDs and the launch duration at the 2.4 GHz peak clock = the fraction of VALU issue slots used
             valu = sqc["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sqc["avg_us_under_pmc"] * 1e-6 * 2.4e9)
