@@ -126,6 +126,10 @@ int vk_get_strict_math(void);
  * optimize_depth.cu:320-396 order) instead of the table + speculative-run kernel; both must give identical maps
  * (tests/test_gpu_kernels.py::test_local_runs_equal_the_step_by_step_chain). */
 int vk_set_local_serial(int on);
+/* Verification aid: 0 = the mean-shift kernel evaluates the initial-mode trials of a camera without a pose itself (20 passes on one
+ * compute unit) instead of taking them from k_mode_trials (one workgroup per trial); same picks, same rule
+ * (tests/test_gpu_voldor.py::test_split_trials_equal_in_kernel_trials).  Default 1. */
+int vk_set_split_trials(int on);
 int vk_profile_enable(int on);           /* HIP-event timing of kernel groups on the library's stream */
 int vk_profile_get(const char* name, double* total_ms, long* count);
 int vk_device_count(void);

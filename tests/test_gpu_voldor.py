@@ -53,6 +53,28 @@ def test_mono_window_tight_with_identical_draws(orc, cfg, rot_tol, tr_tol):
     assert np.mean(rel < 1e-3) > 0.94  # tie-breaks of equal-cost depth candidates differ (module docstring)
 
 
+def test_split_trials_equal_in_kernel_trials():
+    """First EM iteration, cameras without a pose: the 20 initial-mode trials evaluated by k_mode_trials (one workgroup each) against
+    the same trials evaluated inside the mode kernel (vk_set_split_trials(0)).  Same picks, same better-than / good-enough rule; only
+    the summation order of a density differs, so the chosen start -- and with it every pose -- is the same unless two of the 20
+    densities tie to ~1e-7."""
+    from voldor_amd import pyvoldor, synth, kernels
+    sc = synth.make_scene(w=320, h=240, n_flows=5, fx=160, fy=160, cx=160, cy=120, seed=233)
+    fx, fy, cx, cy = sc["K"]
+    cfgs = "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 1 --rg_refine 0"
+    out = []
+    try:
+        for on in (True, False):
+            kernels.set_split_trials(on)
+            kernels.set_rand_epoch(0)
+            out.append(pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config=cfgs))
+    finally:
+        kernels.set_split_trials(True)
+    assert out[0]["n_registered"] == out[1]["n_registered"] == 5
+    assert pyvoldor.last_camera_stats(5)["ms_iters"] is not None
+    np.testing.assert_allclose(out[0]["poses"], out[1]["poses"], rtol=0, atol=2e-6)
+
+
 def test_mono_window_matches_oracle(orc):
     from voldor_amd import pyvoldor, synth, kernels
     sc = synth.make_scene(w=320, h=240, n_flows=5, fx=160, fy=160, cx=160, cy=120, seed=233)

@@ -11,12 +11,15 @@
 // single-workgroup kernel that runs the whole mean-shift (and, on the last EM iteration, a second one for the robust
 // Gaussian) iteration loop with DPP/LDS reductions and writes the new pose straight into the device PoseBlock.
 // Only a CamState record per camera is ever read back, once per EM iteration.
+#include <atomic>
 #include "vk_common.hpp"
 #include "vk_device.hpp"
 #include "vk_p3p.hpp"
 #include "vk_internal.hpp"
 
 namespace vk {
+
+static std::atomic<int> g_split_trials{1};  // vk_set_split_trials (verification aid): 0 = the mode kernel runs the initial-mode trials itself
 
 // phase clocks of the pose kernels (profiling builds only: scripts/phase_clocks.sh compiles a second library with -DVK_PHASE_CLOCKS)
 #ifdef VK_PHASE_CLOCKS
@@ -1388,7 +1391,7 @@ int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* ca
     // them -- external start -- or, without them, runs the trials itself.)
     constexpr int MAX_SPLIT_TRIALS = 64;
     const float* trials = nullptr;
-    if (trials_first && mp.use_external_init_mean <= 0 && mp.ms_max_init_trials > 0 && mp.ms_max_init_trials <= MAX_SPLIT_TRIALS) {
+    if (trials_first && g_split_trials.load(std::memory_order_relaxed) && mp.use_external_init_mean <= 0 && mp.ms_max_init_trials > 0 && mp.ms_max_init_trials <= MAX_SPLIT_TRIALS) {
         if (int e = c->ms_io.reserve(sizeof(float) * (64 + 8 * MAX_SPLIT_TRIALS) + sizeof(int) * 4)) return e;
         float* out = c->ms_io.as<float>() + 64;
         hipLaunchKernelGGL((k_mode_trials<PM_THREADS>), dim3(mp.ms_max_init_trials), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(),
@@ -1417,6 +1420,8 @@ int robust_gaussian_device(Context* c, const float* space_dev, int N, const Mode
 }
 
 }  // namespace vk
+
+extern "C" __attribute__((visibility("default"))) int vk_set_split_trials(int on) { vk::g_split_trials.store(on ? 1 : 0); return 0; }
 
 #ifdef VK_PHASE_CLOCKS
 extern "C" __attribute__((visibility("default"))) int vk_phase_read(unsigned long long* out, int n, int reset) {

@@ -209,3 +209,8 @@ def get_strict_math() -> bool:
 def set_local_serial(on: bool):
     """Verification aid (include/voldor_hip.h: vk_set_local_serial): step-by-step local propagation in fast mode."""
     capi.check(capi.lib().vk_set_local_serial(int(on)), "vk_set_local_serial")
+
+
+def set_split_trials(on: bool):
+    """Verification aid (include/voldor_hip.h: vk_set_split_trials): initial-mode trials as their own workgroups (default) or inside the mode kernel."""
+    capi.check(capi.lib().vk_set_split_trials(1 if on else 0), "vk_set_split_trials")
