@@ -943,7 +943,7 @@ __global__ static void k_reduce_density(const float* __restrict__ partial, int n
 // once per pass and the forward-message scratch of the reference (fb_smooth.h:14-15) is not needed.
 // Rounding differs from the step-by-step evaluation by a few ulp per step (the recurrence contracts,
 // nothing accumulates): deviation D7 in DESIGN.md, stage parity test_fb_smooth_alone_matches_oracle.
-constexpr int FB_SEG = 40;  // steps per lane (multiple of 4: 16-byte row accesses)
+constexpr int FB_SEG = 20;  // steps per lane (multiple of 4: 16-byte row accesses).  40 -> 20: the row pass of a 640x480 x 5 window is only 600 waves and its time is the dependent chain of 2 x FB_SEG steps (15.6 -> 12.5 us per pass); 1080 rows / 20 x 16 columns still fit a 1024-thread workgroup
 struct FbCoef { float p, q, dd, e0, e0p, e0dd, qe0, pqe0, pq; };
 __device__ __forceinline__ FbCoef fb_coef(float e0, float p) {
     FbCoef k;
