@@ -23,6 +23,8 @@ int Context::init(int dev) {
     VK_CHECK(hipEventCreate(&ev3));
     VK_CHECK(hipEventCreateWithFlags(&ev_cams, hipEventDisableTiming));
     VK_CHECK(hipHostMalloc((void**)&h_cams, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
+    VK_CHECK(hipHostMalloc((void**)&h_pb, sizeof(PoseBlock), hipHostMallocDefault));
+    VK_CHECK(hipHostMalloc((void**)&h_cams_up, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
     VK_CHECK(hipHostMalloc((void**)&h_brief, sizeof(CamBrief) * MAX_FRAMES, hipHostMallocMapped));
     VK_CHECK(hipHostGetDevicePointer((void**)&h_brief_dev, h_brief, 0));
     return 0;
@@ -40,6 +42,9 @@ void Context::destroy() {
     if (ev_cams) (void)hipEventDestroy(ev_cams);
     if (h_cams) (void)hipHostFree(h_cams);
     if (h_brief) (void)hipHostFree(h_brief);
+    if (h_pb) (void)hipHostFree(h_pb);
+    if (h_cams_up) (void)hipHostFree(h_cams_up);
+    h_pb = nullptr; h_cams_up = nullptr;
     h_cams = nullptr; h_brief = h_brief_dev = nullptr;
     if (stream) (void)hipStreamDestroy(stream);
     stream = nullptr; ev0 = ev1 = ev2 = ev3 = ev_cams = nullptr;

@@ -171,6 +171,8 @@ struct Context {
     std::map<std::string, ProfEntry> prof_acc;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // outer / inner scope
     hipEvent_t ev_cams = nullptr;  // "camera records of this EM iteration are on the host"
+    PoseBlock* h_pb = nullptr;     // pinned staging of the per-window uploads (pose block, camera records): no host sync before the first launch
+    CamState* h_cams_up = nullptr;
     CamBrief* h_brief = nullptr;   // pinned, written by the device (CamBrief above); h_brief_dev = its device address
     CamBrief* h_brief_dev = nullptr;
     CamState* h_cams = nullptr;    // pinned staging for that copy (a pageable destination would make the copy synchronous)

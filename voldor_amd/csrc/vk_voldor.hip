@@ -128,7 +128,7 @@ struct Voldor {
         if (int e = c->cams.reserve(sizeof(CamState) * MAX_FRAMES)) return e;
         VK_CHECK(hipMemcpyAsync(S.flows.p, flows, sizeof(float) * 2 * npx * N, hipMemcpyDefault, st));
         if (int e = fill_device(c, S.rig.as<float>(), 1.f, npx * N)) return e;
-        PoseBlock pb;
+        PoseBlock& pb = *c->h_pb;  // pinned staging: the previous window of this context ended with a stream synchronize, so it is free
         memset(&pb, 0, sizeof pb);
         pb.n_active = N;
         pb.K4[0] = cfg.fx; pb.K4[1] = cfg.cx; pb.K4[2] = cfg.fy; pb.K4[3] = cfg.cy;
@@ -160,8 +160,8 @@ struct Voldor {
         VK_CHECK(hipMemcpyAsync(S.pose.p, &pb, sizeof pb, hipMemcpyHostToDevice, st));
         memset(hcams, 0, sizeof hcams);
         for (int i = 0; i < MAX_FRAMES; i++) hcams[i].pose_rigidness_density = 1.f;  // rigidness maps start at 1 (:96-98)
-        VK_CHECK(hipMemcpyAsync(c->cams.p, hcams, sizeof hcams, hipMemcpyHostToDevice, st));
-        VK_CHECK(hipStreamSynchronize(st));  // pb / hcams live on the host stack of this object
+        memcpy(c->h_cams_up, hcams, sizeof hcams);
+        VK_CHECK(hipMemcpyAsync(c->cams.p, c->h_cams_up, sizeof hcams, hipMemcpyHostToDevice, st));  // from pinned staging: no host wait here
         if (n_dp > 0) {  // :106-117
             VK_CHECK(hipMemcpyAsync(S.depth.p, S.priors.p, sizeof(float) * npx, hipMemcpyDeviceToDevice, st));
             if (!disparity) { if (int e = optimize_depth(OD_ONLY_USE_DEPTH_PRIOR)) return e; }
