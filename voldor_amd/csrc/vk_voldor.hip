@@ -311,7 +311,7 @@ static int voldor_run_on(Context* c, const float* flows, const float* disparity,
     if (int e = v.solve()) return e;
     // outputs: py_export.cpp:56-76
     const size_t npx = (size_t)w * h;
-    VK_CHECK(hipMemcpyAsync(v.hcams, c->cams.p, sizeof(CamState) * MAX_FRAMES, hipMemcpyDeviceToHost, c->stream));
+    VK_CHECK(hipMemcpyAsync(c->h_cams, c->cams.p, sizeof(CamState) * MAX_FRAMES, hipMemcpyDeviceToHost, c->stream));  // pinned: the host does not wait here
     if (depth) VK_CHECK(hipMemcpyAsync(depth, c->od.depth.p, sizeof(float) * npx, hipMemcpyDefault, c->stream));
     if (depth_conf) {
         if (int e = c->tmp.reserve(sizeof(float) * npx)) return e;
@@ -323,6 +323,7 @@ static int voldor_run_on(Context* c, const float* flows, const float* disparity,
         VK_CHECK_LAST();
     }
     VK_CHECK(hipStreamSynchronize(c->stream));
+    memcpy(v.hcams, c->h_cams, sizeof(CamState) * MAX_FRAMES);
     *n_registered = v.n_flows;
     for (int i = 0; i < v.n_flows; i++) {
         if (poses) { memcpy(poses + i * 6, v.hcams[i].rvec, 12); memcpy(poses + i * 6 + 3, v.hcams[i].t, 12); }
