@@ -1010,6 +1010,7 @@ __device__ __forceinline__ void fb_incoming(const FbMat* sF, const FbMat* sB, in
 
 // Row pass: thread = (row, segment), segments of a row on adjacent lanes -> a wave reads whole contiguous row
 // pieces (160 bytes per lane).  256 threads = floor(256/S) rows.
+struct __attribute__((packed, aligned(4))) FbQuad { float x, y, z, w; };  // 16 bytes at 4-byte alignment: one global_load_dwordx4 on gfx950
 template <bool VEC4>
 __global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps, int w, int h, int S, float e0, float p, const int* __restrict__ n_dev,
                                                         int n_maps, PoseBlock* cumP, int cumN, int cumNdp, float* world_scale) {
@@ -1033,9 +1034,17 @@ __global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps
             if (4 * k < n) t = *reinterpret_cast<const float4*>(m + c0 + 4 * k);
             e[4 * k] = t.x; e[4 * k + 1] = t.y; e[4 * k + 2] = t.z; e[4 * k + 3] = t.w;
         }
-    } else {
+    } else {  // rows that do not start on 16 bytes (w % 4 != 0): the same 16-byte accesses with 4-byte alignment, scalar for a ragged tail
 #pragma unroll
-        for (int k = 0; k < FB_SEG; k++) e[k] = (k < n) ? m[c0 + k] : 0.5f;
+        for (int k = 0; k < FB_SEG / 4; k++) {
+            if (4 * k + 3 < n) {
+                const FbQuad t = *reinterpret_cast<const FbQuad*>(m + c0 + 4 * k);
+                e[4 * k] = t.x; e[4 * k + 1] = t.y; e[4 * k + 2] = t.z; e[4 * k + 3] = t.w;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) e[4 * k + j] = (4 * k + j < n) ? m[c0 + 4 * k + j] : 0.5f;
+            }
+        }
     }
     const float first = m[0], last = m[w - 1];
     FbMat F, B;
@@ -1052,7 +1061,13 @@ __global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps
             if (4 * k < n) *reinterpret_cast<float4*>(m + c0 + 4 * k) = make_float4(e[4 * k], e[4 * k + 1], e[4 * k + 2], e[4 * k + 3]);
     } else {
 #pragma unroll
-        for (int k = 0; k < FB_SEG; k++) if (k < n) m[c0 + k] = e[k];
+        for (int k = 0; k < FB_SEG / 4; k++) {
+            if (4 * k + 3 < n) *reinterpret_cast<FbQuad*>(m + c0 + 4 * k) = FbQuad{ e[4 * k], e[4 * k + 1], e[4 * k + 2], e[4 * k + 3] };
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (4 * k + j < n) m[c0 + 4 * k + j] = e[4 * k + j];
+            }
+        }
     }
 }
 // Column pass: thread = (segment, column); FB_CW adjacent columns share a workgroup, so every access is a
