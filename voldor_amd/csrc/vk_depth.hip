@@ -568,9 +568,12 @@ template <int NMAX>
 __global__ __launch_bounds__(256) static void k_global_prop_sites_lean(Img I, int dir, int step, int nsites) {
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
-    const int s = (tile % gridDim.x) * blockDim.x + threadIdx.x;
-    const int l = tile / gridDim.x;
-    if (s >= nsites) return;
+    // the lanes of a wave run along x either way: along the sites of a row (row passes: grid = site blocks x rows), along the columns
+    // of one site row (column passes: grid = column blocks x site rows -- consecutive lanes on consecutive pixels)
+    const bool rowpass = dir == 0 || dir == 2;
+    const int a = (tile % gridDim.x) * blockDim.x + threadIdx.x, b = tile / gridDim.x;
+    const int s = rowpass ? a : b, l = rowpass ? b : a;
+    if (s >= nsites || l >= (rowpass ? I.h : I.w)) return;
     const LeanK K = lean_consts(I);
     if (dir == 0) { int x = 1 + s * step; try_depth_lean<NMAX>(I, K, x, l, I.depth[l * I.w + x - 1]); }
     else if (dir == 2) { int x = I.w - 2 - s * step; try_depth_lean<NMAX>(I, K, x, l, I.depth[l * I.w + x + 1]); }
@@ -1178,7 +1181,8 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                     const int nsites = (len - 1 + p.global_prop_step - 1) / p.global_prop_step;
                     if (nsites <= 0) continue;
                     if constexpr (STRICT) hipLaunchKernelGGL(k_global_prop_sites_strict<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
-                    else hipLaunchKernelGGL(k_global_prop_sites_lean<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
+                    else if (rowpass) hipLaunchKernelGGL(k_global_prop_sites_lean<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
+                    else hipLaunchKernelGGL(k_global_prop_sites_lean<NMAX>, dim3((lines + 63) / 64, nsites), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
                 } else  // step 1: a true serial chain per line (no shipped config uses it)
                     hipLaunchKernelGGL((k_global_prop_serial<NMAX, STRICT>), dim3((lines + 63) / 64), dim3(64), 0, c->stream, I, dir);
             }
