@@ -163,6 +163,26 @@ def test_local_runs_equal_the_step_by_step_chain(width, noise, n_flows, n_dp):
         np.testing.assert_array_equal(c1.view(np.uint32), c2.view(np.uint32))
 
 
+def test_local_runs_with_the_tiled_table_equal_the_step_by_step_chain():
+    """Above 400k pixels the candidate-cost table of a pass comes from its own tiled kernel (below, every chain tabulates its own steps at
+    the head of the runs kernel): the same equality at 832x512."""
+    from voldor_amd import kernels, synth
+    sc = synth.make_scene(w=832, h=512, n_flows=3, fx=400, fy=400, cx=416, cy=256, seed=22)
+    rng = np.random.default_rng(7)
+    K = K9(*sc["K"])
+    flows, Rs, ts, depth, rig = _state(sc, rng, noise=0.2)
+    over = dict(n_rand_samples=2, global_prop_step=8, local_prop_width=32, fb_smooth=0)
+    try:
+        kernels.set_local_serial(True)
+        d1, r1, _ = _gpu_only(flows, Rs, ts, depth, rig, K, **over)
+    finally:
+        kernels.set_local_serial(False)
+    d2, r2, _ = _gpu_only(flows, Rs, ts, depth, rig, K, **over)
+    assert np.mean(d1 != depth) > 0.05
+    np.testing.assert_array_equal(d1.view(np.uint32), d2.view(np.uint32))
+    np.testing.assert_array_equal(r1.view(np.uint32), r2.view(np.uint32))
+
+
 def test_depth_priors_and_disparity(orc):
     from voldor_amd import synth
     sc = synth.make_scene(w=128, h=96, n_flows=3, fx=64, fy=64, cx=64, cy=48, seed=13, basefocal=30.0)
