@@ -605,13 +605,14 @@ __device__ __forceinline__ float quad_bcast(float v, int q) {  // quad_perm [q,q
     switch (q & 3) { case 0: return dpp_mov<0x00>(v); case 1: return dpp_mov<0x55>(v); case 2: return dpp_mov<0xAA>(v); default: return dpp_mov<0xFF>(v); }
 }
 __device__ __forceinline__ bool quad_bcast(bool b, int q) { return quad_bcast(b ? 1.f : 0.f, q) != 0.f; }
-// lane q of every aligned group of LPP lanes: a DPP move for quads, the LDS crossbar for groups of eight
-template <int LPP> __device__ __forceinline__ float group_bcast(float v, int q) { return LPP == 4 ? quad_bcast(v, q) : __shfl(v, q, LPP); }
-template <int LPP> __device__ __forceinline__ bool group_bcast(bool b, int q) { return LPP == 4 ? quad_bcast(b, q) : (__shfl((int)b, q, LPP) != 0); }
+__device__ __forceinline__ float pair_bcast(float v, int q) { return (q & 1) ? dpp_mov<0xF5>(v) : dpp_mov<0xA0>(v); }  // quad_perm [q,q,2+q,2+q]
+// lane q of every aligned group of LPP lanes: a DPP move for pairs and quads, the LDS crossbar for groups of eight
+template <int LPP> __device__ __forceinline__ float group_bcast(float v, int q) { return LPP == 2 ? pair_bcast(v, q) : LPP == 4 ? quad_bcast(v, q) : __shfl(v, q, LPP); }
+template <int LPP> __device__ __forceinline__ bool group_bcast(bool b, int q) { return group_bcast<LPP>(b ? 1.f : 0.f, q) != 0.f; }
 template <int NMAX, int LPP>
 __device__ __forceinline__ static float cost_split_lean(const Img& I, const LeanK& K, int px, int py, float depth, int g) {
 #pragma clang fp contract(off)
-    constexpr int S = (NMAX + LPP - 1) / LPP, PS = (MAX_DISP_FRAMES + LPP - 1) / LPP;
+    constexpr int S = (NMAX + LPP - 1) / LPP;
     const int w = I.w, h = I.h, npx = w * h, pi = py * w + px;
     const PoseBlock* P = I.P;
     const float x = (float)px, y = (float)py, fw = (float)w, fh = (float)h;
@@ -652,22 +653,20 @@ __device__ __forceinline__ static float cost_split_lean(const Img& I, const Lean
         if (k == 0 && g == 0) l = wt[k] * (0.6931471805599453f * l);  // = the cs lean_head starts from
         lt[k] = use ? l : 0.f; wt[k] = use ? wt[k] : 0.f; vv[k] = use;
     }
-    float pw[PS], pt[PS];
-    bool pk[PS];
-#pragma unroll
-    for (int k = 0; k < PS; k++) {
-        pw[k] = 0.f; pt[k] = 0.f; pk[k] = false;
-        if (g + LPP * k < I.N_dp) pk[k] = prior_parts(I, P, g + LPP * k, x, y, depth, pw[k], pt[k]);
-    }
     // combine in the order of lean_head / lean_rest
     float cs = 0.f, ws = 0.f;
     if (I.N > 0 && group_bcast<LPP>(vv[0], 0)) { cs = group_bcast<LPP>(lt[0], 0); ws = group_bcast<LPP>(wt[0], 0); }
+    // depth priors, LPP at a time: lane g evaluates prior f0 + g, the group adds them up in order (no per-slot arrays: there are up to 16)
+#pragma unroll 1
+    for (int f0 = 0; f0 < I.N_dp; f0 += LPP) {
+        float pw = 0.f, pt = 0.f;
+        bool pk = false;
+        if (f0 + g < I.N_dp) pk = prior_parts(I, P, f0 + g, x, y, depth, pw, pt);
 #pragma unroll
-    for (int f = 0; f < MAX_DISP_FRAMES; f++) {
-        if (f < I.N_dp) {
-            const bool ok = group_bcast<LPP>(pk[f / LPP], f % LPP);
-            const float wg = group_bcast<LPP>(pw[f / LPP], f % LPP), term = group_bcast<LPP>(pt[f / LPP], f % LPP);
-            if (ok) { cs = fmaf(wg, term, cs); ws += wg; }
+        for (int q = 0; q < LPP; q++) {
+            const bool ok = group_bcast<LPP>(pk, q);
+            const float wg = group_bcast<LPP>(pw, q), term = group_bcast<LPP>(pt, q);
+            if (f0 + q < I.N_dp && ok) { cs = fmaf(wg, term, cs); ws += wg; }
         }
     }
     float cl = 0.f;
@@ -693,9 +692,10 @@ __device__ __forceinline__ static float cost_split_lean(const Img& I, const Lean
 // and the pass ends with its slowest chain (measured: 80 % of the chains have no accept at all, a few per launch have 5-7 runs).  So a
 // round is filled with HALF/LPP pixels that are LIKELY to be needed:
 //   in a run     the next HALF/LPP pixels with v (the costs of a run are independent given v), accept / reject scanned with a ballot;
-//   when fresh   the next TWO accepts s_A < s_B of the table with the first HALF/(2 LPP) pixels of the run each would start (measured: an accept
-//                is followed by a short run four times out of five).  Run B's evaluations are the right ones if run A ends before
-//                s_B - 1 -- then s_B is the first accept after it and its predecessor is untouched; otherwise they are dropped.
+//   when fresh   the next R accepts s_0 < s_1 < .. of the table (s_r+1 = the first accept >= s_r + 2) with the first NP pixels of the run each
+//                would start (measured: an accept is followed by a short run four times out of five).  Run r's evaluations are the right
+//                ones if run r - 1 ended before s_r - 1 -- then s_r is the first accept after it and its predecessor is untouched;
+//                otherwise they, and the later ones, are dropped.
 // Every cost that is used was evaluated for exactly the (pixel, value) the step-by-step chain evaluates: identical maps (tests:
 // vk_set_local_serial).  Both chains of a wave share one evaluation per round whatever state each is in; only the cheap
 // bookkeeping diverges.
@@ -703,7 +703,8 @@ template <int HALF, int NMAX, int LPP>
 __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, int width, const float* __restrict__ tbl, int lines, int nchains) {
     if (!clamp_active(I)) return;
     PHD_DECL;
-    constexpr int NH = 64 / HALF, NG = HALF / LPP, NP = NG / 2;  // chains per wave, pixels per round, pixels per planned run
+    constexpr int NH = 64 / HALF, NG = HALF / LPP;  // chains per wave, pixels per round
+    constexpr int NP = NG >= 8 ? 4 : NG / 2, R = NG / NP;  // pixels per planned run, planned runs per round
     const int lane = threadIdx.x, half = lane / HALF, hl = lane % HALF, g = hl / LPP, sub = hl % LPP;
     const int tile = xcd_band_tile(blockIdx.x, gridDim.x);
     const int chain = tile * NH + half;
@@ -740,21 +741,26 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
         rounds_++;
 #endif
         // ---- this round's pixel and value of my group
-        int px, sA = -1, sB = -1;
-        float v, vA = 0.f, vB = 0.f;
+        int px, sr[R];
+        float v, vr[R];
         bool act;
+#pragma unroll
+        for (int r = 0; r < R; r++) { sr[r] = -1; vr[r] = 0.f; }
         if (running) { px = x + g; v = vrun; act = px < n; }
         else {
             unsigned long long m = (tacc >> x) << x;  // accepts at steps >= x (x < n <= 64)
             if (m == 0ull) break;  // no accept left: the rest of the chain keeps its values
-            sA = __ffsll((long long)m) - 1;
-            m = sA + 2 < 64 ? (m >> (sA + 2)) << (sA + 2) : 0ull;
-            sB = m != 0ull ? __ffsll((long long)m) - 1 : -1;
-            const float dA = __shfl(d0, max(sA - 1, 0), HALF), dB = __shfl(d0, max(sB - 1, 0), HALF);
-            vA = sA == 0 ? first_cand : dA; vB = dB;  // s_B >= 2
-            const bool inB = g >= NP;
-            const int s = inB ? sB : sA;
-            px = s + 1 + (inB ? g - NP : g); v = inB ? vB : vA; act = s >= 0 && px < n;
+            int s = -1;
+            v = 0.f;
+#pragma unroll
+            for (int r = 0; r < R; r++) {  // accept r = the first one at least two steps after accept r - 1
+                sr[r] = m != 0ull ? __ffsll((long long)m) - 1 : -1;
+                m = (sr[r] >= 0 && sr[r] + 2 < 64) ? (m >> (sr[r] + 2)) << (sr[r] + 2) : 0ull;
+                const float dp = __shfl(d0, max(sr[r] - 1, 0), HALF);
+                vr[r] = sr[r] == 0 ? first_cand : dp;
+                if (g / NP == r) { s = sr[r]; v = vr[r]; }
+            }
+            px = s + 1 + g % NP; act = s >= 0 && px < n;
         }
         // ---- one evaluation for the whole wave
         const int pi = cg.pi0 + (act ? px : 0) * cg.stride;
@@ -770,18 +776,20 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
             x += L;
             if (L < NG) { running = false; x += 1; }  // the step at x rejected v: its successor is fresh again
         } else {
-            if (hl == sA) { I.depth[mypi] = vA; I.cost[mypi] = t0; }  // replace_if_better_depth (:201-207)
-            const int LA = lead(accm, 0, NP);
-            if (g < LA && sub == 0) { I.depth[pi] = v; I.cost[pi] = c; }
-            if (LA == NP) { running = true; vrun = vA; x = sA + 1 + NP; }  // still going: a run in progress
-            else {
-                x = sA + LA + 2;  // rejected at s_A + 1 + LA (or the chain ended there)
-                if (sB >= x && x < n) {  // run A ended before s_B - 1: s_B is the first accept from x, evaluated with the right value
-                    if (hl == sB) { I.depth[mypi] = vB; I.cost[mypi] = t0; }
-                    const int LB = lead(accm, NP, NP);
-                    if (g >= NP && g < NP + LB && sub == 0) { I.depth[pi] = v; I.cost[pi] = c; }
-                    if (LB == NP) { running = true; vrun = vB; x = sB + 1 + NP; }
-                    else x = sB + LB + 2;
+            bool go = true;  // still fresh, consuming the planned runs in order
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (go) {
+                    const int s = sr[r];
+                    if (s < 0) { x = n; go = false; }  // no table accept from x on: the chain is finished
+                    else if (r > 0 && s < x) go = false;  // the previous run went over this accept: planned with the wrong state, dropped
+                    else {
+                        if (hl == s) { I.depth[mypi] = vr[r]; I.cost[mypi] = t0; }  // replace_if_better_depth (:201-207)
+                        const int L = lead(accm, r * NP, NP);
+                        if (g >= r * NP && g < r * NP + L && sub == 0) { I.depth[pi] = v; I.cost[pi] = c; }
+                        if (L == NP) { running = true; vrun = vr[r]; x = s + 1 + NP; go = false; }  // still going: a run in progress
+                        else { x = s + L + 2; if (x >= n) go = false; }  // rejected at s + 1 + L (or the chain ended there): s + L + 2 is fresh
+                    }
                 }
             }
         }
@@ -1205,7 +1213,9 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                     if (!own_table) hipLaunchKernelGGL(k_local_table_lean<NMAX>, gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
                     const float* tblp = own_table ? nullptr : c->local_tbl.as<float>();
                     const int nchains = lines * nseg;
-                    constexpr int LR_LPP = NMAX <= 8 ? 4 : 8;  // lanes per pixel of a run evaluation (cost_split_lean)
+                    // lanes per pixel of a run evaluation (cost_split_lean): quads up to 8 frames, eight beyond.  (Pairs -- 16 pixels per round, four planned
+                    // runs -- halve the rounds again but need 137 registers: 3 waves per SIMD for a pass of 4.7, 46 us instead of 27.)
+                    constexpr int LR_LPP = NMAX <= 8 ? 4 : 8;
                     if (p.local_prop_width <= 33)  // chains of <= 32 steps: two per wave
                         hipLaunchKernelGGL((k_local_runs_lean<32, NMAX, LR_LPP>), dim3((nchains + 1) / 2), dim3(64), 0, c->stream, I, dir, p.local_prop_width, tblp, lines, nchains);
                     else
