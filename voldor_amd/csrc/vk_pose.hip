@@ -181,6 +181,21 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
     constexpr int LPH = (SOLVER == 1) ? 1 : 4;
     extern __shared__ int s_pref[];  // FROM_MAP: inclusive prefix of blk_counts (rank select only)
     const int gtid = blockIdx.x * 64 + threadIdx.x, idx = gtid / LPH, sub = gtid % LPH;
+    // FROM_MAP: the first batch of rejection probes does not depend on the number of correspondences, so its reads are in flight
+    // together with those of the per-block counts (one memory round trip instead of two at the head of the kernel)
+    constexpr int DRAW_BATCH = 4;
+    int cand0[4][DRAW_BATCH];
+    float probe0[4][DRAW_BATCH];
+    if (FROM_MAP) {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int j = 0; j < DRAW_BATCH; j++) {
+                const uint32_t r = rng3(RAND_SEED, (uint32_t)idx, (uint32_t)(k * DRAW_MAX_TRIES + j));
+                cand0[k][j] = (int)(((unsigned long long)r * (unsigned long long)npx) >> 32);
+                probe0[k][j] = pts2[(size_t)cand0[k][j] * 2];
+            }
+    }
     int n_pts;
     if (FROM_MAP) {
         // number of valid correspondences = sum of k_collect's per-workgroup counts; every wave adds them up itself
@@ -248,10 +263,14 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
             // own candidate sequence j = 0,1,2,...  A probe is a random read (one L2/HBM round trip), so the
             // probes are issued DRAW_BATCH tries x 4 points at a time instead of one dependent read per try;
             // the selected pixels are the same.
-            constexpr int DRAW_BATCH = 4;
 #pragma unroll
             for (int k = 0; k < 4; k++) sel[k] = -1;
-            for (int j0 = 0; j0 < DRAW_MAX_TRIES; j0 += DRAW_BATCH) {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+#pragma unroll
+                for (int j = 0; j < DRAW_BATCH; j++)
+                    if (sel[k] < 0 && isfinite(probe0[k][j])) sel[k] = cand0[k][j];
+            for (int j0 = DRAW_BATCH; j0 < DRAW_MAX_TRIES; j0 += DRAW_BATCH) {
                 if (sel[0] >= 0 && sel[1] >= 0 && sel[2] >= 0 && sel[3] >= 0) break;
                 int cand[4][DRAW_BATCH];
                 float probe[4][DRAW_BATCH];
