@@ -51,6 +51,7 @@ __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict
     if (pi < npx) {
         const int x = pi % w, y = pi / w;
         float d = depth[pi];
+        const float rig_a = rig[(size_t)active_idx * npx + pi];  // the first factor of the trace product, in flight with the depth
         bool ok = !(d < min_depth || (max_depth > 0.f && d > max_depth));
         if (ok && rig_sum_thresh > (float)(N + 1)) {  // inert unless thr > N+1 (sic, :88-90)
             float rs = 0.f;
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict
             float prod = 1.f;
             const int lo = max_trace > 0 ? max(0, active_idx - max_trace + 1) : 0;
             for (int i = active_idx; i >= lo; i--) {
-                prod *= rig[(size_t)i * npx + pi];
+                prod *= i == active_idx ? rig_a : rig[(size_t)i * npx + pi];
                 if (prod > rig_thresh) n_trace++;
                 else break;
             }
@@ -1009,22 +1010,22 @@ __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __res
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     // successive pose? (voldor.cpp:177: pose_sample_count != 0), decided on the device
     const bool external_init = mp.use_external_init_mean < 0 ? (cam->pose_sample_count != 0) : (mp.use_external_init_mean != 0);
-    if (*n_points_dev < 4) {  // geometry.cpp:84-88
-        if (tid == 0) { cam->success = 0; maybe_decide(mp, P, cam, cam_idx); }
-        return;
-    }
     // ---- pool -> registers (coordinate planes [3][n_poses] written by k_solve: every load of a wave is one 256-byte run);
     // rvec pre-scaled (:191); number of finite hypotheses (geometry.cpp:156-165)
     f2 X[MS_PAIRS][6];
     unsigned finmask = 0;
 #pragma unroll
-    for (int k = 0; k < SPT; k++) {  // all 48 loads first, straight into their registers
+    for (int k = 0; k < SPT; k++) {  // all loads first, straight into their registers
         const int i = min(k * THREADS + tid, n_poses - 1);  // slots past the pool read a valid address and are dropped below
 #pragma unroll
         for (int d = 0; d < 6; d++) {
             const float v = d < 3 ? rvecs[(size_t)d * n_poses + i] : tvecs[(size_t)(d - 3) * n_poses + i];
             if (k & 1) X[k >> 1][d].y = v; else X[k >> 1][d].x = v;
         }
+    }
+    if (*n_points_dev < 4) {  // geometry.cpp:84-88 (tested with the pool already on its way: the buffers exist either way)
+        if (tid == 0) { cam->success = 0; maybe_decide(mp, P, cam, cam_idx); }
+        return;
     }
 #pragma unroll
     for (int k = 0; k < SPT; k++) {
