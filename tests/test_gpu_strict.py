@@ -264,3 +264,37 @@ def test_fast_vs_strict_within_the_reference_self_noise(orc, name):
     for other in (s["poses_covar"], gold[f"{name}/m0/poses_covar"]):
         lr = np.abs(np.log(tr_(f["poses_covar"]) / tr_(other)))
         assert lr.max() <= 2 * spread, (lr, spread)
+
+
+@pytest.mark.parametrize("extra", [
+    "--n_poses_to_sample 1000",                 # a pool that does not fill the mode kernel's registers
+    "--meanshift_max_init_trials 3",            # fewer initial-mode trials than a batch
+    "--meanshift_max_init_trials 100",          # more than k_mode_trials takes: the mode kernel runs them itself
+    "--rg_refine 0",                            # no robust-Gaussian refit: k_pose_mode<false> on the last iteration too
+    "--fb_smooth 0",                            # k_cum_poses as its own launch (no fb_smooth launch to ride on)
+    "--norm_world_scale 0",                     # no world-scale factor in the E-step kernel
+    "--depth_local_prop_width 70",              # chains longer than a wave: step-by-step local propagation
+    "--depth_local_prop_width 48",              # one chain per wave (HALF = 64)
+    "--depth_global_prop_step 1",               # serial global propagation
+    "--max_trace_on_flow 0 --lambdatwist 0",    # full-length flow traces; AP3P hypotheses
+])
+def test_config_variants_fast_vs_strict(extra):
+    """Configurations that switch the fast pipeline onto its alternative kernels, each against the strict pipeline on the same
+    window (same draws): registered count equal, poses within twice the reference's self-noise at this size (ref_selfnoise.npz,
+    mono_320x240) -- a wrong code path shows as a lost window or a pose off by orders of magnitude more."""
+    import ref_window_cases as cases
+    from voldor_amd import kernels, pyvoldor, synth
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_selfnoise.npz"))
+    c = dict(cases.window_cases())["mono_320x240"]
+    fx, fy, cx, cy = c["K"]
+    res = {}
+    for mode in ("strict", "fast"):
+        kernels.set_rand_epoch(0)
+        res[mode] = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, config=c["config"] + " " + extra + (" --strict_math 1" if mode == "strict" else " --strict_math 0"))
+    s, f = res["strict"], res["fast"]
+    assert s["n_registered"] == f["n_registered"] == c["flows"].shape[0]
+    rot, tr = synth.pose_errors(f["poses"], s["poses"])
+    nr, nt, _ = _pair_noise(gold, "mono_320x240")
+    # fewer hypotheses / no refit / no smoothing make the estimator itself noisier than the default configuration the noise was measured on
+    slack = 4 if ("n_poses_to_sample" in extra or "lambdatwist" in extra) else 2
+    assert rot.max() <= slack * nr + 2e-4 and tr.max() <= slack * nt, (extra, rot.max(), tr.max(), nr, nt)

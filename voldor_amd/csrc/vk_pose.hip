@@ -1232,7 +1232,6 @@ __global__ __launch_bounds__(THREADS) static void k_mode_trials(const float* __r
     __shared__ int s_cnt[SPT][NW];
     __shared__ float s_pick[6];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, trial = blockIdx.x;
-    if (*n_points_dev < 4) return;
     f2 X[MS_PAIRS][6];
     unsigned finmask = 0;
 #pragma unroll
@@ -1244,6 +1243,7 @@ __global__ __launch_bounds__(THREADS) static void k_mode_trials(const float* __r
             if (k & 1) X[k >> 1][d].y = v; else X[k >> 1][d].x = v;
         }
     }
+    if (*n_points_dev < 4) return;
 #pragma unroll
     for (int k = 0; k < SPT; k++) {
         float v[6];
