@@ -174,12 +174,12 @@ def main():
         # optimize_depth call).  Algorithmic bytes of one launch = every map it must touch once: flows 8N + rigidness 4N read,
         # priors 12 N_dp read, depth and cost read 8 + written 8  ->  w*h*(12N+12N_dp+16)  (DESIGN.md section 3).
         b_cr = W * H * (12 * N_FLOW + 12 * n_dp + 16)
-        nmax = 4 if N_FLOW <= 4 else 6 if N_FLOW <= 6 else 8 if N_FLOW <= 8 else 16
+        nmax = 4 if N_FLOW <= 4 else 6 if N_FLOW <= 6 else 8 if N_FLOW <= 8 else 12 if N_FLOW <= 12 else 16
         kname = f"vk::k_cost_rand_q<{nmax}>"
         traffic = valu = None
         sqc = {}
-        def pmc_file(kind):  # the latest PMC pass of this workload that is committed (r02h: final tree; r02c: same kernel, earlier)
-            for tag in ("r02h", "r02c"):
+        def pmc_file(kind):  # the latest PMC pass of this workload that is committed (r02j, r02h: final kernels; r02c: earlier)
+            for tag in ("r02j", "r02h", "r02c"):
                 f = os.path.join(ROOT, "profiles", f"{tag}_pmc_{kind}_{args.workload}.json")
                 if os.path.exists(f):
                     return f

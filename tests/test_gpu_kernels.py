@@ -129,7 +129,7 @@ def _gpu_only(flows, Rs, ts, depth, rig, K, epoch=5, priors=None, pconfs=None, c
 
 
 @pytest.mark.parametrize("width,noise,n_flows,n_dp", [(32, 0.3, 4, 0), (32, 0.02, 5, 0), (33, 0.1, 5, 1), (7, 0.3, 3, 0), (64, 0.3, 9, 0),
-                                                        (65, 0.05, 13, 2), (5, 0.0, 2, 0), (32, 0.1, 16, 0), (32, 0.2, 6, 5), (32, 0.2, 8, 0), (33, 0.1, 7, 1)])
+                                                        (65, 0.05, 13, 2), (5, 0.0, 2, 0), (32, 0.1, 16, 0), (32, 0.2, 6, 5), (32, 0.2, 8, 0), (33, 0.1, 7, 1), (32, 0.2, 10, 0), (32, 0.1, 12, 1)])
 def test_local_runs_equal_the_step_by_step_chain(width, noise, n_flows, n_dp):
     """The local-propagation kernel of the fast mode (cost table + chain automata whose run evaluations are planned two runs ahead, four
     lanes per pixel, two chains per wave up to width 33) against the literal step-by-step chain of the same arithmetic

@@ -1245,6 +1245,7 @@ static int optimize_depth_dispatch(Context* c, ImageSet& S, const OdParams& p, b
     if (p.N <= 4) return optimize_depth_launch<4, false>(c, S, p, cost_only);
     if (p.N <= 6) return optimize_depth_launch<6, false>(c, S, p, cost_only);  // the SLAM driver's window is 5 flows (voldor_slam.py:85)
     if (p.N <= 8) return optimize_depth_launch<8, false>(c, S, p, cost_only);
+    if (p.N <= 12) return optimize_depth_launch<12, false>(c, S, p, cost_only);  // per-frame register arrays are sized by the bound: 139 -> fewer VGPRs than <16>
     return optimize_depth_launch<16, false>(c, S, p, cost_only);
 }
 
