@@ -134,13 +134,17 @@ VK_HD void boot_null9(double* A, double* f) {
 #define AA(r, c) A[((r) * 9 + (c)) * S]
     int perm[9];
     for (int c = 0; c < 9; c++) perm[c] = c;
+    // On the device the matrix lives in LDS (run-time row / column indices) and one lane walks it alone: what the step costs is the
+    // number of DEPENDENT LDS round trips, so the loops over the trailing block are written with constant bounds and a predicate --
+    // all reads of a step are issued together -- in the same order as the plain r-from-k, c-from-k loops (first maximum wins).
 #pragma unroll 1
     for (int k = 0; k < 8; k++) {
         int pr = k, pc = k; double best = -1.0;
-#pragma unroll 1
-        for (int r = k; r < 8; r++)
-#pragma unroll 1
-            for (int c = k; c < 9; c++) { const double v = vk_abs(AA(r, c)); if (v > best) { best = v; pr = r; pc = c; } }
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+#pragma unroll
+            for (int c = 0; c < 9; c++)
+                if (r >= k && c >= k) { const double v = vk_abs(AA(r, c)); if (v > best) { best = v; pr = r; pc = c; } }
         if (pr != k) for (int c = 0; c < 9; c++) { const double t = AA(k, c); AA(k, c) = AA(pr, c); AA(pr, c) = t; }
         if (pc != k) {
             for (int r = 0; r < 8; r++) { const double t = AA(r, k); AA(r, k) = AA(r, pc); AA(r, pc) = t; }
@@ -153,11 +157,17 @@ VK_HD void boot_null9(double* A, double* f) {
         }
         double piv = AA(k, k);
         if (!(vk_abs(piv) > 1e-300)) piv = 1e-300;  // rank deficient sample
-#pragma unroll 1
-        for (int r = k + 1; r < 8; r++) {
-            const double m = AA(r, k) / piv;
-#pragma unroll 1
-            for (int c = k + 1; c < 9; c++) AA(r, c) -= m * AA(k, c);
+        double rowk[9];
+#pragma unroll
+        for (int c = 0; c < 9; c++) rowk[c] = AA(k, c);
+#pragma unroll
+        for (int r = 1; r < 8; r++) {
+            if (r > k) {
+                const double m = AA(r, k) / piv;
+#pragma unroll
+                for (int c = 1; c < 9; c++)
+                    if (c > k) AA(r, c) -= m * rowk[c];
+            }
         }
         AA(k, k) = piv;
     }
