@@ -122,6 +122,12 @@ unsigned vk_get_rand_epoch(void);
  * default comes from the environment variable VOLDOR_HIP_STRICT_MATH. */
 int vk_set_strict_math(int on);
 int vk_get_strict_math(void);
+/* rodrigues() of the P3P batch (gpu-kernels/rodrigues.h:82-114) through the reference's approximate fp32 SVD
+ * (gpu-kernels/svd3_cuda.h:36-1044, restated to the bit in voldor_amd/csrc/vk_ref_svd.h) instead of the exact polar factor.
+ * Process-wide default (also VOLDOR_HIP_REFERENCE_SVD=1); the window call takes the config key --reference_svd 0|1.  With
+ * --strict_math 1 --reference_draw 1 a window then equals the reference pipeline's strict-math window in every output bit. */
+int vk_set_reference_svd(int on);
+int vk_get_reference_svd(void);
 /* Verification aid: 1 = the local-propagation pass of the fast mode walks every chain step by step (one lane per chain, the literal
  * optimize_depth.cu:320-396 order) instead of the table + speculative-run kernel; both must give identical maps
  * (tests/test_gpu_kernels.py::test_local_runs_equal_the_step_by_step_chain). */

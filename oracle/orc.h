@@ -124,6 +124,11 @@ void orc_rvec_to_rotmat(const float* rvec3, float* R9); /* cv::Rodrigues(vec->ma
 /* gpu-kernels/solve_batch_lambdatwist.cu:51-102 / solve_batch_ap3p.cu:387-437 */
 void orc_last_two_view_translation(float* t3); /* test hook: recoverPose-style t of the last orc_estimate_pose_epipolar call */
 void orc_set_rodrigues_hook(void (*fn)(const float* R9, float* rvec3, float* Rproj9)); /* test hook, see orc_pose.c */
+/* --reference_svd 1 of the product: orc_rodrigues projects with the reference's approximate SVD (svd3_cuda.h:36-1044 restated to the bit
+ * in voldor_amd/csrc/vk_ref_svd.h, shared with the HIP kernels like vk_strict_math.h) instead of the exact polar factor (D8) */
+void orc_set_reference_svd(int on);
+int orc_get_reference_svd(void);
+void orc_reference_project_rotation(const float* R9, float* Q9); /* rodrigues.h:82-108 alone */
 void orc_solve_batch_p3p(const float* pts3, const float* pts2, float* rvecs, float* tvecs,
                          const float* K, int n_pts, int n_poses, int use_ap3p, int use_double);
 /* gpu-kernels/meanshift.cu:34-150 */

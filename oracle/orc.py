@@ -23,7 +23,7 @@ def build(force: bool = False) -> None:
     """Compile liborc.so (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "liborc.so")
     srcs = [os.path.join(_HERE, f) for f in ("orc_model.c", "orc_pose.c", "orc_voldor.c", "orc_align.c", "orc_lambdatwist_impl.h", "orc.h", "orc_math.h",
-                                         "../voldor_amd/csrc/vk_strict_math.h")]
+                                         "../voldor_amd/csrc/vk_strict_math.h", "../voldor_amd/csrc/vk_ref_svd.h")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     ref_so = os.path.join(_HERE, "_ref", "libvoldor_ref.so")
     want_ref = False
@@ -224,6 +224,19 @@ def rodrigues(R):
     r = np.zeros(3, np.float32)
     lib().orc_rodrigues(_fp(R), _fp(r))
     return r
+
+
+def reference_project_rotation(R):
+    """rodrigues.h:82-108 alone: U V^T of the reference's approximate SVD (voldor_amd/csrc/vk_ref_svd.h)."""
+    R = f32(R).reshape(9)
+    Q = np.zeros(9, np.float32)
+    lib().orc_reference_project_rotation(_fp(R), _fp(Q))
+    return Q.reshape(3, 3)
+
+
+def set_reference_svd(on):
+    """orc_rodrigues through the reference's approximate SVD (the product's --reference_svd 1) instead of the exact polar factor (D8)."""
+    lib().orc_set_reference_svd(1 if on else 0)
 
 
 def rotmat_to_angle_axis(R):

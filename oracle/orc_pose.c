@@ -6,6 +6,7 @@
  * lambdatwist/*.h and voldor/geometry.cpp; citations inline. */
 #include "orc.h"
 #include "orc_math.h"
+#include "../voldor_amd/csrc/vk_ref_svd.h"
 #include <tgmath.h>
 #include <float.h>
 #include <stdio.h>
@@ -198,9 +199,17 @@ static void polar_rotation(const float* R9, float* Q9) {
  * to take the approximate-SVD difference out of a whole-window comparison with the reference pipeline.  NULL = the oracle's. */
 static void (*g_rodrigues_hook)(const float* R9, float* rvec3, float* Rproj9) = NULL;
 void orc_set_rodrigues_hook(void (*fn)(const float*, float*, float*)) { g_rodrigues_hook = fn; }
+/* Reference-SVD mode (config key --reference_svd 1 of the product; orc_set_reference_svd here): the projection is U V^T of the
+ * reference's approximate fp32 SVD, restated to the bit in voldor_amd/csrc/vk_ref_svd.h (svd3_cuda.h:36-1044, rodrigues.h:82-108) and
+ * pinned against the reference's own rodrigues() compiled in place (tests/test_oracle_vs_golden.py).  Retires D8 for parity runs. */
+static int g_reference_svd = 0;
+void orc_set_reference_svd(int on) { g_reference_svd = on; }
+int orc_get_reference_svd(void) { return g_reference_svd; }
+void orc_reference_project_rotation(const float* R9, float* Q9) { memcpy(Q9, R9, 9 * sizeof(float)); vrs_project_rotation(Q9); }
 void orc_rodrigues(const float* R9, float* rvec3) {
     if (g_rodrigues_hook) { g_rodrigues_hook(R9, rvec3, NULL); return; }
     float Q[9];
+    if (g_reference_svd) { orc_reference_project_rotation(R9, Q); orc_rotmat_to_angle_axis(Q, rvec3); return; }
     polar_rotation(R9, Q);
     orc_rotmat_to_angle_axis(Q, rvec3);
 }

@@ -26,9 +26,10 @@
  *     pipeline drift apart when only the last bit of the transcendentals differs (tests/golden/ref_selfnoise.npz). */
 #include "../../../voldor_amd/csrc/vk_strict_math.h"
 extern "C" int ref_math_mode;
+extern "C" unsigned int ref_jitter_salt; /* ref_set_jitter_salt: independent jitter patterns (0 = the pattern of ref_selfnoise.npz) */
 static inline float ref_ulp_jitter(float r, float x, float y) {
     uint32_t a, b; memcpy(&a, &x, 4); memcpy(&b, &y, 4);
-    uint32_t h = (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u); h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+    uint32_t h = (a * 0x9E3779B1u) ^ (b * 0x85EBCA77u) ^ (ref_jitter_salt * 0xC2B2AE3Du); h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
     const int k = (int)(h % 3u) - 1;
     if (k == 0 || !(r == r) || std::isinf(r)) return r;
     return std::nextafterf(r, k > 0 ? INFINITY : -INFINITY);

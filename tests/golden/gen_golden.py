@@ -88,7 +88,29 @@ def main():
         Rin[i] = R.reshape(-1).astype(np.float32)
         ref.ref_rodrigues(orc._fp(Rin[i]), orc._fp(rv_out[i]), None)
         ref.ref_rotmat_to_angle_axis(orc._fp(Rin[i]), orc._fp(aa_out[i]))
-    np.savez_compressed(os.path.join(HERE, "ref_rodrigues.npz"), R=Rin, rvec=rv_out, angle_axis_no_svd=aa_out)
+    # the projected matrix itself (U V^T of svd3_cuda.h, no libm in it) and the strict-math rotation vectors: what
+    # voldor_amd/csrc/vk_ref_svd.h (--reference_svd 1) must reproduce to the bit.  Plus matrices far from SO(3): scaled, reflected,
+    # rank-deficient, tiny, with repeated columns -- every branch of the sort / Givens stage.
+    rw = np.random.default_rng(77)
+    wild = [rw.normal(0, s, (512, 9)) for s in (1.0, 1e-3, 50.0)]
+    wild.append(Rin[:256] * rw.uniform(0.3, 3.0, (256, 1)))
+    refl = Rin[:256].reshape(-1, 3, 3).copy(); refl[:, :, 1] *= -1; wild.append(refl.reshape(-1, 9))
+    low = rw.normal(0, 1, (128, 3, 3)); low[:, :, 2] = low[:, :, 0]; wild.append(low.reshape(-1, 9))
+    wild.append(np.zeros((1, 9))); wild.append(np.eye(3).reshape(1, 9)); wild.append(rw.normal(0, 1e-12, (32, 9)))
+    Rw = np.concatenate(wild).astype(np.float32)
+    Rall = np.concatenate([Rin, Rw])
+    proj = np.zeros_like(Rall); rv_all = np.zeros((len(Rall), 3), np.float32); rv_strict = np.zeros((len(Rall), 3), np.float32)
+    for i in range(len(Rall)):
+        ref.ref_rodrigues(orc._fp(Rall[i]), orc._fp(rv_all[i]), orc._fp(proj[i]))
+    ref.ref_set_math_mode(1)
+    try:
+        for i in range(len(Rall)):
+            ref.ref_rodrigues(orc._fp(Rall[i]), orc._fp(rv_strict[i]), None)
+    finally:
+        ref.ref_set_math_mode(0)
+    assert np.array_equal(rv_all[:k].view(np.uint32), rv_out.view(np.uint32))
+    np.savez_compressed(os.path.join(HERE, "ref_rodrigues.npz"), R=Rin, rvec=rv_out, angle_axis_no_svd=aa_out,
+                        R_all=Rall, proj_all=proj, rvec_all=rv_all, rvec_all_strict=rv_strict)
     print("wrote", [f for f in os.listdir(HERE) if f.endswith(".npz")])
 
 

@@ -112,3 +112,65 @@ def test_baseline_cfg2_window_vs_reference_pipeline(gold):
     for poses in (g["poses"], gold[f"{name}/poses"]):
         r, t = synth.pose_errors(poses, gt)
         assert r.max() < 2e-3 and t.max() < 4e-2, (r, t)
+
+
+# ---- strict math + the reference's draw + the reference's SVD: a HIP window IS the reference's window ---------------------------
+STRICT_GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_window_strict.npz")
+ENSEMBLE_GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_ensemble.npz")
+REFERENCE_MODE = " --strict_math 1 --reference_draw 1 --reference_svd 1"
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", ["mono_nonexclusive", "stereo_default", "stereo_ap3p", "depth_priors"])
+def test_strict_window_equals_the_reference(name):
+    """tests/golden/ref_window_strict.npz = the REFERENCE's own pipeline (voldor/*.cpp + gpu-kernels/*.cu, executed on the CPU) with
+    its libm calls served by vk_strict_math.h.  `--strict_math 1 --reference_draw 1 --reference_svd 1` switches the product's three
+    computational deviations (hardware transcendentals / re-associated sums, D3b rejection draw, D8 exact polar factor) to the
+    reference's behaviour; D1 (counter RNG), D2 (exact bilinear) and D5 (injected two-view pose) are in the golden run too.  Then
+    the window must equal the reference's in EVERY bit of the registered count, depth map, confidence map and covariances -- no
+    oracle in between.  Poses: the reference returns Camera::pose6() = cv::Rodrigues(cv::Rodrigues(rvec)) (utils.h:44-53; OpenCV,
+    not in the reference tree), a round trip through a 3x3 float matrix that moves an rvec by at most ~2 ulp: < 1e-9."""
+    from voldor_amd import kernels, pyvoldor
+    g = np.load(STRICT_GOLD)
+    c = dict(CASES)[name]
+    fx, fy, cx, cy = c["K"]
+    kernels.set_rand_epoch(0)
+    o = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"], depth_priors=c["depth_priors"],
+                        depth_prior_poses=c["depth_prior_poses"], depth_prior_pconfs=c["depth_prior_pconfs"], config=c["config"] + REFERENCE_MODE)
+    assert o["n_registered"] == int(g[f"{name}/n_registered"])
+    for k in ("depth", "depth_conf", "poses_covar"):
+        neq = _bits(o[k]) != _bits(g[f"{name}/{k}"])
+        assert not neq.any(), f"{name}/{k}: {int(neq.sum())} of {neq.size} values differ from the reference"
+    assert np.abs(o["poses"].astype(np.float64) - g[f"{name}/poses"]).max() < 1e-9
+    # the switch matters: without the reference's SVD the same window is a different rounding of the same estimate
+    kernels.set_rand_epoch(0)
+    o2 = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"], depth_priors=c["depth_priors"],
+                         depth_prior_poses=c["depth_prior_poses"], depth_prior_pconfs=c["depth_prior_pconfs"],
+                         config=c["config"] + " --strict_math 1 --reference_draw 1")
+    assert (_bits(o2["depth"]) != _bits(g[f"{name}/depth"])).any()
+
+
+def test_strict_cfg2_window_equals_the_reference():
+    """BASELINE configs[1] at full size (640x480, N=5, 8 EM iterations, monocular, refit on the last iteration): the reference
+    pipeline's strict-math window (tests/golden/gen_golden_ensemble.py, `cfg2/s233/strict`: covariances, poses, sha256 of the two
+    maps and every 8th pixel of them) against the HIP window in reference mode."""
+    import hashlib
+    from voldor_amd import kernels, pyvoldor
+    if not os.path.exists(ENSEMBLE_GOLD):
+        pytest.skip("tests/golden/ref_ensemble.npz not generated")
+    g = np.load(ENSEMBLE_GOLD)
+    name, c = cases.cfg2_case()
+    fx, fy, cx, cy = c["K"]
+    kernels.set_rand_epoch(0)
+    o = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, config=c["config"] + REFERENCE_MODE)
+    p = "cfg2/s233/strict/"
+    assert o["n_registered"] == int(g[p + "n_registered"]) == 5
+    assert not (_bits(o["depth"][::8, ::8]) != _bits(g[p + "depth_sub"])).any()
+    assert not (_bits(o["depth_conf"][::8, ::8]) != _bits(g[p + "conf_sub"])).any()
+    assert hashlib.sha256(np.ascontiguousarray(o["depth"]).tobytes()).digest() == g[p + "depth_sha256"].tobytes()
+    assert hashlib.sha256(np.ascontiguousarray(o["depth_conf"]).tobytes()).digest() == g[p + "conf_sha256"].tobytes()
+    assert not (_bits(o["poses_covar"]) != _bits(g[p + "poses_covar"])).any()
+    assert np.abs(o["poses"].astype(np.float64) - g[p + "poses"]).max() < 1e-9

@@ -49,6 +49,29 @@ def test_rodrigues_vs_reference_svd(orc):
     assert np.abs(aa - g["angle_axis_no_svd"]).max() < 1e-6  # Ceres formula alone: same libm
 
 
+def test_reference_svd_restatement_is_bit_identical_to_the_reference(orc):
+    """voldor_amd/csrc/vk_ref_svd.h (--reference_svd 1 of the product, orc_set_reference_svd here) restates svd3_cuda.h:36-1044 and
+    rodrigues.h:82-108.  Against the reference's own rodrigues() compiled in place (golden: tests/golden/gen_golden.py): the projected
+    matrix U V^T in every bit on 3234 inputs -- rotations, noisy rotations, and matrices far from SO(3) that walk every branch of the
+    column sort and the Givens stage --, the rotation vectors in every bit under glibc and under strict math."""
+    g = np.load(os.path.join(G, "ref_rodrigues.npz"))
+    R = g["R_all"]
+    Q = np.array([orc.reference_project_rotation(R[i]).reshape(9) for i in range(len(R))], np.float32)
+    assert np.array_equal(Q.view(np.uint32), g["proj_all"].view(np.uint32)), np.mean(np.any(Q != g["proj_all"], axis=1))
+    orc.set_reference_svd(True)
+    try:
+        rv = np.array([orc.rodrigues(R[i]) for i in range(len(R))], np.float32)
+        assert np.array_equal(rv.view(np.uint32), g["rvec_all"].view(np.uint32))
+        orc.lib().orc_set_strict_math(1)
+        rvs = np.array([orc.rodrigues(R[i]) for i in range(len(R))], np.float32)
+        assert np.array_equal(rvs.view(np.uint32), g["rvec_all_strict"].view(np.uint32))
+    finally:
+        orc.lib().orc_set_strict_math(0)
+        orc.set_reference_svd(False)
+    # and the default (D8) stays what it was: the exact polar factor
+    assert np.abs(orc.rodrigues(R[5]) - g["rvec_all"][5]).max() < 2e-3
+
+
 def test_live_reference_build_if_present(orc):
     """Where /root/reference exists (authoring container) the freshly built oracle/_ref must agree too."""
     ref = orc.ref()

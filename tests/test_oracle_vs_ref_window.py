@@ -40,12 +40,19 @@ def run_oracle(c):
                       depth_prior_poses=c["depth_prior_poses"], depth_prior_pconfs=c["depth_prior_pconfs"], config=c["config"])
 
 
-@pytest.fixture
-def reference_mode(monkeypatch):
+@pytest.fixture(params=["restated_svd", "hooked_reference_rodrigues"])
+def reference_mode(monkeypatch, request):
+    """The reference's rodrigues() either as restated in voldor_amd/csrc/vk_ref_svd.h (orc_set_reference_svd: what the HIP path
+    runs under --reference_svd 1; needs nothing but the oracle) or as the reference's own code hooked in from oracle/_ref."""
+    monkeypatch.setenv("ORC_REFERENCE_DRAW", "1")
+    if request.param == "restated_svd":
+        orc.set_reference_svd(True)
+        yield monkeypatch
+        orc.set_reference_svd(False)
+        return
     ref = orc.ref()
     if ref is None or not hasattr(ref, "ref_rodrigues"):
         pytest.skip("oracle/_ref (the reference's rodrigues.h compiled in place) is not built on this box")
-    monkeypatch.setenv("ORC_REFERENCE_DRAW", "1")
     orc.lib().orc_set_rodrigues_hook(C.cast(ref.ref_rodrigues, C.c_void_p))
     yield monkeypatch
     orc.lib().orc_set_rodrigues_hook(None)
@@ -112,12 +119,14 @@ def test_strict_oracle_bit_identical_to_the_reference_in_strict_math(reference_m
     g = np.load(STRICT_GOLD)
     c = dict(CASES)[name]
     orc.lib().orc_set_strict_math(1)
-    orc.ref().ref_set_math_mode(1)  # the hooked rodrigues() is the reference's own code: its atan2f must be the strict one too
+    if orc.ref() is not None:
+        orc.ref().ref_set_math_mode(1)  # the hooked rodrigues() is the reference's own code: its atan2f must be the strict one too
     try:
         o = run_oracle(c)
     finally:
         orc.lib().orc_set_strict_math(0)
-        orc.ref().ref_set_math_mode(0)
+        if orc.ref() is not None:
+            orc.ref().ref_set_math_mode(0)
     assert o["n_registered"] == int(g[f"{name}/n_registered"])
     assert np.array_equal(bits(o["depth"]), bits(g[f"{name}/depth"]))
     assert np.array_equal(bits(o["depth_conf"]), bits(g[f"{name}/depth_conf"]))

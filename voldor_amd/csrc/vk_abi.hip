@@ -106,6 +106,12 @@ bool strict_math_default() {
     return g_strict_math != 0;
 }
 void set_strict_math_default(int on) { std::lock_guard<std::mutex> lk(g_mu); g_strict_math = on ? 1 : 0; }
+static int g_reference_svd = -1;  // -1: not set -> environment VOLDOR_HIP_REFERENCE_SVD
+bool reference_svd_default() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_reference_svd < 0) { const char* e = getenv("VOLDOR_HIP_REFERENCE_SVD"); g_reference_svd = (e && e[0] == '1') ? 1 : 0; }
+    return g_reference_svd != 0;
+}
 
 int prof_begin(Context* c) { return (int)hipEventRecord(c->ev0, c->stream); }
 int prof_end(Context* c, const char* name) {
@@ -261,7 +267,7 @@ static int solve_batch_host(float* h_p3s, float* h_p2s, float* h_o_rvecs, float*
     VK_CHECK(hipMemcpyAsync(c->n_points.p, &N_pts, sizeof(int), hipMemcpyHostToDevice, c->stream));
     VK_CHECK(hipStreamSynchronize(c->stream));
     if (int e = solve_device(c, c->pts2.as<float>(), c->pts3.as<float>(), c->n_points.as<int>(), h_K[0], h_K[4], h_K[2], h_K[5],
-                             N_poses, solver, strict_math_default()))
+                             N_poses, solver, strict_math_default(), nullptr, reference_svd_default()))
         return e;
     VK_CHECK(hipMemcpyAsync(h_o_rvecs, c->rvecs.p, sizeof(float) * 3 * (size_t)N_poses, hipMemcpyDeviceToHost, c->stream));
     VK_CHECK(hipMemcpyAsync(h_o_tvecs, c->tvecs.p, sizeof(float) * 3 * (size_t)N_poses, hipMemcpyDeviceToHost, c->stream));
@@ -475,6 +481,8 @@ int vk_set_rand_epoch(unsigned epoch) {
 }
 int vk_set_strict_math(int on) { set_strict_math_default(on); return 0; }
 int vk_get_strict_math(void) { return strict_math_default() ? 1 : 0; }
+int vk_set_reference_svd(int on) { std::lock_guard<std::mutex> lk(g_mu); g_reference_svd = on ? 1 : 0; return 0; }
+int vk_get_reference_svd(void) { return reference_svd_default() ? 1 : 0; }
 unsigned vk_get_rand_epoch(void) {
     Context* c = default_context();
     return c ? c->rand_epoch : 0u;

@@ -4,7 +4,7 @@
 //
 // Launch structure per optimize_depth call (reference: 20+ launches, 10 of them streaming a
 // 48-byte RNG state per pixel):
-//   fb_rows / fb_cols           2 launches per map set (reference: 6): one lane per 40-step line segment,
+//   fb_rows / fb_cols           2 launches per map set (reference: 6): one lane per 20-step (40 on very large images) line segment,
 //                               segment maps composed as 2x2 projective matrices, chained through LDS
 //   cost_rand                   1 launch: cost map + all n_rand samples, depth/cost in regs
 //   global_prop x4              1 launch each, one thread per candidate site (step>=2)
@@ -957,7 +957,10 @@ __global__ static void k_reduce_density(const float* __restrict__ partial, int n
 // once per pass and the forward-message scratch of the reference (fb_smooth.h:14-15) is not needed.
 // Rounding differs from the step-by-step evaluation by a few ulp per step (the recurrence contracts,
 // nothing accumulates): deviation D7 in DESIGN.md, stage parity test_fb_smooth_alone_matches_oracle.
-constexpr int FB_SEG = 20;  // steps per lane (multiple of 4: 16-byte row accesses).  40 -> 20: the row pass of a 640x480 x 5 window is only 600 waves and its time is the dependent chain of 2 x FB_SEG steps (15.6 -> 12.5 us per pass); 1080 rows / 20 x 16 columns still fit a 1024-thread workgroup
+// Steps per lane: template parameter FB_SEG of everything below (multiple of 4: 16-byte row accesses).  20 where the line fits
+// its workgroup (rows up to 5120 pixels, columns up to 1280): the row pass of a 640x480 x 5 window is only 600 waves and its time is
+// the dependent chain of 2 x FB_SEG steps (40 -> 20: 15.6 -> 12.5 us per pass); 40 for lines up to twice that (2560x1440, 4K,
+// portrait 1080x1920); beyond (10240 x 2560) the pass falls back to one lane per line (fb_smooth_strict_device: any size).
 struct FbCoef { float p, q, dd, e0, e0p, e0dd, qe0, pqe0, pq; };
 __device__ __forceinline__ FbCoef fb_coef(float e0, float p) {
     FbCoef k;
@@ -971,6 +974,7 @@ __device__ __forceinline__ float fb_apply(const FbMat& M, float x) {
     return n1 * fast_rcp(n1 + n0);
 }
 // segment matrices: F = A_{n-1} ... A_0 with A_t = diag(e_t, e0) T ; B = C_0 ... C_{n-1} with C_t = T diag(e_t, e0)
+template <int FB_SEG>
 __device__ __forceinline__ void fb_compose(const FbCoef& K, const float (&e)[FB_SEG], int n, FbMat& F, FbMat& B) {
     F = { 1.f, 0.f, 0.f, 1.f }; B = { 1.f, 0.f, 0.f, 1.f };
 #pragma unroll
@@ -993,6 +997,7 @@ __device__ __forceinline__ void fb_compose(const FbCoef& K, const float (&e)[FB_
 }
 // re-walk of one segment: forward messages, then backward messages fused with the posterior (:65-69);
 // e[] is overwritten with the smoothed values
+template <int FB_SEG>
 __device__ __forceinline__ void fb_walk(const FbCoef& K, float (&e)[FB_SEG], int n, float xf, float xb) {
     float Fm[FB_SEG];
 #pragma unroll
@@ -1025,7 +1030,7 @@ __device__ __forceinline__ void fb_incoming(const FbMat* sF, const FbMat* sB, in
 // Row pass: thread = (row, segment), segments of a row on adjacent lanes -> a wave reads whole contiguous row
 // pieces (160 bytes per lane).  256 threads = floor(256/S) rows.
 struct __attribute__((packed, aligned(4))) FbQuad { float x, y, z, w; };  // 16 bytes at 4-byte alignment: one global_load_dwordx4 on gfx950
-template <bool VEC4>
+template <bool VEC4, int FB_SEG>
 __global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps, int w, int h, int S, float e0, float p, const int* __restrict__ n_dev,
                                                         int n_maps, PoseBlock* cumP, int cumN, int cumNdp, float* world_scale) {
     __shared__ FbMat sF[256], sB[256];
@@ -1062,13 +1067,13 @@ __global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps
     }
     const float first = m[0], last = m[w - 1];
     FbMat F, B;
-    fb_compose(K, e, n, F, B);
+    fb_compose<FB_SEG>(K, e, n, F, B);
     sF[tid] = F; sB[tid] = B;
     __syncthreads();
     if (!live) return;
     float xf, xb;
     fb_incoming(sF + ll * S, sB + ll * S, 1, seg, S, first, last, xf, xb);
-    fb_walk(K, e, n, xf, xb);
+    fb_walk<FB_SEG>(K, e, n, xf, xb);
     if (VEC4) {
 #pragma unroll
         for (int k = 0; k < FB_SEG / 4; k++)
@@ -1087,6 +1092,7 @@ __global__ __launch_bounds__(256) static void k_fb_rows(float* __restrict__ maps
 // Column pass: thread = (segment, column); FB_CW adjacent columns share a workgroup, so every access is a
 // contiguous 64-byte row piece and a workgroup is FB_CW * S threads (S <= 64).
 constexpr int FB_CW = 16;
+template <int FB_SEG>
 __global__ __launch_bounds__(1024) static void k_fb_cols(float* __restrict__ maps, int w, int h, int S, float e0, float p, const int* __restrict__ n_dev) {
     __shared__ FbMat sF[1024], sB[1024];
     if (n_dev && (int)blockIdx.y >= *n_dev) return;
@@ -1100,31 +1106,45 @@ __global__ __launch_bounds__(1024) static void k_fb_cols(float* __restrict__ map
     for (int k = 0; k < FB_SEG; k++) e[k] = (k < n) ? m[(size_t)(r0 + k) * w] : 0.5f;
     const float first = m[0], last = m[(size_t)(h - 1) * w];
     FbMat F, B;
-    fb_compose(K, e, n, F, B);
+    fb_compose<FB_SEG>(K, e, n, F, B);
     sF[tid] = F; sB[tid] = B;
     __syncthreads();
     if (!live) return;
     float xf, xb;
     fb_incoming(sF + cl, sB + cl, FB_CW, seg, S, first, last, xf, xb);
-    fb_walk(K, e, n, xf, xb);
+    fb_walk<FB_SEG>(K, e, n, xf, xb);
 #pragma unroll
     for (int k = 0; k < FB_SEG; k++) if (k < n) m[(size_t)(r0 + k) * w] = e[k];
 }
 
+template <int SEG>
+static void fb_rows_launch(Context* c, float* maps, int n_maps, int w, int h, float e0, float p, const int* n_dev, PoseBlock* cumP, int cumN, int cumNdp,
+                           float* world_scale) {
+    const int Sr = (w + SEG - 1) / SEG, lpb = 256 / Sr;
+    const bool vec4 = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(maps) % 16) == 0;
+    const dim3 g((h + lpb - 1) / lpb, n_maps + (cumP ? 1 : 0));
+    if (vec4) hipLaunchKernelGGL((k_fb_rows<true, SEG>), g, dim3(256), 0, c->stream, maps, w, h, Sr, e0, p, n_dev, n_maps, cumP, cumN, cumNdp, world_scale);
+    else hipLaunchKernelGGL((k_fb_rows<false, SEG>), g, dim3(256), 0, c->stream, maps, w, h, Sr, e0, p, n_dev, n_maps, cumP, cumN, cumNdp, world_scale);
+}
+template <int SEG>
+static void fb_cols_launch(Context* c, float* maps, int n_maps, int w, int h, float e0, float p, const int* n_dev) {
+    const int Sc = (h + SEG - 1) / SEG;
+    hipLaunchKernelGGL(k_fb_cols<SEG>, dim3((w + FB_CW - 1) / FB_CW, n_maps), dim3(FB_CW * Sc), 0, c->stream, maps, w, h, Sc, e0, p, n_dev);
+}
+constexpr int FB_MAX_ROW_SEGS = 256, FB_MAX_COL_SEGS = 1024 / FB_CW;
 int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev, PoseBlock* cumP,
                      int cumN, int cumNdp, float* world_scale) {
     if (n_maps <= 0) return 0;
-    const int Sr = (w + FB_SEG - 1) / FB_SEG, Sc = (h + FB_SEG - 1) / FB_SEG;
-    if (Sr > 256 || Sc * FB_CW > 1024) {
-        fprintf(stderr, "voldor_hip: fb_smooth supports images up to %d x %d\n", 256 * FB_SEG, 1024 / FB_CW * FB_SEG);
-        return (int)hipErrorInvalidValue;
+    if (w > 40 * FB_MAX_ROW_SEGS || h > 40 * FB_MAX_COL_SEGS) {
+        // larger than any segmented launch: one lane per line walks the recurrence step by step (the reference's own structure,
+        // fb_smooth.h:26-69; no size limit).  The projective maps of the cost kernels then need their own launch.
+        if (cumP) hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, cumP, cumN, cumNdp, world_scale);
+        return fb_smooth_strict_device(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
     }
-    const int lpb = 256 / Sr;
-    const bool vec4 = (w % 4) == 0 && (reinterpret_cast<uintptr_t>(maps) % 16) == 0;
-    const int layers = n_maps + (cumP ? 1 : 0);
-    if (vec4) hipLaunchKernelGGL(k_fb_rows<true>, dim3((h + lpb - 1) / lpb, layers), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob, n_dev, n_maps, cumP, cumN, cumNdp, world_scale);
-    else hipLaunchKernelGGL(k_fb_rows<false>, dim3((h + lpb - 1) / lpb, layers), dim3(256), 0, c->stream, maps, w, h, Sr, s0_ems_prob, no_change_prob, n_dev, n_maps, cumP, cumN, cumNdp, world_scale);
-    hipLaunchKernelGGL(k_fb_cols, dim3((w + FB_CW - 1) / FB_CW, n_maps), dim3(FB_CW * Sc), 0, c->stream, maps, w, h, Sc, s0_ems_prob, no_change_prob, n_dev);
+    if (w <= 20 * FB_MAX_ROW_SEGS) fb_rows_launch<20>(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
+    else fb_rows_launch<40>(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
+    if (h <= 20 * FB_MAX_COL_SEGS) fb_cols_launch<20>(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
+    else fb_cols_launch<40>(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
     VK_CHECK_LAST();
     return 0;
 }

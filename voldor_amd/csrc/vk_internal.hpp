@@ -64,11 +64,11 @@ int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk
 int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
                    float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact);
 int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, float fx, float fy, float cx, float cy,
-                 int n_poses, int solver, bool strict = false, CamState* cam_dev = nullptr);
+                 int n_poses, int solver, bool strict = false, CamState* cam_dev = nullptr, bool ref_svd = false);
 // draw = 0: rejection over the map (D3b), falling back to the compacted list below DRAW_LIST_DENSITY; 1: always the reference's
 // index draw over the compacted list (geometry.cpp:68-88 + solve_batch_lambdatwist.cu:16-19); -1: rejection only (tests)
 int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev,
-                           int draw = 0, bool strict = false);
+                           int draw = 0, bool strict = false, bool ref_svd = false);
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first = false);
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
@@ -78,5 +78,6 @@ int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, 
 
 // vk_abi.hip: process-wide default of the strict-math mode (vk_set_strict_math / VOLDOR_HIP_STRICT_MATH)
 bool strict_math_default();
+bool reference_svd_default();  // vk_set_reference_svd / VOLDOR_HIP_REFERENCE_SVD: rodrigues() through the reference's approximate SVD (vk_ref_svd.h)
 
 }  // namespace vk

@@ -15,6 +15,7 @@
 #include "vk_common.hpp"
 #include "vk_device.hpp"
 #include "vk_p3p.hpp"
+#include "vk_ref_svd.h"
 #include "vk_internal.hpp"
 
 namespace vk {
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                                                       float* __restrict__ rvecs, float* __restrict__ tvecs,
                                                       int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk,
                                                       CamState* cam, int npx, float fx, float fy, float cx, float cy, int n_poses,
-                                                      int draw /* 0 auto, 1 rank select (reference draw), -1 rejection only */, int strict) {
+                                                      int draw /* 0 auto, 1 rank select (reference draw), -1 rejection only */, int strict /* bit 0: strict math, bit 1: reference SVD */) {
     // LambdaTwist: four lanes per hypothesis, one candidate root each (the candidates are independent once the
     // shared cubic / eigen-decomposition is done; a lane per hypothesis walks them one after the other and the wave
     // waits for its slowest lane).  AP3P keeps one lane per hypothesis.
@@ -315,12 +316,16 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
         if (drawn) {
             if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf);
             else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errd);
-            else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t, strict != 0);
+            else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t, (strict & 1) != 0);
         }
     }
     PH_MARK(11);
     float aa[3] = { qnan, qnan, qnan };
-    if (ok) { nearest_rotation(R); rotmat_to_angle_axis(R, aa, strict != 0); }
+    if (ok) {
+        // rodrigues.h:82-114.  Default: the exact polar factor (D8); --reference_svd 1: U V^T of the reference's approximate SVD, bit for bit
+        if (strict & 2) vrs_project_rotation(R); else nearest_rotation(R);
+        rotmat_to_angle_axis(R, aa, (strict & 1) != 0);
+    }
     PH_MARK(12);
     bool writer = true;
     if (LPH == 4) {
@@ -1374,7 +1379,7 @@ int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int activ
 
 template <bool FROM_MAP>
 static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, CamState* cam, int npx, float fx, float fy,
-                        float cx, float cy, int n_poses, int solver, int draw, bool strict) {
+                        float cx, float cy, int n_poses, int solver, int draw, bool strict, bool ref_svd) {
     if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     const int lph = (solver == 1) ? 1 : 4;  // lanes per hypothesis (k_solve)
@@ -1383,7 +1388,7 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
     const int* bc = c->blk_counts.as<int>(); const int nb = FROM_MAP ? c->n_map_blocks : 0;
     const size_t lds = FROM_MAP ? sizeof(int) * (size_t)nb : 0;  // prefix of the block counts (rank-select draw)
     if (lds > 60 * 1024) { fprintf(stderr, "voldor_hip: image too large for the rank-select draw (%d blocks)\n", nb); return (int)hipErrorInvalidValue; }
-    const int st = strict ? 1 : 0;
+    const int st = (strict ? 1 : 0) | (ref_svd ? 2 : 0);
     if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st);
     else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st);
     else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st);
@@ -1391,13 +1396,13 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
     return 0;
 }
 int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, float fx, float fy, float cx, float cy,
-                 int n_poses, int solver, bool strict, CamState* cam_dev) {
-    return solve_launch<false>(c, pts2, pts3, n_pts_dev, cam_dev, 0, fx, fy, cx, cy, n_poses, solver, 0, strict);
+                 int n_poses, int solver, bool strict, CamState* cam_dev, bool ref_svd) {
+    return solve_launch<false>(c, pts2, pts3, n_pts_dev, cam_dev, 0, fx, fy, cx, cy, n_poses, solver, 0, strict, ref_svd);
 }
 int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev, int draw,
-                           bool strict) {
+                           bool strict, bool ref_svd) {
     return solve_launch<true>(c, c->p2_map.as<float>(), c->p3_map.as<float>(), c->n_points.as<int>(), cam_dev, npx, fx, fy, cx, cy, n_poses,
-                              solver, draw, strict);
+                              solver, draw, strict, ref_svd);
 }
 
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first) {

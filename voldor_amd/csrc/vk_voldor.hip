@@ -46,7 +46,10 @@ struct Config {
     //  reference_draw  1: pose hypotheses index the row-major list of valid correspondences like geometry.cpp:68-88 +
     //                  solve_batch_lambdatwist.cu:16-19 (rank select over the map); 0: rejection draw (D3b) with that draw as the
     //                  low-density fallback
-    int strict_math = -1, reference_draw = 0;
+    //  reference_svd   1: rodrigues() of every pose hypothesis through the reference's approximate fp32 SVD (svd3_cuda.h restated to the bit
+    //                  in vk_ref_svd.h) instead of the exact polar factor (D8); with strict_math and reference_draw a window then equals the
+    //                  REFERENCE pipeline's strict window bit for bit; -1 (default) = the process-wide setting of vk_set_reference_svd
+    int strict_math = -1, reference_draw = 0, reference_svd = -1;
 
     // Returns 0, or non-zero where the reference prints and calls exit(1) (config.h:101-108,245-248):
     // a library must not exit its host process, so the error is reported to the caller instead.
@@ -65,7 +68,7 @@ struct Config {
             KI(depth_global_prop_step), KI(depth_local_prop_width), KF(depth_range_factor), KI(meanshift_max_iters),
             KI(meanshift_max_init_trials), KF(meanshift_good_init_confidence), KF(meanshift_epsilon), KI(kitti_estimate_ground),
             KI(kitti_ground_holo_width), KF(kitti_ground_roi), KF(kitti_ground_meanshift_kernel_var),
-            KI(strict_math), KI(reference_draw),
+            KI(strict_math), KI(reference_draw), KI(reference_svd),
         };
 #undef KF
 #undef KI
@@ -197,7 +200,8 @@ struct Voldor {
         // cpu_p3p=1 selects the reference's CPU instantiation lambdatwist_p4p<double,...> (geometry.cpp:112)
         const int solver = cfg.lambdatwist ? (cfg.cpu_p3p ? 2 : 0) : 1;
         if (int e = solve_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i,
-                                           cfg.reference_draw ? 1 : 0, strict))
+                                           cfg.reference_draw ? 1 : 0, strict,
+                                           cfg.reference_svd < 0 ? reference_svd_default() : cfg.reference_svd != 0))
             return e;
         ModeParams mp{};
         mp.dims = 6; mp.kernel_var = cfg.meanshift_kernel_var; mp.ms_epsilon = cfg.meanshift_epsilon;

@@ -206,6 +206,15 @@ def get_strict_math() -> bool:
     return bool(capi.lib().vk_get_strict_math())
 
 
+def set_reference_svd(on: bool):
+    """Process-wide default of rodrigues() through the reference's approximate SVD (include/voldor_hip.h: vk_set_reference_svd)."""
+    capi.check(capi.lib().vk_set_reference_svd(1 if on else 0), "vk_set_reference_svd")
+
+
+def get_reference_svd() -> bool:
+    return bool(capi.lib().vk_get_reference_svd())
+
+
 def set_local_serial(on: bool):
     """Verification aid (include/voldor_hip.h: vk_set_local_serial): step-by-step local propagation in fast mode."""
     capi.check(capi.lib().vk_set_local_serial(int(on)), "vk_set_local_serial")
