@@ -75,7 +75,10 @@ def main():
     ap.add_argument("--prewarm-s", type=float, default=0.5, help="untimed seconds of windows before the warm-up steps (GPU clock ramp-up)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="cfg2")
     ap.add_argument("--in-flight", type=int, default=4, help="windows in flight for the extra 'concurrent' measurement (0 = skip)")
-    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group and run the pose all-gather also with one rank (tests)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL communicator and run the pose all-gather also with one rank (tests)")
+    ap.add_argument("--dist-frontend", choices=("capi", "torch"), default="capi",
+                    help="capi: the exchange below the C-ABI (vk_voldor_sharded: ncclAllGather issued by libvoldor_hip.so, C++ host); "
+                         "torch: the same records through torch.distributed (backend nccl = RCCL)")
     ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive / strict / concurrent / CPU legs (profiling runs)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -93,10 +96,6 @@ def main():
         raise SystemExit("bench.py needs a HIP device: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # backend nccl == RCCL on ROCm
     if args.no_extras:
         args.no_cpu_baseline = True
         args.in_flight = 0
@@ -106,6 +105,30 @@ def main():
 
     lib = capi.lib()
     capi.check(lib.vk_set_device(local_rank), "vk_set_device")
+    frontend, frontend_note = None, None
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        frontend = args.dist_frontend
+        if frontend == "capi":
+            # The communicator lives inside libvoldor_hip.so (vk_dist.hip, C++).  Python only carries rank 0's 128-byte ncclUniqueId
+            # to the other ranks through a TCPStore (no torch process group, no torch collective).  The library binds the RCCL this
+            # process already ships (torch's, built against the HIP runtime loaded above) unless VOLDOR_HIP_RCCL says otherwise.
+            trccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+            if os.path.exists(trccl):
+                os.environ.setdefault("VOLDOR_HIP_RCCL", trccl)
+            try:
+                import datetime
+                store = None
+                if world > 1:
+                    store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, rank == 0, timeout=datetime.timedelta(seconds=300))
+                vdist.capi_init(rank, world, store=store)
+            except Exception as e:  # never lose the scaling run to the rendezvous: fall back to the torch front end, and say so
+                if world > 1:
+                    raise
+                frontend, frontend_note = "torch", f"capi front end unavailable ({e}); fell back to torch.distributed"
+        if frontend == "torch":
+            dist.init_process_group("nccl", rank=rank, world_size=world)  # backend nccl == RCCL on ROCm
     basefocal = wl["basefocal"]
     sc = synth.make_scene(w=W, h=H, n_flows=N_FLOW, fx=FX, fy=FY, cx=CX, cy=CY, seed=233 + rank,
                           basefocal=basefocal if wl["mode"] != "mono" else 0.0)
@@ -120,16 +143,23 @@ def main():
     send = torch.zeros(blk, device="cuda")
     recv = torch.zeros(world * blk, device="cuda")
 
+    blocks_host = [None]
+
     def step():
+        if frontend == "capi":  # window + ncclAllGather of the 1 + 42 N float records, both inside the library (vk_voldor_sharded)
+            out, blocks_host[0] = pyvoldor.voldor_sharded(flows, FX, FY, CX, CY, config=CONFIG, depth_out=depth, depth_conf_out=conf, **extra)
+            return out
         # the library leaves [n_registered | poses N x 6 | covar N x 36] in `send` on the device (vk_voldor_device_block)
         out = pyvoldor.voldor_device(flows, FX, FY, CX, CY, config=CONFIG, depth_out=depth, depth_conf_out=conf, pose_block_out=send, **extra)
-        if use_dist:  # pose exchange: one RCCL all-gather of 1 + 42 N floats per rank, device to device
+        if frontend == "torch":  # pose exchange: one RCCL all-gather of 1 + 42 N floats per rank, device to device
             dist.all_gather_into_tensor(recv, send)
         return out
 
     def fence():
         torch.cuda.synchronize()
-        if use_dist:
+        if frontend == "capi":
+            vdist.capi_barrier()
+        elif frontend == "torch":
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,10 +177,15 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if use_dist:
-        tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        blocks = recv.view(world, -1).cpu().numpy()  # every rank holds every rank's result
+        if frontend == "capi":
+            dt = vdist.capi_max(dt)
+            blocks = blocks_host[0]
+        else:
+            tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+            blocks = recv.view(world, -1).cpu().numpy()  # every rank holds every rank's result
+        assert all(int(round(float(blocks[r, 0]))) >= 0 for r in range(world)), blocks[:, 0]
         assert int(round(float(blocks[rank, 0]))) == int(out["n_registered"]) and np.array_equal(blocks[rank, 1:1 + 6 * int(out["n_registered"])], out["poses"].reshape(-1))
     ms_per_step = dt / args.steps * 1e3
     value = world * args.steps / dt
@@ -176,21 +211,29 @@ def main():
         b_cr = W * H * (12 * N_FLOW + 12 * n_dp + 16)
         nmax = 4 if N_FLOW <= 4 else 6 if N_FLOW <= 6 else 8 if N_FLOW <= 8 else 12 if N_FLOW <= 12 else 16
         kname = f"vk::k_cost_rand_q<{nmax}>"
-        traffic = valu = None
+        traffic = valu = group_traffic = None
         sqc = {}
-        def pmc_file(kind):  # the latest PMC pass of this workload that is committed (r02j, r02h: final kernels; r02c: earlier)
-            for tag in ("r02j", "r02h", "r02c"):
+        src = {}
+        def pmc_file(kind):  # the latest committed PMC pass of this workload (collected separately: rocprofv3 cannot time and count in one run)
+            for tag in ("r03c", "r03b", "r03a", "r02j", "r02h", "r02c"):
                 f = os.path.join(ROOT, "profiles", f"{tag}_pmc_{kind}_{args.workload}.json")
                 if os.path.exists(f):
                     return f
             raise FileNotFoundError(kind)
-        try:  # PMC passes of this workload (collected separately: rocprofv3 cannot time and count in one run)
-            ks = json.load(open(pmc_file("traffic")))["kernels"]
+        def provenance(f, doc):  # these numbers are REPLAYED from a committed counter pass, not measured by this run
+            return {"file": os.path.relpath(f, ROOT), "commit": doc.get("commit"), "replayed": True}
+        try:
+            f = pmc_file("traffic"); doc = json.load(open(f)); ks = doc["kernels"]
             traffic = ks[kname]["hbm_bytes_per_launch"]
+            src["traffic"] = provenance(f, doc)
+            od_kernels = ("k_fb_rows", "k_fb_cols", "k_cum_poses", "k_cost_rand_q", "k_global_prop", "k_local_table", "k_local_runs", "k_local_pass", "k_update_rigidness", "k_reduce_density")
+            # k_cost_rand_q runs once per optimize_depth call: launches relative to it = launches per call
+            group_traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in ks.items() if any(t in k for t in od_kernels)) / ks[kname]["launches"]
         except Exception:
             pass
         try:
-            sqc = json.load(open(pmc_file("sq")))[kname]
+            f = pmc_file("sq"); doc = json.load(open(f)); sqc = doc[kname]
+            src["sq"] = provenance(f, doc)
             # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves (MI355X_MICROARCH.md): x4 = cycles some SIMD spent issuing VALU;
             # over 1024 SIMDs and the launch duration at the 2.4 GHz peak clock = the fraction of VALU issue slots used
             valu = sqc["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sqc["avg_us_under_pmc"] * 1e-6 * 2.4e9)
@@ -198,15 +241,25 @@ def main():
             pass
         if "cost_rand" in groups and "optimize_depth" in groups:
             t_cr = groups["cost_rand"]["avg_us"] * 1e-6
-            ach = b_cr / t_cr / 1e9
+            ach_k = b_cr / t_cr / 1e9
             t_od = groups["optimize_depth"]["avg_us"] * 1e-6
-            roof = {"bound": "hbm", "kernel": kname + " (cost map + random depth samples: exact early rejection, survivor queue in LDS; 1 launch per optimize_depth call)",
+            ach = b_od / t_od / 1e9
+            # Primary figure = SURVEY.md section 8(d)'s definition: unit = one optimize_depth call (one EM iteration's depth half, a
+            # group of dependent launches), achieved = B_od / (duration of the group, HIP events on the library's stream, this run).
+            roof = {"bound": "hbm", "kernel": "optimize_depth launch group (fb_smooth rows + columns, cost + random samples, 4 global + 4 local propagation passes, E-step, density reduction)",
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                    "algorithmic_bytes": b_cr, "avg_us": round(groups["cost_rand"]["avg_us"], 2), "traffic": traffic,
-                    "valu_issue_frac": None if valu is None else round(valu, 3),
-                    "sq_counters_per_launch": {k: sqc[k] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY") if k in sqc} or None,
-                    "optimize_depth_group": {"algorithmic_bytes": b_od, "avg_us": round(groups["optimize_depth"]["avg_us"], 2),
-                                             "achieved": round(b_od / t_od / 1e9, 2), "frac": round(b_od / t_od / 1e9 / HBM_PEAK_GBS, 5)},
+                    "algorithmic_bytes": b_od, "avg_us": round(groups["optimize_depth"]["avg_us"], 2),
+                    "traffic": None if group_traffic is None else round(group_traffic),
+                    "measured": "achieved / frac / avg_us: HIP events of THIS run; traffic, valu_issue_frac, sq_counters_per_launch: replayed from the committed rocprofv3 --pmc passes named in `source`",
+                    "source": src or None,
+                    "traffic_note": "TCC_EA read/write request counters converted to bytes as MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE x2 correction); that correction is "
+                                    "calibrated on wide coalesced reads -- for the 8-byte bilinear gathers of these kernels absolute bytes are an upper estimate (ratios between variants hold); "
+                                    "at cfg2 / cfg3 the working set is MALL resident and TCC-EA counts MALL hits as traffic",
+                    "kernel_frac": round(ach_k / HBM_PEAK_GBS, 5),
+                    "dominant_kernel": {"name": kname + " (cost map + random depth samples: exact early rejection, survivor queue in LDS; 1 launch per optimize_depth call)",
+                                        "algorithmic_bytes": b_cr, "avg_us": round(groups["cost_rand"]["avg_us"], 2), "achieved": round(ach_k, 2), "traffic": traffic,
+                                        "valu_issue_frac": None if valu is None else round(valu, 3),
+                                        "sq_counters_per_launch": {k: sqc[k] for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY") if k in sqc} or None},
                     "groups": {k: {kk: round(vv, 2) for kk, vv in v.items()} for k, v in groups.items()}}
 
     # ---- SURVEY 8(d)'s frame: host buffers in, host results out (py_voldor_wrapper), median of 20 after 3 warm-ups ----
@@ -343,14 +396,19 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"] + ", scene S seed 233+rank, inputs resident in HBM",
-                       "voldor_config": CONFIG, "parallelism": f"one sequence per GPU x{world}, RCCL all-gather of pose blocks"},
+                       "voldor_config": CONFIG, "parallelism": ("single GPU, one sequence, no collective" if not use_dist else
+                                       f"one sequence per GPU x{world}, one ncclAllGather (RCCL) of the {blk}-float pose records per step, "
+                                       + ("issued below the C-ABI by libvoldor_hip.so (vk_voldor_sharded)" if frontend == "capi" else "through torch.distributed"))
+                                      + (f"; {frontend_note}" if frontend_note else "")},
             "n_registered": int(out["n_registered"]),
             "pose_rpe_vs_gt": {"rot_rad_max": float(rot.max()) if len(rot) else None, "rel_trans_max": float(tr.max()) if len(tr) else None},
             "pose_rpe_vs_reference": vs_ref,
             "roofline": roof, "cpu_baseline": cpu, "cpu_reference": cpu_ref, "host_inclusive": host_inc, "strict": strict, "concurrent": conc,
         }
         print(json.dumps(line), flush=True)
-    if use_dist:
+    if frontend == "capi":
+        vdist.capi_finalize()
+    elif frontend == "torch":
         dist.destroy_process_group()
 
 

@@ -7,6 +7,7 @@
  * `int* n_registered` in place of `int&`; vk_voldor_device() is the same call for inputs that are
  * already resident in HBM (any pointer may be a device pointer; direction is inferred).
  * Section C: inspection / control helpers used by tests, bench.py and multi-GPU launchers.
+ * Section D: the multi-GPU exchange (RCCL) below the C-ABI.
  * All functions return 0 on success, else a HIP error code (message on stderr) unless noted.
  */
 #ifndef VOLDOR_HIP_H
@@ -141,6 +142,34 @@ int vk_profile_get(const char* name, double* total_ms, long* count);
 int vk_device_count(void);
 int vk_set_device(int dev);
 const char* vk_version(void);
+
+/* ---- D. multi-GPU (voldor_amd/csrc/vk_dist.hip).  The reference has no multi-GPU path (file-static device
+ * buffers, gpu-kernels/optimize_depth.cu:45-52): nothing to cite but the partition section 8e prescribes -- one process per GPU,
+ * independent sequences sharded across the ranks, no data-path collective, ONE ncclAllGather of the pose records
+ * { n_registered | poses[N][6] | poses_covar[N][36] } (1 + 42 N floats per rank) per batch step over RCCL / xGMI.
+ * The communicator, its stream and the device records are owned by the library (C++ host code); the launcher only carries
+ * the 128-byte ncclUniqueId of rank 0 to the other ranks (or names a file all ranks can see).  RCCL (librccl.so.1, or the path in
+ * VOLDOR_HIP_RCCL) is bound at the first call of this section.  Return codes: 0, a HIP error code, or 1000 + ncclResult_t. */
+#define VK_DIST_ID_BYTES 128
+int vk_dist_get_unique_id(void* id_out);                      /* rank 0: ncclGetUniqueId */
+int vk_dist_init(int rank, int world, const void* id);        /* ncclCommInitRank on the current device (vk_set_device first) */
+int vk_dist_init_file(int rank, int world, const char* path, int timeout_s); /* rendezvous through a file written by rank 0 */
+int vk_dist_rank(void);                                       /* -1 before vk_dist_init */
+int vk_dist_world(void);                                      /* 0 before vk_dist_init */
+int vk_dist_rccl_version(void);
+int vk_dist_allgather(const float* send_dev, float* recv_dev, int count); /* ncclAllGather of `count` floats per rank, device buffers; returns when done */
+int vk_dist_allreduce_max(double* io_host);                   /* max over the ranks (step timing); acts as a barrier */
+int vk_dist_barrier(void);
+/* One batch step of the sharded job: this rank's window through vk_voldor_device_block (arguments as vk_voldor_device; flows ==
+ * NULL: no sequence for this rank in this step), then the all-gather.  all_blocks_host[world][1 + 42 N] (host) receives every
+ * rank's record; n_registered = -1 marks an empty slot. */
+int vk_voldor_sharded(const float* flows, const float* disparity, const float* disparity_pconf,
+                      const float* depth_priors, const float* depth_prior_poses,
+                      const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+                      float basefocal, int N, int N_dp, int w, int h, const char* config,
+                      int* n_registered, float* poses, float* poses_covar, float* depth,
+                      float* depth_conf, float* all_blocks_host);
+int vk_dist_finalize(void);
 
 #pragma GCC visibility pop
 #ifdef __cplusplus

@@ -34,7 +34,9 @@ for k in sorted(acc, key=lambda k: -acc[k].get('SQ_BUSY_CYCLES', 0)):
         v['frac_wait_inst_any'] = v.get('SQ_WAIT_INST_ANY', 0) / wc
     if v.get('SQ_WAVES'): v['valu_insts_per_wave'] = v.get('SQ_INSTS_VALU', 0) / v['SQ_WAVES']
     out[k] = v
-json.dump(out, open(sys.argv[3], 'w'), indent=1)
 for k, v in list(out.items())[:16]:
     print(k[:40].ljust(40), ' '.join(f"{c}={x:.4g}" for c, x in v.items()))
+import os
+out['commit'] = os.environ.get('COMMIT')  # the tree the counters were collected on (bench.py quotes it as the source of its replayed figures)
+json.dump(out, open(sys.argv[3], 'w'), indent=1)
 PY

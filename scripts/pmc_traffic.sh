@@ -8,7 +8,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_${c}_$tag -- python bench.py --workload $WL --steps 2 --warmup 1 --no-extras > gpurun_out/pmc_${c}_$tag.log 2>&1
 done
 python - "$tag" "$WL" <<'PY'
-import csv, glob, json, collections, sys
+import csv, glob, json, collections, os, sys
 tag, wl = sys.argv[1], sys.argv[2]
 def load(c):
     f = glob.glob(f"gpurun_out/pmc_{c}_{tag}/**/*counter_collection.csv", recursive=True)[0]
@@ -23,7 +23,7 @@ F, W = load("FETCH_SIZE"), load("WRITE_SIZE")
 out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRITE_SIZE (pass 2) -- python bench.py --workload WL --steps 2 --warmup 1 "
                 "--no-cpu-baseline --in-flight 0; per-launch averages in KiB as reported.  gfx950: FETCH_SIZE reports 1/2 of the bytes of coalesced "
                 "reads (MI355X_MICROARCH.md), WRITE_SIZE is exact.  hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.",
-       "workload": wl, "kernels": {}}
+       "workload": wl, "commit": os.environ.get("COMMIT"), "kernels": {}}
 for k in sorted(F, key=lambda k: -F[k][0] * F[k][1]):
     w = W.get(k, (0.0, 0))[0]
     out["kernels"][k] = {"launches": F[k][1], "FETCH_SIZE_KiB": round(F[k][0], 1), "WRITE_SIZE_KiB": round(w, 1),

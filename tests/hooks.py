@@ -15,6 +15,7 @@ def lib():
     if _lib is None:
         from voldor_amd import build
         build.build()
+        assert build.build_test_lib() is not None
         _lib = C.CDLL(PATH)
         _lib.vk_host_u01.restype = C.c_float
         _lib.vk_host_rng.restype = C.c_uint

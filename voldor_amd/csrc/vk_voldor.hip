@@ -328,7 +328,7 @@ static int voldor_run_on(Context* c, const float* flows, const float* disparity,
     }
     VK_CHECK(hipStreamSynchronize(c->stream));
     memcpy(v.hcams, c->h_cams, sizeof(CamState) * MAX_FRAMES);
-    *n_registered = v.n_flows;
+    if (n_registered) *n_registered = v.n_flows;
     for (int i = 0; i < v.n_flows; i++) {
         if (poses) { memcpy(poses + i * 6, v.hcams[i].rvec, 12); memcpy(poses + i * 6 + 3, v.hcams[i].t, 12); }
         if (poses_covar) memcpy(poses_covar + i * 36, v.hcams[i].covar, sizeof(float) * 36);

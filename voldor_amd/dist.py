@@ -64,7 +64,12 @@ def allgather_pose_blocks(blk, group=None, device=None):
 def run_sharded(sequences, run_window, n_flows: int, group=None, device=None):
     """Process `sequences` (a list; item i is passed to run_window) sharded over the ranks, then exchange
     the pose blocks so that every rank holds the result of every sequence, in sequence order.
-    `run_window(item) -> dict` is pyvoldor.voldor-like. Ranks with fewer items pad with empty blocks."""
+    `run_window(item) -> dict` is pyvoldor.voldor-like; if the dict carries "pose_block" (the device record that
+    pyvoldor.voldor_device(pose_block_out=...) / vk_voldor_device_block packed: a torch tensor of block_len(n_flows) floats
+    where the collective runs) that record IS the send buffer -- no host packing; otherwise the block is packed from the host
+    arrays.  Ranks with fewer items pad with empty blocks.  Front end over torch.distributed (RCCL: backend "nccl"; gloo in the
+    CPU tests); the same step below the C-ABI is vk_voldor_sharded (capi_* functions of this module)."""
+    import torch
     import torch.distributed as dist
 
     rank, world = dist.get_rank(group), dist.get_world_size(group)
@@ -72,11 +77,91 @@ def run_sharded(sequences, run_window, n_flows: int, group=None, device=None):
     steps = -(-len(sequences) // world)
     results = [None] * len(sequences)
     for s in range(steps):
-        blk = np.zeros(block_len(n_flows), np.float32)
-        blk[0] = -1.0  # marks "no sequence in this slot"
+        blk = None
         if s < len(mine):
-            blk = pack_pose_block(run_window(sequences[mine[s]]), n_flows)
+            out = run_window(sequences[mine[s]])
+            blk = out.get("pose_block")
+            if blk is None:
+                blk = pack_pose_block(out, n_flows)
+        if blk is None:
+            blk = np.zeros(block_len(n_flows), np.float32)
+            blk[0] = -1.0  # marks "no sequence in this slot"
+            if device is not None and str(device) != "cpu":
+                blk = torch.from_numpy(blk).to(device)
         allb = allgather_pose_blocks(blk, group, device)
+        for r in range(world):
+            sh = list(shard(len(sequences), r, world))
+            if s < len(sh) and allb[r, 0] >= 0:
+                results[sh[s]] = unpack_pose_block(allb[r], n_flows)
+    return results
+
+
+# ---- the same exchange below the C-ABI: RCCL driven by libvoldor_hip.so itself (include/voldor_hip.h section D) ----------------
+def capi_init(rank: int, world: int, store=None, path: str | None = None, key: str = "voldor_hip_rccl_id"):
+    """vk_dist_init on the current device.  The 128-byte ncclUniqueId of rank 0 travels through `store` (anything with
+    set(key, bytes) / get(key) -> bytes: torch.distributed.TCPStore / FileStore -- rendezvous plumbing only) or, with `path`,
+    through a file every rank can see (vk_dist_init_file: no Python in the exchange at all)."""
+    import ctypes as C
+    from . import capi
+    lib = capi.lib()
+    if path is not None:
+        capi.check(lib.vk_dist_init_file(int(rank), int(world), str(path).encode(), 120), "vk_dist_init_file")
+        return
+    buf = (C.c_ubyte * 128)()
+    if rank == 0:
+        capi.check(lib.vk_dist_get_unique_id(buf), "vk_dist_get_unique_id")
+        if world > 1:
+            store.set(key, bytes(buf))
+    else:
+        raw = bytes(store.get(key))
+        assert len(raw) == 128, len(raw)
+        buf = (C.c_ubyte * 128).from_buffer_copy(raw)
+    capi.check(lib.vk_dist_init(int(rank), int(world), buf), "vk_dist_init")
+
+
+def capi_finalize():
+    from . import capi
+    capi.lib().vk_dist_finalize()
+
+
+def capi_barrier():
+    from . import capi
+    capi.check(capi.lib().vk_dist_barrier(), "vk_dist_barrier")
+
+
+def capi_max(value: float) -> float:
+    """max over the ranks of a host double (vk_dist_allreduce_max); also a barrier"""
+    import ctypes as C
+    from . import capi
+    v = C.c_double(float(value))
+    capi.check(capi.lib().vk_dist_allreduce_max(C.byref(v)), "vk_dist_allreduce_max")
+    return float(v.value)
+
+
+def capi_allgather(send, recv):
+    """ncclAllGather of send.numel() floats per rank between two torch float32 device tensors (vk_dist_allgather)."""
+    import ctypes as C
+    import torch
+    from . import capi
+    assert send.is_cuda and recv.is_cuda and send.dtype == recv.dtype == torch.float32 and send.is_contiguous() and recv.is_contiguous()
+    torch.cuda.current_stream().synchronize()  # the library's communicator has its own stream
+    PF = C.POINTER(C.c_float)
+    capi.check(capi.lib().vk_dist_allgather(C.cast(send.data_ptr(), PF), C.cast(recv.data_ptr(), PF), C.c_int(send.numel())), "vk_dist_allgather")
+
+
+def capi_run_sharded(sequences, run_step, n_flows: int):
+    """run_sharded over the C-ABI: `run_step(item_or_None) -> [world, block_len] array` is one vk_voldor_sharded call
+    (pyvoldor.voldor_sharded) -- the window of this rank's item (None: no item in this step) and the all-gather, both inside the
+    library.  Returns the per-sequence results on every rank, in sequence order."""
+    from . import capi
+    lib = capi.lib()
+    rank, world = lib.vk_dist_rank(), lib.vk_dist_world()
+    assert world >= 1, "capi_init first"
+    mine = list(shard(len(sequences), rank, world))
+    steps = -(-len(sequences) // world)
+    results = [None] * len(sequences)
+    for s in range(steps):
+        allb = run_step(sequences[mine[s]] if s < len(mine) else None)
         for r in range(world):
             sh = list(shard(len(sequences), r, world))
             if s < len(sh) and allb[r, 0] >= 0:

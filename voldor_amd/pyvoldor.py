@@ -129,6 +129,42 @@ def voldor_device(flows, fx, fy, cx, cy, basefocal=0, disparity=None, disparity_
     return {"n_registered": n, "poses": poses[:n], "poses_covar": poses_covar[:n], "depth": depth_out, "depth_conf": depth_conf_out}
 
 
+def voldor_sharded(flows, fx, fy, cx, cy, basefocal=0, disparity=None, config="", depth_out=None, depth_conf_out=None, n_flows=None, shape=None):
+    """One batch step of the multi-GPU job below the C-ABI (vk_voldor_sharded, include/voldor_hip.h section D): this rank's window
+    (torch device tensors as in voldor_device; flows=None when this rank has no sequence in this step -- then n_flows and
+    shape=(h, w) describe the job) followed by the RCCL all-gather of the pose records, both inside libvoldor_hip.so.
+    Returns (result dict of this rank's window or None, blocks[world, 1 + 42 N] float32: the record of every rank)."""
+    import torch
+
+    def dp(t):
+        if t is None:
+            return None
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()
+        return C.cast(t.data_ptr(), C.POINTER(C.c_float))
+
+    lib = capi.lib()
+    world = lib.vk_dist_world()
+    if world < 1:
+        raise capi.VoldorHipError("voldor_sharded needs voldor_amd.dist.capi_init (vk_dist_init) first")
+    if flows is not None:
+        N, h, w = flows.shape[0], flows.shape[1], flows.shape[2]
+        _check_shapes(tuple(flows.shape), None if disparity is None else tuple(disparity.shape), None, None, None, None)
+    else:
+        N, (h, w) = int(n_flows), shape
+    torch.cuda.current_stream().synchronize()  # see voldor_device
+    poses = np.zeros((N, 6), dtype=np.float32)
+    poses_covar = np.zeros((N, 6, 6), dtype=np.float32)
+    blocks = np.zeros((world, 1 + 42 * N), dtype=np.float32)
+    n_registered = C.c_int(0)
+    rc = lib.vk_voldor_sharded(dp(flows), dp(disparity), None, None, None, None, C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy),
+                               C.c_float(basefocal), C.c_int(N), C.c_int(0), C.c_int(w), C.c_int(h), str(config).encode(), C.byref(n_registered),
+                               capi.fp(poses), capi.fp(poses_covar), dp(depth_out), dp(depth_conf_out), capi.fp(blocks))
+    capi.check(rc, "vk_voldor_sharded")
+    n = n_registered.value
+    out = None if flows is None else {"n_registered": n, "poses": poses[:n], "poses_covar": poses_covar[:n], "depth": depth_out, "depth_conf": depth_conf_out}
+    return out, blocks
+
+
 def voldor_device_batch(flows_list, fx, fy, cx, cy, basefocal=0, disparity_list=None, config="", depth_out=None, depth_conf_out=None):
     """Several independent windows (same geometry / config) in flight together on the current device
     (vk_voldor_device_batch): flows_list[b] is a torch float32 CUDA(HIP) tensor [N,h,w,2]; depth_out / depth_conf_out are
