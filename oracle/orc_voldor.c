@@ -170,15 +170,14 @@ static int v_optimize_camera_pose(orc_voldor_t* v, int active_idx, int successiv
     const int np = c->n_poses_to_sample;
     float* rv = malloc(sizeof(float) * np * 3); float* tv = malloc(sizeof(float) * np * 3);
     float* pool = malloc(sizeof(float) * np * 6);
-    /* :99-170. cpu_p3p=1 is the reference's CPU path: lambdatwist_p4p<double,...> (:112). Draws: D3b by default;
-     * ORC_REFERENCE_DRAW=1 switches to the reference's own draw (index into the compacted list, geometry.cpp:68-80 +
-     * solve_batch_lambdatwist.cu:16-19, clamp D3) so that a whole window can be compared with the reference pipeline
-     * executed on the CPU (oracle/ref_wrap_host.cpp, tests/test_oracle_vs_ref_window.py). */
+    /* :99-170. cpu_p3p=1 is the reference's CPU path: lambdatwist_p4p<double,...> (:112).  Draw: the reference's own (index into the
+     * row-major compacted list, geometry.cpp:68-80 + solve_batch_lambdatwist.cu:16-19, clamp D3) -- the default since round 3: over the
+     * 24-window ensemble the rejection draw D3b, being an INDEPENDENT sample of the hypotheses, puts the depth maps 1.4x further from the
+     * reference's than the reference's own 1-ulp self-distance (tests/test_gpu_ensemble.py), the reference's draw does not.
+     * ORC_REFERENCE_DRAW=0 (product: --reference_draw 0) selects D3b: rejection over the map, which keeps the reference's draw as the
+     * fallback below 5 % valid pixels, where 256 probes per point start to lose hypotheses (product: DRAW_RANK_INV_DENSITY). */
     const char* ref_draw = getenv("ORC_REFERENCE_DRAW");
-    /* D3b keeps a fallback: below 5 % valid pixels the rejection draw (256 probes per point) starts to lose hypotheses, so the
-     * reference's own draw is used there (product: rank select in k_solve, DRAW_RANK_INV_DENSITY) and the pool keeps the
-     * reference's size at any density */
-    if ((ref_draw && ref_draw[0] == '1') || (long long)n_points * 20 < (long long)npx) {
+    if (!(ref_draw && ref_draw[0] == '0') || (long long)n_points * 20 < (long long)npx) {
         float* c2 = malloc(sizeof(float) * npx * 2); float* c3 = malloc(sizeof(float) * npx * 3);
         const int nc = orc_compact_p3p(p2m, p3m, npx, c2, c3);
         orc_solve_batch_p3p(c3, c2, rv, tv, K, nc, np, !c->lambdatwist, c->cpu_p3p ? 1 : 0);

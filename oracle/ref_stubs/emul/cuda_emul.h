@@ -93,8 +93,9 @@ static inline uint32_t emul_rng3(uint32_t seed, uint32_t stream, uint32_t counte
 static inline int emul_host_rand() { return (int)(emul_rng3(233u, emul_rand_trial++, 0x4D53u) % emul_rand_mod); }
 struct curandState { uint32_t seed, stream, counter; };
 static uint32_t emul_curand_epoch = 0;  /* the wrapper's stand-in for "states persist across calls": added to the offset */
+extern "C" unsigned int ref_rand_salt; /* ref_set_rand_salt: "the reference run again with another seed of its random streams" (0 = RAND_SEED as is) */
 static inline void curand_init(unsigned long long seed, unsigned long long sequence, unsigned long long offset, curandState* s) {
-    s->seed = (uint32_t)seed; s->stream = (uint32_t)sequence; s->counter = (uint32_t)offset + emul_curand_epoch;
+    s->seed = (uint32_t)seed ^ (ref_rand_salt * 0x9E3779B1u); s->stream = (uint32_t)sequence; s->counter = (uint32_t)offset + emul_curand_epoch;
 }
 static inline float curand_uniform(curandState* s) {  /* (0, 1] like cuRAND */
     const uint32_t r = emul_rng3(s->seed, s->stream, s->counter++);

@@ -157,6 +157,8 @@ int ref_gblur(float* src, float* dst, int w, int h, int d, float sigma, int ksiz
 // libm / strict / ulp-jitter switch of ref_stubs/emul/cuda_emul.h (and of minicv's Rodrigues)
 int ref_math_mode = 0;
 void ref_set_math_mode(int mode) { ref_math_mode = mode; }
+unsigned int ref_rand_salt = 0;
+void ref_set_rand_salt(unsigned int salt) { ref_rand_salt = salt; }
 unsigned int ref_jitter_salt = 0;
 void ref_set_jitter_salt(unsigned int salt) { ref_jitter_salt = salt; }
 // a new window: the next optimize_depth_gpu call re-creates its cuRAND states, starting from counter value `rand_epoch`

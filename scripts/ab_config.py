@@ -1,0 +1,19 @@
+"""Time one workload under several config suffixes (windows back to back, inputs resident).  usage: python scripts/ab_config.py cfg2 "" "--reference_draw 1" ..."""
+import sys, time
+sys.path.insert(0, ".")
+import numpy as np, torch
+from voldor_amd import pyvoldor, synth, kernels
+import bench
+wl = bench.WORKLOADS[sys.argv[1]]
+sc = synth.make_scene(w=wl["w"], h=wl["h"], n_flows=wl["n"], fx=wl["fx"], fy=wl["fx"], cx=wl["cx"], cy=wl["cy"], seed=233, basefocal=wl["basefocal"] if wl["mode"] != "mono" else 0.0)
+flows = torch.from_numpy(sc["flows"]).cuda()
+kw = dict(basefocal=wl["basefocal"], disparity=torch.from_numpy(sc["disparity"]).cuda()) if wl["mode"] == "stereo" else {}
+depth = torch.empty(wl["h"], wl["w"], device="cuda"); conf = torch.empty_like(depth)
+n = 30 if wl["w"] < 1900 else 8
+for rep in range(2):
+    for sfx in sys.argv[2:]:
+        for _ in range(3): pyvoldor.voldor_device(flows, wl["fx"], wl["fx"], wl["cx"], wl["cy"], config=wl["cfg"] + " " + sfx, depth_out=depth, depth_conf_out=conf, **kw)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): o = pyvoldor.voldor_device(flows, wl["fx"], wl["fx"], wl["cx"], wl["cy"], config=wl["cfg"] + " " + sfx, depth_out=depth, depth_conf_out=conf, **kw)
+        torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+        print(f"{sys.argv[1]} [{sfx:24s}] {dt*1e3:8.3f} ms/window  {1/dt:7.1f} windows/s  n_registered {o['n_registered']}")

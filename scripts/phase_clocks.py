@@ -12,7 +12,8 @@ import torch
 import bench
 from voldor_amd import capi, pyvoldor, synth
 
-wl = bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"]
+wl = dict(bench.WORKLOADS[sys.argv[1] if len(sys.argv) > 1 else "cfg2"])
+wl["cfg"] += " " + os.environ.get("CFG_SUFFIX", "")
 W, H, N = wl["w"], wl["h"], wl["n"]
 sc = synth.make_scene(w=W, h=H, n_flows=N, fx=wl["fx"], fy=wl["fx"], cx=wl["cx"], cy=wl["cy"], seed=233,
                       basefocal=wl["basefocal"] if wl["mode"] != "mono" else 0.0)

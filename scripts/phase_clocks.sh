@@ -8,13 +8,13 @@ LIB=voldor_amd/lib/libvoldor_hip_phase${PHASE_TAG}.so   # PHASE_TAG / PHASE_FLAG
 if [ "$1" = build ]; then
   F="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -fno-slp-vectorize -DVK_PHASE_CLOCKS -Iinclude $PHASE_FLAGS"
   objs=""
-  for f in vk_abi vk_depth vk_pose vk_strict vk_bootstrap vk_voldor vk_slam vk_align; do
+  for f in vk_abi vk_depth vk_pose vk_strict vk_bootstrap vk_voldor vk_slam vk_align vk_dist; do
     extra=""; case $f in vk_pose|vk_bootstrap|vk_strict) extra="-ffp-contract=off";; esac
     /opt/rocm/bin/hipcc $F $extra -c voldor_amd/csrc/$f.hip -o /tmp/phase${PHASE_TAG}_$f.o &
     objs="$objs /tmp/phase${PHASE_TAG}_$f.o"
   done
   wait
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $LIB $objs
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $LIB $objs -ldl
   echo built $LIB
 else
   VOLDOR_HIP_LIB=$PWD/$LIB python scripts/phase_clocks.py "${2:-cfg2}"

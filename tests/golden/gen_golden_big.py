@@ -50,10 +50,38 @@ def noise(which):
         print(f"wrote {path}", flush=True)
 
 
+def strict_ref(which):
+    """python tests/golden/gen_golden_big.py --strict-ref cfg3 -> tests/golden/ref_big_strict_cfg3.npz: the REFERENCE pipeline itself in
+    strict math (ref_set_math_mode(1)) at full size -- what the HIP window in `--strict_math 1 --reference_draw 1 --reference_svd 1`
+    must equal bit for bit (tests/test_gpu_configs.py): registered count, poses, covariances, sha256 of the depth / confidence maps
+    and every 8th pixel of them.  cfg3 ~4 min, cfg5 ~40 min on one core."""
+    ref = orc.ref()
+    for name in which:
+        c = big.make(name)
+        fx, fy, cx, cy = c["K"]
+        t0 = time.time()
+        ref.ref_set_math_mode(1)
+        try:
+            r = orc.ref_voldor(c["flows"], fx, fy, cx, cy, config=c["config"], basefocal=c["basefocal"], disparity=c["disparity"])
+        finally:
+            ref.ref_set_math_mode(0)
+        print(f"{name}: reference pipeline in strict math: {time.time() - t0:.0f} s, n_registered {r['n_registered']}", flush=True)
+        out = {f"{name}/ref_strict/n_registered": np.int32(r["n_registered"]), f"{name}/ref_strict/poses": r["poses"],
+               f"{name}/ref_strict/poses_covar": r["poses_covar"]}
+        for k in ("depth", "depth_conf"):
+            out[f"{name}/ref_strict/{k}_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(r[k]).tobytes()).digest(), np.uint8)
+            out[f"{name}/ref_strict/{k}_sub8"] = r[k][::8, ::8].copy()
+        path = os.path.join(HERE, f"ref_big_strict_{name}.npz")
+        np.savez_compressed(path, **out)
+        print(f"wrote {path}", flush=True)
+
+
 def main():
     which = [a for a in sys.argv[1:] if a in big.CASES] or list(big.CASES)
     if "--noise" in sys.argv:
         return noise(which)
+    if "--strict-ref" in sys.argv:
+        return strict_ref(which)
     path = os.path.join(HERE, "ref_big.npz")
     out = dict(np.load(path)) if os.path.exists(path) else {}
     for name in which:

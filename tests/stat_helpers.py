@@ -7,13 +7,15 @@ from scipy import stats
 
 from voldor_amd import synth
 
-METRICS = ("rot", "trans", "depth", "logcov")
+METRICS = ("rot", "trans", "depth", "within_1e-3", "logcov")
 
 
 def window_distance(a, b, scale_free=False):
     """Distances between two runs of one window (dicts with n_registered, poses, poses_covar, depth, depth_conf -- maps sampled on the
-    same grid).  rot / trans: worst pose of the window (geodesic rad, relative translation); depth: median relative difference over
-    the pixels both runs are confident about (NaN when fewer than 50); logcov: mean |log trace ratio| of the pose covariances.
+    same grid).  rot / trans: worst pose of the window (geodesic rad, relative translation); depth: 90th percentile of the relative
+    difference over the pixels both runs are confident about (NaN when fewer than 50; the median is useless here: two runs of the
+    reference that differ by 1-ulp jitter share most pixels bit for bit on stereo windows); within_1e-3: fraction of those pixels
+    within 1e-3 (north_star's depth bar); logcov: mean |log trace ratio| of the pose covariances.
     Returns None when the registered counts differ (tested separately)."""
     n = int(a["n_registered"])
     if n != int(b["n_registered"]) or n == 0:
@@ -27,7 +29,7 @@ def window_distance(a, b, scale_free=False):
     ta = np.trace(np.asarray(a["poses_covar"], np.float64), axis1=1, axis2=2)
     tb = np.trace(np.asarray(b["poses_covar"], np.float64), axis1=1, axis2=2)
     ok = (ta > 0) & (tb > 0)
-    return {"rot": float(rot.max()), "trans": float(tr.max()), "depth": float(np.median(rel)) if m.sum() >= 50 else float("nan"),
+    return {"rot": float(rot.max()), "trans": float(tr.max()), "depth": float(np.percentile(rel, 90)) if m.sum() >= 50 else float("nan"), "depth_median": float(np.median(rel)) if m.sum() >= 50 else float("nan"),
             "within_1e-3": float(np.mean(rel < 1e-3)) if m.sum() >= 50 else float("nan"),
             "logcov": float(np.mean(np.abs(np.log(ta[ok] / tb[ok])))) if ok.any() else float("nan")}
 

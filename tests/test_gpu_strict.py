@@ -216,85 +216,53 @@ def test_low_density_window_keeps_the_reference_pool(orc, strict):
     assert rot.max() < 2e-3 and tr.max() < 5e-2, (rot, tr)
 
 
-# ---- fast mode held to strict mode by the reference's own self-noise --------------------------------------------------------------
-def _pair_noise(gold, name):
-    """largest pose distance between two runs of the REFERENCE pipeline that differ only in the last bit of their transcendentals
-    (glibc / strict math / glibc with 1-ulp jitter): tests/golden/gen_golden_strict.py"""
-    from voldor_amd import synth
-    rots, trs, meds = [], [], []
-    for a, b in ((0, 1), (0, 2), (1, 2)):
-        r, t = synth.pose_errors(gold[f"{name}/m{a}/poses"], gold[f"{name}/m{b}/poses"])
-        rots.append(r.max()); trs.append(t.max()); meds.append(gold[f"{name}/depth_stats_m{a}_m{b}"][1])
-    return max(rots), max(trs), max(meds)
+# (fast mode vs strict mode over the 24-window ensemble, held to the reference's self-noise DISTRIBUTION: tests/test_gpu_ensemble.py)
 
 
-@pytest.mark.parametrize("name", ["mono_320x240", "cfg2_640x480"])
-def test_fast_vs_strict_within_the_reference_self_noise(orc, name):
-    """The fast kernels (hardware v_log/v_exp, fused multiply-adds, re-associated sums) against the strict ones on the same window,
-    same draws.  Two runs of the reference's OWN code that differ by one ulp in expf/powf/logf end up this far apart
-    (ref_selfnoise.npz: ~2e-4 rad, ~1e-2 relative translation, ~5e-4 median relative depth at cfg2 -- every near-tie of the depth
-    search can flip); fast-vs-strict is one more sample of that distribution, so it is asserted against twice the largest of the
-    three reference pairs.  This replaces the hand-set 3e-2 of round 1."""
-    import ref_window_cases as cases
-    from voldor_amd import kernels, pyvoldor, synth
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_selfnoise.npz"))
-    c = dict(cases.window_cases())["mono_320x240"] if name == "mono_320x240" else cases.cfg2_case()[1]
-    fx, fy, cx, cy = c["K"]
-    res = {}
-    for mode in ("strict", "fast"):
-        kernels.set_rand_epoch(0)
-        res[mode] = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, config=c["config"] + (" --strict_math 1" if mode == "strict" else " --strict_math 0"))
-    s, f = res["strict"], res["fast"]
-    assert s["n_registered"] == f["n_registered"] == int(gold[f"{name}/m0/n_registered"])
-    rot, tr = synth.pose_errors(f["poses"], s["poses"])
-    m = (s["depth_conf"] > 0.5) & (f["depth_conf"] > 0.5)
-    med = float(np.median(np.abs(f["depth"][m] - s["depth"][m]) / s["depth"][m]))
-    nr, nt, nd = _pair_noise(gold, name)
-    print(f"{name}: fast vs strict rot {rot.max():.2e} trans {tr.max():.2e} median depth {med:.2e}; reference self-noise {nr:.2e} {nt:.2e} {nd:.2e}")
-    assert rot.max() <= 2 * nr and tr.max() <= 2 * nt and med <= 2 * nd, (rot.max(), tr.max(), med, nr, nt, nd)
-    # both are as close to the reference's own glibc run as its other runs are
-    for r in (s, f):
-        rr, tt = synth.pose_errors(r["poses"], gold[f"{name}/m0/poses"])
-        assert rr.max() <= max(2 * nr, 1e-3) and tt.max() <= 2 * nt, (rr.max(), tt.max())
-    # covariance (an output of the boundary: the SLAM driver feeds it to its pose graph).  It comes from the hard-gated robust Gaussian,
-    # which keeps ~0.3 % of the samples: between the reference's own three runs its trace moves by up to 1.8x (cfg2).  Same yardstick:
-    # twice the largest log-ratio of the reference pairs, against the strict run and against the reference's glibc run.
-    tr_ = lambda c: np.trace(c, axis1=1, axis2=2)  # noqa: E731
-    spread = max(np.abs(np.log(tr_(gold[f"{name}/m{a}/poses_covar"]) / tr_(gold[f"{name}/m{b}/poses_covar"]))).max() for a, b in ((0, 1), (0, 2), (1, 2)))
-    for other in (s["poses_covar"], gold[f"{name}/m0/poses_covar"]):
-        lr = np.abs(np.log(tr_(f["poses_covar"]) / tr_(other)))
-        assert lr.max() <= 2 * spread, (lr, spread)
+VARIANTS = [  # (config suffix, estimator noise comparable to the default configuration?)
+    ("--n_poses_to_sample 1000", False),              # a pool that does not fill the mode kernel's registers (8x fewer hypotheses: noisier)
+    ("--meanshift_max_init_trials 3", True),          # fewer initial-mode trials than a batch
+    ("--meanshift_max_init_trials 100", True),        # more than k_mode_trials takes: the mode kernel runs them itself
+    ("--rg_refine 0", True),                          # no robust-Gaussian refit: k_pose_mode<false> on the last iteration too
+    ("--fb_smooth 0", True),                          # k_cum_poses as its own launch (no fb_smooth launch to ride on)
+    ("--norm_world_scale 0", True),                   # no world-scale factor in the E-step kernel
+    ("--depth_local_prop_width 70", True),            # chains longer than a wave: step-by-step local propagation
+    ("--depth_local_prop_width 48", True),            # one chain per wave (HALF = 64)
+    ("--depth_global_prop_step 1", True),             # serial global propagation
+    ("--max_trace_on_flow 0 --lambdatwist 0", False), # full-length flow traces; AP3P hypotheses (a different, noisier minimal solver)
+    ("--reference_draw 0", True),                     # the rejection draw D3b on both sides
+]
 
 
-@pytest.mark.parametrize("extra", [
-    "--n_poses_to_sample 1000",                 # a pool that does not fill the mode kernel's registers
-    "--meanshift_max_init_trials 3",            # fewer initial-mode trials than a batch
-    "--meanshift_max_init_trials 100",          # more than k_mode_trials takes: the mode kernel runs them itself
-    "--rg_refine 0",                            # no robust-Gaussian refit: k_pose_mode<false> on the last iteration too
-    "--fb_smooth 0",                            # k_cum_poses as its own launch (no fb_smooth launch to ride on)
-    "--norm_world_scale 0",                     # no world-scale factor in the E-step kernel
-    "--depth_local_prop_width 70",              # chains longer than a wave: step-by-step local propagation
-    "--depth_local_prop_width 48",              # one chain per wave (HALF = 64)
-    "--depth_global_prop_step 1",               # serial global propagation
-    "--max_trace_on_flow 0 --lambdatwist 0",    # full-length flow traces; AP3P hypotheses
-])
-def test_config_variants_fast_vs_strict(extra):
+def test_config_variants_fast_vs_strict():
     """Configurations that switch the fast pipeline onto its alternative kernels, each against the strict pipeline on the same
-    window (same draws): registered count equal, poses within twice the reference's self-noise at this size (ref_selfnoise.npz,
-    mono_320x240) -- a wrong code path shows as a lost window or a pose off by orders of magnitude more."""
+    window (same draws).  Registered counts equal; the pose distances of the variants whose estimator is as noisy as the default one
+    are RANKED inside the reference's own self-distances on this window (tests/golden/ref_window_noise.npz: the reference under eight
+    independent 1-ulp jitter patterns vs its glibc run) -- rank-sum test over the variants, p > 0.01, no tolerance; every variant
+    additionally stays within 10x the largest reference self-distance (a wrong code path loses the window or is off by orders of
+    magnitude)."""
     import ref_window_cases as cases
+    import stat_helpers as sh
     from voldor_amd import kernels, pyvoldor, synth
-    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_selfnoise.npz"))
-    c = dict(cases.window_cases())["mono_320x240"]
+    noise = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_window_noise.npz"))
+    name = "mono_320x240"
+    ref = [synth.pose_errors(noise[f"{name}/s{k}/poses"], noise[f"{name}/s0/poses"]) for k in range(1, 9)]
+    ref_rot, ref_tr = [r.max() for r, _ in ref], [t.max() for _, t in ref]
+    c = dict(cases.window_cases())[name]
     fx, fy, cx, cy = c["K"]
-    res = {}
-    for mode in ("strict", "fast"):
-        kernels.set_rand_epoch(0)
-        res[mode] = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, config=c["config"] + " " + extra + (" --strict_math 1" if mode == "strict" else " --strict_math 0"))
-    s, f = res["strict"], res["fast"]
-    assert s["n_registered"] == f["n_registered"] == c["flows"].shape[0]
-    rot, tr = synth.pose_errors(f["poses"], s["poses"])
-    nr, nt, _ = _pair_noise(gold, "mono_320x240")
-    # fewer hypotheses / no refit / no smoothing make the estimator itself noisier than the default configuration the noise was measured on
-    slack = 4 if ("n_poses_to_sample" in extra or "lambdatwist" in extra) else 2
-    assert rot.max() <= slack * nr + 2e-4 and tr.max() <= slack * nt, (extra, rot.max(), tr.max(), nr, nt)
+    rots, trs = [], []
+    for extra, comparable in VARIANTS:
+        res = {}
+        for mode in ("strict", "fast"):
+            kernels.set_rand_epoch(0)
+            res[mode] = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, config=c["config"] + " " + extra + (" --strict_math 1" if mode == "strict" else " --strict_math 0"))
+        s, f = res["strict"], res["fast"]
+        assert s["n_registered"] == f["n_registered"] == c["flows"].shape[0], extra
+        rot, tr = synth.pose_errors(f["poses"], s["poses"])
+        assert rot.max() <= 10 * max(ref_rot) and tr.max() <= 10 * max(ref_tr), (extra, rot.max(), tr.max())
+        if comparable:
+            rots.append(rot.max()); trs.append(tr.max())
+    p_rot = sh.rank_sum_pvalue(rots, [ref_rot] * len(rots)); p_tr = sh.rank_sum_pvalue(trs, [ref_tr] * len(trs))
+    print(f"fast vs strict over {len(rots)} variants: rot median {np.median(rots):.2e} (reference self-distance {np.median(ref_rot):.2e}) p = {p_rot:.3f}; "
+          f"trans {np.median(trs):.2e} ({np.median(ref_tr):.2e}) p = {p_tr:.3f}")
+    assert p_rot > 0.01 and p_tr > 0.01, (p_rot, p_tr, rots, trs)

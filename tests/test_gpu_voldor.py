@@ -12,11 +12,29 @@ sides (glibc powf/logf vs v_log/v_exp round the near-zero costs of well-fitted p
 different grids), 1-2 % of the depth pixels take another equal-cost branch per iteration, the
 hypotheses that hit those pixels change, and the two runs drift apart up to the estimator's own
 noise floor.  Rotation stays inside 1e-3 rad; translation is asserted against the noise floor.
+
+This module runs BOTH sides with the rejection draw D3b (product: --reference_draw 0, oracle: ORC_REFERENCE_DRAW=0): it is the draw
+that stays the same when one pixel of the valid set flips, which is what makes "identical draws" possible between two
+implementations that are not bit-identical.  The default since round 3 is the reference's index draw, under which one flipped pixel
+re-draws all 8192 tuples; its parity statements are the bit-equality tests (tests/test_gpu_vs_ref_window.py, strict mode) and the
+ensemble / rank tests (tests/test_gpu_ensemble.py), not the tolerances below.
 """
+import os
+
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def rejection_draw_on_both_sides(monkeypatch):
+    from voldor_amd import pyvoldor
+    monkeypatch.setenv("ORC_REFERENCE_DRAW", "0")
+    real, real_dev = pyvoldor.voldor, pyvoldor.voldor_device
+    monkeypatch.setattr(pyvoldor, "voldor", lambda *a, config="", **k: real(*a, config=config + " --reference_draw 0", **k))
+    monkeypatch.setattr(pyvoldor, "voldor_device", lambda *a, config="", **k: real_dev(*a, config=config + " --reference_draw 0", **k))
+    yield
 
 MONO = "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 8"
 STEREO = "--silent --meanshift_kernel_var 0.1 --disp_delta 1 --delta 0.2 --max_iters 8"

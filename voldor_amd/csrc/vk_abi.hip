@@ -32,7 +32,7 @@ int Context::init(int dev) {
 void Context::destroy() {
     DevBuf* bufs[] = { &od.flows, &od.rig, &od.depth, &od.cost, &od.priors, &od.pconfs, &od.confs, &od.pose,
                        &cp.flows, &cp.rig, &cp.depth, &cp.cost, &cp.priors, &cp.pconfs, &cp.confs, &cp.pose,
-                       &rig_partial, &local_tbl, &p2_map, &p3_map, &blk_counts, &blk_offsets, &pts2, &pts3, &n_points,
+                       &rig_partial, &local_tbl, &p2_map, &p3_map, &blk_counts, &blk_offsets, &valid_mask, &pts2, &pts3, &n_points,
                        &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp, &fb_scratch };
     for (DevBuf* b : bufs) b->release();
     if (ev0) (void)hipEventDestroy(ev0);

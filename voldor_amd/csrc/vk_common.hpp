@@ -153,7 +153,7 @@ struct Context {
     DevBuf rig_partial;           // per-block rigidness sums -> pose_rigidness_density
     DevBuf local_tbl;             // [h][w] candidate-cost table of a local propagation pass
     DevBuf p2_map, p3_map;        // [h*w][2], [h*w][3] (collect_p3p_instances.cu:27-34)
-    DevBuf blk_counts, blk_offsets;
+    DevBuf blk_counts, blk_offsets, valid_mask;  // per 256-pixel block: valid correspondences, their exclusive scan; one validity bit per pixel
     DevBuf pts2, pts3;            // compacted correspondences (geometry.cpp:68-80)
     DevBuf n_points;              // int
     int n_map_blocks = 0;         // workgroups of the last k_collect launch (length of blk_counts)

@@ -38,7 +38,7 @@ __device__ unsigned long long g_phase[64];
 __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict__ flows, const float* __restrict__ rig,
                                                          const float* __restrict__ depth, const PoseBlock* __restrict__ P,
                                                          float* __restrict__ p2_map, float* __restrict__ p3_map,
-                                                         int* __restrict__ blk_counts, int N, int w, int h, int active_idx,
+                                                         int* __restrict__ blk_counts, unsigned long long* __restrict__ valid_mask, int N, int w, int h, int active_idx,
                                                          float rig_thresh, float rig_sum_thresh, float min_depth,
                                                          float max_depth, int max_trace) {
     PH_DECL;
@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict
     }
     __shared__ int s_cnt[4];
     unsigned long long m = __ballot(valid);
-    if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = __popcll(m);
+    if ((threadIdx.x & 63) == 0) {
+        s_cnt[threadIdx.x >> 6] = __popcll(m);
+        valid_mask[(size_t)tile * 4 + (threadIdx.x >> 6)] = m;  // one bit per pixel, row-major: what the rank-select draw of k_solve scans
+    }
     __syncthreads();
     if (threadIdx.x == 0) blk_counts[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
     PH_MARK(0); PH_ADD(1, 1);
@@ -176,7 +179,8 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                                                       int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk,
                                                       CamState* cam, int npx, float fx, float fy, float cx, float cy, int n_poses,
                                                       int draw /* 0 auto, 1 rank select (reference draw), -1 rejection only */, int strict /* bit 0: strict math, bit 1: reference SVD */,
-                                                      const int* __restrict__ blk_offsets /* exclusive prefix of blk_counts in global memory when it does not fit the LDS, else null */) {
+                                                      const int* __restrict__ blk_offsets /* exclusive prefix of blk_counts in global memory when it does not fit the LDS, else null */,
+                                                      const unsigned long long* __restrict__ valid_mask /* k_collect's bit per pixel (FROM_MAP) */) {
     // LambdaTwist: four lanes per hypothesis, one candidate root each (the candidates are independent once the
     // shared cubic / eigen-decomposition is done; a lane per hypothesis walks them one after the other and the wave
     // waits for its slowest lane).  AP3P keeps one lane per hypothesis.
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
     constexpr int DRAW_BATCH = 4;
     int cand0[4][DRAW_BATCH];
     float probe0[4][DRAW_BATCH];
-    if (FROM_MAP) {
+    if (FROM_MAP && draw <= 0) {  // (draw > 0: the rank select never probes)
 #pragma unroll
         for (int k = 0; k < 4; k++)
 #pragma unroll
@@ -200,35 +204,61 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
             }
     }
     int n_pts;
-    if (FROM_MAP) {
-        // number of valid correspondences = sum of k_collect's per-workgroup counts; every wave adds them up itself
-        // (a few coalesced loads) instead of a separate single-workgroup launch between collect and solve
-        int part = 0;
-        for (int i0 = 0; i0 < nblk; i0 += 64 * 32) {  // 32 independent loads in flight per lane: one round trip up to 2048 blocks (1080p: 8100)
+    // Inclusive prefix of k_collect's per-block counts into the LDS (what the rank-select draw bisects) and their total.  Per pass lane l
+    // takes 32 CONSECUTIVE blocks (one 128-byte line: eight 16-byte loads in flight), sums them up in registers, the wave scans the 64
+    // chunk totals once (6 shuffle steps per 2048 blocks) and every lane stores its running sums.  LDS layout padded by one word per 32
+    // (pref_at): lane l's j-th store lands in bank (33 l + j) mod 64 -- no conflicts.  640x480: one pass; 1080p (8100 blocks): four.
+    auto pref_at = [](int i) { return i + (i >> 5); };
+    auto prefix_to_lds = [&]() -> int {
+        int carry = 0;
+        for (int i0 = 0; i0 < nblk; i0 += 64 * 32) {
+            const int b0 = i0 + (int)threadIdx.x * 32;
             int v[32];
+            if (b0 + 32 <= nblk) {
 #pragma unroll
-            for (int u = 0; u < 32; u++) { const int i = i0 + u * 64 + (int)threadIdx.x; v[u] = i < nblk ? blk_counts[i] : 0; }
+                for (int q = 0; q < 8; q++) { const int4 t = *reinterpret_cast<const int4*>(blk_counts + b0 + 4 * q); v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+            } else {
 #pragma unroll
-            for (int u = 0; u < 32; u++) part += v[u];
+                for (int j = 0; j < 32; j++) v[j] = b0 + j < nblk ? blk_counts[b0 + j] : 0;
+            }
+#pragma unroll
+            for (int j = 1; j < 32; j++) v[j] += v[j - 1];
+            int incl = v[31];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += t; }
+            const int base = carry + incl - v[31];
+#pragma unroll
+            for (int j = 0; j < 32; j++) if (b0 + j < nblk) s_pref[pref_at(b0 + j)] = base + v[j];
+            carry += __shfl(incl, 63, 64);
         }
+        return carry;
+    };
+    if (FROM_MAP) {
+        if (draw > 0 && !blk_offsets) {  // the reference's draw (default): the prefix is needed anyway, its last entry is the count
+            n_pts = prefix_to_lds();
+            __syncthreads();
+        } else {
+            // number of valid correspondences = sum of k_collect's per-workgroup counts; every wave adds them up itself
+            // (a few coalesced loads) instead of a separate single-workgroup launch between collect and solve
+            int part = 0;
+            for (int i0 = 0; i0 < nblk; i0 += 64 * 32) {  // 32 independent loads in flight per lane: one round trip up to 2048 blocks (1080p: 8100)
+                int v[32];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
-        n_pts = part;
+                for (int u = 0; u < 32; u++) { const int i = i0 + u * 64 + (int)threadIdx.x; v[u] = i < nblk ? blk_counts[i] : 0; }
+#pragma unroll
+                for (int u = 0; u < 32; u++) part += v[u];
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o, 64);
+            n_pts = part;
+        }
         if (gtid == 0) { *n_pts_dev = n_pts; if (cam) cam->n_points = n_pts; }
     } else
         n_pts = *n_pts_dev;
     PH_MARK(8);
     const bool rank_draw = FROM_MAP && n_pts >= 4 && (draw > 0 || (draw == 0 && (long long)n_pts * DRAW_RANK_INV_DENSITY < (long long)npx));
-    if (rank_draw && !blk_offsets) {  // wave-uniform: inclusive prefix sums of the block counts
-        int carry = 0;
-        for (int i0 = 0; i0 < nblk; i0 += 64) {
-            const int i = i0 + (int)threadIdx.x;
-            int incl = i < nblk ? blk_counts[i] : 0;
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += t; }
-            if (i < nblk) s_pref[i] = carry + incl;
-            carry += __shfl(incl, 63, 64);
-        }
+    if (rank_draw && !blk_offsets && draw <= 0) {  // D3b's low-density fallback: wave-uniform
+        prefix_to_lds();
         __syncthreads();
     }
     if (idx >= n_poses) return;
@@ -241,31 +271,64 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
         bool drawn = true;
         int sel[4];
         if (FROM_MAP && rank_draw) {
-#pragma unroll 1
-            for (int k = 0; k < 4; k++) {
+            // LambdaTwist (four lanes per hypothesis): lane `sub` finds point `sub`, the group exchanges the four pixels -- one search
+            // and one mask read per lane instead of four.  AP3P (one lane per hypothesis): four searches side by side.
+            constexpr int NS = LPH == 4 ? 1 : 4;
+            int rk[NS], lo[NS], hi[NS], want[NS], found[NS];
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
                 // (int)(curand_uniform * N_pts), clamped (D3): solve_batch_lambdatwist.cu:16-19
-                const int r = min((int)(u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)k)) * (float)n_pts), n_pts - 1);
-                int lo = 0, hi = nblk - 1;  // first block whose inclusive prefix exceeds r
-                int want;                   // rank inside the block
-                if (blk_offsets) {          // images beyond 15360 blocks (3.9 MP): the scanned counts stay in global memory (k_scan_counts)
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (blk_offsets[mid + 1] > r) hi = mid; else lo = mid + 1; }
-                    want = r - blk_offsets[lo];
-                } else {
-                    while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[mid] > r) hi = mid; else lo = mid + 1; }
-                    want = r - (lo > 0 ? s_pref[lo - 1] : 0);
-                }
-                int pix = lo * 256, found = -1;
-                const int end = min(pix + 256, npx);
-                for (; pix < end && found < 0; pix += 4) {
-                    float pr[4];
+                rk[k] = min((int)(u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)(LPH == 4 ? sub : k))) * (float)n_pts), n_pts - 1);
+                lo[k] = 0; hi[k] = nblk - 1;  // first block whose inclusive prefix exceeds the rank
+            }
+            if (blk_offsets) {  // images beyond 15360 blocks (3.9 MP): the scanned counts stay in global memory (k_scan_counts)
+                for (bool more = true; more;) {
+                    more = false;
 #pragma unroll
-                    for (int u = 0; u < 4; u++) pr[u] = pix + u < end ? pts2[(size_t)(pix + u) * 2] : qnan;
-#pragma unroll
-                    for (int u = 0; u < 4; u++)
-                        if (found < 0 && isfinite(pr[u])) { if (want == 0) found = pix + u; else want--; }
+                    for (int k = 0; k < NS; k++)
+                        if (lo[k] < hi[k]) { const int mid = (lo[k] + hi[k]) >> 1; if (blk_offsets[mid + 1] > rk[k]) hi[k] = mid; else lo[k] = mid + 1; more = true; }
                 }
-                sel[k] = found;
-                if (found < 0) { drawn = false; sel[k] = 0; }  // cannot happen: the counts come from the same map
+#pragma unroll
+                for (int k = 0; k < NS; k++) want[k] = rk[k] - blk_offsets[lo[k]];
+            } else {
+                for (bool more = true; more;) {
+                    more = false;
+#pragma unroll
+                    for (int k = 0; k < NS; k++)
+                        if (lo[k] < hi[k]) { const int mid = (lo[k] + hi[k]) >> 1; if (s_pref[pref_at(mid)] > rk[k]) hi[k] = mid; else lo[k] = mid + 1; more = true; }
+                }
+#pragma unroll
+                for (int k = 0; k < NS; k++) want[k] = rk[k] - (lo[k] > 0 ? s_pref[pref_at(lo[k] - 1)] : 0);
+            }
+            // the want-th valid pixel of block lo: its four 64-bit validity words, popcounts, then a 6-step select inside the word
+            unsigned long long wds[NS][4];
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                const ulonglong2* mw = reinterpret_cast<const ulonglong2*>(valid_mask + (size_t)lo[k] * 4);
+                const ulonglong2 a = mw[0], b = mw[1];
+                wds[k][0] = a.x; wds[k][1] = a.y; wds[k][2] = b.x; wds[k][3] = b.y;
+            }
+#pragma unroll
+            for (int k = 0; k < NS; k++) {
+                int wn = want[k];
+                const int c0 = __popcll(wds[k][0]), c1 = __popcll(wds[k][1]), c2 = __popcll(wds[k][2]);
+                unsigned long long wd = wds[k][0]; int q = 0;
+                if (wn >= c0) { wn -= c0; wd = wds[k][1]; q = 1; if (wn >= c1) { wn -= c1; wd = wds[k][2]; q = 2; if (wn >= c2) { wn -= c2; wd = wds[k][3]; q = 3; } } }
+                found[k] = -1;
+                if (wn < __popcll(wd)) {
+                    int pos = 0;
+#pragma unroll
+                    for (int sft = 32; sft >= 1; sft >>= 1) {
+                        const int c = __popcll(wd & (((1ull << sft) - 1ull) << pos));
+                        if (wn >= c) { wn -= c; pos += sft; }
+                    }
+                    found[k] = lo[k] * 256 + q * 64 + pos;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                sel[k] = LPH == 4 ? __shfl(found[0], (((int)threadIdx.x & 63) & ~3) + k, 64) : found[NS == 4 ? k : 0];
+                if (sel[k] < 0) { drawn = false; sel[k] = 0; }  // cannot happen: the counts come from the same map
             }
         } else if (FROM_MAP) {
             // Rejection draw over the NaN-marked correspondence map: point k takes the first valid pixel of its
@@ -1367,9 +1430,10 @@ int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int activ
     if (int e = c->p3_map.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
     if (int e = c->blk_counts.reserve(sizeof(int) * (size_t)nblk)) return e;
     if (int e = c->blk_offsets.reserve(sizeof(int) * (size_t)nblk)) return e;
+    if (int e = c->valid_mask.reserve(sizeof(unsigned long long) * 4 * (size_t)nblk)) return e;
     if (int e = c->ensure_n_points()) return e;
     hipLaunchKernelGGL(k_collect, dim3(nblk), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
-                       S.pb(), c->p2_map.as<float>(), c->p3_map.as<float>(), c->blk_counts.as<int>(), N, w, h, active_idx,
+                       S.pb(), c->p2_map.as<float>(), c->p3_map.as<float>(), c->blk_counts.as<int>(), c->valid_mask.as<unsigned long long>(), N, w, h, active_idx,
                        rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace);
     c->n_map_blocks = nblk;
     if (compact) {  // the host-pointer API hands the compacted list to its caller (geometry.cpp:68-80)
@@ -1396,7 +1460,7 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
     // rank-select draw: the prefix of the block counts lives in the LDS of every workgroup (32 KB at 1080p: two workgroups of one
     // wave per CU still fit); not allocated when the draw cannot be taken (draw < 0).  Beyond 60 KB (3.9 MP) the counts are scanned
     // into global memory by one extra launch and the bisection reads them from there.
-    size_t lds = (FROM_MAP && draw >= 0) ? sizeof(int) * (size_t)nb : 0;
+    size_t lds = (FROM_MAP && draw >= 0) ? sizeof(int) * ((size_t)nb + nb / 32 + 1) : 0;  // padded: pref_at() in k_solve
     const int* offs = nullptr;
     if (lds > 60 * 1024) {
         if (int e = c->blk_offsets.reserve(sizeof(int) * (size_t)nb)) return e;
@@ -1405,9 +1469,10 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
         lds = 0;
     }
     const int st = (strict ? 1 : 0) | (ref_svd ? 2 : 0);
-    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs);
-    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs);
-    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs);
+    const unsigned long long* vm = FROM_MAP ? c->valid_mask.as<unsigned long long>() : nullptr;
+    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm);
+    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm);
+    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm);
     VK_CHECK_LAST();
     return 0;
 }

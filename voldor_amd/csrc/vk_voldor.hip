@@ -43,13 +43,16 @@ struct Config {
     // Extensions (not in config.h; they select how results are COMPUTED, not what is computed; parity pinning):
     //  strict_math     1: every stage in the reference's operation order on software transcendentals (vk_strict.hip) -- the window then
     //                  reproduces the CPU oracle in strict mode bit for bit; -1 (default) = the process-wide setting of vk_set_strict_math
-    //  reference_draw  1: pose hypotheses index the row-major list of valid correspondences like geometry.cpp:68-88 +
-    //                  solve_batch_lambdatwist.cu:16-19 (rank select over the map); 0: rejection draw (D3b) with that draw as the
-    //                  low-density fallback
+    //  reference_draw  1 (default): pose hypotheses index the row-major list of valid correspondences like geometry.cpp:68-88 +
+    //                  solve_batch_lambdatwist.cu:16-19 -- rank select over k_collect's validity bitmask, the list is never built;
+    //                  0: rejection draw over the map (D3b: same distribution, but an independent sample of the hypotheses) with that
+    //                  draw as the low-density fallback.  Default 1 since the ensemble test (tests/test_gpu_ensemble.py): with the
+    //                  reference's draw the fast path is statistically indistinguishable from the reference under 1-ulp jitter
+    //                  in every metric; with D3b its depth maps sit 1.4x further out
     //  reference_svd   1: rodrigues() of every pose hypothesis through the reference's approximate fp32 SVD (svd3_cuda.h restated to the bit
     //                  in vk_ref_svd.h) instead of the exact polar factor (D8); with strict_math and reference_draw a window then equals the
     //                  REFERENCE pipeline's strict window bit for bit; -1 (default) = the process-wide setting of vk_set_reference_svd
-    int strict_math = -1, reference_draw = 0, reference_svd = -1;
+    int strict_math = -1, reference_draw = 1, reference_svd = -1;
 
     // Returns 0, or non-zero where the reference prints and calls exit(1) (config.h:101-108,245-248):
     // a library must not exit its host process, so the error is reported to the caller instead.
