@@ -9,7 +9,7 @@ its hypotheses by INDEX into the compacted list of valid pixels, so two runs eit
 near-identical output: what 1-ulp jitter gives on these small, prior-constrained windows (90th-percentile depth difference 0) -- or
 differ in one pixel of it and re-draw all 8192 tuples.  Any implementation that is not bit-identical falls into the second case, and
 the second case is what another seed produces.  Stored per run: registered count, poses, covariances, depth and confidence (every
-2nd pixel of the larger windows).
+2nd pixel per axis, every 4th of the larger windows).
 
 Build container only: `python tests/golden/gen_golden_window_noise.py [workers]`; one process per run, a few seconds each."""
 import multiprocessing as mp
@@ -38,7 +38,7 @@ def run_one(job):
     ref.ref_set_rand_salt(salt)
     r = run_reference(c)
     ref.ref_set_rand_salt(0)
-    sub = 1 if c["exact"] else 2
+    sub = 2 if c["exact"] else 4  # enough pixels for percentiles, a quarter / sixteenth of the bytes
     return job, {"n_registered": np.int32(r["n_registered"]), "poses": r["poses"], "poses_covar": r["poses_covar"],
                  "depth": r["depth"][::sub, ::sub].copy(), "depth_conf": r["depth_conf"][::sub, ::sub].copy()}
 

@@ -163,6 +163,35 @@ def test_local_runs_equal_the_step_by_step_chain(width, noise, n_flows, n_dp):
         np.testing.assert_array_equal(c1.view(np.uint32), c2.view(np.uint32))
 
 
+@pytest.mark.parametrize("step,noise,n_flows,n_dp", [(8, 0.3, 5, 0), (2, 0.3, 4, 0), (5, 0.1, 8, 1), (8, 0.2, 10, 0), (3, 0.2, 13, 2), (8, 0.05, 16, 0), (7, 0.3, 1, 0)])
+def test_global_split_equals_one_lane_per_site(step, noise, n_flows, n_dp):
+    """The global-propagation passes with a site evaluated by a group of lanes (k_global_prop_split_lean, the default) against one lane
+    per site (vk_set_global_split(0)): identical depth / rigidness maps, bit for bit, for every way the frames and depth priors fall
+    onto the lanes of a group (4 lanes up to 8 frames, 8 beyond)."""
+    from voldor_amd import kernels, synth
+    sc = synth.make_scene(w=211, h=97, n_flows=n_flows, fx=100, fy=100, cx=105, cy=48, seed=23, basefocal=40.0 if n_dp else 0.0)
+    rng = np.random.default_rng(int(step * 100 + noise * 1000))
+    K = K9(*sc["K"])
+    flows, Rs, ts, depth, rig = _state(sc, rng, noise=noise)
+    h, w = depth.shape
+    extra = {}
+    if n_dp:
+        pri = np.stack([(sc["depth_gt"] * (1 + rng.normal(0, 0.05, (h, w)))).astype(np.float32) for _ in range(n_dp)])
+        pri[:, ::7, ::5] = 0.0  # holes
+        extra = dict(priors=pri, pconfs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32), confs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32),
+                     dp_Rs=np.tile(np.eye(3, dtype=np.float32), (n_dp, 1, 1)), dp_ts=(rng.normal(0, 0.02, (n_dp, 3)) * np.arange(n_dp)[:, None]).astype(np.float32))
+    over = dict(n_rand_samples=2, global_prop_step=step, local_prop_width=0, fb_smooth=0, basefocal=40.0 if n_dp else 0.0, disp_delta=1.0 if n_dp else -1.0)
+    try:
+        kernels.set_global_split(False)
+        d1, r1, c1 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
+    finally:
+        kernels.set_global_split(True)
+    d2, r2, c2 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
+    assert np.mean(d1 != depth) > 0.01  # the passes did replace depths
+    np.testing.assert_array_equal(d1.view(np.uint32), d2.view(np.uint32))
+    np.testing.assert_array_equal(r1.view(np.uint32), r2.view(np.uint32))
+
+
 def test_local_runs_with_the_tiled_table_equal_the_step_by_step_chain():
     """Above 400k pixels the candidate-cost table of a pass comes from its own tiled kernel (below, every chain tabulates its own steps at
     the head of the runs kernel): the same equality at 832x512."""

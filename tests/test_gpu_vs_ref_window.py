@@ -50,7 +50,7 @@ def test_windows_vs_reference_pipeline_rank_test(gold):
         kernels.set_rand_epoch(0)
         o = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"], depth_priors=c["depth_priors"],
                             depth_prior_poses=c["depth_prior_poses"], depth_prior_pconfs=c["depth_prior_pconfs"], config=c["config"])
-        sub = 1 if c["exact"] else 2
+        sub = 2 if c["exact"] else 4
         hip = {"n_registered": o["n_registered"], "poses": o["poses"], "poses_covar": o["poses_covar"], "depth": o["depth"][::sub, ::sub], "depth_conf": o["depth_conf"][::sub, ::sub]}
         def ref(salt):
             p = f"{name}/s{salt}/"

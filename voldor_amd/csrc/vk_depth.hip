@@ -23,6 +23,7 @@
 namespace vk {
 
 static std::atomic<int> g_local_serial{0};  // vk_set_local_serial (verification aid)
+static std::atomic<int> g_global_split{1};  // vk_set_global_split (verification aid): 0 = one lane per site (k_global_prop_sites_lean)
 
 // phase clocks (profiling builds only, scripts/phase_clocks.sh): thread 0 of the middle workgroup of a launch
 #ifdef VK_PHASE_CLOCKS
@@ -410,16 +411,15 @@ __device__ __forceinline__ static void lean_rest(const Img& I, const LeanK& K, c
     unsigned valid = 0;
 #pragma unroll
     for (int f = 1; f < NMAX; f++) {
-        qx[f] = 0.f; qy[f] = 0.f; ex[f] = 0.f; ey[f] = 0.f;
-        if (f < I.N) {
+        if (f < I.N) {  // uniform.  Inside: selects, no divergent branch (a branch per frame costs the zero-fill of its four slots twice over)
             float px2, py2;
             const bool zok = lean_step(P, f, x, y, d, px2, py2);
-            if (zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh) {
-                valid |= 1u << f;
-                qx[f] = px1; qy[f] = py1; ex[f] = px2 - px1; ey[f] = py2 - py1;
-                px1 = px2; py1 = py2;  // advances on contributing frames only (:162-164)
-            }
-        }
+            const bool ok = zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh;
+            valid |= ok ? (1u << f) : 0u;
+            qx[f] = ok ? px1 : 0.f; qy[f] = ok ? py1 : 0.f;  // a frame that does not contribute gathers texel (0,0) and is dropped below
+            ex[f] = px2 - px1; ey[f] = py2 - py1;
+            px1 = ok ? px2 : px1; py1 = ok ? py2 : py1;  // advances on contributing frames only (:162-164)
+        } else { qx[f] = 0.f; qy[f] = 0.f; ex[f] = 0.f; ey[f] = 0.f; }
     }
     float2 obs[NMAX];
     float wgt[NMAX];
@@ -475,7 +475,7 @@ __device__ __forceinline__ static float pixel_cost_lean(const Img& I, const Lean
 //      the one the sequential rule of optimize_depth.cu:269-277 would end up with
 //   4. the pixel takes the winner if it is strictly cheaper than its running best
 // The result does not depend on the order in which entries enter or leave the queue.
-constexpr int CRQ_NS = 5;  // samples per round: queue capacity 256 * CRQ_NS entries (20 KB of LDS)
+constexpr int CRQ_NS = 5;  // samples per round: queue capacity 256 * CRQ_NS entries (20 KB of LDS).  One round of 10 (40 KB): 45 -> 56 us at 640x480, no gain at 1080p -- the second round prunes against the winners of the first
 struct CrqEntry { unsigned id; float d, cs, ws; };  // id = lane-in-workgroup | sample << 8
 __device__ __forceinline__ float sample_depth(int pi, uint32_t epoch, float range_factor) {
 #pragma clang fp contract(off)
@@ -628,8 +628,10 @@ __device__ __forceinline__ static float cost_split_lean(const Img& I, const Lean
                 float px2, py2;
                 const bool zok = lean_step(P, f, x, y, depth, px2, py2);
                 const bool valid = f == 0 ? zok : (zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh);
-                if (f % LPP == g) { vv[f / LPP] = valid; qx[f / LPP] = px1; qy[f / LPP] = py1; ex[f / LPP] = px2 - px1; ey[f / LPP] = py2 - py1; }
-                if (valid) { px1 = px2; py1 = py2; }
+                const bool mine = f % LPP == g;  // selects, no divergent branches (see lean_rest)
+                vv[f / LPP] = mine ? valid : vv[f / LPP]; qx[f / LPP] = mine ? px1 : qx[f / LPP]; qy[f / LPP] = mine ? py1 : qy[f / LPP];
+                ex[f / LPP] = mine ? px2 - px1 : ex[f / LPP]; ey[f / LPP] = mine ? py2 - py1 : ey[f / LPP];
+                px1 = valid ? px2 : px1; py1 = valid ? py2 : py1;
             }
         }
     }
@@ -680,6 +682,34 @@ __device__ __forceinline__ static float cost_split_lean(const Img& I, const Lean
     }
     cs = fmaf(0.6931471805599453f, cl, cs);
     return lean_final(cs, ws);
+}
+// Global propagation with the candidate of a site evaluated by LPP lanes (cost_split_lean: the bits of pixel_cost_lean).  A pass has
+// only w*h/step sites: with one lane per site it is a few hundred (640x480) to a few thousand (1080p) waves, each walking all frames
+// of its 64 sites one after the other -- latency, 26 % VALU issue at 1080p.  LPP lanes per site = LPP times the waves, each lane with
+// ceil(N / LPP) gathers and residuals in flight.  Same decisions, same maps as k_global_prop_sites_lean (vk_set_global_split).
+template <int NMAX, int LPP>
+__global__ __launch_bounds__(64) static void k_global_prop_split_lean(Img I, int dir, int step, int nsites) {
+    if (!clamp_active(I)) return;
+    constexpr int SPW = 64 / LPP;  // sites per wave
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const bool rowpass = dir == 0 || dir == 2;
+    const int g = threadIdx.x % LPP, slot = threadIdx.x / LPP;
+    const int a = (tile % gridDim.x) * SPW + slot, b = tile / gridDim.x;
+    const int s = rowpass ? a : b, l = rowpass ? b : a;
+    const bool live = s < nsites && l < (rowpass ? I.h : I.w);
+    int x = 0, y = 0, sx = 0, sy = 0;  // an idle group evaluates pixel (0,0) under its own depth: the group broadcasts stay uniform
+    if (live) {
+        if (dir == 0) { x = 1 + s * step; y = l; sx = x - 1; sy = y; }
+        else if (dir == 2) { x = I.w - 2 - s * step; y = l; sx = x + 1; sy = y; }
+        else if (dir == 1) { y = 1 + s * step; x = l; sx = x; sy = y - 1; }
+        else { y = I.h - 2 - s * step; x = l; sx = x; sy = y + 1; }
+    }
+    const LeanK K = lean_consts(I);
+    const int pi = y * I.w + x;
+    const float cand = I.depth[sy * I.w + sx];
+    const float c0 = I.cost[pi];
+    const float c = cost_split_lean<NMAX, LPP>(I, K, x, y, cand, g);
+    if (live && g == 0 && c < c0) { I.depth[pi] = cand; I.cost[pi] = c; }
 }
 // Pass 2 of a local propagation: one chain per HALF lanes (HALF = 64: one chain per wave, up to 64 steps; HALF = 32: two chains
 // of up to 32 steps share a wave -- the default width 32 gives chains of 31 steps, so a wave per chain leaves half the lanes idle
@@ -822,16 +852,14 @@ __global__ __launch_bounds__(256) static void k_update_rigidness_lean(Img I, flo
         float px1 = x, py1 = y;
 #pragma unroll
         for (int f = 0; f < NMAX; f++) {
-            qx[f] = 0.f; qy[f] = 0.f; rdx[f] = 0.f; rdy[f] = 0.f;
-            if (f < I.N) {
+            if (f < I.N) {  // uniform; selects inside (see lean_rest)
                 float px2, py2;
                 const bool zok = lean_step(P, f, x, y, d, px2, py2);
-                if (live && zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh) {
-                    valid |= 1u << f;
-                    qx[f] = px1; qy[f] = py1; rdx[f] = px2 - px1; rdy[f] = py2 - py1;
-                    px1 = px2; py1 = py2;  // NOT advanced on invalid frames
-                }
-            }
+                const bool ok = live && zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh;
+                valid |= ok ? (1u << f) : 0u;
+                qx[f] = ok ? px1 : 0.f; qy[f] = ok ? py1 : 0.f; rdx[f] = px2 - px1; rdy[f] = py2 - py1;
+                px1 = ok ? px2 : px1; py1 = ok ? py2 : py1;  // NOT advanced on invalid frames
+            } else { qx[f] = 0.f; qy[f] = 0.f; rdx[f] = 0.f; rdy[f] = 0.f; }
         }
     }
     float2 obs[NMAX];
@@ -1212,6 +1240,11 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                     const int nsites = (len - 1 + p.global_prop_step - 1) / p.global_prop_step;
                     if (nsites <= 0) continue;
                     if constexpr (STRICT) hipLaunchKernelGGL(k_global_prop_sites_strict<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
+                    else if (g_global_split.load(std::memory_order_relaxed) && (size_t)w * h <= 600000) {  // latency regime only (640x480: 5.9 -> 5.0 us per pass, 1241x376: 11.2 -> 10.6); at 1080p the pass is throughput bound and eight lanes re-walking the chain cost 35 -> 52 us
+                        constexpr int GL = NMAX <= 8 ? 4 : 8, SPW = 64 / GL;  // lanes per site as in the run evaluations of the local pass
+                        if (rowpass) hipLaunchKernelGGL((k_global_prop_split_lean<NMAX, GL>), dim3((nsites + SPW - 1) / SPW, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
+                        else hipLaunchKernelGGL((k_global_prop_split_lean<NMAX, GL>), dim3((lines + SPW - 1) / SPW, nsites), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
+                    }
                     else if (rowpass) hipLaunchKernelGGL(k_global_prop_sites_lean<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
                     else hipLaunchKernelGGL(k_global_prop_sites_lean<NMAX>, dim3((lines + 63) / 64, nsites), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
                 } else  // step 1: a true serial chain per line (no shipped config uses it)
@@ -1369,6 +1402,7 @@ int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk
 }  // namespace vk
 
 extern "C" __attribute__((visibility("default"))) int vk_set_local_serial(int on) { vk::g_local_serial.store(on ? 1 : 0); return 0; }
+extern "C" __attribute__((visibility("default"))) int vk_set_global_split(int on) { vk::g_global_split.store(on ? 1 : 0); return 0; }
 
 #ifdef VK_PHASE_CLOCKS
 extern "C" __attribute__((visibility("default"))) int vk_phase_read_depth(unsigned long long* out, int n, int reset) {

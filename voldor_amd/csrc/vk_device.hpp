@@ -121,7 +121,7 @@ __device__ __forceinline__ float2 bilinear2_inside(const float2* __restrict__ im
     const int xb = min(x0, w - 2), yb = min(y0, h - 2);
     const float a = x0 > xb ? 1.f : x - fx, b = y0 > yb ? 1.f : y - fy;
     const char* base = reinterpret_cast<const char*>(img);
-    const unsigned off = (unsigned)(yb * w + xb) * 8u;
+    const unsigned off = (unsigned)(__mul24(yb, w) + xb) * 8u;  // v_mad_i32_i24: full rate (a 32-bit integer multiply issues at a quarter of it); rows and widths are far below 2^23
     const TexPair r0 = *reinterpret_cast<const TexPair*>(base + off);
     const TexPair r1 = *reinterpret_cast<const TexPair*>(base + off + (unsigned)w * 8u);
     const float tx = fmaf(a, r0.bx - r0.ax, r0.ax), ty = fmaf(a, r0.by - r0.ay, r0.ay);
@@ -167,7 +167,8 @@ __device__ __forceinline__ BilIdx bil_index(float x, float y, int w, int h) {
     int x0 = (int)fx, y0 = (int)fy;
     int x1 = min(max(x0 + 1, 0), w - 1), y1 = min(max(y0 + 1, 0), h - 1);
     x0 = min(max(x0, 0), w - 1); y0 = min(max(y0, 0), h - 1);
-    r.i00 = y0 * w + x0; r.i10 = y0 * w + x1; r.i01 = y1 * w + x0; r.i11 = y1 * w + x1;
+    const int r0 = __mul24(y0, w), r1 = __mul24(y1, w);
+    r.i00 = r0 + x0; r.i10 = r0 + x1; r.i01 = r1 + x0; r.i11 = r1 + x1;
     return r;
 }
 // Two horizontally adjacent flow texels in ONE 16-byte access (8-byte aligned; gfx950 global loads
@@ -187,8 +188,8 @@ __device__ __forceinline__ float2 bilinear2(const float2* __restrict__ img, int 
         const int xb = min(x0, w - 2);
         // unsigned 32-bit byte offsets from the (wave-uniform) layer base: scalar base + vector offset addressing
         const char* base = reinterpret_cast<const char*>(img);
-        const TexPair r0 = *reinterpret_cast<const TexPair*>(base + (unsigned)(y0 * w + xb) * 8u);
-        const TexPair r1 = *reinterpret_cast<const TexPair*>(base + (unsigned)(y1 * w + xb) * 8u);
+        const TexPair r0 = *reinterpret_cast<const TexPair*>(base + (unsigned)(__mul24(y0, w) + xb) * 8u);
+        const TexPair r1 = *reinterpret_cast<const TexPair*>(base + (unsigned)(__mul24(y1, w) + xb) * 8u);
         const bool lo0 = x0 == xb, lo1 = x1 == xb;
         t00 = lo0 ? make_float2(r0.ax, r0.ay) : make_float2(r0.bx, r0.by);
         t10 = lo1 ? make_float2(r0.ax, r0.ay) : make_float2(r0.bx, r0.by);

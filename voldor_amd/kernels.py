@@ -220,6 +220,11 @@ def set_local_serial(on: bool):
     capi.check(capi.lib().vk_set_local_serial(int(on)), "vk_set_local_serial")
 
 
+def set_global_split(on: bool):
+    """Verification aid (include/voldor_hip.h: vk_set_global_split): lanes-per-site evaluation of the global propagation (default) or one lane per site."""
+    capi.check(capi.lib().vk_set_global_split(int(on)), "vk_set_global_split")
+
+
 def set_split_trials(on: bool):
     """Verification aid (include/voldor_hip.h: vk_set_split_trials): initial-mode trials as their own workgroups (default) or inside the mode kernel."""
     capi.check(capi.lib().vk_set_split_trials(1 if on else 0), "vk_set_split_trials")
