@@ -190,6 +190,18 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = world * args.steps / dt
 
+    # ---- latency of a single window as a caller sees it (one call, synchronised): p50 / p99 over 100 windows (extra, never `value`) ----
+    latency = None
+    if rank == 0 and not args.no_extras:
+        ts = []
+        for _ in range(100):
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            step()
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t1)
+        ts = np.sort(np.array(ts)) * 1e3
+        latency = {"windows": 100, "p50_ms": round(float(np.percentile(ts, 50)), 3), "p90_ms": round(float(np.percentile(ts, 90)), 3),
+                   "p99_ms": round(float(np.percentile(ts, 99)), 3), "min_ms": round(float(ts[0]), 3), "max_ms": round(float(ts[-1]), 3)}
+
     # ---- roofline of the optimize_depth kernel group (HIP events on the library's own stream) ----
     roof = None
     if rank == 0:
@@ -211,7 +223,8 @@ def main():
         b_cr = W * H * (12 * N_FLOW + 12 * n_dp + 16)
         nmax = 4 if N_FLOW <= 4 else 6 if N_FLOW <= 6 else 8 if N_FLOW <= 8 else 12 if N_FLOW <= 12 else 16
         kname = f"vk::k_cost_rand_q<{nmax}>"
-        traffic = valu = group_traffic = None
+        traffic = valu = group_traffic = group_valu_cycles = None
+        od_kernels = ("k_fb_rows", "k_fb_cols", "k_cum_poses", "k_cost_rand_q", "k_global_prop", "k_local_table", "k_local_runs", "k_local_pass", "k_update_rigidness", "k_reduce_density")
         sqc = {}
         src = {}
         def pmc_file(kind):  # the latest committed PMC pass of this workload (collected separately: rocprofv3 cannot time and count in one run)
@@ -226,7 +239,6 @@ def main():
             f = pmc_file("traffic"); doc = json.load(open(f)); ks = doc["kernels"]
             traffic = ks[kname]["hbm_bytes_per_launch"]
             src["traffic"] = provenance(f, doc)
-            od_kernels = ("k_fb_rows", "k_fb_cols", "k_cum_poses", "k_cost_rand_q", "k_global_prop", "k_local_table", "k_local_runs", "k_local_pass", "k_update_rigidness", "k_reduce_density")
             # k_cost_rand_q runs once per optimize_depth call: launches relative to it = launches per call
             group_traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in ks.items() if any(t in k for t in od_kernels)) / ks[kname]["launches"]
         except Exception:
@@ -237,6 +249,9 @@ def main():
             # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves (MI355X_MICROARCH.md): x4 = cycles some SIMD spent issuing VALU;
             # over 1024 SIMDs and the launch duration at the 2.4 GHz peak clock = the fraction of VALU issue slots used
             valu = sqc["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sqc["avg_us_under_pmc"] * 1e-6 * 2.4e9)
+            # the same for the whole optimize_depth group: SIMD cycles spent issuing VALU per call / (1024 SIMDs x duration of the group)
+            group_valu_cycles = sum(v["SQ_ACTIVE_INST_VALU"] * 4 * v["launches"] for k, v in doc.items()
+                                    if isinstance(v, dict) and any(t in k for t in od_kernels)) / doc[kname]["launches"]
         except Exception:
             pass
         if "cost_rand" in groups and "optimize_depth" in groups:
@@ -255,6 +270,10 @@ def main():
                     "traffic_note": "TCC_EA read/write request counters converted to bytes as MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE x2 correction); that correction is "
                                     "calibrated on wide coalesced reads -- for the 8-byte bilinear gathers of these kernels absolute bytes are an upper estimate (ratios between variants hold); "
                                     "at cfg2 / cfg3 the working set is MALL resident and TCC-EA counts MALL hits as traffic",
+                    "valu": None if group_valu_cycles is None else {
+                        "group_issue_frac": round(group_valu_cycles / (1024 * t_od * 2.4e9), 3),
+                        "note": "SIMD cycles issuing VALU instructions (SQ_ACTIVE_INST_VALU x 4, replayed PMC pass) over 1024 SIMDs x the group's duration of THIS run at the 2.4 GHz peak "
+                                "clock: what actually bounds this path -- no dense contraction, ~150 scalar fp32 instructions per pixel, frame and depth hypothesis, ~13 hypotheses per pixel and call"},
                     "kernel_frac": round(ach_k / HBM_PEAK_GBS, 5),
                     "dominant_kernel": {"name": kname + " (cost map + random depth samples: exact early rejection, survivor queue in LDS; 1 launch per optimize_depth call)",
                                         "algorithmic_bytes": b_cr, "avg_us": round(groups["cost_rand"]["avg_us"], 2), "achieved": round(ach_k, 2), "traffic": traffic,
@@ -403,7 +422,7 @@ def main():
             "n_registered": int(out["n_registered"]),
             "pose_rpe_vs_gt": {"rot_rad_max": float(rot.max()) if len(rot) else None, "rel_trans_max": float(tr.max()) if len(tr) else None},
             "pose_rpe_vs_reference": vs_ref,
-            "roofline": roof, "cpu_baseline": cpu, "cpu_reference": cpu_ref, "host_inclusive": host_inc, "strict": strict, "concurrent": conc,
+            "latency": latency, "roofline": roof, "cpu_baseline": cpu, "cpu_reference": cpu_ref, "host_inclusive": host_inc, "strict": strict, "concurrent": conc,
         }
         print(json.dumps(line), flush=True)
     if frontend == "capi":

@@ -48,7 +48,10 @@ struct PoseBlock {
     // (decide_active in vk_pose.hip, voldor.cpp:187-194): the depth kernels clamp their frame count to it, so the host can enqueue them
     // before it has seen the decision itself.  B-inner callers pass the count by argument: MAX_FRAMES here.
     int n_active;
-    int pad_[3];
+    // bit f: depth prior f sits at the identity pose (R = I, t = 0 exactly: the disparity / RGB-D prior of the reference frame).  Written by
+    // cum_poses_block (fast path); such a prior is sampled AT the pixel -- no projection, no bilinear arithmetic (prior_parts, vk_depth.hip)
+    int dp_ident;
+    int pad_[2];
     // Fast path only (k_cum_poses, vk_depth.hip): the rigid chain of optimize_depth.cu:54-81 folded into one projective map per
     // frame.  With (Rc_f, tc_f) = the pose that takes frame-0 coordinates to frame f+1 (Rc_f = R_f Rc_{f-1}, tc_f = R_f tc_{f-1} + t_f)
     // the homogeneous pixel of (x, y, depth d) in frame f+1 is  d * cumM[f] (x, y, 1)^T + cumT[f],  cumM = K Rc K^-1, cumT = K tc;
