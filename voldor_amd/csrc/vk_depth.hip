@@ -423,41 +423,53 @@ __device__ __forceinline__ static void lean_head(const Img& I, const LeanK& K, c
     }
     for (int f = 0; f < I.N_dp; f++) prior_term_lean(I, P, f, x, y, d, cs, ws);
 }
-// frames 1.. of compute_pixel_cost (optimize_depth.cu:140-198): positions of all frames, then all gathers, then the model
-template <int NMAX>
+// frames 1.. of compute_pixel_cost (optimize_depth.cu:140-198), CH frames at a time: positions of the chunk, then its gathers, then the
+// model.  CH = 1 (one frame after the other) is the default at every size.  Measured (sample pass / table pass per launch): keeping all
+// gathers of a hypothesis in flight together (CH = number of frames, the round-2 kernels) costs 7 staging registers per frame --
+// 122 VGPRs = 4 waves per SIMD for 12 frames; CH = 4 / 3 / 2 / 1 at 1080p N=10: 423 / 412 / 408 / 383 us and 62.4 / 61.5 / 59.7 / 58.6 us
+// (from 457 and 69.6), 1241x376 N=8: 103.5 -> 86.4 us, 640x480 N=5: 45.9 -> 43.1 us.  More resident waves hide the gather latency better
+// than more gathers per wave.  The sums run over the frames in the same order for every CH: same bits.
+constexpr int LEAN_CHUNK = 1;
+template <int NMAX, int CH = LEAN_CHUNK>
 __device__ __forceinline__ static void lean_rest(const Img& I, const LeanK& K, const PoseBlock* P, int pi, float x, float y, float d, float px1, float py1,
                                                  float& cs, float& ws) {
 #pragma clang fp contract(off)
     const int w = I.w, h = I.h, npx = w * h;
     const float fw = (float)w, fh = (float)h;
-    float qx[NMAX], qy[NMAX], ex[NMAX], ey[NMAX];
-    unsigned valid = 0;
-#pragma unroll
-    for (int f = 1; f < NMAX; f++) {
-        if (f < I.N) {  // uniform.  Inside: selects, no divergent branch (a branch per frame costs the zero-fill of its four slots twice over)
-            float px2, py2;
-            const bool zok = lean_step(P, f, x, y, d, px2, py2);
-            const bool ok = zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh;
-            valid |= ok ? (1u << f) : 0u;
-            qx[f] = ok ? px1 : 0.f; qy[f] = ok ? py1 : 0.f;  // a frame that does not contribute gathers texel (0,0) and is dropped below
-            ex[f] = px2 - px1; ey[f] = py2 - py1;
-            px1 = ok ? px2 : px1; py1 = ok ? py2 : py1;  // advances on contributing frames only (:162-164)
-        } else { qx[f] = 0.f; qy[f] = 0.f; ex[f] = 0.f; ey[f] = 0.f; }
-    }
-    float2 obs[NMAX];
-    float wgt[NMAX];
-#pragma unroll
-    for (int f = 1; f < NMAX; f++) {
-        obs[f] = make_float2(0.f, 0.f); wgt[f] = 0.f;
-        if (f < I.N) { obs[f] = bilinear2_inside(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]); wgt[f] = I.rig[(size_t)f * npx + pi]; }
-    }
     float cl = 0.f;
 #pragma unroll
-    for (int f = 1; f < NMAX; f++) {
-        if (f < I.N && ((valid >> f) & 1u)) {
-            const ObsTerms T = obs_terms(obs[f].x, obs[f].y, K.ia2, K.l2q);
-            cl = fmaf(wgt[f], fast_log2(1.f + obs_ratio(T, ex[f] - obs[f].x, ey[f] - obs[f].y, K.qia2)), cl);
-            ws += wgt[f];
+    for (int f0 = 1; f0 < NMAX; f0 += CH) {
+        float qx[CH], qy[CH], ex[CH], ey[CH];
+        unsigned valid = 0;
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int f = f0 + j;
+            if (f < NMAX && f < I.N) {  // uniform.  Inside: selects, no divergent branch (a branch per frame costs the zero-fill of its four slots twice over)
+                float px2, py2;
+                const bool zok = lean_step(P, f, x, y, d, px2, py2);
+                const bool ok = zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh;
+                valid |= ok ? (1u << j) : 0u;
+                qx[j] = ok ? px1 : 0.f; qy[j] = ok ? py1 : 0.f;  // a frame that does not contribute gathers texel (0,0) and is dropped below
+                ex[j] = px2 - px1; ey[j] = py2 - py1;
+                px1 = ok ? px2 : px1; py1 = ok ? py2 : py1;  // advances on contributing frames only (:162-164)
+            } else { qx[j] = 0.f; qy[j] = 0.f; ex[j] = 0.f; ey[j] = 0.f; }
+        }
+        float2 obs[CH];
+        float wgt[CH];
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int f = f0 + j;
+            obs[j] = make_float2(0.f, 0.f); wgt[j] = 0.f;
+            if (f < NMAX && f < I.N) { obs[j] = bilinear2_inside(I.flows + (size_t)f * npx, w, h, qx[j], qy[j]); wgt[j] = I.rig[(size_t)f * npx + pi]; }
+        }
+#pragma unroll
+        for (int j = 0; j < CH; j++) {
+            const int f = f0 + j;
+            if (f < NMAX && f < I.N && ((valid >> j) & 1u)) {
+                const ObsTerms T = obs_terms(obs[j].x, obs[j].y, K.ia2, K.l2q);
+                cl = fmaf(wgt[j], fast_log2(1.f + obs_ratio(T, ex[j] - obs[j].x, ey[j] - obs[j].y, K.qia2)), cl);
+                ws += wgt[j];
+            }
         }
     }
     cs = fmaf(0.6931471805599453f, cl, cs);
@@ -869,39 +881,27 @@ __global__ __launch_bounds__(256) static void k_update_rigidness_lean(Img I, flo
     const int blk = tile, nblk = gridDim.x * gridDim.y;
     const float d = live ? I.depth[pi] : 1.f;
     const float x = (float)(live ? xi : 0), y = (float)(live ? yi : 0), fw = (float)w, fh = (float)h;
-    float qx[NMAX], qy[NMAX], rdx[NMAX], rdy[NMAX];
-    unsigned valid = 0;
+    // one frame after the other (see lean_rest): position, gather, model, store, block sum
     {
         float px1 = x, py1 = y;
 #pragma unroll
         for (int f = 0; f < NMAX; f++) {
-            if (f < I.N) {  // uniform; selects inside (see lean_rest)
+            if (f < I.N) {  // uniform; selects inside
                 float px2, py2;
                 const bool zok = lean_step(P, f, x, y, d, px2, py2);
                 const bool ok = live && zok && px1 >= 0.f && px1 < fw && py1 >= 0.f && py1 < fh;
-                valid |= ok ? (1u << f) : 0u;
-                qx[f] = ok ? px1 : 0.f; qy[f] = ok ? py1 : 0.f; rdx[f] = px2 - px1; rdy[f] = py2 - py1;
+                const float rdx = px2 - px1, rdy = py2 - py1;
+                const float2 obs = (f == 0) ? I.flows[pi] : bilinear2_inside(I.flows + (size_t)f * npx, w, h, ok ? px1 : 0.f, ok ? py1 : 0.f);
                 px1 = ok ? px2 : px1; py1 = ok ? py2 : py1;  // NOT advanced on invalid frames
-            } else { qx[f] = 0.f; qy[f] = 0.f; rdx[f] = 0.f; rdy[f] = 0.f; }
-        }
-    }
-    float2 obs[NMAX];
-#pragma unroll
-    for (int f = 0; f < NMAX; f++) {
-        obs[f] = make_float2(0.f, 0.f);
-        if (f < I.N) obs[f] = (f == 0) ? I.flows[pi] : bilinear2_inside(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
-    }
-#pragma unroll
-    for (int f = 0; f < NMAX; f++) {
-        if (f < I.N) {
-            float r = 0.f;
-            if ((valid >> f) & 1u) {
-                const ObsTerms T = obs_terms(obs[f].x, obs[f].y, K.ia2, K.l2q);
-                r = fast_rcp(1.f + obs_ratio(T, rdx[f] - obs[f].x, rdy[f] - obs[f].y, K.qia2));
+                float r = 0.f;
+                if (ok) {
+                    const ObsTerms T = obs_terms(obs.x, obs.y, K.ia2, K.l2q);
+                    r = fast_rcp(1.f + obs_ratio(T, rdx - obs.x, rdy - obs.y, K.qia2));
+                }
+                if (live) I.rig[(size_t)f * npx + pi] = r;
+                const float ws = wave_sum(live ? r : 0.f);
+                if ((threadIdx.x & 63) == 0) s_part[f][threadIdx.x >> 6] = ws;
             }
-            if (live) I.rig[(size_t)f * npx + pi] = r;
-            const float ws = wave_sum(live ? r : 0.f);
-            if ((threadIdx.x & 63) == 0) s_part[f][threadIdx.x >> 6] = ws;
         }
     }
     __syncthreads();
