@@ -117,16 +117,23 @@ def main():
             trccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
             if os.path.exists(trccl):
                 os.environ.setdefault("VOLDOR_HIP_RCCL", trccl)
+            store = None
             try:
-                import datetime
-                store = None
-                if world > 1:
-                    store = dist.TCPStore(os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]), world, rank == 0, timeout=datetime.timedelta(seconds=300))
+                if "RANK" in os.environ:  # launched by torch.distributed.run: its rendezvous hands out the store (the agent's own TCPStore when
+                    # TORCHELASTIC_USE_AGENT_STORE is set -- binding MASTER_PORT a second time would fail); no process group is created
+                    store, _, _ = next(dist.rendezvous("env://", rank=rank, world_size=world))
                 vdist.capi_init(rank, world, store=store)
-            except Exception as e:  # never lose the scaling run to the rendezvous: fall back to the torch front end, and say so
-                if world > 1:
-                    raise
-                frontend, frontend_note = "torch", f"capi front end unavailable ({e}); fell back to torch.distributed"
+                ok = True
+            except Exception as e:
+                ok, frontend_note = False, f"capi front end unavailable on rank {rank} ({e}); fell back to torch.distributed"
+            if store is not None:  # every rank must take the same front end: agree through the store
+                store.set(f"voldor_capi_ok_{rank}", b"1" if ok else b"0")
+                all_ok = all(bytes(store.get(f"voldor_capi_ok_{r}")) == b"1" for r in range(world))
+                if ok and not all_ok:
+                    vdist.capi_finalize(); frontend_note = "capi front end unavailable on another rank; fell back to torch.distributed"
+                ok = all_ok
+            if not ok:
+                frontend = "torch"
         if frontend == "torch":
             dist.init_process_group("nccl", rank=rank, world_size=world)  # backend nccl == RCCL on ROCm
     basefocal = wl["basefocal"]

@@ -32,6 +32,18 @@ def test_nccl_branch_with_one_rank(frontend):
     assert ("below the C-ABI" in j["config"]["parallelism"]) == (frontend == "capi"), j["config"]["parallelism"]
 
 
+def test_capi_front_end_under_torchrun_with_one_rank():
+    """The launch the driver uses for N > 1 (`python -m torch.distributed.run ... bench.py --gpus N`), here with one rank: the
+    ncclUniqueId store comes from torchrun's own rendezvous (the elastic agent owns MASTER_PORT: a second TCPStore server there
+    would fail), the ranks agree on the front end through it, the library's communicator does the exchange."""
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29545",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--no-extras", "--force-dist"],
+                       capture_output=True, text=True, cwd=ROOT, env=dict(os.environ), timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 1 and j["n_registered"] == 5 and "below the C-ABI" in j["config"]["parallelism"] and "fell back" not in j["config"]["parallelism"], j["config"]
+
+
 @pytest.mark.parametrize("frontend", ["capi", "torch"])
 def test_nccl_two_ranks_all_gather(frontend):
     import torch
