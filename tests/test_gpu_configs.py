@@ -249,3 +249,41 @@ def test_big_window_fast_mode_vs_the_reference_pipeline(name):
     for k in ("rot", "trans", "depth", "logcov"):
         assert d[k] <= GUARD * b[k]["max"], (name, k, d[k], b[k]["max"])
     assert d["within_1e-3"] >= b["within_1e-3"]["min"] / GUARD, (d["within_1e-3"], b["within_1e-3"]["min"])
+
+
+# ---- sizes beyond the BASELINE configs (segment lengths of fb_smooth, prefix of the rank-select draw) ------------------------
+@pytest.mark.parametrize("w,h,why", [(600, 1400, "columns longer than 1280: 40-step fb_smooth segments"),
+                                     (4096, 1040, "16640 blocks of 256 pixels: the scanned block counts of the rank-select draw stay in global memory")])
+# (rows longer than 5120 pixels -- 40-step segments in the row pass -- are covered by test_fb_smooth_segment_lengths_and_serial_fallback: a
+# 5400-pixel-wide window that fits a test is a strip whose geometry no longer constrains the pose)
+def test_large_and_odd_shaped_windows(w, h, why):
+    """Windows whose shape takes the launch-dependent paths of fb_smooth and of the index draw: all frames registered, poses as accurate
+    against ground truth as the guard of this file allows, same result twice."""
+    from voldor_amd import pyvoldor, synth, kernels
+    f = 0.6 * max(w, h)
+    sc = synth.make_scene(w=w, h=h, n_flows=2, fx=f, fy=f, cx=w / 2.0, cy=h / 2.0, seed=251, basefocal=0.5 * f)
+    fx, fy, cx, cy = sc["K"]
+    cfg = "--silent --meanshift_kernel_var 0.1 --disp_delta 1 --delta 0.2 --max_iters 3"
+    outs = []
+    for _ in range(2):
+        kernels.set_rand_epoch(0)
+        outs.append(pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, basefocal=0.5 * f, disparity=sc["disparity"], config=cfg))
+    g = outs[0]
+    assert g["n_registered"] == 2 and np.isfinite(g["depth"]).all(), why
+    rot, tr = synth.pose_errors(g["poses"], sc["poses_gt"])
+    assert _gt_ok("cfg3", rot, tr), (why, rot, tr)
+    for k in ("poses", "poses_covar", "depth", "depth_conf"):
+        np.testing.assert_array_equal(outs[0][k], outs[1][k])
+
+
+def test_fb_smooth_segment_lengths_and_serial_fallback(orc):
+    """fb_smooth alone (B-inner helper) on maps that take 20-step segments, 40-step segments and -- beyond 10240 x 2560 -- the
+    one-lane-per-line fallback, against the oracle's step-by-step recurrence (D7: 2e-5 absolute for the segmented forms; the fallback
+    is the recurrence itself)."""
+    from voldor_amd import kernels
+    rng = np.random.default_rng(11)
+    for (n, h, w) in ((1, 1400, 48), (1, 24, 5400), (1, 8, 10300)):
+        m = rng.uniform(0.02, 0.98, (n, h, w)).astype(np.float32)
+        rc, g = kernels.fb_smooth_gpu(m.copy())
+        assert rc == 0, (h, w)
+        assert np.abs(orc.fb_smooth(m.copy()) - g).max() < 2e-5, (h, w)
