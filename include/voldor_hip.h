@@ -136,6 +136,10 @@ int vk_set_local_serial(int on);
 /* Verification aid: 0 = the global-propagation passes of the fast mode evaluate a site with one lane (k_global_prop_sites_lean) instead of
  * a group of lanes (k_global_prop_split_lean); identical maps (tests/test_gpu_kernels.py::test_global_split_equals_one_lane_per_site).  Default 1. */
 int vk_set_global_split(int on);
+/* Verification aid: 1 = the sample pass of the fast mode evaluates every random depth in full, one after the other (the literal order of
+ * optimize_depth.cu:269-284 on the fast arithmetic) instead of exact early rejection + survivor queue; identical maps
+ * (tests/test_gpu_kernels.py::test_sample_pass_equals_the_plain_sequential_form).  Default 0. */
+int vk_set_cost_rand_plain(int on);
 /* Verification aid: 0 = the mean-shift kernel evaluates the initial-mode trials of a camera without a pose itself (20 passes on one
  * compute unit) instead of taking them from k_mode_trials (one workgroup per trial); same picks, same rule
  * (tests/test_gpu_voldor.py::test_split_trials_equal_in_kernel_trials).  Default 1. */

@@ -163,6 +163,38 @@ def test_local_runs_equal_the_step_by_step_chain(width, noise, n_flows, n_dp):
         np.testing.assert_array_equal(c1.view(np.uint32), c2.view(np.uint32))
 
 
+@pytest.mark.parametrize("noise,n_flows,n_dp,n_rand", [(0.3, 5, 0, 10), (0.02, 5, 0, 10), (0.2, 8, 1, 10), (0.1, 10, 1, 7), (0.3, 13, 2, 10), (0.0, 3, 0, 12), (0.2, 1, 0, 10), (0.2, 16, 0, 3)])
+def test_sample_pass_equals_the_plain_sequential_form(noise, n_flows, n_dp, n_rand):
+    """k_cost_rand_q -- exact early rejection after frame 0 and the priors, survivors compacted into an LDS queue, winner by a 64-bit
+    atomicMin on (cost bits, sample index) -- against the plain loop over the samples in the same fast arithmetic
+    (vk_set_cost_rand_plain): IDENTICAL depth maps and rigidness maps, bit for bit, from noisy starts (most samples rejected late) to
+    converged ones, with and without depth priors (identity and non-identity poses), sample counts that are not a multiple of the round."""
+    from voldor_amd import kernels, synth
+    sc = synth.make_scene(w=211, h=97, n_flows=n_flows, fx=100, fy=100, cx=105, cy=48, seed=29, basefocal=40.0 if n_dp else 0.0)
+    rng = np.random.default_rng(int(n_flows * 100 + noise * 1000))
+    K = K9(*sc["K"])
+    flows, Rs, ts, depth, rig = _state(sc, rng, noise=noise)
+    if noise == 0.0:
+        depth = sc["depth_gt"].astype(np.float32).copy()
+    h, w = depth.shape
+    extra = {}
+    if n_dp:
+        pri = np.stack([(sc["depth_gt"] * (1 + rng.normal(0, 0.05, (h, w)))).astype(np.float32) for _ in range(n_dp)])
+        pri[:, ::7, ::5] = 0.0  # holes
+        extra = dict(priors=pri, pconfs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32), confs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32),
+                     dp_Rs=np.tile(np.eye(3, dtype=np.float32), (n_dp, 1, 1)), dp_ts=(rng.normal(0, 0.02, (n_dp, 3)) * np.arange(n_dp)[:, None]).astype(np.float32))
+    over = dict(n_rand_samples=n_rand, global_prop_step=0, local_prop_width=0, fb_smooth=0, basefocal=40.0 if n_dp else 0.0, disp_delta=1.0 if n_dp else -1.0)
+    try:
+        kernels.set_cost_rand_plain(True)
+        d1, r1, c1 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
+    finally:
+        kernels.set_cost_rand_plain(False)
+    d2, r2, c2 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
+    assert np.mean(d1 != depth) > (0.05 if noise >= 0.1 else 0.0)  # samples were accepted
+    np.testing.assert_array_equal(d1.view(np.uint32), d2.view(np.uint32))
+    np.testing.assert_array_equal(r1.view(np.uint32), r2.view(np.uint32))
+
+
 @pytest.mark.parametrize("step,noise,n_flows,n_dp", [(8, 0.3, 5, 0), (2, 0.3, 4, 0), (5, 0.1, 8, 1), (8, 0.2, 10, 0), (3, 0.2, 13, 2), (8, 0.05, 16, 0), (7, 0.3, 1, 0)])
 def test_global_split_equals_one_lane_per_site(step, noise, n_flows, n_dp):
     """The global-propagation passes with a site evaluated by a group of lanes (k_global_prop_split_lean, the default) against one lane

@@ -23,6 +23,7 @@
 namespace vk {
 
 static std::atomic<int> g_local_serial{0};  // vk_set_local_serial (verification aid)
+static std::atomic<int> g_cost_rand_plain{0};  // vk_set_cost_rand_plain (verification aid): 1 = every random sample evaluated in full, one after the other
 static std::atomic<int> g_global_split{1};  // vk_set_global_split (verification aid): 0 = one lane per site (k_global_prop_sites_lean)
 
 // phase clocks (profiling builds only, scripts/phase_clocks.sh): thread 0 of the middle workgroup of a launch
@@ -591,6 +592,27 @@ __global__ __launch_bounds__(256) static void k_cost_rand_q(Img I, int n_rand, u
         __syncthreads();
     }
     if (live) { I.depth[pi] = d_best; I.cost[pi] = c_best; }
+}
+
+// Verification aid (vk_set_cost_rand_plain): the sample pass in the literal order of optimize_depth.cu:269-284 on the fast arithmetic --
+// incumbent, then every random depth evaluated in full and taken if strictly cheaper -- no early rejection, no queue.  k_cost_rand_q must
+// give the same depth and cost maps bit for bit: its rejection bound is exact and its winner is the cheapest sample, the earliest among
+// equals (tests/test_gpu_kernels.py::test_sample_pass_equals_the_plain_sequential_form).
+template <int NMAX>
+__global__ __launch_bounds__(256) static void k_cost_rand_plain(Img I, int n_rand, uint32_t epoch0, float range_factor) {
+    if (!clamp_active(I)) return;
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int xi = (tile % gridDim.x) * 64 + (threadIdx.x & 63), yi = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
+    if (xi >= I.w || yi >= I.h) return;
+    const int pi = yi * I.w + xi;
+    const LeanK K = lean_consts(I);
+    float d_best = I.depth[pi], c_best = pixel_cost_lean<NMAX>(I, K, xi, yi, d_best);
+    for (int k = 0; k < n_rand; k++) {
+        const float d = sample_depth(pi, epoch0 + (uint32_t)k, range_factor);
+        const float c = pixel_cost_lean<NMAX>(I, K, xi, yi, d);
+        if (c < c_best) { c_best = c; d_best = d; }
+    }
+    I.depth[pi] = d_best; I.cost[pi] = c_best;
 }
 
 template <int NMAX>
@@ -1239,6 +1261,7 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
     if constexpr (!STRICT) { if (!cum_in_fb) hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, S.pb(), p.N, p.N_dp, p.world_scale_out); }
     auto cost_rand = [&](int n_rand, uint32_t epoch) {
         if constexpr (STRICT) hipLaunchKernelGGL(k_cost_rand_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
+        else if (g_cost_rand_plain.load(std::memory_order_relaxed)) hipLaunchKernelGGL(k_cost_rand_plain<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
         else hipLaunchKernelGGL(k_cost_rand_q<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
     };
     if (cost_only) {
@@ -1434,6 +1457,7 @@ int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk
 
 extern "C" __attribute__((visibility("default"))) int vk_set_local_serial(int on) { vk::g_local_serial.store(on ? 1 : 0); return 0; }
 extern "C" __attribute__((visibility("default"))) int vk_set_global_split(int on) { vk::g_global_split.store(on ? 1 : 0); return 0; }
+extern "C" __attribute__((visibility("default"))) int vk_set_cost_rand_plain(int on) { vk::g_cost_rand_plain.store(on ? 1 : 0); return 0; }
 
 #ifdef VK_PHASE_CLOCKS
 extern "C" __attribute__((visibility("default"))) int vk_phase_read_depth(unsigned long long* out, int n, int reset) {

@@ -225,6 +225,11 @@ def set_global_split(on: bool):
     capi.check(capi.lib().vk_set_global_split(int(on)), "vk_set_global_split")
 
 
+def set_cost_rand_plain(on: bool):
+    """Verification aid (include/voldor_hip.h: vk_set_cost_rand_plain): sample pass as the plain sequential loop instead of rejection + survivor queue."""
+    capi.check(capi.lib().vk_set_cost_rand_plain(int(on)), "vk_set_cost_rand_plain")
+
+
 def set_split_trials(on: bool):
     """Verification aid (include/voldor_hip.h: vk_set_split_trials): initial-mode trials as their own workgroups (default) or inside the mode kernel."""
     capi.check(capi.lib().vk_set_split_trials(1 if on else 0), "vk_set_split_trials")
