@@ -156,7 +156,9 @@ const char* vk_version(void);
  * { n_registered | poses[N][6] | poses_covar[N][36] } (1 + 42 N floats per rank) per batch step over RCCL / xGMI.
  * The communicator, its stream and the device records are owned by the library (C++ host code); the launcher only carries
  * the 128-byte ncclUniqueId of rank 0 to the other ranks (or names a file all ranks can see).  RCCL (librccl.so.1, or the path in
- * VOLDOR_HIP_RCCL) is bound at the first call of this section.  Return codes: 0, a HIP error code, or 1000 + ncclResult_t. */
+ * VOLDOR_HIP_RCCL) is bound at the first call of this section.  Return codes: 0, a HIP error code, or 1000 + ncclResult_t.
+ * Like the rest of the library (and the reference: file-static state, one caller thread) this section is driven by ONE thread per process;
+ * vk_dist_init_file needs a path that is new for every job. */
 #define VK_DIST_ID_BYTES 128
 int vk_dist_get_unique_id(void* id_out);                      /* rank 0: ncclGetUniqueId */
 int vk_dist_init(int rank, int world, const void* id);        /* ncclCommInitRank on the current device (vk_set_device first) */

@@ -110,18 +110,27 @@ int vk_dist_init(int rank, int world, const void* id_in) {
     VK_CHECK(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof id);
-    VK_NCCL(g_rccl.CommInitRank(&d.comm, world, id, rank));
+    const ncclResult_t r = g_rccl.CommInitRank(&d.comm, world, id, rank);
+    if (r != ncclSuccess || hipMalloc((void**)&d.scalar, sizeof(double)) != hipSuccess) {  // leave nothing behind: a later vk_dist_init starts clean
+        fprintf(stderr, "voldor_hip: ncclCommInitRank(rank %d of %d) failed: %s\n", rank, world, r != ncclSuccess ? g_rccl.GetErrorString(r) : "out of device memory");
+        if (d.comm) g_rccl.CommDestroy(d.comm);
+        (void)hipStreamDestroy(d.stream);
+        d = Dist{};
+        return r != ncclSuccess ? 1000 + (int)r : (int)hipErrorOutOfMemory;
+    }
     d.rank = rank; d.world = world;
-    VK_CHECK(hipMalloc((void**)&d.scalar, sizeof(double)));
     return 0;
 }
 
 /* Rendezvous through one file every rank can see (a launcher without a store of its own): rank 0 creates the id and publishes it
- * by an atomic rename; the others wait for the file.  The file is left in place (the launcher owns the path). */
+ * by an atomic rename; the others wait for the file.  The path must be NEW for every job (as with any file rendezvous: a file left by
+ * an earlier job would hand its stale id to ranks that start before rank 0 has replaced it); rank 0 removes a leftover it finds, which
+ * covers jobs run one after the other under one name.  The file is left in place (the launcher owns the path). */
 int vk_dist_init_file(int rank, int world, const char* path, int timeout_s) {
     if (!path || world < 1 || rank < 0 || rank >= world) return (int)hipErrorInvalidValue;
     unsigned char id[VK_DIST_ID_BYTES];
     if (rank == 0) {
+        (void)remove(path);
         if (int e = vk_dist_get_unique_id(id)) return e;
         const std::string tmp = std::string(path) + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb");
