@@ -21,11 +21,12 @@
  *     tests/golden/ref_kernels.npz.
  *  3. the host pipeline (voldor/py_export.cpp, voldor.cpp, geometry.cpp, utils.cpp) is compiled in
  *     place against ref_stubs/minicv (stand-in for the OpenCV calls) and linked to 2.
- *     (ref_wrap_host.cpp): the reference's own py_voldor_wrapper runs end to end.  With
- *     ORC_REFERENCE_DRAW=1, the reference rodrigues() installed via orc_set_rodrigues_hook and,
- *     for the reference's default exclusive mode, ORC_EMULATE_B1=1, orc_voldor reproduces every
- *     output of 6 windows bit for bit -- tests/test_oracle_vs_ref_window.py,
- *     tests/golden/ref_window.npz.  These three switches exist for that test only.
+ *     (ref_wrap_host.cpp): the reference's own py_voldor_wrapper runs end to end.  With the
+ *     reference's draw (the default; ORC_REFERENCE_DRAW=0 selects D3b), the reference's rodrigues()
+ *     -- restated to the bit in voldor_amd/csrc/vk_ref_svd.h (orc_set_reference_svd) or installed as
+ *     the reference's own code via orc_set_rodrigues_hook -- and, for the reference's default
+ *     exclusive mode, ORC_EMULATE_B1=1, orc_voldor reproduces every output of the windows bit for
+ *     bit -- tests/test_oracle_vs_ref_window.py, tests/golden/ref_window.npz, ref_window_strict.npz.
  * Still unpinned: OpenCV's own numerics (5-point bootstrap replaced by D5; Rodrigues / inv / gemm
  * restated in minicv from documented behaviour).
  *
@@ -35,17 +36,20 @@
  *     no bleeding between stacked layers) -- gmat.h:175-179.
  *  D3 random sample index clamped to N_pts-1 (reference can read one past the end,
  *     solve_batch_lambdatwist.cu:16-19).
- *  D3b inside the window pipeline the 4 correspondences of a hypothesis are drawn uniformly from the
- *     valid set by rejection over the map instead of by index into the compacted list (same
- *     distribution; a 1-pixel change of the set no longer re-draws all 8192 hypotheses).
+ *  D3b (optional since round 3: ORC_REFERENCE_DRAW=0; the default is the reference's index draw) inside the
+ *     window pipeline the 4 correspondences of a hypothesis are drawn uniformly from the valid set by
+ *     rejection over the map instead of by index into the compacted list (same distribution; a 1-pixel
+ *     change of the set no longer re-draws all 8192 hypotheses -- but an independent sample of them:
+ *     tests/test_gpu_ensemble.py).
  *  D4 one depth buffer shared by the depth and the pose half (the reference keeps a
  *     stale un-normalised copy in optimize_depth.cu).
  *  D5 8-point LMedS two-view bootstrap instead of OpenCV's 5-point findEssentialMat (not in the tree).
  *  D6 world-scale normalisation skipped when the window is lost (reference: 0/0).
- *  D8 rodrigues(): exact polar factor instead of the reference's approximate fp32 SVD (svd3_cuda.h).
+ *  D8 rodrigues(): exact polar factor instead of the reference's approximate fp32 SVD (svd3_cuda.h);
+ *     orc_set_reference_svd(1) switches to that SVD, bit for bit (product: --reference_svd 1).
  *  (D7 is product-only: fb_smooth arithmetic, see DESIGN.md.)
- *  Test-only switches that undo D3b / D4 / D8 for the whole-window comparison with the reference pipeline:
- *  ORC_REFERENCE_DRAW=1, ORC_EMULATE_B1=1, orc_set_rodrigues_hook().
+ *  Switches for the whole-window comparison with the reference pipeline: ORC_REFERENCE_DRAW (default 1),
+ *  orc_set_reference_svd() / orc_set_rodrigues_hook() (D8), ORC_EMULATE_B1=1 (D4, test only).
  *
  * All citations are file:line relative to /root/reference.
  */
