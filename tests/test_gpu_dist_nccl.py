@@ -101,3 +101,60 @@ def test_capi_dist_without_torch_in_the_process():
     vk_voldor_device returns for the same window; an empty step is marked -1."""
     r = subprocess.run([sys.executable, "-c", _STANDALONE.format(root=ROOT)], capture_output=True, text=True, cwd=ROOT, timeout=600)
     assert r.returncode == 0 and "STANDALONE_OK" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
+
+
+_TWO_RANK = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+rank, world, path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+from voldor_amd import capi, synth
+from voldor_amd import dist as vd
+lib = capi.lib()
+capi.check(lib.vk_set_device(0), "vk_set_device")            # both ranks on GPU 0: the stand-in stages through the host
+capi.check(lib.vk_dist_init_file(rank, world, path.encode(), 60), "vk_dist_init_file")
+assert lib.vk_dist_world() == world and lib.vk_dist_rank() == rank and lib.vk_dist_rccl_version() == 999
+N, h, w = 3, 120, 160
+cfg = b"--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 2"
+seeds = [233, 234, 235, 236, 237]                              # five sequences over two ranks: rank 0 gets three, rank 1 two + an empty step
+scenes = {{s: synth.make_scene(w=w, h=h, n_flows=N, fx=80, fy=80, cx=80, cy=60, seed=s) for s in seeds}}
+def window(fn, seed, *tail):
+    poses = np.zeros((N, 6), np.float32); covar = np.zeros((N, 36), np.float32); n = C.c_int(0)
+    lib.vk_set_rand_epoch(0)
+    fl = scenes[seed]["flows"] if seed is not None else None
+    capi.check(fn(capi.fp(fl), None, None, None, None, None, C.c_float(80), C.c_float(80), C.c_float(80), C.c_float(60), C.c_float(0), N, 0, w, h, cfg,
+                  C.byref(n), capi.fp(poses), capi.fp(covar), None, None, *tail), "window")
+    return n.value, poses, covar
+def step(seed):
+    blocks = np.zeros((world, 1 + 42 * N), np.float32)
+    window(lib.vk_voldor_sharded, seed, capi.fp(blocks))
+    return blocks
+res = vd.capi_run_sharded(seeds, step, N)
+assert len(res) == len(seeds) and all(r is not None for r in res)
+for s, r in zip(seeds, res):                                    # every rank holds every sequence's result = the one-at-a-time window
+    n0, p0, c0 = window(lib.vk_voldor_device, s)
+    assert r["n_registered"] == n0 == N and np.array_equal(r["poses"], p0[:n0]) and np.array_equal(r["poses_covar"].reshape(n0, 36), c0[:n0]), s
+v = C.c_double(10.0 + rank); capi.check(lib.vk_dist_allreduce_max(C.byref(v)), "max"); assert v.value == 10.0 + world - 1
+capi.check(lib.vk_dist_barrier(), "barrier")
+lib.vk_dist_finalize()
+print("RANK_OK", rank)
+"""
+
+
+def test_capi_two_ranks_on_one_gpu_through_the_file_backed_stand_in(tmp_path):
+    """The N > 1 paths of vk_dist.hip on a one-GPU box: two processes share GPU 0 and bind tests/cxx/fake_rccl.cpp (a file-backed stand-in
+    for the seven RCCL entry points, loaded through VOLDOR_HIP_RCCL; RCCL itself refuses two ranks on one device).  Five sequences over
+    two ranks through vk_dist_init_file + vk_voldor_sharded (uneven shards: one rank sends an empty record in the last step): every rank
+    ends up with every sequence's poses and covariances, equal to the one-at-a-time window; max-over-ranks and barrier work.  What this
+    cannot show is RCCL with N > 1 -- that is the driver's 8-GPU run."""
+    from voldor_amd import build
+    build.build_test_lib()
+    fake = os.path.join(ROOT, "voldor_amd", "lib", "libfake_rccl_test.so")
+    assert os.path.exists(fake)
+    env = dict(os.environ, VOLDOR_HIP_RCCL=fake)
+    path = str(tmp_path / "id")
+    procs = [subprocess.Popen([sys.executable, "-c", _TWO_RANK.format(root=ROOT), str(r), "2", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+             for r in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in so, (r, so[-1000:], se[-3000:])

@@ -21,6 +21,7 @@ SOURCES = ["vk_abi.hip", "vk_depth.hip", "vk_pose.hip", "vk_strict.hip", "vk_boo
 # with the product flags; nothing in the product loads it and the product build does not depend on it.
 TEST_LIB = os.path.join(LIBDIR, "libvoldor_hip_test.so")
 TEST_SRC = os.path.join(os.path.dirname(HERE), "tests", "cxx", "vk_testhooks.hip")
+FAKE_RCCL_LIB = os.path.join(LIBDIR, "libfake_rccl_test.so")
 # The pose half (one hypothesis per lane) must reproduce the reference's fp32/fp64 rounding
 # sequence to stay inside the pose tolerance (vk_p3p.hpp NUMERICS NOTE): no fma contraction there.
 # It is a few hundred microseconds of work per window, so this costs nothing measurable; the
@@ -87,13 +88,19 @@ def build_test_lib(force: bool = False, verbose: bool = False):
     if not os.path.exists(TEST_SRC):
         return None
     os.makedirs(LIBDIR, exist_ok=True)
-    newest = max(os.path.getmtime(p) for p in _deps() + [TEST_SRC])
-    if not force and os.path.exists(TEST_LIB) and os.path.getmtime(TEST_LIB) >= newest:
+    newest = max(os.path.getmtime(p) for p in _deps() + [TEST_SRC] + [os.path.join(os.path.dirname(TEST_SRC), f) for f in os.listdir(os.path.dirname(TEST_SRC))])
+    if not force and os.path.exists(TEST_LIB) and os.path.getmtime(TEST_LIB) >= newest and os.path.exists(FAKE_RCCL_LIB) and os.path.getmtime(FAKE_RCCL_LIB) >= newest:
         return TEST_LIB
     cmd = [_hipcc()] + FLAGS + ["-ffp-contract=off", "-shared", "-o", TEST_LIB, TEST_SRC]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    fake = os.path.join(os.path.dirname(TEST_SRC), "fake_rccl.cpp")  # file-backed stand-in for librccl (two ranks on one GPU, tests only)
+    if os.path.exists(fake):
+        cmd = [_hipcc(), "-x", "hip", "--offload-arch=gfx950", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", FAKE_RCCL_LIB, fake]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
     return TEST_LIB
 
 
