@@ -158,3 +158,25 @@ def test_capi_two_ranks_on_one_gpu_through_the_file_backed_stand_in(tmp_path):
     outs = [p.communicate(timeout=600) for p in procs]
     for r, (p, (so, se)) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in so, (r, so[-1000:], se[-3000:])
+
+
+def test_bench_with_two_ranks_on_one_gpu_through_the_stand_in():
+    """bench.py's whole N = 2 flow (what the driver launches for its scaling run, minus the second GPU): two processes with RANK 0 / 1,
+    both on GPU 0 (LOCAL_RANK 0), the C-ABI front end bound to the file-backed stand-in.  Rendezvous through env://, agreement on the front
+    end, timed steps with the exchange inside vk_voldor_sharded, max-over-ranks time, and the rank-0-only measurement legs AFTER the
+    timed region, which must not contain a collective (a rank-0-only all-gather would wait for a rank that has already left)."""
+    from voldor_amd import build
+    build.build_test_lib()
+    fake = os.path.join(ROOT, "voldor_amd", "lib", "libfake_rccl_test.so")
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, VOLDOR_HIP_RCCL=fake, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--in-flight", "0"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
+    outs = [p.communicate(timeout=900) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, (r, so[-500:], se[-3000:])
+    j = _line(outs[0][0])
+    assert j["n_gpus"] == 2 and j["n_registered"] == 5 and j["value"] > 20 and "below the C-ABI" in j["config"]["parallelism"] and "fell back" not in j["config"]["parallelism"]
+    assert j["latency"] is not None and j["roofline"] is not None  # the rank-0-only legs ran (without a collective)
+    assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # rank 1 prints nothing
