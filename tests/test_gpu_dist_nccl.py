@@ -180,3 +180,28 @@ def test_bench_with_two_ranks_on_one_gpu_through_the_stand_in():
     assert j["n_gpus"] == 2 and j["n_registered"] == 5 and j["value"] > 20 and "below the C-ABI" in j["config"]["parallelism"] and "fell back" not in j["config"]["parallelism"]
     assert j["latency"] is not None and j["roofline"] is not None  # the rank-0-only legs ran (without a collective)
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # rank 1 prints nothing
+
+
+@pytest.mark.parametrize("world,rccl", [(1, "system"), (2, "stand-in")])
+def test_cxx_launcher_of_the_sharded_job(tmp_path, world, rccl):
+    """Host code above the C-ABI in C++ (north_star): tests/cxx/dist_client.cpp, built with plain g++ against include/voldor_hip.h and
+    linked with -lvoldor_hip, is the whole launcher -- vk_set_device, vk_dist_init_file, vk_voldor_sharded per step, the records of all
+    ranks checked against one-at-a-time windows.  One rank on the real (system) RCCL; two ranks on GPU 0 through the file-backed stand-in."""
+    import shutil
+    from voldor_amd import build, capi
+    if shutil.which("g++") is None:
+        pytest.skip("no g++ on this box")
+    exe = str(tmp_path / "dist_client")
+    libdir = os.path.dirname(capi.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++14", "-O1", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cxx", "dist_client.cpp"),
+                           "-L", libdir, "-lvoldor_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    env = dict(os.environ)
+    env.pop("VOLDOR_HIP_RCCL", None)
+    if rccl == "stand-in":
+        build.build_test_lib()
+        env["VOLDOR_HIP_RCCL"] = os.path.join(ROOT, "voldor_amd", "lib", "libfake_rccl_test.so")
+    path = str(tmp_path / "id")
+    procs = [subprocess.Popen([exe, str(r), str(world), path], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env) for r in range(world)]
+    for r, p in enumerate(procs):
+        out, _ = p.communicate(timeout=600)
+        assert p.returncode == 0 and f"DIST CLIENT OK {r}" in out, (r, p.returncode, out[-2000:])
