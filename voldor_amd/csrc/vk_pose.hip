@@ -931,13 +931,82 @@ constexpr float MS_FAR = 1e18f;
 #define VK_MS_TRIAL_BATCH 5
 #endif
 constexpr int MS_TRIAL_BATCH = VK_MS_TRIAL_BATCH;  // initial-mode trials evaluated per pass (meanshift.cu:72-95 runs them one at a time)
+// The prepare step of a gate iteration (fit_robust_gaussian.cu:172-205: Ledoit-Wolf shrinkage with fixed lambda, aux_funs.cpp:124-141, then
+// the inverse the gate needs) for the refit below, in a form EVERY LANE evaluates for itself from the all-reduced totals: no wave is
+// singled out, nothing goes through LDS, no second workgroup barrier.  The gate only needs the quadratic form d^T C^-1 d, and with
+// the Cholesky factor C = L L^T that is |y|^2, L y = d: a forward substitution per sample with the strict lower triangle of L and the
+// reciprocal of its diagonal -- 21 coefficients like the packed inverse, the same 27 multiply-adds per sample -- and a factorisation
+// of ~80 fp64 instructions (6 reciprocal square roots by v_rsq_f64 + one Newton step) instead of the LU / Newton-Schulz inverse
+// exchanged through LDS by one wave (~40 % of a gate iteration before).  L is better conditioned than C^-1 (square root of its
+// condition number).  A pivot below DBL_EPSILON or not positive: the covariance is not positive definite -- the reference's
+// `det <= 0` verdict (unreliable fit).  W (out): L's strict lower triangle, 1 / L_ii on the diagonal.
+// cov: packed lower triangle (float).  rg_regularised: the regularised covariance rounded to float (what the reference keeps and reports;
+// needed once, when the loop has ended).
+__device__ __forceinline__ double rsqrt_f64(double s) {
+#pragma clang fp contract(fast)
+    double y = __builtin_amdgcn_rsq(s);  // v_rsq_f64: 2^29 ulp = 2^-23 relative; one Newton step squares that (2^-45: the factor ends up in floats)
+    return y * (1.5 - (0.5 * s) * y * y);
+}
+__device__ __forceinline__ void rg_regularised(const float (&cov)[21], bool regularise, float lambda, float (&covr)[21]) {
+    double tr = 0.0;
+#pragma unroll
+    for (int d = 0; d < 6; d++) tr += (double)cov[(d * d + d) / 2 + d];
+    const double m = tr / 6.0, lam = (double)lambda;
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c <= r; c++) {
+            double full = (double)cov[(r * r + r) / 2 + c];
+            if (regularise) full = lam * m * (r == c ? 1.0 : 0.0) + (1 - lam) * full;
+            covr[(r * r + r) / 2 + c] = (float)full;
+        }
+}
+__device__ __forceinline__ bool rg_whiten(const float (&cov)[21], bool regularise, float lambda, float (&W)[21]) {
+#pragma clang fp contract(fast)  // not part of the solver's exact-rounding contract (file-wide: off)
+    double a[21];
+    double tr = 0.0;
+#pragma unroll
+    for (int d = 0; d < 6; d++) tr += (double)cov[(d * d + d) / 2 + d];
+    const double lam = regularise ? (double)lambda : 0.0, lm = lam * (tr / 6.0), ol = 1 - lam;  // lambda = 0: full = 0 + 1 * full, exactly
+#pragma unroll
+    for (int r = 0; r < 6; r++)
+#pragma unroll
+        for (int c = 0; c <= r; c++) a[(r * r + r) / 2 + c] = (r == c ? lm : 0.0) + ol * (double)cov[(r * r + r) / 2 + c];
+    double L[21], inv[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double s = a[(j * j + j) / 2 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) s -= L[(j * j + j) / 2 + k] * L[(j * j + j) / 2 + k];
+        ok = ok && (s >= 2.220446049250313e-16);  // false for NaN as well
+        inv[j] = rsqrt_f64(s);
+        L[(j * j + j) / 2 + j] = s * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double t = a[(i * i + i) / 2 + j];
+#pragma unroll
+            for (int k = 0; k < j; k++) t -= L[(i * i + i) / 2 + k] * L[(j * j + j) / 2 + k];
+            L[(i * i + i) / 2 + j] = t * inv[j];
+        }
+    }
+    // what the gate pass needs: the strict lower triangle of L and the reciprocal diagonal, for a forward substitution per sample
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+#pragma unroll
+        for (int k = 0; k < i; k++) W[(i * i + i) / 2 + k] = (float)L[(i * i + i) / 2 + k];
+        W[(i * i + i) / 2 + i] = (float)inv[i];
+    }
+    return ok;
+}
+
 // robust-Gaussian refit + finalisation (geometry.cpp:201-263, fit_robust_gaussian.cu:131-263); runs
-// on the last EM iteration only, ~30-50 gate/refit iterations per camera, each of them three dependent phases on ONE
-// compute unit: the fp64 inverse of the 6x6 covariance (one wave), the gate + moment pass over the pool (VALU-issue bound),
-// a 28-value all-reduce.  The 8192 scaled hypotheses stay in registers for the whole loop as pairs (two per lane, packed
-// fp32 arithmetic as in k_pose_mode); 512 threads, because everything that is not the pass is executed by every wave.  The gate
-// weight multiplies instead of branching (a wave practically always holds a gated sample).  Wave 0 turns the totals into the
-// new mean / covariance and inverts it right away, so an iteration has two workgroup barriers.
+// on the last EM iteration only, ~30-50 gate/refit iterations per camera, each of them dependent phases on ONE compute unit: the gate +
+// moment pass over the pool (VALU-issue bound), a 28-value all-reduce, the next gate's coefficients.  The 8192 scaled hypotheses stay
+// in registers for the whole loop as pairs (two per lane, packed fp32 arithmetic as in k_pose_mode); 512 threads, because everything
+// that is not the pass is executed by every wave.  The gate weight multiplies instead of branching (a wave practically always holds a
+// gated sample).  After the all-reduce every lane holds the 28 totals and derives the new mean, the regularised covariance and the
+// whitening factor itself (rg_whiten): ONE workgroup barrier per gate iteration, no serial section on a single wave.
 // It continues k_pose_mode<true> in the same kernel: the pool is already in registers (scaled for the mean-shift metric, non-finite
 // hypotheses as MS_FAR: their Mahalanobis distance is huge, infinite or NaN, never inside the gate, and 0 * MS_FAR = 0 in the sums).
 // ms_mean / ms_conf / ms_iters / used: the mean-shift result, the same in every thread.
@@ -946,43 +1015,32 @@ __device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], i
                                             const ModeParams& mp, CamState* cam, PoseBlock* P, int cam_idx, RedBuf& rb) {
 #pragma clang fp contract(fast)  // the gate / scatter sums are not part of the solver's exact-rounding contract
     constexpr int RF_PAIRS = PM_POOL / THREADS / 2, RF_NW = THREADS / 64;
-    __shared__ float s_cinv[21], s_cov[21], s_mean[6];
-    __shared__ int s_flag;
-    __shared__ double s_lu[108];
     PH_DECL;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int tid = threadIdx.x;
     const float sc = mp.rg_pose_scaling;
     // x = [rvec * rvec_scale | t] * rg_pose_scaling (geometry.cpp:191,211)
 #pragma unroll
     for (int p = 0; p < RF_PAIRS; p++)
 #pragma unroll
         for (int d = 0; d < 6; d++) X[p][d] *= f2{ sc, sc };
-    if (tid < 21) s_cov[tid] = 0.f;
-    if (tid < 6) s_mean[tid] = ms_mean[tid] * sc;
-    __syncthreads();
-    if (tid < 6) s_cov[(tid * tid + tid) / 2 + tid] = mp.kernel_var * (sc * sc);  // :203-206
-    __syncthreads();
+    float mean[6], cov[21], W[21];
+#pragma unroll
+    for (int d = 0; d < 6; d++) mean[d] = ms_mean[d] * sc;
+#pragma unroll
+    for (int k = 0; k < 21; k++) cov[k] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 6; d++) cov[(d * d + d) / 2 + d] = mp.kernel_var * (sc * sc);  // :203-206
     const bool regularise = mp.rg_covar_reg_lambda > 0.f;
-    if (wv == 0) {  // inverse for iteration 0 (not regularised, fit_robust_gaussian.cu:180)
-        const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, false, s_lu, false);
-        if (lane == 0) s_flag = ok ? 0 : 2;
-    }
-    __syncthreads();
+    bool pd = rg_whiten(cov, false, mp.rg_covar_reg_lambda, W);  // iteration 0 is not regularised (fit_robust_gaussian.cu:180)
+    bool cov_reg = false;  // `cov` is what the last prepare step regularised (the covariance the reference holds when the loop ends)
     const float sig2 = mp.rg_trunc_sigma * mp.rg_trunc_sigma;
-    float weight = 0.f;
+    float weight = 0.f, density = 0.f;
     int iter = 0, parity = 0;
     bool reliable = true;
     PH_MARK(24);
     for (iter = 0; iter < mp.rg_max_iters; iter++) {
-        if (s_flag == 2) { reliable = false; break; }
-        const float prev_density = weight / (float)used;
-        float cs[21], mean[6];
-#pragma unroll
-        for (int d1 = 0; d1 < 6; d1++)
-#pragma unroll
-            for (int d2 = 0; d2 <= d1; d2++) cs[(d1 * d1 + d1) / 2 + d2] = (d1 == d2 ? 1.f : 2.f) * s_cinv[(d1 * d1 + d1) / 2 + d2];
-#pragma unroll
-        for (int d = 0; d < 6; d++) mean[d] = s_mean[d];
+        if (!pd) { reliable = false; break; }
+        const float prev_density = density;
         // e_step (fit_robust_gaussian.cu:56-97): gate, weight, weighted sample and weighted scatter about
         // the CURRENT mean in one pass -> one 28-value all-reduce per iteration
         f2 acc2[28];
@@ -993,17 +1051,18 @@ __device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], i
             f2 diff[6];
 #pragma unroll
             for (int d = 0; d < 6; d++) diff[d] = X[p][d] - f2{ mean[d], mean[d] };
-            // z = d^T C d over the lower triangle (off-diagonal coefficients doubled in cs): 27 multiply-adds, not 42
-            f2 z = { 0.f, 0.f };
+            // z = |y|^2, L y = d by forward substitution (W: strict lower triangle of L, reciprocal diagonal): 21 + 6 multiply-adds
+            f2 z = { 0.f, 0.f }, y[6];
 #pragma unroll
             for (int d1 = 0; d1 < 6; d1++) {
-                f2 tmp = diff[d1] * cs[(d1 * d1 + d1) / 2 + d1];
+                f2 t = diff[d1];
 #pragma unroll
-                for (int d2 = 0; d2 < d1; d2++) tmp += diff[d2] * cs[(d1 * d1 + d1) / 2 + d2];
-                z += tmp * diff[d1];
+                for (int d2 = 0; d2 < d1; d2++) t -= y[d2] * W[(d1 * d1 + d1) / 2 + d2];
+                y[d1] = t * W[(d1 * d1 + d1) / 2 + d1];
+                z += y[d1] * y[d1];
             }
-            // sqrt(z) < sigma (fit_robust_gaussian.cu:80) as 0 <= z < sigma^2: a negative or NaN form stays outside
-            const f2 wgt = { (z.x >= 0.f && z.x < sig2) ? 1.f : 0.f, (z.y >= 0.f && z.y < sig2) ? 1.f : 0.f };
+            // sqrt(z) < sigma (fit_robust_gaussian.cu:80) as z < sigma^2 (z is a sum of squares: >= 0 or NaN, and NaN stays outside)
+            const f2 wgt = { z.x < sig2 ? 1.f : 0.f, z.y < sig2 ? 1.f : 0.f };
             acc2[0] += wgt;
 #pragma unroll
             for (int d = 0; d < 6; d++) acc2[1 + d] += wgt * X[p][d];
@@ -1025,41 +1084,38 @@ __device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], i
         const float tot = allreduce_lanes<28, RF_NW>(acc, rb, parity); parity ^= 1;  // lane k of every wave: total of sum k
         weight = lane_value(tot, 0);
         if (!isfinite(weight)) { reliable = false; break; }
-        if (fabsf(weight / (float)used - prev_density) < mp.rg_epsilon) { reliable = true; break; }
+        density = weight / (float)used;
+        if (fabsf(density - prev_density) < mp.rg_epsilon) { reliable = true; break; }
         PH_MARK(27);
-        if (wv == 0) {
-            // M-step (:234-246): mean and covariance of the gated set (no -1: it is regularised next), one division per lane where
-            // the totals sit, and -- unless this was the last iteration -- the regularised inverse of the next one
-            if (lane >= 1 && lane < 28) {
-                const float q = tot / weight;
-                if (lane < 7) s_mean[lane - 1] = q; else s_cov[lane - 7] = q;  // the other waves read both before the all-reduce barrier
-            }
-            __builtin_amdgcn_wave_barrier();
-            if (iter + 1 < mp.rg_max_iters) {
-                const bool ok = rg_prepare_lds(s_cov, s_cinv, mp.rg_covar_reg_lambda, regularise, s_lu, true);
-                if (lane == 0) s_flag = ok ? 0 : 2;
-            }
-        }
-        __syncthreads();
+        // M-step (:234-246): mean and covariance of the gated set (no -1: it is regularised next), one division per lane where the
+        // totals sit, broadcast; then -- unless this was the last iteration -- the regularised covariance and its whitening factor
+        const float q = tot / weight;
+#pragma unroll
+        for (int d = 0; d < 6; d++) mean[d] = lane_value(q, 1 + d);
+#pragma unroll
+        for (int k = 0; k < 21; k++) cov[k] = lane_value(q, 7 + k);
+        cov_reg = false;
+        if (iter + 1 < mp.rg_max_iters) { pd = rg_whiten(cov, regularise, mp.rg_covar_reg_lambda, W); cov_reg = regularise; }
         PH_MARK(25);
     }
-    __syncthreads();
     PH_MARK(27); PH_ADD(28, iter); PH_ADD(29, 1);
     if (tid == 0) {
         float mean6[6];
-        float density = ms_conf;
+        density = ms_conf;
         int gu_iters = 0;  // fit_robust_gaussian.cu:158-159 resets *used_iters on entry
         if (reliable) {
+            float covr[21];
+            rg_regularised(cov, cov_reg, mp.rg_covar_reg_lambda, covr);
             density = weight / (float)used; gu_iters = iter;
             for (int i1 = 0; i1 < 6; i1++)
                 for (int i2 = 0; i2 < 6; i2++) {
                     const int hi = i1 >= i2 ? i1 : i2, lo = i1 >= i2 ? i2 : i1;
-                    float c = s_cov[(hi * hi + hi) / 2 + lo] / (sc * sc);  // :224-233
+                    float c = covr[(hi * hi + hi) / 2 + lo] / (sc * sc);  // :224-233
                     if (i1 < 3 || i2 < 3) c /= mp.rvec_scale;
                     if (i1 < 3 && i2 < 3) c /= mp.rvec_scale;
                     cam->covar[i1 * 6 + i2] = c;
                 }
-            for (int d = 0; d < 6; d++) mean6[d] = s_mean[d] / sc;
+            for (int d = 0; d < 6; d++) mean6[d] = mean[d] / sc;
         } else {
             for (int k = 0; k < 36; k++) cam->covar[k] = 0.f;
             for (int d = 0; d < 6; d++) mean6[d] = (ms_mean[d] * sc) / sc;  // pose_opm *= sc; /= sc (:210,:238)
