@@ -47,7 +47,7 @@ show("k_solve (wg 0, lane 0)", [("count blk_counts", 8), ("draw", 9), ("load 4 p
 show("k_pose_mode", [("load hypotheses", 16), ("init / trials", 17), ("mean-shift: pass", 32), ("mean-shift: reduce + update", 33), ("finalize_pose", 21), ("decide + tail", 22)], 20)
 print(f"   mean-shift iterations / call {v[19]/max(v[20],1):.2f}")
 show("k_pose_refit", [("stage", 24), ("prepare (inverse)", 25), ("sample pass", 26), ("all-reduce + M-step", 27), ("finalize", 30)], 29)
-print(f"   gate iterations / call {v[28]/max(v[29],1):.2f}")
+print(f"   gate iterations / call {v[28]/max(v[29],1):.2f}; pair-slots passed / iteration {v[34]/max(v[28],1):.2f} of 8")
 
 assert lib.vk_phase_read_depth(bufd, 64, 0) == 0
 v = np.array(list(bufd), dtype=np.float64)

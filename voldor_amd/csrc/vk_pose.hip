@@ -1000,6 +1000,122 @@ __device__ __forceinline__ bool rg_whiten(const float (&cov)[21], bool regularis
     return ok;
 }
 
+// Distance partition of the pool for the refit.  The gate of iteration t keeps the samples with (x - mu)^T C^-1 (x - mu) < sigma^2; all of
+// them lie in the ball |x - m0| < |mu - m0| + sigma sqrt(trace C) around the mean-shift mode m0 (lambda_max <= trace; the shrinkage
+// keeps the trace), and that ball contracts with the gate: ~7000 of 8192 samples at the start, ~3000 when the gate holds ~1300.  A sample
+// outside the ball has weight exactly 0 -- leaving it out changes no sum.  So the pool is re-dealt ONCE, by distance from m0: pair-slot p
+// of every lane (the 1024 samples a pass handles in one iteration of its unrolled loop) receives the samples of distance rank
+// [1024 p, 1024 p + 1024) up to the resolution of the classes below, and a pass stops at the first pair-slot whose lower distance
+// bound r2[p] lies outside the ball (measured on 640x480 pools: 45-50 % of the pair-slots over the ~35 iterations of a refit).
+//   1. histogram of the squared distances over 1024 logarithmic bins (1/16 octave: the top 13 bits of the float), LDS atomics on integers
+//   2. its prefix sum splits the bins into 16 classes of ~512 ranks; class c starts at rank s_cstart[c]
+//   3. rank of a sample inside its class in a FIXED order (lane-interleaved rows, then slot): per-thread class counters (own row of
+//      an LDS table: the returned old value is the rank among the thread's own slots), then a prefix over the threads per class
+//   4. the six coordinates move to position = class start + rank through an LDS staging plane (position q -> lane q % 512, slot q / 512)
+// Every step is order-independent or in a fixed order: the dealt pool, hence every sum of the refit, is the same from run to run.
+// r2[p]: lower edge of the first bin of the class that holds rank 1024 p (every sample at a rank >= 1024 p is at least that far out).
+template <int THREADS>
+__device__ __forceinline__ void refit_partition(f2 (&X)[PM_POOL / THREADS / 2][6], const float (&m0)[6], float (&r2)[PM_POOL / THREADS / 2]) {
+    static_assert(THREADS == 512 && PM_POOL == 8192, "the class / chunk geometry below is written for 512 threads x 16 samples");
+    constexpr int SPT = PM_POOL / THREADS, PAIRS = SPT / 2, NCLS = 16, NBIN = 1024, ROW = NCLS + 1 /* padded: conflict-free across lanes */;
+    constexpr int BIN_BASE = 1648;  // (bits >> 19) of 2^-24: bins span 2^-24 .. 2^40, clamped at both ends
+    __shared__ unsigned s_hist[NBIN];   // counts, then the class of a bin
+    __shared__ unsigned s_cedge[NCLS];  // float bits: lowest bin edge of a class
+    __shared__ int s_bclass[PAIRS], s_wtot[THREADS / 64];
+    __shared__ unsigned s_cstart[NCLS];  // rank at which a class starts = exclusive bin prefix of its first occupied bin
+    __shared__ float4 s_big[PM_POOL];    // 128 KB: first the class counters [THREADS][ROW], then the staging plane(s)
+    unsigned* cnt = reinterpret_cast<unsigned*>(&s_big[0]);
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    s_hist[tid] = 0u; s_hist[tid + THREADS] = 0u;
+    if (tid < NCLS) { s_cedge[tid] = 0x7f800000u; s_cstart[tid] = 0x7fffffffu; }
+#pragma unroll
+    for (int c = 0; c < NCLS; c++) cnt[tid * ROW + c] = 0u;
+    __syncthreads();
+    int bin[SPT];
+#pragma unroll
+    for (int p = 0; p < PAIRS; p++) {
+        f2 d2 = { 0.f, 0.f };
+#pragma unroll
+        for (int d = 0; d < 6; d++) { const f2 df = X[p][d] - f2{ m0[d], m0[d] }; d2 += df * df; }
+        bin[2 * p] = min(max((int)(__float_as_uint(d2.x) >> 19) - BIN_BASE, 0), NBIN - 1);  // d2 >= 0 or +inf (a dropped hypothesis): no sign, no NaN
+        bin[2 * p + 1] = min(max((int)(__float_as_uint(d2.y) >> 19) - BIN_BASE, 0), NBIN - 1);
+    }
+#pragma unroll
+    for (int k = 0; k < SPT; k++) atomicAdd(&s_hist[bin[k]], 1u);
+    __syncthreads();
+    {   // exclusive prefix over the bins (two per thread) -> classes, class edges, the class that holds rank 1024 p
+        const int v0 = (int)s_hist[2 * tid], v1 = (int)s_hist[2 * tid + 1], sum = v0 + v1;
+        int incl = sum;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) s_wtot[wv] = incl;
+        __syncthreads();
+        int woff = 0;
+#pragma unroll
+        for (int j = 0; j < THREADS / 64; j++) woff += j < wv ? s_wtot[j] : 0;
+        const int e0 = woff + incl - sum, e1 = e0 + v0;
+        const int c0 = min(e0 >> 9, NCLS - 1), c1 = min(e1 >> 9, NCLS - 1);
+        s_hist[2 * tid] = (unsigned)c0; s_hist[2 * tid + 1] = (unsigned)c1;  // own entries: nobody else has read or will read the counts
+        if (v0) { atomicMin(&s_cedge[c0], tid == 0 ? 0u : (unsigned)(2 * tid + BIN_BASE) << 19); atomicMin(&s_cstart[c0], (unsigned)e0); }  // bin 0 also holds everything below its edge
+        if (v1) { atomicMin(&s_cedge[c1], (unsigned)(2 * tid + 1 + BIN_BASE) << 19); atomicMin(&s_cstart[c1], (unsigned)e1); }
+#pragma unroll
+        for (int p = 1; p < PAIRS; p++) {
+            const int pos = p * 2 * THREADS;
+            if (v0 && e0 <= pos && pos < e0 + v0) s_bclass[p] = c0;
+            if (v1 && e1 <= pos && pos < e1 + v1) s_bclass[p] = c1;
+        }
+    }
+    __syncthreads();
+    int cls[SPT], myrank[SPT];
+#pragma unroll
+    for (int k = 0; k < SPT; k++) cls[k] = (int)s_hist[bin[k]];
+#pragma unroll
+    for (int k = 0; k < SPT; k++) myrank[k] = (int)atomicAdd(&cnt[tid * ROW + cls[k]], 1u);  // own row: rank among my earlier slots of that class
+    __syncthreads();
+    {   // per class: prefix of the counters over the threads, on top of the class start.  Thread (c, j) owns rows j, j + 32, .. (lanes one padded row apart)
+        const int c = tid >> 5, j = tid & 31;
+        int a[THREADS / 32], run = 0;
+#pragma unroll
+        for (int i = 0; i < THREADS / 32; i++) { a[i] = (int)cnt[(i * 32 + j) * ROW + c]; run += a[i]; }
+        int incl = run;
+#pragma unroll
+        for (int o = 1; o < 32; o <<= 1) { const int t = __shfl_up(incl, o, 32); if (j >= o) incl += t; }
+        int base = (int)s_cstart[c] + incl - run;  // (an empty class: every a[i] is 0 and nobody reads the row entries)
+#pragma unroll
+        for (int i = 0; i < THREADS / 32; i++) { cnt[(i * 32 + j) * ROW + c] = (unsigned)base; base += a[i]; }
+    }
+    __syncthreads();
+    int q[SPT];
+#pragma unroll
+    for (int k = 0; k < SPT; k++) q[k] = (int)cnt[tid * ROW + cls[k]] + myrank[k];
+    __syncthreads();  // the counters are dead: their memory becomes the staging planes
+    // coordinates 0..3 as one 16-byte plane, then 4..5 as an 8-byte plane: 32 scattered writes per thread instead of 96
+#pragma unroll
+    for (int k = 0; k < SPT; k++)
+        s_big[q[k]] = (k & 1) ? float4{ X[k >> 1][0].y, X[k >> 1][1].y, X[k >> 1][2].y, X[k >> 1][3].y } : float4{ X[k >> 1][0].x, X[k >> 1][1].x, X[k >> 1][2].x, X[k >> 1][3].x };
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        const float4 v = s_big[k * THREADS + tid];
+        if (k & 1) { X[k >> 1][0].y = v.x; X[k >> 1][1].y = v.y; X[k >> 1][2].y = v.z; X[k >> 1][3].y = v.w; }
+        else { X[k >> 1][0].x = v.x; X[k >> 1][1].x = v.y; X[k >> 1][2].x = v.z; X[k >> 1][3].x = v.w; }
+    }
+    __syncthreads();
+    float2* s_two = reinterpret_cast<float2*>(&s_big[0]);
+#pragma unroll
+    for (int k = 0; k < SPT; k++) s_two[q[k]] = (k & 1) ? float2{ X[k >> 1][4].y, X[k >> 1][5].y } : float2{ X[k >> 1][4].x, X[k >> 1][5].x };
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SPT; k++) {
+        const float2 v = s_two[k * THREADS + tid];
+        if (k & 1) { X[k >> 1][4].y = v.x; X[k >> 1][5].y = v.y; } else { X[k >> 1][4].x = v.x; X[k >> 1][5].x = v.y; }
+    }
+    __syncthreads();
+    r2[0] = 0.f;
+#pragma unroll
+    for (int p = 1; p < PAIRS; p++) r2[p] = __uint_as_float(s_cedge[s_bclass[p]]);
+}
+
 // robust-Gaussian refit + finalisation (geometry.cpp:201-263, fit_robust_gaussian.cu:131-263); runs
 // on the last EM iteration only, ~30-50 gate/refit iterations per camera, each of them dependent phases on ONE compute unit: the gate +
 // moment pass over the pool (VALU-issue bound), a 28-value all-reduce, the next gate's coefficients.  The 8192 scaled hypotheses stay
@@ -1031,6 +1147,17 @@ __device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], i
 #pragma unroll
     for (int d = 0; d < 6; d++) cov[(d * d + d) / 2 + d] = mp.kernel_var * (sc * sc);  // :203-206
     const bool regularise = mp.rg_covar_reg_lambda > 0.f;
+    // uniform values the whole loop needs go through v_readfirstlane: scalar registers, not 14 of the 256 vector registers
+    unsigned r2b[RF_PAIRS];  // bounds as float bits (non-negative floats order like their bits: a scalar compare decides a pair-slot)
+    float m0[6];
+    {
+        float r2[RF_PAIRS];
+        refit_partition<THREADS>(X, mean, r2);  // `mean` still is the mean-shift mode here
+#pragma unroll
+        for (int p = 0; p < RF_PAIRS; p++) r2b[p] = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(r2[p]));
+#pragma unroll
+        for (int d = 0; d < 6; d++) m0[d] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, mean[d])));
+    }
     bool pd = rg_whiten(cov, false, mp.rg_covar_reg_lambda, W);  // iteration 0 is not regularised (fit_robust_gaussian.cu:180)
     bool cov_reg = false;  // `cov` is what the last prepare step regularised (the covariance the reference holds when the loop ends)
     const float sig2 = mp.rg_trunc_sigma * mp.rg_trunc_sigma;
@@ -1046,8 +1173,17 @@ __device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], i
         f2 acc2[28];
 #pragma unroll
         for (int k = 0; k < 28; k++) acc2[k] = f2{ 0.f, 0.f };
+        // the ball that holds every sample of this gate (refit_partition), 0.1 % wider than the bound: float rounding of the distances and
+        // of z stays far inside that margin.  (The shrinkage keeps the trace.)
+        float dm2 = 0.f, tr = 0.f;
+#pragma unroll
+        for (int d = 0; d < 6; d++) { dm2 = fmaf(mean[d] - m0[d], mean[d] - m0[d], dm2); tr += cov[(d * d + d) / 2 + d]; }
+        const float ball = (sqrtf(dm2) + mp.rg_trunc_sigma * sqrtf(tr)) * 1.001f;
+        const unsigned ballb = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(ball * ball));  // a NaN (degenerate covariance) is above every bound: skips nothing
 #pragma unroll
         for (int p = 0; p < RF_PAIRS; p++) {
+            if (r2b[p] > ballb) continue;  // scalar compare and branch
+            PH_ADD(34, 1);
             f2 diff[6];
 #pragma unroll
             for (int d = 0; d < 6; d++) diff[d] = X[p][d] - f2{ mean[d], mean[d] };
