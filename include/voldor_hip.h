@@ -133,6 +133,10 @@ int vk_get_reference_svd(void);
  * optimize_depth.cu:320-396 order) instead of the table + speculative-run kernel; both must give identical maps
  * (tests/test_gpu_kernels.py::test_local_runs_equal_the_step_by_step_chain). */
 int vk_set_local_serial(int on);
+/* Tuning / verification aid: steps per lane of the segmented fb_smooth of the fast mode: 0 = chosen by size (default), 20 or 40 = forced
+ * where the line fits (a line longer than 256 row / 64 column segments of 20 steps takes 40 regardless).  The two agree to rounding
+ * (tests/test_gpu_kernels.py::test_fb_smooth_segment_lengths_agree).  Returns nonzero for any other value. */
+int vk_set_fb_segment(int steps);
 /* Verification aid: 0 = the global-propagation passes of the fast mode evaluate a site with one lane (k_global_prop_sites_lean) instead of
  * a group of lanes (k_global_prop_split_lean); identical maps (tests/test_gpu_kernels.py::test_global_split_equals_one_lane_per_site).  Default 1. */
 int vk_set_global_split(int on);

@@ -458,6 +458,30 @@ def test_fb_smooth_alone_matches_oracle(orc, w, h):
     assert np.abs(o - g).max() < 2e-5
 
 
+@pytest.mark.parametrize("w,h", [(640, 480), (1241, 376), (333, 777)])
+def test_fb_smooth_segment_lengths_agree(orc, w, h):
+    """vk_set_fb_segment: the 20- and 40-step segmentations of the fast fb_smooth (chosen by image size, fb_smooth_device) are the same
+    recurrence cut differently; each stays within the stage tolerance of the oracle and they agree with each other to rounding."""
+    from voldor_amd import kernels
+    rng = np.random.default_rng(w + 7 * h)
+    maps = rng.uniform(0.02, 0.98, (2, h, w)).astype(np.float32)
+    maps[1, :, w // 3:] = 0.9999
+    o = orc.fb_smooth(maps, 0.5, 0.9)
+    out = {}
+    try:
+        for seg in (20, 40):
+            kernels.set_fb_segment(seg)
+            rc, out[seg] = kernels.fb_smooth_gpu(maps, 0.5, 0.9)
+            assert rc == 0 and np.isfinite(out[seg]).all()
+            assert np.abs(o - out[seg]).max() < 2e-5, seg
+    finally:
+        kernels.set_fb_segment(0)
+    assert np.abs(out[20] - out[40]).max() < 1e-5
+    assert not np.array_equal(out[20], out[40]) or w * h < 1000  # the switch really changes the launch
+    with pytest.raises(Exception):
+        kernels.set_fb_segment(30)
+
+
 @pytest.mark.parametrize("with_priors,n_rand", [(False, 10), (True, 10), (False, 23), (False, 3), (False, 0)])
 def test_sample_pass_with_survivor_queue_matches_strict(small_scene, with_priors, n_rand):
     """The fast cost-map + random-sample pass (k_cost_rand_q: exact early rejection after frame 0 / the priors, survivors compacted

@@ -160,6 +160,7 @@ struct Context {
     DevBuf pts2, pts3;            // compacted correspondences (geometry.cpp:68-80)
     DevBuf n_points;              // int
     int n_map_blocks = 0;         // workgroups of the last k_collect launch (length of blk_counts)
+    bool maps_block_compact = false;  // layout p2_map / p3_map were last written in: valid entries at the head of each block's segment (k_collect<true>) or NaN-marked per pixel
     DevBuf rvecs, tvecs;          // [n_poses][3]
     DevBuf pool;                  // [n_poses][dims]
     DevBuf ms_io;                 // small float/int scratch for B-inner meanshift / robust fit

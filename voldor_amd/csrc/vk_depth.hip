@@ -24,6 +24,7 @@ namespace vk {
 
 static std::atomic<int> g_local_serial{0};  // vk_set_local_serial (verification aid)
 static std::atomic<int> g_cost_rand_plain{0};  // vk_set_cost_rand_plain (verification aid): 1 = every random sample evaluated in full, one after the other
+static std::atomic<int> g_fb_segment{0};   // vk_set_fb_segment: 0 = by size (fb_smooth_device), 20 / 40 = that many steps per lane where the line fits
 static std::atomic<int> g_global_split{1};  // vk_set_global_split (verification aid): 0 = one lane per site (k_global_prop_sites_lean)
 
 // phase clocks (profiling builds only, scripts/phase_clocks.sh): thread 0 of the middle workgroup of a launch
@@ -1222,9 +1223,18 @@ int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0
         if (cumP) hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, cumP, cumN, cumNdp, world_scale);
         return fb_smooth_strict_device(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
     }
-    if (w <= 20 * FB_MAX_ROW_SEGS) fb_rows_launch<20>(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
+    // Steps per lane.  A lane also chains the S - 1 segment matrices of its line up to its own segment (fb_incoming): S - 1 Moebius steps
+    // next to the 2 x FB_SEG of its segment.  In the latency regime (one or two waves per SIMD: 640x480, 1241x376) short segments
+    // win -- the dependent chain is what takes the time.  Where the pass fills the chip many times over it is bound by VALU issue (0.91
+    // at 1080p) and the chaining is half of all instructions with 20-step segments (1920 wide: 95 + 40 steps per lane): 40-step
+    // segments then do the same work in 37 % fewer instructions.
+    const int forced = g_fb_segment.load(std::memory_order_relaxed);
+    const bool many_waves = (size_t)w * h * n_maps >= ((size_t)8 << 20);  // >= 8 waves per SIMD at 20 steps per lane
+    const bool rows40 = w > 20 * FB_MAX_ROW_SEGS || (forced ? forced == 40 : many_waves);
+    const bool cols40 = h > 20 * FB_MAX_COL_SEGS || (forced ? forced == 40 : many_waves);
+    if (!rows40) fb_rows_launch<20>(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
     else fb_rows_launch<40>(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
-    if (h <= 20 * FB_MAX_COL_SEGS) fb_cols_launch<20>(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
+    if (!cols40) fb_cols_launch<20>(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
     else fb_cols_launch<40>(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
     VK_CHECK_LAST();
     return 0;
@@ -1456,6 +1466,11 @@ int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk
 }  // namespace vk
 
 extern "C" __attribute__((visibility("default"))) int vk_set_local_serial(int on) { vk::g_local_serial.store(on ? 1 : 0); return 0; }
+extern "C" __attribute__((visibility("default"))) int vk_set_fb_segment(int steps) {
+    if (steps != 0 && steps != 20 && steps != 40) return (int)hipErrorInvalidValue;
+    vk::g_fb_segment.store(steps);
+    return 0;
+}
 extern "C" __attribute__((visibility("default"))) int vk_set_global_split(int on) { vk::g_global_split.store(on ? 1 : 0); return 0; }
 extern "C" __attribute__((visibility("default"))) int vk_set_cost_rand_plain(int on) { vk::g_cost_rand_plain.store(on ? 1 : 0); return 0; }
 

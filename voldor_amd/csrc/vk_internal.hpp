@@ -62,7 +62,7 @@ int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk
 
 // vk_pose.hip
 int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
-                   float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact);
+                   float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact, bool block_compact = false);
 int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, float fx, float fy, float cx, float cy,
                  int n_poses, int solver, bool strict = false, CamState* cam_dev = nullptr, bool ref_svd = false);
 // draw = 0: rejection over the map (D3b), falling back to the compacted list below DRAW_LIST_DENSITY; 1: always the reference's

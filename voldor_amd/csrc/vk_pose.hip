@@ -35,6 +35,11 @@ __device__ unsigned long long g_phase[64];
 #endif
 
 // ---- collect_p3p_instances.cu:70-145, 1-D pixel indexing so that block order == row-major order
+// BLOCK_COMPACT (the window pipeline with the reference's index draw): instead of NaN-marked maps the workgroup writes its VALID
+// correspondences only, in pixel order, to the head of its own 256-entry segment of the same buffers -- entry r of block b sits at
+// b * 256 + r.  The rank-select draw of k_solve then reads the point it bisected for directly (block, rank in block): no validity
+// words, no select inside a word, one dependent memory round trip less per hypothesis, and the collect writes valid entries only.
+template <bool BLOCK_COMPACT>
 __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict__ flows, const float* __restrict__ rig,
                                                          const float* __restrict__ depth, const PoseBlock* __restrict__ P,
                                                          float* __restrict__ p2_map, float* __restrict__ p3_map,
@@ -87,18 +92,27 @@ __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict
             // geometry.cpp:73 keeps only entries whose sum is finite
             valid = valid && isfinite(px + py + o.x + o.y + o.z);
         }
-        p2_map[(size_t)pi * 2] = valid ? px : qnan; p2_map[(size_t)pi * 2 + 1] = valid ? py : qnan;
-        p3_map[(size_t)pi * 3] = valid ? o.x : qnan; p3_map[(size_t)pi * 3 + 1] = valid ? o.y : qnan;
-        p3_map[(size_t)pi * 3 + 2] = valid ? o.z : qnan;
+        if (!BLOCK_COMPACT) {
+            p2_map[(size_t)pi * 2] = valid ? px : qnan; p2_map[(size_t)pi * 2 + 1] = valid ? py : qnan;
+            p3_map[(size_t)pi * 3] = valid ? o.x : qnan; p3_map[(size_t)pi * 3 + 1] = valid ? o.y : qnan;
+            p3_map[(size_t)pi * 3 + 2] = valid ? o.z : qnan;
+        }
     }
     __shared__ int s_cnt[4];
     unsigned long long m = __ballot(valid);
     if ((threadIdx.x & 63) == 0) {
         s_cnt[threadIdx.x >> 6] = __popcll(m);
-        valid_mask[(size_t)tile * 4 + (threadIdx.x >> 6)] = m;  // one bit per pixel, row-major: what the rank-select draw of k_solve scans
+        if (!BLOCK_COMPACT) valid_mask[(size_t)tile * 4 + (threadIdx.x >> 6)] = m;  // one bit per pixel, row-major: what the rank-select draw of k_solve scans over NaN-marked maps
     }
     __syncthreads();
     if (threadIdx.x == 0) blk_counts[tile] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+    if (BLOCK_COMPACT && valid) {
+        int r = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1ull));
+        for (int k = 0; k < (int)(threadIdx.x >> 6); k++) r += s_cnt[k];
+        const size_t slot = (size_t)tile * 256 + r;
+        p2_map[slot * 2] = px; p2_map[slot * 2 + 1] = py;
+        p3_map[slot * 3] = o.x; p3_map[slot * 3 + 1] = o.y; p3_map[slot * 3 + 2] = o.z;
+    }
     PH_MARK(0); PH_ADD(1, 1);
 }
 
@@ -178,7 +192,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                                                       float* __restrict__ rvecs, float* __restrict__ tvecs,
                                                       int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk,
                                                       CamState* cam, int npx, float fx, float fy, float cx, float cy, int n_poses,
-                                                      int draw /* 0 auto, 1 rank select (reference draw), -1 rejection only */, int strict /* bit 0: strict math, bit 1: reference SVD */,
+                                                      int draw /* 0 auto, 1 rank select (reference draw), -1 rejection only */, int strict /* bit 0: strict math, bit 1: reference SVD, bit 2: block-compacted correspondences (with draw 1) */,
                                                       const int* __restrict__ blk_offsets /* exclusive prefix of blk_counts in global memory when it does not fit the LDS, else null */,
                                                       const unsigned long long* __restrict__ valid_mask /* k_collect's bit per pixel (FROM_MAP) */) {
     // LambdaTwist: four lanes per hypothesis, one candidate root each (the candidates are independent once the
@@ -300,6 +314,10 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
 #pragma unroll
                 for (int k = 0; k < NS; k++) want[k] = rk[k] - (lo[k] > 0 ? s_pref[pref_at(lo[k] - 1)] : 0);
             }
+            if (strict & 4) {  // block-compacted correspondences (k_collect<true>): entry `want` of block lo is the point itself
+#pragma unroll
+                for (int k = 0; k < NS; k++) found[k] = lo[k] * 256 + want[k];
+            } else {
             // the want-th valid pixel of block lo: its four 64-bit validity words, popcounts, then a 6-step select inside the word
             unsigned long long wds[NS][4];
 #pragma unroll
@@ -324,6 +342,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                     }
                     found[k] = lo[k] * 256 + q * 64 + pos;
                 }
+            }
             }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -1616,7 +1635,7 @@ __global__ __launch_bounds__(MS_THREADS) static void k_robust_gaussian_only(cons
 
 // ---- host launchers ------------------------------------------------------------------------------
 int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
-                   float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact) {
+                   float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact, bool block_compact) {
     const int npx = w * h, nblk = (npx + 255) / 256;
     if (int e = c->p2_map.reserve(sizeof(float) * 2 * (size_t)npx)) return e;
     if (int e = c->p3_map.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
@@ -1624,10 +1643,17 @@ int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int activ
     if (int e = c->blk_offsets.reserve(sizeof(int) * (size_t)nblk)) return e;
     if (int e = c->valid_mask.reserve(sizeof(unsigned long long) * 4 * (size_t)nblk)) return e;
     if (int e = c->ensure_n_points()) return e;
-    hipLaunchKernelGGL(k_collect, dim3(nblk), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
-                       S.pb(), c->p2_map.as<float>(), c->p3_map.as<float>(), c->blk_counts.as<int>(), c->valid_mask.as<unsigned long long>(), N, w, h, active_idx,
-                       rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace);
+    if (block_compact && compact) return (int)hipErrorInvalidValue;  // the ordered list of the host-pointer API is built from the NaN-marked maps
+    if (block_compact)
+        hipLaunchKernelGGL(k_collect<true>, dim3(nblk), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
+                           S.pb(), c->p2_map.as<float>(), c->p3_map.as<float>(), c->blk_counts.as<int>(), c->valid_mask.as<unsigned long long>(), N, w, h, active_idx,
+                           rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace);
+    else
+        hipLaunchKernelGGL(k_collect<false>, dim3(nblk), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
+                           S.pb(), c->p2_map.as<float>(), c->p3_map.as<float>(), c->blk_counts.as<int>(), c->valid_mask.as<unsigned long long>(), N, w, h, active_idx,
+                           rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace);
     c->n_map_blocks = nblk;
+    c->maps_block_compact = block_compact;
     if (compact) {  // the host-pointer API hands the compacted list to its caller (geometry.cpp:68-80)
         hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, c->stream, c->blk_counts.as<int>(), c->blk_offsets.as<int>(), nblk,
                            c->n_points.as<int>(), cam_dev);
@@ -1660,7 +1686,11 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
         offs = c->blk_offsets.as<int>();
         lds = 0;
     }
-    const int st = (strict ? 1 : 0) | (ref_svd ? 2 : 0);
+    if (FROM_MAP && c->maps_block_compact && draw <= 0) {
+        fprintf(stderr, "voldor_hip: block-compacted correspondences can only be drawn by rank (draw = 1)\n");
+        return (int)hipErrorInvalidValue;
+    }
+    const int st = (strict ? 1 : 0) | (ref_svd ? 2 : 0) | ((FROM_MAP && c->maps_block_compact) ? 4 : 0);
     const unsigned long long* vm = FROM_MAP ? c->valid_mask.as<unsigned long long>() : nullptr;
     if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm);
     else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm);

@@ -198,7 +198,8 @@ struct Voldor {
         ImageSet& S = c->od;
         if (c->prof) prof_begin(c);
         if (int e = collect_device(c, S, n_flows, w, h, i, cfg.rigidness_threshold, cfg.rigidness_sum_threshold,
-                                   cfg.pose_sample_min_depth, cfg.pose_sample_max_depth, cfg.max_trace_on_flow, dcams() + i, false))
+                                   cfg.pose_sample_min_depth, cfg.pose_sample_max_depth, cfg.max_trace_on_flow, dcams() + i, false,
+                                   /*block_compact=*/cfg.reference_draw != 0))  // the index draw reads (block, rank in block) directly
             return e;
         // cpu_p3p=1 selects the reference's CPU instantiation lambdatwist_p4p<double,...> (geometry.cpp:112)
         const int solver = cfg.lambdatwist ? (cfg.cpu_p3p ? 2 : 0) : 1;

@@ -220,6 +220,11 @@ def set_local_serial(on: bool):
     capi.check(capi.lib().vk_set_local_serial(int(on)), "vk_set_local_serial")
 
 
+def set_fb_segment(steps: int):
+    """Tuning / verification aid (include/voldor_hip.h: vk_set_fb_segment): 0 = by size, 20 / 40 = steps per lane of the segmented fb_smooth."""
+    capi.check(capi.lib().vk_set_fb_segment(int(steps)), "vk_set_fb_segment")
+
+
 def set_global_split(on: bool):
     """Verification aid (include/voldor_hip.h: vk_set_global_split): lanes-per-site evaluation of the global propagation (default) or one lane per site."""
     capi.check(capi.lib().vk_set_global_split(int(on)), "vk_set_global_split")
