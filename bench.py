@@ -238,7 +238,7 @@ def main():
         sqc = {}
         src = {}
         def pmc_file(kind):  # the latest committed PMC pass of this workload (collected separately: rocprofv3 cannot time and count in one run)
-            for tag in ("r03c", "r03b", "r03a", "r02j", "r02h", "r02c"):
+            for tag in ("r03d", "r03c", "r03b", "r03a", "r02j", "r02h", "r02c"):
                 f = os.path.join(ROOT, "profiles", f"{tag}_pmc_{kind}_{args.workload}.json")
                 if os.path.exists(f):
                     return f
