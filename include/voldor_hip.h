@@ -133,6 +133,20 @@ int vk_get_reference_svd(void);
  * optimize_depth.cu:320-396 order) instead of the table + speculative-run kernel; both must give identical maps
  * (tests/test_gpu_kernels.py::test_local_runs_equal_the_step_by_step_chain). */
 int vk_set_local_serial(int on);
+/* Verification entry: the mode kernel of the window pipeline (k_pose_mode: packed-pair mean shift; with do_rg the robust-Gaussian refit on
+ * the same registers -- geometry.cpp:156-263, meanshift.cu:34-150, fit_robust_gaussian.cu:131-263) on a caller-supplied pool of pose
+ * hypotheses, so that the kernels of the timed path can be held against the oracle stage by stage
+ * (tests/test_gpu_kernels.py::test_pipeline_mode_kernel_matches_oracle).  h_rvecs / h_tvecs: [n_poses][3], n_poses <= 8192, a non-finite
+ * hypothesis is dropped; io_pose6: rvec and t of the starting pose in (used when use_external_init_mean), the estimate out;
+ * o_covar36: the camera record's covariance (zeros unless the refit ran and was reliable).  Returns nonzero on a device error. */
+int vk_pose_mode_pool(const float* h_rvecs, const float* h_tvecs, int n_poses, int use_external_init_mean, float* io_pose6,
+                      float kernel_var, float rvec_scale, float ms_epsilon, int ms_max_iters, int ms_max_init_trials, float ms_good_init_confidence,
+                      int do_rg, float rg_trunc_sigma, float rg_covar_reg_lambda, float rg_epsilon, int rg_max_iters, float rg_pose_scaling,
+                      float* o_covar36, float* o_density, int* o_sample_count, int* o_ms_iters, int* o_gu_iters, int* o_success);
+/* Verification aid: 0 = every gate pass of the refit walks the whole pool in its arrival order instead of the pool re-dealt by distance
+ * from the mean-shift mode and a pass that stops outside the ball holding the gate.  The same sums up to the order of their terms
+ * (tests/test_gpu_kernels.py::test_refit_partition_changes_no_sum).  Default 1. */
+int vk_set_refit_partition(int on);
 /* Tuning / verification aid: steps per lane of the segmented fb_smooth of the fast mode: 0 = chosen by size (default), 20 or 40 = forced
  * where the line fits (a line longer than 256 row / 64 column segments of 20 steps takes 40 regardless).  The two agree to rounding
  * (tests/test_gpu_kernels.py::test_fb_smooth_segment_lengths_agree).  Returns nonzero for any other value. */

@@ -393,6 +393,73 @@ def test_meanshift_and_robust_gaussian(orc, small_scene):
     assert np.abs(ocov - gcov).max() < 2e-2 * np.abs(ocov).max()
 
 
+def _pose_pool(orc, scene, active, n=8192):
+    pts2, pts3, K = _corr(orc, scene, active)
+    rv, tv = orc.solve_batch_p3p(pts3, pts2, K, n)
+    return rv, tv
+
+
+@pytest.mark.parametrize("active,n", [(1, 8192), (0, 8192), (2, 3000)])
+def test_pipeline_mode_kernel_matches_oracle(orc, small_scene, active, n):
+    """vk_pose_mode_pool: the mode kernel of the WINDOW PIPELINE (k_mode_trials + k_pose_mode<REFIT,512>: packed pairs in registers,
+    Cholesky-whitened gate, pool re-dealt by distance) against the oracle's meanshift + fit_robust_gaussian glued as
+    geometry.cpp:156-263 does -- the stage test of the kernels the timed path runs (the host-pointer meanshift_gpu /
+    fit_robust_gaussian are other kernels).  Tolerances as for those: the hard 3-sigma gate makes the refit sensitive to last bits."""
+    from voldor_amd import kernels
+    rv, tv = _pose_pool(orc, small_scene, active, n)
+    rs, var, sc = 25.0, 0.2, 100.0
+    fin = np.isfinite(rv.sum(1) + tv.sum(1))
+    assert fin.sum() > 0.5 * n
+    pool = np.concatenate([rv[fin] * rs, tv[fin]], 1).astype(np.float32)
+    init = np.zeros(6, np.float32)
+    for ext in (True, False):
+        om, oc, oi = orc.meanshift(pool, var, init, ext)
+        g = kernels.pose_mode_pool(rv, tv, init, use_external_init_mean=ext, refit=False, kernel_var=var, rvec_scale=rs)
+        assert g["success"] == 1 and g["sample_count"] == fin.sum()
+        gm = np.concatenate([g["pose6"][:3] * rs, g["pose6"][3:]])
+        assert np.abs(om - gm).max() < 2e-4, (ext, om, gm)
+        assert abs(oc - g["density"]) < 1e-4 * max(1, oc) and abs(oi - g["ms_iters"]) <= 2
+        assert not g["covar"].any()
+    cov0 = (np.eye(6) * var * sc * sc).astype(np.float32)
+    orc_rc, omean, ocov, odens, oit = orc.fit_robust_gaussian(pool * sc, om * sc, cov0)
+    g = kernels.pose_mode_pool(rv, tv, init, use_external_init_mean=False, refit=True, kernel_var=var, rvec_scale=rs, rg_pose_scaling=sc)
+    assert orc_rc == 0 and g["success"] == 1
+    gmean = np.concatenate([g["pose6"][:3] * rs, g["pose6"][3:]]) * sc
+    unit = np.array([rs] * 3 + [1.0] * 3)
+    gcov = g["covar"] * sc * sc * unit[:, None] * unit[None, :]  # geometry.cpp:224-233 undone
+    assert abs(odens - g["density"]) < 2e-3
+    assert np.abs(omean - gmean).max() < 5e-2  # pose x100 units
+    assert np.abs(ocov - gcov).max() < 2e-2 * np.abs(ocov).max()
+    assert abs(oit - g["gu_iters"]) <= 3, (oit, g["gu_iters"])
+
+
+@pytest.mark.parametrize("active,n", [(1, 8192), (2, 8192), (0, 5000)])
+def test_refit_partition_changes_no_sum(orc, small_scene, active, n):
+    """vk_set_refit_partition: with the pool re-dealt by distance a gate pass leaves out samples whose weight is exactly 0, so every sum has
+    the same terms in another order.  Both forms must therefore agree to the rounding of a 28-value float reduction over <= 8192 terms
+    (the gate is hard: a sample within that rounding of the 3-sigma surface may fall on the other side, which moves the fit by one
+    sample in a few thousand)."""
+    from voldor_amd import kernels
+    rv, tv = _pose_pool(orc, small_scene, active, n)
+    init = np.zeros(6, np.float32)
+    out = {}
+    try:
+        for part in (1, 0):
+            kernels.set_refit_partition(bool(part))
+            out[part] = kernels.pose_mode_pool(rv, tv, init, use_external_init_mean=False, refit=True, kernel_var=0.2, rvec_scale=25.0)
+            again = kernels.pose_mode_pool(rv, tv, init, use_external_init_mean=False, refit=True, kernel_var=0.2, rvec_scale=25.0)
+            for k in ("pose6", "covar"):
+                np.testing.assert_array_equal(out[part][k], again[k])  # either form is the same from run to run
+    finally:
+        kernels.set_refit_partition(True)
+    a, b = out[1], out[0]
+    assert a["success"] == b["success"] == 1 and a["sample_count"] == b["sample_count"] and a["ms_iters"] == b["ms_iters"]
+    # measured on these pools: pose 1.5e-8, covariance 3e-7 relative, the same iteration count and density
+    assert np.abs(a["pose6"] - b["pose6"]).max() < 1e-6
+    assert np.abs(a["covar"] - b["covar"]).max() < 2e-5 * np.abs(b["covar"]).max()
+    assert abs(a["density"] - b["density"]) < 1e-5 and abs(a["gu_iters"] - b["gu_iters"]) <= 1
+
+
 def test_robust_gaussian_rejects_degenerate(orc):
     from voldor_amd import kernels
     rng = np.random.default_rng(10)

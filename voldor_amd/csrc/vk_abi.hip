@@ -317,6 +317,54 @@ int meanshift_gpu(float* h_space, float kernel_var, float* h_io_mean, float* h_o
     return 0;
 }
 
+// Verification entry (include/voldor_hip.h): the mode kernel of the WINDOW PIPELINE -- k_pose_mode<REFIT,512>, the packed-pair mean shift
+// and, with do_rg, the whitened / distance-partitioned refit on the same registers -- run on a caller-supplied pool of hypotheses, so
+// that the kernels the timed path uses can be held against the oracle stage by stage (the host-pointer meanshift_gpu /
+// fit_robust_gaussian above are different, generic-dimension kernels).  h_rvecs / h_tvecs: [n_poses][3] (non-finite = dropped, as
+// k_solve marks them); io_pose6: rvec, t of the starting pose in, result out.  Returns nonzero on a launch error; *o_success is the
+// camera record's success flag.
+extern "C" __attribute__((visibility("default"))) int vk_pose_mode_pool(const float* h_rvecs, const float* h_tvecs, int n_poses, int use_external_init_mean,
+        float* io_pose6, float kernel_var, float rvec_scale, float ms_epsilon, int ms_max_iters, int ms_max_init_trials, float ms_good_init_confidence,
+        int do_rg, float rg_trunc_sigma, float rg_covar_reg_lambda, float rg_epsilon, int rg_max_iters, float rg_pose_scaling,
+        float* o_covar36, float* o_density, int* o_sample_count, int* o_ms_iters, int* o_gu_iters, int* o_success) {
+    using namespace vk;
+    Context* c = default_context();
+    if (!c) return (int)hipErrorNoDevice;
+    if (n_poses <= 0 || !h_rvecs || !h_tvecs || !io_pose6) return (int)hipErrorInvalidValue;
+    if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
+    if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
+    if (int e = c->cams.reserve(sizeof(CamState) * MAX_FRAMES)) return e;
+    if (int e = c->ensure_n_points()) return e;
+    if (int e = c->od.ensure_pose()) return e;
+    std::vector<float> planes((size_t)6 * n_poses);  // coordinate planes [3][n_poses], the layout k_solve writes for the mode kernels
+    for (int i = 0; i < n_poses; i++)
+        for (int d = 0; d < 3; d++) { planes[(size_t)d * n_poses + i] = h_rvecs[(size_t)i * 3 + d]; planes[(size_t)(3 + d) * n_poses + i] = h_tvecs[(size_t)i * 3 + d]; }
+    CamState cam{};
+    for (int d = 0; d < 3; d++) { cam.rvec[d] = io_pose6[d]; cam.t[d] = io_pose6[3 + d]; }
+    const int enough = 4;
+    VK_CHECK(hipMemcpyAsync(c->rvecs.p, planes.data(), sizeof(float) * 3 * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipMemcpyAsync(c->tvecs.p, planes.data() + (size_t)3 * n_poses, sizeof(float) * 3 * (size_t)n_poses, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipMemcpyAsync(c->cams.p, &cam, sizeof cam, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipMemcpyAsync(c->n_points.p, &enough, sizeof enough, hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    ModeParams mp{};
+    mp.dims = 6; mp.kernel_var = kernel_var; mp.ms_epsilon = ms_epsilon; mp.ms_max_iters = ms_max_iters; mp.ms_max_init_trials = ms_max_init_trials;
+    mp.ms_good_init_confidence = ms_good_init_confidence; mp.use_external_init_mean = use_external_init_mean ? 1 : 0;
+    mp.rvec_scale = rvec_scale; mp.rg_pose_scaling = rg_pose_scaling; mp.do_rg = do_rg ? 1 : 0; mp.rg_trunc_sigma = rg_trunc_sigma;
+    mp.rg_covar_reg_lambda = rg_covar_reg_lambda; mp.rg_epsilon = rg_epsilon; mp.rg_max_iters = rg_max_iters;
+    if (int e = pose_mode_device(c, n_poses, mp, c->cams.as<CamState>(), c->od.pb(), 0, !use_external_init_mean)) return e;
+    VK_CHECK(hipMemcpyAsync(&cam, c->cams.p, sizeof cam, hipMemcpyDeviceToHost, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    for (int d = 0; d < 3; d++) { io_pose6[d] = cam.rvec[d]; io_pose6[3 + d] = cam.t[d]; }
+    if (o_covar36) memcpy(o_covar36, cam.covar, sizeof cam.covar);
+    if (o_density) *o_density = cam.pose_density;
+    if (o_sample_count) *o_sample_count = cam.pose_sample_count;
+    if (o_ms_iters) *o_ms_iters = cam.last_used_ms_iters;
+    if (o_gu_iters) *o_gu_iters = cam.last_used_gu_iters;
+    if (o_success) *o_success = cam.success;
+    return 0;
+}
+
 // gpu_kernels.h:17-22 / fit_robust_gaussian.cu:101-286. Returns 0 iff the fit is reliable.
 int fit_robust_gaussian(float* h_space, float* h_io_mean, float* h_io_covar, float trunc_sigma, float covar_reg_lambda,
                         float* h_o_density, int* used_iters, int N, int dims, float epsilon, int max_iters) {

@@ -10,6 +10,7 @@ struct ModeParams {
     int use_external_init_mean;  // -1: derive from CamState.pose_sample_count on the device
     float rvec_scale, rg_pose_scaling;
     int do_rg; float rg_trunc_sigma, rg_covar_reg_lambda, rg_epsilon; int rg_max_iters;
+    int rg_partition = 1;  // refit: re-deal the pool by distance and stop a pass outside the gate's ball (filled in by pose_mode_device: vk_set_refit_partition)
     // > 0 on the LAST camera of an EM iteration: the kernel that finishes it also takes the truncation decision for the
     // decide_n cameras (voldor.cpp:171-194 -> PoseBlock::n_active) instead of a separate one-thread launch
     int decide_n = 0, decide_allow_trunc = 0; float decide_trunc_rigidness_density = 0.f, decide_trunc_sample_density = 0.f;

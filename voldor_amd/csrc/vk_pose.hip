@@ -20,6 +20,7 @@
 
 namespace vk {
 
+static std::atomic<int> g_refit_partition{1};  // vk_set_refit_partition (verification aid): 0 = every gate pass of the refit walks the whole pool in its arrival order
 static std::atomic<int> g_split_trials{1};  // vk_set_split_trials (verification aid): 0 = the mode kernel runs the initial-mode trials itself
 
 // phase clocks of the pose kernels (profiling builds only: scripts/phase_clocks.sh compiles a second library with -DVK_PHASE_CLOCKS)
@@ -1171,7 +1172,9 @@ __device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], i
     float m0[6];
     {
         float r2[RF_PAIRS];
-        refit_partition<THREADS>(X, mean, r2);  // `mean` still is the mean-shift mode here
+#pragma unroll
+        for (int p = 0; p < RF_PAIRS; p++) r2[p] = 0.f;  // without the partition: nothing is ever outside
+        if (mp.rg_partition) refit_partition<THREADS>(X, mean, r2);  // `mean` still is the mean-shift mode here
 #pragma unroll
         for (int p = 0; p < RF_PAIRS; p++) r2b[p] = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(r2[p]));
 #pragma unroll
@@ -1708,7 +1711,9 @@ int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, fl
                               solver, draw, strict, ref_svd);
 }
 
-int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first) {
+int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first) {
+    ModeParams mp = mp_in;
+    mp.rg_partition = g_refit_partition.load(std::memory_order_relaxed);
     if (n_poses > PM_POOL) {
         fprintf(stderr, "voldor_hip: n_poses_to_sample=%d exceeds the %d hypotheses the mode kernel keeps in registers\n", n_poses,
                 PM_POOL);
@@ -1749,6 +1754,7 @@ int robust_gaussian_device(Context* c, const float* space_dev, int N, const Mode
 
 }  // namespace vk
 
+extern "C" __attribute__((visibility("default"))) int vk_set_refit_partition(int on) { vk::g_refit_partition.store(on ? 1 : 0); return 0; }
 extern "C" __attribute__((visibility("default"))) int vk_set_split_trials(int on) { vk::g_split_trials.store(on ? 1 : 0); return 0; }
 
 #ifdef VK_PHASE_CLOCKS
