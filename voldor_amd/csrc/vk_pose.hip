@@ -1200,7 +1200,7 @@ __device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], i
         float dm2 = 0.f, tr = 0.f;
 #pragma unroll
         for (int d = 0; d < 6; d++) { dm2 = fmaf(mean[d] - m0[d], mean[d] - m0[d], dm2); tr += cov[(d * d + d) / 2 + d]; }
-        const float ball = (sqrtf(dm2) + mp.rg_trunc_sigma * sqrtf(tr)) * 1.001f;
+        const float ball = (__builtin_amdgcn_sqrtf(dm2) + mp.rg_trunc_sigma * __builtin_amdgcn_sqrtf(tr)) * 1.001f;  // v_sqrt_f32 (1 ulp): the margin is a thousand times that
         const unsigned ballb = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(ball * ball));  // a NaN (degenerate covariance) is above every bound: skips nothing
 #pragma unroll
         for (int p = 0; p < RF_PAIRS; p++) {
