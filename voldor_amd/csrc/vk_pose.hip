@@ -1048,6 +1048,7 @@ __device__ __forceinline__ void refit_partition(f2 (&X)[PM_POOL / THREADS / 2][6
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     s_hist[tid] = 0u; s_hist[tid + THREADS] = 0u;
     if (tid < NCLS) { s_cedge[tid] = 0x7f800000u; s_cstart[tid] = 0x7fffffffu; }
+    if (tid < PAIRS) s_bclass[tid] = 0;  // (every rank lies in some bin, so each entry is overwritten below; class 0 = the bound that never skips)
 #pragma unroll
     for (int c = 0; c < NCLS; c++) cnt[tid * ROW + c] = 0u;
     __syncthreads();
