@@ -8,7 +8,7 @@
  * PARITY PINNING: the reference ships no tests / golden vectors for this path
  *  and its CUDA+OpenCV build cannot run here.  Two levels of pinning
  * against the reference's own code stand in for them:
- *  1. the headers that compile on the host (lambdatwist/*.h, residual_model.h,
+ *  1. the headers that compile on the host (the lambdatwist headers, residual_model.h,
  *     rodrigues.h+svd3_cuda.h) are built in place into oracle/_ref (ref_wrap.cpp;
  *     tests/test_oracle_vs_golden.py, tests/golden/ref_{lambdatwist,residual,rodrigues}.npz);
  *  2. the CUDA kernel files themselves (optimize_depth.cu, fb_smooth.h, collect_p3p_instances.cu,
