@@ -3,7 +3,7 @@
  * (LambdaTwist / AP3P), rotation -> angle-axis, mean-shift, robust Gaussian fit.
  * Restated from gpu-kernels/{collect_p3p_instances.cu,solve_batch_lambdatwist.cu,
  * solve_batch_ap3p.cu,rodrigues.h,meanshift.cu,fit_robust_gaussian.cu,aux_funs.cpp},
- * lambdatwist/*.h and voldor/geometry.cpp; citations inline. */
+ * the lambdatwist headers and voldor/geometry.cpp; citations inline. */
 #include "orc.h"
 #include "orc_math.h"
 #include "../voldor_amd/csrc/vk_ref_svd.h"
