@@ -1482,7 +1482,7 @@ __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __res
         PH_MARK(32);
         const float tot = allreduce_lanes<7, NW>(acc, rb, parity); parity ^= 1;  // lane k: total of sum k
         const float wsum = lane_value(tot, 0);
-        conf = wsum / (float)used;
+        conf = wsum;  // (divided by the sample count once, after the loop: off the per-iteration chain)
         ms_iters = iter + 1;
         const float quot = tot / wsum;  // lanes 1..6: the new mean, one division per wave instead of six per thread
         float disp = 0.f;
@@ -1492,9 +1492,10 @@ __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __res
             disp += (io_mean[d] - m) * (io_mean[d] - m);  // vs. the stale io mean on the first pass (SURVEY B-6)
             io_mean[d] = m; c_mean[d] = m;
         }
-        if (sqrtf(disp) < mp.ms_epsilon) break;  // uniform: every thread holds the same totals
+        if (__builtin_amdgcn_sqrtf(disp) < mp.ms_epsilon) break;  // uniform: every thread holds the same totals (v_sqrt_f32: the test is a threshold on a displacement, not a result)
         PH_MARK(33);
     }
+    conf = conf / (float)used;
     PH_MARK(33); PH_ADD(19, ms_iters); PH_ADD(20, 1);
     if (DEFER) {  // robust-Gaussian refit on the same registers (geometry.cpp:201-263), which finalises the pose itself
         refit_block<THREADS>(X, used, io_mean, conf, ms_iters, mp, cam, P, cam_idx, rb);
