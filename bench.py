@@ -63,6 +63,17 @@ WORKLOADS = {
                  name="BASELINE cfg5: 1920x1080, N_flow=10, disparity prior from depth (RGB-D), 12 EM iterations + fb_smooth"),
 }
 HBM_PEAK_GBS = 8000.0
+KERNEL_SOURCES = ("vk_depth.hip", "vk_pose.hip", "vk_device.hpp", "vk_p3p.hpp", "vk_common.hpp")  # what the replayed counter passes were taken on
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources the quoted kernels live in (the GPU box has no .git: a content hash, not a commit)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "voldor_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def main():
@@ -151,6 +162,7 @@ def main():
     recv = torch.zeros(world * blk, device="cuda")
 
     blocks_host = [None]
+    ag_events, ag_dev_ms = [], []
 
     def step():
         if frontend == "capi":  # window + ncclAllGather of the 1 + 42 N float records, both inside the library (vk_voldor_sharded)
@@ -159,7 +171,9 @@ def main():
         # the library leaves [n_registered | poses N x 6 | covar N x 36] in `send` on the device (vk_voldor_device_block)
         out = pyvoldor.voldor_device(flows, FX, FY, CX, CY, config=CONFIG, depth_out=depth, depth_conf_out=conf, pose_block_out=send, **extra)
         if frontend == "torch":  # pose exchange: one RCCL all-gather of 1 + 42 N floats per rank, device to device
-            dist.all_gather_into_tensor(recv, send)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); dist.all_gather_into_tensor(recv, send); e1.record()
+            ag_events.append((e0, e1))
         return out
 
     def local_step():  # the window alone, no exchange: what the measurement legs after the timed region run (on rank 0 ONLY -- a collective there would wait for ranks that have moved on)
@@ -186,6 +200,7 @@ def main():
         out = step()
     fence()
     dt = time.perf_counter() - t0
+    ag_dev_ms = [a.elapsed_time(b) for a, b in ag_events]
     if use_dist:
         if frontend == "capi":
             dt = vdist.capi_max(dt)
@@ -199,6 +214,22 @@ def main():
         assert int(round(float(blocks[rank, 0]))) == int(out["n_registered"]) and np.array_equal(blocks[rank, 1:1 + 6 * int(out["n_registered"])], out["poses"].reshape(-1))
     ms_per_step = dt / args.steps * 1e3
     value = world * args.steps / dt
+    # aggregate AND per-GPU frames/s, and the latency of the pose all-gather on its own
+    exchange = None
+    if use_dist:
+        if frontend == "capi":
+            dev_us, host_us = vdist.capi_allgather_stats()
+            dev_us, host_us = dev_us[-args.steps:], host_us[-args.steps:]  # the timed steps (the warm-up ones come first)
+        else:
+            dev_us = np.array(ag_dev_ms[-args.steps:]) * 1e3 if ag_dev_ms else np.zeros(0)
+            host_us = np.zeros(0)
+        def pct(a):
+            return None if len(a) == 0 else {"p50": round(float(np.percentile(a, 50)), 2), "p99": round(float(np.percentile(a, 99)), 2), "max": round(float(np.max(a)), 2)}
+        exchange = {"collective": f"ncclAllGather of {blk} floats ({4 * blk} B) per rank, {world} ranks, once per step", "samples": int(len(dev_us)),
+                    "allgather_us": pct(dev_us), "allgather_host_us": pct(host_us),
+                    "note": "allgather_us: HIP events around the collective on the communicator's stream (rank 0); allgather_host_us: rank 0's wall clock from issuing the "
+                            "collective to its completion, i.e. including the wait for the slowest rank's window",
+                    "per_gpu_frames_per_s": round(value / world, 3), "aggregate_frames_per_s": round(value, 3)}
 
     # ---- latency of a single window as a caller sees it (one call, synchronised): p50 / p99 over 100 windows (extra, never `value`) ----
     latency = None
@@ -238,24 +269,34 @@ def main():
         sqc = {}
         src = {}
         def pmc_file(kind):  # the latest committed PMC pass of this workload (collected separately: rocprofv3 cannot time and count in one run)
-            for tag in ("r03d", "r03c", "r03b", "r03a", "r02j", "r02h", "r02c"):
+            for tag in ("r04b", "r04a", "r03d", "r03c", "r02j", "r02h", "r02c"):
                 f = os.path.join(ROOT, "profiles", f"{tag}_pmc_{kind}_{args.workload}.json")
                 if os.path.exists(f):
                     return f
             raise FileNotFoundError(kind)
         def provenance(f, doc):  # these numbers are REPLAYED from a committed counter pass, not measured by this run
-            return {"file": os.path.relpath(f, ROOT), "commit": doc.get("commit"), "replayed": True}
+            # the pass records the sha256 of the kernel sources it was collected on (scripts/pmc_*.sh); a pass of another tree is STALE:
+            # its figures are withheld from the line (null) and only named here
+            cur = kernel_source_hash()
+            stale = doc.get("kernel_source_sha256") != cur
+            return {"file": os.path.relpath(f, ROOT), "commit": doc.get("commit"), "replayed": True, "kernel_source_sha256": doc.get("kernel_source_sha256"),
+                    "current_kernel_source_sha256": cur, "stale": bool(stale)}
         try:
             f = pmc_file("traffic"); doc = json.load(open(f)); ks = doc["kernels"]
-            traffic = ks[kname]["hbm_bytes_per_launch"]
             src["traffic"] = provenance(f, doc)
+            if src["traffic"]["stale"]:
+                raise LookupError("stale counter pass")
+            traffic = ks[kname]["hbm_bytes_per_launch"]
             # k_cost_rand_q runs once per optimize_depth call: launches relative to it = launches per call
             group_traffic = sum(v["hbm_bytes_per_launch"] * v["launches"] for k, v in ks.items() if any(t in k for t in od_kernels)) / ks[kname]["launches"]
         except Exception:
             pass
         try:
-            f = pmc_file("sq"); doc = json.load(open(f)); sqc = doc[kname]
+            f = pmc_file("sq"); doc = json.load(open(f))
             src["sq"] = provenance(f, doc)
+            if src["sq"]["stale"]:
+                raise LookupError("stale counter pass")
+            sqc = doc[kname]
             # SQ_ACTIVE_INST_VALU counts quad-cycles summed over waves (MI355X_MICROARCH.md): x4 = cycles some SIMD spent issuing VALU;
             # over 1024 SIMDs and the launch duration at the 2.4 GHz peak clock = the fraction of VALU issue slots used
             valu = sqc["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * sqc["avg_us_under_pmc"] * 1e-6 * 2.4e9)
@@ -275,7 +316,8 @@ def main():
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                     "algorithmic_bytes": b_od, "avg_us": round(groups["optimize_depth"]["avg_us"], 2),
                     "traffic": None if group_traffic is None else round(group_traffic),
-                    "measured": "achieved / frac / avg_us: HIP events of THIS run; traffic, valu_issue_frac, sq_counters_per_launch: replayed from the committed rocprofv3 --pmc passes named in `source`",
+                    "measured": "achieved / frac / avg_us: HIP events of THIS run; traffic, valu_issue_frac, sq_counters_per_launch: replayed from the committed rocprofv3 --pmc passes named in `source` "
+                                "(null when that pass was collected on other kernel sources than this tree's: `source.*.stale`)",
                     "source": src or None,
                     "traffic_note": "TCC_EA read/write request counters converted to bytes as MI355X_MICROARCH.md prescribes (gfx950 FETCH_SIZE x2 correction); that correction is "
                                     "calibrated on wide coalesced reads -- for the 8-byte bilinear gathers of these kernels absolute bytes are an upper estimate (ratios between variants hold); "
@@ -429,7 +471,7 @@ def main():
                 except Exception:
                     pass
         line = {
-            "metric": f"VO frames/s ({W}x{H}, N_flow={N_FLOW}, {EM_ITERS} EM iters)", "value": round(value, 3), "unit": "frames/s",
+            "metric": f"VO frames/s ({W}x{H}, N_flow={N_FLOW}, {EM_ITERS} EM iters), inputs resident in HBM", "value": round(value, 3), "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"] + ", scene S seed 233+rank, inputs resident in HBM",
@@ -440,7 +482,7 @@ def main():
             "n_registered": int(out["n_registered"]),
             "pose_rpe_vs_gt": {"rot_rad_max": float(rot.max()) if len(rot) else None, "rel_trans_max": float(tr.max()) if len(tr) else None},
             "pose_rpe_vs_reference": vs_ref,
-            "latency": latency, "roofline": roof, "cpu_baseline": cpu, "cpu_reference": cpu_ref, "host_inclusive": host_inc, "strict": strict, "concurrent": conc,
+            "exchange": exchange, "latency": latency, "roofline": roof, "cpu_baseline": cpu, "cpu_reference": cpu_ref, "host_inclusive": host_inc, "strict": strict, "concurrent": conc,
         }
         print(json.dumps(line), flush=True)
     if frontend == "capi":

@@ -129,39 +129,6 @@ int vk_get_strict_math(void);
  * --strict_math 1 --reference_draw 1 a window then equals the reference pipeline's strict-math window in every output bit. */
 int vk_set_reference_svd(int on);
 int vk_get_reference_svd(void);
-/* Verification aid: 1 = the local-propagation pass of the fast mode walks every chain step by step (one lane per chain, the literal
- * optimize_depth.cu:320-396 order) instead of the table + speculative-run kernel; both must give identical maps
- * (tests/test_gpu_kernels.py::test_local_runs_equal_the_step_by_step_chain). */
-int vk_set_local_serial(int on);
-/* Verification entry: the mode kernel of the window pipeline (k_pose_mode: packed-pair mean shift; with do_rg the robust-Gaussian refit on
- * the same registers -- geometry.cpp:156-263, meanshift.cu:34-150, fit_robust_gaussian.cu:131-263) on a caller-supplied pool of pose
- * hypotheses, so that the kernels of the timed path can be held against the oracle stage by stage
- * (tests/test_gpu_kernels.py::test_pipeline_mode_kernel_matches_oracle).  h_rvecs / h_tvecs: [n_poses][3], n_poses <= 8192, a non-finite
- * hypothesis is dropped; io_pose6: rvec and t of the starting pose in (used when use_external_init_mean), the estimate out;
- * o_covar36: the camera record's covariance (zeros unless the refit ran and was reliable).  Returns nonzero on a device error. */
-int vk_pose_mode_pool(const float* h_rvecs, const float* h_tvecs, int n_poses, int use_external_init_mean, float* io_pose6,
-                      float kernel_var, float rvec_scale, float ms_epsilon, int ms_max_iters, int ms_max_init_trials, float ms_good_init_confidence,
-                      int do_rg, float rg_trunc_sigma, float rg_covar_reg_lambda, float rg_epsilon, int rg_max_iters, float rg_pose_scaling,
-                      float* o_covar36, float* o_density, int* o_sample_count, int* o_ms_iters, int* o_gu_iters, int* o_success);
-/* Verification aid: 0 = every gate pass of the refit walks the whole pool in its arrival order instead of the pool re-dealt by distance
- * from the mean-shift mode and a pass that stops outside the ball holding the gate.  The same sums up to the order of their terms
- * (tests/test_gpu_kernels.py::test_refit_partition_changes_no_sum).  Default 1. */
-int vk_set_refit_partition(int on);
-/* Tuning / verification aid: steps per lane of the segmented fb_smooth of the fast mode: 0 = chosen by size (default), 20 or 40 = forced
- * where the line fits (a line longer than 256 row / 64 column segments of 20 steps takes 40 regardless).  The two agree to rounding
- * (tests/test_gpu_kernels.py::test_fb_smooth_segment_lengths_agree).  Returns nonzero for any other value. */
-int vk_set_fb_segment(int steps);
-/* Verification aid: 0 = the global-propagation passes of the fast mode evaluate a site with one lane (k_global_prop_sites_lean) instead of
- * a group of lanes (k_global_prop_split_lean); identical maps (tests/test_gpu_kernels.py::test_global_split_equals_one_lane_per_site).  Default 1. */
-int vk_set_global_split(int on);
-/* Verification aid: 1 = the sample pass of the fast mode evaluates every random depth in full, one after the other (the literal order of
- * optimize_depth.cu:269-284 on the fast arithmetic) instead of exact early rejection + survivor queue; identical maps
- * (tests/test_gpu_kernels.py::test_sample_pass_equals_the_plain_sequential_form).  Default 0. */
-int vk_set_cost_rand_plain(int on);
-/* Verification aid: 0 = the mean-shift kernel evaluates the initial-mode trials of a camera without a pose itself (20 passes on one
- * compute unit) instead of taking them from k_mode_trials (one workgroup per trial); same picks, same rule
- * (tests/test_gpu_voldor.py::test_split_trials_equal_in_kernel_trials).  Default 1. */
-int vk_set_split_trials(int on);
 int vk_profile_enable(int on);           /* HIP-event timing of kernel groups on the library's stream */
 int vk_profile_get(const char* name, double* total_ms, long* count);
 int vk_device_count(void);
@@ -187,9 +154,17 @@ int vk_dist_rccl_version(void);
 int vk_dist_allgather(const float* send_dev, float* recv_dev, int count); /* ncclAllGather of `count` floats per rank, device buffers; returns when done */
 int vk_dist_allreduce_max(double* io_host);                   /* max over the ranks (step timing); acts as a barrier */
 int vk_dist_barrier(void);
+/* Latency of the all-gathers issued so far (vk_voldor_sharded, vk_dist_allgather), in call order, microseconds: dev_us = HIP events around
+ * ncclAllGather on the communicator's stream, host_us = the host's wall clock from issue to completion.  Either array may be NULL; at most
+ * `cap` samples (the library keeps the first VK_DIST_STATS_MAX since the last reset); *n = samples written; reset != 0 clears the record. */
+#define VK_DIST_STATS_MAX 65536
+int vk_dist_allgather_stats(float* dev_us, float* host_us, int cap, int* n, int reset);
 /* One batch step of the sharded job: this rank's window through vk_voldor_device_block (arguments as vk_voldor_device; flows ==
  * NULL: no sequence for this rank in this step), then the all-gather.  all_blocks_host[world][1 + 42 N] (host) receives every
- * rank's record; n_registered = -1 marks an empty slot. */
+ * rank's record; n_registered = -1 marks an empty slot.  A rank whose own window fails STILL takes part in the all-gather (the others
+ * would wait for it forever): its record is { VK_DIST_FAILED, its error code, 0 ... }, its own call returns that error code, and the
+ * other ranks return 0 and find the failure in the gathered records. */
+#define VK_DIST_FAILED (-2)
 int vk_voldor_sharded(const float* flows, const float* disparity, const float* disparity_pconf,
                       const float* depth_priors, const float* depth_prior_poses,
                       const float* depth_prior_pconfs, float fx, float fy, float cx, float cy,

@@ -10,10 +10,21 @@ flows = torch.from_numpy(sc["flows"]).cuda()
 kw = dict(basefocal=wl["basefocal"], disparity=torch.from_numpy(sc["disparity"]).cuda()) if wl["mode"] == "stereo" else {}
 depth = torch.empty(wl["h"], wl["w"], device="cuda"); conf = torch.empty_like(depth)
 n = 30 if wl["w"] < 1900 else 8
+from voldor_amd import capi
+def switches(sfx):  # "@name=value" tokens of a suffix set verification switches (vk_debug.h) for that variant; the rest is config text
+    toks = sfx.split()
+    for t in toks:
+        if t.startswith("@"):
+            k, v = t[1:].split("=")
+            assert capi.lib().vk_debug_switch(k.encode(), int(v)) >= 0, t
+    return " ".join(t for t in toks if not t.startswith("@"))
 for rep in range(2):
-    for sfx in sys.argv[2:]:
+    for raw in sys.argv[2:]:
+        for k, v in (("newton_cap", 12), ("strict_plain", 0)):
+            capi.lib().vk_debug_switch(k.encode(), v)
+        sfx = switches(raw)
         for _ in range(3): pyvoldor.voldor_device(flows, wl["fx"], wl["fx"], wl["cx"], wl["cy"], config=wl["cfg"] + " " + sfx, depth_out=depth, depth_conf_out=conf, **kw)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for _ in range(n): o = pyvoldor.voldor_device(flows, wl["fx"], wl["fx"], wl["cx"], wl["cy"], config=wl["cfg"] + " " + sfx, depth_out=depth, depth_conf_out=conf, **kw)
         torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
-        print(f"{sys.argv[1]} [{sfx:24s}] {dt*1e3:8.3f} ms/window  {1/dt:7.1f} windows/s  n_registered {o['n_registered']}")
+        print(f"{sys.argv[1]} [{raw:24s}] {dt*1e3:8.3f} ms/window  {1/dt:7.1f} windows/s  n_registered {o['n_registered']}")

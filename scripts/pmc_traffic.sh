@@ -25,6 +25,11 @@ out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRIT
                 "reads (MI355X_MICROARCH.md), WRITE_SIZE is exact.  hbm_bytes = (fetch_factor*FETCH_SIZE + WRITE_SIZE)*1024; fetch_factor 2 for kernels of 8/16-byte "
                 "loads, 1 for kernels of 4-byte loads (calibrated on kernels of known byte count, see scripts/pmc_traffic.sh).",
        "workload": wl, "commit": os.environ.get("COMMIT"), "kernels": {}}
+import hashlib
+h = hashlib.sha256()
+for f in ("vk_depth.hip", "vk_pose.hip", "vk_device.hpp", "vk_p3p.hpp", "vk_common.hpp"):  # = bench.KERNEL_SOURCES: bench.py withholds a pass taken on other sources
+    h.update(open(os.path.join("voldor_amd", "csrc", f), "rb").read())
+out["kernel_source_sha256"] = h.hexdigest()[:16]
 # Calibration of the x2 on kernels whose byte count is known (profiles/r02h_pmc_traffic_cfg2.json, r02j_pmc_traffic_cfg5.json): FETCH_SIZE reports
 # HALF the bytes of 8- and 16-byte loads (k_fb_rows: 20 B/px read as float4 -> 10.5 reported; k_depth_conf 44 -> 22; k_disp_to_depth 4 -> 2;
 # k_update_rigidness_lean, 16-byte texel-pair gathers: ~44 -> 19.9) and ALL the bytes of 4-byte loads (k_fb_cols: 20 -> 20.5).  The flow

@@ -5,8 +5,8 @@ the CPU) over an ensemble of independent windows, each run under three libms tha
   jA  glibc with every result moved by -1/0/+1 ulp, salt 1      (ref_set_math_mode(2), ref_set_jitter_salt(1))
   jB  the same with an independent pattern, salt 2
 
-  * BASELINE cfg2 (640x480, N=5, monocular, 8 iterations): seeds CFG2_SEEDS (24 windows)
-  * BASELINE cfg3 (1241x376, N=8, stereo prior):            seeds CFG3_SEEDS (8 windows)
+  * BASELINE cfg2 (640x480, N=5, monocular, 8 iterations): seeds CFG2_SEEDS (72 windows)
+  * BASELINE cfg3 (1241x376, N=8, stereo prior):            seeds CFG3_SEEDS (48 windows)
 
 What the distances between those runs are is the estimator's reproducibility under a 1-ulp change of its transcendentals -- the
 yardstick the fast HIP path (hardware v_exp / v_log) is held to in tests/test_gpu_ensemble.py: a two-sample Kolmogorov-Smirnov
@@ -58,18 +58,23 @@ def run_one(job):
 
 
 def main():
-    workers = int(sys.argv[1]) if len(sys.argv) > 1 else max(1, (os.cpu_count() or 2) - 1)
+    workers = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else max(1, (os.cpu_count() or 2) - 1)
     jobs = [("cfg2", 233, "strict")]
     jobs += [("cfg3", s, m) for s in ens.CFG3_SEEDS for m in ("g", "jA", "jB")]  # the long ones first
     jobs += [("cfg2", s, m) for s in ens.CFG2_SEEDS for m in ("g", "jA", "jB")]
     out = {}
+    path = os.path.join(HERE, "ref_ensemble.npz")
+    if os.path.exists(path) and "--fresh" not in sys.argv:  # incremental: runs already in the file are kept (each is a pure function of (kind, seed, mode))
+        with np.load(path) as old:
+            out = {k: old[k] for k in old.files}
+        jobs = [j for j in jobs if f"{j[0]}/s{j[1]}/{j[2]}/n_registered" not in out]
+        print(f"{len(out)} arrays kept, {len(jobs)} runs to do", flush=True)
     t0 = time.time()
     with mp.get_context("spawn").Pool(workers, maxtasksperchild=1) as pool:
         for (kind, seed, mode), r, dt in pool.imap_unordered(run_one, jobs):
             for k, v in r.items():
                 out[f"{kind}/s{seed}/{mode}/{k}"] = v
             print(f"[{time.time() - t0:6.0f}s] {kind} seed {seed} {mode:6s} n_registered {int(r['n_registered'])}  ({dt:.0f} s)", flush=True)
-    path = os.path.join(HERE, "ref_ensemble.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
 

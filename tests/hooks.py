@@ -64,3 +64,42 @@ def rodrigues(R9, strict, device):
     else:
         L.vkt_rodrigues_host(_p(R9), _p(rv), R9.shape[0], int(strict))
     return rv
+
+
+# ---- verification entry points of the PRODUCT library that are not part of its C-ABI (voldor_amd/csrc/vk_debug.h) ----
+def debug_switch(name: str, value: int) -> int:
+    """vk_debug_switch: returns the previous value; raises for an unknown name / value."""
+    from voldor_amd import capi
+    old = capi.lib().vk_debug_switch(name.encode(), int(value))
+    if old < 0:
+        raise ValueError(f"vk_debug_switch({name!r}, {value}) rejected")
+    return old
+
+
+def set_local_serial(on): debug_switch("local_serial", int(bool(on)))
+def set_cost_rand_plain(on): debug_switch("cost_rand_plain", int(bool(on)))
+def set_fb_segment(steps): debug_switch("fb_segment", int(steps))
+def set_global_split(on): debug_switch("global_split", int(bool(on)))
+def set_refit_partition(on): debug_switch("refit_partition", int(bool(on)))
+def set_split_trials(on): debug_switch("split_trials", int(bool(on)))
+def set_strict_plain(on): debug_switch("strict_plain", int(bool(on)))
+
+
+def pose_mode_pool(rvecs, tvecs, init_pose6, use_external_init_mean=True, refit=False, kernel_var=0.2, rvec_scale=1.0, ms_epsilon=1e-5,
+                   ms_max_iters=100, ms_max_init_trials=20, ms_good_init_confidence=0.5, rg_trunc_sigma=3.0, rg_covar_reg_lambda=1e-3,
+                   rg_epsilon=1e-5, rg_max_iters=100, rg_pose_scaling=100.0):
+    """vk_pose_mode_pool (vk_debug.h): the window pipeline's own mode kernel on a pool of hypotheses (strict-math kernel when the process-wide
+    strict mode is on).  Returns dict(pose6, covar [6,6], density, sample_count, ms_iters, gu_iters, success)."""
+    from voldor_amd import capi
+    from voldor_amd.capi import f32, fp
+    rv, tv = f32(rvecs).reshape(-1, 3), f32(tvecs).reshape(-1, 3)
+    pose = f32(init_pose6).copy().reshape(6)
+    cov = np.zeros((6, 6), np.float32)
+    dens = C.c_float(0)
+    cnt, msi, gui, ok = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    capi.check(capi.lib().vk_pose_mode_pool(fp(rv), fp(tv), rv.shape[0], int(use_external_init_mean), fp(pose), C.c_float(kernel_var), C.c_float(rvec_scale),
+                                            C.c_float(ms_epsilon), int(ms_max_iters), int(ms_max_init_trials), C.c_float(ms_good_init_confidence), int(refit),
+                                            C.c_float(rg_trunc_sigma), C.c_float(rg_covar_reg_lambda), C.c_float(rg_epsilon), int(rg_max_iters),
+                                            C.c_float(rg_pose_scaling), fp(cov), C.byref(dens), C.byref(cnt), C.byref(msi), C.byref(gui), C.byref(ok)),
+               "vk_pose_mode_pool")
+    return dict(pose6=pose, covar=cov, density=dens.value, sample_count=cnt.value, ms_iters=msi.value, gu_iters=gui.value, success=ok.value)

@@ -160,6 +160,61 @@ def test_capi_two_ranks_on_one_gpu_through_the_file_backed_stand_in(tmp_path):
         assert p.returncode == 0 and f"RANK_OK {r}" in so, (r, so[-1000:], se[-3000:])
 
 
+_FAILING_RANK = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+rank, world, path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+from voldor_amd import capi, synth
+lib = capi.lib()
+capi.check(lib.vk_set_device(0), "vk_set_device")
+if rank == 1:                                                   # a leftover of ANOTHER job under the same path: rank 1 must not join it
+    assert os.path.exists(path)
+capi.check(lib.vk_dist_init_file(rank, world, path.encode(), 60), "vk_dist_init_file")
+N, h, w = 3, 120, 160
+sc = synth.make_scene(w=w, h=h, n_flows=N, fx=80, fy=80, cx=80, cy=60, seed=233)
+good = b"--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 2"
+bad = good + b" --resize_factor 0.5"                            # rejected by the window call (vk_voldor.hip): a LOCAL error on rank 1 only
+blocks = np.zeros((world, 1 + 42 * N), np.float32)
+poses = np.zeros((N, 6), np.float32); covar = np.zeros((N, 36), np.float32); n = C.c_int(0)
+rc = lib.vk_voldor_sharded(capi.fp(sc["flows"]), None, None, None, None, None, C.c_float(80), C.c_float(80), C.c_float(80), C.c_float(60), C.c_float(0), N, 0, w, h,
+                           bad if rank == 1 else good, C.byref(n), capi.fp(poses), capi.fp(covar), None, None, capi.fp(blocks))
+# nobody hangs: the failing rank took part in the all-gather with a marked record and returns its own error; the others return 0
+if rank == 1:
+    assert rc != 0 and n.value == -2, (rc, n.value)
+else:
+    assert rc == 0 and n.value == N, (rc, n.value)
+assert blocks[0, 0] == N and blocks[1, 0] == -2 and blocks[1, 1] != 0 and not blocks[1, 2:].any(), blocks[:, :3]
+capi.check(lib.vk_dist_barrier(), "barrier")                     # the communicator is still usable
+dev = np.zeros(8, np.float32); host = np.zeros(8, np.float32); k = C.c_int(0)
+capi.check(lib.vk_dist_allgather_stats(capi.fp(dev), capi.fp(host), 8, C.byref(k), 1), "stats")
+assert k.value == 1 and dev[0] >= 0 and host[0] > 0, (k.value, dev[:2], host[:2])
+lib.vk_dist_finalize()
+print("RANK_OK", rank)
+"""
+
+
+def test_a_rank_whose_window_fails_still_joins_the_all_gather(tmp_path):
+    """one rank's LOCAL error (here a rejected config key) must not hang the job -- the other ranks are already inside
+    ncclAllGather + hipStreamSynchronize with no timeout.  vk_voldor_sharded on the failing rank sends { VK_DIST_FAILED, its error code }
+    and returns the error; rank 0 returns 0 and sees which peer failed.  Also: the rendezvous file of ANOTHER job (other job tag) left under
+    the same path is ignored by the waiting rank (VOLDOR_HIP_JOB_ID), and vk_dist_allgather_stats reports the collective's latency."""
+    from voldor_amd import build
+    build.build_test_lib()
+    fake = os.path.join(ROOT, "voldor_amd", "lib", "libfake_rccl_test.so")
+    path = str(tmp_path / "id")
+    with open(path, "wb") as f:  # a stale file of "another job": 64-byte tag + 128 bytes of a dead id
+        f.write(b"some-other-job".ljust(64, b"\0") + bytes(128))
+    env = dict(os.environ, VOLDOR_HIP_RCCL=fake, VOLDOR_HIP_JOB_ID="this-job")
+    p1 = subprocess.Popen([sys.executable, "-c", _FAILING_RANK.format(root=ROOT), "1", "2", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+    import time
+    time.sleep(3.0)  # rank 1 is now polling the stale file; rank 0 starts late and replaces it
+    p0 = subprocess.Popen([sys.executable, "-c", _FAILING_RANK.format(root=ROOT), "0", "2", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env)
+    for r, p in ((0, p0), (1, p1)):
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0 and f"RANK_OK {r}" in so, (r, so[-1000:], se[-3000:])
+
+
 def test_bench_with_two_ranks_on_one_gpu_through_the_stand_in():
     """bench.py's whole N = 2 flow (what the driver launches for its scaling run, minus the second GPU): two processes with RANK 0 / 1,
     both on GPU 0 (LOCAL_RANK 0), the C-ABI front end bound to the file-backed stand-in.  Rendezvous through env://, agreement on the front
@@ -179,6 +234,8 @@ def test_bench_with_two_ranks_on_one_gpu_through_the_stand_in():
     j = _line(outs[0][0])
     assert j["n_gpus"] == 2 and j["n_registered"] == 5 and j["value"] > 20 and "below the C-ABI" in j["config"]["parallelism"] and "fell back" not in j["config"]["parallelism"]
     assert j["latency"] is not None and j["roofline"] is not None  # the rank-0-only legs ran (without a collective)
+    ex = j["exchange"]  # the collective's own latency and the per-GPU rate are in the line
+    assert ex["samples"] == 3 and ex["allgather_us"]["p50"] >= 0 and ex["allgather_host_us"]["p99"] > 0 and abs(ex["per_gpu_frames_per_s"] * 2 - j["value"]) < 0.01 * j["value"]
     assert not [ln for ln in outs[1][0].splitlines() if ln.startswith("{")]  # rank 1 prints nothing
 
 

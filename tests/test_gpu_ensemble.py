@@ -7,7 +7,10 @@ logf does to the reference's OWN output; the fast path (v_exp_f32 / v_log_f32, r
 
   (i)  the distances {fast HIP vs g} and {jitter vs g} come from one distribution: two-sample Kolmogorov-Smirnov p > 0.01 for the
        worst rotation, worst relative translation, 90th-percentile relative depth, fraction of the confident pixels within 1e-3 and
-       |log covariance-trace ratio| of a window;
+       |log covariance-trace ratio| of a window; AND, since a KS test can only fail to reject (round 4): the 95 %
+       bootstrap interval of mean(d_hip) / mean(d_ref), windows resampled as pairs (stat_helpers.paired_mean_ratio_ci), lies below 1.25
+       (above 0.8 for the within-1e-3 fraction) -- equivalence within a margin, on 72 cfg2 / 48 cfg3 windows (24 / 8 in round 3).  The
+       test bites: a 12-step cap on the Newton loop of the P3P cubic (vk_debug_switch "newton_cap", 0.13 ms faster) fails it;
   (ii) the errors against analytic ground truth of {fast HIP} and {reference g} come from one distribution (same test);
   (iii) every window registers the reference's frame count.
 
@@ -25,6 +28,18 @@ pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_ensemble.npz")
 SUB = 8
 ALPHA = 0.01
+FS_SEEDS = ens.CFG2_SEEDS  # windows of the fast-vs-strict test (a strict window costs ~15 ms since round 4)
+
+
+def _dump(name, obj):
+    """raw per-window distances next to the verdict (gpurun_out/ is merged back from the GPU box): what the numbers in DESIGN.md are made from"""
+    import json
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        json.dump(obj, open(os.path.join(d, name + ".json"), "w"))
+    except OSError:
+        pass
 
 
 def _ref_run(g, kind, seed, mode):
@@ -77,17 +92,30 @@ def test_fast_path_is_a_draw_from_the_reference_self_noise(kind, seeds):
         eh, er = _gt_errors(hip, c, mono), _gt_errors(rg, c, mono)
         for k in e_hip:
             e_hip[k].append(eh[k]); e_ref[k].append(er[k])
+    _dump(f"ensemble_{kind}", {"d_hip": d_hip, "d_ref": d_ref, "e_hip": e_hip, "e_ref": e_ref, "seeds": list(seeds)})
     report = {}
-    for k in sh.METRICS:  # (i)
-        p = sh.ks_pvalue(d_hip[k], d_ref[k])
-        report[k] = (float(np.median(d_hip[k])), float(np.median(d_ref[k])), p)
-        assert p > ALPHA, f"{kind}: {k} distance to the reference's glibc run is not a draw from the reference's self-noise (KS p = {p:.4f}); medians {report[k][:2]}"
+    fails = []
+    for k in sh.METRICS:  # (i) KS: "one distribution" cannot be rejected; and the EFFECT SIZE: median ratio inside the equivalence margin
+        p = sh.ks_pvalue(d_hip[k], d_ref[k], f"{kind} {k}")
+        ok, r, lo, hi = sh.equivalence_ok(k, d_hip[k], np.asarray(d_ref[k]).reshape(-1, 2))  # (window w: its two jittered reference runs)
+        report[k] = (float(np.median(d_hip[k])), float(np.median(d_ref[k])), p, r, lo, hi)
+        if not p > ALPHA:
+            fails.append(f"{kind}: {k} distance to the reference's glibc run is not a draw from the reference's self-noise (KS p = {p:.4f}); medians {report[k][:2]}")
+        if not ok:
+            fails.append(f"{kind}: {k} paired ratio of means fast-HIP / reference-self-noise {r:.3f}, 95 % bootstrap interval [{lo:.3f}, {hi:.3f}] leaves the margin "
+                         f"({'>= %.2f' % sh.RATIO_MIN if k == 'within_1e-3' else '<= %.2f' % sh.RATIO_MAX})")
     for k in e_hip:  # (ii)
-        p = sh.ks_pvalue(e_hip[k], e_ref[k])
-        assert p > ALPHA, f"{kind}: {k} error against ground truth differs in distribution (KS p = {p:.4f}); medians {np.median(e_hip[k]):.3e} vs {np.median(e_ref[k]):.3e}"
-    print(f"\n{kind}: median distance to the reference's glibc run, fast HIP | reference under 1-ulp jitter | KS p")
-    for k, (a, b, p) in report.items():
-        print(f"  {k:7s} {a:.3e} | {b:.3e} | {p:.3f}")
+        p = sh.ks_pvalue(e_hip[k], e_ref[k], f"{kind} gt {k}")
+        r, lo, hi = sh.paired_mean_ratio_ci(e_hip[k], e_ref[k])
+        report["gt_" + k] = (float(np.median(e_hip[k])), float(np.median(e_ref[k])), p, r, lo, hi)
+        if not p > ALPHA:
+            fails.append(f"{kind}: {k} error against ground truth differs in distribution (KS p = {p:.4f}); medians {np.median(e_hip[k]):.3e} vs {np.median(e_ref[k]):.3e}")
+        if not hi <= sh.RATIO_MAX:
+            fails.append(f"{kind}: {k} error against ground truth: paired ratio of means {r:.3f} [{lo:.3f}, {hi:.3f}] above {sh.RATIO_MAX}")
+    print(f"\n{kind} ({len(seeds)} windows): median distance to the reference's glibc run, fast HIP | reference under 1-ulp jitter | KS p | paired ratio of means [95 % bootstrap interval over the windows]")
+    for k, (a, b, p, r, lo, hi) in report.items():
+        print(f"  {k:12s} {a:.3e} | {b:.3e} | {p:.3f} | {r:.3f} [{lo:.3f}, {hi:.3f}]")
+    assert not fails, "\n".join(fails)
     print(f"  fraction of confident pixels within 1e-3: fast HIP {np.median(d_hip['within_1e-3']):.3f} | reference vs itself {np.median(d_ref['within_1e-3']):.3f} (north_star asks 0.99)")
     print(f"  worst relative translation: fast HIP {np.max(d_hip['trans']):.2e} | reference vs itself {np.max(d_ref['trans']):.2e} (north_star asks 1e-3)")
 
@@ -103,7 +131,7 @@ def test_fast_vs_strict_is_a_draw_from_the_reference_self_noise():
     g = np.load(GOLD)
     d_fs = {k: [] for k in sh.METRICS}
     d_ref = {k: [] for k in sh.METRICS}
-    for seed in ens.CFG2_SEEDS:
+    for seed in FS_SEEDS:
         c = ens.make("cfg2", seed)
         fx, fy, cx, cy = c["K"]
         runs = {}
@@ -121,8 +149,15 @@ def test_fast_vs_strict_is_a_draw_from_the_reference_self_noise():
             dj = sh.window_distance(_ref_run(g, "cfg2", seed, mode), rg)
             for k in d_ref:
                 d_ref[k].append(dj[k])
-    print("\ncfg2: median distance fast vs strict | reference under 1-ulp jitter vs reference | KS p")
+    _dump("ensemble_fast_vs_strict", {"d_fs": d_fs, "d_ref": d_ref, "seeds": list(FS_SEEDS)})
+    print(f"\ncfg2 ({len(FS_SEEDS)} windows): median distance fast vs strict | reference under 1-ulp jitter vs reference | KS p | paired ratio of means [95 % bootstrap interval over the windows]")
+    fails = []
     for k in sh.METRICS:
-        p = sh.ks_pvalue(d_fs[k], d_ref[k])
-        print(f"  {k:12s} {np.median(d_fs[k]):.3e} | {np.median(d_ref[k]):.3e} | {p:.3f}")
-        assert p > ALPHA, f"{k}: fast vs strict is not a draw from the reference's self-noise (KS p = {p:.4f})"
+        p = sh.ks_pvalue(d_fs[k], d_ref[k], f"fast vs strict {k}")
+        ok, r, lo, hi = sh.equivalence_ok(k, d_fs[k], np.asarray(d_ref[k]).reshape(-1, 2))
+        print(f"  {k:12s} {np.median(d_fs[k]):.3e} | {np.median(d_ref[k]):.3e} | {p:.3f} | {r:.3f} [{lo:.3f}, {hi:.3f}]")
+        if not p > ALPHA:
+            fails.append(f"{k}: fast vs strict is not a draw from the reference's self-noise (KS p = {p:.4f})")
+        if not ok:
+            fails.append(f"{k}: paired ratio of means {r:.3f} [{lo:.3f}, {hi:.3f}] leaves the equivalence margin")
+    assert not fails, "\n".join(fails)

@@ -10,6 +10,8 @@ is a steep function of a small end-point error, so a map agrees to ~1e-5 typical
 import numpy as np
 import pytest
 
+import hooks
+
 from conftest import K9
 
 pytestmark = pytest.mark.gpu
@@ -133,7 +135,7 @@ def _gpu_only(flows, Rs, ts, depth, rig, K, epoch=5, priors=None, pconfs=None, c
 def test_local_runs_equal_the_step_by_step_chain(width, noise, n_flows, n_dp):
     """The local-propagation kernel of the fast mode (cost table + chain automata whose run evaluations are planned two runs ahead, four
     lanes per pixel, two chains per wave up to width 33) against the literal step-by-step chain of the same arithmetic
-    (vk_set_local_serial): identical depth and rigidness maps, bit for bit, at replacement rates from ~50 % (noisy start) to ~0, for
+    (vk_debug_switch "local_serial"): identical depth and rigidness maps, bit for bit, at replacement rates from ~50 % (noisy start) to ~0, for
     every way the frames and depth priors fall onto the four lanes of a pixel."""
     from voldor_amd import kernels, synth
     sc = synth.make_scene(w=211, h=97, n_flows=n_flows, fx=100, fy=100, cx=105, cy=48, seed=21, basefocal=40.0 if n_dp else 0.0)  # ragged: 211 = 6 * 32 + 19
@@ -151,10 +153,10 @@ def test_local_runs_equal_the_step_by_step_chain(width, noise, n_flows, n_dp):
                      dp_Rs=np.tile(np.eye(3, dtype=np.float32), (n_dp, 1, 1)), dp_ts=(rng.normal(0, 0.02, (n_dp, 3)) * np.arange(n_dp)[:, None]).astype(np.float32))
     over = dict(n_rand_samples=3, global_prop_step=5, local_prop_width=width, fb_smooth=0, basefocal=40.0 if n_dp else 0.0, disp_delta=1.0 if n_dp else -1.0)
     try:
-        kernels.set_local_serial(True)
+        hooks.set_local_serial(True)
         d1, r1, c1 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
     finally:
-        kernels.set_local_serial(False)
+        hooks.set_local_serial(False)
     d2, r2, c2 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
     assert np.mean(d1 != depth) > (0.05 if noise >= 0.1 else 0.0)  # the passes did replace depths
     np.testing.assert_array_equal(d1.view(np.uint32), d2.view(np.uint32))
@@ -167,7 +169,7 @@ def test_local_runs_equal_the_step_by_step_chain(width, noise, n_flows, n_dp):
 def test_sample_pass_equals_the_plain_sequential_form(noise, n_flows, n_dp, n_rand):
     """k_cost_rand_q -- exact early rejection after frame 0 and the priors, survivors compacted into an LDS queue, winner by a 64-bit
     atomicMin on (cost bits, sample index) -- against the plain loop over the samples in the same fast arithmetic
-    (vk_set_cost_rand_plain): IDENTICAL depth maps and rigidness maps, bit for bit, from noisy starts (most samples rejected late) to
+    (vk_debug_switch "cost_rand_plain"): IDENTICAL depth maps and rigidness maps, bit for bit, from noisy starts (most samples rejected late) to
     converged ones, with and without depth priors (identity and non-identity poses), sample counts that are not a multiple of the round."""
     from voldor_amd import kernels, synth
     sc = synth.make_scene(w=211, h=97, n_flows=n_flows, fx=100, fy=100, cx=105, cy=48, seed=29, basefocal=40.0 if n_dp else 0.0)
@@ -185,10 +187,10 @@ def test_sample_pass_equals_the_plain_sequential_form(noise, n_flows, n_dp, n_ra
                      dp_Rs=np.tile(np.eye(3, dtype=np.float32), (n_dp, 1, 1)), dp_ts=(rng.normal(0, 0.02, (n_dp, 3)) * np.arange(n_dp)[:, None]).astype(np.float32))
     over = dict(n_rand_samples=n_rand, global_prop_step=0, local_prop_width=0, fb_smooth=0, basefocal=40.0 if n_dp else 0.0, disp_delta=1.0 if n_dp else -1.0)
     try:
-        kernels.set_cost_rand_plain(True)
+        hooks.set_cost_rand_plain(True)
         d1, r1, c1 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
     finally:
-        kernels.set_cost_rand_plain(False)
+        hooks.set_cost_rand_plain(False)
     d2, r2, c2 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
     assert np.mean(d1 != depth) > (0.05 if noise >= 0.1 else 0.0)  # samples were accepted
     np.testing.assert_array_equal(d1.view(np.uint32), d2.view(np.uint32))
@@ -198,7 +200,7 @@ def test_sample_pass_equals_the_plain_sequential_form(noise, n_flows, n_dp, n_ra
 @pytest.mark.parametrize("step,noise,n_flows,n_dp", [(8, 0.3, 5, 0), (2, 0.3, 4, 0), (5, 0.1, 8, 1), (8, 0.2, 10, 0), (3, 0.2, 13, 2), (8, 0.05, 16, 0), (7, 0.3, 1, 0)])
 def test_global_split_equals_one_lane_per_site(step, noise, n_flows, n_dp):
     """The global-propagation passes with a site evaluated by a group of lanes (k_global_prop_split_lean, the default) against one lane
-    per site (vk_set_global_split(0)): identical depth / rigidness maps, bit for bit, for every way the frames and depth priors fall
+    per site (vk_debug_switch "global_split"(0)): identical depth / rigidness maps, bit for bit, for every way the frames and depth priors fall
     onto the lanes of a group (4 lanes up to 8 frames, 8 beyond)."""
     from voldor_amd import kernels, synth
     sc = synth.make_scene(w=211, h=97, n_flows=n_flows, fx=100, fy=100, cx=105, cy=48, seed=23, basefocal=40.0 if n_dp else 0.0)
@@ -214,10 +216,10 @@ def test_global_split_equals_one_lane_per_site(step, noise, n_flows, n_dp):
                      dp_Rs=np.tile(np.eye(3, dtype=np.float32), (n_dp, 1, 1)), dp_ts=(rng.normal(0, 0.02, (n_dp, 3)) * np.arange(n_dp)[:, None]).astype(np.float32))
     over = dict(n_rand_samples=2, global_prop_step=step, local_prop_width=0, fb_smooth=0, basefocal=40.0 if n_dp else 0.0, disp_delta=1.0 if n_dp else -1.0)
     try:
-        kernels.set_global_split(False)
+        hooks.set_global_split(False)
         d1, r1, c1 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
     finally:
-        kernels.set_global_split(True)
+        hooks.set_global_split(True)
     d2, r2, c2 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
     assert np.mean(d1 != depth) > 0.01  # the passes did replace depths
     np.testing.assert_array_equal(d1.view(np.uint32), d2.view(np.uint32))
@@ -234,10 +236,10 @@ def test_local_runs_with_the_tiled_table_equal_the_step_by_step_chain():
     flows, Rs, ts, depth, rig = _state(sc, rng, noise=0.2)
     over = dict(n_rand_samples=2, global_prop_step=8, local_prop_width=32, fb_smooth=0)
     try:
-        kernels.set_local_serial(True)
+        hooks.set_local_serial(True)
         d1, r1, _ = _gpu_only(flows, Rs, ts, depth, rig, K, **over)
     finally:
-        kernels.set_local_serial(False)
+        hooks.set_local_serial(False)
     d2, r2, _ = _gpu_only(flows, Rs, ts, depth, rig, K, **over)
     assert np.mean(d1 != depth) > 0.05
     np.testing.assert_array_equal(d1.view(np.uint32), d2.view(np.uint32))
@@ -414,7 +416,7 @@ def test_pipeline_mode_kernel_matches_oracle(orc, small_scene, active, n):
     init = np.zeros(6, np.float32)
     for ext in (True, False):
         om, oc, oi = orc.meanshift(pool, var, init, ext)
-        g = kernels.pose_mode_pool(rv, tv, init, use_external_init_mean=ext, refit=False, kernel_var=var, rvec_scale=rs)
+        g = hooks.pose_mode_pool(rv, tv, init, use_external_init_mean=ext, refit=False, kernel_var=var, rvec_scale=rs)
         assert g["success"] == 1 and g["sample_count"] == fin.sum()
         gm = np.concatenate([g["pose6"][:3] * rs, g["pose6"][3:]])
         assert np.abs(om - gm).max() < 2e-4, (ext, om, gm)
@@ -422,7 +424,7 @@ def test_pipeline_mode_kernel_matches_oracle(orc, small_scene, active, n):
         assert not g["covar"].any()
     cov0 = (np.eye(6) * var * sc * sc).astype(np.float32)
     orc_rc, omean, ocov, odens, oit = orc.fit_robust_gaussian(pool * sc, om * sc, cov0)
-    g = kernels.pose_mode_pool(rv, tv, init, use_external_init_mean=False, refit=True, kernel_var=var, rvec_scale=rs, rg_pose_scaling=sc)
+    g = hooks.pose_mode_pool(rv, tv, init, use_external_init_mean=False, refit=True, kernel_var=var, rvec_scale=rs, rg_pose_scaling=sc)
     assert orc_rc == 0 and g["success"] == 1
     gmean = np.concatenate([g["pose6"][:3] * rs, g["pose6"][3:]]) * sc
     unit = np.array([rs] * 3 + [1.0] * 3)
@@ -435,7 +437,7 @@ def test_pipeline_mode_kernel_matches_oracle(orc, small_scene, active, n):
 
 @pytest.mark.parametrize("active,n", [(1, 8192), (2, 8192), (0, 5000)])
 def test_refit_partition_changes_no_sum(orc, small_scene, active, n):
-    """vk_set_refit_partition: with the pool re-dealt by distance a gate pass leaves out samples whose weight is exactly 0, so every sum has
+    """vk_debug_switch "refit_partition": with the pool re-dealt by distance a gate pass leaves out samples whose weight is exactly 0, so every sum has
     the same terms in another order.  Both forms must therefore agree to the rounding of a 28-value float reduction over <= 8192 terms
     (the gate is hard: a sample within that rounding of the 3-sigma surface may fall on the other side, which moves the fit by one
     sample in a few thousand)."""
@@ -445,13 +447,13 @@ def test_refit_partition_changes_no_sum(orc, small_scene, active, n):
     out = {}
     try:
         for part in (1, 0):
-            kernels.set_refit_partition(bool(part))
-            out[part] = kernels.pose_mode_pool(rv, tv, init, use_external_init_mean=False, refit=True, kernel_var=0.2, rvec_scale=25.0)
-            again = kernels.pose_mode_pool(rv, tv, init, use_external_init_mean=False, refit=True, kernel_var=0.2, rvec_scale=25.0)
+            hooks.set_refit_partition(bool(part))
+            out[part] = hooks.pose_mode_pool(rv, tv, init, use_external_init_mean=False, refit=True, kernel_var=0.2, rvec_scale=25.0)
+            again = hooks.pose_mode_pool(rv, tv, init, use_external_init_mean=False, refit=True, kernel_var=0.2, rvec_scale=25.0)
             for k in ("pose6", "covar"):
                 np.testing.assert_array_equal(out[part][k], again[k])  # either form is the same from run to run
     finally:
-        kernels.set_refit_partition(True)
+        hooks.set_refit_partition(True)
     a, b = out[1], out[0]
     assert a["success"] == b["success"] == 1 and a["sample_count"] == b["sample_count"] and a["ms_iters"] == b["ms_iters"]
     # measured on these pools: pose 1.5e-8, covariance 3e-7 relative, the same iteration count and density
@@ -527,7 +529,7 @@ def test_fb_smooth_alone_matches_oracle(orc, w, h):
 
 @pytest.mark.parametrize("w,h", [(640, 480), (1241, 376), (333, 777)])
 def test_fb_smooth_segment_lengths_agree(orc, w, h):
-    """vk_set_fb_segment: the 20- and 40-step segmentations of the fast fb_smooth (chosen by image size, fb_smooth_device) are the same
+    """vk_debug_switch "fb_segment": the 20- and 40-step segmentations of the fast fb_smooth (chosen by image size, fb_smooth_device) are the same
     recurrence cut differently; each stays within the stage tolerance of the oracle and they agree with each other to rounding."""
     from voldor_amd import kernels
     rng = np.random.default_rng(w + 7 * h)
@@ -537,16 +539,16 @@ def test_fb_smooth_segment_lengths_agree(orc, w, h):
     out = {}
     try:
         for seg in (20, 40):
-            kernels.set_fb_segment(seg)
+            hooks.set_fb_segment(seg)
             rc, out[seg] = kernels.fb_smooth_gpu(maps, 0.5, 0.9)
             assert rc == 0 and np.isfinite(out[seg]).all()
             assert np.abs(o - out[seg]).max() < 2e-5, seg
     finally:
-        kernels.set_fb_segment(0)
+        hooks.set_fb_segment(0)
     assert np.abs(out[20] - out[40]).max() < 1e-5
     assert not np.array_equal(out[20], out[40]) or w * h < 1000  # the switch really changes the launch
     with pytest.raises(Exception):
-        kernels.set_fb_segment(30)
+        hooks.set_fb_segment(30)
 
 
 @pytest.mark.parametrize("with_priors,n_rand", [(False, 10), (True, 10), (False, 23), (False, 3), (False, 0)])

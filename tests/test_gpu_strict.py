@@ -185,6 +185,100 @@ def test_strict_baseline_cfg2_window_bits(orc, strict):
     _assert_window_bits(o, g)
 
 
+# ---- round 4: strict arithmetic on the parallel launch structures == strict arithmetic on the plain ones -------------------------
+def _plain_vs_parallel(run):
+    """run() once on the parallel structures (default) and once with vk_debug_switch "strict_plain" = 1 (rounds 1-3: one lane per chain /
+    line / site, every sample in full, one 256-thread workgroup walking the sum tree block by block)."""
+    import hooks
+    from voldor_amd import kernels
+    out = {}
+    try:
+        for plain in (0, 1):
+            hooks.set_strict_plain(plain)
+            kernels.set_rand_epoch(0)
+            out[plain] = run()
+    finally:
+        hooks.set_strict_plain(0)
+    return out[0], out[1]
+
+
+@pytest.mark.parametrize("name", ["mono_320x240", "stereo_priors", "truncated", "refit_every_iteration", "ap3p", "cfg2", "wide_1241", "odd_323x241"])
+def test_strict_parallel_structures_equal_the_plain_ones(strict, name):
+    """strict mode now runs on the fast launch structures -- survivor queue with an exact rejection bound in the
+    reference's own rounding (k_cost_rand_q_strict), lanes per site (k_global_prop_split_lean<.,.,true>), table + planned runs with the
+    lane-split strict evaluation (k_local_runs_lean<.,.,.,true>), chunked fb_smooth lines, and the reference's 512-wide float tree as the
+    XOR butterfly it is (k_pose_strict_par) -- and must give the bits of the plain structures in every output of a window: registered
+    count, depth map, confidence map, poses, covariances, per-camera iteration counts and densities."""
+    from voldor_amd import pyvoldor, synth
+    mono = "--silent --meanshift_kernel_var 0.2 --delta 1.5 --strict_math 1"
+    kw = {}
+    if name == "cfg2":
+        sc = synth.make_scene(w=640, h=480, n_flows=5, fx=320, fy=320, cx=320, cy=240, seed=233); cfg = mono + " --max_iters 8"
+    elif name == "wide_1241":  # the separate table kernel (> 400k pixels), 8 frames, a disparity prior at the identity pose
+        sc = synth.make_scene(w=1241, h=376, n_flows=8, fx=718.856, fy=718.856, cx=607.19, cy=185.22, seed=501, basefocal=386.1)
+        cfg = "--silent --meanshift_kernel_var 0.1 --disp_delta 1 --delta 0.2 --max_iters 2 --strict_math 1"; kw = dict(basefocal=386.1, disparity=sc["disparity"])
+    elif name == "odd_323x241":  # ragged chunks of the fb_smooth lines, partial tiles, partial chains
+        sc = synth.make_scene(w=323, h=241, n_flows=3, fx=160, fy=160, cx=160, cy=120, seed=21); cfg = mono + " --max_iters 3"
+    else:
+        sc = synth.make_scene(w=320, h=240, n_flows=5 if name == "truncated" else 4, fx=160, fy=160, cx=160, cy=120, seed=dict(mono_320x240=11, stereo_priors=16, truncated=17, refit_every_iteration=15, ap3p=13)[name])
+        cfg = mono + " --max_iters 3"
+        if name == "stereo_priors":
+            rng = np.random.default_rng(2)
+            h, w = sc["depth_gt"].shape
+            kw = dict(depth_priors=(sc["depth_gt"][None] * (1 + rng.normal(0, 0.03, (2, h, w)))).astype(np.float32),
+                      depth_prior_poses=np.array([[0.002, -0.001, 0.0005, 0.01, 0.0, -0.02], [0, 0, 0, 0, 0, 0]], np.float32),
+                      depth_prior_pconfs=rng.uniform(0.3, 1.0, (2, h, w)).astype(np.float32))
+            cfg = "--silent --meanshift_kernel_var 0.1 --delta 0.5 --max_iters 3 --strict_math 1"
+        elif name == "truncated":
+            fl = sc["flows"].copy()
+            fl[3:] = np.random.default_rng(4).uniform(-25, 25, fl[3:].shape).astype(np.float32)
+            sc = dict(sc, flows=fl); cfg = mono + " --max_iters 5"
+        elif name == "refit_every_iteration":
+            cfg += " --rg_refine_last_only 0"
+        elif name == "ap3p":
+            cfg += " --lambdatwist 0"
+    fx, fy, cx, cy = sc["K"]
+
+    def run():
+        o = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config=cfg, **kw)
+        o["stats"] = pyvoldor.last_camera_stats(sc["flows"].shape[0]) if hasattr(pyvoldor, "last_camera_stats") else None
+        return o
+    a, b = _plain_vs_parallel(run)
+    assert a["n_registered"] == b["n_registered"]
+    for k in ("depth", "depth_conf", "poses", "poses_covar"):
+        assert_bits(a[k], b[k], f"{name}: {k}")
+    if a["stats"] is not None:
+        for k in a["stats"]:
+            np.testing.assert_array_equal(np.asarray(a["stats"][k]), np.asarray(b["stats"][k]), err_msg=f"{name}: {k}")
+
+
+@pytest.mark.parametrize("n,nan_every,refit", [(8192, 0, True), (8192, 37, True), (8192, 3, False), (5000, 11, True), (700, 0, True), (500, 7, True), (6, 2, False), (1, 0, False), (2, 0, True)])
+def test_strict_mode_kernel_parallel_tree_equals_the_block_walk(orc, small_scene, strict, n, nan_every, refit):
+    """The strict mode kernel alone (vk_pose_mode_pool under strict math): k_pose_strict_par -- wave w owns blocks 2w, 2w+1 of the reference's
+    512-row reduction, rows dealt to the lanes in bit-reversed order so that one transposing wave reduction IS strides 32 .. 1 of
+    reduce_vector_sum.h:12-61 -- against k_pose_strict, which walks the blocks one after the other.  Pools of every shape the tree
+    distinguishes: full (16 blocks), a partial last block, a pool inside one block (no second level), two rows, ONE row (the reference's
+    loop does not run), NaN hypotheses anywhere (ordered compaction); with and without the refit; external and sampled start."""
+    import hooks
+    import test_gpu_kernels as tk
+    rv, tv = tk._pose_pool(orc, small_scene, 1, max(n, 8))
+    rv, tv = rv[:n].copy(), tv[:n].copy()
+    fin = np.isfinite(rv.sum(1) + tv.sum(1))
+    rv[~fin] = 0.01; tv[~fin] = 0.02  # start from an all-finite pool, then plant the NaNs
+    if nan_every:
+        rv[::nan_every] = np.nan
+        if n > 1:
+            rv[0] = 0.01  # (keep one finite row in any case)
+    init = np.array([0.01, -0.005, 0.002, 0.1, -0.2, 0.9], np.float32)
+    for ext in (True, False):
+        def run():
+            return hooks.pose_mode_pool(rv, tv, init, use_external_init_mean=ext, refit=refit, kernel_var=0.2, rvec_scale=25.0)
+        a, b = _plain_vs_parallel(run)
+        assert a["success"] == b["success"] and a["sample_count"] == b["sample_count"] == int(np.isfinite(rv.sum(1) + tv.sum(1)).sum())
+        assert a["ms_iters"] == b["ms_iters"] and a["gu_iters"] == b["gu_iters"], (a["ms_iters"], b["ms_iters"], a["gu_iters"], b["gu_iters"])
+        assert_bits(a["pose6"], b["pose6"], "pose"); assert_bits(a["covar"], b["covar"], "covar"); assert_bits(np.float32(a["density"]), np.float32(b["density"]), "density")
+
+
 # ---- the low-density regime (VERDICT r1 item 2) ---------------------------------------------------------------------------------
 def test_low_density_window_keeps_the_reference_pool(orc, strict):
     """~1 % valid correspondences for camera 0, a few dozen pixels for camera 1 (tests/ref_window_cases.py low_density): the
@@ -237,12 +331,12 @@ VARIANTS = [  # (config suffix, estimator noise comparable to the default config
 def test_config_variants_fast_vs_strict():
     """Configurations that switch the fast pipeline onto its alternative kernels, each against the strict pipeline on the same
     window (same draws).  Registered counts equal; the pose distances of the variants whose estimator is as noisy as the default one
-    are RANKED inside the reference's own self-distances on this window (tests/golden/ref_window_noise.npz: the reference under eight
-    independent 1-ulp jitter patterns vs its glibc run) -- rank-sum test over the variants, p > 0.01, no tolerance; every variant
-    additionally stays within 10x the largest reference self-distance (a wrong code path loses the window or is off by orders of
-    magnitude)."""
+    are held to the reference's own self-distances on this window (tests/golden/ref_window_noise.npz: the reference under eight
+    independent 1-ulp jitter patterns vs its glibc run): every such variant within 2x the LARGEST of them and the median over the variants
+    within the largest -- plain bounds: all variants run on ONE window and share ONE reference sample, so a rank-sum over them (round 3)
+    assumed an independence that is not there; every variant additionally stays within 10x the largest reference
+    self-distance (a wrong code path loses the window or is off by orders of magnitude)."""
     import ref_window_cases as cases
-    import stat_helpers as sh
     from voldor_amd import kernels, pyvoldor, synth
     noise = np.load(os.path.join(os.path.dirname(__file__), "golden", "ref_window_noise.npz"))
     name = "mono_320x240"
@@ -262,7 +356,7 @@ def test_config_variants_fast_vs_strict():
         assert rot.max() <= 10 * max(ref_rot) and tr.max() <= 10 * max(ref_tr), (extra, rot.max(), tr.max())
         if comparable:
             rots.append(rot.max()); trs.append(tr.max())
-    p_rot = sh.rank_sum_pvalue(rots, [ref_rot] * len(rots)); p_tr = sh.rank_sum_pvalue(trs, [ref_tr] * len(trs))
-    print(f"fast vs strict over {len(rots)} variants: rot median {np.median(rots):.2e} (reference self-distance {np.median(ref_rot):.2e}) p = {p_rot:.3f}; "
-          f"trans {np.median(trs):.2e} ({np.median(ref_tr):.2e}) p = {p_tr:.3f}")
-    assert p_rot > 0.01 and p_tr > 0.01, (p_rot, p_tr, rots, trs)
+    print(f"fast vs strict over {len(rots)} variants: rot median {np.median(rots):.2e} max {max(rots):.2e} (reference self-distance median {np.median(ref_rot):.2e} max {max(ref_rot):.2e}); "
+          f"trans median {np.median(trs):.2e} max {max(trs):.2e} ({np.median(ref_tr):.2e} / {max(ref_tr):.2e})")
+    assert max(rots) <= 2 * max(ref_rot) and max(trs) <= 2 * max(ref_tr), (rots, trs, max(ref_rot), max(ref_tr))
+    assert np.median(rots) <= max(ref_rot) and np.median(trs) <= max(ref_tr), (np.median(rots), np.median(trs))

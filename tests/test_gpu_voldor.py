@@ -24,6 +24,8 @@ import os
 import numpy as np
 import pytest
 
+import hooks
+
 pytestmark = pytest.mark.gpu
 
 
@@ -73,7 +75,7 @@ def test_mono_window_tight_with_identical_draws(orc, cfg, rot_tol, tr_tol):
 
 def test_split_trials_equal_in_kernel_trials():
     """First EM iteration, cameras without a pose: the 20 initial-mode trials evaluated by k_mode_trials (one workgroup each) against
-    the same trials evaluated inside the mode kernel (vk_set_split_trials(0)).  Same picks, same better-than / good-enough rule; only
+    the same trials evaluated inside the mode kernel (vk_debug_switch "split_trials"(0)).  Same picks, same better-than / good-enough rule; only
     the summation order of a density differs, so the chosen start -- and with it every pose -- is the same unless two of the 20
     densities tie to ~1e-7."""
     from voldor_amd import pyvoldor, synth, kernels
@@ -83,11 +85,11 @@ def test_split_trials_equal_in_kernel_trials():
     out = []
     try:
         for on in (True, False):
-            kernels.set_split_trials(on)
+            hooks.set_split_trials(on)
             kernels.set_rand_epoch(0)
             out.append(pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config=cfgs))
     finally:
-        kernels.set_split_trials(True)
+        hooks.set_split_trials(True)
     assert out[0]["n_registered"] == out[1]["n_registered"] == 5
     assert pyvoldor.last_camera_stats(5)["ms_iters"] is not None
     np.testing.assert_allclose(out[0]["poses"], out[1]["poses"], rtol=0, atol=2e-6)

@@ -113,6 +113,35 @@ bool reference_svd_default() {
     return g_reference_svd != 0;
 }
 
+static DebugSwitches g_debug;
+extern "C" int vk_debug_switch(const char* name, int value);
+DebugSwitches& debug_switches() {
+    static const bool from_env = [] {  // VOLDOR_HIP_DEBUG="name=value,name=value": the switches of vk_debug.h for a whole process (A/B runs of the test suite)
+        const char* e = getenv("VOLDOR_HIP_DEBUG");
+        if (e) {
+            std::string s(e);
+            size_t pos = 0;
+            while (pos < s.size()) {
+                const size_t end = s.find(',', pos), eq = s.find('=', pos);
+                const size_t stop = end == std::string::npos ? s.size() : end;
+                if (eq != std::string::npos && eq < stop) {
+                    const std::string k = s.substr(pos, eq - pos), v = s.substr(eq + 1, stop - eq - 1);
+                    struct { const char* n; int* p; } tab[] = { { "local_serial", &g_debug.local_serial }, { "cost_rand_plain", &g_debug.cost_rand_plain }, { "fb_segment", &g_debug.fb_segment },
+                        { "global_split", &g_debug.global_split }, { "refit_partition", &g_debug.refit_partition }, { "split_trials", &g_debug.split_trials },
+                        { "strict_plain", &g_debug.strict_plain }, { "newton_cap", &g_debug.newton_cap }, { "strict_own_table", &g_debug.strict_own_table }, { "strict_lpp8", &g_debug.strict_lpp8 } };
+                    bool known = false;
+                    for (auto& t : tab) if (k == t.n) { *t.p = atoi(v.c_str()); known = true; }
+                    if (!known) fprintf(stderr, "voldor_hip: VOLDOR_HIP_DEBUG: unknown switch '%s'\n", k.c_str());
+                }
+                pos = stop + 1;
+            }
+        }
+        return true;
+    }();
+    (void)from_env;
+    return g_debug;
+}
+
 int prof_begin(Context* c) { return (int)hipEventRecord(c->ev0, c->stream); }
 int prof_end(Context* c, const char* name) {
     VK_CHECK(hipEventRecord(c->ev1, c->stream));
@@ -317,7 +346,28 @@ int meanshift_gpu(float* h_space, float kernel_var, float* h_io_mean, float* h_o
     return 0;
 }
 
-// Verification entry (include/voldor_hip.h): the mode kernel of the WINDOW PIPELINE -- k_pose_mode<REFIT,512>, the packed-pair mean shift
+// The ONE entry of the verification switches (vk_debug.h; not in include/voldor_hip.h): returns the previous value, -1 for an unknown
+// name or a value the switch does not take.
+extern "C" __attribute__((visibility("default"))) int vk_debug_switch(const char* name, int value) {
+    using namespace vk;
+    if (!name) return -1;
+    DebugSwitches& d = debug_switches();
+    struct { const char* n; int* p; } tab[] = { { "local_serial", &d.local_serial }, { "cost_rand_plain", &d.cost_rand_plain }, { "fb_segment", &d.fb_segment },
+        { "global_split", &d.global_split }, { "refit_partition", &d.refit_partition }, { "split_trials", &d.split_trials }, { "strict_plain", &d.strict_plain }, { "newton_cap", &d.newton_cap },
+        { "strict_own_table", &d.strict_own_table }, { "strict_lpp8", &d.strict_lpp8 } };
+    for (auto& t : tab)
+        if (strcmp(t.n, name) == 0) {
+            if (t.p == &d.fb_segment) { if (value != 0 && value != 20 && value != 40) return -1; }
+            else if (t.p == &d.newton_cap) { if (value < 0 || value > 50 || (value & 1)) return -1; }
+            else value = value ? 1 : 0;
+            const int old = *t.p;
+            *t.p = value;
+            return old;
+        }
+    return -1;
+}
+
+// Verification entry (vk_debug.h): the mode kernel of the WINDOW PIPELINE -- k_pose_mode<REFIT,512>, the packed-pair mean shift
 // and, with do_rg, the whitened / distance-partitioned refit on the same registers -- run on a caller-supplied pool of hypotheses, so
 // that the kernels the timed path uses can be held against the oracle stage by stage (the host-pointer meanshift_gpu /
 // fit_robust_gaussian above are different, generic-dimension kernels).  h_rvecs / h_tvecs: [n_poses][3] (non-finite = dropped, as
@@ -352,7 +402,9 @@ extern "C" __attribute__((visibility("default"))) int vk_pose_mode_pool(const fl
     mp.ms_good_init_confidence = ms_good_init_confidence; mp.use_external_init_mean = use_external_init_mean ? 1 : 0;
     mp.rvec_scale = rvec_scale; mp.rg_pose_scaling = rg_pose_scaling; mp.do_rg = do_rg ? 1 : 0; mp.rg_trunc_sigma = rg_trunc_sigma;
     mp.rg_covar_reg_lambda = rg_covar_reg_lambda; mp.rg_epsilon = rg_epsilon; mp.rg_max_iters = rg_max_iters;
-    if (int e = pose_mode_device(c, n_poses, mp, c->cams.as<CamState>(), c->od.pb(), 0, !use_external_init_mean)) return e;
+    if (strict_math_default()) {  // the strict mode kernel of the window pipeline (k_pose_strict_par, or k_pose_strict with the "strict_plain" switch)
+        if (int e = pose_mode_strict_device(c, n_poses, mp, c->cams.as<CamState>(), c->od.pb(), 0)) return e;
+    } else if (int e = pose_mode_device(c, n_poses, mp, c->cams.as<CamState>(), c->od.pb(), 0, !use_external_init_mean)) return e;
     VK_CHECK(hipMemcpyAsync(&cam, c->cams.p, sizeof cam, hipMemcpyDeviceToHost, c->stream));
     VK_CHECK(hipStreamSynchronize(c->stream));
     for (int d = 0; d < 3; d++) { io_pose6[d] = cam.rvec[d]; io_pose6[3 + d] = cam.t[d]; }

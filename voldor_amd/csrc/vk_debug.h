@@ -1,0 +1,38 @@
+/* voldor_amd/csrc/vk_debug.h -- verification entry points of libvoldor_hip.so.  NOT part of the product C-ABI (include/voldor_hip.h):
+ * nothing a caller of the library needs, only what the test suite uses to hold each launch structure of the pipeline against its plain
+ * form (tests/hooks.py binds them).  The switches are one plain struct inside the library (vk_internal.hpp DebugSwitches), written
+ * between calls by the one thread that drives the library. */
+#ifndef VK_DEBUG_H
+#define VK_DEBUG_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+/* name / values (default first):
+ *   "local_serial"    0 | 1   fast mode: local propagation step by step, one lane per chain (optimize_depth.cu:320-396 order), instead of table + planned runs
+ *   "cost_rand_plain" 0 | 1   the sample pass evaluates every random depth in full, one after the other (optimize_depth.cu:269-284), instead of exact
+ *                             early rejection + survivor queue -- fast AND strict arithmetic
+ *   "fb_segment"      0 | 20 | 40   steps per lane of the segmented fb_smooth of the fast mode (0: by image size)
+ *   "global_split"    1 | 0   0: global propagation with one lane per site instead of a group of lanes
+ *   "refit_partition" 1 | 0   0: every gate pass of the refit walks the whole pool in arrival order
+ *   "split_trials"    1 | 0   0: the mode kernel evaluates the initial-mode trials itself instead of one workgroup per trial
+ *   "strict_plain"    0 | 1   1: strict mode on the plain launch structures (one lane per chain / line, one 256-thread workgroup walking the
+ *                             reference's sum tree block by block) instead of the parallel structures -- both give the same bits
+ *   "newton_cap"      0 | even <= 50   Newton steps of the P3P cubic in the fast window pipeline (0 = the reference's 50).  A cap of 12 saves 0.13 ms of a
+ *                             3.9 ms window and was NOT adopted: over 72 windows it halves the fraction of confident pixels within 1e-3 of the reference
+ *                             (0.32 against the reference's own 0.64) -- the ~1.4 % of cubics that are still moving after 12 steps re-draw the pool
+ * Returns the previous value, -1 for an unknown name / value. */
+int vk_debug_switch(const char* name, int value);
+/* The mode kernel of the window pipeline (k_pose_mode: packed-pair mean shift; with do_rg the robust-Gaussian refit on the same registers --
+ * geometry.cpp:156-263, meanshift.cu:34-150, fit_robust_gaussian.cu:131-263) on a caller-supplied pool of pose hypotheses, so that the kernels
+ * of the timed path can be held against the oracle stage by stage.  h_rvecs / h_tvecs: [n_poses][3], n_poses <= 8192, a non-finite
+ * hypothesis is dropped; io_pose6: rvec and t of the starting pose in (used when use_external_init_mean), the estimate out; o_covar36: the
+ * camera record's covariance (zeros unless the refit ran and was reliable).  With the process-wide strict mode on (vk_set_strict_math) the
+ * strict-math mode kernel runs instead.  Nonzero on a device error. */
+int vk_pose_mode_pool(const float* h_rvecs, const float* h_tvecs, int n_poses, int use_external_init_mean, float* io_pose6,
+                      float kernel_var, float rvec_scale, float ms_epsilon, int ms_max_iters, int ms_max_init_trials, float ms_good_init_confidence,
+                      int do_rg, float rg_trunc_sigma, float rg_covar_reg_lambda, float rg_epsilon, int rg_max_iters, float rg_pose_scaling,
+                      float* o_covar36, float* o_density, int* o_sample_count, int* o_ms_iters, int* o_gu_iters, int* o_success);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -13,7 +13,6 @@
 //   update_rigidness            1 launch (+ per-block rigidness sums for the density test)
 // Every per-pixel kernel clamps its frame count to PoseBlock::n_active (device-side truncation decision) and
 // remaps its workgroup id so that an XCD works on one band of the image (xcd_band_tile).
-#include <atomic>
 #include "vk_common.hpp"
 #include "vk_device.hpp"
 #include "vk_strict_model.hpp"
@@ -22,10 +21,6 @@
 
 namespace vk {
 
-static std::atomic<int> g_local_serial{0};  // vk_set_local_serial (verification aid)
-static std::atomic<int> g_cost_rand_plain{0};  // vk_set_cost_rand_plain (verification aid): 1 = every random sample evaluated in full, one after the other
-static std::atomic<int> g_fb_segment{0};   // vk_set_fb_segment: 0 = by size (fb_smooth_device), 20 / 40 = that many steps per lane where the line fits
-static std::atomic<int> g_global_split{1};  // vk_set_global_split (verification aid): 0 = one lane per site (k_global_prop_sites_lean)
 
 // phase clocks (profiling builds only, scripts/phase_clocks.sh): thread 0 of the middle workgroup of a launch
 #ifdef VK_PHASE_CLOCKS
@@ -494,6 +489,12 @@ __device__ __forceinline__ static float pixel_cost_lean(const Img& I, const Lean
     return lean_final(cs, ws);
 }
 
+// one arithmetic switch for the kernels that exist in both modes
+template <int NMAX, bool STRICT>
+__device__ __forceinline__ static float pixel_cost_any(const Img& I, const LeanK& K, int px, int py, float depth) {
+    if constexpr (STRICT) return pixel_cost_strict<NMAX>(I, px, py, depth); else return pixel_cost_lean<NMAX>(I, K, px, py, depth);
+}
+
 // ---- cost map + random samples with EXACT EARLY REJECTION and SURVIVOR COMPACTION ---------------------------------------------------
 // (a) The cost is sum(w_f c_f) / sum(w_f) over the contributing frames with every c_f >= 0, so after the part that needs no divergent
 // gather (lean_head: frame 0 and the depth priors) the final cost is at least cs / (ws + wrest), wrest = the weight frames 1.. can
@@ -638,7 +639,7 @@ __global__ __launch_bounds__(256) static void k_global_prop_sites_lean(Img I, in
     else if (dir == 1) { int y = 1 + s * step; try_depth_lean<NMAX>(I, K, l, y, I.depth[(y - 1) * I.w + l]); }
     else { int y = I.h - 2 - s * step; try_depth_lean<NMAX>(I, K, l, y, I.depth[(y + 1) * I.w + l]); }
 }
-template <int NMAX>
+template <int NMAX, bool STRICT = false>
 __global__ __launch_bounds__(256) static void k_local_table_lean(Img I, int dir, int width, float* __restrict__ tbl) {
     if (!clamp_active(I)) return;
     const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
@@ -651,7 +652,7 @@ __global__ __launch_bounds__(256) static void k_local_table_lean(Img I, int dir,
     else if (dir == 1) { member = y >= 1 && (y % width) != 0; nb = (y - 1) * w + x; }
     else { member = y <= h - 2 && (y % width) != width - 1; nb = (y + 1) * w + x; }
     if (!member) return;
-    tbl[y * w + x] = pixel_cost_lean<NMAX>(I, lean_consts(I), x, y, I.depth[nb]);
+    tbl[y * w + x] = pixel_cost_any<NMAX, STRICT>(I, lean_consts(I), x, y, I.depth[nb]);
 }
 // Lane-split evaluation for k_local_runs_lean: LPP (4 or 8) lanes per pixel, lane g owns frames g, g+LPP, .. and priors g, g+LPP, ..  Every lane walks
 // the (cheap) chain of positions, evaluates the gathers and residuals of its own frames, and the terms are combined in exactly the order
@@ -741,11 +742,246 @@ __device__ __forceinline__ static float cost_split_lean(const Img& I, const Lean
     cs = fmaf(0.6931471805599453f, cl, cs);
     return lean_final(cs, ws);
 }
+
+// ---- STRICT arithmetic on the fast launch structures (round 4) -----------------------------------------------------------------------
+// The identity tests of the fast kernels (survivor queue vs plain loop, planned runs vs step-by-step chain, lanes per site vs one lane)
+// show that those STRUCTURES change no result; what separates a fast kernel from a strict one is arithmetic only.  So strict mode runs
+// on the same structures with pixel_cost_strict's operation sequence: 22 of the 100 ms of a strict cfg2 window were one lane per
+// 31-step chain each evaluating 5 frames x 7 software transcendentals in fp64 one after the other (k_local_serial<., true>).
+// Lane-split form of pixel_cost_strict: every lane of the group walks the rigid chain (the un-fused reference geometry), lane g owns
+// frames g, g + LPP, .. and priors g, g + LPP, ..: gathers, strict::rigidness and the product weight * logf(rigidness) (the rounded
+// product cost_acc subtracts); the group then replays cost_sum - term / wsum + weight in the order of pixel_cost_strict: frames, then
+// priors.  Same bits as the one-lane evaluation.
+__device__ __forceinline__ static bool prior_parts_strict(const Img& I, const PoseBlock* P, int f, int px, int py, float depth, float& wg, float& term) {
+#pragma clang fp contract(off)
+    const int w = I.w, h = I.h, npx = w * h;
+    wg = 0.f; term = 0.f;
+    P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
+    float qx2, qy2;
+    project(P, q, qx2, qy2);
+    if (!(q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h)) return false;
+    const float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+    if (!(td > 0.f)) return false;
+    const float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
+    const float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
+    wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
+    term = wg * vsm_logf(strict::depth_rigidness(q.z, td, I.basefocal, I.omega, I.arf));  // the product cost_acc subtracts (fun_depth_cost, residual_model.h:64-68)
+    return true;
+}
+template <int NMAX, int LPP>
+__device__ __forceinline__ static float cost_split_strict(const Img& I, int px, int py, float depth, int g) {
+#pragma clang fp contract(off)
+    constexpr int S = (NMAX + LPP - 1) / LPP;
+    const int w = I.w, h = I.h, npx = w * h, pi = py * w + px;
+    const PoseBlock* P = I.P;
+    float qx[S], qy[S], rdx[S], rdy[S];
+    bool vv[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) { qx[k] = 0.f; qy[k] = 0.f; rdx[k] = 0.f; rdy[k] = 0.f; vv[k] = false; }
+    {
+        P3 o = backproject(P, (float)px, (float)py, depth);
+        float px1 = (float)px, py1 = (float)py;
+#pragma unroll
+        for (int f = 0; f < NMAX; f++) {
+            if (f < I.N) {
+                o = transform(P->Rs[f], P->ts[f], o);
+                float px2, py2;
+                project(P, o, px2, py2);
+                const bool valid = o.z > 0.f && px1 >= 0.f && px1 < (float)w && py1 >= 0.f && py1 < (float)h;
+                const bool mine = f % LPP == g;
+                vv[f / LPP] = mine ? valid : vv[f / LPP]; qx[f / LPP] = (mine && valid) ? px1 : qx[f / LPP]; qy[f / LPP] = (mine && valid) ? py1 : qy[f / LPP];
+                rdx[f / LPP] = (mine && valid) ? px2 - px1 : rdx[f / LPP]; rdy[f / LPP] = (mine && valid) ? py2 - py1 : rdy[f / LPP];
+                px1 = valid ? px2 : px1; py1 = valid ? py2 : py1;  // advances on contributing frames only (:162-164)
+            }
+        }
+    }
+    float tm[S], wt[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) {
+        const int f = g + LPP * k, fl = f < I.N ? f : 0;
+        const float2 ob = (f == 0) ? I.flows[pi] : bilinear2(I.flows + (size_t)fl * npx, w, h, qx[k], qy[k]);
+        wt[k] = I.rig[(size_t)fl * npx + pi];
+        tm[k] = wt[k] * vsm_logf(strict::rigidness(rdx[k], rdy[k], ob.x, ob.y, I.lambda, I.arf));
+        vv[k] = vv[k] && f < I.N;
+    }
+    float cost_sum = 0.f, wsum = 0.f;
+#pragma unroll
+    for (int f = 0; f < NMAX; f++) {
+        if (f < I.N) {
+            const bool ok = group_bcast<LPP>(vv[f / LPP], f % LPP);
+            const float t = group_bcast<LPP>(tm[f / LPP], f % LPP), wg = group_bcast<LPP>(wt[f / LPP], f % LPP);
+            if (ok) { cost_sum = cost_sum - t; wsum += wg; }
+        }
+    }
+#pragma unroll 1
+    for (int f0 = 0; f0 < I.N_dp; f0 += LPP) {
+        float pw = 0.f, pt = 0.f;
+        bool pk = false;
+        if (f0 + g < I.N_dp) pk = prior_parts_strict(I, P, f0 + g, px, py, depth, pw, pt);
+#pragma unroll
+        for (int q = 0; q < LPP; q++) {
+            const bool ok = group_bcast<LPP>(pk, q);
+            const float wg = group_bcast<LPP>(pw, q), term = group_bcast<LPP>(pt, q);
+            if (f0 + q < I.N_dp && ok) { cost_sum = cost_sum - term; wsum += wg; }
+        }
+    }
+    if (wsum == 0.f) return INFINITY;
+    return cost_sum / fmaxf(wsum, 1.1920929e-07f);
+}
+template <int NMAX, int LPP, bool STRICT>
+__device__ __forceinline__ static float cost_split_any(const Img& I, const LeanK& K, int px, int py, float depth, int g) {
+    if constexpr (STRICT) return cost_split_strict<NMAX, LPP>(I, px, py, depth, g); else return cost_split_lean<NMAX, LPP>(I, K, px, py, depth, g);
+}
+
+// The sample pass in strict arithmetic: exact PROGRESSIVE rejection over a survivor queue.  The strict cost is
+// fl(cost_sum / max(wsum, eps)) with cost_sum = ((0 - t_0) - t_1 ..) - priors.., every t = weight * logf(rigidness) <= 0 and every weight >= 0,
+// both sums taken left to right (pixel_cost_strict).  Rounded addition is monotone in each operand, so dropping terms from the numerator
+// chain can only lower it and adding terms to the denominator chain can only raise it: after frames 0 .. f of a hypothesis
+//   cost >= fl(L_f / max(U_f, eps)),  L_f = the chain over frames 0 .. f (the true prefix) and the priors,
+//                                     U_f = the chain over the contributing frames of 0 .. f, ALL of frames f+1 .. and the contributing priors
+// -- an EXACT bound in the reference's own rounding (no margin).  A sample whose bound is >= the incumbent's cost cannot win the
+// `cost < best` test (optimize_depth.cu:201-207).  A strict frame is ~1100 fp64-heavy instructions and the pass is bound by their issue,
+// so the bound is applied after EVERY frame: the samples still alive sit in an LDS queue (pixel, sample, partial sums), each stage
+// evaluates frame f of the queue's entries dense -- one entry per lane, whichever lane -- and re-compacts the survivors; a typical random
+// depth dies after one or two frames instead of N.  The chain of positions is re-walked per stage from the sample's depth (the
+// un-fused geometry, ~60 instructions per frame: the same values every time).  NaNs fail the >= and stay alive to the end.  A sample that
+// survives all frames carries exactly pixel_cost_strict's sums; the winner rule is k_cost_rand_q's (cheapest, earliest among equals).
+// Up to one depth prior rides along in the entry (its term and weight are needed at the end of the chain and in every bound); with more
+// priors the launcher takes the plain kernel.
+struct CrqsEntry { unsigned id; float cs, ws, tp, wp; };  // id = lane-in-workgroup | sample << 8 | prior contributes << 16
+template <int NMAX>
+__global__ __launch_bounds__(256) static void k_cost_rand_q_strict(Img I, int n_rand, uint32_t epoch0, float range_factor) {
+#pragma clang fp contract(off)
+    __shared__ unsigned long long s_best[256];
+    __shared__ float s_cbest[256];
+    __shared__ CrqsEntry s_q[256 * CRQ_NS];
+    __shared__ int s_qn, s_qw;
+    if (!clamp_active(I)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int x0 = (tile % gridDim.x) * 64, y0 = (tile / gridDim.x) * 4;
+    const int xi = x0 + lane, yi = y0 + (tid >> 6);
+    const bool live = xi < I.w && yi < I.h;
+    const int w = I.w, h = I.h, npx = w * h, px = live ? xi : 0, py = live ? yi : 0, pi = py * w + px;
+    const PoseBlock* P = I.P;
+    const float2 o0 = I.N > 0 ? I.flows[pi] : make_float2(0.f, 0.f);
+    const float wgt0 = I.N > 0 ? I.rig[pi] : 0.f;
+    const strict::RigObs ob0 = strict::rigidness_obs(o0.x, o0.y, I.lambda, I.arf);  // frame 0 observes at the pixel: shared by the ten samples
+    float wall = 0.f;  // weights of frames 1.. (the denominator bound of stage 0 adds them one by one: same chain as below)
+    (void)wall;
+    float d_best = I.depth[pi], c_best = pixel_cost_strict<NMAX>(I, px, py, d_best);
+    // bound of an entry whose sums stand after frame f: dead iff it cannot beat the pixel's incumbent
+    auto dead_after = [&](int epi, int f, float cs, float ws, bool pk, float tp, float wp, float cb) {
+        float U = ws;
+        for (int g = f + 1; g < I.N; g++) U += I.rig[(size_t)g * npx + epi];
+        float L = cs;
+        if (pk) { L = L - tp; U += wp; }
+        return U == 0.f || (L / fmaxf(U, 1.1920929e-07f)) >= cb;
+    };
+    for (int it = 0; it < n_rand; it += CRQ_NS) {
+        const int nh = min(CRQ_NS, n_rand - it);
+        s_best[tid] = ~0ull;
+        s_cbest[tid] = c_best;
+        if (tid == 0) s_qn = 0;
+        __syncthreads();
+        // ---- stage 0: frame 0 (observed at the pixel itself) and the prior of every sample of this round, by the pixel's own lane
+        for (int k = 0; k < nh; k++) {
+            const float d = sample_depth(pi, epoch0 + (uint32_t)(it + k), range_factor);
+            float cs = 0.f, ws = 0.f, tp = 0.f, wp = 0.f;
+            bool pk = false;
+            if (I.N > 0) {
+                const P3 o = transform(P->Rs[0], P->ts[0], backproject(P, (float)px, (float)py, d));
+                float px2, py2;
+                project(P, o, px2, py2);
+                if (o.z > 0.f) {  // the pixel itself is inside the image
+                    cs = cs - wgt0 * vsm_logf(strict::rigidness_with(ob0, px2 - (float)px, py2 - (float)py, I.arf));
+                    ws += wgt0;
+                }
+            }
+            if (I.N_dp > 0) pk = prior_parts_strict(I, P, 0, px, py, d, wp, tp);
+            const bool alive = live && !dead_after(pi, 0, cs, ws, pk, tp, wp, c_best);
+            const unsigned long long m = __ballot(alive);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_qn, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (alive) s_q[base + __popcll(m & ((1ull << lane) - 1ull))] = { (unsigned)tid | ((unsigned)k << 8) | (pk ? 1u << 16 : 0u), cs, ws, tp, wp };
+        }
+        __syncthreads();
+        // ---- stages 1 .. N-1: frame f of every entry still alive; survivors re-compacted in place (an entry is read before the barrier
+        // that precedes the writes of its batch, and writes only go to slots at or below the batch that was just read)
+        for (int f = 1; f < I.N; f++) {
+            const int qn = s_qn;
+            if (qn == 0) break;
+            if (tid == 0) s_qw = 0;
+            __syncthreads();
+            for (int e0 = 0; e0 < qn; e0 += 256) {
+                const int e = e0 + tid;
+                const bool have = e < qn;
+                CrqsEntry q = { 0u, 0.f, 0.f, 0.f, 0.f };
+                if (have) q = s_q[e];
+                const int t = (int)(q.id & 255u), k = (int)((q.id >> 8) & 255u);
+                const bool pk = (q.id >> 16) & 1u;
+                const int ex_ = x0 + (t & 63), ey_ = y0 + (t >> 6), epi = have ? ey_ * w + ex_ : 0;
+                bool alive = false;
+                if (have) {
+                    const float d = sample_depth(epi, epoch0 + (uint32_t)(it + k), range_factor);
+                    // the chain of positions up to frame f (pixel_cost_strict's own walk: positions advance on contributing frames only)
+                    P3 o = backproject(P, (float)ex_, (float)ey_, d);
+                    float px1 = (float)ex_, py1 = (float)ey_, px2 = 0.f, py2 = 0.f;
+                    bool valid = false;
+                    for (int g = 0; g <= f; g++) {
+                        o = transform(P->Rs[g], P->ts[g], o);
+                        project(P, o, px2, py2);
+                        valid = o.z > 0.f && px1 >= 0.f && px1 < (float)w && py1 >= 0.f && py1 < (float)h;
+                        if (g < f && valid) { px1 = px2; py1 = py2; }
+                    }
+                    if (valid) {
+                        const float2 obs = bilinear2(I.flows + (size_t)f * npx, w, h, px1, py1);
+                        const float wg = I.rig[(size_t)f * npx + epi];
+                        q.cs = q.cs - wg * vsm_logf(strict::rigidness(px2 - px1, py2 - py1, obs.x, obs.y, I.lambda, I.arf));
+                        q.ws += wg;
+                    }
+                    alive = (f == I.N - 1) || !dead_after(epi, f, q.cs, q.ws, pk, q.tp, q.wp, s_cbest[t]);
+                }
+                __syncthreads();  // every entry of this batch has been read
+                const unsigned long long m = __ballot(alive);
+                int base = 0;
+                if (lane == 0 && m) base = atomicAdd(&s_qw, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (alive) s_q[base + __popcll(m & ((1ull << lane) - 1ull))] = q;
+                __syncthreads();
+            }
+            if (tid == 0) s_qn = s_qw;
+            __syncthreads();
+        }
+        // ---- the entries that lived through every frame: the prior closes the chain, the cheapest sample of a pixel wins
+        {
+            const int qn = s_qn;
+            for (int e = tid; e < qn; e += 256) {
+                const CrqsEntry q = s_q[e];
+                const int t = (int)(q.id & 255u), k = (int)((q.id >> 8) & 255u);
+                float cs = q.cs, ws = q.ws;
+                if ((q.id >> 16) & 1u) { cs = cs - q.tp; ws += q.wp; }
+                const float c = ws == 0.f ? INFINITY : cs / fmaxf(ws, 1.1920929e-07f);
+                if (c == c) atomicMin(&s_best[t], ((unsigned long long)__float_as_uint(fmaxf(c, 0.f)) << 32) | (unsigned)k);
+            }
+        }
+        __syncthreads();
+        const unsigned long long key = s_best[tid];
+        if (key != ~0ull) {
+            const float c = __uint_as_float((unsigned)(key >> 32));
+            if (c < c_best) { c_best = c; d_best = sample_depth(pi, epoch0 + (uint32_t)(it + (int)(key & 0xffu)), range_factor); }
+        }
+        __syncthreads();
+    }
+    if (live) { I.depth[pi] = d_best; I.cost[pi] = c_best; }
+}
+
 // Global propagation with the candidate of a site evaluated by LPP lanes (cost_split_lean: the bits of pixel_cost_lean).  A pass has
 // only w*h/step sites: with one lane per site it is a few hundred (640x480) to a few thousand (1080p) waves, each walking all frames
 // of its 64 sites one after the other -- latency, 26 % VALU issue at 1080p.  LPP lanes per site = LPP times the waves, each lane with
 // ceil(N / LPP) gathers and residuals in flight.  Same decisions, same maps as k_global_prop_sites_lean (vk_set_global_split).
-template <int NMAX, int LPP>
+template <int NMAX, int LPP, bool STRICT = false>
 __global__ __launch_bounds__(64) static void k_global_prop_split_lean(Img I, int dir, int step, int nsites) {
     if (!clamp_active(I)) return;
     constexpr int SPW = 64 / LPP;  // sites per wave
@@ -766,7 +1002,7 @@ __global__ __launch_bounds__(64) static void k_global_prop_split_lean(Img I, int
     const int pi = y * I.w + x;
     const float cand = I.depth[sy * I.w + sx];
     const float c0 = I.cost[pi];
-    const float c = cost_split_lean<NMAX, LPP>(I, K, x, y, cand, g);
+    const float c = cost_split_any<NMAX, LPP, STRICT>(I, K, x, y, cand, g);
     if (live && g == 0 && c < c0) { I.depth[pi] = cand; I.cost[pi] = c; }
 }
 // Pass 2 of a local propagation: one chain per HALF lanes (HALF = 64: one chain per wave, up to 64 steps; HALF = 32: two chains
@@ -787,7 +1023,7 @@ __global__ __launch_bounds__(64) static void k_global_prop_split_lean(Img I, int
 // Every cost that is used was evaluated for exactly the (pixel, value) the step-by-step chain evaluates: identical maps (tests:
 // vk_set_local_serial).  Both chains of a wave share one evaluation per round whatever state each is in; only the cheap
 // bookkeeping diverges.
-template <int HALF, int NMAX, int LPP>
+template <int HALF, int NMAX, int LPP, bool STRICT = false>
 __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, int width, const float* __restrict__ tbl, int lines, int nchains) {
     if (!clamp_active(I)) return;
     PHD_DECL;
@@ -809,7 +1045,7 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
     const float first_cand = I.depth[cg.prev0];
     float t0 = INFINITY;
     if (tbl) t0 = has ? tbl[mypi] : INFINITY;
-    else if (has) t0 = pixel_cost_lean<NMAX>(I, K, mypi % I.w, mypi / I.w, I.depth[mypi - cg.stride]);  // the table entry of my own step
+    else if (has) t0 = pixel_cost_any<NMAX, STRICT>(I, K, mypi % I.w, mypi / I.w, I.depth[mypi - cg.stride]);  // the table entry of my own step
     const unsigned long long tacc = (__ballot(has && t0 < c0) & hmask) >> hshift;  // steps whose table cost beats their current cost
     // number of leading groups of [g0, g0 + cnt) whose lanes are set in `m` (one bit per lane, a group's lanes agree)
     auto lead = [](unsigned long long m, int g0, int cnt) {
@@ -852,7 +1088,7 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
         }
         // ---- one evaluation for the whole wave
         const int pi = cg.pi0 + (act ? px : 0) * cg.stride;
-        const float c = cost_split_lean<NMAX, LPP>(I, K, pi % I.w, pi / I.w, v, sub);
+        const float c = cost_split_any<NMAX, LPP, STRICT>(I, K, pi % I.w, pi / I.w, v, sub);
         const float c0p = __shfl(c0, min(max(px, 0), HALF - 1), HALF);
         const bool acc = act && c < c0p;
         const unsigned long long accm = (__ballot(acc) & hmask) >> hshift;
@@ -1260,7 +1496,7 @@ int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0
     // win -- the dependent chain is what takes the time.  Where the pass fills the chip many times over it is bound by VALU issue (0.91
     // at 1080p) and the chaining is half of all instructions with 20-step segments (1920 wide: 95 + 40 steps per lane): 40-step
     // segments then do the same work in 37 % fewer instructions.
-    const int forced = g_fb_segment.load(std::memory_order_relaxed);
+    const int forced = debug_switches().fb_segment;
     const bool many_waves = (size_t)w * h * n_maps >= ((size_t)8 << 20);  // >= 8 waves per SIMD at 20 steps per lane
     const bool rows40 = w > 20 * FB_MAX_ROW_SEGS || (forced ? forced == 40 : many_waves);
     const bool cols40 = h > 20 * FB_MAX_COL_SEGS || (forced ? forced == 40 : many_waves);
@@ -1297,13 +1533,17 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
     const int w = p.w, h = p.h;
     Img I = make_img(S, p);
     const dim3 gpx((w + 63) / 64, (h + 3) / 4), bpx(256);
+    const bool plain = STRICT && debug_switches().strict_plain;  // strict mode on the plain launch structures of rounds 1-3 (verification: same bits either way)
     // fast mode: the projective maps of the chain (and the world-scale factor) are prepared by an extra workgroup of the first fb_smooth
     // launch when there is one, by their own small launch otherwise
     const bool cum_in_fb = !STRICT && !cost_only && !p.update_rigidness_only && p.fb_smooth && p.N > 0;
     if constexpr (!STRICT) { if (!cum_in_fb) hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, S.pb(), p.N, p.N_dp, p.world_scale_out); }
     auto cost_rand = [&](int n_rand, uint32_t epoch) {
-        if constexpr (STRICT) hipLaunchKernelGGL(k_cost_rand_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
-        else if (g_cost_rand_plain.load(std::memory_order_relaxed)) hipLaunchKernelGGL(k_cost_rand_plain<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
+        if constexpr (STRICT) {
+            if (plain || debug_switches().cost_rand_plain || p.N_dp > 1) hipLaunchKernelGGL(k_cost_rand_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
+            else hipLaunchKernelGGL(k_cost_rand_q_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
+        }
+        else if (debug_switches().cost_rand_plain) hipLaunchKernelGGL(k_cost_rand_plain<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
         else hipLaunchKernelGGL(k_cost_rand_q<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
     };
     if (cost_only) {
@@ -1335,8 +1575,13 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                 if (p.global_prop_step >= 2) {
                     const int nsites = (len - 1 + p.global_prop_step - 1) / p.global_prop_step;
                     if (nsites <= 0) continue;
-                    if constexpr (STRICT) hipLaunchKernelGGL(k_global_prop_sites_strict<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
-                    else if (g_global_split.load(std::memory_order_relaxed) && (size_t)w * h <= 600000) {  // latency regime only (640x480: 5.9 -> 5.0 us per pass, 1241x376: 11.2 -> 10.6); at 1080p the pass is throughput bound and eight lanes re-walking the chain cost 35 -> 52 us
+                    if (STRICT && plain) hipLaunchKernelGGL(k_global_prop_sites_strict<NMAX>, dim3((nsites + 63) / 64, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
+                    else if (STRICT) {  // a site's strict evaluation is ~10 us of dependent fp64 on one lane: a group of lanes per site at every size, one frame per lane
+                        constexpr int GL = 8, SPW = 64 / GL;
+                        if (rowpass) hipLaunchKernelGGL((k_global_prop_split_lean<NMAX, GL, STRICT>), dim3((nsites + SPW - 1) / SPW, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
+                        else hipLaunchKernelGGL((k_global_prop_split_lean<NMAX, GL, STRICT>), dim3((lines + SPW - 1) / SPW, nsites), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
+                    }
+                    else if (debug_switches().global_split && (size_t)w * h <= 600000) {  // latency regime only (640x480: 5.9 -> 5.0 us per pass, 1241x376: 11.2 -> 10.6); at 1080p the pass is throughput bound and eight lanes re-walking the chain cost 35 -> 52 us
                         constexpr int GL = NMAX <= 8 ? 4 : 8, SPW = 64 / GL;  // lanes per site as in the run evaluations of the local pass
                         if (rowpass) hipLaunchKernelGGL((k_global_prop_split_lean<NMAX, GL>), dim3((nsites + SPW - 1) / SPW, lines), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
                         else hipLaunchKernelGGL((k_global_prop_split_lean<NMAX, GL>), dim3((lines + SPW - 1) / SPW, nsites), dim3(64), 0, c->stream, I, dir, p.global_prop_step, nsites);
@@ -1354,21 +1599,25 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                 const bool rowpass = (dir == 0 || dir == 2);
                 const int len = rowpass ? w : h, lines = rowpass ? h : w;
                 const int nseg = (len + p.local_prop_width - 1) / p.local_prop_width;
-                if (!STRICT && p.local_prop_width <= 65 && !g_local_serial.load(std::memory_order_relaxed)) {  // chains of <= 64 steps: table + one wave per chain
+                if (p.local_prop_width <= 65 && !(STRICT ? plain : debug_switches().local_serial != 0)) {  // chains of <= 64 steps: table + one wave per chain
                     // small images (the pass is a few thousand waves, its time is latency): every chain tabulates its own steps, one lane per
                     // pixel, at the head of the runs kernel -- one launch less per pass (cfg2: 28.0 -> 27.0 us).  Larger ones are throughput
                     // bound and the tiled table kernel reads coalesced (column chains do not): measured neutral at 1241x376, 5 % slower at 1080p
-                    const bool own_table = (size_t)w * h <= 400000;
-                    if (!own_table) hipLaunchKernelGGL(k_local_table_lean<NMAX>, gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
+                    const bool own_table = (size_t)w * h <= 400000 && !(STRICT && !debug_switches().strict_own_table);
+                    if (!own_table) hipLaunchKernelGGL((k_local_table_lean<NMAX, STRICT>), gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
                     const float* tblp = own_table ? nullptr : c->local_tbl.as<float>();
                     const int nchains = lines * nseg;
                     // lanes per pixel of a run evaluation (cost_split_lean): quads up to 8 frames, eight beyond.  (Pairs -- 16 pixels per round, four planned
                     // runs -- halve the rounds again but need 137 registers: 3 waves per SIMD for a pass of 4.7, 46 us instead of 27.)
                     constexpr int LR_LPP = NMAX <= 8 ? 4 : 8;
+                    if (STRICT && NMAX <= 8 && debug_switches().strict_lpp8) {  // (experiment: eight lanes per pixel -- one frame per lane -- in strict arithmetic)
+                        if (p.local_prop_width <= 33) hipLaunchKernelGGL((k_local_runs_lean<32, NMAX, 8, STRICT>), dim3((nchains + 1) / 2), dim3(64), 0, c->stream, I, dir, p.local_prop_width, tblp, lines, nchains);
+                        else hipLaunchKernelGGL((k_local_runs_lean<64, NMAX, 8, STRICT>), dim3(nchains), dim3(64), 0, c->stream, I, dir, p.local_prop_width, tblp, lines, nchains);
+                    } else
                     if (p.local_prop_width <= 33)  // chains of <= 32 steps: two per wave
-                        hipLaunchKernelGGL((k_local_runs_lean<32, NMAX, LR_LPP>), dim3((nchains + 1) / 2), dim3(64), 0, c->stream, I, dir, p.local_prop_width, tblp, lines, nchains);
+                        hipLaunchKernelGGL((k_local_runs_lean<32, NMAX, LR_LPP, STRICT>), dim3((nchains + 1) / 2), dim3(64), 0, c->stream, I, dir, p.local_prop_width, tblp, lines, nchains);
                     else
-                        hipLaunchKernelGGL((k_local_runs_lean<64, NMAX, LR_LPP>), dim3(nchains), dim3(64), 0, c->stream, I, dir, p.local_prop_width, tblp, lines, nchains);
+                        hipLaunchKernelGGL((k_local_runs_lean<64, NMAX, LR_LPP, STRICT>), dim3(nchains), dim3(64), 0, c->stream, I, dir, p.local_prop_width, tblp, lines, nchains);
                 } else
                     hipLaunchKernelGGL((k_local_serial<NMAX, STRICT>), dim3((lines + 63) / 64, nseg), dim3(64), 0, c->stream, I, dir, p.local_prop_width);
             }
@@ -1497,14 +1746,6 @@ int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk
 
 }  // namespace vk
 
-extern "C" __attribute__((visibility("default"))) int vk_set_local_serial(int on) { vk::g_local_serial.store(on ? 1 : 0); return 0; }
-extern "C" __attribute__((visibility("default"))) int vk_set_fb_segment(int steps) {
-    if (steps != 0 && steps != 20 && steps != 40) return (int)hipErrorInvalidValue;
-    vk::g_fb_segment.store(steps);
-    return 0;
-}
-extern "C" __attribute__((visibility("default"))) int vk_set_global_split(int on) { vk::g_global_split.store(on ? 1 : 0); return 0; }
-extern "C" __attribute__((visibility("default"))) int vk_set_cost_rand_plain(int on) { vk::g_cost_rand_plain.store(on ? 1 : 0); return 0; }
 
 #ifdef VK_PHASE_CLOCKS
 extern "C" __attribute__((visibility("default"))) int vk_phase_read_depth(unsigned long long* out, int n, int reset) {

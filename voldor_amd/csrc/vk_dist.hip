@@ -19,6 +19,8 @@
 #include <cstring>
 #include <mutex>
 #include <thread>
+#include <algorithm>
+#include <vector>
 
 namespace vk {
 namespace {
@@ -38,6 +40,8 @@ struct Dist {
     int rank = 0, world = 0, device = -1;
     float* send = nullptr; float* recv = nullptr; size_t cap = 0;  // device records (floats per rank: cap)
     double* scalar = nullptr;                                      // device scalar for barrier / max
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;                       // around the ncclAllGather on `stream` (vk_dist_allgather_stats)
+    std::vector<float> ag_dev_us, ag_host_us;                      // per all-gather: HIP-event time on the stream / host wall time incl. the wait
 };
 std::mutex g_dmu;
 Rccl g_rccl;
@@ -75,13 +79,25 @@ int ensure_records(size_t floats_per_rank) {
 int allgather_locked(const float* send_dev, float* recv_dev, int count) {
     Dist& d = g_dist;
     if (!d.comm) return (int)hipErrorNotInitialized;
+    // BASELINE.md cfg4 asks for the latency of the collective on its own: HIP events around it on the communicator's stream (device
+    // time of the exchange) and the host's wall clock from issue to completion (what a step pays for it)
+    const auto t0 = std::chrono::steady_clock::now();
+    if (d.ev0) VK_CHECK(hipEventRecord(d.ev0, d.stream));
     VK_NCCL(g_rccl.AllGather(send_dev, recv_dev, (size_t)count, ncclFloat, d.comm, d.stream));
+    if (d.ev1) VK_CHECK(hipEventRecord(d.ev1, d.stream));
     VK_CHECK(hipStreamSynchronize(d.stream));
+    if (d.ev0 && d.ev1 && d.ag_dev_us.size() < (size_t)VK_DIST_STATS_MAX) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, d.ev0, d.ev1) == hipSuccess) {
+            d.ag_dev_us.push_back(ms * 1e3f);
+            d.ag_host_us.push_back((float)std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count());
+        }
+    }
     return 0;
 }
-__global__ void k_mark_empty(float* blk, int n) {  // "no sequence in this slot": n_registered = -1, the rest zero
+__global__ void k_mark_empty(float* blk, int n, float tag, float code) {  // "no sequence in this slot": n_registered = -1 (or VK_DIST_FAILED + the error code), the rest zero
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) blk[i] = i == 0 ? -1.f : 0.f;
+    if (i < n) blk[i] = i == 0 ? tag : (i == 1 ? code : 0.f);
 }
 }  // namespace
 }  // namespace vk
@@ -111,9 +127,13 @@ int vk_dist_init(int rank, int world, const void* id_in) {
     ncclUniqueId id;
     memcpy(&id, id_in, sizeof id);
     const ncclResult_t r = g_rccl.CommInitRank(&d.comm, world, id, rank);
-    if (r != ncclSuccess || hipMalloc((void**)&d.scalar, sizeof(double)) != hipSuccess) {  // leave nothing behind: a later vk_dist_init starts clean
+    if (r != ncclSuccess || hipMalloc((void**)&d.scalar, sizeof(double)) != hipSuccess || hipEventCreate(&d.ev0) != hipSuccess ||
+        hipEventCreate(&d.ev1) != hipSuccess) {  // leave nothing behind: a later vk_dist_init starts clean
         fprintf(stderr, "voldor_hip: ncclCommInitRank(rank %d of %d) failed: %s\n", rank, world, r != ncclSuccess ? g_rccl.GetErrorString(r) : "out of device memory");
         if (d.comm) g_rccl.CommDestroy(d.comm);
+        if (d.scalar) (void)hipFree(d.scalar);
+        if (d.ev0) (void)hipEventDestroy(d.ev0);
+        if (d.ev1) (void)hipEventDestroy(d.ev1);
         (void)hipStreamDestroy(d.stream);
         d = Dist{};
         return r != ncclSuccess ? 1000 + (int)r : (int)hipErrorOutOfMemory;
@@ -125,9 +145,19 @@ int vk_dist_init(int rank, int world, const void* id_in) {
 /* Rendezvous through one file every rank can see (a launcher without a store of its own): rank 0 creates the id and publishes it
  * by an atomic rename; the others wait for the file.  The path must be NEW for every job (as with any file rendezvous: a file left by
  * an earlier job would hand its stale id to ranks that start before rank 0 has replaced it); rank 0 removes a leftover it finds, which
- * covers jobs run one after the other under one name.  The file is left in place (the launcher owns the path). */
+ * covers jobs run one after the other under one name; with a job tag in the environment (VOLDOR_HIP_JOB_ID, or torchrun's
+ * TORCHELASTIC_RUN_ID) a leftover of ANOTHER job is recognised and ignored by the waiting ranks as well.  The file is left in place
+ * (the launcher owns the path). */
 int vk_dist_init_file(int rank, int world, const char* path, int timeout_s) {
     if (!path || world < 1 || rank < 0 || rank >= world) return (int)hipErrorInvalidValue;
+    // File = 64-byte job tag + the id.  The tag is what the launcher says identifies THIS job (VOLDOR_HIP_JOB_ID, else torchrun's
+    // TORCHELASTIC_RUN_ID, else empty): a rank that starts before rank 0 has replaced a file left by an earlier job under the same
+    // path reads that job's tag, sees it is not its own and keeps waiting instead of joining a communicator nobody else is in.
+    char tag[64];
+    memset(tag, 0, sizeof tag);
+    const char* job = getenv("VOLDOR_HIP_JOB_ID");
+    if (!job || !*job) job = getenv("TORCHELASTIC_RUN_ID");
+    if (job) strncpy(tag, job, sizeof tag - 1);
     unsigned char id[VK_DIST_ID_BYTES];
     if (rank == 0) {
         (void)remove(path);
@@ -135,14 +165,19 @@ int vk_dist_init_file(int rank, int world, const char* path, int timeout_s) {
         const std::string tmp = std::string(path) + ".tmp";
         FILE* f = fopen(tmp.c_str(), "wb");
         if (!f) return (int)hipErrorFileNotFound;
-        const size_t n = fwrite(id, 1, sizeof id, f);
+        const size_t n = fwrite(tag, 1, sizeof tag, f) + fwrite(id, 1, sizeof id, f);
         fclose(f);
-        if (n != sizeof id || rename(tmp.c_str(), path) != 0) return (int)hipErrorFileNotFound;
+        if (n != sizeof tag + sizeof id || rename(tmp.c_str(), path) != 0) return (int)hipErrorFileNotFound;
     } else {
         const auto t0 = std::chrono::steady_clock::now();
         for (;;) {
             FILE* f = fopen(path, "rb");
-            if (f) { const size_t n = fread(id, 1, sizeof id, f); fclose(f); if (n == sizeof id) break; }
+            if (f) {
+                char ftag[64];
+                const size_t n = fread(ftag, 1, sizeof ftag, f) + fread(id, 1, sizeof id, f);
+                fclose(f);
+                if (n == sizeof ftag + sizeof id && memcmp(ftag, tag, sizeof tag) == 0) break;  // (another job's file: not ours, wait for rank 0)
+            }
             if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(timeout_s > 0 ? timeout_s : 120)) {
                 fprintf(stderr, "voldor_hip: rank %d timed out waiting for %s\n", rank, path);
                 return (int)hipErrorNotReady;
@@ -193,21 +228,49 @@ int vk_voldor_sharded(const float* flows, const float* disparity, const float* d
         if (int e = ensure_records((size_t)len)) return e;
         send = g_dist.send; recv = g_dist.recv; st = g_dist.stream; world = g_dist.world;
     }
+    // A rank whose own window fails must STILL take part in the collective: the other ranks are already inside ncclAllGather +
+    // hipStreamSynchronize, which has no timeout -- returning here would hang the whole job on one rank's local error (bad config,
+    // out of memory, a lost device).  The failing rank sends the record { VK_DIST_FAILED | error code | 0 ... }, every rank sees which
+    // peer failed (n_registered slot == VK_DIST_FAILED, slot 1 = that rank's error code), and this call returns the saved error.
+    int local_err = 0;
     if (flows) {
-        if (int e = vk_voldor_device_block(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, fx, fy, cx, cy,
-                                           basefocal, N, N_dp, w, h, config, n_registered, poses, poses_covar, depth, depth_conf, send))
-            return e;  // returns after the window's stream has drained: the record is complete
+        local_err = vk_voldor_device_block(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, fx, fy, cx, cy,
+                                           basefocal, N, N_dp, w, h, config, n_registered, poses, poses_covar, depth, depth_conf, send);
+        // (returns after the window's stream has drained: on success the record is complete)
     } else {
-        hipLaunchKernelGGL(k_mark_empty, dim3((len + 255) / 256), dim3(256), 0, st, send, len);
-        VK_CHECK_LAST();
+        hipLaunchKernelGGL(k_mark_empty, dim3((len + 255) / 256), dim3(256), 0, st, send, len, -1.f, 0.f);
+        local_err = (int)hipGetLastError();
         if (n_registered) *n_registered = -1;
+    }
+    if (local_err) {
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_mark_empty, dim3((len + 255) / 256), dim3(256), 0, st, send, len, (float)VK_DIST_FAILED, (float)local_err);
+        if (hipGetLastError() != hipSuccess) {  // not even a marker launch: the device is gone.  Send what the buffer holds, marked from the host if that still works
+            const float mark[2] = { (float)VK_DIST_FAILED, (float)local_err };
+            (void)hipMemcpyAsync(send, mark, sizeof mark, hipMemcpyHostToDevice, st);
+        }
+        if (n_registered) *n_registered = VK_DIST_FAILED;
     }
     {
         std::lock_guard<std::mutex> lk(g_dmu);
-        if (int e = allgather_locked(send, recv, len)) return e;
+        if (int e = allgather_locked(send, recv, len)) return local_err ? local_err : e;
         VK_CHECK(hipMemcpyAsync(all_blocks_host, recv, sizeof(float) * (size_t)len * world, hipMemcpyDeviceToHost, st));
         VK_CHECK(hipStreamSynchronize(st));
     }
+    return local_err;
+}
+
+/* Latency of the all-gathers issued so far (vk_voldor_sharded, vk_dist_allgather): up to `cap` samples each of the HIP-event time of the
+ * collective on the communicator's stream and of the host's wall clock from issue to completion, microseconds, in call order.
+ * *n = samples written.  reset != 0 clears the record afterwards. */
+int vk_dist_allgather_stats(float* dev_us, float* host_us, int cap, int* n, int reset) {
+    std::lock_guard<std::mutex> lk(g_dmu);
+    Dist& d = g_dist;
+    if (!n || cap < 0) return (int)hipErrorInvalidValue;
+    const int m = (int)std::min<size_t>((size_t)cap, d.ag_dev_us.size());
+    for (int i = 0; i < m; i++) { if (dev_us) dev_us[i] = d.ag_dev_us[i]; if (host_us) host_us[i] = d.ag_host_us[i]; }
+    *n = m;
+    if (reset) { d.ag_dev_us.clear(); d.ag_host_us.clear(); }
     return 0;
 }
 
@@ -218,6 +281,8 @@ int vk_dist_finalize(void) {
     if (d.send) (void)hipFree(d.send);
     if (d.recv) (void)hipFree(d.recv);
     if (d.scalar) (void)hipFree(d.scalar);
+    if (d.ev0) (void)hipEventDestroy(d.ev0);
+    if (d.ev1) (void)hipEventDestroy(d.ev1);
     if (d.stream) (void)hipStreamDestroy(d.stream);
     d = Dist{};
     return 0;

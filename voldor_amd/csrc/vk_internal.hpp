@@ -17,6 +17,23 @@ struct ModeParams {
     CamBrief* host_brief = nullptr;  // with decide_n: pinned host records the same thread fills for the host's copy of the decision
 };
 
+// Verification switches (NOT part of the product C-ABI: declared in vk_debug.h, set through the one entry vk_debug_switch; the test
+// suite uses them to hold every launch structure of the fast / strict pipelines against its plain form).  One plain struct, written
+// by the test thread between calls, read by the launchers.
+struct DebugSwitches {
+    int local_serial = 0;      // 1: local propagation walks every chain step by step (k_local_serial) instead of table + runs
+    int cost_rand_plain = 0;   // 1: the sample pass evaluates every random depth in full, one after the other
+    int fb_segment = 0;        // 0: by size; 20 / 40: steps per lane of the segmented fb_smooth
+    int global_split = 1;      // 0: global propagation with one lane per site
+    int refit_partition = 1;   // 0: every gate pass of the refit walks the whole pool in its arrival order
+    int split_trials = 1;      // 0: the mode kernel runs the initial-mode trials itself
+    int newton_cap = 0;        // (experiment, measured and NOT adopted: DESIGN.md section 6) Newton steps of the P3P cubic in the FAST window pipeline: 0 = the reference's 50; an even cap <= 50 otherwise; strict mode always 50
+    int strict_own_table = 0;  // (tuning) strict local pass: 1 = every chain tabulates its own steps at the head of the runs kernel, 0 = the tiled table kernel
+    int strict_lpp8 = 0;       // (tuning) strict local pass: 8 lanes per pixel instead of 4 for up to 8 frames
+    int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
+};
+DebugSwitches& debug_switches();  // vk_abi.hip
+
 #ifdef __HIPCC__
 // voldor.cpp:171-194 on the device: the first camera that failed, was not allowed to run (rigidness density) or is not
 // confident enough truncates the window at its index.  The host applies the same rule to its copy of the records.

@@ -16,12 +16,11 @@
 #include "vk_device.hpp"
 #include "vk_p3p.hpp"
 #include "vk_ref_svd.h"
+#include "vk_lu.hpp"
 #include "vk_internal.hpp"
 
 namespace vk {
 
-static std::atomic<int> g_refit_partition{1};  // vk_set_refit_partition (verification aid): 0 = every gate pass of the refit walks the whole pool in its arrival order
-static std::atomic<int> g_split_trials{1};  // vk_set_split_trials (verification aid): 0 = the mode kernel runs the initial-mode trials itself
 
 // phase clocks of the pose kernels (profiling builds only: scripts/phase_clocks.sh compiles a second library with -DVK_PHASE_CLOCKS)
 #ifdef VK_PHASE_CLOCKS
@@ -195,7 +194,8 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                                                       CamState* cam, int npx, float fx, float fy, float cx, float cy, int n_poses,
                                                       int draw /* 0 auto, 1 rank select (reference draw), -1 rejection only */, int strict /* bit 0: strict math, bit 1: reference SVD, bit 2: block-compacted correspondences (with draw 1) */,
                                                       const int* __restrict__ blk_offsets /* exclusive prefix of blk_counts in global memory when it does not fit the LDS, else null */,
-                                                      const unsigned long long* __restrict__ valid_mask /* k_collect's bit per pixel (FROM_MAP) */) {
+                                                      const unsigned long long* __restrict__ valid_mask /* k_collect's bit per pixel (FROM_MAP) */,
+                                                      int newton_steps /* cubic_root (vk_p3p.hpp): 50 = the reference's loop */) {
     // LambdaTwist: four lanes per hypothesis, one candidate root each (the candidates are independent once the
     // shared cubic / eigen-decomposition is done; a lane per hypothesis walks them one after the other and the wave
     // waits for its slowest lane).  AP3P keeps one lane per hypothesis.
@@ -404,8 +404,8 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
 #endif
         PH_MARK(10);
         if (drawn) {
-            if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf);
-            else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errd);
+            if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf, nullptr, newton_steps);
+            else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errd, nullptr, newton_steps);
             else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t, (strict & 1) != 0);
         }
     }
@@ -547,119 +547,6 @@ __device__ static void meanshift_block(const float* __restrict__ space, int N, i
     }
     *o_conf = conf;
     *o_iters = iters;
-}
-
-// n x n (n<=6) inverse + determinant in double by LU with partial pivoting, the algorithm behind
-// cv::determinant / cv::Matx::inv that the reference calls on the host every iteration
-// (aux_funs.cpp:101-118).  Lane r (< n) of ONE wave holds row r of A and of the right-hand side B
-// (starts as I) in registers; pivot columns and pivot rows are broadcast with v_readlane (the
-// source lane is wave-uniform), so there is no LDS or scratch traffic on the critical path.  Within
-// an elimination step every element update is independent, hence each element sees exactly the
-// operation sequence of the serial algorithm: the result is bit-identical to it.
-// Must be called by all 64 lanes of the wave; lanes >= n carry don't-care rows.
-__device__ __forceinline__ double readlane_d(double v, int src) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
-    return __hiloint2double(hi, lo);
-}
-__device__ __forceinline__ double lu_inverse_rows(double (&a)[6], double (&b)[6], int n) {
-    const int lane = threadIdx.x & 63;
-    double det = 1.0;
-    bool singular = false;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        if (i < n && !singular) {
-            int k = i;
-            double best = fabs(readlane_d(a[i], i));
-#pragma unroll
-            for (int j = i + 1; j < 6; j++) {
-                if (j < n) {
-                    const double v = fabs(readlane_d(a[i], j));
-                    if (v > best) { best = v; k = j; }
-                }
-            }
-            if (best < 2.220446049250313e-16) singular = true;
-            else {
-                if (k != i) {  // row swap i <-> k
-#pragma unroll
-                    for (int c = 0; c < 6; c++) {
-                        const double ai = readlane_d(a[c], i), ak = readlane_d(a[c], k);
-                        const double bi = readlane_d(b[c], i), bk = readlane_d(b[c], k);
-                        if (lane == i) { a[c] = ak; b[c] = bk; }
-                        else if (lane == k) { a[c] = ai; b[c] = bi; }
-                    }
-                    det = -det;
-                }
-                const double piv = readlane_d(a[i], i);
-                det *= piv;
-                const double d = -1.0 / piv;
-                const double alpha = a[i] * d;  // own row, column i
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    const double ric = readlane_d(a[c], i), bic = readlane_d(b[c], i);
-                    if (lane > i && lane < n && c < n) {
-                        if (c > i) a[c] += alpha * ric;
-                        b[c] += alpha * bic;
-                    }
-                }
-            }
-        }
-    }
-    if (singular) return 0.0;
-    if (det > 0.0) {
-#pragma unroll
-        for (int i = 5; i >= 0; i--) {  // back substitution, row i lives in lane i
-            if (i < n) {
-#pragma unroll
-                for (int c = 0; c < 6; c++) {
-                    double sacc = b[c];
-#pragma unroll
-                    for (int k = i + 1; k < 6; k++) {
-                        if (k < n) sacc -= a[k] * readlane_d(b[c], k);
-                    }
-                    const double q = sacc / a[i];
-                    if (lane == i && c < n) b[c] = q;
-                }
-            }
-        }
-    }
-    return det;
-}
-
-// One robust-Gaussian "prepare" step (fit_robust_gaussian.cu:172-205): packed half -> full, Ledoit-
-// Wolf shrinkage with fixed lambda (aux_funs.cpp:124-141), inverse; writes the (regularised) covariance
-// and its inverse back in packed form.  Called by all lanes of wave 0; returns false when det <= 0.
-__device__ static bool rg_prepare_wave(float* covar_half, float* cinv_half, int dims, bool regularise, float lambda) {
-    const int lane = threadIdx.x & 63;
-    const int r = lane < dims ? lane : 0;
-    double a[6], b[6];
-    double tr = 0;
-#pragma unroll
-    for (int d = 0; d < 6; d++) if (d < dims) tr += (double)covar_half[(d * d + d) / 2 + d];
-    const double m = tr / (double)dims, lam = (double)lambda;
-#pragma unroll
-    for (int c = 0; c < 6; c++) {
-        const int hi = r >= c ? r : c, lo = r >= c ? c : r;
-        double full = (c < dims) ? (double)covar_half[(hi * hi + hi) / 2 + lo] : 0.0;
-        if (regularise) full = lam * m * (r == c ? 1.0 : 0.0) + (1 - lam) * full;
-        a[c] = full;
-        b[c] = (r == c) ? 1.0 : 0.0;
-    }
-    double keep[6];
-#pragma unroll
-    for (int c = 0; c < 6; c++) keep[c] = a[c];
-    const double det = lu_inverse_rows(a, b, dims);
-    if (det <= 0) return false;
-    if (lane < dims) {
-#pragma unroll
-        for (int c = 0; c < 6; c++) {
-            if (c <= r && c < dims) {
-                covar_half[(r * r + r) / 2 + c] = (float)keep[c];
-                cinv_half[(r * r + r) / 2 + c] = (float)b[c];
-            }
-        }
-    }
-    return true;
 }
 
 // The same prepare step with the matrices in LDS (A, B: 36 doubles each) and one lane per element:
@@ -1697,9 +1584,13 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
     }
     const int st = (strict ? 1 : 0) | (ref_svd ? 2 : 0) | ((FROM_MAP && c->maps_block_compact) ? 4 : 0);
     const unsigned long long* vm = FROM_MAP ? c->valid_mask.as<unsigned long long>() : nullptr;
-    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm);
-    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm);
-    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm);
+    // Newton steps of the cubic (vk_p3p.hpp cubic_root): the reference's 50 in strict mode and behind the host-pointer API (whose translations are
+    // held to the reference kernel's bits); an even cap in the fast window pipeline
+    const int cap = debug_switches().newton_cap;
+    const int ns = (FROM_MAP && !strict && cap > 0) ? cap : 50;
+    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns);
+    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns);
+    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns);
     VK_CHECK_LAST();
     return 0;
 }
@@ -1715,7 +1606,7 @@ int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, fl
 
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first) {
     ModeParams mp = mp_in;
-    mp.rg_partition = g_refit_partition.load(std::memory_order_relaxed);
+    mp.rg_partition = debug_switches().refit_partition;
     if (n_poses > PM_POOL) {
         fprintf(stderr, "voldor_hip: n_poses_to_sample=%d exceeds the %d hypotheses the mode kernel keeps in registers\n", n_poses,
                 PM_POOL);
@@ -1726,7 +1617,7 @@ int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState*
     // them -- external start -- or, without them, runs the trials itself.)
     constexpr int MAX_SPLIT_TRIALS = 64;
     const float* trials = nullptr;
-    if (trials_first && g_split_trials.load(std::memory_order_relaxed) && mp.use_external_init_mean <= 0 && mp.ms_max_init_trials > 0 && mp.ms_max_init_trials <= MAX_SPLIT_TRIALS) {
+    if (trials_first && debug_switches().split_trials && mp.use_external_init_mean <= 0 && mp.ms_max_init_trials > 0 && mp.ms_max_init_trials <= MAX_SPLIT_TRIALS) {
         if (int e = c->ms_io.reserve(sizeof(float) * (64 + 8 * MAX_SPLIT_TRIALS) + sizeof(int) * 4)) return e;
         float* out = c->ms_io.as<float>() + 64;
         hipLaunchKernelGGL((k_mode_trials<PM_THREADS>), dim3(mp.ms_max_init_trials), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(),
@@ -1756,8 +1647,6 @@ int robust_gaussian_device(Context* c, const float* space_dev, int N, const Mode
 
 }  // namespace vk
 
-extern "C" __attribute__((visibility("default"))) int vk_set_refit_partition(int on) { vk::g_refit_partition.store(on ? 1 : 0); return 0; }
-extern "C" __attribute__((visibility("default"))) int vk_set_split_trials(int on) { vk::g_split_trials.store(on ? 1 : 0); return 0; }
 
 #ifdef VK_PHASE_CLOCKS
 extern "C" __attribute__((visibility("default"))) int vk_phase_read(unsigned long long* out, int n, int reset) {

@@ -16,6 +16,7 @@
 #include "vk_device.hpp"
 #include "vk_p3p.hpp"
 #include "vk_strict_math.h"
+#include "vk_lu.hpp"
 #include "vk_internal.hpp"
 
 namespace vk {
@@ -24,41 +25,160 @@ namespace vk {
 // pass 0: rows (line = row, stride 1), pass 1: columns (line = column, stride w).  F = forward messages of the line (scratch,
 // same layout as the maps).  The backward recurrence and the posterior are fused: step i of the backward chain needs the raw
 // e1[i], which is overwritten by the posterior only after it has been used.
-__global__ __launch_bounds__(64) static void k_fb_strict(float* __restrict__ maps, float* __restrict__ fwd, int w, int h, int pass, float e0, float p,
+// The chain of a line is serial (the next message needs the previous one: ~15 dependent operations and an IEEE division per step), so what a
+// lane can do about time is to keep the MEMORY off that chain: the values of FBS_CH steps are loaded together, one chunk ahead of the
+// arithmetic, and the results of a chunk are stored together -- one exposed memory round trip per line instead of one per step
+// (293 -> ~60 us per pass on five 640x480 maps; the arithmetic, its order and its rounding are untouched).
+constexpr int FBS_CH = 16;
+struct __attribute__((packed, aligned(4))) FbsQuad { float x, y, z, w; };  // 16 bytes at 4-byte alignment: one global_load_dwordx4 on gfx950
+// chunk [i0, i0 + FBS_CH) of a line into registers / back.  Row pass (PASS 0: a lane walks along x, lanes are w floats apart): 16-byte
+// accesses -- a scalar access per step is 64 cache lines per wave instruction and the pass was bound by that, not by its chain; column
+// pass (PASS 1): lanes sit on adjacent columns, every access is one coalesced row piece.
+template <int PASS>
+__device__ __forceinline__ void fbs_load(const float* __restrict__ p, size_t stride, int i0, int n, float (&v)[FBS_CH]) {
+    if (PASS == 0) {
+#pragma unroll
+        for (int k = 0; k < FBS_CH; k += 4) {
+            if (i0 >= 0 && i0 + k + 3 < n) { const FbsQuad q = *reinterpret_cast<const FbsQuad*>(p + i0 + k); v[k] = q.x; v[k + 1] = q.y; v[k + 2] = q.z; v[k + 3] = q.w; }
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const int i = i0 + k + j; v[k + j] = (i >= 0 && i < n) ? p[i] : 0.f; }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < FBS_CH; k++) { const int i = i0 + k; v[k] = (i >= 0 && i < n) ? p[(size_t)i * stride] : 0.f; }
+    }
+}
+template <int PASS>
+__device__ __forceinline__ void fbs_store(float* __restrict__ p, size_t stride, int i0, int n, const float (&v)[FBS_CH]) {
+    if (PASS == 0) {
+#pragma unroll
+        for (int k = 0; k < FBS_CH; k += 4) {
+            if (i0 + k + 3 < n) *reinterpret_cast<FbsQuad*>(p + i0 + k) = FbsQuad{ v[k], v[k + 1], v[k + 2], v[k + 3] };
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) if (i0 + k + j < n) p[i0 + k + j] = v[k + j];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < FBS_CH; k++) if (i0 + k < n) p[(size_t)(i0 + k) * stride] = v[k];
+    }
+}
+__device__ __forceinline__ float fb_fwd_step(float prev, float e, float e0, float p) {  // FB_MSG_L2R / T2B (fb_smooth.h:27-36, :47-55)
+#pragma clang fp contract(off)
+    const float s0 = (prev * (1.f - p) + (1.f - prev) * p) * e0;
+    const float s1 = (prev * p + (1.f - prev) * (1.f - p)) * e;
+    return s1 / (s0 + s1);
+}
+__device__ __forceinline__ float fb_bwd_step(float prev, float e, float e0, float p) {  // FB_MSG_R2L / B2T (:37-46, :56-64)
+#pragma clang fp contract(off)
+    const float s0 = prev * e * (1.f - p) + (1.f - prev) * p * e0;
+    const float s1 = prev * e * p + (1.f - prev) * (1.f - p) * e0;
+    return s1 / (s0 + s1);
+}
+__device__ __forceinline__ float fb_posterior(float f, float b) {  // FB_POSTERIOR (:65-69)
+#pragma clang fp contract(off)
+    const float q0 = (1.f - f) * (1.f - b), q1 = f * b;
+    return q1 / (q0 + q1);
+}
+// chunk loads / stores at ANY base (the backward chain's chunks are aligned to the top of the line, the last chunk of either may hang over an end)
+template <int PASS>
+__device__ __forceinline__ void fbs_load_any(const float* __restrict__ p, size_t stride, int base, int n, float (&v)[FBS_CH]) {
+    if (base >= 0 || PASS != 0) { fbs_load<PASS>(p, stride, base, n, v); return; }
+#pragma unroll
+    for (int k = 0; k < FBS_CH; k++) { const int i = base + k; v[k] = (i >= 0 && i < n) ? p[i] : 0.f; }
+}
+template <int PASS>
+__device__ __forceinline__ void fbs_store_range(float* __restrict__ p, size_t stride, int base, int lo, int hi, const float (&v)[FBS_CH]) {  // indices [lo, hi] of the chunk at `base`
+    if (PASS == 0) {
+#pragma unroll
+        for (int k = 0; k < FBS_CH; k += 4) {
+            if (base + k >= lo && base + k + 3 <= hi) *reinterpret_cast<FbsQuad*>(p + base + k) = FbsQuad{ v[k], v[k + 1], v[k + 2], v[k + 3] };
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; j++) { const int i = base + k + j; if (i >= lo && i <= hi) p[i] = v[k + j]; }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < FBS_CH; k++) { const int i = base + k; if (i >= lo && i <= hi) p[(size_t)i * stride] = v[k]; }
+    }
+}
+// The forward chain (fb_smooth.h:27-36) and the backward chain (:37-46) of a line are INDEPENDENT of each other -- both read the raw
+// map -- and only the posterior (:65-69) joins them.  The pass is a few dozen waves on an otherwise idle chip and each wave is bound by
+// its own instruction issue (~60 instructions per index with two IEEE divisions), so the two chains of a line run on two WAVES of one
+// workgroup (two SIMDs): wave 0 walks 64 lines forwards, wave 1 the same 64 lines backwards.  Phase 1: either chain covers its own
+// half of the line, messages to scratch (F / B); one workgroup barrier; phase 2: either chain walks on through the OTHER half, where it
+// finds the other chain's message at every index and stores the posterior (by then both chains have consumed the raw value there).
+// (Both chains interleaved in ONE lane were measured first: slower, 160 -> 186 us -- the wave is issue bound, not latency bound.)
+// Every value is computed by the operation sequence of the step-by-step form: same bits.
+// One chain over steps [s0, s1) of its line: index = DIR ? n - 1 - step : step.  POST: the other chain's messages `other` are there ->
+// posterior to the map; else this chain's messages to `mine`.
+template <int PASS, int DIR, bool POST>
+__device__ __forceinline__ float fb_chain(float* __restrict__ e1, float* __restrict__ mine, const float* __restrict__ other, size_t stride, int n, int s0, int s1,
+                                          float prev, float e0, float p, bool live) {
+#pragma clang fp contract(off)
+    if (s0 >= s1) return prev;
+    float buf[FBS_CH], oth[FBS_CH];
+    const int first = DIR ? n - 1 - s0 : s0, last = DIR ? n - s1 : s1 - 1;  // first and last index of the walk (inclusive)
+    int base = DIR ? first - (FBS_CH - 1) : first;                          // lowest index of the chunk the walk starts in
+    fbs_load_any<PASS>(e1, stride, base, n, buf);
+    if (POST) fbs_load_any<PASS>(other, stride, base, n, oth);
+    for (;;) {
+        const int nbase = DIR ? base - FBS_CH : base + FBS_CH;
+        float nxt[FBS_CH], noth[FBS_CH], out[FBS_CH];
+        fbs_load_any<PASS>(e1, stride, nbase, n, nxt);  // one chunk ahead of the arithmetic
+        if (POST) fbs_load_any<PASS>(other, stride, nbase, n, noth);
+#pragma unroll
+        for (int kk = 0; kk < FBS_CH; kk++) {
+            const int k = DIR ? FBS_CH - 1 - kk : kk, i = base + k;
+            out[k] = 0.f;
+            const bool in = DIR ? (i >= last && i <= first) : (i >= first && i <= last);  // (uniform: every line of a pass has n steps)
+            if (in) {
+                prev = DIR ? fb_bwd_step(prev, buf[k], e0, p) : fb_fwd_step(prev, buf[k], e0, p);
+                out[k] = POST ? (DIR ? fb_posterior(oth[k], prev) : fb_posterior(prev, oth[k])) : prev;
+            }
+        }
+        const int lo = max(base, DIR ? last : first), hi = min(base + FBS_CH - 1, DIR ? first : last);
+        if (live) fbs_store_range<PASS>(POST ? e1 : mine, stride, base, lo, hi, out);  // (an idle lane of the last workgroup walks along on line 0 and stores nothing)
+        if (DIR ? base <= last : base + FBS_CH - 1 >= last) break;
+        base = nbase;
+#pragma unroll
+        for (int k = 0; k < FBS_CH; k++) { buf[k] = nxt[k]; if (POST) oth[k] = noth[k]; }
+    }
+    return prev;
+}
+template <int PASS>
+__global__ __launch_bounds__(128) static void k_fb_strict(float* __restrict__ maps, float* __restrict__ fwd, float* __restrict__ bwd, int w, int h, float e0, float p,
                                                           const int* __restrict__ n_dev) {
 #pragma clang fp contract(off)
     if (n_dev && (int)blockIdx.y >= *n_dev) return;
-    const int l = blockIdx.x * 64 + threadIdx.x;
-    const int n = pass == 0 ? w : h, lines = pass == 0 ? h : w, stride = pass == 0 ? 1 : w;
-    if (l >= lines) return;
-    const size_t base = (size_t)blockIdx.y * w * h + (pass == 0 ? (size_t)l * w : (size_t)l);
+    const int dir = threadIdx.x >> 6, l = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int n = PASS == 0 ? w : h, lines = PASS == 0 ? h : w;
+    const size_t stride = PASS == 0 ? 1 : (size_t)w;
+    const bool live = l < lines;
+    const size_t base = (size_t)blockIdx.y * w * h + (PASS == 0 ? (size_t)(live ? l : 0) * w : (size_t)(live ? l : 0));
     float* e1 = maps + base;
     float* F = fwd + base;
-    float prev = e1[0];
-    for (int i = 0; i < n; i++) {  // FB_MSG_L2R / T2B (:27-36, :47-55)
-        const float s0 = (prev * (1.f - p) + (1.f - prev) * p) * e0;
-        const float s1 = (prev * p + (1.f - prev) * (1.f - p)) * e1[(size_t)i * stride];
-        prev = s1 / (s0 + s1);
-        F[(size_t)i * stride] = prev;
-    }
-    prev = e1[(size_t)(n - 1) * stride];
-    for (int i = n - 1; i >= 0; i--) {  // FB_MSG_R2L / B2T (:37-46, :56-64), then FB_POSTERIOR (:65-69)
-        const float e = e1[(size_t)i * stride];
-        const float s0 = prev * e * (1.f - p) + (1.f - prev) * p * e0;
-        const float s1 = prev * e * p + (1.f - prev) * (1.f - p) * e0;
-        prev = s1 / (s0 + s1);
-        const float f = F[(size_t)i * stride];
-        const float q0 = (1.f - f) * (1.f - prev), q1 = f * prev;
-        e1[(size_t)i * stride] = q1 / (q0 + q1);
-    }
+    float* B = bwd + base;
+    const int H = n / 2;  // the forward chain's half is [0, H), the backward chain's [H, n)
+    // every lane of the workgroup reaches the ONE barrier (no early return: an idle lane follows line 0 with its stores masked)
+    float prev = dir == 0 ? e1[0] : e1[(size_t)(n - 1) * stride];  // the chains start from the raw end values (:28, :38)
+    if (dir == 0) prev = fb_chain<PASS, 0, false>(e1, F, nullptr, stride, n, 0, H, prev, e0, p, live);
+    else prev = fb_chain<PASS, 1, false>(e1, B, nullptr, stride, n, 0, n - H, prev, e0, p, live);
+    __syncthreads();
+    if (dir == 0) fb_chain<PASS, 0, true>(e1, nullptr, B, stride, n, H, n, prev, e0, p, live);
+    else fb_chain<PASS, 1, true>(e1, nullptr, F, stride, n, n - H, n, prev, e0, p, live);
 }
 int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev) {
     if (n_maps <= 0) return 0;
-    if (int e = c->fb_scratch.reserve(sizeof(float) * (size_t)n_maps * w * h)) return e;
-    hipLaunchKernelGGL(k_fb_strict, dim3((h + 63) / 64, n_maps), dim3(64), 0, c->stream, maps, c->fb_scratch.as<float>(), w, h, 0, s0_ems_prob,
-                       no_change_prob, n_dev);
-    hipLaunchKernelGGL(k_fb_strict, dim3((w + 63) / 64, n_maps), dim3(64), 0, c->stream, maps, c->fb_scratch.as<float>(), w, h, 1, s0_ems_prob,
-                       no_change_prob, n_dev);
+    const size_t plane = (size_t)n_maps * w * h;
+    if (int e = c->fb_scratch.reserve(sizeof(float) * 2 * plane)) return e;  // forward and backward messages
+    float* F = c->fb_scratch.as<float>(); float* B = F + plane;
+    hipLaunchKernelGGL(k_fb_strict<0>, dim3((h + 63) / 64, n_maps), dim3(128), 0, c->stream, maps, F, B, w, h, s0_ems_prob, no_change_prob, n_dev);
+    hipLaunchKernelGGL(k_fb_strict<1>, dim3((w + 63) / 64, n_maps), dim3(128), 0, c->stream, maps, F, B, w, h, s0_ems_prob, no_change_prob, n_dev);
     VK_CHECK_LAST();
     return 0;
 }
@@ -393,6 +513,337 @@ __global__ __launch_bounds__(ST_THREADS) static void k_pose_strict(const float* 
     }
 }
 
+
+// ---- the same per-camera mode finding on a PARALLEL launch structure (round 4) ------------------------------------------------------
+// k_pose_strict above walks the reference's sum tree block by block on 256 threads (16 blocks x 9 barriers per sum): 1.67 ms per camera,
+// two thirds of a strict window.  The tree itself is parallel: reduce_vector_sum.h:12-61 starts thread t of block b from
+// x[512 b + t] + x[512 b + t + 256] and then adds s[t] += s[t + stride] for strides 128 .. 1 -- an XOR BUTTERFLY over the nine index bits
+// of a row inside its block, taken from the highest bit to the lowest (float addition commutes, so the lane that ends up with the sum
+// does not matter), followed by the same tree over the <= 16 block sums.  So:
+//   * 512 threads; wave w owns blocks 2w and 2w+1; lane l holds, per block, the eight rows 64 j + bitrev6(l), j = 0..7, in registers
+//   * strides 256, 128, 64 pair rows INSIDE a lane (j <-> j+4, j+2, j+1); strides 32 .. 1 pair lanes -- with the rows dealt in
+//     bit-reversed order the lane distances come out as 1, 2, .. 32, which is the order wave_reduce_transpose (vk_device.hpp) takes
+//     them in: all 28 values of a block cross the wave in one transposing reduction (DPP moves, no LDS)
+//   * the 16 block sums meet in LDS (double buffered: ONE workgroup barrier per sum) and lanes k < NV of every wave walk the second-level
+//     tree of value k -- the reference's zero padding included: a block beyond the pool is 0.f, strides 128 .. 16 add 0.f (which turns a
+//     -0.f into +0.f, nothing else), a partial block starts from (h0 ? (h1 ? v0 + v1 : v0) : 0.f)
+//   * the 6x6 inverse is the row-per-lane LU of vk_lu.hpp on wave 0 (element updates independent within a pivot step: the bits of the
+//     serial LU), not a serial fp64 chain on one lane
+// Every sum is the reference's tree term by term: the same bits as k_pose_strict (vk_debug_switch "strict_plain" selects that one;
+// tests/test_gpu_strict.py holds the two against each other and both against the reference's own kernels).
+constexpr int SP_THREADS = 512, SP_WAVES = SP_THREADS / 64, SP_SLOTS = 16;  // rows per lane: 2 blocks x 8
+constexpr int SP_MAX_POSES = SP_THREADS * SP_SLOTS;                        // 8192 = cfg.n_poses_to_sample default
+struct StrictParShared {
+    float lvl[2][16][32];  // [parity][block][value]
+    float raw[32];         // the single row of a one-row pool (the reference's loop `while (n > 1)` does not run)
+    int cnt[SP_SLOTS * SP_WAVES + 1];
+    int flag;
+    float cov[21], cinv[21], mean[6];
+};
+// out[k] = sum over rows i < n of row(i)[k], k < NV, in the reference's tree order; rowfn(slot, v) = the NV values of this lane's row in
+// slot `slot` (block 2 wv + slot / 8, row 64 (slot % 8) + bitrev6(lane) of it; called for every slot, rows beyond n are discarded).
+// All threads call it; the result is in every thread.
+// lane_total (optional): the total of value `lane` in lanes < NV of every wave (what the broadcast below reads) -- lets the caller finish
+// per-value work (the refit's 27 divisions by the weight) in one lane per value instead of in every thread.
+template <int NV, typename RowFn>
+__device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared& S, int& parity, float (&out)[NV], float* lane_total = nullptr) {
+#pragma clang fp contract(off)
+    constexpr int P = NV <= 8 ? 8 : 32;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, q = (int)(__brev((unsigned)lane) >> 26);
+    const int nb = (n + 511) / 512;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const int blk = 2 * wv + h, base = blk * 512 + q;
+        float acc[P];
+        // stride 256: rows (j, j + 4); stride 128: (j, j + 2); stride 64: (0, 1)
+        auto pair = [&](int j, float (&s)[NV]) {
+            float v0[NV], v1[NV];
+            rowfn(h * 8 + j, v0);
+            rowfn(h * 8 + j + 4, v1);
+            const bool h0 = base + 64 * j < n, h1 = base + 64 * j + 256 < n;
+            if (n == 1 && threadIdx.x == 0 && h == 0 && j == 0) {
+#pragma unroll
+                for (int k = 0; k < NV; k++) S.raw[k] = v0[k];
+            }
+#pragma unroll
+            for (int k = 0; k < NV; k++) s[k] = h0 ? (h1 ? v0[k] + v1[k] : v0[k]) : 0.f;
+        };
+        {
+            float s0[NV], s2[NV];
+            pair(0, s0); pair(2, s2);
+#pragma unroll
+            for (int k = 0; k < NV; k++) acc[k] = s0[k] + s2[k];
+        }
+        {
+            float s1[NV], s3[NV];
+            pair(1, s1); pair(3, s3);
+#pragma unroll
+            for (int k = 0; k < NV; k++) acc[k] = acc[k] + (s1[k] + s3[k]);
+        }
+#pragma unroll
+        for (int k = NV; k < P; k++) acc[k] = 0.f;
+        const float mine = wave_reduce_transpose<P>(acc);  // strides 32 .. 1 of the rows = lane distances 1 .. 32
+        const int slot = wave_slot<P>(lane);
+        if (lane < P && slot < NV) S.lvl[parity][blk][slot] = mine;
+    }
+    __syncthreads();
+    float tot = 0.f;
+    if (lane < NV) {
+        if (n == 1) tot = S.raw[lane];
+        else if (nb == 1) tot = S.lvl[parity][0][lane];
+        else {
+            float b[16];
+#pragma unroll
+            for (int t = 0; t < 16; t++) b[t] = (t < nb ? S.lvl[parity][t][lane] : 0.f) + 0.f;  // strides 128 .. 16 of the second level add zeros
+#pragma unroll
+            for (int st = 8; st >= 1; st >>= 1)
+#pragma unroll
+                for (int t = 0; t < st; t++) b[t] = b[t] + b[t + st];
+            tot = b[0];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NV; k++) out[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), k));
+    if (lane_total) *lane_total = tot;
+    parity ^= 1;
+}
+
+__global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_par(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp,
+                                                                        CamState* cam, PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev,
+                                                                        float* __restrict__ pool) {
+#pragma clang fp contract(off)
+    __shared__ StrictParShared S;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (*n_points_dev < 4) {  // geometry.cpp:84-88
+        if (t == 0) { cam->success = 0; maybe_decide(mp, P, cam, cam_idx); }
+        return;
+    }
+    // ---- pool of finite hypotheses, in index order (geometry.cpp:156-165): counts per (slice of 512, wave), one prefix, ordered writes
+    auto load6 = [&](int i, float (&v)[6]) {
+        v[0] = rvecs[i]; v[1] = rvecs[(size_t)n_poses + i]; v[2] = rvecs[(size_t)2 * n_poses + i];
+        v[3] = tvecs[i]; v[4] = tvecs[(size_t)n_poses + i]; v[5] = tvecs[(size_t)2 * n_poses + i];
+    };
+    unsigned finbits = 0;
+#pragma unroll
+    for (int k = 0; k < SP_SLOTS; k++) {
+        const int i = k * SP_THREADS + t;
+        bool fin = false;
+        if (i < n_poses) { float v[6]; load6(i, v); fin = isfinite(v[0] + v[1] + v[2] + v[3] + v[4] + v[5]); }
+        const unsigned long long m = __ballot(fin);
+        if (lane == 0) S.cnt[k * SP_WAVES + wv] = __popcll(m);
+        finbits |= fin ? (1u << k) : 0u;
+    }
+    __syncthreads();
+    if (wv == 0) {  // exclusive prefix of the 128 counts
+        const int a = S.cnt[lane], b = S.cnt[64 + lane];
+        int ia = a, ib = b;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const int ta = __shfl_up(ia, o, 64), tb = __shfl_up(ib, o, 64); if (lane >= o) { ia += ta; ib += tb; } }
+        const int tota = __shfl(ia, 63, 64), totb = __shfl(ib, 63, 64);
+        S.cnt[lane] = ia - a; S.cnt[64 + lane] = tota + ib - b;
+        if (lane == 0) S.cnt[SP_SLOTS * SP_WAVES] = tota + totb;
+    }
+    __syncthreads();
+    const int used = S.cnt[SP_SLOTS * SP_WAVES];
+    if (used == 0) {
+        if (t == 0) { cam->success = 0; maybe_decide(mp, P, cam, cam_idx); }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < SP_SLOTS; k++) {
+        const int i = k * SP_THREADS + t;
+        const bool fin = (finbits >> k) & 1u;
+        const unsigned long long m = __ballot(fin);
+        if (fin) {
+            float v[6];
+            load6(i, v);
+            const int r = S.cnt[k * SP_WAVES + wv] + __popcll(m & ((1ull << lane) - 1ull));
+            pool[(size_t)r * 6] = v[0] * mp.rvec_scale; pool[(size_t)r * 6 + 1] = v[1] * mp.rvec_scale; pool[(size_t)r * 6 + 2] = v[2] * mp.rvec_scale;  // :191
+            pool[(size_t)r * 6 + 3] = v[3]; pool[(size_t)r * 6 + 4] = v[4]; pool[(size_t)r * 6 + 5] = v[5];
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    // ---- this lane's rows into registers
+    float X[SP_SLOTS][6];
+    {
+        const int q = (int)(__brev((unsigned)lane) >> 26);
+#pragma unroll
+        for (int sl = 0; sl < SP_SLOTS; sl++) {
+            const int i = (2 * wv + (sl >> 3)) * 512 + 64 * (sl & 7) + q;
+#pragma unroll
+            for (int d = 0; d < 6; d++) X[sl][d] = i < used ? pool[(size_t)i * 6 + d] : 0.f;
+        }
+    }
+    int parity = 0;
+    // ---- mean-shift, meanshift.cu:34-150 (host rand() of :76 -> rng3, as everywhere)
+    const bool external_init = mp.use_external_init_mean < 0 ? (cam->pose_sample_count != 0) : (mp.use_external_init_mean != 0);
+    float io_mean[6], c_mean[6];
+    for (int d = 0; d < 3; d++) { io_mean[d] = cam->rvec[d] * mp.rvec_scale; io_mean[3 + d] = cam->t[d]; }
+    const float two_var = 2 * mp.kernel_var;
+    if (external_init) {
+        for (int d = 0; d < 6; d++) c_mean[d] = io_mean[d];
+    } else {
+        float best = 0;
+        int best_idx = -1;
+        for (int trial = 0; trial < mp.ms_max_init_trials; trial++) {  // :75-95
+            const int idx_rand = (int)(rng3(RAND_SEED, (uint32_t)trial, 0x4D53u) % (uint32_t)used);
+            float c[6];
+            for (int d = 0; d < 6; d++) c[d] = pool[(size_t)idx_rand * 6 + d];
+            auto row = [&](int sl, float (&v)[1]) {
+                float l2 = 0;
+#pragma unroll
+                for (int d = 0; d < 6; d++) { const float df = X[sl][d] - c[d]; l2 += df * df; }
+                v[0] = vsm_expf(-l2 / two_var);
+            };
+            float o1[1];
+            tree_sum_par<1>(used, row, S, parity, o1);
+            const float wsum = o1[0];
+            if (wsum > best) { best = wsum; best_idx = idx_rand; }
+            if (best > mp.ms_good_init_confidence * (float)used) break;
+        }
+        if (best_idx < 0) best_idx = 0;
+        for (int d = 0; d < 6; d++) c_mean[d] = pool[(size_t)best_idx * 6 + d];
+    }
+    int ms_iters = 0;
+    float conf = 0.f;
+    for (int iter = 0; iter < mp.ms_max_iters; iter++) {  // :103-134
+        auto row = [&](int sl, float (&v)[7]) {
+            float l2 = 0;
+#pragma unroll
+            for (int d = 0; d < 6; d++) { const float df = X[sl][d] - c_mean[d]; l2 += df * df; }
+            const float wgt = vsm_expf(-l2 / two_var);
+            v[0] = wgt;
+#pragma unroll
+            for (int d = 0; d < 6; d++) v[1 + d] = X[sl][d] * wgt;
+        };
+        float o7[7];
+        tree_sum_par<7>(used, row, S, parity, o7);
+        const float wsum = o7[0];
+        float m[6];
+        for (int d = 0; d < 6; d++) m[d] = o7[1 + d] / wsum;
+        conf = wsum / (float)used;
+        ms_iters = iter + 1;
+        float disp = 0;
+        for (int d = 0; d < 6; d++) disp += (io_mean[d] - m[d]) * (io_mean[d] - m[d]);  // vs. the stale io mean on the 1st pass (SURVEY B-6)
+        disp = sqrtf(disp);
+        for (int d = 0; d < 6; d++) io_mean[d] = m[d];
+        if (disp < mp.ms_epsilon) break;
+        for (int d = 0; d < 6; d++) c_mean[d] = io_mean[d];
+    }
+    float pose_opm[6];
+    for (int d = 0; d < 6; d++) pose_opm[d] = io_mean[d];
+    float density = conf;
+    int gu_iters = cam->last_used_gu_iters;
+    float covar_out[36];
+    bool write_covar = false;
+    if (mp.do_rg) {  // geometry.cpp:201-246, fit_robust_gaussian.cu:101-286
+        const float sc = mp.rg_pose_scaling;
+        const int N = used;
+        if (t < 21) S.cov[t] = 0.f;
+        __syncthreads();
+        if (t < 6) S.cov[(t * t + t) / 2 + t] = mp.kernel_var * (sc * sc);  // diag(var) *= sc*sc (:203-208)
+        if (t < 6) S.mean[t] = pose_opm[t] * sc;
+        __syncthreads();
+        float weight = 0;
+        int iter = 0;
+        bool reliable = true;
+        gu_iters = 0;  // fit_robust_gaussian.cu:158-159 resets *used_iters on entry
+        for (iter = 0; iter < mp.rg_max_iters; iter++) {
+            if (wv == 0) {  // covar_half_to_full (:17-25), Ledoit-Wolf shrinkage (aux_funs.cpp:124-141), inverse (:101-118): rows in lanes
+                const bool ok = rg_prepare_wave(S.cov, S.cinv, 6, iter > 0 && mp.rg_covar_reg_lambda > 0, mp.rg_covar_reg_lambda);
+                if (lane == 0) S.flag = ok ? 0 : 2;
+            }
+            __syncthreads();
+            if (S.flag == 2) { reliable = false; break; }
+            const float prev_density = weight / (float)N;
+            float mean[6], cinv[21];
+            for (int d = 0; d < 6; d++) mean[d] = S.mean[d];
+            for (int k = 0; k < 21; k++) cinv[k] = S.cinv[k];
+            auto row = [&](int sl, float (&v)[28]) {  // e_step (:56-97)
+                float x[6], diff[6];
+#pragma unroll
+                for (int d = 0; d < 6; d++) { x[d] = X[sl][d] * sc; diff[d] = x[d] - mean[d]; }
+                float z = 0;
+#pragma unroll
+                for (int d1 = 0; d1 < 6; d1++) {
+                    float tmp = 0;
+#pragma unroll
+                    for (int d2 = 0; d2 < 6; d2++) {
+                        const int hi = d1 >= d2 ? d1 : d2, lo = d1 >= d2 ? d2 : d1;
+                        tmp += cinv[(hi * hi + hi) / 2 + lo] * diff[d2];
+                    }
+                    z += tmp * diff[d1];
+                }
+                z = sqrtf(z);
+                const float wgt = z < mp.rg_trunc_sigma ? 1.f : 0.f;
+                v[0] = wgt;
+#pragma unroll
+                for (int d = 0; d < 6; d++) v[1 + d] = wgt * x[d];
+#pragma unroll
+                for (int d1 = 0; d1 < 6; d1++)
+#pragma unroll
+                    for (int d2 = 0; d2 <= d1; d2++) v[7 + (d1 * d1 + d1) / 2 + d2] = wgt * diff[d1] * diff[d2];
+            };
+            float o1[1], mine;
+            // only the weight is needed by every thread; thread k (< 28) of wave 0 finishes value k itself
+            {
+                float o28[28];
+                tree_sum_par<28>(N, row, S, parity, o28, &mine);
+                o1[0] = o28[0];
+            }
+            weight = o1[0];
+            if (!isfinite(weight)) { reliable = false; break; }
+            if (fabsf(weight / (float)N - prev_density) < mp.rg_epsilon) { reliable = true; break; }
+            __syncthreads();  // every thread has read S.mean / S.cinv of this iteration
+            if (t >= 1 && t < 7) S.mean[t - 1] = mine / weight;  // m step (:213-243)
+            else if (t >= 7 && t < 28) S.cov[t - 7] = mine / weight;
+            __syncthreads();
+        }
+        __syncthreads();
+        if (reliable) {
+            density = weight / (float)N; gu_iters = iter;
+            const float isc2 = cv_div_scale(sc * sc);  // pose_covar /= sc*sc (cv::Mat, :224)
+            for (int i1 = 0; i1 < 6; i1++)
+                for (int i2 = 0; i2 < 6; i2++) {
+                    const int hi = i1 >= i2 ? i1 : i2, lo = i1 >= i2 ? i2 : i1;
+                    float cv = S.cov[(hi * hi + hi) / 2 + lo] * isc2;
+                    if (i1 < 3 || i2 < 3) cv /= mp.rvec_scale;  // element-wise at<float>() /= (:226-233)
+                    if (i1 < 3 && i2 < 3) cv /= mp.rvec_scale;
+                    covar_out[i1 * 6 + i2] = cv;
+                }
+            for (int d = 0; d < 6; d++) pose_opm[d] = S.mean[d];
+        } else {
+            for (int k = 0; k < 36; k++) covar_out[k] = 0.f;
+            for (int d = 0; d < 6; d++) pose_opm[d] = pose_opm[d] * sc;  // pose_opm *= sc (:210) stays as it went in
+        }
+        write_covar = true;
+        const float isc = cv_div_scale(sc);  // pose_opm /= sc (:238)
+        for (int d = 0; d < 6; d++) pose_opm[d] *= isc;
+    }
+    {
+        const float irs = cv_div_scale(mp.rvec_scale);  // :249
+        for (int d = 0; d < 3; d++) pose_opm[d] *= irs;
+    }
+    if (t == 0) {
+        bool ok = true;
+        for (int d = 0; d < 6; d++) ok = ok && isfinite(pose_opm[d]);  // checkRange :256
+        cam->pose_sample_count = used;
+        cam->pose_density = density;
+        cam->last_used_ms_iters = ms_iters;
+        cam->last_used_gu_iters = gu_iters;
+        if (write_covar) for (int k = 0; k < 36; k++) cam->covar[k] = covar_out[k];
+        cam->success = ok ? 1 : 0;
+        if (ok) {
+            for (int d = 0; d < 3; d++) { cam->rvec[d] = pose_opm[d]; cam->t[d] = pose_opm[3 + d]; P->ts[cam_idx][d] = pose_opm[3 + d]; }
+            float R[9];
+            angle_axis_to_rotmat(pose_opm, R, true);
+            for (int k = 0; k < 9; k++) P->Rs[cam_idx][k] = R[k];
+        }
+        maybe_decide(mp, P, cam, cam_idx);
+    }
+}
+
 // ---- B-inner, strict: meanshift_gpu / fit_robust_gaussian on a host-supplied sample matrix space[N][dims] ------------------------
 // Same arithmetic as k_pose_strict (the reference's tree-order sums, serial fp64 LU), generic in the dimension like the reference's
 // entry points (meanshift.cu:34-150: dims <= 16; fit_robust_gaussian.cu:101-286: dims <= 6).  io layout as k_meanshift_only /
@@ -563,6 +1014,12 @@ int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamSt
         return (int)hipErrorInvalidValue;
     }
     if (int e = c->pool.reserve(sizeof(float) * 6 * (size_t)n_poses)) return e;
+    if (!debug_switches().strict_plain && n_poses <= SP_MAX_POSES) {  // the parallel tree (same bits)
+        hipLaunchKernelGGL(k_pose_strict_par, dim3(1), dim3(SP_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp, cam_dev, P, cam_idx,
+                           c->n_points.as<int>(), c->pool.as<float>());
+        VK_CHECK_LAST();
+        return 0;
+    }
     hipLaunchKernelGGL(k_pose_strict, dim3(1), dim3(ST_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp, cam_dev, P, cam_idx,
                        c->n_points.as<int>(), c->pool.as<float>());
     VK_CHECK_LAST();

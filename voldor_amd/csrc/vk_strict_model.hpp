@@ -43,6 +43,26 @@ VK_SHD float rigidness(float dx1, float dy1, float dx2, float dy2, float lambda,
     const float p = fisk_pdf(diff_fmag, c, s), mu = fisk_pdf(lambda * obs_fmag, c, s);
     return p / (p + mu);
 }
+// fun_rigidness with its observation-only part split off: c, s and mu = fisk_pdf(lambda |obs|) depend on the OBSERVED flow alone, and frame 0
+// observes at the pixel itself -- every depth hypothesis of a pixel shares them (ten random samples: k_cost_rand_q_strict).  The same
+// operations on the same values in the same order as rigidness() above: the same bits.
+struct RigObs { float c, s, mu, dx2, dy2; };
+VK_SHD RigObs rigidness_obs(float dx2, float dy2, float lambda, float abs_rf) {
+#pragma clang fp contract(off)
+    const float obs_fmag = sqrtf(dx2 * dx2 + dy2 * dy2) / abs_rf;
+    RigObs o;
+    o.c = fmag_c(obs_fmag); o.s = fmag_scale(obs_fmag);
+    o.mu = fisk_pdf(lambda * obs_fmag, o.c, o.s);
+    o.dx2 = dx2; o.dy2 = dy2;
+    return o;
+}
+VK_SHD float rigidness_with(const RigObs& o, float dx1, float dy1, float abs_rf) {
+#pragma clang fp contract(off)
+    const float ex = dx1 - o.dx2, ey = dy1 - o.dy2;
+    const float diff_fmag = sqrtf(ex * ex + ey * ey) / abs_rf;
+    const float p = fisk_pdf(diff_fmag, o.c, o.s);
+    return p / (p + o.mu);
+}
 VK_SHD float depth_rigidness(float d1, float d2, float basefocal, float omega, float abs_rf) {  // fun_depth_rigidness :51-61
 #pragma clang fp contract(off)
     const float disp1 = (basefocal / d1) / abs_rf, disp2 = (basefocal / d2) / abs_rf;

@@ -76,6 +76,12 @@ def run_sharded(sequences, run_window, n_flows: int, group=None, device=None):
     mine = list(shard(len(sequences), rank, world))
     steps = -(-len(sequences) // world)
     results = [None] * len(sequences)
+    # where the collective runs: the caller's `device`, else what the backend needs (nccl = RCCL: this process's current device), else
+    # wherever the previous record of this rank lived -- an idle rank must not feed a CPU tensor to a collective whose peers send
+    # device tensors (it would error or hang on the last, uneven step)
+    coll_dev = device
+    if coll_dev is None and dist.get_backend(group) == "nccl":
+        coll_dev = torch.device("cuda", torch.cuda.current_device())
     for s in range(steps):
         blk = None
         if s < len(mine):
@@ -83,12 +89,14 @@ def run_sharded(sequences, run_window, n_flows: int, group=None, device=None):
             blk = out.get("pose_block")
             if blk is None:
                 blk = pack_pose_block(out, n_flows)
+            elif torch.is_tensor(blk) and coll_dev is None:
+                coll_dev = blk.device
         if blk is None:
             blk = np.zeros(block_len(n_flows), np.float32)
             blk[0] = -1.0  # marks "no sequence in this slot"
-            if device is not None and str(device) != "cpu":
-                blk = torch.from_numpy(blk).to(device)
-        allb = allgather_pose_blocks(blk, group, device)
+            if coll_dev is not None and str(coll_dev) != "cpu":
+                blk = torch.from_numpy(blk).to(coll_dev)
+        allb = allgather_pose_blocks(blk, group, coll_dev)
         for r in range(world):
             sh = list(shard(len(sequences), r, world))
             if s < len(sh) and allb[r, 0] >= 0:
@@ -136,6 +144,18 @@ def capi_max(value: float) -> float:
     v = C.c_double(float(value))
     capi.check(capi.lib().vk_dist_allreduce_max(C.byref(v)), "vk_dist_allreduce_max")
     return float(v.value)
+
+
+def capi_allgather_stats(reset: bool = False):
+    """(dev_us, host_us): latency of every all-gather the library has issued since the last reset (vk_dist_allgather_stats) -- HIP events
+    around ncclAllGather on the communicator's stream, and the host's wall clock from issue to completion -- as numpy arrays."""
+    import ctypes as C
+    from . import capi
+    cap = 65536
+    dev, host = np.zeros(cap, np.float32), np.zeros(cap, np.float32)
+    n = C.c_int(0)
+    capi.check(capi.lib().vk_dist_allgather_stats(capi.fp(dev), capi.fp(host), cap, C.byref(n), int(bool(reset))), "vk_dist_allgather_stats")
+    return dev[:n.value].copy(), host[:n.value].copy()
 
 
 def capi_allgather(send, recv):

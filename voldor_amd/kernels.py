@@ -213,51 +213,3 @@ def set_reference_svd(on: bool):
 
 def get_reference_svd() -> bool:
     return bool(capi.lib().vk_get_reference_svd())
-
-
-def set_local_serial(on: bool):
-    """Verification aid (include/voldor_hip.h: vk_set_local_serial): step-by-step local propagation in fast mode."""
-    capi.check(capi.lib().vk_set_local_serial(int(on)), "vk_set_local_serial")
-
-
-def pose_mode_pool(rvecs, tvecs, init_pose6, use_external_init_mean=True, refit=False, kernel_var=0.2, rvec_scale=1.0, ms_epsilon=1e-5,
-                   ms_max_iters=100, ms_max_init_trials=20, ms_good_init_confidence=0.5, rg_trunc_sigma=3.0, rg_covar_reg_lambda=1e-3,
-                   rg_epsilon=1e-5, rg_max_iters=100, rg_pose_scaling=100.0):
-    """Verification entry (include/voldor_hip.h: vk_pose_mode_pool): the window pipeline's own mode kernel on a pool of hypotheses.
-    Returns dict(pose6, covar [6,6], density, sample_count, ms_iters, gu_iters, success)."""
-    rv, tv = f32(rvecs).reshape(-1, 3), f32(tvecs).reshape(-1, 3)
-    pose = f32(init_pose6).copy().reshape(6)
-    cov = np.zeros((6, 6), np.float32)
-    dens = C.c_float(0)
-    cnt, msi, gui, ok = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
-    capi.check(capi.lib().vk_pose_mode_pool(fp(rv), fp(tv), rv.shape[0], int(use_external_init_mean), fp(pose), C.c_float(kernel_var), C.c_float(rvec_scale),
-                                            C.c_float(ms_epsilon), int(ms_max_iters), int(ms_max_init_trials), C.c_float(ms_good_init_confidence), int(refit),
-                                            C.c_float(rg_trunc_sigma), C.c_float(rg_covar_reg_lambda), C.c_float(rg_epsilon), int(rg_max_iters),
-                                            C.c_float(rg_pose_scaling), fp(cov), C.byref(dens), C.byref(cnt), C.byref(msi), C.byref(gui), C.byref(ok)),
-               "vk_pose_mode_pool")
-    return dict(pose6=pose, covar=cov, density=dens.value, sample_count=cnt.value, ms_iters=msi.value, gu_iters=gui.value, success=ok.value)
-
-
-def set_refit_partition(on: bool):
-    """Verification aid (include/voldor_hip.h: vk_set_refit_partition): distance partition of the refit's pool (default) or none."""
-    capi.check(capi.lib().vk_set_refit_partition(int(on)), "vk_set_refit_partition")
-
-
-def set_fb_segment(steps: int):
-    """Tuning / verification aid (include/voldor_hip.h: vk_set_fb_segment): 0 = by size, 20 / 40 = steps per lane of the segmented fb_smooth."""
-    capi.check(capi.lib().vk_set_fb_segment(int(steps)), "vk_set_fb_segment")
-
-
-def set_global_split(on: bool):
-    """Verification aid (include/voldor_hip.h: vk_set_global_split): lanes-per-site evaluation of the global propagation (default) or one lane per site."""
-    capi.check(capi.lib().vk_set_global_split(int(on)), "vk_set_global_split")
-
-
-def set_cost_rand_plain(on: bool):
-    """Verification aid (include/voldor_hip.h: vk_set_cost_rand_plain): sample pass as the plain sequential loop instead of rejection + survivor queue."""
-    capi.check(capi.lib().vk_set_cost_rand_plain(int(on)), "vk_set_cost_rand_plain")
-
-
-def set_split_trials(on: bool):
-    """Verification aid (include/voldor_hip.h: vk_set_split_trials): initial-mode trials as their own workgroups (default) or inside the mode kernel."""
-    capi.check(capi.lib().vk_set_split_trials(1 if on else 0), "vk_set_split_trials")
