@@ -130,6 +130,37 @@ def _gpu_only(flows, Rs, ts, depth, rig, K, epoch=5, priors=None, pconfs=None, c
                                       kw["update_rigidness_only"])
 
 
+@pytest.mark.parametrize("w,h,noise,n_flows,n_dp", [(211, 97, 0.3, 4, 0), (640, 480, 0.1, 5, 0), (320, 240, 0.02, 5, 1), (353, 289, 0.2, 9, 0), (96, 64, 0.3, 13, 2), (31, 17, 0.3, 3, 0)])
+def test_fused_local_passes_equal_the_four_launches(w, h, noise, n_flows, n_dp):
+    """k_local_fused_lean -- the four local passes of a call as ONE launch, a workgroup per 32 x 32 tile (closed under row and column chains
+    of width 32), 8 or 16 waves per tile (measured slower than one launch per pass at every size and therefore behind
+    vk_debug_switch "local_fused", default 0) -- against one launch per pass: identical depth, rigidness and prior-confidence maps, bit for
+    bit; ragged sizes (partial tiles on both edges, an image smaller than a tile), up to 13 frames, priors."""
+    from voldor_amd import synth
+    sc = synth.make_scene(w=w, h=h, n_flows=n_flows, fx=0.5 * w, fy=0.5 * w, cx=0.5 * w, cy=0.5 * h, seed=23, basefocal=40.0 if n_dp else 0.0)
+    rng = np.random.default_rng(w * 7 + h)
+    K = K9(*sc["K"])
+    flows, Rs, ts, depth, rig = _state(sc, rng, noise=noise)
+    extra = {}
+    if n_dp:
+        pri = np.stack([(sc["depth_gt"] * (1 + rng.normal(0, 0.05, (h, w)))).astype(np.float32) for _ in range(n_dp)])
+        pri[:, ::7, ::5] = 0.0
+        extra = dict(priors=pri, pconfs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32), confs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32),
+                     dp_Rs=np.tile(np.eye(3, dtype=np.float32), (n_dp, 1, 1)), dp_ts=(rng.normal(0, 0.02, (n_dp, 3)) * np.arange(n_dp)[:, None]).astype(np.float32))
+    over = dict(n_rand_samples=3, global_prop_step=5, local_prop_width=32, fb_smooth=0, basefocal=40.0 if n_dp else 0.0, disp_delta=1.0 if n_dp else -1.0)
+    out = {}
+    try:
+        for waves in (0, 8, 16):
+            hooks.set_local_fused(waves)
+            out[waves] = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
+    finally:
+        hooks.set_local_fused(0)
+    assert np.mean(out[0][0] != depth) > 0.02  # the passes did replace depths
+    for waves in (8, 16):
+        for a, b in zip(out[0][:3 if n_dp else 2], out[waves]):
+            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 @pytest.mark.parametrize("width,noise,n_flows,n_dp", [(32, 0.3, 4, 0), (32, 0.02, 5, 0), (33, 0.1, 5, 1), (7, 0.3, 3, 0), (64, 0.3, 9, 0),
                                                         (65, 0.05, 13, 2), (5, 0.0, 2, 0), (32, 0.1, 16, 0), (32, 0.2, 6, 5), (32, 0.2, 8, 0), (33, 0.1, 7, 1), (32, 0.2, 10, 0), (32, 0.1, 12, 1)])
 def test_local_runs_equal_the_step_by_step_chain(width, noise, n_flows, n_dp):

@@ -1023,22 +1023,17 @@ __global__ __launch_bounds__(64) static void k_global_prop_split_lean(Img I, int
 // Every cost that is used was evaluated for exactly the (pixel, value) the step-by-step chain evaluates: identical maps (tests:
 // vk_set_local_serial).  Both chains of a wave share one evaluation per round whatever state each is in; only the cheap
 // bookkeeping diverges.
-template <int HALF, int NMAX, int LPP, bool STRICT = false>
-__global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, int width, const float* __restrict__ tbl, int lines, int nchains) {
-    if (!clamp_active(I)) return;
+// The chains of ONE wave (two of up to 32 steps, or one of up to 64): cg / n = the chain of this lane's half (n <= 0: none).  Called by
+// k_local_runs_lean (one launch per pass) and by k_local_fused_lean (all four passes of a tile in one launch).
+template <int HALF, int NMAX, int LPP, bool STRICT>
+__device__ __forceinline__ static void local_runs_body(const Img& I, const LeanK& K, const ChainGeom cg, const int n, const float* __restrict__ tbl) {
     PHD_DECL;
-    constexpr int NH = 64 / HALF, NG = HALF / LPP;  // chains per wave, pixels per round
+    constexpr int NG = HALF / LPP;  // pixels per round
     constexpr int NP = NG >= 8 ? 4 : NG / 2, R = NG / NP;  // pixels per planned run, planned runs per round
-    const int lane = threadIdx.x, half = lane / HALF, hl = lane % HALF, g = hl / LPP, sub = hl % LPP;
-    const int tile = xcd_band_tile(blockIdx.x, gridDim.x);
-    const int chain = tile * NH + half;
-    const bool in_range = chain < nchains;
-    const ChainGeom cg = chain_geom(I.w, I.h, dir, width, in_range ? chain % lines : 0, in_range ? chain / lines : 0);
-    const int n = in_range ? cg.n : 0;
+    const int lane = threadIdx.x & 63, half = lane / HALF, hl = lane % HALF, g = hl / LPP, sub = hl % LPP;
     const unsigned long long hmask = HALF == 64 ? ~0ull : (0xffffffffull << (32 * half));
     const int hshift = HALF == 64 ? 0 : 32 * half;
     if (n <= 0) return;  // (a whole half leaves together; the other half's ballots are masked to itself)
-    const LeanK K = lean_consts(I);
     const bool has = hl < n;
     const int mypi = has ? cg.pi0 + hl * cg.stride : cg.pi0;
     const float d0 = has ? I.depth[mypi] : 0.f, c0 = has ? I.cost[mypi] : 0.f;
@@ -1124,6 +1119,55 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
 #ifdef VK_PHASE_CLOCKS
     if (hl == 0) atomicAdd(&g_phase_d[16 + min(rounds_, 31)], 1ull);  // histogram of the rounds a chain's half took part in
 #endif
+}
+template <int HALF, int NMAX, int LPP, bool STRICT = false>
+__global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, int width, const float* __restrict__ tbl, int lines, int nchains) {
+    if (!clamp_active(I)) return;
+    constexpr int NH = 64 / HALF;  // chains per wave
+    const int half = threadIdx.x / HALF;
+    const int tile = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int chain = tile * NH + half;
+    const bool in_range = chain < nchains;
+    const ChainGeom cg = chain_geom(I.w, I.h, dir, width, in_range ? chain % lines : 0, in_range ? chain / lines : 0);
+    local_runs_body<HALF, NMAX, LPP, STRICT>(I, lean_consts(I), cg, in_range ? cg.n : 0, tbl);
+}
+// ALL FOUR local passes of a call in one launch -- built, identical maps, and SLOWER at every size (kill criterion of
+// the verdict: cfg5 had to drop by 15 %; measured cfg2 3.90 -> 4.05 ms per window, cfg3 6.95 -> 6.97 / 7.12, cfg5 28.5 -> 31.9 ms with 16 waves per
+// tile, 37.5 with 8): kept behind vk_debug_switch "local_fused" as the record of the experiment, not on the product path.  Why it loses: a
+// pass of the four-launch form has every chain pair of the image resident at once (4.7 waves per SIMD at 640x480) and its slow chains
+// overlap with everybody's table evaluations; a tile's workgroup has to carry 16 chain pairs through FOUR dependent passes on at most
+// 16 waves, pays a barrier per pass on ITS slowest chain, and a tile whose workgroup is still in pass 2 holds registers that the
+// next tiles' table evaluations would have used.  The tail of a launch was not what bounded the four-launch form.
+// A local pass walks chains of `width` steps inside segments that
+// start at multiples of `width` (optimize_depth.cu:242-265); a step reads the pixel before it in the SAME segment.  A width x width tile is
+// therefore closed under the row passes and under the column passes: nothing a chain of the tile reads or writes (depth, cost) lies
+// outside the tile -- the flows, rigidness maps and priors it gathers are read-only during the M-step.  So a workgroup takes one tile
+// through L2R, B2T, R2L, T2B with a workgroup barrier between the passes and no launch boundary: a tile moves on when ITS chains are done,
+// not when the slowest chain of the image is (a pass used to end on chains with 5-7 planned runs: 80 % of the chains have none; 1080p:
+// avg 144 us, max 449 per launch), and three launches per call disappear.  Wave j of the workgroup takes chain pairs j, j + NW, .. of
+// the tile's 32 chains; every chain is the chain of k_local_runs_lean (own table at its head, planned runs): identical maps
+// (vk_debug_switch "local_fused" = 0 is the four-launch form; tests/test_gpu_kernels.py::test_fused_local_passes_equal_the_four_launches).
+template <int NMAX, int LPP, int NW, bool STRICT = false>
+__global__ __launch_bounds__(64 * NW) static void k_local_fused_lean(Img I, int tiles_x) {
+    if (!clamp_active(I)) return;
+    constexpr int W = 32;
+    const LeanK K = lean_consts(I);
+    const int tile = xcd_band_tile(blockIdx.x, gridDim.x);
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int wv = threadIdx.x >> 6, half = (threadIdx.x & 63) >> 5;  // (the planned form described below; see the note above for the outcome)
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        const int dir = k == 0 ? 0 : k == 1 ? 3 : k == 2 ? 2 : 1;  // L2R, B2T, R2L, T2B (optimize_depth.cu:487-490)
+        const bool rowpass = dir == 0 || dir == 2;
+#pragma unroll 1
+        for (int q = wv; q < W / 2; q += NW) {
+            const int line = (rowpass ? ty : tx) * W + 2 * q + half;
+            const bool in_range = line < (rowpass ? I.h : I.w);
+            const ChainGeom cg = chain_geom(I.w, I.h, dir, W, in_range ? line : 0, rowpass ? tx : ty);
+            local_runs_body<32, NMAX, LPP, STRICT>(I, K, cg, in_range ? cg.n : 0, nullptr);
+        }
+        __syncthreads();  // the tile's depth / cost of this pass are visible to the chains of the next one
+    }
 }
 // E-step (optimize_depth.cu:84-138), lean geometry and model; per-block rigidness sums as k_update_rigidness
 template <int NMAX>
@@ -1592,6 +1636,15 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
                     hipLaunchKernelGGL((k_global_prop_serial<NMAX, STRICT>), dim3((lines + 63) / 64), dim3(64), 0, c->stream, I, dir);
             }
         }
+        const int fused = debug_switches().local_fused;  // 0: four launches; 8 / 16: waves per tile of the fused kernel
+        if (p.local_prop_width == 32 && fused > 0 && !(STRICT ? plain : debug_switches().local_serial != 0)) {
+            if (c->prof) prof_begin_inner(c);
+            const int tiles_x = (w + 31) / 32, tiles_y = (h + 31) / 32;
+            constexpr int LR_LPP = NMAX <= 8 ? 4 : 8;
+            if (fused >= 16) hipLaunchKernelGGL((k_local_fused_lean<NMAX, LR_LPP, 16, STRICT>), dim3(tiles_x * tiles_y), dim3(1024), 0, c->stream, I, tiles_x);
+            else hipLaunchKernelGGL((k_local_fused_lean<NMAX, LR_LPP, 8, STRICT>), dim3(tiles_x * tiles_y), dim3(512), 0, c->stream, I, tiles_x);
+            if (c->prof) prof_end_inner(c, "local_pass", 4);
+        } else
         if (p.local_prop_width > 0) {
             if (c->prof) prof_begin_inner(c);
             for (int k = 0; k < 4; k++) {

@@ -27,6 +27,7 @@ struct DebugSwitches {
     int global_split = 1;      // 0: global propagation with one lane per site
     int refit_partition = 1;   // 0: every gate pass of the refit walks the whole pool in its arrival order
     int split_trials = 1;      // 0: the mode kernel runs the initial-mode trials itself
+    int local_fused = 0;       // (experiment, measured and NOT adopted: DESIGN.md section 6) 8 / 16: the four local passes of a call as ONE launch over 32 x 32 tiles with that many waves per tile; 0: one launch per pass
     int newton_cap = 0;        // (experiment, measured and NOT adopted: DESIGN.md section 6) Newton steps of the P3P cubic in the FAST window pipeline: 0 = the reference's 50; an even cap <= 50 otherwise; strict mode always 50
     int strict_own_table = 0;  // (tuning) strict local pass: 1 = every chain tabulates its own steps at the head of the runs kernel, 0 = the tiled table kernel
     int strict_lpp8 = 0;       // (tuning) strict local pass: 8 lanes per pixel instead of 4 for up to 8 frames
