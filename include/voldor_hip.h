@@ -129,6 +129,16 @@ int vk_get_strict_math(void);
  * --strict_math 1 --reference_draw 1 a window then equals the reference pipeline's strict-math window in every output bit. */
 int vk_set_reference_svd(int on);
 int vk_get_reference_svd(void);
+/* Reference mode, the last two stand-ins (process-wide defaults, also VOLDOR_HIP_REFERENCE_RNG / _TEX = 1; config keys --reference_rng /
+ * --reference_tex 0|1; effective with strict math only): the depth samples and the hypothesis draws from cuRAND's XORWOW streams as the
+ * reference seeds and advances them (gpu-kernels/optimize_depth.cu:273,286-291; solve_batch_lambdatwist.cu:16-19,44-48) instead of the
+ * counter generator, and every at_tex of the reference (gpu-kernels/gmat.h:49-62,175-179) through CUDA's linear texture filter -- 8-bit
+ * fractions, one texture over the stacked layers -- instead of the exact per-layer bilinear; both restated from their published
+ * definitions in voldor_amd/csrc/vk_ref_cuda.h. */
+int vk_set_reference_rng(int on);
+int vk_get_reference_rng(void);
+int vk_set_reference_tex(int on);
+int vk_get_reference_tex(void);
 int vk_profile_enable(int on);           /* HIP-event timing of kernel groups on the library's stream */
 int vk_profile_get(const char* name, double* total_ms, long* count);
 int vk_device_count(void);

@@ -130,6 +130,16 @@ void orc_last_two_view_translation(float* t3); /* test hook: recoverPose-style t
 void orc_set_rodrigues_hook(void (*fn)(const float* R9, float* rvec3, float* Rproj9)); /* test hook, see orc_pose.c */
 /* --reference_svd 1 of the product: orc_rodrigues projects with the reference's approximate SVD (svd3_cuda.h:36-1044 restated to the bit
  * in voldor_amd/csrc/vk_ref_svd.h, shared with the HIP kernels like vk_strict_math.h) instead of the exact polar factor (D8) */
+/* reference mode, round 4 (voldor_amd/csrc/vk_ref_cuda.h): cuRAND XORWOW streams as the reference seeds them (D1 off) / CUDA's
+ * 8-bit-fraction linear filter over the stacked layers (D2 off) */
+void orc_set_reference_rng(int on);
+void orc_set_reference_tex(int on);
+int orc_get_reference_rng(void);
+int orc_get_reference_tex(void);
+const uint32_t* orc_xorwow_jumps(void); /* [32][800]: T^(2^67 * 2^k) of the XORWOW transition */
+void orc_xorwow_stream(unsigned long long seed, uint32_t sub, int n, uint32_t* raw, float* uni, uint32_t* state6);
+float orc_fetch1(const float* stack, int f, int n_layers, int w, int h, float x, float y);
+void orc_fetch2(const float* stack, int f, int n_layers, int w, int h, float x, float y, float* ox, float* oy);
 void orc_set_reference_svd(int on);
 int orc_get_reference_svd(void);
 void orc_reference_project_rotation(const float* R9, float* Q9); /* rodrigues.h:82-108 alone */

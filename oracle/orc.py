@@ -23,7 +23,7 @@ def build(force: bool = False) -> None:
     """Compile liborc.so (and oracle/_ref when /root/reference exists)."""
     so = os.path.join(_HERE, "liborc.so")
     srcs = [os.path.join(_HERE, f) for f in ("orc_model.c", "orc_pose.c", "orc_voldor.c", "orc_align.c", "orc_lambdatwist_impl.h", "orc.h", "orc_math.h",
-                                         "../voldor_amd/csrc/vk_strict_math.h", "../voldor_amd/csrc/vk_ref_svd.h")]
+                                         "../voldor_amd/csrc/vk_strict_math.h", "../voldor_amd/csrc/vk_ref_svd.h", "../voldor_amd/csrc/vk_ref_cuda.h")]
     stale = force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs)
     ref_so = os.path.join(_HERE, "_ref", "libvoldor_ref.so")
     want_ref = False

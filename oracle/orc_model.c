@@ -50,6 +50,54 @@ uint32_t orc_rng(uint32_t seed, uint32_t stream, uint32_t counter) {
 }
 float orc_u01(uint32_t r) { return (float)((r >> 8) + 1u) * (1.0f / 16777216.0f); }
 
+/* ---- reference mode, round 4: D1 and D2 switched back to CUDA's published behaviour (voldor_amd/csrc/vk_ref_cuda.h, shared with the
+ * product and with the launch-emulation layer of the reference build).  orc_set_reference_rng(1): cuRAND XORWOW streams as the
+ * reference seeds and advances them; orc_set_reference_tex(1): 8-bit-fraction linear filtering over the STACKED layers. */
+#include "../voldor_amd/csrc/vk_ref_cuda.h"
+static int g_ref_rng = 0, g_ref_tex = 0;
+void orc_set_reference_rng(int on) { g_ref_rng = on ? 1 : 0; }
+void orc_set_reference_tex(int on) { g_ref_tex = on ? 1 : 0; }
+int orc_get_reference_rng(void) { return g_ref_rng; }
+int orc_get_reference_tex(void) { return g_ref_tex; }
+static uint32_t* g_xw_J = NULL;  /* [32][VRC_XW_MAT] sequence jumps, built once */
+const uint32_t* orc_xorwow_jumps(void) {
+    if (!g_xw_J) {
+#pragma omp critical(orc_xw_jumps)
+        if (!g_xw_J) {
+            uint32_t* J = (uint32_t*)malloc(sizeof(uint32_t) * 32 * VRC_XW_MAT);
+            vrc_build_sequence_jumps(J);
+            g_xw_J = J;
+        }
+    }
+    return g_xw_J;
+}
+/* test access: state after curand_init(seed, sub, 0) and the first n outputs of curand_uniform / curand */
+void orc_xorwow_stream(unsigned long long seed, uint32_t sub, int n, uint32_t* raw, float* uni, uint32_t* state6) {
+    vrc_xorwow s;
+    vrc_xorwow_init(orc_xorwow_jumps(), seed, sub, &s);
+    if (state6) { for (int k = 0; k < 5; k++) state6[k] = s.v[k]; state6[5] = s.d; }
+    for (int i = 0; i < n; i++) { const uint32_t x = vrc_xorwow_next(&s); if (raw) raw[i] = x; if (uni) uni[i] = vrc_uniform(x); }
+}
+/* per-pixel states of the depth sampling (optimize_depth.cu:286-291: initialised when the size changes, then one draw per pixel per
+ * sample launch, persisting): a cache that stands `epoch` draws after curand_init; rebuilt when the caller's epoch does not continue it */
+static vrc_xorwow* g_px_states = NULL;
+static int g_px_n = 0;
+static uint32_t g_px_epoch = 0;
+static vrc_xorwow* pixel_states(int npx, uint32_t epoch) {
+    if (g_px_n != npx || g_px_epoch != epoch || !g_px_states) {
+        const uint32_t* J = orc_xorwow_jumps();
+        free(g_px_states);
+        g_px_states = (vrc_xorwow*)malloc(sizeof(vrc_xorwow) * (size_t)npx);
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < npx; i++) {
+            vrc_xorwow_init(J, 233ull, (uint32_t)i, &g_px_states[i]);
+            for (uint32_t e = 0; e < epoch; e++) (void)vrc_xorwow_next(&g_px_states[i]);
+        }
+        g_px_n = npx; g_px_epoch = epoch;
+    }
+    return g_px_states;
+}
+
 /* ------------------------------------------------------------------ residual model
  * residual_model.h:6-13 */
 #define EST_RF 0.5
@@ -168,6 +216,16 @@ void orc_bilinear2(const float* img, int w, int h, float x, float y, float* ox, 
     *oy = w00 * p00[1] + w10 * p10[1] + w01 * p01[1] + w11 * p11[1];
 }
 
+/* at_tex of layer f of a stack of n_layers (gmat.h:175-179): D2's exact per-layer bilinear, or CUDA's filter over the stack */
+float orc_fetch1(const float* stack, int f, int n_layers, int w, int h, float x, float y) {
+    if (g_ref_tex) return vrc_tex_fetch1(stack, x, y, f, w, h, n_layers);
+    return orc_bilinear1(stack + (size_t)f * w * h, w, h, x, y);
+}
+void orc_fetch2(const float* stack, int f, int n_layers, int w, int h, float x, float y, float* ox, float* oy) {
+    if (g_ref_tex) { vrc_tex_fetch2(stack, x, y, f, w, h, n_layers, ox, oy); return; }
+    orc_bilinear2(stack + (size_t)f * w * h * 2, w, h, x, y, ox, oy);
+}
+
 /* ------------------------------------------------------------------ pixel cost
  * optimize_depth.cu:140-198 */
 typedef struct {
@@ -187,7 +245,7 @@ static float pixel_cost(const cost_ctx* c, int px, int py, float depth) {
         p3_to_p2(&c->k, o, &px2, &py2);
         if (o[2] > 0 && px1 >= 0 && px1 < w && py1 >= 0 && py1 < h) {
             float d2x, d2y;
-            orc_bilinear2(c->flows + (size_t)f * npx * 2, w, h, px1, py1, &d2x, &d2y);
+            orc_fetch2(c->flows, f, p->N, w, h, px1, py1, &d2x, &d2y);
             float dx1 = px2 - px1, dy1 = py2 - py1;
             px1 = px2; py1 = py2;
             fun_cost(dx1, dy1, d2x, d2y, c->rig[(size_t)f * npx + py * w + px], &cost_sum, &wsum,
@@ -199,9 +257,9 @@ static float pixel_cost(const cost_ctx* c, int px, int py, float depth) {
         trans_p3(o, p->dp_Rs[f], p->dp_ts[f]);
         p3_to_p2(&c->k, o, &px1, &py1);
         if (o[2] > 0 && px1 >= 0 && px1 < w && py1 >= 0 && py1 < h) {
-            float td = orc_bilinear1(c->priors + (size_t)f * npx, w, h, px1, py1);
-            float tpc = orc_bilinear1(c->pconfs + (size_t)f * npx, w, h, px1, py1);
-            float tc = orc_bilinear1(c->confs + (size_t)f * npx, w, h, px1, py1);
+            float td = orc_fetch1(c->priors, f, p->N_dp, w, h, px1, py1);
+            float tpc = orc_fetch1(c->pconfs, f, p->N_dp, w, h, px1, py1);
+            float tc = orc_fetch1(c->confs, f, p->N_dp, w, h, px1, py1);
             if (td > 0) {
                 if (p->disp_delta > 0 && f == 0)
                     fun_depth_cost(o[2], td, p->basefocal, tpc * tc * p->disp_delta, &cost_sum, &wsum,
@@ -251,7 +309,7 @@ void orc_update_rigidnesses(const orc_od_params* p, const float* flows, float* r
                 p3_to_p2(&k, o, &px2, &py2);
                 if (o[2] > 0 && px1 >= 0 && px1 < w && py1 >= 0 && py1 < h) {
                     float d2x, d2y;
-                    orc_bilinear2(flows + (size_t)f * npx * 2, w, h, px1, py1, &d2x, &d2y);
+                    orc_fetch2(flows, f, p->N, w, h, px1, py1, &d2x, &d2y);
                     float dx1 = px2 - px1, dy1 = py2 - py1;
                     px1 = px2; py1 = py2;
                     rig[(size_t)f * npx + y * w + x] =
@@ -265,7 +323,7 @@ void orc_update_rigidnesses(const orc_od_params* p, const float* flows, float* r
                 trans_p3(o, p->dp_Rs[f], p->dp_ts[f]);
                 p3_to_p2(&k, o, &px1, &py1);
                 if (o[2] > 0 && px1 >= 0 && px1 < w && py1 >= 0 && py1 < h) {
-                    float td = orc_bilinear1(priors + (size_t)f * npx, w, h, px1, py1);
+                    float td = orc_fetch1(priors, f, p->N_dp, w, h, px1, py1);
                     if (td > 0) /* else: conf left untouched (:129) */
                         confs[(size_t)f * npx + y * w + x] =
                             orc_fun_depth_rigidness(o[2], td, p->basefocal, p->omega, p->abs_resize_factor);
@@ -326,10 +384,12 @@ void orc_fb_smooth(float* maps, int n_maps, int w, int h, float s0_ems_prob, flo
 /* optimize_depth.cu:269-277 with deviation D1 for the uniform */
 static void pass_rand(const cost_ctx* c, float* depth, float* cost, uint32_t epoch) {
     const int w = c->p->w, h = c->p->h;
+    vrc_xorwow* states = g_ref_rng ? pixel_states(w * h, epoch) : NULL;  /* curand_uniform(&_d_rand_states.at(x, y)) */
+    if (states) g_px_epoch = epoch + 1;
 #pragma omp parallel for schedule(static)
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
-            float u = orc_u01(orc_rng(233u, (uint32_t)(y * w + x), epoch));
+            float u = states ? vrc_uniform(vrc_xorwow_next(&states[y * w + x])) : orc_u01(orc_rng(233u, (uint32_t)(y * w + x), epoch));
             float depth_rnd = 1.0f / (c->p->range_factor * u + (1.0f / MAXIMUM_DEPTH));
             replace_if_better(c, x, y, depth_rnd, &depth[y * w + x], &cost[y * w + x]);
         }

@@ -42,6 +42,10 @@ int orc_lambdatwist_p4p(const float* y8, const float* x12, float fx, float fy, f
 /* ------------------------------------------------------------------ collect_p3p
  * collect_p3p_instances.cu:38-55 helpers, :57-67 rigidness sum, :70-145 map kernel */
 extern void orc_bilinear2(const float* img, int w, int h, float x, float y, float* ox, float* oy);
+extern void orc_fetch2(const float* stack, int f, int n_layers, int w, int h, float x, float y, float* ox, float* oy);  /* at_tex: D2 or CUDA's filter (orc_set_reference_tex) */
+extern int orc_get_reference_rng(void);
+extern const uint32_t* orc_xorwow_jumps(void);
+#include "../voldor_amd/csrc/vk_ref_cuda.h"
 
 void orc_collect_p3p(const float* flows, const float* rig, const float* depth, const float* K,
                      const float (*Rs)[9], const float (*ts)[3], float* p2_map, float* p3_map,
@@ -83,7 +87,7 @@ void orc_collect_p3p(const float* flows, const float* rig, const float* depth, c
                     }
                     if (px > 0 && px < w && py > 0 && py < h) { /* strict, :120 */
                         float fx_, fy_;
-                        orc_bilinear2(flows + (size_t)i * npx * 2, w, h, px, py, &fx_, &fy_);
+                        orc_fetch2(flows, i, N, w, h, px, py, &fx_, &fy_);
                         px += fx_; py += fy_;
                     } else { out = 1; break; }
                 }
@@ -123,8 +127,11 @@ int orc_compact_p3p(const float* p2_map, const float* p3_map, int npx, float* pt
 /* solve_batch_lambdatwist.cu:16-19 with deviations D1 (RNG) and D3 (clamp). The reference
  * re-seeds per call (:80-81), so the pattern depends only on (idx, n_pts). */
 void orc_pose_sample_indices(int idx, int n_pts, int out4[4]) {
+    vrc_xorwow st;
+    const int xw = orc_get_reference_rng();
+    if (xw) vrc_xorwow_init(orc_xorwow_jumps(), 233ull, (uint32_t)idx, &st);  /* curand_init(RAND_SEED, idx, 0, ..) per call (:44-48) */
     for (int k = 0; k < 4; k++) {
-        float u = orc_u01(orc_rng(233u, (uint32_t)idx, (uint32_t)k));
+        float u = xw ? vrc_uniform(vrc_xorwow_next(&st)) : orc_u01(orc_rng(233u, (uint32_t)idx, (uint32_t)k));
         int i = (int)(u * (float)n_pts);
         if (i > n_pts - 1) i = n_pts - 1;
         out4[k] = i;

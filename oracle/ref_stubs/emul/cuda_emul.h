@@ -91,13 +91,27 @@ static inline uint32_t emul_rng3(uint32_t seed, uint32_t stream, uint32_t counte
     return h;
 }
 static inline int emul_host_rand() { return (int)(emul_rng3(233u, emul_rand_trial++, 0x4D53u) % emul_rand_mod); }
-struct curandState { uint32_t seed, stream, counter; };
+/* ref_set_reference_rng(1) / ref_set_reference_tex(1) (round 4): D1 / D2 OFF -- cuRAND's XORWOW and CUDA's linear texture filter restated
+ * from their published definitions (voldor_amd/csrc/vk_ref_cuda.h, the header the oracle and the HIP kernels use for the same switches) */
+#include "../../../voldor_amd/csrc/vk_ref_cuda.h"
+extern "C" int ref_reference_rng, ref_reference_tex;
+static uint32_t* emul_xw_J = nullptr;
+static inline const uint32_t* emul_xw_jumps() {
+    if (!emul_xw_J) { emul_xw_J = (uint32_t*)malloc(sizeof(uint32_t) * 32 * VRC_XW_MAT); vrc_build_sequence_jumps(emul_xw_J); }
+    return emul_xw_J;
+}
+struct curandState { uint32_t seed, stream, counter; vrc_xorwow xw; };
 static uint32_t emul_curand_epoch = 0;  /* the wrapper's stand-in for "states persist across calls": added to the offset */
 extern "C" unsigned int ref_rand_salt; /* ref_set_rand_salt: "the reference run again with another seed of its random streams" (0 = RAND_SEED as is) */
 static inline void curand_init(unsigned long long seed, unsigned long long sequence, unsigned long long offset, curandState* s) {
     s->seed = (uint32_t)seed ^ (ref_rand_salt * 0x9E3779B1u); s->stream = (uint32_t)sequence; s->counter = (uint32_t)offset + emul_curand_epoch;
+    if (ref_reference_rng) {  /* curand_init(seed, subsequence, offset): seed scramble, subsequence * 2^67 outputs skipped, then `offset` outputs */
+        vrc_xorwow_init(emul_xw_jumps(), seed ^ (unsigned long long)(ref_rand_salt * 0x9E3779B1u), (uint32_t)sequence, &s->xw);
+        for (uint32_t e = 0; e < s->counter; e++) (void)vrc_xorwow_next(&s->xw);
+    }
 }
 static inline float curand_uniform(curandState* s) {  /* (0, 1] like cuRAND */
+    if (ref_reference_rng) return vrc_uniform(vrc_xorwow_next(&s->xw));
     const uint32_t r = emul_rng3(s->seed, s->stream, s->counter++);
     return (float)((r >> 8) + 1u) * (1.0f / 16777216.0f);
 }
@@ -147,12 +161,14 @@ static inline void emul_bil_idx(float x, float y, int w, int h, int& x0, int& x1
     x0 = ix; x1 = ix1; y0 = iy; y1 = iy1;
 }
 template <> inline float GMat<float>::at_tex(const float x, const float y, const int d) const {
+    if (ref_reference_tex) return vrc_tex_fetch1(ptr, x, y, d, _width, _height, _depth);  /* gmat.h:49-62, :175-179: one texture over the stacked layers */
     int x0, x1, y0, y1; float a, b;
     emul_bil_idx(x, y, _width, _height, x0, x1, y0, y1, a, b);
     const float* m = ptr + (size_t)d * _height * _width;
     return (1.f - a) * (1.f - b) * m[y0 * _width + x0] + a * (1.f - b) * m[y0 * _width + x1] + (1.f - a) * b * m[y1 * _width + x0] + a * b * m[y1 * _width + x1];
 }
 template <> inline float2 GMat<float2>::at_tex(const float x, const float y, const int d) const {
+    if (ref_reference_tex) { float2 r; vrc_tex_fetch2(&ptr->x, x, y, d, _width, _height, _depth, &r.x, &r.y); return r; }
     int x0, x1, y0, y1; float a, b;
     emul_bil_idx(x, y, _width, _height, x0, x1, y0, y1, a, b);
     const float2* m = ptr + (size_t)d * _height * _width;

@@ -159,6 +159,10 @@ int ref_math_mode = 0;
 void ref_set_math_mode(int mode) { ref_math_mode = mode; }
 unsigned int ref_rand_salt = 0;
 void ref_set_rand_salt(unsigned int salt) { ref_rand_salt = salt; }
+// round 4: cuRAND XORWOW streams / CUDA linear texture filtering instead of the stand-ins D1 / D2 (cuda_emul.h, vk_ref_cuda.h)
+int ref_reference_rng = 0, ref_reference_tex = 0;
+void ref_set_reference_rng(int on) { ref_reference_rng = on ? 1 : 0; }
+void ref_set_reference_tex(int on) { ref_reference_tex = on ? 1 : 0; }
 unsigned int ref_jitter_salt = 0;
 void ref_set_jitter_salt(unsigned int salt) { ref_jitter_salt = salt; }
 // a new window: the next optimize_depth_gpu call re-creates its cuRAND states, starting from counter value `rand_epoch`

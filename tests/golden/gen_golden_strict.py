@@ -30,6 +30,13 @@ def main():
     ref = orc.ref()
     allc = dict(cases.window_cases())
     out = {}
+    if "--cuda-only" not in sys.argv:
+        strict_windows(ref, allc)
+    cuda_windows_and_noise(ref, allc)
+
+
+def strict_windows(ref, allc):
+    out = {}
     ref.ref_set_math_mode(1)
     orc.lib().orc_set_strict_math(1)  # the injected two-view pose comes from the oracle's bootstrap: no transcendental in it, but keep one mode
     try:
@@ -44,6 +51,36 @@ def main():
     path = os.path.join(HERE, "ref_window_strict.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def cuda_windows_and_noise(ref, allc):
+    # ---- round 4: the same windows with the reference's LAST two stand-ins switched off as well -- cuRAND XORWOW streams (D1) and CUDA's
+    # linear texture filter over the stacked layers (D2), both restated in voldor_amd/csrc/vk_ref_cuda.h (ref_set_reference_rng / _tex)
+    out = {}
+    ref.ref_set_math_mode(1); ref.ref_set_reference_rng(1); ref.ref_set_reference_tex(1)
+    orc.lib().orc_set_strict_math(1)
+    try:
+        for name in STRICT_CASES:
+            r = run_reference(allc[name])
+            out[f"{name}/n_registered"] = np.int32(r["n_registered"])
+            for k in ("poses", "poses_covar", "depth", "depth_conf"):
+                out[f"{name}/{k}"] = r[k]
+            print(f"strict + xorwow + tex {name:20s} n_registered {r['n_registered']}")
+        import hashlib
+        name, c = cases.cfg2_case()
+        r = run_reference(c)
+        out[f"{name}/n_registered"], out[f"{name}/poses"], out[f"{name}/poses_covar"] = np.int32(r["n_registered"]), r["poses"], r["poses_covar"]
+        for k in ("depth", "depth_conf"):
+            out[f"{name}/{k}_sub8"] = r[k][::8, ::8].copy()
+            out[f"{name}/{k}_sha256"] = np.frombuffer(hashlib.sha256(r[k].tobytes()).digest(), np.uint8)
+        print(f"strict + xorwow + tex {name:20s} n_registered {r['n_registered']}")
+    finally:
+        ref.ref_set_math_mode(0); ref.ref_set_reference_rng(0); ref.ref_set_reference_tex(0); orc.lib().orc_set_strict_math(0)
+    path = os.path.join(HERE, "ref_window_cuda.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
+    if "--cuda-only" in sys.argv:
+        return
 
     noise = {}
     big = dict(cases.window_cases())["mono_320x240"]

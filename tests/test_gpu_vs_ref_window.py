@@ -171,6 +171,46 @@ def test_strict_window_equals_the_reference(name):
     assert (_bits(o2["depth"]) != _bits(g[f"{name}/depth"])).any()
 
 
+CUDA_GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_window_cuda.npz")
+CUDA_MODE = REFERENCE_MODE + " --reference_rng 1 --reference_tex 1"
+
+
+@pytest.mark.parametrize("name", ["mono_nonexclusive", "stereo_default", "stereo_ap3p", "depth_priors", "cfg2_640x480"])
+def test_window_with_xorwow_and_texture_filter_equals_the_reference(name):
+    """Reference mode with NOTHING stood in for but OpenCV's two-view bootstrap: tests/golden/ref_window_cuda.npz = the
+    reference's own pipeline in strict math whose curand_init / curand_uniform draw from cuRAND's XORWOW streams and whose at_tex is CUDA's
+    linear filter over the stacked layers (both restated in voldor_amd/csrc/vk_ref_cuda.h from their published definitions: KATs in
+    tests/test_reference_cuda.py).  `--reference_rng 1 --reference_tex 1` on top of the reference mode: every output bit of the window --
+    four small windows (monocular, stereo, AP3P, depth priors from other poses) and BASELINE cfg2 at full size."""
+    import hashlib
+    from voldor_amd import kernels, pyvoldor
+    if not os.path.exists(CUDA_GOLD):
+        pytest.skip("tests/golden/ref_window_cuda.npz not generated")
+    g = np.load(CUDA_GOLD)
+    c = cases.cfg2_case()[1] if name == "cfg2_640x480" else dict(CASES)[name]
+    fx, fy, cx, cy = c["K"]
+    kernels.set_rand_epoch(0)
+    o = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"], depth_priors=c["depth_priors"],
+                        depth_prior_poses=c["depth_prior_poses"], depth_prior_pconfs=c["depth_prior_pconfs"], config=c["config"] + CUDA_MODE)
+    assert o["n_registered"] == int(g[f"{name}/n_registered"])
+    if name == "cfg2_640x480":
+        for k in ("depth", "depth_conf"):
+            assert not (_bits(o[k][::8, ::8]) != _bits(g[f"{name}/{k}_sub8"])).any(), k
+            assert hashlib.sha256(np.ascontiguousarray(o[k]).tobytes()).digest() == g[f"{name}/{k}_sha256"].tobytes(), k
+    else:
+        for k in ("depth", "depth_conf"):
+            neq = _bits(o[k]) != _bits(g[f"{name}/{k}"])
+            assert not neq.any(), f"{name}/{k}: {int(neq.sum())} of {neq.size} values differ from the reference"
+    assert not (_bits(o["poses_covar"]) != _bits(g[f"{name}/poses_covar"])).any()
+    assert np.abs(o["poses"].astype(np.float64) - g[f"{name}/poses"]).max() < 1e-9
+    # each switch matters: with only one of them the window is another one
+    for only in (" --reference_rng 1", " --reference_tex 1"):
+        kernels.set_rand_epoch(0)
+        o2 = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"], depth_priors=c["depth_priors"],
+                             depth_prior_poses=c["depth_prior_poses"], depth_prior_pconfs=c["depth_prior_pconfs"], config=c["config"] + REFERENCE_MODE + only)
+        assert (_bits(o2["depth"]) != _bits(o["depth"])).any(), only
+
+
 def test_strict_cfg2_window_equals_the_reference():
     """BASELINE configs[1] at full size (640x480, N=5, 8 EM iterations, monocular, refit on the last iteration): the reference
     pipeline's strict-math window (tests/golden/gen_golden_ensemble.py, `cfg2/s233/strict`: covariances, poses, sha256 of the two

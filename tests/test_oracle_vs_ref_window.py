@@ -134,3 +134,37 @@ def test_strict_oracle_bit_identical_to_the_reference_in_strict_math(reference_m
     assert np.abs(o["poses"] - g[f"{name}/poses"]).max() < 1e-9
     # and it is a different rounding of the same window than the glibc run
     assert not np.array_equal(bits(g[f"{name}/depth"]), bits(np.load(GOLD)[f"{name}/depth"]))
+
+
+# ---- round 4: the last two stand-ins switched off -- cuRAND XORWOW streams and CUDA's texture filter (vk_ref_cuda.h) ------------------
+CUDA_GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_window_cuda.npz")
+
+
+@pytest.mark.parametrize("name", ["mono_nonexclusive", "stereo_default", "stereo_ap3p", "depth_priors"])
+def test_oracle_with_xorwow_and_texture_filter_equals_the_reference(reference_mode, name):
+    """tests/golden/ref_window_cuda.npz = the reference pipeline in strict math with ref_set_reference_rng(1) / ref_set_reference_tex(1):
+    its curand_init / curand_uniform calls served by the XORWOW restatement, its at_tex by the 8-bit-fraction filter over the stacked
+    layers (oracle/ref_stubs/emul/cuda_emul.h <- voldor_amd/csrc/vk_ref_cuda.h).  The oracle with orc_set_reference_rng(1) /
+    orc_set_reference_tex(1) implements the same two rules at ITS call sites (per-pixel states that persist across the sample passes, the
+    solver's re-seeded streams, every fetch of flows / priors / confidences): same bits in every output."""
+    if not os.path.exists(CUDA_GOLD):
+        pytest.skip("tests/golden/ref_window_cuda.npz not generated")
+    g = np.load(CUDA_GOLD)
+    c = dict(CASES)[name]
+    L = orc.lib()
+    L.orc_set_strict_math(1); L.orc_set_reference_rng(1); L.orc_set_reference_tex(1)
+    if orc.ref() is not None:
+        orc.ref().ref_set_math_mode(1)
+    try:
+        o = run_oracle(c)
+    finally:
+        L.orc_set_strict_math(0); L.orc_set_reference_rng(0); L.orc_set_reference_tex(0)
+        if orc.ref() is not None:
+            orc.ref().ref_set_math_mode(0)
+    assert o["n_registered"] == int(g[f"{name}/n_registered"])
+    assert np.array_equal(bits(o["depth"]), bits(g[f"{name}/depth"]))
+    assert np.array_equal(bits(o["depth_conf"]), bits(g[f"{name}/depth_conf"]))
+    assert np.array_equal(bits(o["poses_covar"]), bits(g[f"{name}/poses_covar"]))
+    assert np.abs(o["poses"] - g[f"{name}/poses"]).max() < 1e-9
+    # the switches matter: another window than the strict one with the stand-ins
+    assert not np.array_equal(bits(g[f"{name}/depth"]), bits(np.load(STRICT_GOLD)[f"{name}/depth"]))

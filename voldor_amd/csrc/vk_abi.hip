@@ -113,6 +113,35 @@ bool reference_svd_default() {
     return g_reference_svd != 0;
 }
 
+static int g_reference_rng = -1, g_reference_tex = -1;  // -1: not set -> environment
+bool reference_rng_default() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_reference_rng < 0) { const char* e = getenv("VOLDOR_HIP_REFERENCE_RNG"); g_reference_rng = (e && e[0] == '1') ? 1 : 0; }
+    return g_reference_rng != 0;
+}
+bool reference_tex_default() {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (g_reference_tex < 0) { const char* e = getenv("VOLDOR_HIP_REFERENCE_TEX"); g_reference_tex = (e && e[0] == '1') ? 1 : 0; }
+    return g_reference_tex != 0;
+}
+
+// VOLDOR_HIP_BACKTRACE=1: a C backtrace on SIGABRT / SIGSEGV (diagnostics on boxes without a debugger)
+#include <execinfo.h>
+#include <signal.h>
+static void vk_bt_handler(int sig) {
+    void* fr[64];
+    const int n = backtrace(fr, 64);
+    fprintf(stderr, "voldor_hip: signal %d, backtrace:\n", sig);
+    backtrace_symbols_fd(fr, n, 2);
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+static const bool g_bt_installed = [] {
+    const char* e = getenv("VOLDOR_HIP_BACKTRACE");
+    if (e && e[0] == '1') { signal(SIGABRT, vk_bt_handler); signal(SIGSEGV, vk_bt_handler); }
+    return true;
+}();
+
 static DebugSwitches g_debug;
 extern "C" int vk_debug_switch(const char* name, int value);
 DebugSwitches& debug_switches() {
@@ -241,6 +270,7 @@ int optimize_depth_gpu(float* h_flows[], float* h_rigidnesses[], float* h_o_rigi
     p.s0_ems_prob = s0_ems_prob; p.no_change_prob = no_change_prob; p.range_factor = range_factor;
     p.update_rigidness_only = update_rigidness_only;
     p.strict = strict_math_default();
+    p.ref_rng = p.strict && reference_rng_default(); p.ref_tex = p.strict && reference_tex_default();
     // the frame count comes by argument here: undo whatever a window call (py_voldor_wrapper: device-side truncation,
     // PoseBlock::n_active) left in the shared pose block
     const int all_frames = MAX_FRAMES;
@@ -275,7 +305,7 @@ int collect_p3p_instances(float* h_flows[], float* h_rigidnesses[], float* h_dep
     if (int e = S.depth.reserve(sizeof(float) * npx)) return e;
     if (h_depth) VK_CHECK(hipMemcpyAsync(S.depth.p, h_depth, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
     if (int e = collect_device(c, S, N, w, h, active_idx, rigidness_thresh, rigidness_sum_thresh, sample_min_depth,
-                               sample_max_depth, max_trace_on_flow, nullptr, true))
+                               sample_max_depth, max_trace_on_flow, nullptr, true, false, reference_tex_default()))
         return e;
     if (h_o_p2_map) VK_CHECK(hipMemcpyAsync(h_o_p2_map, c->p2_map.p, sizeof(float) * 2 * npx, hipMemcpyDeviceToHost, c->stream));
     if (h_o_p3_map) VK_CHECK(hipMemcpyAsync(h_o_p3_map, c->p3_map.p, sizeof(float) * 3 * npx, hipMemcpyDeviceToHost, c->stream));
@@ -296,7 +326,7 @@ static int solve_batch_host(float* h_p3s, float* h_p2s, float* h_o_rvecs, float*
     VK_CHECK(hipMemcpyAsync(c->n_points.p, &N_pts, sizeof(int), hipMemcpyHostToDevice, c->stream));
     VK_CHECK(hipStreamSynchronize(c->stream));
     if (int e = solve_device(c, c->pts2.as<float>(), c->pts3.as<float>(), c->n_points.as<int>(), h_K[0], h_K[4], h_K[2], h_K[5],
-                             N_poses, solver, strict_math_default(), nullptr, reference_svd_default()))
+                             N_poses, solver, strict_math_default(), nullptr, reference_svd_default(), reference_rng_default()))
         return e;
     VK_CHECK(hipMemcpyAsync(h_o_rvecs, c->rvecs.p, sizeof(float) * 3 * (size_t)N_poses, hipMemcpyDeviceToHost, c->stream));
     VK_CHECK(hipMemcpyAsync(h_o_tvecs, c->tvecs.p, sizeof(float) * 3 * (size_t)N_poses, hipMemcpyDeviceToHost, c->stream));
@@ -583,6 +613,10 @@ int vk_set_rand_epoch(unsigned epoch) {
 int vk_set_strict_math(int on) { set_strict_math_default(on); return 0; }
 int vk_get_strict_math(void) { return strict_math_default() ? 1 : 0; }
 int vk_set_reference_svd(int on) { std::lock_guard<std::mutex> lk(g_mu); g_reference_svd = on ? 1 : 0; return 0; }
+int vk_set_reference_rng(int on) { std::lock_guard<std::mutex> lk(g_mu); g_reference_rng = on ? 1 : 0; return 0; }
+int vk_get_reference_rng(void) { return reference_rng_default() ? 1 : 0; }
+int vk_set_reference_tex(int on) { std::lock_guard<std::mutex> lk(g_mu); g_reference_tex = on ? 1 : 0; return 0; }
+int vk_get_reference_tex(void) { return reference_tex_default() ? 1 : 0; }
 int vk_get_reference_svd(void) { return reference_svd_default() ? 1 : 0; }
 unsigned vk_get_rand_epoch(void) {
     Context* c = default_context();

@@ -142,6 +142,9 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
     float s0_ems_prob = 0.5f, no_change_prob = 0.9f, range_factor = 1.f;
     bool update_rigidness_only = false;
     bool strict = false;  // strict-math mode: reference-order arithmetic on vk_strict_math.h (vk_strict.hip)
+    // reference mode, round 4 (vk_ref_cuda.h; strict kernels only): cuRAND XORWOW streams for the depth samples / CUDA's 8-bit-fraction
+    // linear filter over the stacked layers for every at_tex of the reference (D1 / D2 switched off)
+    bool ref_rng = false, ref_tex = false;
     float* world_scale_out = nullptr;  // device float: also run normalize_world_scale's pose half (voldor.cpp:309-317) in the last launch
 };
 
@@ -168,6 +171,12 @@ struct Context {
     DevBuf tmp;                   // misc scratch (gblur, depth_conf ...)
     DevBuf fb_scratch;            // strict fb_smooth: forward messages [n_maps][h][w]
     bool strict = false;          // strict-math mode of the B-inner entry points that use this context (vk_set_strict_math)
+    // --reference_rng 1: the jump matrices T^(2^67 2^k) (vk_ref_cuda.h), the per-pixel XORWOW states of the depth samples
+    // (optimize_depth.cu:286-291; they stand xw_px_epoch draws after curand_init for a xw_px_n-pixel image) and the states right after
+    // curand_init(RAND_SEED, idx, 0) of the solver's hypotheses (solve_batch_lambdatwist.cu:44-48: re-seeded per call, so a fixed table)
+    DevBuf xw_jumps, xw_px_states, xw_pose_states;
+    int xw_px_n = 0, xw_pose_n = 0;
+    uint32_t xw_px_epoch = 0;
     uint32_t rand_epoch = 0;      // persistent depth-sampling RNG counter (optimize_depth.cu:358-361)
     int rand_w = 0, rand_h = 0;
     // profiling (off by default): HIP events on ctx.stream around kernel groups

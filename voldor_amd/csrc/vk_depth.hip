@@ -16,6 +16,7 @@
 #include "vk_common.hpp"
 #include "vk_device.hpp"
 #include "vk_strict_model.hpp"
+#include "vk_ref_cuda.h"
 #include "vk_internal.hpp"
 #include <cstdlib>
 
@@ -46,7 +47,20 @@ struct Img {
     const PoseBlock* __restrict__ P;
     int N, N_dp, w, h;
     float lambda, omega, inv_arf, arf, basefocal, disp_delta, delta;
+    // reference mode (strict kernels only; vk_ref_cuda.h): tex = CUDA's linear filter over the STACK of n_layers flow layers (the frame
+    // count of the launch, before the device-side truncation clamps N) / of N_dp prior layers; xw = the per-pixel XORWOW states
+    int tex, n_layers;
+    vrc_xorwow* xw;
 };
+// at_tex of the reference (gmat.h:175-179) in the strict kernels: D2's exact per-layer bilinear, or CUDA's filter (--reference_tex 1)
+__device__ __forceinline__ static float2 fetch_flow_strict(const Img& I, int f, float x, float y) {
+    if (I.tex) { float2 r; vrc_tex_fetch2(reinterpret_cast<const float*>(I.flows), x, y, f, I.w, I.h, I.n_layers, &r.x, &r.y); return r; }
+    return bilinear2(I.flows + (size_t)f * I.w * I.h, I.w, I.h, x, y);
+}
+__device__ __forceinline__ static float fetch_prior_strict(const Img& I, const float* __restrict__ stack, int f, float x, float y) {
+    if (I.tex) return vrc_tex_fetch1(stack, x, y, f, I.w, I.h, I.N_dp);
+    return bilinear1(stack + (size_t)f * I.w * I.h, I.w, I.h, x, y);
+}
 // Frames still registered: the launch-time count clamped by the device-side decision of this EM iteration
 // (PoseBlock::n_active).  Returns false when nothing is left to evaluate (window lost, no priors).
 __device__ __forceinline__ bool clamp_active(Img& I) {
@@ -58,15 +72,15 @@ __device__ __forceinline__ bool clamp_active(Img& I) {
 // prior map, weighted by the prior's confidences (all three sampled bilinearly at the projected position)
 __device__ __forceinline__ static void prior_term_strict(const Img& I, const PoseBlock* P, int f, int px, int py, float depth, float& cost_sum, float& wsum) {
 #pragma clang fp contract(off)  // strict: one rounding per operation, also across statements (wsum += wg must not become an fma)
-    const int w = I.w, h = I.h, npx = w * h;
+    const int w = I.w, h = I.h;
     P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
     float qx2, qy2;
     project(P, q, qx2, qy2);
     if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
-        float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+        float td = fetch_prior_strict(I, I.priors, f, qx2, qy2);
         if (td > 0.f) {
-            float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
-            float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
+            float tpc = fetch_prior_strict(I, I.pconfs, f, qx2, qy2);
+            float tc = fetch_prior_strict(I, I.confs, f, qx2, qy2);
             float wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
             cost_sum = strict::cost_acc(cost_sum, wg, strict::depth_rigidness(q.z, td, I.basefocal, I.omega, I.arf));  // fun_depth_cost, residual_model.h:64-68
             wsum += wg;
@@ -115,7 +129,7 @@ __device__ __forceinline__ static float pixel_cost_strict(const Img& I, int px, 
         if (f < I.N) {  // unconditional (clamped) gathers: no divergent branch around the loads
             // frame 0 is sampled at the pixel itself: weights (1,0,0,0), the fetch is the texel (and it does not
             // depend on the depth hypothesis, so it leaves the candidate loops)
-            obs[f] = (f == 0) ? I.flows[pi] : bilinear2(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
+            obs[f] = (f == 0) ? I.flows[pi] : fetch_flow_strict(I, f, qx[f], qy[f]);
             wgt[f] = I.rig[(size_t)f * npx + pi];
         }
     }
@@ -145,12 +159,15 @@ __global__ __launch_bounds__(256) static void k_cost_rand_strict(Img I, int n_ra
     const int pi = y * I.w + x;
     float d = I.depth[pi];
     float c = pixel_cost_strict<NMAX>(I, x, y, d);
+    vrc_xorwow st;
+    if (I.xw) st = I.xw[pi];  // --reference_rng 1: curand_uniform(&_d_rand_states.at(x, y)), the state persists (:273)
     for (int it = 0; it < n_rand; it++) {
-        float u = u01(rng3(RAND_SEED, (uint32_t)pi, epoch0 + (uint32_t)it));
+        float u = I.xw ? vrc_uniform(vrc_xorwow_next(&st)) : u01(rng3(RAND_SEED, (uint32_t)pi, epoch0 + (uint32_t)it));
         float dn = 1.0f / (range_factor * u + (1.0f / 1e5f));  // MAXIMUM_DEPTH, :15,:273
         float cn = pixel_cost_strict<NMAX>(I, x, y, dn);
         if (cn < c) { c = cn; d = dn; }
     }
+    if (I.xw) I.xw[pi] = st;
     I.depth[pi] = d;
     I.cost[pi] = c;
 }
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(256) static void k_update_rigidness_strict(Img I, f
 #pragma unroll
     for (int f = 0; f < NMAX; f++) {
         obs[f] = make_float2(0.f, 0.f);
-        if (f < I.N) obs[f] = (f == 0) ? I.flows[pi] : bilinear2(I.flows + (size_t)f * npx, w, h, qx[f], qy[f]);
+        if (f < I.N) obs[f] = (f == 0) ? I.flows[pi] : fetch_flow_strict(I, f, qx[f], qy[f]);
     }
 #pragma unroll
     for (int f = 0; f < NMAX; f++) {
@@ -264,7 +281,7 @@ __global__ __launch_bounds__(256) static void k_update_rigidness_strict(Img I, f
         float qx2, qy2;
         project(P, q, qx2, qy2);
         if (q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h) {
-            float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+            float td = fetch_prior_strict(I, I.priors, f, qx2, qy2);
             if (td > 0.f)  // else: the confidence is left untouched (:129)
                 I.confs[(size_t)f * npx + pi] = strict::depth_rigidness(q.z, td, I.basefocal, I.omega, I.arf);
         } else
@@ -754,16 +771,16 @@ __device__ __forceinline__ static float cost_split_lean(const Img& I, const Lean
 // priors.  Same bits as the one-lane evaluation.
 __device__ __forceinline__ static bool prior_parts_strict(const Img& I, const PoseBlock* P, int f, int px, int py, float depth, float& wg, float& term) {
 #pragma clang fp contract(off)
-    const int w = I.w, h = I.h, npx = w * h;
+    const int w = I.w, h = I.h;
     wg = 0.f; term = 0.f;
     P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
     float qx2, qy2;
     project(P, q, qx2, qy2);
     if (!(q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h)) return false;
-    const float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+    const float td = fetch_prior_strict(I, I.priors, f, qx2, qy2);
     if (!(td > 0.f)) return false;
-    const float tpc = bilinear1(I.pconfs + (size_t)f * npx, w, h, qx2, qy2);
-    const float tc = bilinear1(I.confs + (size_t)f * npx, w, h, qx2, qy2);
+    const float tpc = fetch_prior_strict(I, I.pconfs, f, qx2, qy2);
+    const float tc = fetch_prior_strict(I, I.confs, f, qx2, qy2);
     wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
     term = wg * vsm_logf(strict::depth_rigidness(q.z, td, I.basefocal, I.omega, I.arf));  // the product cost_acc subtracts (fun_depth_cost, residual_model.h:64-68)
     return true;
@@ -799,8 +816,12 @@ __device__ __forceinline__ static float cost_split_strict(const Img& I, int px, 
 #pragma unroll
     for (int k = 0; k < S; k++) {
         const int f = g + LPP * k, fl = f < I.N ? f : 0;
-        const float2 ob = (f == 0) ? I.flows[pi] : bilinear2(I.flows + (size_t)fl * npx, w, h, qx[k], qy[k]);
-        wt[k] = I.rig[(size_t)fl * npx + pi];
+        float2 ob = make_float2(0.f, 0.f);
+        wt[k] = 0.f;
+        if (f < I.N) {  // (a slot without a frame fetches nothing: with N = 0 -- depth priors only -- there may be no flow layer at all)
+            ob = (f == 0) ? I.flows[pi] : fetch_flow_strict(I, fl, qx[k], qy[k]);
+            wt[k] = I.rig[(size_t)fl * npx + pi];
+        }
         tm[k] = wt[k] * vsm_logf(strict::rigidness(rdx[k], rdy[k], ob.x, ob.y, I.lambda, I.arf));
         vv[k] = vv[k] && f < I.N;
     }
@@ -855,6 +876,7 @@ __global__ __launch_bounds__(256) static void k_cost_rand_q_strict(Img I, int n_
     __shared__ unsigned long long s_best[256];
     __shared__ float s_cbest[256];
     __shared__ CrqsEntry s_q[256 * CRQ_NS];
+    __shared__ float s_d[CRQ_NS][256];  // the random depths of this round: whichever lane evaluates an entry reads the pixel's sample here
     __shared__ int s_qn, s_qw;
     if (!clamp_active(I)) return;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -870,6 +892,8 @@ __global__ __launch_bounds__(256) static void k_cost_rand_q_strict(Img I, int n_
     float wall = 0.f;  // weights of frames 1.. (the denominator bound of stage 0 adds them one by one: same chain as below)
     (void)wall;
     float d_best = I.depth[pi], c_best = pixel_cost_strict<NMAX>(I, px, py, d_best);
+    vrc_xorwow st;
+    if (I.xw) st = I.xw[pi];  // --reference_rng 1: this pixel's cuRAND state (optimize_depth.cu:273), one draw per sample, stored back at the end
     // bound of an entry whose sums stand after frame f: dead iff it cannot beat the pixel's incumbent
     auto dead_after = [&](int epi, int f, float cs, float ws, bool pk, float tp, float wp, float cb) {
         float U = ws;
@@ -883,10 +907,12 @@ __global__ __launch_bounds__(256) static void k_cost_rand_q_strict(Img I, int n_
         s_best[tid] = ~0ull;
         s_cbest[tid] = c_best;
         if (tid == 0) s_qn = 0;
+        for (int k = 0; k < nh; k++)
+            s_d[k][tid] = I.xw ? 1.0f / (range_factor * vrc_uniform(vrc_xorwow_next(&st)) + (1.0f / 1e5f)) : sample_depth(pi, epoch0 + (uint32_t)(it + k), range_factor);
         __syncthreads();
         // ---- stage 0: frame 0 (observed at the pixel itself) and the prior of every sample of this round, by the pixel's own lane
         for (int k = 0; k < nh; k++) {
-            const float d = sample_depth(pi, epoch0 + (uint32_t)(it + k), range_factor);
+            const float d = s_d[k][tid];
             float cs = 0.f, ws = 0.f, tp = 0.f, wp = 0.f;
             bool pk = false;
             if (I.N > 0) {
@@ -924,7 +950,7 @@ __global__ __launch_bounds__(256) static void k_cost_rand_q_strict(Img I, int n_
                 const int ex_ = x0 + (t & 63), ey_ = y0 + (t >> 6), epi = have ? ey_ * w + ex_ : 0;
                 bool alive = false;
                 if (have) {
-                    const float d = sample_depth(epi, epoch0 + (uint32_t)(it + k), range_factor);
+                    const float d = s_d[k][t];
                     // the chain of positions up to frame f (pixel_cost_strict's own walk: positions advance on contributing frames only)
                     P3 o = backproject(P, (float)ex_, (float)ey_, d);
                     float px1 = (float)ex_, py1 = (float)ey_, px2 = 0.f, py2 = 0.f;
@@ -936,7 +962,7 @@ __global__ __launch_bounds__(256) static void k_cost_rand_q_strict(Img I, int n_
                         if (g < f && valid) { px1 = px2; py1 = py2; }
                     }
                     if (valid) {
-                        const float2 obs = bilinear2(I.flows + (size_t)f * npx, w, h, px1, py1);
+                        const float2 obs = fetch_flow_strict(I, f, px1, py1);
                         const float wg = I.rig[(size_t)f * npx + epi];
                         q.cs = q.cs - wg * vsm_logf(strict::rigidness(px2 - px1, py2 - py1, obs.x, obs.y, I.lambda, I.arf));
                         q.ws += wg;
@@ -970,11 +996,11 @@ __global__ __launch_bounds__(256) static void k_cost_rand_q_strict(Img I, int n_
         const unsigned long long key = s_best[tid];
         if (key != ~0ull) {
             const float c = __uint_as_float((unsigned)(key >> 32));
-            if (c < c_best) { c_best = c; d_best = sample_depth(pi, epoch0 + (uint32_t)(it + (int)(key & 0xffu)), range_factor); }
+            if (c < c_best) { c_best = c; d_best = s_d[key & 0xffu][tid]; }
         }
         __syncthreads();
     }
-    if (live) { I.depth[pi] = d_best; I.cost[pi] = c_best; }
+    if (live) { I.depth[pi] = d_best; I.cost[pi] = c_best; if (I.xw) I.xw[pi] = st; }
 }
 
 // Global propagation with the candidate of a site evaluated by LPP lanes (cost_split_lean: the bits of pixel_cost_lean).  A pass has
@@ -1560,6 +1586,7 @@ static Img make_img(const ImageSet& S, const OdParams& p) {
     I.N = p.N; I.N_dp = p.N_dp; I.w = p.w; I.h = p.h;
     I.lambda = p.lambda; I.omega = p.omega; I.inv_arf = 1.f / p.abs_resize_factor; I.arf = p.abs_resize_factor;
     I.basefocal = p.basefocal; I.disp_delta = p.disp_delta; I.delta = p.delta;
+    I.tex = (p.strict && p.ref_tex) ? 1 : 0; I.n_layers = p.N; I.xw = nullptr;
     return I;
 }
 
@@ -1607,7 +1634,12 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
             }
         }
         if (c->prof) prof_begin_inner(c);
+        if (STRICT && p.ref_rng && p.n_rand_samples > 0) {  // --reference_rng 1: the per-pixel cuRAND states, standing rand_epoch draws after curand_init
+            if (int e = xorwow_pixel_states_device(c, w * h, c->rand_epoch)) return e;
+            I.xw = c->xw_px_states.as<vrc_xorwow>();
+        }
         cost_rand(p.n_rand_samples, c->rand_epoch);
+        if (I.xw) { c->xw_px_epoch += (uint32_t)p.n_rand_samples; I.xw = nullptr; }
         if (c->prof) prof_end_inner(c, "cost_rand", 1);
         c->rand_epoch += (uint32_t)(p.n_rand_samples > 0 ? p.n_rand_samples : 0);
         const int order[4] = { 0, 3, 2, 1 };  // L2R, B2T, R2L, T2B (:481-484, :487-490)

@@ -81,13 +81,17 @@ int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk
 
 // vk_pose.hip
 int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
-                   float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact, bool block_compact = false);
+                   float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact, bool block_compact = false, bool ref_tex = false);
 int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, float fx, float fy, float cx, float cy,
-                 int n_poses, int solver, bool strict = false, CamState* cam_dev = nullptr, bool ref_svd = false);
+                 int n_poses, int solver, bool strict = false, CamState* cam_dev = nullptr, bool ref_svd = false, bool ref_rng = false);
 // draw = 0: rejection over the map (D3b), falling back to the compacted list below DRAW_LIST_DENSITY; 1: always the reference's
 // index draw over the compacted list (geometry.cpp:68-88 + solve_batch_lambdatwist.cu:16-19); -1: rejection only (tests)
 int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev,
-                           int draw = 0, bool strict = false, bool ref_svd = false);
+                           int draw = 0, bool strict = false, bool ref_svd = false, bool ref_rng = false);
+// vk_ref_cuda.h on the device (vk_pose.hip): jump matrices, XORWOW state tables
+int xorwow_jumps_device(Context* c);                              // c->xw_jumps ready
+int xorwow_pixel_states_device(Context* c, int npx, uint32_t epoch);  // c->xw_px_states = states `epoch` draws after curand_init(RAND_SEED, pixel, 0)
+int xorwow_pose_states_device(Context* c, int n_poses);           // c->xw_pose_states = states after curand_init(RAND_SEED, idx, 0)
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first = false);
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
@@ -97,6 +101,8 @@ int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, 
 
 // vk_abi.hip: process-wide default of the strict-math mode (vk_set_strict_math / VOLDOR_HIP_STRICT_MATH)
 bool strict_math_default();
+bool reference_rng_default();  // vk_set_reference_rng / VOLDOR_HIP_REFERENCE_RNG
+bool reference_tex_default();  // vk_set_reference_tex / VOLDOR_HIP_REFERENCE_TEX
 bool reference_svd_default();  // vk_set_reference_svd / VOLDOR_HIP_REFERENCE_SVD: rodrigues() through the reference's approximate SVD (vk_ref_svd.h)
 
 }  // namespace vk

@@ -17,6 +17,7 @@
 #include "vk_p3p.hpp"
 #include "vk_ref_svd.h"
 #include "vk_lu.hpp"
+#include "vk_ref_cuda.h"
 #include "vk_internal.hpp"
 
 namespace vk {
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict
                                                          float* __restrict__ p2_map, float* __restrict__ p3_map,
                                                          int* __restrict__ blk_counts, unsigned long long* __restrict__ valid_mask, int N, int w, int h, int active_idx,
                                                          float rig_thresh, float rig_sum_thresh, float min_depth,
-                                                         float max_depth, int max_trace) {
+                                                         float max_depth, int max_trace, int ref_tex /* --reference_tex 1: CUDA's linear filter over the N stacked flow layers (vk_ref_cuda.h) */) {
     PH_DECL;
     const int npx = w * h;
     const int tile = xcd_band_tile(blockIdx.x, gridDim.x);  // XCD k works on the k-th band of rows (vk_device.hpp)
@@ -82,7 +83,9 @@ __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict
                 if (i >= active_idx - n_trace + 1) {
                     if (i == active_idx - n_trace + 1) project(P, o, px, py);
                     if (px > 0.f && px < (float)w && py > 0.f && py < (float)h) {  // strict (:120)
-                        float2 f2 = bilinear2(flows + (size_t)i * npx, w, h, px, py);
+                        float2 f2;
+                        if (ref_tex) vrc_tex_fetch2(reinterpret_cast<const float*>(flows), px, py, i, w, h, N, &f2.x, &f2.y);
+                        else f2 = bilinear2(flows + (size_t)i * npx, w, h, px, py);
                         px += f2.x; py += f2.y;
                     } else { out = true; break; }
                 }
@@ -185,6 +188,17 @@ __global__ __launch_bounds__(256) static void k_compact(const float* __restrict_
 //                  1/DRAW_RANK_INV_DENSITY, where rejection within DRAW_MAX_TRIES probes starts to lose hypotheses
 //                  (a hypothesis survives with probability (1-(1-rho)^256)^4: 73 % at rho = 1 %), so that the pool has the
 //                  reference's size at ANY density >= 4 points; (b) always in reference-draw mode (--reference_draw 1).
+// draw k (0..3) of hypothesis idx: curand_uniform number k of the stream curand_init(RAND_SEED, idx, 0) (solve_batch_lambdatwist.cu:16-19,
+// :44-48 -- re-seeded per call, so the state table is the same for every launch) with --reference_rng 1, else the counter generator (D1)
+__device__ __forceinline__ float draw_uniform(const vrc_xorwow* __restrict__ xw, int idx, int k) {
+    if (xw) {
+        vrc_xorwow s = xw[idx];
+        uint32_t x = 0u;
+        for (int j = 0; j <= k; j++) x = vrc_xorwow_next(&s);
+        return vrc_uniform(x);
+    }
+    return u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)k));
+}
 constexpr int DRAW_MAX_TRIES = 256;
 constexpr int DRAW_RANK_INV_DENSITY = 20;  // rank select below 5 % valid pixels (rejection then needs > 90 tries for 1 % of the points)
 template <int SOLVER, bool FROM_MAP>  // SOLVER: 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>
@@ -195,7 +209,8 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                                                       int draw /* 0 auto, 1 rank select (reference draw), -1 rejection only */, int strict /* bit 0: strict math, bit 1: reference SVD, bit 2: block-compacted correspondences (with draw 1) */,
                                                       const int* __restrict__ blk_offsets /* exclusive prefix of blk_counts in global memory when it does not fit the LDS, else null */,
                                                       const unsigned long long* __restrict__ valid_mask /* k_collect's bit per pixel (FROM_MAP) */,
-                                                      int newton_steps /* cubic_root (vk_p3p.hpp): 50 = the reference's loop */) {
+                                                      int newton_steps /* cubic_root (vk_p3p.hpp): 50 = the reference's loop */,
+                                                      const vrc_xorwow* __restrict__ xw /* --reference_rng 1: states after curand_init(RAND_SEED, idx, 0), else null */) {
     // LambdaTwist: four lanes per hypothesis, one candidate root each (the candidates are independent once the
     // shared cubic / eigen-decomposition is done; a lane per hypothesis walks them one after the other and the wave
     // waits for its slowest lane).  AP3P keeps one lane per hypothesis.
@@ -293,7 +308,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
 #pragma unroll
             for (int k = 0; k < NS; k++) {
                 // (int)(curand_uniform * N_pts), clamped (D3): solve_batch_lambdatwist.cu:16-19
-                rk[k] = min((int)(u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)(LPH == 4 ? sub : k))) * (float)n_pts), n_pts - 1);
+                rk[k] = min((int)(draw_uniform(xw, idx, LPH == 4 ? sub : k) * (float)n_pts), n_pts - 1);
                 lo[k] = 0; hi[k] = nblk - 1;  // first block whose inclusive prefix exceeds the rank
             }
             if (blk_offsets) {  // images beyond 15360 blocks (3.9 MP): the scanned counts stay in global memory (k_scan_counts)
@@ -388,7 +403,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                 // the reference re-seeds per call, so the pattern depends only on (idx, n_pts)
                 // (solve_batch_lambdatwist.cu:16-19,80-81). u in (0,1]: clamp the one-past-the-end
                 // index the reference can produce.
-                int i = (int)(u01(rng3(RAND_SEED, (uint32_t)idx, (uint32_t)k)) * (float)n_pts);
+                int i = (int)(draw_uniform(xw, idx, k) * (float)n_pts);
                 sel[k] = min(i, n_pts - 1);
             }
         }
@@ -1527,7 +1542,7 @@ __global__ __launch_bounds__(MS_THREADS) static void k_robust_gaussian_only(cons
 
 // ---- host launchers ------------------------------------------------------------------------------
 int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
-                   float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact, bool block_compact) {
+                   float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact, bool block_compact, bool ref_tex) {
     const int npx = w * h, nblk = (npx + 255) / 256;
     if (int e = c->p2_map.reserve(sizeof(float) * 2 * (size_t)npx)) return e;
     if (int e = c->p3_map.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
@@ -1539,11 +1554,11 @@ int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int activ
     if (block_compact)
         hipLaunchKernelGGL(k_collect<true>, dim3(nblk), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
                            S.pb(), c->p2_map.as<float>(), c->p3_map.as<float>(), c->blk_counts.as<int>(), c->valid_mask.as<unsigned long long>(), N, w, h, active_idx,
-                           rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace);
+                           rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace, ref_tex ? 1 : 0);
     else
         hipLaunchKernelGGL(k_collect<false>, dim3(nblk), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
                            S.pb(), c->p2_map.as<float>(), c->p3_map.as<float>(), c->blk_counts.as<int>(), c->valid_mask.as<unsigned long long>(), N, w, h, active_idx,
-                           rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace);
+                           rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace, ref_tex ? 1 : 0);
     c->n_map_blocks = nblk;
     c->maps_block_compact = block_compact;
     if (compact) {  // the host-pointer API hands the compacted list to its caller (geometry.cpp:68-80)
@@ -1560,7 +1575,13 @@ int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int activ
 
 template <bool FROM_MAP>
 static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, CamState* cam, int npx, float fx, float fy,
-                        float cx, float cy, int n_poses, int solver, int draw, bool strict, bool ref_svd) {
+                        float cx, float cy, int n_poses, int solver, int draw, bool strict, bool ref_svd, bool ref_rng) {
+    const vrc_xorwow* xw = nullptr;
+    if (ref_rng) {
+        if (FROM_MAP && draw <= 0) { fprintf(stderr, "voldor_hip: --reference_rng 1 needs the reference's index draw (--reference_draw 1)\n"); return (int)hipErrorInvalidValue; }
+        if (int e = xorwow_pose_states_device(c, n_poses)) return e;
+        xw = c->xw_pose_states.as<vrc_xorwow>();
+    }
     if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     const int lph = (solver == 1) ? 1 : 4;  // lanes per hypothesis (k_solve)
@@ -1588,20 +1609,58 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
     // held to the reference kernel's bits); an even cap in the fast window pipeline
     const int cap = debug_switches().newton_cap;
     const int ns = (FROM_MAP && !strict && cap > 0) ? cap : 50;
-    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns);
-    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns);
-    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns);
+    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns, xw);
+    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns, xw);
+    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns, xw);
     VK_CHECK_LAST();
     return 0;
 }
 int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, float fx, float fy, float cx, float cy,
-                 int n_poses, int solver, bool strict, CamState* cam_dev, bool ref_svd) {
-    return solve_launch<false>(c, pts2, pts3, n_pts_dev, cam_dev, 0, fx, fy, cx, cy, n_poses, solver, 0, strict, ref_svd);
+                 int n_poses, int solver, bool strict, CamState* cam_dev, bool ref_svd, bool ref_rng) {
+    return solve_launch<false>(c, pts2, pts3, n_pts_dev, cam_dev, 0, fx, fy, cx, cy, n_poses, solver, 0, strict, ref_svd, ref_rng);
 }
 int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev, int draw,
-                           bool strict, bool ref_svd) {
+                           bool strict, bool ref_svd, bool ref_rng) {
     return solve_launch<true>(c, c->p2_map.as<float>(), c->p3_map.as<float>(), c->n_points.as<int>(), cam_dev, npx, fx, fy, cx, cy, n_poses,
-                              solver, draw, strict, ref_svd);
+                              solver, draw, strict, ref_svd, ref_rng);
+}
+
+// ---- --reference_rng 1: cuRAND XORWOW state tables (vk_ref_cuda.h) ------------------------------------------------------------------
+// states[i] = the state after curand_init(RAND_SEED, first + i, 0) advanced by `epoch` outputs
+__global__ __launch_bounds__(256) static void k_xorwow_init(vrc_xorwow* __restrict__ states, const uint32_t* __restrict__ J, int n, uint32_t epoch) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    vrc_xorwow s;
+    vrc_xorwow_init(J, (unsigned long long)RAND_SEED, (uint32_t)i, &s);
+    for (uint32_t e = 0; e < epoch; e++) (void)vrc_xorwow_next(&s);
+    states[i] = s;
+}
+int xorwow_jumps_device(Context* c) {
+    if (c->xw_jumps.p) return 0;
+    std::vector<uint32_t> J((size_t)32 * VRC_XW_MAT);
+    vrc_build_sequence_jumps(J.data());  // T^(2^67 2^k), k < 32: 98 products of 160 x 160 bit matrices, a few milliseconds once per context
+    if (int e = c->xw_jumps.reserve(sizeof(uint32_t) * J.size())) return e;
+    VK_CHECK(hipMemcpyAsync(c->xw_jumps.p, J.data(), sizeof(uint32_t) * J.size(), hipMemcpyHostToDevice, c->stream));
+    VK_CHECK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+int xorwow_pixel_states_device(Context* c, int npx, uint32_t epoch) {
+    if (c->xw_px_states.p && c->xw_px_n == npx && c->xw_px_epoch == epoch) return 0;  // the states continue where the last sample launch left them
+    if (int e = xorwow_jumps_device(c)) return e;
+    if (int e = c->xw_px_states.reserve(sizeof(vrc_xorwow) * (size_t)npx)) return e;
+    hipLaunchKernelGGL(k_xorwow_init, dim3((npx + 255) / 256), dim3(256), 0, c->stream, c->xw_px_states.as<vrc_xorwow>(), c->xw_jumps.as<uint32_t>(), npx, epoch);
+    VK_CHECK_LAST();
+    c->xw_px_n = npx; c->xw_px_epoch = epoch;
+    return 0;
+}
+int xorwow_pose_states_device(Context* c, int n_poses) {
+    if (c->xw_pose_states.p && c->xw_pose_n >= n_poses) return 0;
+    if (int e = xorwow_jumps_device(c)) return e;
+    if (int e = c->xw_pose_states.reserve(sizeof(vrc_xorwow) * (size_t)n_poses)) return e;
+    hipLaunchKernelGGL(k_xorwow_init, dim3((n_poses + 255) / 256), dim3(256), 0, c->stream, c->xw_pose_states.as<vrc_xorwow>(), c->xw_jumps.as<uint32_t>(), n_poses, 0u);
+    VK_CHECK_LAST();
+    c->xw_pose_n = n_poses;
+    return 0;
 }
 
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first) {

@@ -52,7 +52,11 @@ struct Config {
     //  reference_svd   1: rodrigues() of every pose hypothesis through the reference's approximate fp32 SVD (svd3_cuda.h restated to the bit
     //                  in vk_ref_svd.h) instead of the exact polar factor (D8); with strict_math and reference_draw a window then equals the
     //                  REFERENCE pipeline's strict window bit for bit; -1 (default) = the process-wide setting of vk_set_reference_svd
-    int strict_math = -1, reference_draw = 1, reference_svd = -1;
+    //  reference_rng   1 (with strict_math): the depth samples and the hypothesis draws come from cuRAND's XORWOW streams as the reference
+    //                  seeds and advances them (curand_init(233, pixel | idx, 0); vk_ref_cuda.h) instead of the counter generator (D1)
+    //  reference_tex   1 (with strict_math): every at_tex of the reference through CUDA's linear filter -- 8-bit fractions, one texture over
+    //                  the stacked layers -- instead of the exact per-layer bilinear (D2).  -1 (default) = the process-wide settings
+    int strict_math = -1, reference_draw = 1, reference_svd = -1, reference_rng = -1, reference_tex = -1;
 
     // Returns 0, or non-zero where the reference prints and calls exit(1) (config.h:101-108,245-248):
     // a library must not exit its host process, so the error is reported to the caller instead.
@@ -71,7 +75,7 @@ struct Config {
             KI(depth_global_prop_step), KI(depth_local_prop_width), KF(depth_range_factor), KI(meanshift_max_iters),
             KI(meanshift_max_init_trials), KF(meanshift_good_init_confidence), KF(meanshift_epsilon), KI(kitti_estimate_ground),
             KI(kitti_ground_holo_width), KF(kitti_ground_roi), KF(kitti_ground_meanshift_kernel_var),
-            KI(strict_math), KI(reference_draw), KI(reference_svd),
+            KI(strict_math), KI(reference_draw), KI(reference_svd), KI(reference_rng), KI(reference_tex),
         };
 #undef KF
 #undef KI
@@ -103,7 +107,7 @@ struct Voldor {
     Context* c = nullptr;
     Config cfg;
     int n_flows = 0, n_flows_init = 0, n_dp = 0, w = 0, h = 0, iters_cur = 0, iters_remain = 0;
-    bool has_disparity = false, strict = false;
+    bool has_disparity = false, strict = false, ref_rng = false, ref_tex = false;
     CamState hcams[MAX_FRAMES];
 
     CamState* dcams() { return c->cams.as<CamState>(); }
@@ -113,6 +117,9 @@ struct Voldor {
              const float* depth_prior_poses, const float* depth_prior_pconfs, int N, int N_dp_in, int w_, int h_) {
         w = w_; h = h_;
         strict = cfg.strict_math < 0 ? strict_math_default() : cfg.strict_math != 0;
+        ref_rng = strict && (cfg.reference_rng < 0 ? reference_rng_default() : cfg.reference_rng != 0);  // (the fast kernels keep D1 / D2: their arithmetic is not the reference's anyway)
+        ref_tex = strict && (cfg.reference_tex < 0 ? reference_tex_default() : cfg.reference_tex != 0);
+        if (ref_rng && !cfg.reference_draw) { std::cout << "--reference_rng 1 needs --reference_draw 1" << std::endl; return (int)hipErrorInvalidValue; }
         n_flows = n_flows_init = N;
         iters_cur = 0; iters_remain = cfg.max_iters;
         n_dp = N_dp_in + (disparity ? 1 : 0);
@@ -185,7 +192,7 @@ struct Voldor {
         p.lambda = cfg.lambda; p.omega = cfg.omega; p.disp_delta = has_disparity ? cfg.disp_delta : -1.f; p.delta = cfg.delta;
         p.fb_smooth = cfg.fb_smooth != 0; p.s0_ems_prob = cfg.fb_emm; p.no_change_prob = cfg.fb_no_change_prob;
         p.range_factor = cfg.depth_range_factor; p.update_rigidness_only = (flag == OD_UPDATE_RIGIDNESS_ONLY);
-        p.strict = strict;
+        p.strict = strict; p.ref_rng = ref_rng; p.ref_tex = ref_tex;
         if (with_world_scale) {  // voldor.cpp:309-317: the pose half rides on the density launch, the depth half follows
             if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
             p.world_scale_out = c->ms_io.as<float>() + 48;
@@ -199,13 +206,13 @@ struct Voldor {
         if (c->prof) prof_begin(c);
         if (int e = collect_device(c, S, n_flows, w, h, i, cfg.rigidness_threshold, cfg.rigidness_sum_threshold,
                                    cfg.pose_sample_min_depth, cfg.pose_sample_max_depth, cfg.max_trace_on_flow, dcams() + i, false,
-                                   /*block_compact=*/cfg.reference_draw != 0))  // the index draw reads (block, rank in block) directly
+                                   /*block_compact=*/cfg.reference_draw != 0, ref_tex))  // the index draw reads (block, rank in block) directly
             return e;
         // cpu_p3p=1 selects the reference's CPU instantiation lambdatwist_p4p<double,...> (geometry.cpp:112)
         const int solver = cfg.lambdatwist ? (cfg.cpu_p3p ? 2 : 0) : 1;
         if (int e = solve_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i,
                                            cfg.reference_draw ? 1 : 0, strict,
-                                           cfg.reference_svd < 0 ? reference_svd_default() : cfg.reference_svd != 0))
+                                           cfg.reference_svd < 0 ? reference_svd_default() : cfg.reference_svd != 0, ref_rng))
             return e;
         ModeParams mp{};
         mp.dims = 6; mp.kernel_var = cfg.meanshift_kernel_var; mp.ms_epsilon = cfg.meanshift_epsilon;

@@ -213,3 +213,13 @@ def set_reference_svd(on: bool):
 
 def get_reference_svd() -> bool:
     return bool(capi.lib().vk_get_reference_svd())
+
+
+def set_reference_rng(on: bool):
+    """Process-wide default of the cuRAND XORWOW streams in strict mode (include/voldor_hip.h: vk_set_reference_rng)."""
+    capi.check(capi.lib().vk_set_reference_rng(1 if on else 0), "vk_set_reference_rng")
+
+
+def set_reference_tex(on: bool):
+    """Process-wide default of CUDA's linear texture filter in strict mode (include/voldor_hip.h: vk_set_reference_tex)."""
+    capi.check(capi.lib().vk_set_reference_tex(1 if on else 0), "vk_set_reference_tex")
