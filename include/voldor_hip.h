@@ -110,6 +110,12 @@ int vk_last_camera_stats(int* pose_sample_count, float* pose_density, float* pos
 int vk_estimate_pose_epipolar(const float* h_flow, const float* h_K, int w, int h, float* h_o_R9, float* h_o_t3);
 /* the GPU bootstrap of the window pipeline on one host flow [h][w][2] (pose + closed-form depth) */
 int vk_bootstrap_gpu(const float* h_flow, const float* h_K, int w, int h, float* h_o_R9, float* h_o_t3, float* h_o_depth);
+/* the same procedure with the FIVE-point minimal solver (Nister 2004; the solver behind cv::findEssentialMat, which geometry.cpp:316-326 calls):
+ * host path, GPU path (points = 8 | 5; config key --bootstrap_points), and the solver alone (host code: five normalised correspondences
+ * q1[5][2], q2[5][2] -> up to ten essential matrices Es[10][9], returns their number) */
+int vk_estimate_pose_epipolar5(const float* h_flow, const float* h_K, int w, int h, float* h_o_R9, float* h_o_t3);
+int vk_bootstrap_gpu_points(const float* h_flow, const float* h_K, int w, int h, int points, float* h_o_R9, float* h_o_t3, float* h_o_depth);
+int vk_fivept_solve(const double* q1, const double* q2, double* Es);
 int vk_estimate_depth_closed_form(const float* h_flow, const float* h_K, const float* h_R9, const float* h_t3,
                                   int w, int h, float* h_o_depth);
 

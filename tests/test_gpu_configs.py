@@ -25,14 +25,20 @@ B = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_ensemb
 GUARD = 2.0
 
 
+# ... and never looser than the absolute bars of round 2: the ensembles grew to 72 / 48 windows in round 4 and a maximum
+# over more windows only grows, which must not loosen a regression guard (rotation: north_star's 1e-3 rad class; translation: 5e-2)
+ABS_ROT, ABS_TRANS = 1.5e-3, 5e-2
+
+
 def _gt_ok(kind, rot, tr, depth_med=None):
     b = B[kind]["gt"]
-    return rot.max() <= GUARD * b["rot"]["max"] and tr.max() <= GUARD * b["trans"]["max"] and (depth_med is None or depth_med <= GUARD * b["depth"]["max"])
+    return (rot.max() <= min(GUARD * b["rot"]["max"], ABS_ROT) and tr.max() <= min(GUARD * b["trans"]["max"], ABS_TRANS)
+            and (depth_med is None or depth_med <= GUARD * b["depth"]["max"]))
 
 
 def _self_ok(kind, rot, tr):
     b = B[kind]["self"]
-    return rot.max() <= GUARD * b["rot"]["max"] and tr.max() <= GUARD * b["trans"]["max"]
+    return rot.max() <= min(GUARD * b["rot"]["max"], ABS_ROT) and tr.max() <= min(GUARD * b["trans"]["max"], ABS_TRANS)
 
 pytestmark = pytest.mark.gpu
 
@@ -83,6 +89,9 @@ def test_cfg3_kitti_size_stereo_matches_oracle_and_metric_scale(orc):
     m = (g["depth_conf"] > 0.5) & (o["depth_conf"] > 0.5)
     rel = np.abs(g["depth"][m] - o["depth"][m]) / o["depth"][m]
     assert np.percentile(rel, 90) <= GUARD * B["cfg3"]["self"]["depth"]["max"], np.percentile(rel, 90)
+    # the median as well: two runs of this estimator share most stereo-prior pixels bit for bit or nearly so -- the reference against
+    # itself has a median relative depth difference of 0 over the ensemble; the fast path against the oracle stays below 1e-3
+    assert np.median(rel) <= 1e-3, np.median(rel)
 
 
 def test_cfg5_1080p_disparity_prior_ground_truth():

@@ -187,19 +187,27 @@ def test_strict_baseline_cfg2_window_bits(orc, strict):
 
 # ---- round 4: strict arithmetic on the parallel launch structures == strict arithmetic on the plain ones -------------------------
 def _plain_vs_parallel(run):
-    """run() once on the parallel structures (default) and once with vk_debug_switch "strict_plain" = 1 (rounds 1-3: one lane per chain /
-    line / site, every sample in full, one 256-thread workgroup walking the sum tree block by block)."""
+    """run() on the parallel structures (default: the mode kernel as 16 cooperating single-wave workgroups), once more with the mode kernel as
+    ONE 512-thread workgroup (vk_debug_switch "strict_pose_coop" = 0), and once with vk_debug_switch "strict_plain" = 1 (rounds 1-3: one lane
+    per chain / line / site, every sample in full, one 256-thread workgroup walking the sum tree block by block).  Returns (default, plain)
+    after asserting that the single-workgroup form gives what the cooperative one gives."""
     import hooks
     from voldor_amd import kernels
     out = {}
     try:
-        for plain in (0, 1):
-            hooks.set_strict_plain(plain)
+        for key, (plain, coop) in {"coop": (0, 1), "one_wg": (0, 0), "plain": (1, 1)}.items():
+            hooks.set_strict_plain(plain); hooks.set_strict_pose_coop(coop)
             kernels.set_rand_epoch(0)
-            out[plain] = run()
+            out[key] = run()
     finally:
-        hooks.set_strict_plain(0)
-    return out[0], out[1]
+        hooks.set_strict_plain(0); hooks.set_strict_pose_coop(1)
+    a, b = out["coop"], out["one_wg"]
+    for k in a:
+        if isinstance(a[k], np.ndarray):
+            assert_bits(a[k], b[k], f"cooperative vs single-workgroup mode kernel: {k}")
+        elif isinstance(a[k], (int, float, np.integer, np.floating)):
+            assert np.float32(a[k]).view(np.uint32) == np.float32(b[k]).view(np.uint32) if isinstance(a[k], (float, np.floating)) else a[k] == b[k], k
+    return out["coop"], out["plain"]
 
 
 @pytest.mark.parametrize("name", ["mono_320x240", "stereo_priors", "truncated", "refit_every_iteration", "ap3p", "cfg2", "wide_1241", "odd_323x241"])

@@ -48,6 +48,14 @@ def _run_depth(c):
         kw["no_change_prob"], kw["range_factor"], kw["update_rigidness_only"])
 
 
+# Gates of the FAST kernels against the reference's own kernel code (glibc): the measured value on the MI355X minus one percentage point
+# (`exact > 0.5`, `> 0.93`, `0.97 / 0.99` let a regression of k_solve or of the lean arithmetic through); the
+# measured values are printed by the tests (pytest -s) and quoted in DESIGN.md section 5.
+DEPTH_BRANCH_AGREEMENT = {"rand": 0.99, "global": 0.99, "local": 0.99, "all": 0.989, "all_priors": 0.986, "ragged_all": 0.989}  # measured 1.0, 1.0, 1.0, 0.99967, 0.99674, 0.99907
+SOLVE_WITHIN = {"lambdatwist": 0.99, "ap3p": 0.989, "lambdatwist_small": 0.99, "ap3p_small": 0.99}                                  # measured 1.0, 0.99944, 1.0, 1.0
+SOLVE_EXACT = {"lambdatwist": 0.99, "lambdatwist_small": 0.99}                                                                      # measured 1.0, 1.0: every translation bit-identical
+
+
 @pytest.mark.parametrize("name,c", list(cases.depth_cases()), ids=[c[0] for c in cases.depth_cases()])
 def test_optimize_depth_vs_reference_kernels(gold, name, c):
     g_depth, g_rig = gold[f"od/{name}/depth"], gold[f"od/{name}/rig"]
@@ -56,7 +64,8 @@ def test_optimize_depth_vs_reference_kernels(gold, name, c):
     if name in ("cost", "update_only"):  # no search: the depth map must come back untouched
         np.testing.assert_array_equal(depth, g_depth)
     else:
-        need = 0.97 if name == "ragged_all" else 0.99
+        need = DEPTH_BRANCH_AGREEMENT[name]
+        print(f"MEASURED depth branch agreement {name}: {same.mean():.5f} (gate {need})")
         assert same.mean() >= need, f"{name}: only {same.mean():.4f} of the depth pixels take the reference's branch"
     # E-step on the pixels whose depth agrees (another depth means another residual, legitimately)
     assert np.abs(rig - g_rig)[:, same].max() < 5e-4
@@ -93,10 +102,13 @@ def test_solve_batch_p3p_vs_reference_kernel(gold, name, X, uv, K, n_poses, use_
     assert np.mean(fg != fo) < 0.02
     both = fg & fo
     err = np.maximum(np.abs(rv - g_rv).max(1), np.abs(tv - g_tv).max(1))[both]
-    assert np.mean(err < 2e-3) > 0.93, np.percentile(err, [50, 90, 99])
+    within = float(np.mean(err < 2e-3))
+    print(f"MEASURED solve {name}: within 2e-3 {within:.5f} (gate {SOLVE_WITHIN[name]})")
+    assert within >= SOLVE_WITHIN[name], np.percentile(err, [50, 90, 99])
     if not use_ap3p:  # LambdaTwist is written with the reference's literal types and no fma contraction
-        exact = np.mean(np.all(tv[both] == g_tv[both], axis=1))
-        assert exact > 0.5, f"only {exact:.3f} of the translations are bit-identical"
+        exact = float(np.mean(np.all(tv[both] == g_tv[both], axis=1)))
+        print(f"MEASURED solve {name}: bit-identical translations {exact:.5f} (gate {SOLVE_EXACT[name]})")
+        assert exact >= SOLVE_EXACT[name], f"only {exact:.3f} of the translations are bit-identical"
 
 
 @pytest.mark.parametrize("name,space,kernel_var,init_mean,ext,a", list(cases.meanshift_cases()), ids=[c[0] for c in cases.meanshift_cases()])

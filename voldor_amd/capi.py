@@ -21,7 +21,7 @@ C_SYMBOLS = [
     "vk_meanshift_gpu", "vk_fit_robust_gaussian", "vk_collect_p3p_instances", "vk_solve_batch_p3p_ap3p_gpu",
     "vk_solve_batch_p3p_lambdatwist_gpu", "vk_solve_batch_p3p_lambdatwist_f64_gpu", "vk_optimize_depth_gpu", "vk_gblur", "vk_fb_smooth",
     "vk_py_voldor_wrapper", "vk_voldor_device", "vk_voldor_device_block", "vk_voldor_device_batch", "vk_read_flo", "vk_write_flo", "vk_eval_covisibility", "vk_align_frame_init_gpu", "vk_align_frame_eval_gpu", "vk_last_camera_stats", "vk_estimate_pose_epipolar",
-    "vk_estimate_depth_closed_form", "vk_bootstrap_gpu", "vk_get_compacted_points", "vk_set_rand_epoch", "vk_get_rand_epoch", "vk_set_strict_math", "vk_get_strict_math", "vk_set_reference_svd", "vk_get_reference_svd", "vk_set_reference_rng", "vk_get_reference_rng", "vk_set_reference_tex", "vk_get_reference_tex",
+    "vk_estimate_depth_closed_form", "vk_estimate_pose_epipolar5", "vk_bootstrap_gpu_points", "vk_fivept_solve", "vk_bootstrap_gpu", "vk_get_compacted_points", "vk_set_rand_epoch", "vk_get_rand_epoch", "vk_set_strict_math", "vk_get_strict_math", "vk_set_reference_svd", "vk_get_reference_svd", "vk_set_reference_rng", "vk_get_reference_rng", "vk_set_reference_tex", "vk_get_reference_tex",
     "vk_profile_enable", "vk_profile_get", "vk_device_count", "vk_set_device", "vk_version",
     "vk_dist_get_unique_id", "vk_dist_init", "vk_dist_init_file", "vk_dist_rank", "vk_dist_world", "vk_dist_rccl_version", "vk_dist_allgather",
     "vk_dist_allreduce_max", "vk_dist_barrier", "vk_dist_allgather_stats", "vk_voldor_sharded", "vk_dist_finalize",

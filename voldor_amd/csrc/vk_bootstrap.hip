@@ -21,6 +21,7 @@
 #include "vk_device.hpp"
 #include "vk_internal.hpp"
 #include "vk_p3p.hpp"
+#include "vk_fivept.hpp"
 #include "../../include/voldor_hip.h"
 #include <vector>
 #include <algorithm>
@@ -29,6 +30,11 @@
 namespace vk {
 
 constexpr int BOOT_HYPS = 256, BOOT_SCORE_MAX = 2048, BOOT_STEP = 4;
+// --bootstrap_points 5: the five-point minimal solver (vk_fivept.hpp), the solver behind the reference's cv::findEssentialMat(.., LMEDS,
+// 0.999, 1.0) (geometry.cpp:316-326).  OpenCV's LMedS draws round(log(1 - 0.999) / log(1 - (1 - 0.45)^5)) = 134 samples; every sample yields up
+// to ten essential matrices and each one is a model of its own (median squared Sampson distance).  192 samples = three waves of lanes.
+constexpr int BOOT5_SAMPLES = 192, BOOT5_MODELS = BOOT5_SAMPLES * 10;
+constexpr int BOOT_MAX_MODELS = BOOT5_MODELS > BOOT_HYPS ? BOOT5_MODELS : BOOT_HYPS;
 
 // ---- shared host/device numerics --------------------------------------------------------------
 // Cyclic Jacobi for a symmetric NxN matrix stored with element stride S (A[(i*N+j)*S]):
@@ -284,6 +290,54 @@ int lmeds_essential_host(const float* p2, int w, int h, float fx, float fy, floa
     return 1;
 }
 
+// the five correspondences of sample `hy` -> up to ten essential matrices (unused slots NaN)
+VK_HD inline void boot5_sample(const BootGeom& g, const float* p2, int hy, double (*Es)[9]) {
+    double q1[5][2], q2[5][2];
+    for (int k = 0; k < 5; k++) {
+        const int i = (int)(rng3(RAND_SEED, (uint32_t)hy, 0x200u + (uint32_t)k) % (uint32_t)g.n);
+        boot_corr(g, p2, i, q1[k], q2[k]);
+    }
+    const int n = fivept::solve(q1, q2, Es);
+    const double qnan = __builtin_nan("");
+    for (int m = n; m < 10; m++) for (int c = 0; c < 9; c++) Es[m][c] = qnan;
+}
+int lmeds_essential_host5(const float* p2, int w, int h, float fx, float fy, float cx, float cy, float* R9, float* t3) {
+    const BootGeom g = boot_geom(w, h, fx, fy, cx, cy);
+    if (g.n < 8) return 0;
+    std::vector<double> errs(g.ns);
+    double best_med = INFINITY, bestE[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 0 };
+    for (int hy = 0; hy < BOOT5_SAMPLES; hy++) {
+        double Es[10][9];
+        boot5_sample(g, p2, hy, Es);
+        for (int m = 0; m < 10; m++) {
+            if (!(Es[m][0] == Es[m][0])) continue;
+            for (int j = 0; j < g.ns; j++) {
+                double q1[2], q2[2];
+                boot_corr(g, p2, j * g.sstride, q1, q2);
+                double v = boot_sampson(Es[m], q1, q2);
+                errs[j] = (v == v) ? v : INFINITY;
+            }
+            std::nth_element(errs.begin(), errs.begin() + g.ns / 2, errs.end());
+            const double med = errs[g.ns / 2];
+            if (med < best_med) { best_med = med; memcpy(bestE, Es[m], sizeof bestE); }  // first strict minimum in (sample, model) order
+        }
+    }
+    double Rc[2][9], tc[3];
+    boot_decompose(bestE, Rc, tc);
+    int best = 0, best_cnt = -1;
+    for (int cand = 0; cand < 4; cand++) {
+        int cnt = 0;
+        for (int j = 0; j < g.ns; j++) {
+            double q1[2], q2[2];
+            boot_corr(g, p2, j * g.sstride, q1, q2);
+            if (boot_in_front(Rc[cand >> 1], tc, (cand & 1) ? -1.0 : 1.0, q1, q2)) cnt++;
+        }
+        if (cnt > best_cnt) { best_cnt = cnt; best = cand; }
+    }
+    boot_finish(Rc[best >> 1], tc, (best & 1) ? -1.0 : 1.0, R9, t3);
+    return 1;
+}
+
 // ---- kernels --------------------------------------------------------------------------------------
 __global__ static void k_extract_corr(const float2* __restrict__ flow, float* __restrict__ out, int w, int h, int step, int nx, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -306,6 +360,15 @@ __global__ __launch_bounds__(64) static void k_boot_hyp(const float* __restrict_
     for (int k = 0; k < 9; k++) Es[(size_t)hy * 9 + k] = E[k];
 }
 
+// five-point samples: one lane per sample, up to ten models each (private arrays: the bootstrap runs once per window)
+__global__ __launch_bounds__(64) static void k_boot_hyp5(const float* __restrict__ p2, BootGeom g, double* __restrict__ Es) {
+    const int hy = blockIdx.x * 64 + threadIdx.x;
+    if (hy >= BOOT5_SAMPLES) return;
+    double E[10][9];
+    boot5_sample(g, p2, hy, E);
+    for (int m = 0; m < 10; m++) for (int k = 0; k < 9; k++) Es[((size_t)hy * 10 + m) * 9 + k] = E[m][k];
+}
+
 // one workgroup per hypothesis: squared Sampson distances of the scoring subset and their median = the element of rank ns / 2 in
 // ascending order (what a full sort would leave at s[ns / 2]).  The distances are >= 0 (NaN counted as +inf), so their bit patterns
 // order like the values: a most-significant-digit-first radix SELECT finds that element in 8 passes of 8 bits over values that stay in
@@ -320,6 +383,7 @@ __global__ __launch_bounds__(256) static void k_boot_score(const float* __restri
     const int hy = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     double E[9];
     for (int k = 0; k < 9; k++) E[k] = Es[(size_t)hy * 9 + k];
+    if (!(E[0] == E[0])) { if (tid == 0) med[hy] = INFINITY; return; }  // an unused model slot of a five-point sample (uniform: the whole workgroup leaves)
     unsigned long long key[PER];
 #pragma unroll
     for (int u = 0; u < PER; u++) {
@@ -364,7 +428,7 @@ __global__ __launch_bounds__(256) static void k_boot_score(const float* __restri
 
 // argmin over hypotheses, decomposition, cheirality vote, pose write-back (single workgroup)
 __global__ __launch_bounds__(256) static void k_boot_select(const float* __restrict__ p2, BootGeom g, const double* __restrict__ Es,
-                                                             const double* __restrict__ med, PoseBlock* P, CamState* cam0, float* __restrict__ Mb, int strict) {
+                                                             const double* __restrict__ med, PoseBlock* P, CamState* cam0, float* __restrict__ Mb, int strict, int n_models) {
     __shared__ double sRc[2][9], stc[3];
     __shared__ int s_cnt[4][4];
     const int tid = threadIdx.x;
@@ -372,10 +436,9 @@ __global__ __launch_bounds__(256) static void k_boot_select(const float* __restr
     __shared__ double s_bm[4];
     __shared__ int s_bi[4];
     {
-        static_assert(BOOT_HYPS == 256, "one hypothesis per thread");
-        double bm = med[tid];
-        int bi = tid;
-        if (!(bm < INFINITY)) { bm = INFINITY; bi = BOOT_HYPS; }  // never "below": loses against everything, like the sequential scan
+        double bm = INFINITY;
+        int bi = n_models;  // never "below": loses against everything, like the sequential scan
+        for (int i = tid; i < n_models; i += 256) { const double m = med[i]; if (m < bm) { bm = m; bi = i; } }  // (ascending indices: ties stay with the lower one)
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const double om = __shfl_xor(bm, o, 64);
@@ -386,12 +449,12 @@ __global__ __launch_bounds__(256) static void k_boot_select(const float* __restr
     }
     __syncthreads();
     if (tid == 0) {
-        int best = BOOT_HYPS;
+        int best = n_models;
         double bm = INFINITY;
         for (int k = 0; k < 4; k++) if (s_bm[k] < bm || (s_bm[k] == bm && s_bi[k] < best)) { bm = s_bm[k]; best = s_bi[k]; }
-        if (best >= BOOT_HYPS) best = 0;
-        double E[9], Rc[2][9], tc[3];
-        for (int k = 0; k < 9; k++) E[k] = Es[(size_t)best * 9 + k];
+        double E[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 0 }, Rc[2][9], tc[3];
+        if (best >= n_models) best = (n_models == BOOT_HYPS) ? 0 : -1;  // no finite median: the 8-point path falls back to hypothesis 0, the five-point path to a fixed E
+        if (best >= 0) for (int k = 0; k < 9; k++) E[k] = Es[(size_t)best * 9 + k];
         boot_decompose(E, Rc, tc);
         for (int k = 0; k < 9; k++) { sRc[0][k] = Rc[0][k]; sRc[1][k] = Rc[1][k]; }
         for (int k = 0; k < 3; k++) stc[k] = tc[k];
@@ -443,20 +506,22 @@ __global__ __launch_bounds__(256) static void k_depth_closed_form(const float2* 
     depth[y * w + x] = fminf(fmaxf(zn / zd, min_depth), max_depth);
 }
 
-int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, float cx, float cy, CamState* cam0_dev, bool strict) {
+int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, float cx, float cy, CamState* cam0_dev, bool strict, int points) {
     const BootGeom g = boot_geom(w, h, fx, fy, cx, cy);
-    const size_t bytes = sizeof(double) * (BOOT_HYPS * 10 + 4) + sizeof(float) * (2 * (size_t)g.n + 16) + 64;
+    const size_t bytes = sizeof(double) * (BOOT_MAX_MODELS * 10 + 4) + sizeof(float) * (2 * (size_t)g.n + 16) + 64;
     if (int e = c->tmp.reserve(bytes)) return e;
     char* base = c->tmp.as<char>();
-    double* d_E = reinterpret_cast<double*>(base);                       // [256][9]
-    double* d_med = d_E + BOOT_HYPS * 9;                                  // [256]
-    float* d_Mb = reinterpret_cast<float*>(d_med + BOOT_HYPS);            // [12] (+4 pad)
+    double* d_E = reinterpret_cast<double*>(base);                       // [models][9]
+    double* d_med = d_E + BOOT_MAX_MODELS * 9;                            // [models]
+    float* d_Mb = reinterpret_cast<float*>(d_med + BOOT_MAX_MODELS);      // [12] (+4 pad)
     float* d_p2 = d_Mb + 16;                                              // [n][2]
     if (g.n >= 8) {
         hipLaunchKernelGGL(k_extract_corr, dim3((g.n + 255) / 256), dim3(256), 0, c->stream, S.flows.as<float2>(), d_p2, w, h, g.step, g.nx, g.n);
-        hipLaunchKernelGGL(k_boot_hyp, dim3(BOOT_HYPS / 64), dim3(64), 0, c->stream, d_p2, g, d_E);
-        hipLaunchKernelGGL(k_boot_score, dim3(BOOT_HYPS), dim3(256), 0, c->stream, d_p2, g, d_E, d_med);
-        hipLaunchKernelGGL(k_boot_select, dim3(1), dim3(256), 0, c->stream, d_p2, g, d_E, d_med, S.pb(), cam0_dev, d_Mb, strict ? 1 : 0);
+        const int n_models = points == 5 ? BOOT5_MODELS : BOOT_HYPS;
+        if (points == 5) hipLaunchKernelGGL(k_boot_hyp5, dim3((BOOT5_SAMPLES + 63) / 64), dim3(64), 0, c->stream, d_p2, g, d_E);
+        else hipLaunchKernelGGL(k_boot_hyp, dim3(BOOT_HYPS / 64), dim3(64), 0, c->stream, d_p2, g, d_E);
+        hipLaunchKernelGGL(k_boot_score, dim3(n_models), dim3(256), 0, c->stream, d_p2, g, d_E, d_med);
+        hipLaunchKernelGGL(k_boot_select, dim3(1), dim3(256), 0, c->stream, d_p2, g, d_E, d_med, S.pb(), cam0_dev, d_Mb, strict ? 1 : 0, n_models);
     } else {  // too few correspondences: identity pose (the host path returns failure and keeps R=I, t=0)
         const float K9[9] = { fx, 0, cx, 0, fy, cy, 0, 0, 1 }, R[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 }, t[3] = { 0, 0, 0 };
         float Mb[12];
@@ -485,8 +550,33 @@ int vk_estimate_pose_epipolar(const float* h_flow, const float* h_K, int w, int 
         }
     return vk::lmeds_essential_host(p2.data(), w, h, h_K[0], h_K[4], h_K[2], h_K[5], h_o_R9, h_o_t3) ? 0 : 1;
 }
+// the same with the five-point minimal solver (vk_fivept.hpp; config key --bootstrap_points 5): host path, no GPU needed
+int vk_estimate_pose_epipolar5(const float* h_flow, const float* h_K, int w, int h, float* h_o_R9, float* h_o_t3) {
+    const int step = vk::BOOT_STEP, nx = (w + step - 1) / step, ny = (h + step - 1) / step;
+    std::vector<float> p2((size_t)nx * ny * 2);
+    for (int j = 0; j < ny; j++)
+        for (int i = 0; i < nx; i++) {
+            const int x = i * step, y = j * step;
+            p2[(size_t)(j * nx + i) * 2] = (float)x + h_flow[((size_t)y * w + x) * 2];
+            p2[(size_t)(j * nx + i) * 2 + 1] = (float)y + h_flow[((size_t)y * w + x) * 2 + 1];
+        }
+    return vk::lmeds_essential_host5(p2.data(), w, h, h_K[0], h_K[4], h_K[2], h_K[5], h_o_R9, h_o_t3) ? 0 : 1;
+}
+// the five-point solver alone: q1, q2 = five normalised correspondences [5][2] (image 1, image 2); Es receives up to ten essential matrices
+// (row-major, Frobenius norm sqrt 2); returns their number.  Host code.
+int vk_fivept_solve(const double* q1, const double* q2, double* Es) {
+    return vk::fivept::solve(reinterpret_cast<const double (*)[2]>(q1), reinterpret_cast<const double (*)[2]>(q2), reinterpret_cast<double (*)[9]>(Es));
+}
+// (vk_debug.h) the degree-10 polynomial of a sample and the real roots the solver found
+__attribute__((visibility("default"))) int vk_fivept_debug(const double* q1, const double* q2, double* poly11, double* roots10) {
+    double Es[10][9]; int nr = 0;
+    vk::fivept::solve(reinterpret_cast<const double (*)[2]>(q1), reinterpret_cast<const double (*)[2]>(q2), Es, poly11, roots10, &nr);
+    return nr;
+}
 // GPU path on a host flow: runs the bootstrap kernels, returns pose and closed-form depth
-int vk_bootstrap_gpu(const float* h_flow, const float* h_K, int w, int h, float* h_o_R9, float* h_o_t3, float* h_o_depth) {
+int vk_bootstrap_gpu(const float* h_flow, const float* h_K, int w, int h, float* h_o_R9, float* h_o_t3, float* h_o_depth) { return vk_bootstrap_gpu_points(h_flow, h_K, w, h, 8, h_o_R9, h_o_t3, h_o_depth); }
+int vk_bootstrap_gpu_points(const float* h_flow, const float* h_K, int w, int h, int points, float* h_o_R9, float* h_o_t3, float* h_o_depth) {
+    if (points != 5 && points != 8) return (int)hipErrorInvalidValue;
     vk::Context* c = vk::default_context();
     if (!c) return (int)hipErrorNoDevice;
     vk::ImageSet& S = c->od;
@@ -496,7 +586,7 @@ int vk_bootstrap_gpu(const float* h_flow, const float* h_K, int w, int h, float*
     if (int e = S.depth.reserve(sizeof(float) * npx)) return e;
     if (int e = c->cams.reserve(sizeof(vk::CamState) * vk::MAX_FRAMES)) return e;
     VK_CHECK(hipMemcpyAsync(S.flows.p, h_flow, sizeof(float) * 2 * npx, hipMemcpyHostToDevice, c->stream));
-    if (int e = vk::bootstrap_device(c, S, w, h, h_K[0], h_K[4], h_K[2], h_K[5], c->cams.as<vk::CamState>())) return e;
+    if (int e = vk::bootstrap_device(c, S, w, h, h_K[0], h_K[4], h_K[2], h_K[5], c->cams.as<vk::CamState>(), false, points)) return e;
     if (h_o_R9) VK_CHECK(hipMemcpyAsync(h_o_R9, S.pb()->Rs[0], sizeof(float) * 9, hipMemcpyDeviceToHost, c->stream));
     if (h_o_t3) VK_CHECK(hipMemcpyAsync(h_o_t3, S.pb()->ts[0], sizeof(float) * 3, hipMemcpyDeviceToHost, c->stream));
     if (h_o_depth) VK_CHECK(hipMemcpyAsync(h_o_depth, S.depth.p, sizeof(float) * npx, hipMemcpyDeviceToHost, c->stream));

@@ -170,6 +170,7 @@ struct Context {
     DevBuf cams;                  // CamState[MAX_FRAMES]
     DevBuf tmp;                   // misc scratch (gblur, depth_conf ...)
     DevBuf fb_scratch;            // strict fb_smooth: forward messages [n_maps][h][w]
+    DevBuf sp_coop;               // strict mode kernel, cooperative form: block sums, pool size and the grid barrier's counter (vk_strict.hip CoopGlobal)
     bool strict = false;          // strict-math mode of the B-inner entry points that use this context (vk_set_strict_math)
     // --reference_rng 1: the jump matrices T^(2^67 2^k) (vk_ref_cuda.h), the per-pixel XORWOW states of the depth samples
     // (optimize_depth.cu:286-291; they stand xw_px_epoch draws after curand_init for a xw_px_n-pixel image) and the states right after

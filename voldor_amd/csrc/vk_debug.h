@@ -15,6 +15,8 @@ extern "C" {
  *   "global_split"    1 | 0   0: global propagation with one lane per site instead of a group of lanes
  *   "refit_partition" 1 | 0   0: every gate pass of the refit walks the whole pool in arrival order
  *   "split_trials"    1 | 0   0: the mode kernel evaluates the initial-mode trials itself instead of one workgroup per trial
+ *   "strict_pose_coop" 1 | 0  strict mode kernel: 16 single-wave workgroups (one per 512-row block of the pool, block sums through global memory, one grid
+ *                             barrier per sum) or ONE 512-thread workgroup; the same bits
  *   "strict_plain"    0 | 1   1: strict mode on the plain launch structures (one lane per chain / line, one 256-thread workgroup walking the
  *                             reference's sum tree block by block) instead of the parallel structures -- both give the same bits
  *   "local_fused"     0 | 8 | 16   8 / 16: the four local passes of a call as ONE launch over 32 x 32 tiles with that many waves per tile (local_prop_width 32);

@@ -31,6 +31,7 @@ struct DebugSwitches {
     int newton_cap = 0;        // (experiment, measured and NOT adopted: DESIGN.md section 6) Newton steps of the P3P cubic in the FAST window pipeline: 0 = the reference's 50; an even cap <= 50 otherwise; strict mode always 50
     int strict_own_table = 0;  // (tuning) strict local pass: 1 = every chain tabulates its own steps at the head of the runs kernel, 0 = the tiled table kernel
     int strict_lpp8 = 0;       // (tuning) strict local pass: 8 lanes per pixel instead of 4 for up to 8 frames
+    int strict_pose_coop = 1;  // strict mode kernel on one single-wave workgroup per 512-row block of the pool (16 compute units) instead of one 512-thread workgroup; same bits
     int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
 };
 DebugSwitches& debug_switches();  // vk_abi.hip
@@ -97,7 +98,7 @@ int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 
 // vk_bootstrap.hip
-int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, float cx, float cy, CamState* cam0_dev, bool strict = false);
+int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, float cx, float cy, CamState* cam0_dev, bool strict = false, int points = 8);
 
 // vk_abi.hip: process-wide default of the strict-math mode (vk_set_strict_math / VOLDOR_HIP_STRICT_MATH)
 bool strict_math_default();

@@ -860,7 +860,7 @@ constexpr int MS_TRIAL_BATCH = VK_MS_TRIAL_BATCH;  // initial-mode trials evalua
 // reciprocal of its diagonal -- 21 coefficients like the packed inverse, the same 27 multiply-adds per sample -- and a factorisation
 // of ~80 fp64 instructions (6 reciprocal square roots by v_rsq_f64 + one Newton step) instead of the LU / Newton-Schulz inverse
 // exchanged through LDS by one wave (~40 % of a gate iteration before).  L is better conditioned than C^-1 (square root of its
-// condition number).  A pivot below DBL_EPSILON or not positive: the covariance is not positive definite -- the reference's
+// condition number).  A pivot that is not positive: the covariance is not positive definite -- the reference's
 // `det <= 0` verdict (unreliable fit).  W (out): L's strict lower triangle, 1 / L_ii on the diagonal.
 // cov: packed lower triangle (float).  rg_regularised: the regularised covariance rounded to float (what the reference keeps and reports;
 // needed once, when the loop has ended).
@@ -901,7 +901,7 @@ __device__ __forceinline__ bool rg_whiten(const float (&cov)[21], bool regularis
         double s = a[(j * j + j) / 2 + j];
 #pragma unroll
         for (int k = 0; k < j; k++) s -= L[(j * j + j) / 2 + k] * L[(j * j + j) / 2 + k];
-        ok = ok && (s >= 2.220446049250313e-16);  // false for NaN as well
+        ok = ok && (s > 0.0);  // every pivot positive <=> positive definite <=> the reference's det > 0 (fit_robust_gaussian.cu:195); false for NaN as well (the reference lets a NaN determinant pass and reports NaNs: here the fit counts as unreliable, which checkRange would have made of it anyway)
         inv[j] = rsqrt_f64(s);
         L[(j * j + j) / 2 + j] = s * inv[j];
 #pragma unroll

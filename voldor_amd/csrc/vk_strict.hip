@@ -539,21 +539,47 @@ struct StrictParShared {
     int cnt[SP_SLOTS * SP_WAVES + 1];
     int flag;
     float cov[21], cinv[21], mean[6];
+    float cent[28][6];  // centres of a batch of initial-mode trials
 };
 // out[k] = sum over rows i < n of row(i)[k], k < NV, in the reference's tree order; rowfn(slot, v) = the NV values of this lane's row in
 // slot `slot` (block 2 wv + slot / 8, row 64 (slot % 8) + bitrev6(lane) of it; called for every slot, rows beyond n are discarded).
 // All threads call it; the result is in every thread.
 // lane_total (optional): the total of value `lane` in lanes < NV of every wave (what the broadcast below reads) -- lets the caller finish
 // per-value work (the refit's 27 divisions by the weight) in one lane per value instead of in every thread.
-template <int NV, typename RowFn>
-__device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared& S, int& parity, float (&out)[NV], float* lane_total = nullptr) {
+// COOPERATIVE form (k_pose_strict_par<true>): the pool's 16 blocks on 16 single-wave workgroups (16 compute units instead of one: a refit
+// iteration's pass over 8192 rows is ~130 instructions per row and was bound by the issue rate of ONE compute unit).  Workgroup b owns
+// block b: the same in-lane pair sums and the same transposing wave reduction, then the block sums meet in GLOBAL memory (agent-scope
+// atomic stores / loads), one grid barrier per sum (double buffered like the LDS form), and every workgroup walks the second-level tree
+// itself -- every workgroup carries the whole control flow redundantly on identical numbers, so they agree on every branch.
+struct CoopGlobal { float lvl[2][16][32]; float raw[32]; unsigned counter; int used; unsigned err; unsigned pad; };
+// grid barrier of the NB single-wave workgroups: an arrival counter that only grows (zeroed by k_pose_strict_compact, which runs right
+// before on the same stream).  The spin is BOUNDED: a workgroup that never sees the others (it cannot happen while all NB are resident --
+// 16 waves on a 256-CU chip -- but a hang here would take the GPU box with it) raises G->err and goes on with whatever it reads.
+__device__ __forceinline__ void coop_grid_sync(CoopGlobal* G, unsigned& target, int nb_wg) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    target += (unsigned)nb_wg;
+    if ((threadIdx.x & 63) == 0) {
+        __hip_atomic_fetch_add(&G->counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while (__hip_atomic_load(&G->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1u << 24)) { __hip_atomic_store(&G->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+template <int NV, bool COOP, typename RowFn>
+__device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared& S, CoopGlobal* G, unsigned& sync_target, int& parity, float (&out)[NV],
+                                             float* lane_total = nullptr) {
 #pragma clang fp contract(off)
     constexpr int P = NV <= 8 ? 8 : 32;
+    constexpr int NBLK_OWN = COOP ? 1 : 2;  // blocks per wave
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, q = (int)(__brev((unsigned)lane) >> 26);
     const int nb = (n + 511) / 512;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int blk = 2 * wv + h, base = blk * 512 + q;
+    for (int h = 0; h < NBLK_OWN; h++) {
+        const int blk = COOP ? (int)blockIdx.x : 2 * wv + h, base = blk * 512 + q;
         float acc[P];
         // stride 256: rows (j, j + 4); stride 128: (j, j + 2); stride 64: (0, 1)
         auto pair = [&](int j, float (&s)[NV]) {
@@ -561,9 +587,9 @@ __device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared
             rowfn(h * 8 + j, v0);
             rowfn(h * 8 + j + 4, v1);
             const bool h0 = base + 64 * j < n, h1 = base + 64 * j + 256 < n;
-            if (n == 1 && threadIdx.x == 0 && h == 0 && j == 0) {
+            if (n == 1 && blk == 0 && lane == 0 && j == 0) {
 #pragma unroll
-                for (int k = 0; k < NV; k++) S.raw[k] = v0[k];
+                for (int k = 0; k < NV; k++) { if (COOP) __hip_atomic_store(&G->raw[k], v0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else S.raw[k] = v0[k]; }
             }
 #pragma unroll
             for (int k = 0; k < NV; k++) s[k] = h0 ? (h1 ? v0[k] + v1[k] : v0[k]) : 0.f;
@@ -584,17 +610,21 @@ __device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared
         for (int k = NV; k < P; k++) acc[k] = 0.f;
         const float mine = wave_reduce_transpose<P>(acc);  // strides 32 .. 1 of the rows = lane distances 1 .. 32
         const int slot = wave_slot<P>(lane);
-        if (lane < P && slot < NV) S.lvl[parity][blk][slot] = mine;
+        if (lane < P && slot < NV) {
+            if (COOP) __hip_atomic_store(&G->lvl[parity][blk][slot], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else S.lvl[parity][blk][slot] = mine;
+        }
     }
-    __syncthreads();
+    if (COOP) coop_grid_sync(G, sync_target, (int)gridDim.x); else __syncthreads();
     float tot = 0.f;
     if (lane < NV) {
-        if (n == 1) tot = S.raw[lane];
-        else if (nb == 1) tot = S.lvl[parity][0][lane];
+        auto at = [&](int t) { return COOP ? __hip_atomic_load(&G->lvl[parity][t][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.lvl[parity][t][lane]; };
+        if (n == 1) tot = COOP ? __hip_atomic_load(&G->raw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.raw[lane];
+        else if (nb == 1) tot = at(0);
         else {
             float b[16];
 #pragma unroll
-            for (int t = 0; t < 16; t++) b[t] = (t < nb ? S.lvl[parity][t][lane] : 0.f) + 0.f;  // strides 128 .. 16 of the second level add zeros
+            for (int t = 0; t < 16; t++) b[t] = (t < nb ? at(t) : 0.f) + 0.f;  // strides 128 .. 16 of the second level add zeros
 #pragma unroll
             for (int st = 8; st >= 1; st >>= 1)
 #pragma unroll
@@ -608,17 +638,11 @@ __device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared
     parity ^= 1;
 }
 
-__global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_par(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp,
-                                                                        CamState* cam, PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev,
-                                                                        float* __restrict__ pool) {
-#pragma clang fp contract(off)
-    __shared__ StrictParShared S;
+// ordered compaction of the finite hypotheses into `pool` (geometry.cpp:156-165): counts per (slice of 512, wave), one prefix, ordered
+// writes.  Called by all SP_THREADS threads of one workgroup; returns the pool size (0: nothing finite).
+__device__ __forceinline__ int strict_compact_pool(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, float rvec_scale,
+                                                   float* __restrict__ pool, StrictParShared& S) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    if (*n_points_dev < 4) {  // geometry.cpp:84-88
-        if (t == 0) { cam->success = 0; maybe_decide(mp, P, cam, cam_idx); }
-        return;
-    }
-    // ---- pool of finite hypotheses, in index order (geometry.cpp:156-165): counts per (slice of 512, wave), one prefix, ordered writes
     auto load6 = [&](int i, float (&v)[6]) {
         v[0] = rvecs[i]; v[1] = rvecs[(size_t)n_poses + i]; v[2] = rvecs[(size_t)2 * n_poses + i];
         v[3] = tvecs[i]; v[4] = tvecs[(size_t)n_poses + i]; v[5] = tvecs[(size_t)2 * n_poses + i];
@@ -645,10 +669,6 @@ __global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_par(const flo
     }
     __syncthreads();
     const int used = S.cnt[SP_SLOTS * SP_WAVES];
-    if (used == 0) {
-        if (t == 0) { cam->success = 0; maybe_decide(mp, P, cam, cam_idx); }
-        return;
-    }
 #pragma unroll
     for (int k = 0; k < SP_SLOTS; k++) {
         const int i = k * SP_THREADS + t;
@@ -658,19 +678,53 @@ __global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_par(const flo
             float v[6];
             load6(i, v);
             const int r = S.cnt[k * SP_WAVES + wv] + __popcll(m & ((1ull << lane) - 1ull));
-            pool[(size_t)r * 6] = v[0] * mp.rvec_scale; pool[(size_t)r * 6 + 1] = v[1] * mp.rvec_scale; pool[(size_t)r * 6 + 2] = v[2] * mp.rvec_scale;  // :191
+            pool[(size_t)r * 6] = v[0] * rvec_scale; pool[(size_t)r * 6 + 1] = v[1] * rvec_scale; pool[(size_t)r * 6 + 2] = v[2] * rvec_scale;  // :191
             pool[(size_t)r * 6 + 3] = v[3]; pool[(size_t)r * 6 + 4] = v[4]; pool[(size_t)r * 6 + 5] = v[5];
         }
     }
-    __threadfence_block();
-    __syncthreads();
+    return used;
+}
+// first launch of the cooperative form: the pool, its size, and the grid barrier's counter back to zero
+__global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_compact(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, float rvec_scale,
+                                                                            const int* __restrict__ n_points_dev, float* __restrict__ pool, CoopGlobal* G) {
+    __shared__ StrictParShared S;
+    int used = 0;
+    if (*n_points_dev >= 4) used = strict_compact_pool(rvecs, tvecs, n_poses, rvec_scale, pool, S);
+    if (threadIdx.x == 0) { G->used = used; G->counter = 0u; G->err = 0u; }
+}
+
+template <bool COOP>
+__global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_par(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp,
+                                                                                   CamState* cam, PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev,
+                                                                                   float* __restrict__ pool, CoopGlobal* G) {
+#pragma clang fp contract(off)
+    __shared__ StrictParShared S;
+    constexpr int NSLOT = COOP ? 8 : SP_SLOTS;  // rows per lane
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const bool writer = t == 0 && (!COOP || blockIdx.x == 0);  // the one thread that writes the camera record (every cooperative workgroup computes the same numbers)
+    unsigned sync_target = 0u;
+    if (*n_points_dev < 4) {  // geometry.cpp:84-88
+        if (writer) { cam->success = 0; maybe_decide(mp, P, cam, cam_idx); }
+        return;
+    }
+    int used;
+    if constexpr (COOP) used = G->used;  // k_pose_strict_compact ran before
+    else {
+        used = strict_compact_pool(rvecs, tvecs, n_poses, mp.rvec_scale, pool, S);
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (used == 0) {
+        if (writer) { cam->success = 0; maybe_decide(mp, P, cam, cam_idx); }
+        return;
+    }
     // ---- this lane's rows into registers
-    float X[SP_SLOTS][6];
+    float X[NSLOT][6];
     {
         const int q = (int)(__brev((unsigned)lane) >> 26);
 #pragma unroll
-        for (int sl = 0; sl < SP_SLOTS; sl++) {
-            const int i = (2 * wv + (sl >> 3)) * 512 + 64 * (sl & 7) + q;
+        for (int sl = 0; sl < NSLOT; sl++) {
+            const int i = (COOP ? (int)blockIdx.x : 2 * wv + (sl >> 3)) * 512 + 64 * (sl & 7) + q;
 #pragma unroll
             for (int d = 0; d < 6; d++) X[sl][d] = i < used ? pool[(size_t)i * 6 + d] : 0.f;
         }
@@ -684,23 +738,39 @@ __global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_par(const flo
     if (external_init) {
         for (int d = 0; d < 6; d++) c_mean[d] = io_mean[d];
     } else {
+        // :75-95.  The density of a trial does not depend on the other trials, only the decision WHICH trials run does (better-than /
+        // good-enough, in order): up to 28 trials are summed in ONE tree (28 values side by side: one barrier instead of 28) and the
+        // reference's sequential rule is replayed on the numbers.  Same sums, same picks.
         float best = 0;
         int best_idx = -1;
-        for (int trial = 0; trial < mp.ms_max_init_trials; trial++) {  // :75-95
-            const int idx_rand = (int)(rng3(RAND_SEED, (uint32_t)trial, 0x4D53u) % (uint32_t)used);
-            float c[6];
-            for (int d = 0; d < 6; d++) c[d] = pool[(size_t)idx_rand * 6 + d];
-            auto row = [&](int sl, float (&v)[1]) {
-                float l2 = 0;
+        bool done = false;
+        for (int t0 = 0; t0 < mp.ms_max_init_trials && !done; t0 += 28) {
+            const int nt = min(28, mp.ms_max_init_trials - t0);
+            __syncthreads();
+            if (t < 28 * 6) {
+                const int k = t / 6, d = t % 6;
+                if (k < nt) S.cent[k][d] = pool[(size_t)(rng3(RAND_SEED, (uint32_t)(t0 + k), 0x4D53u) % (uint32_t)used) * 6 + d];
+            }
+            if (COOP && t < 64) {  // (64 threads: three rounds)
+                for (int e = t + 64; e < 28 * 6; e += 64) { const int k = e / 6, d = e % 6; if (k < nt) S.cent[k][d] = pool[(size_t)(rng3(RAND_SEED, (uint32_t)(t0 + k), 0x4D53u) % (uint32_t)used) * 6 + d]; }
+            }
+            __syncthreads();
+            auto row = [&](int sl, float (&v)[28]) {
+#pragma unroll 1
+                for (int k = 0; k < 28; k++) {
+                    float l2 = 0;
 #pragma unroll
-                for (int d = 0; d < 6; d++) { const float df = X[sl][d] - c[d]; l2 += df * df; }
-                v[0] = vsm_expf(-l2 / two_var);
+                    for (int d = 0; d < 6; d++) { const float df = X[sl][d] - S.cent[k < nt ? k : 0][d]; l2 += df * df; }
+                    v[k] = k < nt ? vsm_expf(-l2 / two_var) : 0.f;
+                }
             };
-            float o1[1];
-            tree_sum_par<1>(used, row, S, parity, o1);
-            const float wsum = o1[0];
-            if (wsum > best) { best = wsum; best_idx = idx_rand; }
-            if (best > mp.ms_good_init_confidence * (float)used) break;
+            float o28[28];
+            tree_sum_par<28, COOP>(used, row, S, G, sync_target, parity, o28);
+            for (int k = 0; k < nt; k++) {
+                const float wsum = o28[k];
+                if (wsum > best) { best = wsum; best_idx = (int)(rng3(RAND_SEED, (uint32_t)(t0 + k), 0x4D53u) % (uint32_t)used); }
+                if (best > mp.ms_good_init_confidence * (float)used) { done = true; break; }
+            }
         }
         if (best_idx < 0) best_idx = 0;
         for (int d = 0; d < 6; d++) c_mean[d] = pool[(size_t)best_idx * 6 + d];
@@ -718,7 +788,7 @@ __global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_par(const flo
             for (int d = 0; d < 6; d++) v[1 + d] = X[sl][d] * wgt;
         };
         float o7[7];
-        tree_sum_par<7>(used, row, S, parity, o7);
+        tree_sum_par<7, COOP>(used, row, S, G, sync_target, parity, o7);
         const float wsum = o7[0];
         float m[6];
         for (int d = 0; d < 6; d++) m[d] = o7[1 + d] / wsum;
@@ -789,7 +859,7 @@ __global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_par(const flo
             // only the weight is needed by every thread; thread k (< 28) of wave 0 finishes value k itself
             {
                 float o28[28];
-                tree_sum_par<28>(N, row, S, parity, o28, &mine);
+                tree_sum_par<28, COOP>(N, row, S, G, sync_target, parity, o28, &mine);
                 o1[0] = o28[0];
             }
             weight = o1[0];
@@ -825,9 +895,10 @@ __global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_par(const flo
         const float irs = cv_div_scale(mp.rvec_scale);  // :249
         for (int d = 0; d < 3; d++) pose_opm[d] *= irs;
     }
-    if (t == 0) {
+    if (writer) {
         bool ok = true;
         for (int d = 0; d < 6; d++) ok = ok && isfinite(pose_opm[d]);  // checkRange :256
+        if (COOP && __hip_atomic_load(&G->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok = false;  // a grid barrier gave up: never report a pose from it
         cam->pose_sample_count = used;
         cam->pose_density = density;
         cam->last_used_ms_iters = ms_iters;
@@ -1015,8 +1086,17 @@ int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamSt
     }
     if (int e = c->pool.reserve(sizeof(float) * 6 * (size_t)n_poses)) return e;
     if (!debug_switches().strict_plain && n_poses <= SP_MAX_POSES) {  // the parallel tree (same bits)
-        hipLaunchKernelGGL(k_pose_strict_par, dim3(1), dim3(SP_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp, cam_dev, P, cam_idx,
-                           c->n_points.as<int>(), c->pool.as<float>());
+        if (debug_switches().strict_pose_coop) {  // one single-wave workgroup per 512-row block, block sums through global memory
+            if (int e = c->sp_coop.reserve(sizeof(CoopGlobal))) return e;
+            CoopGlobal* G = c->sp_coop.as<CoopGlobal>();
+            const int nblk = (n_poses + 511) / 512;
+            hipLaunchKernelGGL(k_pose_strict_compact, dim3(1), dim3(SP_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp.rvec_scale,
+                               c->n_points.as<int>(), c->pool.as<float>(), G);
+            hipLaunchKernelGGL(k_pose_strict_par<true>, dim3(nblk), dim3(64), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp, cam_dev, P, cam_idx,
+                               c->n_points.as<int>(), c->pool.as<float>(), G);
+        } else
+            hipLaunchKernelGGL(k_pose_strict_par<false>, dim3(1), dim3(SP_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp, cam_dev, P, cam_idx,
+                               c->n_points.as<int>(), c->pool.as<float>(), (CoopGlobal*)nullptr);
         VK_CHECK_LAST();
         return 0;
     }

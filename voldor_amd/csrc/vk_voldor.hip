@@ -57,6 +57,10 @@ struct Config {
     //  reference_tex   1 (with strict_math): every at_tex of the reference through CUDA's linear filter -- 8-bit fractions, one texture over
     //                  the stacked layers -- instead of the exact per-layer bilinear (D2).  -1 (default) = the process-wide settings
     int strict_math = -1, reference_draw = 1, reference_svd = -1, reference_rng = -1, reference_tex = -1;
+    //  bootstrap_points  8 (default): normalised 8-point LMedS for the monocular two-view bootstrap; 5: the five-point minimal solver of
+    //                  cv::findEssentialMat (voldor/geometry.cpp:316-326; vk_fivept.hpp), 192 samples x up to ten models (deviation D5 narrows
+    //                  to "OpenCV's numerics are not reproduced")
+    int bootstrap_points = 8;
 
     // Returns 0, or non-zero where the reference prints and calls exit(1) (config.h:101-108,245-248):
     // a library must not exit its host process, so the error is reported to the caller instead.
@@ -75,7 +79,7 @@ struct Config {
             KI(depth_global_prop_step), KI(depth_local_prop_width), KF(depth_range_factor), KI(meanshift_max_iters),
             KI(meanshift_max_init_trials), KF(meanshift_good_init_confidence), KF(meanshift_epsilon), KI(kitti_estimate_ground),
             KI(kitti_ground_holo_width), KF(kitti_ground_roi), KF(kitti_ground_meanshift_kernel_var),
-            KI(strict_math), KI(reference_draw), KI(reference_svd), KI(reference_rng), KI(reference_tex),
+            KI(strict_math), KI(reference_draw), KI(reference_svd), KI(reference_rng), KI(reference_tex), KI(bootstrap_points),
         };
 #undef KF
 #undef KI
@@ -283,7 +287,7 @@ struct Voldor {
     int solve() {
         if (n_dp == 0) {  // bootstrap :151-162
             if (c->prof) prof_begin(c);
-            if (int e = bootstrap_device(c, c->od, w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, dcams(), strict)) return e;
+            if (int e = bootstrap_device(c, c->od, w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, dcams(), strict, cfg.bootstrap_points == 5 ? 5 : 8)) return e;
             if (c->prof) prof_end(c, "bootstrap");
         }
         while (iters_remain > 0 && n_flows > 0) {

@@ -169,14 +169,33 @@ def estimate_pose_epipolar(flow, K):
     return rc == 0, R.reshape(3, 3), t
 
 
-def bootstrap_gpu(flow, K):
-    """GPU bootstrap kernels of the window pipeline (pose by LMedS + closed-form depth)."""
+def estimate_pose_epipolar5(flow, K):
+    """Host path of the two-view bootstrap with the five-point minimal solver (vk_estimate_pose_epipolar5; --bootstrap_points 5)."""
+    flow = f32(flow)
+    h, w, _ = flow.shape
+    R = np.zeros(9, np.float32)
+    t = np.zeros(3, np.float32)
+    rc = capi.lib().vk_estimate_pose_epipolar5(fp(flow), fp(f32(K).reshape(9)), w, h, fp(R), fp(t))
+    return rc == 0, R.reshape(3, 3), t
+
+
+def fivept_solve(q1, q2):
+    """The five-point solver alone (vk_fivept_solve, host code): q1, q2 [5, 2] normalised correspondences -> [n, 3, 3] essential matrices."""
+    q1 = np.ascontiguousarray(q1, np.float64).reshape(5, 2); q2 = np.ascontiguousarray(q2, np.float64).reshape(5, 2)
+    Es = np.zeros((10, 9), np.float64)
+    D = C.POINTER(C.c_double)
+    n = capi.lib().vk_fivept_solve(q1.ctypes.data_as(D), q2.ctypes.data_as(D), Es.ctypes.data_as(D))
+    return Es[:n].reshape(n, 3, 3)
+
+
+def bootstrap_gpu(flow, K, points=8):
+    """GPU bootstrap kernels of the window pipeline (pose by LMedS + closed-form depth); points = 8 | 5 (minimal solver)."""
     flow = f32(flow)
     h, w, _ = flow.shape
     R = np.zeros(9, np.float32)
     t = np.zeros(3, np.float32)
     d = np.zeros((h, w), np.float32)
-    capi.check(capi.lib().vk_bootstrap_gpu(fp(flow), fp(f32(K).reshape(9)), w, h, fp(R), fp(t), fp(d)), "vk_bootstrap_gpu")
+    capi.check(capi.lib().vk_bootstrap_gpu_points(fp(flow), fp(f32(K).reshape(9)), w, h, int(points), fp(R), fp(t), fp(d)), "vk_bootstrap_gpu_points")
     return R.reshape(3, 3), t, d
 
 
