@@ -12,17 +12,20 @@ HBM when the timed region starts (vk_voldor_device).  With N>1 every rank owns o
 per step.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     dominant streaming kernel k_cost_rand_q (cost map + random depth samples): algorithmic bytes
-               w*h*(12N+12N_dp+16) / average launch duration measured with HIP events on the library's stream
-               (vk_profile_*), against the 8 TB/s HBM peak; `traffic` = PMC FETCH_SIZE/WRITE_SIZE bytes per
-               launch and `valu_issue_frac` from the raw SQ counters of the same kernel (profiles/r02h_pmc_*.json / r02c_pmc_*.json,
-               scripts/pmc_traffic.sh, scripts/pmc_sq.sh).  The optimize_depth group (B_od = w*h*(40N+36N_dp+12),
-               BASELINE.md §4) is reported next to it.
-  host_inclusive  SURVEY.md §8(d)'s own definition of a frame: py_voldor_wrapper with the flows in pageable HOST memory
+  roofline     SURVEY 8(d)'s unit: one optimize_depth call (a group of dependent launches): B_od = w*h*(40N+36N_dp+12) bytes
+                / the group's duration measured with HIP events on the library's stream in THIS run
+               (vk_profile_*), against the 8 TB/s HBM peak.  `dominant_kernel`: k_cost_rand_q (cost map + random depth samples),
+               w*h*(12N+12N_dp+16) bytes per launch.  `traffic`, `valu`, `sq_counters_per_launch` are REPLAYED from the committed
+               rocprofv3 --pmc passes (scripts/pmc_traffic.sh, scripts/pmc_sq.sh -> profiles/rNN*_pmc_*.json); every pass records the
+               sha256 of the kernel sources it was collected on, and a pass from other sources is flagged `stale` and withheld (null).
+  host_inclusive  SURVEY.md 8(d)'s own definition of a frame: py_voldor_wrapper with the flows in pageable HOST memory
                and depth / confidence returned to the host; median of 20 calls after 3 warm-ups (never `value`).
-  strict       one window in strict-math mode (--strict_math 1: bit-identical to the CPU oracle in the
-               same mode, tests/test_gpu_strict.py): its time, its pose distance from the fast window and from the
-               reference pipeline's own run of this window (tests/golden/ref_window.npz).
+  strict       the window in REFERENCE MODE (--strict_math 1 --reference_draw 1 --reference_svd 1: every output bit equals the
+               reference pipeline's own strict-math window, tests/test_gpu_vs_ref_window.py): median of 5 windows after 2 warm-ups,
+               checked against the committed reference run of this window where one exists (cfg2: tests/golden/ref_ensemble.npz);
+               `with_xorwow_and_texture_filter` = the same with --reference_rng 1 --reference_tex 1.
+  exchange     (N > 1, C-ABI front end) p50 / p99 of the all-gather on the device clock (HIP events on the communicator's stream)
+               and on the host clock (enqueue -> records on the host), and frames/s per GPU next to the aggregate.
   cpu_baseline the oracle (C restatement of the reference path, OpenMP) timed on this box's host
                cores on the same workload, a bounded number of windows (rank 0, N=1 only).
   cpu_reference  the reference's own code on one host core (oracle/_ref: voldor/*.cpp + gpu-kernels/*.cu compiled for the
@@ -473,11 +476,11 @@ def main():
                 r2, t2 = synth.pose_errors(out["poses"], ref_poses)
                 vs_ref = {"rot_rad_max": float(r2.max()), "rel_trans_max": float(t2.max()),
                           "note": "fast mode vs the reference pipeline's own run of this window (one window: no statistical statement).  The distribution-level "
-                                  "statement is tests/test_gpu_ensemble.py: over 24 cfg2 windows the distances fast-vs-reference and reference-under-1-ulp-jitter-vs-"
-                                  "reference are one distribution (KS, all metrics); `reference_self_distance` = that ensemble's numbers"}
+                                  "statement is tests/test_gpu_ensemble.py: over 72 cfg2 windows the distances fast-vs-reference and reference-under-1-ulp-jitter-vs-"
+                                  "reference are one distribution (KS, all metrics; window-paired ratio of means inside [0.8, 1.25]); `reference_self_distance` = that ensemble's numbers"}
                 try:
                     eb = json.load(open(os.path.join(ROOT, "tests", "golden", "ref_ensemble_bounds.json")))["cfg2"]["self"]
-                    vs_ref["reference_self_distance"] = {"windows": 24, "rot_rad_max": {k: eb["rot"][k] for k in ("median", "max")},
+                    vs_ref["reference_self_distance"] = {"windows": json.load(open(os.path.join(ROOT, "tests", "golden", "ref_ensemble_bounds.json")))["cfg2"]["windows"], "rot_rad_max": {k: eb["rot"][k] for k in ("median", "max")},
                                                          "rel_trans_max": {k: eb["trans"][k] for k in ("median", "max")}}
                 except Exception:
                     pass

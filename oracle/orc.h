@@ -31,9 +31,13 @@
  * restated in minicv from documented behaviour).
  *
  * Deliberate, documented deviations from the reference:
- *  D1 random numbers: counter-based hash (orc_rng) instead of cuRAND XORWOW.
+ *  D1 random numbers: counter-based hash (orc_rng) instead of cuRAND XORWOW.  orc_set_reference_rng(1) (round 4): XORWOW
+ *     streams as the reference seeds them, restated from the published algorithm (voldor_amd/csrc/vk_ref_cuda.h); pinned against an
+ *     independent implementation and rocRAND's jump table, NOT against a cuRAND run (the seed-scramble constants are unverifiable here).
  *  D2 bilinear sampling: exact fp32 weights, clamp per layer (no 8-bit weights,
- *     no bleeding between stacked layers) -- gmat.h:175-179.
+ *     no bleeding between stacked layers) -- gmat.h:175-179.  orc_set_reference_tex(1) (round 4): the texture unit's linear filter
+ *     (8 fractional bits, one texture over the stacked layers) from the CUDA programming guide's formula; rounding of the fraction and
+ *     the order of the four products are that guide's open ends, NOT pinned against a CUDA run.
  *  D3 random sample index clamped to N_pts-1 (reference can read one past the end,
  *     solve_batch_lambdatwist.cu:16-19).
  *  D3b (optional since round 3: ORC_REFERENCE_DRAW=0; the default is the reference's index draw) inside the
