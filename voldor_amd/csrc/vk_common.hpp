@@ -60,6 +60,11 @@ struct PoseBlock {
     float cumT[MAX_FRAMES][4];
     float dpM[MAX_DISP_FRAMES][9];
     float dpT[MAX_DISP_FRAMES][4];
+#ifdef VK_PK_GEOM
+    // (experiment, off by default: see lean_step) cumM / cumT of a frame once more, laid out for packed fp32: the x and y rows of the map side
+    // by side -- { M0, M3,  M1, M4,  M2, M5,  T0, T1,  M6, M7, M8, T2 } -- so that a scalar load leaves each pair in an aligned SGPR pair
+    __attribute__((aligned(16))) float cumP[MAX_FRAMES][12];
+#endif
 };
 
 // Per-camera state kept on the device (voldor/utils.h:31-45 Camera, minus OpenCV).

@@ -319,15 +319,20 @@ __device__ __forceinline__ static void cum_poses_block(PoseBlock* P, int N, int 
     for (int i = l; i < N * 3; i += 64) sT[i / 3][i % 3] = P->ts[i / 3][i % 3];
     const double fx = P->K4[0], cx = P->K4[1], fy = P->K4[2], cy = P->K4[3];
     __syncthreads();
-    auto emit = [&](const double* R, const double* t, float* M, float* T) {  // K R K^-1 and K t
+    auto emit = [&](const double* R, const double* t, float* M, float* T, float* packed) {  // K R K^-1 and K t; packed: PoseBlock::cumP's order
+        const int pos[12] = { 0, 2, 4, 1, 3, 5, 8, 9, 10, 6, 7, 11 };
         if (l < 9) {
             const int r = l / 3, c = l % 3;
             double kr[3];
             for (int j = 0; j < 3; j++) kr[j] = r == 0 ? fx * R[j] + cx * R[6 + j] : (r == 1 ? fy * R[3 + j] + cy * R[6 + j] : R[6 + j]);
-            M[l] = (float)(c == 0 ? kr[0] / fx : (c == 1 ? kr[1] / fy : kr[2] - kr[0] * cx / fx - kr[1] * cy / fy));
+            const float v = (float)(c == 0 ? kr[0] / fx : (c == 1 ? kr[1] / fy : kr[2] - kr[0] * cx / fx - kr[1] * cy / fy));
+            M[l] = v;
+            if (packed) packed[pos[l]] = v;
         } else if (l < 12) {
             const int r = l - 9;
-            T[r] = (float)(r == 0 ? fx * t[0] + cx * t[2] : (r == 1 ? fy * t[1] + cy * t[2] : t[2]));
+            const float v = (float)(r == 0 ? fx * t[0] + cx * t[2] : (r == 1 ? fy * t[1] + cy * t[2] : t[2]));
+            T[r] = v;
+            if (packed) packed[pos[l]] = v;
         }
     };
     for (int f = 0; f < N; f++) {
@@ -343,13 +348,17 @@ __device__ __forceinline__ static void cum_poses_block(PoseBlock* P, int N, int 
         __syncthreads();
         if (l < 9) Rc[l] = nv; else if (l < 12) tc[l - 9] = nv;
         __syncthreads();
-        emit(Rc, tc, P->cumM[f], P->cumT[f]);
+#ifdef VK_PK_GEOM
+        emit(Rc, tc, P->cumM[f], P->cumT[f], P->cumP[f]);
+#else
+        emit(Rc, tc, P->cumM[f], P->cumT[f], nullptr);
+#endif
     }
     for (int f = 0; f < N_dp; f++) {
         double R[9], t[3];
         for (int k = 0; k < 9; k++) R[k] = P->dpRs[f][k];
         for (int k = 0; k < 3; k++) t[k] = P->dpts[f][k];
-        emit(R, t, P->dpM[f], P->dpT[f]);
+        emit(R, t, P->dpM[f], P->dpT[f], nullptr);
     }
     if (l == 0) {
         int ident = 0;
@@ -417,10 +426,29 @@ __device__ __forceinline__ static void prior_term_lean(const Img& I, const PoseB
 // one frame step of the chain: homogeneous pixel -> position in the next frame; returns z > 0
 __device__ __forceinline__ static bool lean_step(const PoseBlock* P, int f, float x, float y, float d, float& px2, float& py2) {
 #pragma clang fp contract(off)
+#ifdef VK_PK_GEOM
+    // MEASURED AND REJECTED (round 4; build with -DVK_PK_GEOM -DVK_PK_BILINEAR to reproduce, scripts/runs/r04_ab_pk.sh):
+    // the x and y rows of the map -- and, in bilinear2_inside, the two flow components of a texel -- as packed fp32.  v_pk_fma_f32 / v_pk_mul_f32 /
+    // v_pk_add_f32 round each half like the scalar forms: every output bit of a cfg2 / cfg3 / cfg5 window is unchanged (scripts/window_hash.py).
+    // Static VALU count -6.4 % (table pass, 12 frames: 1740 -> 1629), -6.5 % (sample pass), -5.8 % (runs), -7.4 % (E-step), registers unchanged --
+    // and NO time: 1080p table pass 59.0 -> 59.7 us, sample pass 378 -> 392, runs 143 -> 141, E-step 76.9 -> 75.2; windows 3.90 / 6.97 / 28.1 ms
+    // -> 3.91 / 7.03 / 28.2.  These kernels do not wait for VALU issue slots of this kind.
+    const float* C = P->cumP[f];
+    const vf2 m0 = { C[0], C[1] }, m1 = { C[2], C[3] }, m2 = { C[4], C[5] }, t = { C[6], C[7] };
+    const vf2 xx = { x, x }, yy = { y, y }, dd = { d, d };
+    const vf2 axy = __builtin_elementwise_fma(m0, xx, __builtin_elementwise_fma(m1, yy, m2));
+    const float az = fmaf(C[8], x, fmaf(C[9], y, C[10]));
+    const float hz = fmaf(d, az, C[11]), iz = fast_rcp(hz);
+    const vf2 ii = { iz, iz };
+    const vf2 p2 = __builtin_elementwise_fma(dd, axy, t) * ii;
+    px2 = p2.x; py2 = p2.y;
+    return hz > 0.f;
+#else
     const H3 a = hom_dir(P->cumM[f], x, y);
     const float hz = fmaf(d, a.z, P->cumT[f][2]), iz = fast_rcp(hz);
     px2 = fmaf(d, a.x, P->cumT[f][0]) * iz; py2 = fmaf(d, a.y, P->cumT[f][1]) * iz;
     return hz > 0.f;
+#endif
 }
 // frame 0 (observed at the pixel itself) + depth priors of one hypothesis; leaves the position the chain continues from
 __device__ __forceinline__ static void lean_head(const Img& I, const LeanK& K, const PoseBlock* P, float x, float y, float d, float2 o0, const ObsTerms& T0,
