@@ -46,7 +46,10 @@
  *     change of the set no longer re-draws all 8192 hypotheses -- but an independent sample of them:
  *     tests/test_gpu_ensemble.py).
  *  D4 one depth buffer shared by the depth and the pose half (the reference keeps a
- *     stale un-normalised copy in optimize_depth.cu).
+ *     stale un-normalised copy in optimize_depth.cu).  ORC_EMULATE_B1=1 reproduces the reference's
+ *     default exclusive_gpu_context mode (product: --reference_stale_depth 1).
+ *  A camera's rotation vector is Camera::rvec() of its float matrix (cv::Rodrigues round trip, utils.h:44-53; round 4,
+ *     voldor_amd/csrc/vk_ref_cv.h): what the next mean shift starts from and what the window returns -- not a deviation, a correction.
  *  D5 8-point LMedS two-view bootstrap instead of OpenCV's 5-point findEssentialMat (not in the tree).
  *  D6 world-scale normalisation skipped when the window is lost (reference: 0/0).
  *  D8 rodrigues(): exact polar factor instead of the reference's approximate fp32 SVD (svd3_cuda.h);

@@ -9,6 +9,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stddef.h>
+#include "../voldor_amd/csrc/vk_ref_cv.h"
 
 /* ------------------------------------------------------------------ Config (config.h:4-82) */
 typedef struct {
@@ -200,6 +201,15 @@ static int v_optimize_camera_pose(orc_voldor_t* v, int active_idx, int successiv
     float pose_opm[6] = { cam->rvec[0], cam->rvec[1], cam->rvec[2], cam->t[0], cam->t[1], cam->t[2] };
     for (int i = 0; i < used; i++) for (int d = 0; d < 3; d++) pool[i * 6 + d] *= c->meanshift_rvec_scale; /* :191 */
     for (int d = 0; d < 3; d++) pose_opm[d] *= c->meanshift_rvec_scale;
+    { /* test aid: ORC_DUMP_POOL="<iter>,<camera>,<path>" writes the scaled pool and the start of the mean shift of that call ([used][6] floats,
+       * then 6 floats), for stage-level replays against the reference's meanshift_gpu */
+        const char* dp = getenv("ORC_DUMP_POOL");
+        int di, dc; char path[512];
+        if (dp && sscanf(dp, "%d,%d,%511s", &di, &dc, path) == 3 && di == v->iters_cur && dc == active_idx) {
+            FILE* f = fopen(path, "wb");
+            if (f) { fwrite(&used, sizeof used, 1, f); fwrite(pool, sizeof(float), (size_t)used * 6, f); fwrite(pose_opm, sizeof(float), 6, f); fclose(f); }
+        }
+    }
     orc_meanshift(pool, c->meanshift_kernel_var, pose_opm, &cam->pose_density, &cam->last_used_ms_iters,
                   successive_pose, used, 6, c->meanshift_epsilon, c->meanshift_max_iters,
                   c->meanshift_max_init_trials, c->meanshift_good_init_confidence);
@@ -227,8 +237,9 @@ static int v_optimize_camera_pose(orc_voldor_t* v, int active_idx, int successiv
     int ok = 1; /* checkRange :256 */
     for (int d = 0; d < 6; d++) if (!isfinite(pose_opm[d])) ok = 0;
     if (!ok) return 0;
-    memcpy(cam->rvec, pose_opm, 12);
-    orc_rvec_to_rotmat(cam->rvec, cam->R);
+    orc_rvec_to_rotmat(pose_opm, cam->R);            /* Rodrigues(pose_opm -> cams[i].R), :258 */
+    vrcv_rvec_of_R32(cam->R, cam->rvec, orc_get_strict_math()); /* the reference keeps the float MATRIX only: Camera::rvec() (utils.h:49-53) is what the
+                                                      * next mean shift starts from (:184) and what pose6() returns -- a round trip through float R */
     memcpy(cam->t, pose_opm + 3, 12);
     return 1;
 }
@@ -246,6 +257,13 @@ static void v_optimize_cameras(orc_voldor_t* v) {
         if (!allow_trunc || v->cams[i].pose_rigidness_density > c->trunc_rigidness_density)
             ok = v_optimize_camera_pose(v, i, v->cams[i].pose_sample_count == 0 ? 0 : 1,
                                         c->rg_refine && (!c->rg_refine_last_only || v->iters_remain == 0));
+        if (getenv("ORC_TRACE")) { /* the lines of Camera::print_info (utils.h:66-76), for side-by-side traces with a non-silent reference run */
+            const orc_cam* q = &v->cams[i];
+            fprintf(stderr, "orc: iter %d cam %d pool %d rigidness density %.6g pose density %.6g ms iters %d gu iters %d trans mag %.6g rot mag %.6g\n",
+                    v->iters_cur, i, q->pose_sample_count, q->pose_rigidness_density, q->pose_density, q->last_used_ms_iters, q->last_used_gu_iters,
+                    sqrt((double)q->t[0] * q->t[0] + (double)q->t[1] * q->t[1] + (double)q->t[2] * q->t[2]),
+                    sqrt((double)q->rvec[0] * q->rvec[0] + (double)q->rvec[1] * q->rvec[1] + (double)q->rvec[2] * q->rvec[2]) * 180 / 3.14159);
+        }
         if (!ok || (allow_trunc && v->cams[i].pose_density < c->trunc_sample_density)) {
             v->iters_remain = v->iters_remain > c->min_iters_after_trunc ? v->iters_remain : c->min_iters_after_trunc;
             v->n_flows = i;
@@ -562,7 +580,7 @@ int orc_voldor(const float* flows, const float* disparity, const float* disparit
     if (v->n_dp == 0) { /* bootstrap :151-162 */
         float K[9] = { c->fx, 0, c->cx, 0, c->fy, c->cy, 0, 0, 1 };
         orc_cam* cam = &v->cams[0];
-        if (orc_estimate_pose_epipolar(flows, K, w, h, 4, cam->R, cam->t)) orc_rotmat_to_angle_axis(cam->R, cam->rvec);
+        if (orc_estimate_pose_epipolar(flows, K, w, h, 4, cam->R, cam->t)) vrcv_rvec_of_R32(cam->R, cam->rvec, orc_get_strict_math());
         orc_estimate_depth_closed_form(flows, v->depth, K, cam->R, cam->t, w, h, 1e-2f, 1e10f);
     }
     while (v->iters_remain > 0 && v->n_flows > 0) {

@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "../../../voldor_amd/csrc/vk_strict_math.h"
+#include "../../../voldor_amd/csrc/vk_ref_cv.h"
 extern "C" int ref_math_mode;  /* ref_wrap_kernels.cpp; 1 = strict math (ref_stubs/emul/cuda_emul.h) */
 
 #define CV_32F 5
@@ -243,52 +244,10 @@ static inline Scalar mean(const Mat& m) { return Scalar(sum(m)[0] / std::max(1, 
 static inline double norm(const Mat& m, int = NORM_L2) { double s = 0; for (int r = 0; r < m.rows; r++) for (int c = 0; c < m.width1(); c++) s += m.get(r, c) * m.get(r, c); return std::sqrt(s); }
 static inline bool checkRange(const Mat& m) { for (int r = 0; r < m.rows; r++) for (int c = 0; c < m.width1(); c++) if (!std::isfinite(m.get(r, c))) return false; return true; }
 
-// ---- cv::Rodrigues (calib3d cvRodrigues2), double arithmetic
-static inline void minicv_rvec_to_R(const double r_in[3], double R[9]) {
-    double rx = r_in[0], ry = r_in[1], rz = r_in[2];
-    const double theta = std::sqrt(rx * rx + ry * ry + rz * rz);
-    if (theta < DBL_EPSILON) { for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0); return; }
-    const double c = ref_math_mode == 1 ? vsm_cos(theta) : std::cos(theta), s = ref_math_mode == 1 ? vsm_sin(theta) : std::sin(theta), c1 = 1. - c, it = 1. / theta;  /* strict mode: oracle/ref_stubs/emul/cuda_emul.h */
-    rx *= it; ry *= it; rz *= it;
-    const double rrt[9] = { rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz };
-    const double rxm[9] = { 0, -rz, ry, rz, 0, -rx, -ry, rx, 0 };
-    for (int i = 0; i < 9; i++) R[i] = c * (i % 4 == 0 ? 1. : 0.) + c1 * rrt[i] + s * rxm[i];
-}
-static inline void minicv_orthonormalise(double X[9]) {  // R <- U V^T of its SVD, as the polar factor (Newton: X <- (X + X^-T) / 2)
-    for (int it = 0; it < 40; it++) {
-        const double d = X[0] * (X[4] * X[8] - X[5] * X[7]) - X[1] * (X[3] * X[8] - X[5] * X[6]) + X[2] * (X[3] * X[7] - X[4] * X[6]);
-        if (d == 0) return;
-        const double id = 1. / d;
-        const double invT[9] = { (X[4] * X[8] - X[5] * X[7]) * id, (X[5] * X[6] - X[3] * X[8]) * id, (X[3] * X[7] - X[4] * X[6]) * id,
-                                 (X[2] * X[7] - X[1] * X[8]) * id, (X[0] * X[8] - X[2] * X[6]) * id, (X[1] * X[6] - X[0] * X[7]) * id,
-                                 (X[1] * X[5] - X[2] * X[4]) * id, (X[2] * X[3] - X[0] * X[5]) * id, (X[0] * X[4] - X[1] * X[3]) * id };
-        double delta = 0;
-        for (int i = 0; i < 9; i++) { const double n = 0.5 * (X[i] + invT[i]); delta = std::max(delta, std::fabs(n - X[i])); X[i] = n; }
-        if (delta < 1e-16) break;
-    }
-}
-static inline void minicv_R_to_rvec(const double R_in[9], double r[3]) {
-    double R[9]; memcpy(R, R_in, sizeof R);
-    minicv_orthonormalise(R);
-    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
-    const double s = std::sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
-    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
-    c = c > 1. ? 1. : c < -1. ? -1. : c;
-    const double theta = std::acos(c);
-    if (s < 1e-5) {
-        if (c > 0) { r[0] = r[1] = r[2] = 0; return; }
-        double t;
-        t = (R[0] + 1) * 0.5; rx = std::sqrt(std::max(t, 0.));
-        t = (R[4] + 1) * 0.5; ry = std::sqrt(std::max(t, 0.)) * (R[1] < 0 ? -1. : 1.);
-        t = (R[8] + 1) * 0.5; rz = std::sqrt(std::max(t, 0.)) * (R[2] < 0 ? -1. : 1.);
-        if (std::fabs(rx) < std::fabs(ry) && std::fabs(rx) < std::fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
-        const double k = theta / std::sqrt(rx * rx + ry * ry + rz * rz);
-        r[0] = rx * k; r[1] = ry * k; r[2] = rz * k;
-        return;
-    }
-    const double vth = 1. / (2 * s) * theta;
-    r[0] = rx * vth; r[1] = ry * vth; r[2] = rz * vth;
-}
+// ---- cv::Rodrigues (calib3d cvRodrigues2), double arithmetic: restated in voldor_amd/csrc/vk_ref_cv.h (one copy for this stand-in, the
+// oracle and the strict kernels of the product; strict mode = ref_math_mode 1: sin / cos / acos from vk_strict_math.h)
+static inline void minicv_rvec_to_R(const double r_in[3], double R[9]) { vrcv_rvec_to_R(r_in, R, ref_math_mode == 1); }
+static inline void minicv_R_to_rvec(const double R_in[9], double r[3]) { vrcv_R_to_rvec(R_in, r, ref_math_mode == 1); }
 static inline void Rodrigues(const Vec3f& rvec, Mat& R) {  // vector -> 3x3 CV_32F
     const double r[3] = { rvec.val[0], rvec.val[1], rvec.val[2] }; double Rd[9];
     minicv_rvec_to_R(r, Rd);

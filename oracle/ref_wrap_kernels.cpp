@@ -177,6 +177,16 @@ void ref_reset_window_state(unsigned rand_epoch) {
 int meanshift_gpu(float* h_space, float kernel_var, float* h_io_mean, float* h_o_confidence, int* used_iters, bool use_external_init_mean, int N,
                   int dims, float epsilon, int max_iters, int max_init_trials, float good_init_confidence) {
     emul_rand_trial = 0; emul_rand_mod = (uint32_t)N;
+    {  // test aid: REF_DUMP_POOL="<call index>,<path>" writes the pool and the start of that mean-shift call (same layout as ORC_DUMP_POOL, oracle/orc_voldor.c)
+        static int call = 0;
+        const char* dp = getenv("REF_DUMP_POOL");
+        int want; char path[512];
+        if (dp && sscanf(dp, "%d,%511s", &want, path) == 2 && want == call && dims == 6) {
+            FILE* f = fopen(path, "wb");
+            if (f) { fwrite(&N, sizeof N, 1, f); fwrite(h_space, sizeof(float), (size_t)N * 6, f); fwrite(h_io_mean, sizeof(float), 6, f); fclose(f); }
+        }
+        call++;
+    }
     return ref_ms::meanshift_gpu(h_space, kernel_var, h_io_mean, h_o_confidence, used_iters, use_external_init_mean, N, dims, epsilon, max_iters,
                                  max_init_trials, good_init_confidence);
 }

@@ -14,6 +14,7 @@
 #include "../../voldor_amd/csrc/vk_device.hpp"
 #include "../../voldor_amd/csrc/vk_strict_math.h"
 #include "../../voldor_amd/csrc/vk_strict_model.hpp"
+#include "../../voldor_amd/csrc/vk_ref_cv.h"
 
 #define VKT_API extern "C" __attribute__((visibility("default")))
 
@@ -167,6 +168,24 @@ VKT_API int vkt_rodrigues_device(const float* R9, float* rv, int n, int strict) 
     return rc;
 }
 // strict residual model on the host (vs the oracle in strict mode, CPU tier)
+// cv::Rodrigues(matrix -> vector) as reference mode applies it to a camera's float matrix (vk_ref_cv.h): host build and gfx950 build
+VKT_API void vkt_cv_rvec_of_R_host(const float* R9, float* rv, int n, int strict) {
+    for (int i = 0; i < n; i++) vrcv_rvec_of_R32(R9 + 9 * i, rv + 3 * i, strict);
+}
+__global__ static void k_cv_rvec_of_R(const float* R9, float* rv, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) vrcv_rvec_of_R32(R9 + 9 * i, rv + 3 * i, 1);
+}
+VKT_API int vkt_cv_rvec_of_R_device(const float* R9, float* rv, int n) {
+    float *dR = nullptr, *dv = nullptr;
+    if (hipMalloc(&dR, sizeof(float) * 9 * n) || hipMalloc(&dv, sizeof(float) * 3 * n)) return 1;
+    hipMemcpy(dR, R9, sizeof(float) * 9 * n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_cv_rvec_of_R, dim3((n + 63) / 64), dim3(64), 0, 0, dR, dv, n);
+    int rc = (int)hipDeviceSynchronize();
+    hipMemcpy(rv, dv, sizeof(float) * 3 * n, hipMemcpyDeviceToHost);
+    hipFree(dR); hipFree(dv);
+    return rc;
+}
 VKT_API float vkt_strict_rigidness(float dx1, float dy1, float dx2, float dy2, float lambda, float abs_rf) {
     return vk::strict::rigidness(dx1, dy1, dx2, dy2, lambda, abs_rf);
 }

@@ -6,7 +6,7 @@ Two records per window:
   ref/...     the REFERENCE's own py_voldor_wrapper executed on the CPU (oracle/_ref, as tests/golden/gen_golden_window.py): poses,
               covariances, depth / confidence sub-sampled 4x4.  The HIP path is compared with it statistically (the reference's
               approximate-SVD rodrigues and its draw differ from the product's).
-  strict/...  the oracle in strict-math mode (orc_set_strict_math(1), default draw): sha256 of the full depth and confidence maps,
+  strict/...  the oracle in strict-math mode (orc_set_strict_math(1), rejection draw D3b = ORC_REFERENCE_DRAW=0): sha256 of the full depth and confidence maps,
               poses, covariances.  The HIP path in --strict_math 1 must reproduce these BIT FOR BIT at full size
               (tests/test_gpu_configs.py).
 
@@ -90,16 +90,22 @@ def main():
         kw = dict(basefocal=c["basefocal"], disparity=c["disparity"])
         t0 = time.time()
         orc.lib().orc_set_strict_math(1)
+        os.environ["ORC_REFERENCE_DRAW"] = "0"  # these records keep the rejection draw D3b covered at full size (product: --reference_draw 0); the reference's draw is held by ref_big_strict_*.npz
         try:
             s = orc.voldor(c["flows"], fx, fy, cx, cy, config=c["config"], **kw)
         finally:
             orc.lib().orc_set_strict_math(0)
+            os.environ.pop("ORC_REFERENCE_DRAW", None)
         print(f"{name}: strict oracle {time.time() - t0:.0f} s, n_registered {s['n_registered']}", flush=True)
         out[f"{name}/strict/n_registered"] = np.int32(s["n_registered"])
         out[f"{name}/strict/poses"], out[f"{name}/strict/poses_covar"] = s["poses"], s["poses_covar"]
         for k in ("depth", "depth_conf"):
             out[f"{name}/strict/{k}_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(s[k]).tobytes()).digest(), np.uint8)
             out[f"{name}/strict/{k}_sub8"] = s[k][::8, ::8].copy()
+        if "--oracle-only" in sys.argv:  # only the strict/... records (e.g. after a change of the oracle that leaves the reference's run as it is)
+            np.savez_compressed(path, **out)
+            print(f"wrote {path}: {len(out)} arrays (strict oracle records of {name} renewed)", flush=True)
+            continue
         t0 = time.time()
         r = orc.ref_voldor(c["flows"], fx, fy, cx, cy, config=c["config"], **kw)
         print(f"{name}: reference pipeline {time.time() - t0:.0f} s, n_registered {r['n_registered']}", flush=True)

@@ -30,9 +30,48 @@ def main():
     ref = orc.ref()
     allc = dict(cases.window_cases())
     out = {}
+    if "--default-only" in sys.argv:
+        default_mode_windows(ref, allc)
+        return
     if "--cuda-only" not in sys.argv:
         strict_windows(ref, allc)
+        default_mode_windows(ref, allc)
     cuda_windows_and_noise(ref, allc)
+
+
+DEFAULT_MODE_CASES = ("mono_default_b1", "truncated_b1")
+
+
+def default_mode_windows(ref, allc):
+    """ref_window_default.npz -- round 4: monocular windows under the reference's DEFAULT `exclusive_gpu_context 1`, in strict math: the runs
+    that show SURVEY Appendix B-1 (optimize_depth.cu searches from a device copy of the depth map that never saw normalize_world_scale()).
+    The product reproduces them with `--reference_stale_depth 1` on top of the reference mode, the oracle with ORC_EMULATE_B1=1.  Two small
+    windows (one of them truncated) and BASELINE cfg2 at full size (sha256 + every 8th pixel)."""
+    import hashlib
+    out = {}
+    ref.ref_set_math_mode(1)
+    orc.lib().orc_set_strict_math(1)
+    try:
+        for name in DEFAULT_MODE_CASES:
+            r = run_reference(allc[name])
+            out[f"{name}/n_registered"] = np.int32(r["n_registered"])
+            for k in ("poses", "poses_covar", "depth", "depth_conf"):
+                out[f"{name}/{k}"] = r[k]
+            print(f"strict, default exclusive mode {name:20s} n_registered {r['n_registered']}")
+        name, c = cases.cfg2_case()
+        c = dict(c, ref_config=c["config"])  # the reference's default: exclusive_gpu_context 1
+        r = run_reference(c)
+        name = name + "_default"
+        out[f"{name}/n_registered"], out[f"{name}/poses"], out[f"{name}/poses_covar"] = np.int32(r["n_registered"]), r["poses"], r["poses_covar"]
+        for k in ("depth", "depth_conf"):
+            out[f"{name}/{k}_sub8"] = r[k][::8, ::8].copy()
+            out[f"{name}/{k}_sha256"] = np.frombuffer(hashlib.sha256(r[k].tobytes()).digest(), np.uint8)
+        print(f"strict, default exclusive mode {name:20s} n_registered {r['n_registered']}")
+    finally:
+        ref.ref_set_math_mode(0); orc.lib().orc_set_strict_math(0)
+    path = os.path.join(HERE, "ref_window_default.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
 
 
 def strict_windows(ref, allc):

@@ -66,6 +66,18 @@ def rodrigues(R9, strict, device):
     return rv
 
 
+def cv_rvec_of_R(R9, strict, device):
+    """cv::Rodrigues(matrix -> vector) of float matrices (voldor_amd/csrc/vk_ref_cv.h): host build, or the gfx950 build (strict only)."""
+    R9 = np.ascontiguousarray(R9, np.float32).reshape(-1, 9)
+    rv = np.zeros((R9.shape[0], 3), np.float32)
+    L = lib()
+    if device:
+        assert strict and L.vkt_cv_rvec_of_R_device(_p(R9), _p(rv), R9.shape[0]) == 0
+    else:
+        L.vkt_cv_rvec_of_R_host(_p(R9), _p(rv), R9.shape[0], int(strict))
+    return rv
+
+
 # ---- verification entry points of the PRODUCT library that are not part of its C-ABI (voldor_amd/csrc/vk_debug.h) ----
 def debug_switch(name: str, value: int) -> int:
     """vk_debug_switch: returns the previous value; raises for an unknown name / value."""

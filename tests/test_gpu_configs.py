@@ -183,6 +183,10 @@ import os
 BIG_GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_big.npz")
 
 
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
 def _sha(a):
     return np.frombuffer(hashlib.sha256(np.ascontiguousarray(a, np.float32).tobytes()).digest(), np.uint8)
 
@@ -231,7 +235,7 @@ def test_big_window_in_reference_mode_equals_the_reference_bit_for_bit(name):
     assert np.array_equal(_sha(o["depth"]), g[p + "depth_sha256"])
     assert np.array_equal(_sha(o["depth_conf"]), g[p + "depth_conf_sha256"])
     assert np.array_equal(o["poses_covar"].view(np.uint32), g[p + "poses_covar"].view(np.uint32))
-    assert np.abs(o["poses"].astype(np.float64) - g[p + "poses"]).max() < 1e-9
+    assert not (_bits(o["poses"]) != _bits(g[p + "poses"])).any()  # Camera::pose6(): the strict kernels take its round trip through the float matrix (vk_ref_cv.h)
 
 
 @pytest.mark.parametrize("name", ["cfg3", "cfg5"])

@@ -22,6 +22,7 @@
 #include "vk_internal.hpp"
 #include "vk_p3p.hpp"
 #include "vk_fivept.hpp"
+#include "vk_ref_cv.h"
 #include "../../include/voldor_hip.h"
 #include <vector>
 #include <algorithm>
@@ -483,7 +484,8 @@ __global__ __launch_bounds__(256) static void k_boot_select(const float* __restr
         }
         float R[9], t[3], rv[3];
         boot_finish(sRc[best >> 1], stc, (best & 1) ? -1.0 : 1.0, R, t);
-        rotmat_to_angle_axis(R, rv, strict != 0);
+        if (strict) vrcv_rvec_of_R32(R, rv, 1);  // reference mode: Camera::rvec() of the float matrix (vk_ref_cv.h), what the first mean shift's displacement test sees
+        else rotmat_to_angle_axis(R, rv, false);
         for (int k = 0; k < 9; k++) P->Rs[0][k] = R[k];
         for (int k = 0; k < 3; k++) { P->ts[0][k] = t[k]; cam0->rvec[k] = rv[k]; cam0->t[k] = t[k]; }
         const float K9[9] = { (float)g.fx, 0, (float)g.cx, 0, (float)g.fy, (float)g.cy, 0, 0, 1 };

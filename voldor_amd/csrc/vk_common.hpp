@@ -151,6 +151,12 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
     // linear filter over the stacked layers for every at_tex of the reference (D1 / D2 switched off)
     bool ref_rng = false, ref_tex = false;
     float* world_scale_out = nullptr;  // device float: also run normalize_world_scale's pose half (voldor.cpp:309-317) in the last launch
+    // --reference_stale_depth 1 (strict mode; SURVEY Appendix B-1, deviation D4 switched off): the depth map optimize_depth.cu keeps on the device.
+    // With exclusive_gpu_context the reference uploads its depth map for the first call only (voldor.cpp:250-291), so from the second EM
+    // iteration on the search starts from a copy that never saw normalize_world_scale().  Non-null: the kernels of this call work on that copy
+    // (refreshed from the window's map first when stale_refresh), the window's map then receives the result (and, alone, the world scale).
+    float* stale_depth = nullptr;
+    bool stale_refresh = false;
 };
 
 struct ProfEntry { double ms = 0; long count = 0; };
@@ -175,6 +181,7 @@ struct Context {
     DevBuf cams;                  // CamState[MAX_FRAMES]
     DevBuf tmp;                   // misc scratch (gblur, depth_conf ...)
     DevBuf fb_scratch;            // strict fb_smooth: forward messages [n_maps][h][w]
+    DevBuf stale_depth;           // --reference_stale_depth 1: optimize_depth.cu's own device copy of the depth map (OdParams::stale_depth)
     DevBuf sp_coop;               // strict mode kernel, cooperative form: block sums, pool size and the grid barrier's counter (vk_strict.hip CoopGlobal)
     bool strict = false;          // strict-math mode of the B-inner entry points that use this context (vk_set_strict_math)
     // --reference_rng 1: the jump matrices T^(2^67 2^k) (vk_ref_cuda.h), the per-pixel XORWOW states of the depth samples

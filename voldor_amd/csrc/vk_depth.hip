@@ -1631,6 +1631,11 @@ template <int NMAX, bool STRICT>
 static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_only) {
     const int w = p.w, h = p.h;
     Img I = make_img(S, p);
+    const bool stale = STRICT && p.stale_depth != nullptr;  // OdParams::stale_depth: the reference's own device copy of the map (Appendix B-1)
+    if (stale) {
+        if (p.stale_refresh) VK_CHECK(hipMemcpyAsync(p.stale_depth, S.depth.p, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToDevice, c->stream));
+        I.depth = p.stale_depth;
+    }
     const dim3 gpx((w + 63) / 64, (h + 3) / 4), bpx(256);
     const bool plain = STRICT && debug_switches().strict_plain;  // strict mode on the plain launch structures of rounds 1-3 (verification: same bits either way)
     // fast mode: the projective maps of the chain (and the world-scale factor) are prepared by an extra workgroup of the first fb_smooth
@@ -1744,7 +1749,8 @@ static int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, boo
         hipLaunchKernelGGL(k_reduce_density, dim3(p.N + (p.world_scale_out ? 1 : 0)), dim3(256), 0, c->stream, c->rig_partial.as<float>(), nblk,
                            w * h, c->cams.as<CamState>(), S.pb(), p.N, p.world_scale_out, STRICT ? 0 : 1);
     // normalize_world_scale's depth half: strict mode as its own pass after the E-step; the fast E-step kernel has stored the scaled map
-    if (STRICT && p.N > 0 && p.world_scale_out) hipLaunchKernelGGL(k_scale, dim3((unsigned)(((size_t)w * h + 255) / 256)), dim3(256), 0, c->stream, I.depth, p.world_scale_out, (size_t)w * h);
+    if (stale) VK_CHECK(hipMemcpyAsync(S.depth.p, p.stale_depth, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToDevice, c->stream));  // d_depth.copy_to_host(h_o_depth): the host's map, which alone is normalised
+    if (STRICT && p.N > 0 && p.world_scale_out) hipLaunchKernelGGL(k_scale, dim3((unsigned)(((size_t)w * h + 255) / 256)), dim3(256), 0, c->stream, S.depth.as<float>(), p.world_scale_out, (size_t)w * h);
     VK_CHECK_LAST();
     return 0;
 }

@@ -16,6 +16,7 @@
 #include "vk_device.hpp"
 #include "vk_p3p.hpp"
 #include "vk_strict_math.h"
+#include "vk_ref_cv.h"
 #include "vk_lu.hpp"
 #include "vk_internal.hpp"
 
@@ -504,10 +505,13 @@ __global__ __launch_bounds__(ST_THREADS) static void k_pose_strict(const float* 
         if (write_covar) for (int k = 0; k < 36; k++) cam->covar[k] = covar_out[k];
         cam->success = ok ? 1 : 0;
         if (ok) {
-            for (int d = 0; d < 3; d++) { cam->rvec[d] = pose_opm[d]; cam->t[d] = pose_opm[3 + d]; P->ts[cam_idx][d] = pose_opm[3 + d]; }
+            for (int d = 0; d < 3; d++) { cam->t[d] = pose_opm[3 + d]; P->ts[cam_idx][d] = pose_opm[3 + d]; }
             float R[9];
             angle_axis_to_rotmat(pose_opm, R, true);
             for (int k = 0; k < 9; k++) P->Rs[cam_idx][k] = R[k];
+            // the reference keeps the float matrix only; the vector the next mean shift starts from and the window returns is
+            // Camera::rvec() = cv::Rodrigues(R) (utils.h:44-53, geometry.cpp:184): vk_ref_cv.h
+            vrcv_rvec_of_R32(R, cam->rvec, 1);
         }
         maybe_decide(mp, P, cam, cam_idx);
     }
@@ -906,10 +910,13 @@ __global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_p
         if (write_covar) for (int k = 0; k < 36; k++) cam->covar[k] = covar_out[k];
         cam->success = ok ? 1 : 0;
         if (ok) {
-            for (int d = 0; d < 3; d++) { cam->rvec[d] = pose_opm[d]; cam->t[d] = pose_opm[3 + d]; P->ts[cam_idx][d] = pose_opm[3 + d]; }
+            for (int d = 0; d < 3; d++) { cam->t[d] = pose_opm[3 + d]; P->ts[cam_idx][d] = pose_opm[3 + d]; }
             float R[9];
             angle_axis_to_rotmat(pose_opm, R, true);
             for (int k = 0; k < 9; k++) P->Rs[cam_idx][k] = R[k];
+            // the reference keeps the float matrix only; the vector the next mean shift starts from and the window returns is
+            // Camera::rvec() = cv::Rodrigues(R) (utils.h:44-53, geometry.cpp:184): vk_ref_cv.h
+            vrcv_rvec_of_R32(R, cam->rvec, 1);
         }
         maybe_decide(mp, P, cam, cam_idx);
     }

@@ -56,7 +56,11 @@ struct Config {
     //                  seeds and advances them (curand_init(233, pixel | idx, 0); vk_ref_cuda.h) instead of the counter generator (D1)
     //  reference_tex   1 (with strict_math): every at_tex of the reference through CUDA's linear filter -- 8-bit fractions, one texture over
     //                  the stacked layers -- instead of the exact per-layer bilinear (D2).  -1 (default) = the process-wide settings
-    int strict_math = -1, reference_draw = 1, reference_svd = -1, reference_rng = -1, reference_tex = -1;
+    //  reference_stale_depth  1 (with strict_math, monocular windows, exclusive_gpu_context 1 = the reference's default): reproduce SURVEY
+    //                  Appendix B-1 -- optimize_depth.cu keeps its own device copy of the depth map, which the reference refreshes for the first
+    //                  call only and which never sees normalize_world_scale() (voldor.cpp:250-291, :309-317) -- instead of the one
+    //                  normalised map (D4).  0 (default) = what the reference does with --exclusive_gpu_context 0
+    int strict_math = -1, reference_draw = 1, reference_svd = -1, reference_rng = -1, reference_tex = -1, reference_stale_depth = 0;
     //  bootstrap_points  8 (default): normalised 8-point LMedS for the monocular two-view bootstrap; 5: the five-point minimal solver of
     //                  cv::findEssentialMat (voldor/geometry.cpp:316-326; vk_fivept.hpp), 192 samples x up to ten models (deviation D5 narrows
     //                  to "OpenCV's numerics are not reproduced")
@@ -79,7 +83,7 @@ struct Config {
             KI(depth_global_prop_step), KI(depth_local_prop_width), KF(depth_range_factor), KI(meanshift_max_iters),
             KI(meanshift_max_init_trials), KF(meanshift_good_init_confidence), KF(meanshift_epsilon), KI(kitti_estimate_ground),
             KI(kitti_ground_holo_width), KF(kitti_ground_roi), KF(kitti_ground_meanshift_kernel_var),
-            KI(strict_math), KI(reference_draw), KI(reference_svd), KI(reference_rng), KI(reference_tex), KI(bootstrap_points),
+            KI(strict_math), KI(reference_draw), KI(reference_svd), KI(reference_rng), KI(reference_tex), KI(reference_stale_depth), KI(bootstrap_points),
         };
 #undef KF
 #undef KI
@@ -197,6 +201,11 @@ struct Voldor {
         p.fb_smooth = cfg.fb_smooth != 0; p.s0_ems_prob = cfg.fb_emm; p.no_change_prob = cfg.fb_no_change_prob;
         p.range_factor = cfg.depth_range_factor; p.update_rigidness_only = (flag == OD_UPDATE_RIGIDNESS_ONLY);
         p.strict = strict; p.ref_rng = ref_rng; p.ref_tex = ref_tex;
+        if (strict && cfg.reference_stale_depth && cfg.exclusive_gpu_context && cfg.norm_world_scale && n_dp == 0) {
+            if (int e = c->stale_depth.reserve(sizeof(float) * (size_t)w * h)) return e;
+            p.stale_depth = c->stale_depth.as<float>();
+            p.stale_refresh = iters_cur < 2;  // voldor.cpp:250: "iters_cur == 0 || iters_cur == 1": the calls that upload the map
+        }
         if (with_world_scale) {  // voldor.cpp:309-317: the pose half rides on the density launch, the depth half follows
             if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
             p.world_scale_out = c->ms_io.as<float>() + 48;
