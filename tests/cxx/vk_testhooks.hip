@@ -179,11 +179,10 @@ __global__ static void k_cv_rvec_of_R(const float* R9, float* rv, int n) {
 VKT_API int vkt_cv_rvec_of_R_device(const float* R9, float* rv, int n) {
     float *dR = nullptr, *dv = nullptr;
     if (hipMalloc(&dR, sizeof(float) * 9 * n) || hipMalloc(&dv, sizeof(float) * 3 * n)) return 1;
-    hipMemcpy(dR, R9, sizeof(float) * 9 * n, hipMemcpyHostToDevice);
+    (void)hipMemcpy(dR, R9, sizeof(float) * 9 * n, hipMemcpyHostToDevice);
     hipLaunchKernelGGL(k_cv_rvec_of_R, dim3((n + 63) / 64), dim3(64), 0, 0, dR, dv, n);
-    int rc = (int)hipDeviceSynchronize();
-    hipMemcpy(rv, dv, sizeof(float) * 3 * n, hipMemcpyDeviceToHost);
-    hipFree(dR); hipFree(dv);
+    const int rc = (int)hipMemcpy(rv, dv, sizeof(float) * 3 * n, hipMemcpyDeviceToHost);
+    (void)hipFree(dR); (void)hipFree(dv);
     return rc;
 }
 VKT_API float vkt_strict_rigidness(float dx1, float dy1, float dx2, float dy2, float lambda, float abs_rf) {

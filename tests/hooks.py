@@ -97,6 +97,7 @@ def set_split_trials(on): debug_switch("split_trials", int(bool(on)))
 def set_strict_plain(on): debug_switch("strict_plain", int(bool(on)))
 def set_local_fused(waves): debug_switch("local_fused", int(waves))
 def set_strict_pose_coop(on): debug_switch("strict_pose_coop", int(bool(on)))
+def set_fuse_solve_mode(on): debug_switch("fuse_solve_mode", int(bool(on)))
 
 
 def pose_mode_pool(rvecs, tvecs, init_pose6, use_external_init_mean=True, refit=False, kernel_var=0.2, rvec_scale=1.0, ms_epsilon=1e-5,

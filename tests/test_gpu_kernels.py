@@ -620,3 +620,51 @@ def test_sample_pass_with_survivor_queue_matches_strict(small_scene, with_priors
     assert np.mean(fd != sd) <= 5e-4, np.mean(fd != sd)
     same = fd == sd
     _assert_map_close(sr[:, same], fr[:, same])
+
+
+@pytest.mark.parametrize("case", ["mono_320x240", "stereo_312x96", "mono_640x480_refit_every_iteration", "ap3p", "double_solver", "low_density", "batch_of_4"])
+def test_fused_solve_and_mode_launch_equals_the_two_launches(case):
+    """k_solve_mode (round 4): the P3P batch and the mode kernel of a camera as ONE launch -- 512-thread workgroups, the workgroup that stores the
+    last hypotheses of the pool (ticket counter, release / acquire at agent scope) goes on with the mean shift (and the refit) -- against the two
+    launches (vk_debug_switch "fuse_solve_mode" = 0, the default: the fused launch was measured and gains nothing): every output of the window, bit for bit.  Windows with and without depth priors, the refit
+    in every iteration (the 141 KB variant), AP3P (not fused: same answer by construction), the fp64 solver, a window whose correspondence
+    density collapses, and four windows in flight (four ticket counters)."""
+    import ref_window_cases as rc
+    from voldor_amd import kernels, pyvoldor, synth
+    extra, batch = "", 1
+    if case == "mono_320x240":
+        c = dict(rc.window_cases())["mono_320x240"]
+    elif case == "stereo_312x96":
+        c = dict(rc.window_cases())["stereo_312x96"]
+    elif case == "low_density":
+        c = dict(rc.window_cases())["low_density"]
+    else:
+        c = rc.cfg2_case()[1] if case.startswith("mono_640") else dict(rc.window_cases())["mono_320x240"]
+        extra = {"mono_640x480_refit_every_iteration": " --rg_refine_last_only 0", "ap3p": " --lambdatwist 0", "double_solver": " --cpu_p3p 1", "batch_of_4": ""}[case]
+        batch = 4 if case == "batch_of_4" else 1
+    fx, fy, cx, cy = c["K"]
+    kw = dict(basefocal=c["basefocal"], disparity=c["disparity"], depth_priors=c["depth_priors"], depth_prior_poses=c["depth_prior_poses"],
+              depth_prior_pconfs=c["depth_prior_pconfs"], config=c["config"] + extra)
+
+    def run():
+        kernels.set_rand_epoch(0)
+        if batch == 1:
+            return [pyvoldor.voldor(c["flows"], fx, fy, cx, cy, **kw)]
+        import torch
+        fl = [torch.from_numpy(np.ascontiguousarray(c["flows"] * (1.0 + 0.01 * b))).cuda() for b in range(batch)]
+        h, w = c["flows"].shape[1:3]
+        d = [torch.empty(h, w, device="cuda") for _ in range(batch)]; cf = [torch.empty(h, w, device="cuda") for _ in range(batch)]
+        return pyvoldor.voldor_device_batch(fl, fx, fy, cx, cy, config=kw["config"], depth_out=d, depth_conf_out=cf)
+    out = {}
+    try:
+        for on in (1, 0):
+            hooks.set_fuse_solve_mode(on)
+            out[on] = run()
+    finally:
+        hooks.set_fuse_solve_mode(0)  # the default: measured, no time gained (DESIGN.md section 6)
+    for a, b in zip(out[1], out[0]):
+        assert a["n_registered"] == b["n_registered"] and a["n_registered"] > 0
+        for k in ("poses", "poses_covar", "depth", "depth_conf"):
+            x = a[k].cpu().numpy() if hasattr(a[k], "cpu") else np.asarray(a[k]); y = b[k].cpu().numpy() if hasattr(b[k], "cpu") else np.asarray(b[k])
+            np.testing.assert_array_equal(np.ascontiguousarray(x, np.float32).view(np.uint32), np.ascontiguousarray(y, np.float32).view(np.uint32), err_msg=f"{case}/{k}")
+

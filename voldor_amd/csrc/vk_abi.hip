@@ -157,7 +157,7 @@ DebugSwitches& debug_switches() {
                     const std::string k = s.substr(pos, eq - pos), v = s.substr(eq + 1, stop - eq - 1);
                     struct { const char* n; int* p; } tab[] = { { "local_serial", &g_debug.local_serial }, { "cost_rand_plain", &g_debug.cost_rand_plain }, { "fb_segment", &g_debug.fb_segment },
                         { "global_split", &g_debug.global_split }, { "refit_partition", &g_debug.refit_partition }, { "split_trials", &g_debug.split_trials },
-                        { "strict_plain", &g_debug.strict_plain }, { "newton_cap", &g_debug.newton_cap }, { "strict_own_table", &g_debug.strict_own_table }, { "strict_lpp8", &g_debug.strict_lpp8 }, { "local_fused", &g_debug.local_fused }, { "strict_pose_coop", &g_debug.strict_pose_coop } };
+                        { "strict_plain", &g_debug.strict_plain }, { "newton_cap", &g_debug.newton_cap }, { "strict_own_table", &g_debug.strict_own_table }, { "strict_lpp8", &g_debug.strict_lpp8 }, { "local_fused", &g_debug.local_fused }, { "strict_pose_coop", &g_debug.strict_pose_coop }, { "fuse_solve_mode", &g_debug.fuse_solve_mode } };
                     bool known = false;
                     for (auto& t : tab) if (k == t.n) { *t.p = atoi(v.c_str()); known = true; }
                     if (!known) fprintf(stderr, "voldor_hip: VOLDOR_HIP_DEBUG: unknown switch '%s'\n", k.c_str());
@@ -384,7 +384,7 @@ extern "C" __attribute__((visibility("default"))) int vk_debug_switch(const char
     DebugSwitches& d = debug_switches();
     struct { const char* n; int* p; } tab[] = { { "local_serial", &d.local_serial }, { "cost_rand_plain", &d.cost_rand_plain }, { "fb_segment", &d.fb_segment },
         { "global_split", &d.global_split }, { "refit_partition", &d.refit_partition }, { "split_trials", &d.split_trials }, { "strict_plain", &d.strict_plain }, { "newton_cap", &d.newton_cap },
-        { "strict_own_table", &d.strict_own_table }, { "strict_lpp8", &d.strict_lpp8 }, { "local_fused", &d.local_fused }, { "strict_pose_coop", &d.strict_pose_coop } };
+        { "strict_own_table", &d.strict_own_table }, { "strict_lpp8", &d.strict_lpp8 }, { "local_fused", &d.local_fused }, { "strict_pose_coop", &d.strict_pose_coop }, { "fuse_solve_mode", &d.fuse_solve_mode } };
     for (auto& t : tab)
         if (strcmp(t.n, name) == 0) {
             if (t.p == &d.fb_segment) { if (value != 0 && value != 20 && value != 40) return -1; }

@@ -182,6 +182,8 @@ struct Context {
     DevBuf tmp;                   // misc scratch (gblur, depth_conf ...)
     DevBuf fb_scratch;            // strict fb_smooth: forward messages [n_maps][h][w]
     DevBuf stale_depth;           // --reference_stale_depth 1: optimize_depth.cu's own device copy of the depth map (OdParams::stale_depth)
+    DevBuf ticket;                // k_solve_mode: the counter its workgroups draw tickets from (only grows; ticket_base = its value before the launch)
+    unsigned ticket_base = 0;
     DevBuf sp_coop;               // strict mode kernel, cooperative form: block sums, pool size and the grid barrier's counter (vk_strict.hip CoopGlobal)
     bool strict = false;          // strict-math mode of the B-inner entry points that use this context (vk_set_strict_math)
     // --reference_rng 1: the jump matrices T^(2^67 2^k) (vk_ref_cuda.h), the per-pixel XORWOW states of the depth samples

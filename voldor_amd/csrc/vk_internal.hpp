@@ -32,6 +32,7 @@ struct DebugSwitches {
     int strict_own_table = 0;  // (tuning) strict local pass: 1 = every chain tabulates its own steps at the head of the runs kernel, 0 = the tiled table kernel
     int strict_lpp8 = 0;       // (tuning) strict local pass: 8 lanes per pixel instead of 4 for up to 8 frames
     int strict_pose_coop = 1;  // strict mode kernel on one single-wave workgroup per 512-row block of the pool (16 compute units) instead of one 512-thread workgroup; same bits
+    int fuse_solve_mode = 0;   // (experiment, measured and NOT adopted: DESIGN.md section 6) 1: P3P batch and mode kernel of a camera as ONE launch (k_solve_mode: the workgroup that stores the last hypotheses goes on as the mode kernel); same bits, no time gained
     int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
 };
 DebugSwitches& debug_switches();  // vk_abi.hip
@@ -94,6 +95,10 @@ int xorwow_jumps_device(Context* c);                              // c->xw_jumps
 int xorwow_pixel_states_device(Context* c, int npx, uint32_t epoch);  // c->xw_px_states = states `epoch` draws after curand_init(RAND_SEED, pixel, 0)
 int xorwow_pose_states_device(Context* c, int n_poses);           // c->xw_pose_states = states after curand_init(RAND_SEED, idx, 0)
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first = false);
+// k_solve + k_pose_mode in one launch (fast mode, index draw over block-compacted correspondences, no initial-mode trials); returns -1 when the
+// combination is not available for this call (the caller then issues the two launches)
+int solve_mode_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev, bool ref_svd,
+                                const ModeParams& mp, PoseBlock* P, int cam_idx);
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 

@@ -201,8 +201,14 @@ __device__ __forceinline__ float draw_uniform(const vrc_xorwow* __restrict__ xw,
 }
 constexpr int DRAW_MAX_TRIES = 256;
 constexpr int DRAW_RANK_INV_DENSITY = 20;  // rank select below 5 % valid pixels (rejection then needs > 90 tries for 1 % of the points)
-template <int SOLVER, bool FROM_MAP>  // SOLVER: 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>
-__global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ pts2, const float* __restrict__ pts3,
+// NW: waves per workgroup.  1 = the stand-alone kernel k_solve (one wave per workgroup); PM_THREADS / 64 = inside k_solve_mode, whose last
+// workgroup goes on with the mode kernel's work (below): every wave is what a one-wave workgroup was, the prefix of the block counts is
+// built once per workgroup by wave 0.
+// NWS (<= NW): the waves of a workgroup that solve.  The P3P chain of a wave is bound by its own instruction issue, so two such waves on one SIMD
+// take nearly twice as long: k_solve_mode lets waves 0 .. 3 of its eight solve (one per SIMD, as in the stand-alone kernel) and parks the others at
+// the barrier (measured with all eight solving: 33.8 us against 17.6 + 13.8 for the two launches).
+template <int SOLVER, bool FROM_MAP, int NW, int NWS = NW>  // SOLVER: 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>
+__device__ __forceinline__ static void solve_body(const float* __restrict__ pts2, const float* __restrict__ pts3,
                                                       float* __restrict__ rvecs, float* __restrict__ tvecs,
                                                       int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk,
                                                       CamState* cam, int npx, float fx, float fy, float cx, float cy, int n_poses,
@@ -217,7 +223,12 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
     PH_DECL;
     constexpr int LPH = (SOLVER == 1) ? 1 : 4;
     extern __shared__ int s_pref[];  // FROM_MAP: inclusive prefix of blk_counts (rank select only)
-    const int gtid = blockIdx.x * 64 + threadIdx.x, idx = gtid / LPH, sub = gtid % LPH;
+    const int ln = threadIdx.x & 63, wvi = threadIdx.x >> 6;
+    const int gtid = (blockIdx.x * NWS + wvi) * 64 + ln, idx = gtid / LPH, sub = gtid % LPH;
+    if (NWS < NW && wvi >= NWS) {  // parked wave (k_solve_mode: index draw, prefix in the LDS): it only keeps the workgroup's one barrier company
+        __syncthreads();
+        return;
+    }
     // FROM_MAP: the first batch of rejection probes does not depend on the number of correspondences, so its reads are in flight
     // together with those of the per-block counts (one memory round trip instead of two at the head of the kernel)
     constexpr int DRAW_BATCH = 4;
@@ -242,7 +253,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
     auto prefix_to_lds = [&]() -> int {
         int carry = 0;
         for (int i0 = 0; i0 < nblk; i0 += 64 * 32) {
-            const int b0 = i0 + (int)threadIdx.x * 32;
+            const int b0 = i0 + ln * 32;
             int v[32];
             if (b0 + 32 <= nblk) {
 #pragma unroll
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
             for (int j = 1; j < 32; j++) v[j] += v[j - 1];
             int incl = v[31];
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if ((int)threadIdx.x >= o) incl += t; }
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (ln >= o) incl += t; }
             const int base = carry + incl - v[31];
 #pragma unroll
             for (int j = 0; j < 32; j++) if (b0 + j < nblk) s_pref[pref_at(b0 + j)] = base + v[j];
@@ -265,8 +276,12 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
     };
     if (FROM_MAP) {
         if (draw > 0 && !blk_offsets) {  // the reference's draw (default): the prefix is needed anyway, its last entry is the count
-            n_pts = prefix_to_lds();
-            __syncthreads();
+            if (NW == 1) { n_pts = prefix_to_lds(); __syncthreads(); }
+            else {  // one wave builds it for the workgroup
+                if (wvi == 0) (void)prefix_to_lds();
+                __syncthreads();
+                n_pts = nblk > 0 ? s_pref[pref_at(nblk - 1)] : 0;
+            }
         } else {
             // number of valid correspondences = sum of k_collect's per-workgroup counts; every wave adds them up itself
             // (a few coalesced loads) instead of a separate single-workgroup launch between collect and solve
@@ -274,7 +289,7 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
             for (int i0 = 0; i0 < nblk; i0 += 64 * 32) {  // 32 independent loads in flight per lane: one round trip up to 2048 blocks (1080p: 8100)
                 int v[32];
 #pragma unroll
-                for (int u = 0; u < 32; u++) { const int i = i0 + u * 64 + (int)threadIdx.x; v[u] = i < nblk ? blk_counts[i] : 0; }
+                for (int u = 0; u < 32; u++) { const int i = i0 + u * 64 + ln; v[u] = i < nblk ? blk_counts[i] : 0; }
 #pragma unroll
                 for (int u = 0; u < 32; u++) part += v[u];
             }
@@ -287,8 +302,8 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
         n_pts = *n_pts_dev;
     PH_MARK(8);
     const bool rank_draw = FROM_MAP && n_pts >= 4 && (draw > 0 || (draw == 0 && (long long)n_pts * DRAW_RANK_INV_DENSITY < (long long)npx));
-    if (rank_draw && !blk_offsets && draw <= 0) {  // D3b's low-density fallback: wave-uniform
-        prefix_to_lds();
+    if (rank_draw && !blk_offsets && draw <= 0) {  // D3b's low-density fallback: uniform over the workgroup (n_pts is)
+        if (NW == 1 || wvi == 0) (void)prefix_to_lds();
         __syncthreads();
     }
     if (idx >= n_poses) return;
@@ -457,6 +472,14 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
         }
     }
     PH_MARK(13); PH_ADD(14, 1);
+}
+template <int SOLVER, bool FROM_MAP>
+__global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ pts2, const float* __restrict__ pts3, float* __restrict__ rvecs, float* __restrict__ tvecs,
+                                                      int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk, CamState* cam, int npx, float fx, float fy,
+                                                      float cx, float cy, int n_poses, int draw, int strict, const int* __restrict__ blk_offsets,
+                                                      const unsigned long long* __restrict__ valid_mask, int newton_steps, const vrc_xorwow* __restrict__ xw) {
+    solve_body<SOLVER, FROM_MAP, 1>(pts2, pts3, rvecs, tvecs, n_pts_dev, blk_counts, nblk, cam, npx, fx, fy, cx, cy, n_poses, draw, strict, blk_offsets, valid_mask,
+                                    newton_steps, xw);
 }
 
 // ---- single-workgroup mode finding ---------------------------------------------------------------
@@ -1190,9 +1213,9 @@ __device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], i
 // THREADS: the per-iteration all-reduce, the mean update and the convergence test are executed by every wave (~100 instructions next
 // to ~30 per pair of hypotheses), so fewer, fatter waves do less redundant work: THREADS * SPT = PM_POOL.
 template <bool DEFER, int THREADS>
-__global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
-                                                                  int n_poses, ModeParams mp, CamState* cam, PoseBlock* P, int cam_idx,
-                                                                  const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
+__device__ __forceinline__ static void pose_mode_body(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
+                                                      int n_poses, const ModeParams& mp, CamState* cam, PoseBlock* P, int cam_idx,
+                                                      const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
 #pragma clang fp contract(fast)  // kernel-weighted sums: not part of the solver's exact-rounding contract (file-wide: off)
     constexpr int SPT = PM_POOL / THREADS, MS_PAIRS = SPT / 2, NW = THREADS / 64;
     __shared__ RedBuf rb;
@@ -1409,6 +1432,40 @@ __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __res
         maybe_decide(mp, P, cam, cam_idx);
     }
     PH_MARK(22);
+}
+template <bool DEFER, int THREADS>
+__global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp, CamState* cam,
+                                                                  PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
+    pose_mode_body<DEFER, THREADS>(rvecs, tvecs, n_poses, mp, cam, P, cam_idx, n_points_dev, trials_in);
+}
+// k_solve + k_pose_mode in ONE launch (round 4): PM_THREADS-thread workgroups, every wave a group of hypotheses as in k_solve; a workgroup that has
+// stored its part of the pool takes a ticket, and the workgroup that draws the LAST ticket -- all 8192 hypotheses are in memory -- goes on as the
+// mode kernel.  Nobody waits for anybody (no spinning, nothing to deadlock); one launch boundary per camera less: the mode kernel's dispatch,
+// its wave launch and the gap before it (~3-4 us of a 14 us kernel).  The pool still goes through memory (it is produced by 512 waves on other
+// compute units).  Release: the stores of a workgroup are ordered before its ticket by the barrier + agent-scope fence of thread 0; acquire: the
+// last workgroup invalidates before it reads the pool.  Same results as the two launches, bit for bit (tests/test_gpu_kernels.py).
+// MEASURED AND NOT ADOPTED (debug switch `fuse_solve_mode`, default 0): 30.9 us per launch against 17.6 + 13.8 us for the two kernels, and the
+// window takes 3.91 ms either way (cfg3 6.98 against 6.94, cfg5 equal): the ticket's round trip, the two fences and the pool arriving from
+// memory instead of the second kernel's fresh L2 cost what the dispatch cost.
+constexpr int SM_SOLVE_WAVES = 4;  // solving waves per workgroup of k_solve_mode: one per SIMD
+template <int SOLVER, bool DEFER>
+__global__ __launch_bounds__(PM_THREADS) static void k_solve_mode(const float* __restrict__ pts2, const float* __restrict__ pts3, float* __restrict__ rvecs, float* __restrict__ tvecs,
+                                                                   int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk, CamState* cam, int npx, float fx,
+                                                                   float fy, float cx, float cy, int n_poses, int draw, int strict, const unsigned long long* __restrict__ valid_mask,
+                                                                   int newton_steps, ModeParams mp, PoseBlock* P, int cam_idx, unsigned* __restrict__ ticket, unsigned ticket_base) {
+    solve_body<SOLVER, true, PM_THREADS / 64, SM_SOLVE_WAVES>(pts2, pts3, rvecs, tvecs, n_pts_dev, blk_counts, nblk, cam, npx, fx, fy, cx, cy, n_poses, draw, strict, nullptr, valid_mask,
+                                              newton_steps, nullptr);
+    __shared__ int s_last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t - ticket_base) == gridDim.x - 1u ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    pose_mode_body<DEFER, PM_THREADS>(rvecs, tvecs, n_poses, mp, cam, P, cam_idx, n_pts_dev, nullptr);
 }
 
 // The initial-mode trials of a camera that has no pose yet (first EM iteration; meanshift.cu:72-95: the kernel density at up to
@@ -1689,6 +1746,39 @@ int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState*
     else
         hipLaunchKernelGGL((k_pose_mode<false, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
                            mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials);
+    VK_CHECK_LAST();
+    return 0;
+}
+
+int solve_mode_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev, bool ref_svd,
+                                const ModeParams& mp_in, PoseBlock* P, int cam_idx) {
+    if (!debug_switches().fuse_solve_mode || !c->maps_block_compact || n_poses > PM_POOL || solver == 1) return -1;
+    const int nb = c->n_map_blocks;
+    const size_t lds = sizeof(int) * ((size_t)nb + nb / 32 + 1);  // the prefix of the block counts (pref_at() in solve_body)
+    // the refit variant carries 141 KB of static LDS (refit_partition's staging planes): the prefix has to fit next to it
+    if (lds > (mp_in.do_rg ? (size_t)14 * 1024 : (size_t)60 * 1024)) return -1;
+    ModeParams mp = mp_in;
+    mp.rg_partition = debug_switches().refit_partition;
+    if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
+    if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
+    if (!c->ticket.p) {
+        if (int e = c->ticket.reserve(sizeof(unsigned))) return e;
+        VK_CHECK(hipMemsetAsync(c->ticket.p, 0, sizeof(unsigned), c->stream));
+        c->ticket_base = 0;
+    }
+    const dim3 g((n_poses * 4 + SM_SOLVE_WAVES * 64 - 1) / (SM_SOLVE_WAVES * 64)), b(PM_THREADS);
+    const int st = (ref_svd ? 2 : 0) | 4;
+    const int cap = debug_switches().newton_cap, ns = cap > 0 ? cap : 50;
+    float* rv = c->rvecs.as<float>(); float* tv = c->tvecs.as<float>();
+    const float* p2 = c->p2_map.as<float>(); const float* p3 = c->p3_map.as<float>();
+    int* npd = c->n_points.as<int>(); const int* bc = c->blk_counts.as<int>();
+    const unsigned long long* vm = c->valid_mask.as<unsigned long long>();
+    unsigned* tk = c->ticket.as<unsigned>();
+#define VK_LAUNCH_SM(S, D) hipLaunchKernelGGL((k_solve_mode<S, D>), g, b, lds, c->stream, p2, p3, rv, tv, npd, bc, nb, cam_dev, npx, fx, fy, cx, cy, n_poses, 1, st, vm, ns, mp, P, cam_idx, tk, c->ticket_base)
+    if (solver == 0) { if (mp.do_rg) VK_LAUNCH_SM(0, true); else VK_LAUNCH_SM(0, false); }
+    else { if (mp.do_rg) VK_LAUNCH_SM(2, true); else VK_LAUNCH_SM(2, false); }
+#undef VK_LAUNCH_SM
+    c->ticket_base += g.x;
     VK_CHECK_LAST();
     return 0;
 }

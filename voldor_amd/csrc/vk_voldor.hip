@@ -223,10 +223,7 @@ struct Voldor {
             return e;
         // cpu_p3p=1 selects the reference's CPU instantiation lambdatwist_p4p<double,...> (geometry.cpp:112)
         const int solver = cfg.lambdatwist ? (cfg.cpu_p3p ? 2 : 0) : 1;
-        if (int e = solve_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i,
-                                           cfg.reference_draw ? 1 : 0, strict,
-                                           cfg.reference_svd < 0 ? reference_svd_default() : cfg.reference_svd != 0, ref_rng))
-            return e;
+        const bool ref_svd = cfg.reference_svd < 0 ? reference_svd_default() : cfg.reference_svd != 0;
         ModeParams mp{};
         mp.dims = 6; mp.kernel_var = cfg.meanshift_kernel_var; mp.ms_epsilon = cfg.meanshift_epsilon;
         mp.ms_max_iters = cfg.meanshift_max_iters; mp.ms_max_init_trials = cfg.meanshift_max_init_trials;
@@ -239,6 +236,14 @@ struct Voldor {
             mp.decide_trunc_rigidness_density = cfg.trunc_rigidness_density; mp.decide_trunc_sample_density = cfg.trunc_sample_density;
             mp.host_brief = c->h_brief_dev;
         }
+        // fast mode, a camera that already has a pose (no initial-mode trials between the two), the index draw: P3P batch and mode kernel in ONE launch
+        if (!strict && !ref_rng && cfg.reference_draw && hcams[i].pose_sample_count != 0) {
+            const int e = solve_mode_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i, ref_svd, mp, S.pb(), i);
+            if (e >= 0) { if (e) return e; if (c->prof) prof_end(c, "optimize_camera_pose"); return 0; }
+        }
+        if (int e = solve_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i,
+                                           cfg.reference_draw ? 1 : 0, strict, ref_svd, ref_rng))
+            return e;
         if (strict) { if (int e = pose_mode_strict_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e; }
         else if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i, hcams[i].pose_sample_count == 0)) return e;
         if (c->prof) prof_end(c, "optimize_camera_pose");
