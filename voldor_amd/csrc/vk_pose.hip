@@ -860,8 +860,8 @@ __device__ __forceinline__ void finalize_pose(const float* mean6 /*scaled space*
 // (refit_block) runs on the same registers and finalises.
 //
 // One compute unit does all of it, and its passes over the pool are VALU-issue bound (16 waves on 4 SIMDs), so the pool is
-// held as PAIRS of hypotheses per lane and the arithmetic is written on float2: gfx950 issues v_pk_{add,mul,fma}_f32 at the
-// rate of the scalar forms, two hypotheses per instruction.  Hypothesis i lives in thread i % 1024, pair (i / 1024) / 2,
+// held as PAIRS of hypotheses per lane and the arithmetic is written on float2: a v_pk_{add,mul,fma}_f32 takes 1.5x the issue time of
+// the scalar form on gfx950 (8.5 against 5.5 clocks per wave: scripts/micro/pk_rate.hip) and does two hypotheses.  Hypothesis i lives in thread i % 1024, pair (i / 1024) / 2,
 // half (i / 1024) % 2.  A non-finite hypothesis (geometry.cpp:156-165 drops those) is stored as MS_FAR in every coordinate:
 // its squared distance to anything is ~6e36, its kernel weight exp(-6e36 / 2 var) is exactly 0 and 0 * MS_FAR = 0, so it
 // contributes exactly nothing to any sum -- no mask in the loops.
