@@ -555,23 +555,38 @@ struct StrictParShared {
 // block b: the same in-lane pair sums and the same transposing wave reduction, then the block sums meet in GLOBAL memory (agent-scope
 // atomic stores / loads), one grid barrier per sum (double buffered like the LDS form), and every workgroup walks the second-level tree
 // itself -- every workgroup carries the whole control flow redundantly on identical numbers, so they agree on every branch.
-struct CoopGlobal { float lvl[2][16][32]; float raw[32]; unsigned counter; int used; unsigned err; unsigned pad; };
-// grid barrier of the NB single-wave workgroups: an arrival counter that only grows (zeroed by k_pose_strict_compact, which runs right
-// before on the same stream).  The spin is BOUNDED: a workgroup that never sees the others (it cannot happen while all NB are resident --
-// 16 waves on a 256-CU chip -- but a hang here would take the GPU box with it) raises G->err and goes on with whatever it reads.
-__device__ __forceinline__ void coop_grid_sync(CoopGlobal* G, unsigned& target, int nb_wg) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    target += (unsigned)nb_wg;
-    if ((threadIdx.x & 63) == 0) {
-        __hip_atomic_fetch_add(&G->counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        unsigned spins = 0;
-        while (__hip_atomic_load(&G->counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1u << 24)) { __hip_atomic_store(&G->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+struct CoopGlobal {
+    // a block sum and the number of the sum it belongs to in ONE 64-bit word (value bits | epoch << 32): the store of the word is the arrival, the
+    // reader that finds the epoch has the value -- no counter, no fence, no second round trip (tagged[.][.][.] = 0 never matches: epochs start at 1)
+    unsigned long long tagged[2][16][32];
+    unsigned long long tagged_raw[32];
+    int used; unsigned err; unsigned pad[2];
+};
+// The workgroups of the cooperative form meet once per sum, in the tagged block sums themselves (CoopGlobal): lane k (< NV) of every workgroup reads
+// block sums k of all blocks until each carries this sum's epoch.  A slot is reused two sums later; a workgroup can be at most ONE sum ahead of the
+// slowest (it needs everybody's sums to get on), so nobody overwrites a word that is still being waited for.  Round 4, first form: an arrival counter
+// + release / acquire fences + the loads (three dependent round trips per sum); this form: one.  The spin is BOUNDED: a workgroup that never sees
+// the others (it cannot happen while all of them are resident -- 16 waves on a 256-CU chip -- but a hang here would take the GPU box with it) raises
+// G->err, and the pose is reported as failed.
+__device__ __forceinline__ unsigned long long coop_pack(float v, unsigned epoch) { return (unsigned long long)__builtin_bit_cast(unsigned, v) | ((unsigned long long)epoch << 32); }
+// the words p[t * stride], t < nb (<= 16), all read together until every one carries `epoch`; out[t] = its value (0 beyond nb)
+__device__ __forceinline__ void coop_wait(const unsigned long long* p, int stride, int nb, unsigned epoch, CoopGlobal* G, float (&out)[16]) {
+    unsigned spins = 0;
+    for (;;) {
+        unsigned long long w[16];
+#pragma unroll
+        for (int t = 0; t < 16; t++) w[t] = t < nb ? __hip_atomic_load(p + (size_t)t * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)epoch << 32);
+        bool all = true;
+#pragma unroll
+        for (int t = 0; t < 16; t++) all = all && (unsigned)(w[t] >> 32) == epoch;
+        if (all || ++spins > (1u << 22)) {
+            if (!all) __hip_atomic_store(&G->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int t = 0; t < 16; t++) out[t] = t < nb ? __builtin_bit_cast(float, (unsigned)w[t]) : 0.f;
+            return;
         }
+        __builtin_amdgcn_s_sleep(1);
     }
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 template <int NV, bool COOP, typename RowFn>
 __device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared& S, CoopGlobal* G, unsigned& sync_target, int& parity, float (&out)[NV],
@@ -593,7 +608,7 @@ __device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared
             const bool h0 = base + 64 * j < n, h1 = base + 64 * j + 256 < n;
             if (n == 1 && blk == 0 && lane == 0 && j == 0) {
 #pragma unroll
-                for (int k = 0; k < NV; k++) { if (COOP) __hip_atomic_store(&G->raw[k], v0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else S.raw[k] = v0[k]; }
+                for (int k = 0; k < NV; k++) { if (COOP) __hip_atomic_store(&G->tagged_raw[k], coop_pack(v0[k], sync_target + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else S.raw[k] = v0[k]; }
             }
 #pragma unroll
             for (int k = 0; k < NV; k++) s[k] = h0 ? (h1 ? v0[k] + v1[k] : v0[k]) : 0.f;
@@ -615,15 +630,20 @@ __device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared
         const float mine = wave_reduce_transpose<P>(acc);  // strides 32 .. 1 of the rows = lane distances 1 .. 32
         const int slot = wave_slot<P>(lane);
         if (lane < P && slot < NV) {
-            if (COOP) __hip_atomic_store(&G->lvl[parity][blk][slot], mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (COOP) __hip_atomic_store(&G->tagged[parity][blk][slot], coop_pack(mine, sync_target + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             else S.lvl[parity][blk][slot] = mine;
         }
     }
-    if (COOP) coop_grid_sync(G, sync_target, (int)gridDim.x); else __syncthreads();
+    if (COOP) ++sync_target; else __syncthreads();  // COOP: the epoch of this sum; the meeting is in coop_wait below
     float tot = 0.f;
     if (lane < NV) {
-        auto at = [&](int t) { return COOP ? __hip_atomic_load(&G->lvl[parity][t][lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.lvl[parity][t][lane]; };
-        if (n == 1) tot = COOP ? __hip_atomic_load(&G->raw[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : S.raw[lane];
+        float got[16];
+        if (COOP) {  // this is where the workgroups meet
+            if (n == 1) coop_wait(&G->tagged_raw[lane], 0, 1, sync_target, G, got);
+            else coop_wait(&G->tagged[parity][0][lane], 32, nb, sync_target, G, got);
+        }
+        auto at = [&](int t) { return COOP ? got[t] : S.lvl[parity][t][lane]; };
+        if (n == 1) tot = COOP ? got[0] : S.raw[lane];
         else if (nb == 1) tot = at(0);
         else {
             float b[16];
@@ -688,13 +708,17 @@ __device__ __forceinline__ int strict_compact_pool(const float* __restrict__ rve
     }
     return used;
 }
-// first launch of the cooperative form: the pool, its size, and the grid barrier's counter back to zero
+// first launch of the cooperative form: the pool, its size, and the tagged block sums back to zero
 __global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_compact(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, float rvec_scale,
                                                                             const int* __restrict__ n_points_dev, float* __restrict__ pool, CoopGlobal* G) {
     __shared__ StrictParShared S;
     int used = 0;
     if (*n_points_dev >= 4) used = strict_compact_pool(rvecs, tvecs, n_poses, rvec_scale, pool, S);
-    if (threadIdx.x == 0) { G->used = used; G->counter = 0u; G->err = 0u; }
+    if (threadIdx.x == 0) { G->used = used; G->err = 0u; }
+    // epochs restart at 1 with every launch of the mode kernel: no word of an earlier launch may carry one
+    unsigned long long* tg = &G->tagged[0][0][0];
+    for (int i = threadIdx.x; i < 2 * 16 * 32; i += SP_THREADS) tg[i] = 0ull;
+    if (threadIdx.x < 32) G->tagged_raw[threadIdx.x] = 0ull;
 }
 
 template <bool COOP>
