@@ -56,22 +56,25 @@ def strict_ref(which):
     must equal bit for bit (tests/test_gpu_configs.py): registered count, poses, covariances, sha256 of the depth / confidence maps
     and every 8th pixel of them.  cfg3 ~4 min, cfg5 ~40 min on one core."""
     ref = orc.ref()
+    cuda = "--cuda" in sys.argv  # with cuRAND's XORWOW streams and CUDA's linear texture filter as well (vk_ref_cuda.h; product: --reference_rng 1 --reference_tex 1) -> ref_big_cuda_<name>.npz
     for name in which:
         c = big.make(name)
         fx, fy, cx, cy = c["K"]
         t0 = time.time()
         ref.ref_set_math_mode(1)
+        if cuda: ref.ref_set_reference_rng(1); ref.ref_set_reference_tex(1)
         try:
             r = orc.ref_voldor(c["flows"], fx, fy, cx, cy, config=c["config"], basefocal=c["basefocal"], disparity=c["disparity"])
         finally:
             ref.ref_set_math_mode(0)
-        print(f"{name}: reference pipeline in strict math: {time.time() - t0:.0f} s, n_registered {r['n_registered']}", flush=True)
+            if cuda: ref.ref_set_reference_rng(0); ref.ref_set_reference_tex(0)
+        print(f"{name}: reference pipeline in strict math{' + xorwow + texture filter' if cuda else ''}: {time.time() - t0:.0f} s, n_registered {r['n_registered']}", flush=True)
         out = {f"{name}/ref_strict/n_registered": np.int32(r["n_registered"]), f"{name}/ref_strict/poses": r["poses"],
                f"{name}/ref_strict/poses_covar": r["poses_covar"]}
         for k in ("depth", "depth_conf"):
             out[f"{name}/ref_strict/{k}_sha256"] = np.frombuffer(hashlib.sha256(np.ascontiguousarray(r[k]).tobytes()).digest(), np.uint8)
             out[f"{name}/ref_strict/{k}_sub8"] = r[k][::8, ::8].copy()
-        path = os.path.join(HERE, f"ref_big_strict_{name}.npz")
+        path = os.path.join(HERE, f"ref_big_{'cuda' if cuda else 'strict'}_{name}.npz")
         np.savez_compressed(path, **out)
         print(f"wrote {path}", flush=True)
 

@@ -239,6 +239,33 @@ def test_big_window_in_reference_mode_equals_the_reference_bit_for_bit(name):
 
 
 @pytest.mark.parametrize("name", ["cfg3", "cfg5"])
+def test_big_window_with_xorwow_and_texture_filter_equals_the_reference(name):
+    """The same windows with the reference's last two stand-ins switched off as well: tests/golden/ref_big_cuda_<name>.npz = the reference's own pipeline
+    in strict math whose curand_* draw from cuRAND's XORWOW streams and whose at_tex is CUDA's linear filter over the stacked layers (both restated in
+    voldor_amd/csrc/vk_ref_cuda.h; tests/golden/gen_golden_big.py --strict-ref --cuda).  With `--reference_rng 1 --reference_tex 1` on top of the reference
+    mode the HIP window equals it in every bit -- at 1080p that is 2 073 600 XORWOW subsequences (the 2^67-step jump for every pixel) and ten stacked
+    flow layers whose bottom rows bleed into the next layer."""
+    import big_window_cases as big
+    from voldor_amd import kernels, pyvoldor
+    path = os.path.join(os.path.dirname(BIG_GOLD), f"ref_big_cuda_{name}.npz")
+    if not os.path.exists(path):
+        pytest.skip(f"{os.path.basename(path)} not generated")
+    g = np.load(path)
+    c = big.make(name)
+    fx, fy, cx, cy = c["K"]
+    kernels.set_rand_epoch(0)
+    o = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"],
+                        config=c["config"] + " --strict_math 1 --reference_draw 1 --reference_svd 1 --reference_rng 1 --reference_tex 1")
+    p = f"{name}/ref_strict/"
+    assert o["n_registered"] == int(g[p + "n_registered"]) == c["flows"].shape[0]
+    assert np.array_equal(o["depth"][::8, ::8].view(np.uint32), g[p + "depth_sub8"].view(np.uint32)), np.mean(o["depth"][::8, ::8] != g[p + "depth_sub8"])
+    assert np.array_equal(_sha(o["depth"]), g[p + "depth_sha256"])
+    assert np.array_equal(_sha(o["depth_conf"]), g[p + "depth_conf_sha256"])
+    assert np.array_equal(o["poses_covar"].view(np.uint32), g[p + "poses_covar"].view(np.uint32))
+    assert not (_bits(o["poses"]) != _bits(g[p + "poses"])).any()
+
+
+@pytest.mark.parametrize("name", ["cfg3", "cfg5"])
 def test_big_window_fast_mode_vs_the_reference_pipeline(name):
     """The same windows in fast mode against the REFERENCE's own pipeline run on the CPU (oracle/_ref, ~80 s / ~15 min on one core,
     outputs committed sub-sampled): same registered count; rotation, translation, 90th-percentile depth difference and covariance
