@@ -51,6 +51,7 @@
  *  A camera's rotation vector is Camera::rvec() of its float matrix (cv::Rodrigues round trip, utils.h:44-53; round 4,
  *     voldor_amd/csrc/vk_ref_cv.h): what the next mean shift starts from and what the window returns -- not a deviation, a correction.
  *  D5 8-point LMedS two-view bootstrap instead of OpenCV's 5-point findEssentialMat (not in the tree).
+ *     The product's five-point option (--bootstrap_points 5) is held against orc_fivept.py: the same constraints solved by another algorithm.
  *  D6 world-scale normalisation skipped when the window is lost (reference: 0/0).
  *  D8 rodrigues(): exact polar factor instead of the reference's approximate fp32 SVD (svd3_cuda.h);
  *     orc_set_reference_svd(1) switches to that SVD, bit for bit (product: --reference_svd 1).

@@ -54,7 +54,7 @@ def test_solutions_are_essential_matrices_and_contain_the_planted_one():
     resid, dist = np.array(resid), np.array(dist)
     print(f"solutions per sample: mean {np.mean(n_sol):.2f}, max {max(n_sol)}; essential-matrix constraint residual: median {np.median(resid):.1e}, 99th percentile "
           f"{np.percentile(resid, 99):.1e}; planted E found to 1e-9 in {(dist < 1e-9).sum()} of {n_trials} samples")
-    # measured: residual 2e-16 / 9e-16 (median / 99th percentile), planted E found in 982 of 1000 samples (the rest: a root of the degree-10
+    # measured: residual 2e-16 / 9e-16 (median / 99th percentile), planted E found in 984 of 1000 samples (the rest: a root of the degree-10
     # polynomial lost in a cluster of roots -- small baselines and pure forward motion make up a third of these samples)
     assert np.percentile(resid, 99) < 1e-10 and np.mean(resid < 1e-6) > 0.995
     assert (dist < 1e-9).sum() >= 0.97 * n_trials
@@ -118,3 +118,43 @@ def test_five_point_bootstrap_kernels_give_the_host_bits(small_scene):
     print(f"window from the five-point bootstrap: rot {r5.max():.2e} rad, rel. trans {t5.max():.2e}; from the 8-point bootstrap: {r8.max():.2e}, {t8.max():.2e}")
     # the bootstrap only seeds the EM: both windows end at the same accuracy against ground truth (160x120, 4 iterations: a noisy estimate either way)
     assert r5.max() <= 1.5 * r8.max() + 1e-3 and t5.max() <= 1.5 * t8.max() + 2e-2, (r5, t5, r8, t8)
+
+
+def test_solution_sets_equal_those_of_an_independent_solver():
+    """oracle/orc_fivept.py solves the same ten cubic constraints by the action-matrix / eigenvector method of Stewenius et al. (numpy SVD + eig): no
+    code and no formulation shared with vk_fivept.hpp (degree-10 polynomial, Laguerre roots with deflation).  (a) PRECISION: every essential matrix
+    the product returns is one the oracle returns (to 1e-6, up to sign) -- no spurious models; (b) RECALL: on generic geometries the two sets are the
+    same set in >= 97 % of the samples and the product finds >= 99 % of the oracle's matrices; on the hard ones (pure forward motion with a 5 %
+    baseline: near-multiple roots) the eigen-solver keeps roots the deflation loses -- measured and printed, the LMedS on top draws 192 samples."""
+    from oracle import orc_fivept
+    from voldor_amd import kernels
+    rng = np.random.default_rng(12)
+
+    def partner(E, S):
+        return min([min(np.abs(E - F).max(), np.abs(E + F).max()) for F in S] + [9.0])
+    stats = {False: dict(samples=0, same=0, prod=0, spurious=0, orc=0, found=0, planted_p=0, planted_o=0), True: None}
+    stats[True] = dict(stats[False])
+    for i in range(400):
+        hard = i % 5 == 0
+        q1, q2, E0, _, _ = _geometry(rng, forward=hard, baseline=(0.05 if hard else 1.0))
+        P = kernels.fivept_solve(q1, q2)
+        O = orc_fivept.solve(q1, q2)
+        st = stats[hard]
+        st["samples"] += 1
+        tol = 1e-4 if hard else 1e-6  # the hard samples are ill conditioned: a root is good to ~1e-5 in either solver
+        sp = sum(1 for E in P if partner(E, O) > tol); fo = sum(1 for F in O if partner(F, P) <= tol)
+        st["prod"] += len(P); st["spurious"] += sp; st["orc"] += len(O); st["found"] += fo
+        st["same"] += int(len(P) == len(O) and sp == 0 and fo == len(O))
+        st["planted_p"] += int(partner(E0, P) < tol); st["planted_o"] += int(partner(E0, O) < tol)
+    for hard in (False, True):
+        st = stats[hard]
+        print(f"{'hard' if hard else 'generic'}: {st['samples']} samples, identical sets {st['same']}, product models {st['prod']} (not in the oracle's set: {st['spurious']}), "
+              f"oracle models {st['orc']} (found by the product: {st['found']}), planted E found by product / oracle: {st['planted_p']} / {st['planted_o']}")
+    g, h = stats[False], stats[True]
+    # measured: generic 320 / 320 identical sets (1588 models each), planted matrix 320 / 320 in both; hard (80 samples): product 354 models, 6 without
+    # a partner, 340 of the oracle's 410 found, planted matrix 62 (product) / 78 (oracle) -- the degree-10 polynomial loses near-multiple roots that
+    # the eigenvalue problem keeps (OpenCV's solver is a polynomial solver as well); the bootstrap draws 192 samples
+    assert g["spurious"] == 0 and g["same"] == g["samples"] and g["found"] == g["orc"]
+    assert g["planted_o"] == g["samples"] and g["planted_p"] == g["samples"]
+    assert h["spurious"] <= 0.03 * h["prod"] and h["found"] >= 0.8 * h["orc"]
+    assert h["planted_o"] >= 0.95 * h["samples"] and h["planted_p"] >= 0.75 * h["samples"]

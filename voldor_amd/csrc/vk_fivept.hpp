@@ -198,16 +198,25 @@ VK_HD inline int real_roots(const double* p, int deg, double* roots) {
     for (int m = deg; m >= 1; m--) {
         Cx x = laguerre(work, m, { 0.0, 0.0 });
         x = laguerre(c, deg, x);  // polish on the undeflated polynomial
-        if (vk_abs(x.im) <= 1e-7 * (1.0 + vk_abs(x.re))) {
-            double z = x.re;
-            for (int it = 0; it < 3; it++) {  // real Newton steps on the real polynomial
-                double v = p[deg], dv = 0.0;
-                for (int i = deg - 1; i >= 0; i--) { dv = dv * z + v; v = v * z + p[i]; }
-                if (dv != 0.0) z -= v / dv;
+        // A real root, or one member of a near-double real pair: where two real roots nearly coincide (forward motion, small baselines) the
+        // polynomial's rounding turns them into a complex pair re +- i im with a small imaginary part.  Such a pair is tried as the two real
+        // starts re -+ |im| (the conjugate produces the same two: the duplicate test drops them); a start that belongs to no real root ends up
+        // as a model whose residual the LMedS discards.  (Round 4, found with the independent solver oracle/orc_fivept.py: with the strict
+        // 1e-7 test alone the planted motion was missing in a quarter of the forward-motion samples.)
+        const double tol_im = vk_abs(x.im) / (1.0 + vk_abs(x.re));
+        if (tol_im <= 1e-3) {
+            const int n_start = tol_im <= 1e-7 ? 1 : 2;
+            for (int st = 0; st < n_start; st++) {
+                double z = n_start == 1 ? x.re : x.re + (st == 0 ? -vk_abs(x.im) : vk_abs(x.im));
+                for (int it = 0; it < 3; it++) {  // real Newton steps on the real polynomial
+                    double v = p[deg], dv = 0.0;
+                    for (int i = deg - 1; i >= 0; i--) { dv = dv * z + v; v = v * z + p[i]; }
+                    if (dv != 0.0) z -= v / dv;
+                }
+                bool dup = false;
+                for (int k = 0; k < n; k++) dup = dup || vk_abs(roots[k] - z) <= 1e-9 * (1.0 + vk_abs(z));
+                if (!dup && n < 10) roots[n++] = z;
             }
-            bool dup = false;
-            for (int k = 0; k < n; k++) dup = dup || vk_abs(roots[k] - z) <= 1e-9 * (1.0 + vk_abs(z));
-            if (!dup && n < 10) roots[n++] = z;
         }
         // deflate by (t - x): synthetic division from the top
         Cx rem = work[m];
@@ -292,6 +301,18 @@ VK_HD inline int solve(const double (*q1)[2], const double (*q2)[2], double (*Es
             if (step > 0.5 * size) break;  // not in the basin of a solution: keep what the polynomial gave
             x = X - d0; y = Y - d1; zz = Z - d2;
             if (step <= 1e-15 * size) break;
+        }
+        {  // what is not a solution of the ten cubics after the polish is dropped (starts of the near-double-root handling that belong to no real root)
+            const double X = x, Y = y, Z = zz;
+            const double mo[20] = { X * X * X, Y * Y * Y, X * X * Y, X * Y * Y, X * X * Z, X * X, Y * Y * Z, Y * Y, X * Y * Z, X * Y, X * Z * Z, X * Z, X, Y * Z * Z, Y * Z, Y, Z * Z * Z, Z * Z, Z, 1.0 };
+            double worst = 0.0;
+            for (int r = 0; r < 10; r++) {
+                double res = 0, mag = 0;
+                for (int c = 0; c < 20; c++) { res += A0[r][c] * mo[c]; mag += vk_abs(A0[r][c] * mo[c]); }
+                const double rel = mag > 0.0 ? vk_abs(res) / mag : 0.0;
+                worst = rel > worst ? rel : worst;
+            }
+            if (!(worst <= 1e-9)) continue;
         }
         double E[9], nn = 0.0;
         for (int c = 0; c < 9; c++) { E[c] = x * N[0][c] + y * N[1][c] + zz * N[2][c] + N[3][c]; nn += E[c] * E[c]; }
