@@ -54,10 +54,10 @@ def test_solutions_are_essential_matrices_and_contain_the_planted_one():
     resid, dist = np.array(resid), np.array(dist)
     print(f"solutions per sample: mean {np.mean(n_sol):.2f}, max {max(n_sol)}; essential-matrix constraint residual: median {np.median(resid):.1e}, 99th percentile "
           f"{np.percentile(resid, 99):.1e}; planted E found to 1e-9 in {(dist < 1e-9).sum()} of {n_trials} samples")
-    # measured: residual 2e-16 / 9e-16 (median / 99th percentile), planted E found in 984 of 1000 samples (the rest: a root of the degree-10
+    # measured: residual 2e-16 / 9e-16 (median / 99th percentile), planted E found in 999 of 1000 samples (984 when the system was solved in one basis of the null space only: a root of the degree-10
     # polynomial lost in a cluster of roots -- small baselines and pure forward motion make up a third of these samples)
     assert np.percentile(resid, 99) < 1e-10 and np.mean(resid < 1e-6) > 0.995
-    assert (dist < 1e-9).sum() >= 0.97 * n_trials
+    assert (dist < 1e-9).sum() >= 0.99 * n_trials
     assert max(n_sol) >= 6 and np.mean(n_sol) > 3.0  # several real roots per sample, as the degree-10 polynomial allows
 
 
@@ -151,10 +151,11 @@ def test_solution_sets_equal_those_of_an_independent_solver():
         print(f"{'hard' if hard else 'generic'}: {st['samples']} samples, identical sets {st['same']}, product models {st['prod']} (not in the oracle's set: {st['spurious']}), "
               f"oracle models {st['orc']} (found by the product: {st['found']}), planted E found by product / oracle: {st['planted_p']} / {st['planted_o']}")
     g, h = stats[False], stats[True]
-    # measured: generic 320 / 320 identical sets (1588 models each), planted matrix 320 / 320 in both; hard (80 samples): product 354 models, 6 without
-    # a partner, 340 of the oracle's 410 found, planted matrix 62 (product) / 78 (oracle) -- the degree-10 polynomial loses near-multiple roots that
-    # the eigenvalue problem keeps (OpenCV's solver is a polynomial solver as well); the bootstrap draws 192 samples
+    # measured: generic 320 / 320 identical sets (1588 models each), planted matrix 320 / 320 in both; hard (80 samples): product 409 models, 7 without
+    # a partner at 1e-4 (none at 1e-2), 394 of the oracle's 410 found, planted matrix 76 (product) / 78 (oracle).  Solving in ONE basis of the null
+    # space the product found the planted matrix in 62 of the 80 -- the degree-10 polynomial loses near-multiple roots; the union over two bases is
+    # what closed the gap to the eigenvalue method (vk_fivept.hpp solve)
     assert g["spurious"] == 0 and g["same"] == g["samples"] and g["found"] == g["orc"]
     assert g["planted_o"] == g["samples"] and g["planted_p"] == g["samples"]
-    assert h["spurious"] <= 0.03 * h["prod"] and h["found"] >= 0.8 * h["orc"]
-    assert h["planted_o"] >= 0.95 * h["samples"] and h["planted_p"] >= 0.75 * h["samples"]
+    assert h["spurious"] <= 0.03 * h["prod"] and h["found"] >= 0.93 * h["orc"]
+    assert h["planted_o"] >= 0.95 * h["samples"] and h["planted_p"] >= 0.9 * h["samples"]

@@ -225,14 +225,9 @@ VK_HD inline int real_roots(const double* p, int deg, double* roots) {
     return n;
 }
 
-// q1, q2: five normalised correspondences (image 1, image 2), [5][2].  Es: up to ten essential matrices (row-major, Frobenius norm sqrt 2).
-VK_HD inline int solve(const double (*q1)[2], const double (*q2)[2], double (*Es)[9], double* dbg_poly = nullptr, double* dbg_roots = nullptr, int* dbg_nroots = nullptr) {
-    double Q[5][9], N[4][9], A[10][20];
-    for (int k = 0; k < 5; k++) {
-        const double a[9] = { q2[k][0] * q1[k][0], q2[k][0] * q1[k][1], q2[k][0], q2[k][1] * q1[k][0], q2[k][1] * q1[k][1], q2[k][1], q1[k][0], q1[k][1], 1.0 };
-        for (int c = 0; c < 9; c++) Q[k][c] = a[c];
-    }
-    if (!null_space_5x9(Q, N)) return 0;
+// the solutions E = x N0 + y N1 + z N2 + N3 for ONE basis N of the null space (steps 2 .. 5)
+VK_HD inline int solve_basis(const double (*N)[9], double (*Es)[9], double* dbg_poly = nullptr, double* dbg_roots = nullptr, int* dbg_nroots = nullptr) {
+    double A[10][20];
     constraint_matrix(N, A);
     double A0[10][20];  // the constraints before the elimination: every solution is polished on them (below)
     for (int r = 0; r < 10; r++) for (int c = 0; c < 20; c++) A0[r][c] = A[r][c];
@@ -320,6 +315,44 @@ VK_HD inline int solve(const double (*q1)[2], const double (*q2)[2], double (*Es
         const double s = 1.4142135623730951 / vk_sqrt(nn);
         for (int c = 0; c < 9; c++) Es[ne][c] = E[c] * s;
         ne++;
+    }
+    return ne;
+}
+
+// q1, q2: five normalised correspondences (image 1, image 2), [5][2].  Es: up to ten essential matrices (row-major, Frobenius norm sqrt 2).
+// The basis of the four-dimensional null space is arbitrary, the solutions are not: where the roots of the degree-10 polynomial in z cluster (pure
+// forward motion, small baselines: near-multiple roots get lost) they are spread out in another basis.  The system is therefore solved in TWO bases --
+// the one the elimination produced and a fixed rotation of it -- and the union is returned (round 4; measured against the independent solver
+// oracle/orc_fivept.py, tests/test_fivept.py).
+VK_HD inline int solve(const double (*q1)[2], const double (*q2)[2], double (*Es)[9], double* dbg_poly = nullptr, double* dbg_roots = nullptr, int* dbg_nroots = nullptr) {
+    double Q[5][9], N[4][9];
+    for (int k = 0; k < 5; k++) {
+        const double a[9] = { q2[k][0] * q1[k][0], q2[k][0] * q1[k][1], q2[k][0], q2[k][1] * q1[k][0], q2[k][1] * q1[k][1], q2[k][1], q1[k][0], q1[k][1], 1.0 };
+        for (int c = 0; c < 9; c++) Q[k][c] = a[c];
+    }
+    if (!null_space_5x9(Q, N)) return 0;
+    int ne = solve_basis(N, Es, dbg_poly, dbg_roots, dbg_nroots);
+    // second basis: an orthogonal mix of the four vectors (a product of two plane rotations by 45 and ~59 degrees with a row swap: every new
+    // vector has a share of every old one)
+    const double c1 = 0.7071067811865476, s1 = 0.7071067811865476, c2 = 0.5144957554275265, s2 = 0.8574929257125441;
+    double M[4][9], T[4][9], E2[10][9];
+    for (int c = 0; c < 9; c++) {
+        T[0][c] = c1 * N[0][c] + s1 * N[3][c]; T[3][c] = -s1 * N[0][c] + c1 * N[3][c];
+        T[1][c] = c1 * N[1][c] + s1 * N[2][c]; T[2][c] = -s1 * N[1][c] + c1 * N[2][c];
+    }
+    for (int c = 0; c < 9; c++) {
+        M[0][c] = c2 * T[0][c] + s2 * T[1][c]; M[1][c] = -s2 * T[0][c] + c2 * T[1][c];
+        M[2][c] = c2 * T[2][c] + s2 * T[3][c]; M[3][c] = -s2 * T[2][c] + c2 * T[3][c];
+    }
+    const int n2 = solve_basis(M, E2);
+    for (int k = 0; k < n2 && ne < 10; k++) {
+        bool dup = false;
+        for (int j = 0; j < ne && !dup; j++) {
+            double dp = 0.0, dm = 0.0;
+            for (int c = 0; c < 9; c++) { const double a = vk_abs(E2[k][c] - Es[j][c]), b2 = vk_abs(E2[k][c] + Es[j][c]); dp = a > dp ? a : dp; dm = b2 > dm ? b2 : dm; }
+            dup = (dp < dm ? dp : dm) <= 1e-6;
+        }
+        if (!dup) { for (int c = 0; c < 9; c++) Es[ne][c] = E2[k][c]; ne++; }
     }
     return ne;
 }
