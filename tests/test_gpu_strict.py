@@ -368,3 +368,34 @@ def test_config_variants_fast_vs_strict():
           f"trans median {np.median(trs):.2e} max {max(trs):.2e} ({np.median(ref_tr):.2e} / {max(ref_tr):.2e})")
     assert max(rots) <= 2 * max(ref_rot) and max(trs) <= 2 * max(ref_tr), (rots, trs, max(ref_rot), max(ref_tr))
     assert np.median(rots) <= max(ref_rot) and np.median(trs) <= max(ref_tr), (np.median(rots), np.median(trs))
+
+
+@pytest.mark.gpu
+def test_reference_mode_with_four_windows_in_flight_equals_one_at_a_time():
+    """Four windows in flight in reference mode: four cooperative mode kernels (16 single-wave workgroups each) meet in their own CoopGlobal records at
+    the same time, next to the other windows' per-pixel kernels.  Every output bit equals the window run alone; three repetitions."""
+    import torch
+    import ref_window_cases as rc
+    from voldor_amd import kernels, pyvoldor
+    c = dict(rc.window_cases())["mono_320x240"]
+    fx, fy, cx, cy = c["K"]
+    cfg = c["config"] + " --strict_math 1 --reference_draw 1 --reference_svd 1"
+    B = 4
+    fl = [torch.from_numpy(np.ascontiguousarray(c["flows"] * (1.0 + 0.01 * b))).cuda() for b in range(B)]
+    h, w = c["flows"].shape[1:3]
+    bits = lambda a: np.ascontiguousarray(np.asarray(a), np.float32).view(np.uint32)
+    one = []
+    for b in range(B):
+        kernels.set_rand_epoch(0)
+        d = torch.empty(h, w, device="cuda"); cf = torch.empty(h, w, device="cuda")
+        o = pyvoldor.voldor_device(fl[b], fx, fy, cx, cy, config=cfg, depth_out=d, depth_conf_out=cf)
+        one.append((o, d.cpu().numpy(), cf.cpu().numpy()))
+    for rep in range(3):
+        kernels.set_rand_epoch(0)
+        d = [torch.empty(h, w, device="cuda") for _ in range(B)]; cf = [torch.empty(h, w, device="cuda") for _ in range(B)]
+        out = pyvoldor.voldor_device_batch(fl, fx, fy, cx, cy, config=cfg, depth_out=d, depth_conf_out=cf)
+        for b in range(B):
+            o, dd, cc = one[b]
+            assert out[b]["n_registered"] == o["n_registered"] > 0
+            assert np.array_equal(bits(out[b]["poses"]), bits(o["poses"])) and np.array_equal(bits(out[b]["poses_covar"]), bits(o["poses_covar"])), (rep, b)
+            assert np.array_equal(bits(d[b].cpu().numpy()), bits(dd)) and np.array_equal(bits(cf[b].cpu().numpy()), bits(cc)), (rep, b)
