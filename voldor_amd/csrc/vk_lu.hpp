@@ -118,5 +118,102 @@ __device__ static bool rg_prepare_wave(float* covar_half, float* cinv_half, int 
     return true;
 }
 
+// The same inverse with the RIGHT-HAND SIDE dealt out as well: lane 6 r + c (< 36) holds row r of A (six values, shared by the six lanes of the
+// row) and ONE element B[r][c].  lu_inverse_rows has every lane update all six columns of B and, in the back substitution, perform all 36 fp64
+// divisions although it keeps six of them (~3500 instructions per call: most of a strict refit iteration, measured round 4); here a lane updates
+// its own element (the pivot row's element of its column arrives by ds_bpermute) and divides once per level.  Every element still sees exactly the
+// operation sequence of the serial algorithm: bit-identical (tests/test_gpu_strict.py holds the strict kernels that use it to the serial LU).
+// Must be called by all 64 lanes of the wave.  a: row r of A (in), bb: B[r][c] (in: identity; out: the inverse's element); returns det.
+__device__ __forceinline__ double shfl_d(double v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ double lu_inverse_rc(double (&a)[6], double& bb, int n) {
+    const int lane = threadIdx.x & 63, r = lane / 6, c = lane % 6;
+    const bool in = lane < 36 && r < n && c < n;
+    double det = 1.0;
+    bool singular = false;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        if (i < n && !singular) {
+            int k = i;
+            double best = fabs(readlane_d(a[i], 6 * i));
+#pragma unroll
+            for (int j = i + 1; j < 6; j++) {
+                if (j < n) {
+                    const double v = fabs(readlane_d(a[i], 6 * j));
+                    if (v > best) { best = v; k = j; }
+                }
+            }
+            if (best < 2.220446049250313e-16) singular = true;
+            else {
+                if (k != i) {  // row swap i <-> k (wave-uniform decision)
+#pragma unroll
+                    for (int cc = 0; cc < 6; cc++) {
+                        const double ai = readlane_d(a[cc], 6 * i), ak = readlane_d(a[cc], 6 * k);
+                        if (r == i) a[cc] = ak; else if (r == k) a[cc] = ai;
+                    }
+                    const double bi = shfl_d(bb, 6 * i + c), bk = shfl_d(bb, 6 * k + c);
+                    if (r == i) bb = bk; else if (r == k) bb = bi;
+                    det = -det;
+                }
+                const double piv = readlane_d(a[i], 6 * i);
+                det *= piv;
+                const double d = -1.0 / piv;
+                const double alpha = a[i] * d;  // own row, column i
+                const double bic = shfl_d(bb, 6 * i + c);
+#pragma unroll
+                for (int cc = 0; cc < 6; cc++) {
+                    const double ric = readlane_d(a[cc], 6 * i);
+                    if (r > i && r < n && cc < n && cc > i) a[cc] += alpha * ric;
+                }
+                if (in && r > i) bb += alpha * bic;
+            }
+        }
+    }
+    if (singular) return 0.0;
+    if (det > 0.0) {
+#pragma unroll
+        for (int i = 5; i >= 0; i--) {  // back substitution, level i: the elements of row i
+            if (i < n) {
+                double sacc = bb;
+#pragma unroll
+                for (int k = i + 1; k < 6; k++) {
+                    const double bkc = shfl_d(bb, 6 * k + c);  // the solved element (k, c)
+                    if (k < n) sacc -= a[k] * bkc;
+                }
+                const double q = sacc / a[i];
+                if (in && r == i) bb = q;
+            }
+        }
+    }
+    return det;
+}
+// rg_prepare_wave on that layout (strict mode kernel, vk_strict.hip)
+__device__ static bool rg_prepare_wave_rc(float* covar_half, float* cinv_half, int dims, bool regularise, float lambda) {
+    const int lane = threadIdx.x & 63;
+    const int r = lane < 36 ? lane / 6 : 0, c0 = lane < 36 ? lane % 6 : 0;
+    const int rr = r < dims ? r : 0;
+    double a[6];
+    double tr = 0;
+#pragma unroll
+    for (int d = 0; d < 6; d++) if (d < dims) tr += (double)covar_half[(d * d + d) / 2 + d];
+    const double m = tr / (double)dims, lam = (double)lambda;
+#pragma unroll
+    for (int c = 0; c < 6; c++) {
+        const int hi = rr >= c ? rr : c, lo = rr >= c ? c : rr;
+        double full = (c < dims) ? (double)covar_half[(hi * hi + hi) / 2 + lo] : 0.0;
+        if (regularise) full = lam * m * (rr == c ? 1.0 : 0.0) + (1 - lam) * full;
+        a[c] = full;
+    }
+    double keep = 0.0;
+#pragma unroll
+    for (int c = 0; c < 6; c++) if (c == c0) keep = a[c];
+    double bb = (rr == c0) ? 1.0 : 0.0;
+    const double det = lu_inverse_rc(a, bb, dims);
+    if (det <= 0) return false;
+    if (lane < 36 && r < dims && c0 <= r) {
+        covar_half[(r * r + r) / 2 + c0] = (float)keep;
+        cinv_half[(r * r + r) / 2 + c0] = (float)bb;
+    }
+    return true;
+}
 
 }  // namespace vk

@@ -849,7 +849,7 @@ __global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_p
         gu_iters = 0;  // fit_robust_gaussian.cu:158-159 resets *used_iters on entry
         for (iter = 0; iter < mp.rg_max_iters; iter++) {
             if (wv == 0) {  // covar_half_to_full (:17-25), Ledoit-Wolf shrinkage (aux_funs.cpp:124-141), inverse (:101-118): rows in lanes
-                const bool ok = rg_prepare_wave(S.cov, S.cinv, 6, iter > 0 && mp.rg_covar_reg_lambda > 0, mp.rg_covar_reg_lambda);
+                const bool ok = rg_prepare_wave_rc(S.cov, S.cinv, 6, iter > 0 && mp.rg_covar_reg_lambda > 0, mp.rg_covar_reg_lambda);
                 if (lane == 0) S.flag = ok ? 0 : 2;
             }
             __syncthreads();
