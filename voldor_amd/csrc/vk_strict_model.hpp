@@ -28,11 +28,29 @@ VK_SHD float fmag_scale(float fmag) {
 #pragma clang fp contract(off)
     return 0.01f * vsm_expf(0.09f * clamp_fmag(fmag));  // FISK_A1 * expf(FISK_A2 * fmag) (:23)
 }
+// vsm_powf(x, y) = (float)exp(y log x) behind its special cases (vk_strict_math.h): two powers of ONE base share the logarithm.  Same operations on
+// the same values as two calls of vsm_powf -- the same bits -- without relying on the compiler to find the common subexpression.
+VK_SHD void powf2_same_base(float x, float y1, float y2, float& o1, float& o2) {
+#pragma clang fp contract(off)
+    const double xd = (double)x;
+    if (xd != xd || xd < 0.0 || xd == 0.0 || xd == 1.0) { o1 = vsm_powf(x, y1); o2 = vsm_powf(x, y2); return; }  // special bases: the plain calls
+    const double l = vsm_log(xd);
+    auto one = [&](float y) -> float {
+        const double yd = (double)y;
+        if (yd == 0.0) return 1.0f;
+        if (yd != yd) return (float)vsm_nan();
+        if (l == 0.0) return 1.0f;
+        return (float)vsm_exp(yd * l);
+    };
+    o1 = one(y1); o2 = one(y2);
+}
 VK_SHD float fisk_pdf(float x, float c, float scale) {  // :28-31
 #pragma clang fp contract(off)
     x = fmaxf((float)((double)x * 0.5), 1.1920929e-07f);
     const float r = (x * x) / scale;
-    return (c * vsm_powf(r, -c - 1.f) * vsm_powf(1.f + vsm_powf(r, -c), -2.f)) / scale;
+    float p1, p2;
+    powf2_same_base(r, -c - 1.f, -c, p1, p2);
+    return (c * p1 * vsm_powf(1.f + p2, -2.f)) / scale;
 }
 VK_SHD float rigidness(float dx1, float dy1, float dx2, float dy2, float lambda, float abs_rf) {  // fun_rigidness :34-42
 #pragma clang fp contract(off)
