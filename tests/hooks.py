@@ -95,9 +95,8 @@ def set_global_split(on): debug_switch("global_split", int(bool(on)))
 def set_refit_partition(on): debug_switch("refit_partition", int(bool(on)))
 def set_split_trials(on): debug_switch("split_trials", int(bool(on)))
 def set_strict_plain(on): debug_switch("strict_plain", int(bool(on)))
-def set_local_fused(waves): debug_switch("local_fused", int(waves))
 def set_strict_pose_coop(on): debug_switch("strict_pose_coop", int(bool(on)))
-def set_fuse_solve_mode(on): debug_switch("fuse_solve_mode", int(bool(on)))
+def set_pose_persist(on): debug_switch("pose_persist", int(bool(on)))
 
 
 def pose_mode_pool(rvecs, tvecs, init_pose6, use_external_init_mean=True, refit=False, kernel_var=0.2, rvec_scale=1.0, ms_epsilon=1e-5,

@@ -130,37 +130,6 @@ def _gpu_only(flows, Rs, ts, depth, rig, K, epoch=5, priors=None, pconfs=None, c
                                       kw["update_rigidness_only"])
 
 
-@pytest.mark.parametrize("w,h,noise,n_flows,n_dp", [(211, 97, 0.3, 4, 0), (640, 480, 0.1, 5, 0), (320, 240, 0.02, 5, 1), (353, 289, 0.2, 9, 0), (96, 64, 0.3, 13, 2), (31, 17, 0.3, 3, 0)])
-def test_fused_local_passes_equal_the_four_launches(w, h, noise, n_flows, n_dp):
-    """k_local_fused_lean -- the four local passes of a call as ONE launch, a workgroup per 32 x 32 tile (closed under row and column chains
-    of width 32), 8 or 16 waves per tile (measured slower than one launch per pass at every size and therefore behind
-    vk_debug_switch "local_fused", default 0) -- against one launch per pass: identical depth, rigidness and prior-confidence maps, bit for
-    bit; ragged sizes (partial tiles on both edges, an image smaller than a tile), up to 13 frames, priors."""
-    from voldor_amd import synth
-    sc = synth.make_scene(w=w, h=h, n_flows=n_flows, fx=0.5 * w, fy=0.5 * w, cx=0.5 * w, cy=0.5 * h, seed=23, basefocal=40.0 if n_dp else 0.0)
-    rng = np.random.default_rng(w * 7 + h)
-    K = K9(*sc["K"])
-    flows, Rs, ts, depth, rig = _state(sc, rng, noise=noise)
-    extra = {}
-    if n_dp:
-        pri = np.stack([(sc["depth_gt"] * (1 + rng.normal(0, 0.05, (h, w)))).astype(np.float32) for _ in range(n_dp)])
-        pri[:, ::7, ::5] = 0.0
-        extra = dict(priors=pri, pconfs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32), confs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32),
-                     dp_Rs=np.tile(np.eye(3, dtype=np.float32), (n_dp, 1, 1)), dp_ts=(rng.normal(0, 0.02, (n_dp, 3)) * np.arange(n_dp)[:, None]).astype(np.float32))
-    over = dict(n_rand_samples=3, global_prop_step=5, local_prop_width=32, fb_smooth=0, basefocal=40.0 if n_dp else 0.0, disp_delta=1.0 if n_dp else -1.0)
-    out = {}
-    try:
-        for waves in (0, 8, 16):
-            hooks.set_local_fused(waves)
-            out[waves] = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
-    finally:
-        hooks.set_local_fused(0)
-    assert np.mean(out[0][0] != depth) > 0.02  # the passes did replace depths
-    for waves in (8, 16):
-        for a, b in zip(out[0][:3 if n_dp else 2], out[waves]):
-            np.testing.assert_array_equal(a.view(np.uint32), b.view(np.uint32))
-
-
 @pytest.mark.parametrize("width,noise,n_flows,n_dp", [(32, 0.3, 4, 0), (32, 0.02, 5, 0), (33, 0.1, 5, 1), (7, 0.3, 3, 0), (64, 0.3, 9, 0),
                                                         (65, 0.05, 13, 2), (5, 0.0, 2, 0), (32, 0.1, 16, 0), (32, 0.2, 6, 5), (32, 0.2, 8, 0), (33, 0.1, 7, 1), (32, 0.2, 10, 0), (32, 0.1, 12, 1)])
 def test_local_runs_equal_the_step_by_step_chain(width, noise, n_flows, n_dp):
@@ -623,12 +592,12 @@ def test_sample_pass_with_survivor_queue_matches_strict(small_scene, with_priors
 
 
 @pytest.mark.parametrize("case", ["mono_320x240", "stereo_312x96", "mono_640x480_refit_every_iteration", "ap3p", "double_solver", "low_density", "batch_of_4"])
-def test_fused_solve_and_mode_launch_equals_the_two_launches(case):
-    """k_solve_mode (round 4): the P3P batch and the mode kernel of a camera as ONE launch -- 512-thread workgroups, the workgroup that stores the
-    last hypotheses of the pool (ticket counter, release / acquire at agent scope) goes on with the mean shift (and the refit) -- against the two
-    launches (vk_debug_switch "fuse_solve_mode" = 0, the default: the fused launch was measured and gains nothing): every output of the window, bit for bit.  Windows with and without depth priors, the refit
-    in every iteration (the 141 KB variant), AP3P (not fused: same answer by construction), the fp64 solver, a window whose correspondence
-    density collapses, and four windows in flight (four ticket counters)."""
+def test_persistent_pose_kernel_equals_the_launch_chain(case):
+    """k_pose_persist (round 5): the pose half of an EM iteration -- collect, P3P batch, mean shift for every camera -- as ONE launch whose workgroups
+    meet in tagged data (vk_debug_switch "pose_persist" = 1, the default where it applies) against one launch per stage ("pose_persist" = 0): every
+    output of the window, bit for bit.  Windows with and without depth priors, the refit in every iteration (the persistent kernel hands those
+    iterations to the launch chain), AP3P and the fp64 solver (launch chain either way: same answer by construction), a window whose correspondence
+    density collapses (truncation decided inside the kernel), and four windows in flight (pool contexts take the launch chain)."""
     import ref_window_cases as rc
     from voldor_amd import kernels, pyvoldor, synth
     extra, batch = "", 1
@@ -658,10 +627,10 @@ def test_fused_solve_and_mode_launch_equals_the_two_launches(case):
     out = {}
     try:
         for on in (1, 0):
-            hooks.set_fuse_solve_mode(on)
+            hooks.set_pose_persist(on)
             out[on] = run()
     finally:
-        hooks.set_fuse_solve_mode(0)  # the default: measured, no time gained
+        hooks.set_pose_persist(1)
     for a, b in zip(out[1], out[0]):
         assert a["n_registered"] == b["n_registered"] and a["n_registered"] > 0
         for k in ("poses", "poses_covar", "depth", "depth_conf"):

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libvoldor_hip.so")
-SOURCES = ["vk_abi.hip", "vk_depth.hip", "vk_pose.hip", "vk_strict.hip", "vk_bootstrap.hip", "vk_voldor.hip", "vk_slam.hip", "vk_align.hip", "vk_dist.hip"]
+SOURCES = ["vk_depth_i6.hip", "vk_depth_i12.hip", "vk_depth_i16.hip", "vk_depth_s8.hip", "vk_depth_s16.hip", "vk_depth_i8.hip", "vk_depth_i4.hip", "vk_abi.hip", "vk_depth.hip", "vk_pose.hip", "vk_strict.hip", "vk_bootstrap.hip", "vk_voldor.hip", "vk_slam.hip", "vk_align.hip", "vk_dist.hip"]
 # test-only library (host builds of the per-lane math + device-vs-host probes): tests/cxx/vk_testhooks.hip, built by build_test_lib()
 # with the product flags; nothing in the product loads it and the product build does not depend on it.
 TEST_LIB = os.path.join(LIBDIR, "libvoldor_hip_test.so")

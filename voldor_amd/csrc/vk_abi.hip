@@ -17,6 +17,11 @@ int Context::init(int dev) {
     device = dev;
     VK_CHECK(hipSetDevice(dev));
     VK_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    VK_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    VK_CHECK(hipEventCreateWithFlags(&ev_estep, hipEventDisableTiming));
+    VK_CHECK(hipEventCreateWithFlags(&ev_fb, hipEventDisableTiming));
+    VK_CHECK(hipEventCreate(&ev4));
+    VK_CHECK(hipEventCreate(&ev5));
     VK_CHECK(hipEventCreate(&ev0));
     VK_CHECK(hipEventCreate(&ev1));
     VK_CHECK(hipEventCreate(&ev2));
@@ -30,16 +35,19 @@ int Context::init(int dev) {
     return 0;
 }
 void Context::destroy() {
-    DevBuf* bufs[] = { &od.flows, &od.rig, &od.depth, &od.cost, &od.priors, &od.pconfs, &od.confs, &od.pose,
+    DevBuf* bufs[] = { &od.flows, &od.rig, &od.rig2, &od.depth, &od.cost, &od.priors, &od.pconfs, &od.confs, &od.pose,
                        &cp.flows, &cp.rig, &cp.depth, &cp.cost, &cp.priors, &cp.pconfs, &cp.confs, &cp.pose,
                        &rig_partial, &local_tbl, &p2_map, &p3_map, &blk_counts, &blk_offsets, &valid_mask, &pts2, &pts3, &n_points,
-                       &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp, &fb_scratch };
+                       &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp, &fb_scratch, &stale_depth, &sp_coop, &xw_jumps, &xw_px_states, &xw_pose_states };
     for (DevBuf* b : bufs) b->release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev2) (void)hipEventDestroy(ev2);
     if (ev3) (void)hipEventDestroy(ev3);
     if (ev_cams) (void)hipEventDestroy(ev_cams);
+    for (hipEvent_t* e : { &ev_estep, &ev_fb, &ev4, &ev5 }) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
+    if (stream2) (void)hipStreamDestroy(stream2);
+    stream2 = nullptr;
     if (h_cams) (void)hipHostFree(h_cams);
     if (h_brief) (void)hipHostFree(h_brief);
     if (h_pb) (void)hipHostFree(h_pb);
@@ -79,6 +87,7 @@ Context* pool_context(int idx) {
     while ((int)v.size() <= idx) {
         Context* c = new Context();
         if (c->init(dev) != 0) { delete c; return nullptr; }
+        c->is_pool = true;
         v.push_back(c);
     }
     return v[(size_t)idx];
@@ -143,7 +152,29 @@ static const bool g_bt_installed = [] {
 }();
 
 static DebugSwitches g_debug;
-extern "C" int vk_debug_switch(const char* name, int value);
+// ONE table of the verification switches (vk_debug.h): name, field, accepted values.  vk_debug_switch and the VOLDOR_HIP_DEBUG parser both go
+// through debug_switch_set, so a value the launch paths were never tested with cannot reach them from either side.
+struct DebugEntry { const char* name; int DebugSwitches::*field; int kind; };  // kind 0: 0 | 1; 1: 0 | 20 | 40; 2: any value >= 0
+static const DebugEntry g_debug_tab[] = {
+    { "local_serial", &DebugSwitches::local_serial, 0 }, { "cost_rand_plain", &DebugSwitches::cost_rand_plain, 0 }, { "fb_segment", &DebugSwitches::fb_segment, 1 },
+    { "global_split", &DebugSwitches::global_split, 0 }, { "refit_partition", &DebugSwitches::refit_partition, 0 }, { "split_trials", &DebugSwitches::split_trials, 0 },
+    { "strict_plain", &DebugSwitches::strict_plain, 0 }, { "strict_pose_coop", &DebugSwitches::strict_pose_coop, 0 },
+    { "pose_persist", &DebugSwitches::pose_persist, 0 }, { "fb_overlap", &DebugSwitches::fb_overlap, 0 }, { "solve_fp32", &DebugSwitches::solve_fp32, 0 },
+    { "local_table4", &DebugSwitches::local_table4, 0 }, { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 },
+};
+// returns the previous value; -1: unknown name; -2: a value the switch does not take
+static int debug_switch_set(const char* name, int value) {
+    for (const DebugEntry& t : g_debug_tab)
+        if (strcmp(t.name, name) == 0) {
+            if (t.kind == 0) value = value ? 1 : 0;
+            else if (t.kind == 1) { if (value != 0 && value != 20 && value != 40) return -2; }
+            else if (value < 0) return -2;
+            const int old = g_debug.*t.field;
+            g_debug.*t.field = value;
+            return old;
+        }
+    return -1;
+}
 DebugSwitches& debug_switches() {
     static const bool from_env = [] {  // VOLDOR_HIP_DEBUG="name=value,name=value": the switches of vk_debug.h for a whole process (A/B runs of the test suite)
         const char* e = getenv("VOLDOR_HIP_DEBUG");
@@ -155,12 +186,14 @@ DebugSwitches& debug_switches() {
                 const size_t stop = end == std::string::npos ? s.size() : end;
                 if (eq != std::string::npos && eq < stop) {
                     const std::string k = s.substr(pos, eq - pos), v = s.substr(eq + 1, stop - eq - 1);
-                    struct { const char* n; int* p; } tab[] = { { "local_serial", &g_debug.local_serial }, { "cost_rand_plain", &g_debug.cost_rand_plain }, { "fb_segment", &g_debug.fb_segment },
-                        { "global_split", &g_debug.global_split }, { "refit_partition", &g_debug.refit_partition }, { "split_trials", &g_debug.split_trials },
-                        { "strict_plain", &g_debug.strict_plain }, { "newton_cap", &g_debug.newton_cap }, { "strict_own_table", &g_debug.strict_own_table }, { "strict_lpp8", &g_debug.strict_lpp8 }, { "local_fused", &g_debug.local_fused }, { "strict_pose_coop", &g_debug.strict_pose_coop }, { "fuse_solve_mode", &g_debug.fuse_solve_mode } };
-                    bool known = false;
-                    for (auto& t : tab) if (k == t.n) { *t.p = atoi(v.c_str()); known = true; }
-                    if (!known) fprintf(stderr, "voldor_hip: VOLDOR_HIP_DEBUG: unknown switch '%s'\n", k.c_str());
+                    char* endp = nullptr;
+                    const long val = strtol(v.c_str(), &endp, 10);
+                    if (v.empty() || (endp && *endp != '\0')) fprintf(stderr, "voldor_hip: VOLDOR_HIP_DEBUG: '%s' is not an integer (switch '%s' left alone)\n", v.c_str(), k.c_str());
+                    else {
+                        const int r = debug_switch_set(k.c_str(), (int)val);
+                        if (r == -1) fprintf(stderr, "voldor_hip: VOLDOR_HIP_DEBUG: unknown switch '%s'\n", k.c_str());
+                        else if (r == -2) fprintf(stderr, "voldor_hip: VOLDOR_HIP_DEBUG: switch '%s' does not take the value %ld\n", k.c_str(), val);
+                    }
                 }
                 pos = stop + 1;
             }
@@ -305,7 +338,7 @@ int collect_p3p_instances(float* h_flows[], float* h_rigidnesses[], float* h_dep
     if (int e = S.depth.reserve(sizeof(float) * npx)) return e;
     if (h_depth) VK_CHECK(hipMemcpyAsync(S.depth.p, h_depth, sizeof(float) * npx, hipMemcpyHostToDevice, c->stream));
     if (int e = collect_device(c, S, N, w, h, active_idx, rigidness_thresh, rigidness_sum_thresh, sample_min_depth,
-                               sample_max_depth, max_trace_on_flow, nullptr, true, false, reference_tex_default()))
+                               sample_max_depth, max_trace_on_flow, nullptr, true, false, strict_math_default() && reference_tex_default()))  // the texture filter is a strict-mode switch (voldor_hip.h)
         return e;
     if (h_o_p2_map) VK_CHECK(hipMemcpyAsync(h_o_p2_map, c->p2_map.p, sizeof(float) * 2 * npx, hipMemcpyDeviceToHost, c->stream));
     if (h_o_p3_map) VK_CHECK(hipMemcpyAsync(h_o_p3_map, c->p3_map.p, sizeof(float) * 3 * npx, hipMemcpyDeviceToHost, c->stream));
@@ -379,23 +412,10 @@ int meanshift_gpu(float* h_space, float kernel_var, float* h_io_mean, float* h_o
 // The ONE entry of the verification switches (vk_debug.h; not in include/voldor_hip.h): returns the previous value, -1 for an unknown
 // name or a value the switch does not take.
 extern "C" __attribute__((visibility("default"))) int vk_debug_switch(const char* name, int value) {
-    using namespace vk;
     if (!name) return -1;
-    DebugSwitches& d = debug_switches();
-    struct { const char* n; int* p; } tab[] = { { "local_serial", &d.local_serial }, { "cost_rand_plain", &d.cost_rand_plain }, { "fb_segment", &d.fb_segment },
-        { "global_split", &d.global_split }, { "refit_partition", &d.refit_partition }, { "split_trials", &d.split_trials }, { "strict_plain", &d.strict_plain }, { "newton_cap", &d.newton_cap },
-        { "strict_own_table", &d.strict_own_table }, { "strict_lpp8", &d.strict_lpp8 }, { "local_fused", &d.local_fused }, { "strict_pose_coop", &d.strict_pose_coop }, { "fuse_solve_mode", &d.fuse_solve_mode } };
-    for (auto& t : tab)
-        if (strcmp(t.n, name) == 0) {
-            if (t.p == &d.fb_segment) { if (value != 0 && value != 20 && value != 40) return -1; }
-            else if (t.p == &d.newton_cap) { if (value < 0 || value > 50 || (value & 1)) return -1; }
-            else if (t.p == &d.local_fused) { if (value != 0 && value != 8 && value != 16) return -1; }
-            else value = value ? 1 : 0;
-            const int old = *t.p;
-            *t.p = value;
-            return old;
-        }
-    return -1;
+    (void)vk::debug_switches();  // the environment is applied first, once
+    const int r = vk::debug_switch_set(name, value);
+    return r < 0 ? -1 : r;
 }
 
 // Verification entry (vk_debug.h): the mode kernel of the WINDOW PIPELINE -- k_pose_mode<REFIT,512>, the packed-pair mean shift

@@ -60,11 +60,6 @@ struct PoseBlock {
     float cumT[MAX_FRAMES][4];
     float dpM[MAX_DISP_FRAMES][9];
     float dpT[MAX_DISP_FRAMES][4];
-#ifdef VK_PK_GEOM
-    // (experiment, off by default: see lean_step) cumM / cumT of a frame once more, laid out for packed fp32: the x and y rows of the map side
-    // by side -- { M0, M3,  M1, M4,  M2, M5,  T0, T1,  M6, M7, M8, T2 } -- so that a scalar load leaves each pair in an aligned SGPR pair
-    __attribute__((aligned(16))) float cumP[MAX_FRAMES][12];
-#endif
 };
 
 // Per-camera state kept on the device (voldor/utils.h:31-45 Camera, minus OpenCV).
@@ -118,6 +113,7 @@ struct ImageSet {
     int w = 0, h = 0;
     DevBuf flows;   // [N][h][w] float2
     DevBuf rig;     // [N][h][w]
+    DevBuf rig2;    // window pipeline, round 5: the other half of the rigidness ping-pong (fb_smooth writes rig -> rig2 on the second stream while the pose half still reads rig; the E-step then writes rig2 and the two swap)
     DevBuf depth;   // [h][w]
     DevBuf cost;    // [h][w]
     DevBuf priors, pconfs, confs;  // [N_dp][h][w]
@@ -146,6 +142,7 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
     bool fb_smooth = true;
     float s0_ems_prob = 0.5f, no_change_prob = 0.9f, range_factor = 1.f;
     bool update_rigidness_only = false;
+    bool fb_done = false;  // the caller has already smoothed the rigidness / prior-confidence maps of this call (window pipeline: on the second stream, next to the pose half)
     bool strict = false;  // strict-math mode: reference-order arithmetic on vk_strict_math.h (vk_strict.hip)
     // reference mode, round 4 (vk_ref_cuda.h; strict kernels only): cuRAND XORWOW streams for the depth samples / CUDA's 8-bit-fraction
     // linear filter over the stacked layers for every at_tex of the reference (D1 / D2 switched off)
@@ -164,6 +161,10 @@ struct ProfEntry { double ms = 0; long count = 0; };
 struct Context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // window pipeline: work that does not depend on this iteration's poses (fb_smooth of the rigidness maps) next to the pose half
+    hipEvent_t ev_estep = nullptr, ev_fb = nullptr;  // "the E-step's maps are written" (stream -> stream2), "the smoothed maps are there" (stream2 -> stream)
+    hipEvent_t ev4 = nullptr, ev5 = nullptr;         // profiling scope on stream2
+    bool is_pool = false;           // one of the extra contexts of vk_voldor_device_batch (windows in flight next to each other)
     // B-inner keeps the reference's two independent caches (optimize_depth.cu vs
     // collect_p3p_instances.cu statics); the B-outer pipeline uses `od` for everything.
     ImageSet od, cp;
@@ -182,8 +183,6 @@ struct Context {
     DevBuf tmp;                   // misc scratch (gblur, depth_conf ...)
     DevBuf fb_scratch;            // strict fb_smooth: forward messages [n_maps][h][w]
     DevBuf stale_depth;           // --reference_stale_depth 1: optimize_depth.cu's own device copy of the depth map (OdParams::stale_depth)
-    DevBuf ticket;                // k_solve_mode: the counter its workgroups draw tickets from (only grows; ticket_base = its value before the launch)
-    unsigned ticket_base = 0;
     DevBuf sp_coop;               // strict mode kernel, cooperative form: block sums, pool size and the grid barrier's counter (vk_strict.hip CoopGlobal)
     bool strict = false;          // strict-math mode of the B-inner entry points that use this context (vk_set_strict_math)
     // --reference_rng 1: the jump matrices T^(2^67 2^k) (vk_ref_cuda.h), the per-pixel XORWOW states of the depth samples

@@ -19,15 +19,6 @@ extern "C" {
  *                             barrier per sum) or ONE 512-thread workgroup; the same bits
  *   "strict_plain"    0 | 1   1: strict mode on the plain launch structures (one lane per chain / line, one 256-thread workgroup walking the
  *                             reference's sum tree block by block) instead of the parallel structures -- both give the same bits
- *   "local_fused"     0 | 8 | 16   8 / 16: the four local passes of a call as ONE launch over 32 x 32 tiles with that many waves per tile (local_prop_width 32);
- *                             0: one launch per pass.  Identical maps either way; measured SLOWER at every size (cfg2 3.90 -> 4.05 ms per window,
- *                             cfg5 28.5 -> 31.9 / 37.5 ms) and not adopted
- *   "newton_cap"      0 | even <= 50   Newton steps of the P3P cubic in the fast window pipeline (0 = the reference's 50).  A cap of 12 saves 0.13 ms of a
- *                             3.9 ms window and was NOT adopted: over 72 windows it halves the fraction of confident pixels within 1e-3 of the reference
- *                             (0.32 against the reference's own 0.64) -- the ~1.4 % of cubics that are still moving after 12 steps re-draw the pool
- *   fuse_solve_mode   0 | 1   (experiment, default 0) fast window pipeline: the P3P batch and the mode kernel of a camera as ONE launch (k_solve_mode:
- *                              512-thread workgroups, four waves solve, the workgroup that draws the last ticket goes on as the mode kernel); identical
- *                              results; measured: 30.9 us per launch against 17.6 + 13.8, the window 3.91 ms either way
  * Returns the previous value, -1 for an unknown name / value. */
 int vk_debug_switch(const char* name, int value);
 /* The mode kernel of the window pipeline (k_pose_mode: packed-pair mean shift; with do_rg the robust-Gaussian refit on the same registers --

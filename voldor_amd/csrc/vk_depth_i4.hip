@@ -1,0 +1,5 @@
+// vk_depth_i4.hip -- optimize_depth_launch<4, false> and its kernels (vk_depth_impl.hpp): one translation unit per frame bound
+#include "vk_depth_impl.hpp"
+namespace vk {
+template int optimize_depth_launch<4, false>(Context* c, ImageSet& S, const OdParams& p, bool cost_only);
+}

@@ -125,18 +125,9 @@ __device__ __forceinline__ float2 bilinear2_inside(const float2* __restrict__ im
     const unsigned off = (unsigned)(__mul24(yb, w) + xb) * 8u;  // v_mad_i32_i24: full rate (a 32-bit integer multiply issues at a quarter of it); rows and widths are far below 2^23
     const TexPair r0 = *reinterpret_cast<const TexPair*>(base + off);
     const TexPair r1 = *reinterpret_cast<const TexPair*>(base + off + (unsigned)w * 8u);
-#ifdef VK_PK_BILINEAR
-    // (experiment, off by default: measured and rejected, see lean_step in vk_depth.hip) the two flow components of a texel as one packed operand
-    const vf2 a0 = { r0.ax, r0.ay }, b0 = { r0.bx, r0.by }, a1 = { r1.ax, r1.ay }, b1 = { r1.bx, r1.by };
-    const vf2 aa = { a, a }, bb = { b, b };
-    const vf2 t = __builtin_elementwise_fma(aa, b0 - a0, a0), u = __builtin_elementwise_fma(aa, b1 - a1, a1);
-    const vf2 r = __builtin_elementwise_fma(bb, u - t, t);
-    return make_float2(r.x, r.y);
-#else
     const float tx = fmaf(a, r0.bx - r0.ax, r0.ax), ty = fmaf(a, r0.by - r0.ay, r0.ay);
     const float ux = fmaf(a, r1.bx - r1.ax, r1.ax), uy = fmaf(a, r1.by - r1.ay, r1.ay);
     return make_float2(fmaf(b, ux - tx, tx), fmaf(b, uy - ty, ty));
-#endif
 }
 // homogeneous pixel of (x, y, d) under one projective map (PoseBlock::cumM / cumT)
 struct H3 { float x, y, z; };

@@ -27,12 +27,13 @@ struct DebugSwitches {
     int global_split = 1;      // 0: global propagation with one lane per site
     int refit_partition = 1;   // 0: every gate pass of the refit walks the whole pool in its arrival order
     int split_trials = 1;      // 0: the mode kernel runs the initial-mode trials itself
-    int local_fused = 0;       // (experiment, measured and NOT adopted: DESIGN.md section 6) 8 / 16: the four local passes of a call as ONE launch over 32 x 32 tiles with that many waves per tile; 0: one launch per pass
-    int newton_cap = 0;        // (experiment, measured and NOT adopted: DESIGN.md section 6) Newton steps of the P3P cubic in the FAST window pipeline: 0 = the reference's 50; an even cap <= 50 otherwise; strict mode always 50
-    int strict_own_table = 0;  // (tuning) strict local pass: 1 = every chain tabulates its own steps at the head of the runs kernel, 0 = the tiled table kernel
-    int strict_lpp8 = 0;       // (tuning) strict local pass: 8 lanes per pixel instead of 4 for up to 8 frames
     int strict_pose_coop = 1;  // strict mode kernel on one single-wave workgroup per 512-row block of the pool (16 compute units) instead of one 512-thread workgroup; same bits
-    int fuse_solve_mode = 0;   // (experiment, measured and NOT adopted: DESIGN.md section 6) 1: P3P batch and mode kernel of a camera as ONE launch (k_solve_mode: the workgroup that stores the last hypotheses goes on as the mode kernel); same bits, no time gained
+    // round 5
+    int pose_persist = 1;      // 0: the pose half of an EM iteration as one launch per stage and camera (collect, P3P batch, mode) instead of the persistent kernel k_pose_persist (same bits)
+    int fb_overlap = 1;        // 0: fb_smooth of the rigidness maps in place on the window's stream (rounds 1-4) instead of out of place on a second stream, next to the pose half (same bits)
+    int solve_fp32 = 1;        // 0: the fast window pipeline's P3P batch in the reference's mixed fp32 / fp64 rounding sequence (rounds 1-4; what strict mode and the host-pointer API always run) instead of plain fp32
+    int local_table4 = 1;      // 0: one table sweep per local-propagation direction (rounds 2-4) instead of one sweep for the four directions + dirty-entry repair (same bits)
+    int strict_coop_max_polls = 0;  // > 0: the cooperative strict mode kernel gives up a meeting after this many polls (tests force the give-up path); 0: 2^22
     int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
 };
 DebugSwitches& debug_switches();  // vk_abi.hip
@@ -69,7 +70,8 @@ __device__ __forceinline__ void maybe_decide(const ModeParams& mp, PoseBlock* P,
 int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p);
 int cost_map_device(Context* c, ImageSet& S, const OdParams& p);
 int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr,
-                     PoseBlock* cumP = nullptr, int cumN = 0, int cumNdp = 0, float* world_scale = nullptr);
+                     PoseBlock* cumP = nullptr, int cumN = 0, int cumNdp = 0, float* world_scale = nullptr, float* dst = nullptr, hipStream_t st = nullptr);
+bool fb_smooth_segmented(int w, int h);  // the segmented kernels take this size (else: the step-by-step fallback, in place on the context's stream only)
 // vk_strict.hip
 int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr);
 int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
@@ -95,10 +97,6 @@ int xorwow_jumps_device(Context* c);                              // c->xw_jumps
 int xorwow_pixel_states_device(Context* c, int npx, uint32_t epoch);  // c->xw_px_states = states `epoch` draws after curand_init(RAND_SEED, pixel, 0)
 int xorwow_pose_states_device(Context* c, int n_poses);           // c->xw_pose_states = states after curand_init(RAND_SEED, idx, 0)
 int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first = false);
-// k_solve + k_pose_mode in one launch (fast mode, index draw over block-compacted correspondences, no initial-mode trials); returns -1 when the
-// combination is not available for this call (the caller then issues the two launches)
-int solve_mode_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev, bool ref_svd,
-                                const ModeParams& mp, PoseBlock* P, int cam_idx);
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 

@@ -60,14 +60,11 @@ template <typename S> VK_HD __forceinline__ bool root2real(S b, S c, S& r1, S& r
 }
 
 // One real root of x^3 + b x^2 + c x + d with the steepest derivative (solve_cubic.h:154-210)
-// newton_steps: the reference runs up to 50 Newton steps and leaves early only on |f| <= 1e-7 (float), a threshold most cubics never
-// meet in float arithmetic although the iterate has long stopped moving (measured on 640x480 pools: 89 % of the hypotheses run all 50
-// steps; 70 % sit on a fixed point, 17 % on a two-cycle of neighbouring floats).  Every mode runs the reference's 50.  An even cap
-// (vk_debug_switch "newton_cap") gives the bits of the 50-step loop wherever a fixed point or a two-cycle is reached by then; the ~1.4 % of
-// cubics still wandering (near-double roots) end a few ulps away -- measured with a cap of 12 in the fast pipeline: k_solve 17.6 -> 14.4 us,
-// window 3.90 -> 3.77 ms, and over 72 windows the depth maps leave the reference's self-noise (fraction of confident pixels within 1e-3:
-// 0.32 against 0.64; paired ratio of means 0.71-1.14 against the 0.8 margin): not adopted (tests/test_gpu_ensemble.py arbitrates).
-template <typename S> VK_HD __forceinline__ S cubic_root(S b, S c, S d, int newton_steps = 50) {
+// The reference runs up to 50 Newton steps and leaves early only on |f| <= 1e-7 (float), a threshold most cubics never meet in float
+// arithmetic although the iterate has long stopped moving (measured on 640x480 pools: 89 % of the hypotheses run all 50 steps; 70 % sit on
+// a fixed point, 17 % on a two-cycle of neighbouring floats).  Every mode runs the reference's 50: a cap of 12 steps was measured in round 4
+// (k_solve 17.6 -> 14.4 us) and fails the ensemble test -- the ~1.4 % of cubics still wandering near a double root re-draw the pool.
+template <typename S> VK_HD __forceinline__ S cubic_root(S b, S c, S d) {
 #pragma clang fp contract(off)
     S r0;
     if (b * b >= 3.0 * c) {
@@ -86,7 +83,7 @@ template <typename S> VK_HD __forceinline__ S cubic_root(S b, S c, S d, int newt
     }
     const S lim = sizeof(S) == 4 ? S(1e-7) : S(1e-13);  // get_numeric_limit<T>() (solve_cubic.h:87-108)
 #pragma unroll 1
-    for (int cnt = 0; cnt < newton_steps; ++cnt) {
+    for (int cnt = 0; cnt < 50; ++cnt) {
         S fx = (((r0 + b) * r0 + c) * r0 + d);
         if (cnt < 7 || vk_abs(fx) > lim) {
             S fpx = ((S(3.0) * r0 + S(2.0) * b) * r0 + c);
@@ -210,8 +207,7 @@ VK_HD __forceinline__ void consider(BestPose<S>& B, V3<S> L, S a12, S a13, S a23
 template <typename S>
 VK_HD static bool lambdatwist_p4p(const float* yu, const float* yv, const float (*xp)[3], float fxf, float fyf,
                                        float cxf, float cyf, float* Rout, float* tout, int only = -1, S* err_out = nullptr,
-                                       S* dbg = nullptr /* tests only: intermediate values of the sequential path (tests/cxx/vk_testhooks.hip) */,
-                                       int newton_steps = 50 /* cubic_root */) {
+                                       S* dbg = nullptr /* tests only: intermediate values of the sequential path (tests/cxx/vk_testhooks.hip) */) {
 #pragma clang fp contract(off)
     // bearings are formed in float and then widened (lambdatwist_p4p.h:13-15)
     V3<S> y1 = normalized<S>({ (S)((yu[0] - cxf) / fxf), (S)((yv[0] - cyf) / fyf), S(1.0) });
@@ -231,7 +227,7 @@ VK_HD static bool lambdatwist_p4p(const float* yu, const float* yv, const float 
     S p0 = a12 * (a12 * s23 - a23 * s12);
     p3 = 1.0 / p3;
     p2 *= p3; p1 *= p3; p0 *= p3;
-    S g = cubic_root<S>(p2, p1, p0, newton_steps);
+    S g = cubic_root<S>(p2, p1, p0);
 
     S A[9];
     A[0] = a23 * (1.0 - g); A[1] = (a23 * b12) * 0.5; A[2] = (a23 * b13 * g) * (-0.5);

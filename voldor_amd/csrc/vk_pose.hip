@@ -15,6 +15,7 @@
 #include "vk_common.hpp"
 #include "vk_device.hpp"
 #include "vk_p3p.hpp"
+#include "vk_p3p_fast.hpp"
 #include "vk_ref_svd.h"
 #include "vk_lu.hpp"
 #include "vk_ref_cuda.h"
@@ -201,13 +202,7 @@ __device__ __forceinline__ float draw_uniform(const vrc_xorwow* __restrict__ xw,
 }
 constexpr int DRAW_MAX_TRIES = 256;
 constexpr int DRAW_RANK_INV_DENSITY = 20;  // rank select below 5 % valid pixels (rejection then needs > 90 tries for 1 % of the points)
-// NW: waves per workgroup.  1 = the stand-alone kernel k_solve (one wave per workgroup); PM_THREADS / 64 = inside k_solve_mode, whose last
-// workgroup goes on with the mode kernel's work (below): every wave is what a one-wave workgroup was, the prefix of the block counts is
-// built once per workgroup by wave 0.
-// NWS (<= NW): the waves of a workgroup that solve.  The P3P chain of a wave is bound by its own instruction issue, so two such waves on one SIMD
-// take nearly twice as long: k_solve_mode lets waves 0 .. 3 of its eight solve (one per SIMD, as in the stand-alone kernel) and parks the others at
-// the barrier (measured with all eight solving: 33.8 us against 17.6 + 13.8 for the two launches).
-template <int SOLVER, bool FROM_MAP, int NW, int NWS = NW>  // SOLVER: 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>
+template <int SOLVER, bool FROM_MAP, bool FAST = false>  // SOLVER: 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>; FAST (SOLVER 0, fast window pipeline): plain fp32 (vk_p3p_fast.hpp)
 __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2, const float* __restrict__ pts3,
                                                       float* __restrict__ rvecs, float* __restrict__ tvecs,
                                                       int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk,
@@ -215,7 +210,6 @@ __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2
                                                       int draw /* 0 auto, 1 rank select (reference draw), -1 rejection only */, int strict /* bit 0: strict math, bit 1: reference SVD, bit 2: block-compacted correspondences (with draw 1) */,
                                                       const int* __restrict__ blk_offsets /* exclusive prefix of blk_counts in global memory when it does not fit the LDS, else null */,
                                                       const unsigned long long* __restrict__ valid_mask /* k_collect's bit per pixel (FROM_MAP) */,
-                                                      int newton_steps /* cubic_root (vk_p3p.hpp): 50 = the reference's loop */,
                                                       const vrc_xorwow* __restrict__ xw /* --reference_rng 1: states after curand_init(RAND_SEED, idx, 0), else null */) {
     // LambdaTwist: four lanes per hypothesis, one candidate root each (the candidates are independent once the
     // shared cubic / eigen-decomposition is done; a lane per hypothesis walks them one after the other and the wave
@@ -223,12 +217,8 @@ __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2
     PH_DECL;
     constexpr int LPH = (SOLVER == 1) ? 1 : 4;
     extern __shared__ int s_pref[];  // FROM_MAP: inclusive prefix of blk_counts (rank select only)
-    const int ln = threadIdx.x & 63, wvi = threadIdx.x >> 6;
-    const int gtid = (blockIdx.x * NWS + wvi) * 64 + ln, idx = gtid / LPH, sub = gtid % LPH;
-    if (NWS < NW && wvi >= NWS) {  // parked wave (k_solve_mode: index draw, prefix in the LDS): it only keeps the workgroup's one barrier company
-        __syncthreads();
-        return;
-    }
+    const int ln = threadIdx.x & 63;
+    const int gtid = blockIdx.x * 64 + ln, idx = gtid / LPH, sub = gtid % LPH;
     // FROM_MAP: the first batch of rejection probes does not depend on the number of correspondences, so its reads are in flight
     // together with those of the per-block counts (one memory round trip instead of two at the head of the kernel)
     constexpr int DRAW_BATCH = 4;
@@ -276,12 +266,8 @@ __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2
     };
     if (FROM_MAP) {
         if (draw > 0 && !blk_offsets) {  // the reference's draw (default): the prefix is needed anyway, its last entry is the count
-            if (NW == 1) { n_pts = prefix_to_lds(); __syncthreads(); }
-            else {  // one wave builds it for the workgroup
-                if (wvi == 0) (void)prefix_to_lds();
-                __syncthreads();
-                n_pts = nblk > 0 ? s_pref[pref_at(nblk - 1)] : 0;
-            }
+            n_pts = prefix_to_lds();
+            __syncthreads();
         } else {
             // number of valid correspondences = sum of k_collect's per-workgroup counts; every wave adds them up itself
             // (a few coalesced loads) instead of a separate single-workgroup launch between collect and solve
@@ -303,7 +289,7 @@ __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2
     PH_MARK(8);
     const bool rank_draw = FROM_MAP && n_pts >= 4 && (draw > 0 || (draw == 0 && (long long)n_pts * DRAW_RANK_INV_DENSITY < (long long)npx));
     if (rank_draw && !blk_offsets && draw <= 0) {  // D3b's low-density fallback: uniform over the workgroup (n_pts is)
-        if (NW == 1 || wvi == 0) (void)prefix_to_lds();
+        (void)prefix_to_lds();
         __syncthreads();
     }
     if (idx >= n_poses) return;
@@ -434,8 +420,9 @@ __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2
 #endif
         PH_MARK(10);
         if (drawn) {
-            if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf, nullptr, newton_steps);
-            else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errd, nullptr, newton_steps);
+            if (SOLVER == 0 && FAST) ok = p3pf::lambdatwist_candidate(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf);
+            else if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf);
+            else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errd);
             else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t, (strict & 1) != 0);
         }
     }
@@ -443,7 +430,7 @@ __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2
     float aa[3] = { qnan, qnan, qnan };
     if (ok) {
         // rodrigues.h:82-114.  Default: the exact polar factor (D8); --reference_svd 1: U V^T of the reference's approximate SVD, bit for bit
-        if (strict & 2) vrs_project_rotation(R); else nearest_rotation(R);
+        if (strict & 2) vrs_project_rotation(R); else if (FAST) p3pf::nearest_rotation(R); else nearest_rotation(R);
         rotmat_to_angle_axis(R, aa, (strict & 1) != 0);
     }
     PH_MARK(12);
@@ -473,13 +460,12 @@ __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2
     }
     PH_MARK(13); PH_ADD(14, 1);
 }
-template <int SOLVER, bool FROM_MAP>
+template <int SOLVER, bool FROM_MAP, bool FAST = false>
 __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ pts2, const float* __restrict__ pts3, float* __restrict__ rvecs, float* __restrict__ tvecs,
                                                       int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk, CamState* cam, int npx, float fx, float fy,
                                                       float cx, float cy, int n_poses, int draw, int strict, const int* __restrict__ blk_offsets,
-                                                      const unsigned long long* __restrict__ valid_mask, int newton_steps, const vrc_xorwow* __restrict__ xw) {
-    solve_body<SOLVER, FROM_MAP, 1>(pts2, pts3, rvecs, tvecs, n_pts_dev, blk_counts, nblk, cam, npx, fx, fy, cx, cy, n_poses, draw, strict, blk_offsets, valid_mask,
-                                    newton_steps, xw);
+                                                      const unsigned long long* __restrict__ valid_mask, const vrc_xorwow* __restrict__ xw) {
+    solve_body<SOLVER, FROM_MAP, FAST>(pts2, pts3, rvecs, tvecs, n_pts_dev, blk_counts, nblk, cam, npx, fx, fy, cx, cy, n_poses, draw, strict, blk_offsets, valid_mask, xw);
 }
 
 // ---- single-workgroup mode finding ---------------------------------------------------------------
@@ -1438,36 +1424,6 @@ __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __res
                                                                   PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
     pose_mode_body<DEFER, THREADS>(rvecs, tvecs, n_poses, mp, cam, P, cam_idx, n_points_dev, trials_in);
 }
-// k_solve + k_pose_mode in ONE launch (round 4): PM_THREADS-thread workgroups, every wave a group of hypotheses as in k_solve; a workgroup that has
-// stored its part of the pool takes a ticket, and the workgroup that draws the LAST ticket -- all 8192 hypotheses are in memory -- goes on as the
-// mode kernel.  Nobody waits for anybody (no spinning, nothing to deadlock); one launch boundary per camera less: the mode kernel's dispatch,
-// its wave launch and the gap before it (~3-4 us of a 14 us kernel).  The pool still goes through memory (it is produced by 512 waves on other
-// compute units).  Release: the stores of a workgroup are ordered before its ticket by the barrier + agent-scope fence of thread 0; acquire: the
-// last workgroup invalidates before it reads the pool.  Same results as the two launches, bit for bit (tests/test_gpu_kernels.py).
-// MEASURED AND NOT ADOPTED (debug switch `fuse_solve_mode`, default 0): 30.9 us per launch against 17.6 + 13.8 us for the two kernels, and the
-// window takes 3.91 ms either way (cfg3 6.98 against 6.94, cfg5 equal): the ticket's round trip, the two fences and the pool arriving from
-// memory instead of the second kernel's fresh L2 cost what the dispatch cost.
-constexpr int SM_SOLVE_WAVES = 4;  // solving waves per workgroup of k_solve_mode: one per SIMD
-template <int SOLVER, bool DEFER>
-__global__ __launch_bounds__(PM_THREADS) static void k_solve_mode(const float* __restrict__ pts2, const float* __restrict__ pts3, float* __restrict__ rvecs, float* __restrict__ tvecs,
-                                                                   int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk, CamState* cam, int npx, float fx,
-                                                                   float fy, float cx, float cy, int n_poses, int draw, int strict, const unsigned long long* __restrict__ valid_mask,
-                                                                   int newton_steps, ModeParams mp, PoseBlock* P, int cam_idx, unsigned* __restrict__ ticket, unsigned ticket_base) {
-    solve_body<SOLVER, true, PM_THREADS / 64, SM_SOLVE_WAVES>(pts2, pts3, rvecs, tvecs, n_pts_dev, blk_counts, nblk, cam, npx, fx, fy, cx, cy, n_poses, draw, strict, nullptr, valid_mask,
-                                              newton_steps, nullptr);
-    __shared__ int s_last;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = (t - ticket_base) == gridDim.x - 1u ? 1 : 0;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    pose_mode_body<DEFER, PM_THREADS>(rvecs, tvecs, n_poses, mp, cam, P, cam_idx, n_pts_dev, nullptr);
-}
-
 // The initial-mode trials of a camera that has no pose yet (first EM iteration; meanshift.cu:72-95: the kernel density at up to
 // max_init_trials random hypotheses, the densest one starts the mean shift) are independent of one another and each is a full pass
 // over the pool: inside the single-workgroup mode kernel they cost 20 passes on one compute unit (~33 us).  Here trial b is
@@ -1662,13 +1618,12 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
     }
     const int st = (strict ? 1 : 0) | (ref_svd ? 2 : 0) | ((FROM_MAP && c->maps_block_compact) ? 4 : 0);
     const unsigned long long* vm = FROM_MAP ? c->valid_mask.as<unsigned long long>() : nullptr;
-    // Newton steps of the cubic (vk_p3p.hpp cubic_root): the reference's 50 in strict mode and behind the host-pointer API (whose translations are
-    // held to the reference kernel's bits); an even cap in the fast window pipeline
-    const int cap = debug_switches().newton_cap;
-    const int ns = (FROM_MAP && !strict && cap > 0) ? cap : 50;
-    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns, xw);
-    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns, xw);
-    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, ns, xw);
+    // fast window pipeline, float LambdaTwist: plain fp32 (vk_p3p_fast.hpp); strict mode and the host-pointer API keep the reference's rounding sequence
+    if (solver == 0 && FROM_MAP && !strict && !ref_rng && debug_switches().solve_fp32)
+        hipLaunchKernelGGL((k_solve<0, FROM_MAP, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, xw);
+    else if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, xw);
+    else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, xw);
+    else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, xw);
     VK_CHECK_LAST();
     return 0;
 }
@@ -1746,39 +1701,6 @@ int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState*
     else
         hipLaunchKernelGGL((k_pose_mode<false, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
                            mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials);
-    VK_CHECK_LAST();
-    return 0;
-}
-
-int solve_mode_from_maps_device(Context* c, int npx, float fx, float fy, float cx, float cy, int n_poses, int solver, CamState* cam_dev, bool ref_svd,
-                                const ModeParams& mp_in, PoseBlock* P, int cam_idx) {
-    if (!debug_switches().fuse_solve_mode || !c->maps_block_compact || n_poses > PM_POOL || solver == 1) return -1;
-    const int nb = c->n_map_blocks;
-    const size_t lds = sizeof(int) * ((size_t)nb + nb / 32 + 1);  // the prefix of the block counts (pref_at() in solve_body)
-    // the refit variant carries 141 KB of static LDS (refit_partition's staging planes): the prefix has to fit next to it
-    if (lds > (mp_in.do_rg ? (size_t)14 * 1024 : (size_t)60 * 1024)) return -1;
-    ModeParams mp = mp_in;
-    mp.rg_partition = debug_switches().refit_partition;
-    if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
-    if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
-    if (!c->ticket.p) {
-        if (int e = c->ticket.reserve(sizeof(unsigned))) return e;
-        VK_CHECK(hipMemsetAsync(c->ticket.p, 0, sizeof(unsigned), c->stream));
-        c->ticket_base = 0;
-    }
-    const dim3 g((n_poses * 4 + SM_SOLVE_WAVES * 64 - 1) / (SM_SOLVE_WAVES * 64)), b(PM_THREADS);
-    const int st = (ref_svd ? 2 : 0) | 4;
-    const int cap = debug_switches().newton_cap, ns = cap > 0 ? cap : 50;
-    float* rv = c->rvecs.as<float>(); float* tv = c->tvecs.as<float>();
-    const float* p2 = c->p2_map.as<float>(); const float* p3 = c->p3_map.as<float>();
-    int* npd = c->n_points.as<int>(); const int* bc = c->blk_counts.as<int>();
-    const unsigned long long* vm = c->valid_mask.as<unsigned long long>();
-    unsigned* tk = c->ticket.as<unsigned>();
-#define VK_LAUNCH_SM(S, D) hipLaunchKernelGGL((k_solve_mode<S, D>), g, b, lds, c->stream, p2, p3, rv, tv, npd, bc, nb, cam_dev, npx, fx, fy, cx, cy, n_poses, 1, st, vm, ns, mp, P, cam_idx, tk, c->ticket_base)
-    if (solver == 0) { if (mp.do_rg) VK_LAUNCH_SM(0, true); else VK_LAUNCH_SM(0, false); }
-    else { if (mp.do_rg) VK_LAUNCH_SM(2, true); else VK_LAUNCH_SM(2, false); }
-#undef VK_LAUNCH_SM
-    c->ticket_base += g.x;
     VK_CHECK_LAST();
     return 0;
 }

@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <utility>
 #include <vector>
 
 namespace vk {
@@ -139,11 +140,13 @@ struct Voldor {
         }
         ImageSet& S = c->od;
         hipStream_t st = c->stream;
+        VK_CHECK(hipStreamWaitEvent(st, c->ev_fb, 0));  // (a window that ended on an error may have left work on the second stream)
         const size_t npx = (size_t)w * h;
         S.w = w; S.h = h;
         if (int e = S.ensure_pose()) return e;
         if (int e = S.flows.reserve(sizeof(float) * 2 * npx * N)) return e;
         if (int e = S.rig.reserve(sizeof(float) * npx * N)) return e;
+        if (int e = S.rig2.reserve(sizeof(float) * npx * N)) return e;
         if (int e = S.depth.reserve(sizeof(float) * npx)) return e;
         if (int e = S.cost.reserve(sizeof(float) * npx)) return e;
         if (int e = c->cams.reserve(sizeof(CamState) * MAX_FRAMES)) return e;
@@ -187,13 +190,36 @@ struct Voldor {
             VK_CHECK(hipMemcpyAsync(S.depth.p, S.priors.p, sizeof(float) * npx, hipMemcpyDeviceToDevice, st));
             if (!disparity) { if (int e = optimize_depth(OD_ONLY_USE_DEPTH_PRIOR)) return e; }
         } else if (int e = fill_device(c, S.depth.as<float>(), 1.f, npx)) return e;
+        VK_CHECK(hipEventRecord(c->ev_estep, st));  // the rigidness / prior-confidence maps the first fb_smooth reads are enqueued
+        return 0;
+    }
+
+    // Round 5: fb_smooth of an EM iteration's depth half (optimize_depth.cu:462-466) reads what the previous E-step wrote and nothing of this
+    // iteration's poses, and the pose half in front of it keeps one compute unit in 256 busy: the two launches run on the context's second
+    // stream NEXT TO the pose half.  The pose half still reads the unsmoothed rigidness maps (collect_p3p_instances.cu:84-100), so the row pass
+    // writes the other buffer of a ping-pong (rig -> rig2, the column pass in place on rig2), the depth half works on rig2, its E-step writes
+    // rig2, and the two swap.  The prior-confidence maps are not read by the pose half: smoothed in place.  Same kernels, same values, same
+    // bits as the in-place order (vk_debug_switch "fb_overlap" = 0; tests/test_gpu_kernels.py).  Every map of the frames still registered is
+    // smoothed: a frame this iteration's decision drops is never read again.
+    bool fb_overlap_ok() const {
+        return !strict && !c->is_pool && cfg.optimize_depth && cfg.fb_smooth && debug_switches().fb_overlap && fb_smooth_segmented(w, h) && n_flows > 0;  // (windows in flight fill the chip with each other's kernels: nothing to gain, and twice the streams)
+    }
+    int enqueue_fb_overlap() {
+        ImageSet& S = c->od;
+        VK_CHECK(hipStreamWaitEvent(c->stream2, c->ev_estep, 0));
+        if (c->prof) VK_CHECK(hipEventRecord(c->ev4, c->stream2));
+        if (int e = fb_smooth_device(c, S.rig.as<float>(), n_flows, w, h, cfg.fb_emm, cfg.fb_no_change_prob, nullptr, nullptr, 0, 0, nullptr, S.rig2.as<float>(), c->stream2)) return e;
+        if (int e = fb_smooth_device(c, S.confs.as<float>(), n_dp, w, h, cfg.fb_emm, cfg.fb_no_change_prob, nullptr, nullptr, 0, 0, nullptr, nullptr, c->stream2)) return e;
+        if (c->prof) VK_CHECK(hipEventRecord(c->ev5, c->stream2));
+        VK_CHECK(hipEventRecord(c->ev_fb, c->stream2));
         return 0;
     }
 
     // voldor.cpp:203-307 (the upload / "minimal cache" branches collapse: everything is resident)
-    int optimize_depth(OdFlag flag, bool with_world_scale = false) {
+    int optimize_depth(OdFlag flag, bool with_world_scale = false, bool fb_done = false) {
         if (n_flows == 0 && n_dp == 0) return 0;
         OdParams p;
+        p.fb_done = fb_done;
         p.abs_resize_factor = cfg.abs_resize_factor;
         p.N = (flag == OD_ONLY_USE_DEPTH_PRIOR) ? 0 : n_flows; p.N_dp = n_dp; p.w = w; p.h = h; p.basefocal = cfg.basefocal;
         p.n_rand_samples = cfg.depth_rand_samples; p.global_prop_step = cfg.depth_global_prop_step; p.local_prop_width = cfg.depth_local_prop_width;
@@ -210,7 +236,21 @@ struct Voldor {
             if (int e = c->ms_io.reserve(sizeof(float) * 64 + sizeof(int) * 4)) return e;
             p.world_scale_out = c->ms_io.as<float>() + 48;
         }
-        return optimize_depth_device(c, c->od, p);  // with world_scale_out: depth and poses leave normalised (voldor.cpp:309-317)
+        if (fb_done) {  // the smoothed maps are in the other buffer (enqueue_fb_overlap): the depth half works there
+            if (c->prof) {  // what the two launches took on their own stream (they ran next to the pose half: not part of the depth half's critical path)
+                VK_CHECK(hipEventSynchronize(c->ev5));
+                float ms = 0.f;
+                VK_CHECK(hipEventElapsedTime(&ms, c->ev4, c->ev5));
+                ProfEntry& pe = c->prof_acc["fb_smooth_overlapped"];
+                pe.ms += ms; pe.count += 1;
+            }
+            VK_CHECK(hipStreamWaitEvent(c->stream, c->ev_fb, 0));
+            std::swap(c->od.rig, c->od.rig2);
+        }
+        const int e = optimize_depth_device(c, c->od, p);  // with world_scale_out: depth and poses leave normalised (voldor.cpp:309-317)
+        if (e) return e;
+        VK_CHECK(hipEventRecord(c->ev_estep, c->stream));
+        return 0;
     }
 
     // voldor/geometry.cpp:5-265, all on the device; success / density come back in CamState
@@ -235,11 +275,6 @@ struct Voldor {
             mp.decide_n = n_flows; mp.decide_allow_trunc = iters_cur > cfg.no_trunc_iters ? 1 : 0;
             mp.decide_trunc_rigidness_density = cfg.trunc_rigidness_density; mp.decide_trunc_sample_density = cfg.trunc_sample_density;
             mp.host_brief = c->h_brief_dev;
-        }
-        // fast mode, a camera that already has a pose (no initial-mode trials between the two), the index draw: P3P batch and mode kernel in ONE launch
-        if (!strict && !ref_rng && cfg.reference_draw && hcams[i].pose_sample_count != 0) {
-            const int e = solve_mode_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i, ref_svd, mp, S.pb(), i);
-            if (e >= 0) { if (e) return e; if (c->prof) prof_end(c, "optimize_camera_pose"); return 0; }
         }
         if (int e = solve_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i,
                                            cfg.reference_draw ? 1 : 0, strict, ref_svd, ref_rng))
@@ -306,9 +341,11 @@ struct Voldor {
         }
         while (iters_remain > 0 && n_flows > 0) {
             iters_cur++; iters_remain--;
+            const bool fb_ov = fb_overlap_ok();
+            if (fb_ov) { if (int e = enqueue_fb_overlap()) return e; }
             if (int e = enqueue_cameras()) return e;
             // the depth half is enqueued with the pre-decision frame count; on the device it runs with n_active
-            if (int e = optimize_depth(cfg.optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY, cfg.norm_world_scale && n_dp == 0)) return e;
+            if (int e = optimize_depth(cfg.optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY, cfg.norm_world_scale && n_dp == 0, fb_ov)) return e;
             if (int e = finish_cameras()) return e;
         }
         return 0;
