@@ -29,7 +29,10 @@ Extra objects in the line:
   cpu_baseline the oracle (C restatement of the reference path, OpenMP) timed on this box's host
                cores on the same workload, a bounded number of windows (rank 0, N=1 only).
   cpu_reference  the reference's own code on one host core (oracle/_ref: voldor/*.cpp + gpu-kernels/*.cu compiled for the
-               CPU, BASELINE configs[0] "--cpu_p3p 1"), 2 of the 8 EM iterations of one window, scaled.
+               CPU, BASELINE configs[0] "--cpu_p3p 1"), one whole window.
+  workloads    (default run only) BASELINE configs[2] (cfg3) and configs[4] (cfg5), time-bounded: window time, the optimize_depth
+               group against the roofline, the reference-mode window.
+  value_host_inclusive  = host_inclusive.value at the top level: SURVEY 8(d)'s own frame next to `value` (inputs resident in HBM).
 """
 from __future__ import annotations
 
@@ -94,6 +97,7 @@ def main():
                     help="capi: the exchange below the C-ABI (vk_voldor_sharded: ncclAllGather issued by libvoldor_hip.so, C++ host); "
                          "torch: the same records through torch.distributed (backend nccl = RCCL)")
     ap.add_argument("--no-extras", action="store_true", help="skip host_inclusive / strict / concurrent / CPU legs (profiling runs)")
+    ap.add_argument("--no-workloads", action="store_true", help="skip the time-bounded cfg3 / cfg5 measurements of the default run (`workloads` object)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     W, H, N_FLOW, EM_ITERS = wl["w"], wl["h"], wl["n"], wl["iters"]
@@ -256,7 +260,7 @@ def main():
         torch.cuda.synchronize()
         tot, cnt = C.c_double(0), C.c_long(0)
         groups = {}
-        for name in ("optimize_depth", "optimize_camera_pose", "bootstrap", "local_pass", "cost_rand"):
+        for name in ("optimize_depth", "fb_smooth_overlapped", "optimize_camera_pose", "bootstrap", "local_pass", "cost_rand"):
             if lib.vk_profile_get(name.encode(), C.byref(tot), C.byref(cnt)) == 0 and cnt.value > 0:
                 groups[name] = {"avg_us": tot.value / cnt.value * 1e3, "calls_per_window": cnt.value / nprof}
         lib.vk_profile_enable(0)
@@ -272,11 +276,11 @@ def main():
         sqc = {}
         src = {}
         def pmc_file(kind):  # the latest committed PMC pass of this workload (collected separately: rocprofv3 cannot time and count in one run)
-            for tag in ("r04b", "r04a", "r03d", "r03c", "r02j", "r02h", "r02c"):
-                f = os.path.join(ROOT, "profiles", f"{tag}_pmc_{kind}_{args.workload}.json")
-                if os.path.exists(f):
-                    return f
-            raise FileNotFoundError(kind)
+            import glob
+            fs = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_{kind}_{args.workload}.json")))  # rNN<letter>_...: the last name is the newest pass
+            if not fs:
+                raise FileNotFoundError(kind)
+            return fs[-1]
         def provenance(f, doc):  # these numbers are REPLAYED from a committed counter pass, not measured by this run
             # the pass records the sha256 of the kernel sources it was collected on (scripts/pmc_*.sh); a pass of another tree is STALE:
             # its figures are withheld from the line (null) and only named here
@@ -308,16 +312,46 @@ def main():
                                     if isinstance(v, dict) and any(t in k for t in od_kernels)) / doc[kname]["launches"]
         except Exception:
             pass
+        # per-kernel table of the group from the two replayed counter passes: which kernels sit at the memory ceiling on REAL traffic (counter bytes /
+        # duration against the ~6.3 TB/s a copy reaches), which are bound by VALU issue, which by latency -- and how many sweeps of the maps the group makes
+        ktable, sweeps = None, None
+        try:
+            if src.get("traffic", {}).get("stale") is False and src.get("sq", {}).get("stale") is False:
+                tdoc = json.load(open(pmc_file("traffic")))["kernels"]; qdoc = json.load(open(pmc_file("sq")))
+                per_call = qdoc[kname]["launches"]
+                ktable = {}
+                for k, v in qdoc.items():
+                    if not isinstance(v, dict) or not any(t in k for t in od_kernels) or k not in tdoc:
+                        continue
+                    us = v["avg_us_under_pmc"]; by = tdoc[k]["hbm_bytes_per_launch"]
+                    tbs = by / (us * 1e-6) / 1e12
+                    issue = v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * us * 1e-6 * 2.4e9)
+                    ktable[k] = {"launches_per_call": round(v["launches"] / per_call, 2), "avg_us": round(us, 2), "counter_bytes": by, "TB_per_s": round(tbs, 3),
+                                 "frac_of_copy_ceiling": round(tbs / 6.3, 3), "valu_issue_frac": round(issue, 3), "wait_any_frac": round(v.get("frac_wait_any", 0.0), 3),
+                                 "bound": "memory" if tbs / 6.3 >= 0.5 else ("valu issue" if issue >= 0.7 else "latency")}
+                one_sweep = W * H * (12 * N_FLOW + 12 * n_dp + 8)  # every map of the M-step read once: flows 8N, rigidness 4N, priors + their two confidences 12 N_dp, depth, cost
+                sweeps = {"one_sweep_bytes": one_sweep, "group_counter_bytes": round(group_traffic), "sweeps": round(group_traffic / one_sweep, 2),
+                          "per_kernel": {k: round(v["counter_bytes"] * v["launches_per_call"] / one_sweep, 2) for k, v in ktable.items()}}
+        except Exception:
+            ktable, sweeps = None, None
         if "cost_rand" in groups and "optimize_depth" in groups:
             t_cr = groups["cost_rand"]["avg_us"] * 1e-6
             ach_k = b_cr / t_cr / 1e9
-            t_od = groups["optimize_depth"]["avg_us"] * 1e-6
+            # Round 5: the two fb_smooth launches of a call run on the library's second stream NEXT TO the pose half (vk_voldor.hip enqueue_fb_overlap) -- the
+            # events of the group on the main stream no longer contain them.  `frac` stays the conservative figure: B_od / (main-stream group + the two
+            # launches' own duration on their stream); `critical_path` is what a window pays.
+            t_crit = groups["optimize_depth"]["avg_us"] * 1e-6
+            t_fb = groups.get("fb_smooth_overlapped", {}).get("avg_us", 0.0) * 1e-6
+            t_od = t_crit + t_fb
             ach = b_od / t_od / 1e9
             # Primary figure = SURVEY.md section 8(d)'s definition: unit = one optimize_depth call (one EM iteration's depth half, a
             # group of dependent launches), achieved = B_od / (duration of the group, HIP events on the library's stream, this run).
             roof = {"bound": "hbm", "kernel": "optimize_depth launch group (fb_smooth rows + columns, cost + random samples, 4 global + 4 local propagation passes, E-step, density reduction)",
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
-                    "algorithmic_bytes": b_od, "avg_us": round(groups["optimize_depth"]["avg_us"], 2),
+                    "algorithmic_bytes": b_od, "avg_us": round(t_od * 1e6, 2),
+                    "critical_path": {"avg_us": round(t_crit * 1e6, 2), "fb_smooth_on_second_stream_us": round(t_fb * 1e6, 2), "achieved": round(b_od / t_crit / 1e9, 2), "frac": round(b_od / t_crit / 1e9 / HBM_PEAK_GBS, 5),
+                                      "note": "the group as the window pays for it: fb_smooth (rows + columns) runs on the second stream next to the pose half, off the depth half's critical path; `frac` / `avg_us` above add its own duration back"},
+                    "kernels": ktable, "sweeps": sweeps,
                     "traffic": None if group_traffic is None else round(group_traffic),
                     "measured": "achieved / frac / avg_us: HIP events of THIS run; traffic, valu_issue_frac, sq_counters_per_launch: replayed from the committed rocprofv3 --pmc passes named in `source` "
                                 "(null when that pass was collected on other kernel sources than this tree's: `source.*.stale`)",
@@ -394,6 +428,62 @@ def main():
                                                                                                      np.ascontiguousarray(g_["cfg2/s233/strict/poses_covar"], np.float32).view(np.uint32)))
         out = fo
 
+    # ---- the other single-GPU BASELINE configurations (configs[2] cfg3, configs[4] cfg5), time-bounded, so that the driver's default run sees them ----
+    others = None
+    if rank == 0 and world == 1 and not args.no_extras and not args.no_workloads and args.workload == "cfg2":
+        from voldor_amd import kernels
+        others = {}
+        for oname in ("cfg3", "cfg5"):
+            try:
+                ow = WORKLOADS[oname]
+                t_gen = time.perf_counter()
+                osc = synth.make_scene(w=ow["w"], h=ow["h"], n_flows=ow["n"], fx=ow["fx"], fy=ow["fx"], cx=ow["cx"], cy=ow["cy"], seed=233, basefocal=ow["basefocal"])
+                t_gen = time.perf_counter() - t_gen
+                ofl = torch.from_numpy(osc["flows"]).cuda()
+                okw = dict(basefocal=ow["basefocal"], disparity=torch.from_numpy(osc["disparity"]).cuda())
+                od_, oc_ = torch.empty(ow["h"], ow["w"], device="cuda"), torch.empty(ow["h"], ow["w"], device="cuda")
+
+                def orun(cfg):
+                    return pyvoldor.voldor_device(ofl, ow["fx"], ow["fx"], ow["cx"], ow["cy"], config=cfg, depth_out=od_, depth_conf_out=oc_, **okw)
+                for _ in range(3):
+                    oo = orun(ow["cfg"])
+                nwin = 10 if oname == "cfg3" else 6
+                tw = []
+                for _ in range(nwin):
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    oo = orun(ow["cfg"])
+                    torch.cuda.synchronize(); tw.append(time.perf_counter() - t1)
+                lib.vk_profile_enable(1)
+                for _ in range(2):
+                    orun(ow["cfg"])
+                torch.cuda.synchronize()
+                g_ = {}
+                for gname in ("optimize_depth", "fb_smooth_overlapped", "cost_rand", "local_pass"):
+                    if lib.vk_profile_get(gname.encode(), C.byref(tot), C.byref(cnt)) == 0 and cnt.value > 0:
+                        g_[gname] = tot.value / cnt.value * 1e3
+                lib.vk_profile_enable(0)
+                ob = ow["w"] * ow["h"] * (40 * ow["n"] + 36 * 1 + 12)
+                t_all = (g_.get("optimize_depth", 0.0) + g_.get("fb_smooth_overlapped", 0.0)) * 1e-6
+                ts_ = []
+                for i in range(3):  # reference mode: one warm-up window, two timed
+                    kernels.set_rand_epoch(0)
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    so_ = orun(ow["cfg"] + " --strict_math 1 --reference_draw 1 --reference_svd 1")
+                    torch.cuda.synchronize()
+                    if i:
+                        ts_.append(time.perf_counter() - t1)
+                others[oname] = {"workload": ow["name"], "windows": nwin, "ms_per_window": round(float(np.median(tw)) * 1e3, 3), "frames_per_s": round(1.0 / float(np.median(tw)), 2),
+                                 "n_registered": int(oo["n_registered"]),
+                                 "optimize_depth": None if not t_all else {"algorithmic_bytes": ob, "avg_us": round(t_all * 1e6, 2), "critical_path_us": round(g_.get("optimize_depth", 0.0), 2),
+                                                                           "achieved": round(ob / t_all / 1e9, 2), "frac": round(ob / t_all / 1e9 / HBM_PEAK_GBS, 5),
+                                                                           "cost_rand_us": round(g_.get("cost_rand", 0.0), 2), "local_pass_us": round(g_.get("local_pass", 0.0), 2)},
+                                 "reference_mode_ms_per_window": round(float(np.median(ts_)) * 1e3, 2), "reference_mode_n_registered": int(so_["n_registered"]),
+                                 "scene_generation_s": round(t_gen, 1)}
+                del ofl, okw, od_, oc_
+            except Exception as e:  # an extra measurement, never a reason to fail the bench
+                others[oname] = {"error": str(e)}
+        torch.cuda.empty_cache()
+
     # ---- extra: several independent windows in flight on the one GPU (never the headline value) ----
     conc = None
     if rank == 0 and world == 1 and args.in_flight > 1:
@@ -449,13 +539,12 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and wl["mode"] == "mono":
         try:
             from oracle import orc
-            sample_iters = 2
-            cfg_ref = CONFIG.replace(f"--max_iters {EM_ITERS}", f"--max_iters {sample_iters}") + " --cpu_p3p 1"
+            cfg_ref = CONFIG + " --cpu_p3p 1"
             t0 = time.perf_counter()
-            orc.ref_voldor(sc["flows"], FX, FY, CX, CY, config=cfg_ref)
+            orc.ref_voldor(sc["flows"], FX, FY, CX, CY, config=cfg_ref)  # the WHOLE window, once (round 5; rounds 3-4 timed 2 of the 8 iterations and scaled)
             tr_s = time.perf_counter() - t0
-            cpu_ref = {"value": round(1.0 / (tr_s * EM_ITERS / sample_iters), 5), "unit": "frames/s", "cores": 1, "kind": "reference",
-                       "sample": f"{sample_iters} of the {EM_ITERS} EM iterations of one {W}x{H} N_flow={N_FLOW} window ({tr_s:.1f} s), scaled to the full window; "
+            cpu_ref = {"value": round(1.0 / tr_s, 5), "unit": "frames/s", "cores": 1, "kind": "reference",
+                       "sample": f"one whole {W}x{H} N_flow={N_FLOW} window, all {EM_ITERS} EM iterations ({tr_s:.1f} s); "
                                  "the reference's own voldor/*.cpp + gpu-kernels/*.cu compiled for the host (oracle/_ref: CPU geometry path "
                                  "--cpu_p3p 1, per-pixel kernels run thread by thread on one core)"}
         except Exception as e:
@@ -486,6 +575,7 @@ def main():
                     pass
         line = {
             "metric": f"VO frames/s ({W}x{H}, N_flow={N_FLOW}, {EM_ITERS} EM iters), inputs resident in HBM", "value": round(value, 3), "unit": "frames/s",
+            "value_host_inclusive": None if host_inc is None else host_inc["value"],  # SURVEY 8(d)'s own frame: host buffers in, results out (py_voldor_wrapper); `value` is the brief's "inputs resident in HBM"
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": wl["name"] + ", scene S seed 233+rank, inputs resident in HBM",
@@ -496,7 +586,7 @@ def main():
             "n_registered": int(out["n_registered"]),
             "pose_rpe_vs_gt": {"rot_rad_max": float(rot.max()) if len(rot) else None, "rel_trans_max": float(tr.max()) if len(tr) else None},
             "pose_rpe_vs_reference": vs_ref,
-            "exchange": exchange, "latency": latency, "roofline": roof, "cpu_baseline": cpu, "cpu_reference": cpu_ref, "host_inclusive": host_inc, "strict": strict, "concurrent": conc,
+            "exchange": exchange, "latency": latency, "roofline": roof, "cpu_baseline": cpu, "cpu_reference": cpu_ref, "host_inclusive": host_inc, "strict": strict, "concurrent": conc, "workloads": others,
         }
         print(json.dumps(line), flush=True)
     if frontend == "capi":

@@ -97,6 +97,22 @@ def set_split_trials(on): debug_switch("split_trials", int(bool(on)))
 def set_strict_plain(on): debug_switch("strict_plain", int(bool(on)))
 def set_strict_pose_coop(on): debug_switch("strict_pose_coop", int(bool(on)))
 def set_pose_persist(on): debug_switch("pose_persist", int(bool(on)))
+def set_fb_overlap(on): debug_switch("fb_overlap", int(bool(on)))
+def set_solve_fp32(on): debug_switch("solve_fp32", int(bool(on)))
+def set_local_table4(on): debug_switch("local_table4", int(bool(on)))
+def set_strict_coop_max_polls(n): debug_switch("strict_coop_max_polls", int(n))
+
+
+def debug_counter(name):
+    """vk_debug_counter (vk_debug.h): read and clear"""
+    from voldor_amd import capi
+    import ctypes
+    f = capi.lib().vk_debug_counter
+    f.argtypes = [ctypes.c_char_p]; f.restype = ctypes.c_int
+    v = f(name.encode())
+    if v < 0:
+        raise ValueError(f"vk_debug_counter({name!r}) failed")
+    return v
 
 
 def pose_mode_pool(rvecs, tvecs, init_pose6, use_external_init_mean=True, refit=False, kernel_var=0.2, rvec_scale=1.0, ms_epsilon=1e-5,

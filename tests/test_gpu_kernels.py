@@ -591,17 +591,28 @@ def test_sample_pass_with_survivor_queue_matches_strict(small_scene, with_priors
     _assert_map_close(sr[:, same], fr[:, same])
 
 
-@pytest.mark.parametrize("case", ["mono_320x240", "stereo_312x96", "mono_640x480_refit_every_iteration", "ap3p", "double_solver", "low_density", "batch_of_4"])
-def test_persistent_pose_kernel_equals_the_launch_chain(case):
-    """k_pose_persist (round 5): the pose half of an EM iteration -- collect, P3P batch, mean shift for every camera -- as ONE launch whose workgroups
+@pytest.mark.parametrize("switch", ["pose_persist", "fb_overlap", "local_table4"])
+@pytest.mark.parametrize("case", ["mono_320x240", "stereo_312x96", "mono_640x480_refit_every_iteration", "ap3p", "double_solver", "low_density", "batch_of_4", "odd_323x241_truncating"])
+def test_round5_launch_structures_change_no_bit(case, switch):
+    """The launch structures of round 5 against the ones they replace, every output of a window bit for bit:
+    "fb_overlap"    fb_smooth of the rigidness maps out of place on the second stream, next to the pose half, against in place on the window's stream;
+    "local_table4"  one table sweep for the four local-propagation directions + repair of the entries whose neighbour changed, against one sweep per direction;
+    "pose_persist"  k_pose_persist (round 5): the pose half of an EM iteration -- collect, P3P batch, mean shift for every camera -- as ONE launch whose workgroups
     meet in tagged data (vk_debug_switch "pose_persist" = 1, the default where it applies) against one launch per stage ("pose_persist" = 0): every
     output of the window, bit for bit.  Windows with and without depth priors, the refit in every iteration (the persistent kernel hands those
     iterations to the launch chain), AP3P and the fp64 solver (launch chain either way: same answer by construction), a window whose correspondence
-    density collapses (truncation decided inside the kernel), and four windows in flight (pool contexts take the launch chain)."""
+    density collapses (truncation decided inside the kernel), four windows in flight (pool contexts take the launch chain), and a ragged size whose
+    last frames are noise (the window truncates: maps of dropped frames, partial tiles and chains)."""
     import ref_window_cases as rc
     from voldor_amd import kernels, pyvoldor, synth
     extra, batch = "", 1
-    if case == "mono_320x240":
+    if case == "odd_323x241_truncating":
+        sc = synth.make_scene(w=323, h=241, n_flows=5, fx=160, fy=160, cx=160, cy=120, seed=31)
+        fl = sc["flows"].copy()
+        fl[3:] = np.random.default_rng(4).uniform(-25, 25, fl[3:].shape).astype(np.float32)
+        c = dict(K=sc["K"], flows=fl, basefocal=0.0, disparity=None, depth_priors=None, depth_prior_poses=None, depth_prior_pconfs=None,
+                 config="--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 6")
+    elif case == "mono_320x240":
         c = dict(rc.window_cases())["mono_320x240"]
     elif case == "stereo_312x96":
         c = dict(rc.window_cases())["stereo_312x96"]
@@ -627,13 +638,13 @@ def test_persistent_pose_kernel_equals_the_launch_chain(case):
     out = {}
     try:
         for on in (1, 0):
-            hooks.set_pose_persist(on)
+            hooks.debug_switch(switch, on)
             out[on] = run()
     finally:
-        hooks.set_pose_persist(1)
+        hooks.debug_switch(switch, 1)
     for a, b in zip(out[1], out[0]):
         assert a["n_registered"] == b["n_registered"] and a["n_registered"] > 0
         for k in ("poses", "poses_covar", "depth", "depth_conf"):
             x = a[k].cpu().numpy() if hasattr(a[k], "cpu") else np.asarray(a[k]); y = b[k].cpu().numpy() if hasattr(b[k], "cpu") else np.asarray(b[k])
-            np.testing.assert_array_equal(np.ascontiguousarray(x, np.float32).view(np.uint32), np.ascontiguousarray(y, np.float32).view(np.uint32), err_msg=f"{case}/{k}")
+            np.testing.assert_array_equal(np.ascontiguousarray(x, np.float32).view(np.uint32), np.ascontiguousarray(y, np.float32).view(np.uint32), err_msg=f"{switch}: {case}/{k}")
 

@@ -195,19 +195,37 @@ def _plain_vs_parallel(run):
     from voldor_amd import kernels
     out = {}
     try:
-        for key, (plain, coop) in {"coop": (0, 1), "one_wg": (0, 0), "plain": (1, 1)}.items():
-            hooks.set_strict_plain(plain); hooks.set_strict_pose_coop(coop)
+        # "gave_up" (round 5): the cooperative form with a poll bound of ONE -- its workgroups give up their meetings almost at once, nothing of the
+        # camera record is written and the single-workgroup kernel launched behind it takes the camera over (vk_strict.hip coop_wait): same bits
+        for key, (plain, coop, polls) in {"coop": (0, 1, 0), "one_wg": (0, 0, 0), "gave_up": (0, 1, 1), "plain": (1, 1, 0)}.items():
+            hooks.set_strict_plain(plain); hooks.set_strict_pose_coop(coop); hooks.set_strict_coop_max_polls(polls)
             kernels.set_rand_epoch(0)
+            hooks.debug_counter("strict_coop_fallbacks")
             out[key] = run()
+            _FALLBACKS[key] = _FALLBACKS.get(key, 0) + hooks.debug_counter("strict_coop_fallbacks")
     finally:
-        hooks.set_strict_plain(0); hooks.set_strict_pose_coop(1)
-    a, b = out["coop"], out["one_wg"]
-    for k in a:
-        if isinstance(a[k], np.ndarray):
-            assert_bits(a[k], b[k], f"cooperative vs single-workgroup mode kernel: {k}")
-        elif isinstance(a[k], (int, float, np.integer, np.floating)):
-            assert np.float32(a[k]).view(np.uint32) == np.float32(b[k]).view(np.uint32) if isinstance(a[k], (float, np.floating)) else a[k] == b[k], k
+        hooks.set_strict_plain(0); hooks.set_strict_pose_coop(1); hooks.set_strict_coop_max_polls(0)
+    a = out["coop"]
+    for other in ("one_wg", "gave_up"):
+        b = out[other]
+        for k in a:
+            if isinstance(a[k], np.ndarray):
+                assert_bits(a[k], b[k], f"cooperative vs {other} mode kernel: {k}")
+            elif isinstance(a[k], (int, float, np.integer, np.floating)):
+                assert np.float32(a[k]).view(np.uint32) == np.float32(b[k]).view(np.uint32) if isinstance(a[k], (float, np.floating)) else a[k] == b[k], (other, k)
     return out["coop"], out["plain"]
+
+
+_FALLBACKS = {}  # per variant of _plain_vs_parallel: cameras the single-workgroup kernel took over (vk_debug_counter)
+
+
+def test_the_give_up_path_of_the_cooperative_mode_kernel_was_taken(strict):
+    """Runs after the comparisons above (file order): with the poll bound at one, workgroups DID give up and the single-workgroup kernel DID take
+    cameras over (else "gave_up" compared the cooperative form with itself); with the product's bound nobody gave up."""
+    if not _FALLBACKS:
+        pytest.skip("the comparison tests of this file did not run")
+    assert _FALLBACKS.get("gave_up", 0) > 0, _FALLBACKS
+    assert _FALLBACKS.get("coop", 0) == 0 and _FALLBACKS.get("one_wg", 0) == 0, _FALLBACKS
 
 
 @pytest.mark.parametrize("name", ["mono_320x240", "stereo_priors", "truncated", "refit_every_iteration", "ap3p", "cfg2", "wide_1241", "odd_323x241"])
@@ -260,7 +278,7 @@ def test_strict_parallel_structures_equal_the_plain_ones(strict, name):
             np.testing.assert_array_equal(np.asarray(a["stats"][k]), np.asarray(b["stats"][k]), err_msg=f"{name}: {k}")
 
 
-@pytest.mark.parametrize("n,nan_every,refit", [(8192, 0, True), (8192, 37, True), (8192, 3, False), (5000, 11, True), (700, 0, True), (500, 7, True), (6, 2, False), (1, 0, False), (2, 0, True)])
+@pytest.mark.parametrize("n,nan_every,refit", [(8192, 0, True), (8192, 37, True), (8192, 3, False), (8192, 1, True), (8192, 600, False), (5000, 11, True), (700, 0, True), (500, 7, True), (6, 2, False), (1, 0, False), (2, 0, True)])
 def test_strict_mode_kernel_parallel_tree_equals_the_block_walk(orc, small_scene, strict, n, nan_every, refit):
     """The strict mode kernel alone (vk_pose_mode_pool under strict math): k_pose_strict_par -- wave w owns blocks 2w, 2w+1 of the reference's
     512-row reduction, rows dealt to the lanes in bit-reversed order so that one transposing wave reduction IS strides 32 .. 1 of
@@ -273,7 +291,10 @@ def test_strict_mode_kernel_parallel_tree_equals_the_block_walk(orc, small_scene
     rv, tv = rv[:n].copy(), tv[:n].copy()
     fin = np.isfinite(rv.sum(1) + tv.sum(1))
     rv[~fin] = 0.01; tv[~fin] = 0.02  # start from an all-finite pool, then plant the NaNs
-    if nan_every:
+    if nan_every == 600:  # fewer finite rows than one block of the tree (14 of 8192): fifteen of the sixteen workgroups own no block
+        keep = np.zeros(n, bool); keep[::600] = True
+        rv[~keep] = np.nan
+    elif nan_every:  # (nan_every == 1: ONE finite row in a pool of 8192 -- the reference's loop does not run, every other workgroup has nothing)
         rv[::nan_every] = np.nan
         if n > 1:
             rv[0] = 0.01  # (keep one finite row in any case)

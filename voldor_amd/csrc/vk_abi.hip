@@ -411,6 +411,14 @@ int meanshift_gpu(float* h_space, float kernel_var, float* h_io_mean, float* h_o
 
 // The ONE entry of the verification switches (vk_debug.h; not in include/voldor_hip.h): returns the previous value, -1 for an unknown
 // name or a value the switch does not take.
+// counters of the verification interface (vk_debug.h): read and cleared; -1 for an unknown name or a device error
+extern "C" __attribute__((visibility("default"))) int vk_debug_counter(const char* name) {
+    if (!name) return -1;
+    vk::Context* c = vk::default_context();
+    if (!c) return -1;
+    if (strcmp(name, "strict_coop_fallbacks") == 0) return vk::strict_coop_fallbacks(c);
+    return -1;
+}
 extern "C" __attribute__((visibility("default"))) int vk_debug_switch(const char* name, int value) {
     if (!name) return -1;
     (void)vk::debug_switches();  // the environment is applied first, once

@@ -19,8 +19,21 @@ extern "C" {
  *                             barrier per sum) or ONE 512-thread workgroup; the same bits
  *   "strict_plain"    0 | 1   1: strict mode on the plain launch structures (one lane per chain / line, one 256-thread workgroup walking the
  *                             reference's sum tree block by block) instead of the parallel structures -- both give the same bits
+ *   "pose_persist"    1 | 0   0: the pose half of an EM iteration of the fast window pipeline as one launch per stage and camera (collect, P3P batch, mode kernel)
+ *                             instead of the persistent kernel k_pose_persist; the same bits
+ *   "fb_overlap"      1 | 0   0: fb_smooth of the rigidness maps in place on the window's stream instead of out of place on the second stream, next to the
+ *                             pose half; the same bits
+ *   "solve_fp32"      1 | 0   0: the P3P batch of the fast window pipeline in the reference's mixed fp32 / fp64 rounding sequence (vk_p3p.hpp: what strict
+ *                             mode and the host-pointer API always run) instead of plain fp32 (vk_p3p_fast.hpp)
+ *   "local_table4"    1 | 0   0: one table sweep per local-propagation direction instead of one sweep for the four directions + repair of the entries
+ *                             whose neighbour changed; the same bits
+ *   "strict_coop_max_polls"  0 | n > 0   polls after which a workgroup of the cooperative strict mode kernel gives up a meeting (0: 2^20); tests set 1 to
+ *                             force the hand-over to the single-workgroup kernel
  * Returns the previous value, -1 for an unknown name / value. */
 int vk_debug_switch(const char* name, int value);
+/* Counters, read and cleared: "strict_coop_fallbacks" = cameras (default context) whose cooperative strict mode kernel gave up a meeting and were
+ * computed by the single-workgroup kernel launched behind it.  -1: unknown name / device error. */
+int vk_debug_counter(const char* name);
 /* The mode kernel of the window pipeline (k_pose_mode: packed-pair mean shift; with do_rg the robust-Gaussian refit on the same registers --
  * geometry.cpp:156-263, meanshift.cu:34-150, fit_robust_gaussian.cu:131-263) on a caller-supplied pool of pose hypotheses, so that the kernels
  * of the timed path can be held against the oracle stage by stage.  h_rvecs / h_tvecs: [n_poses][3], n_poses <= 8192, a non-finite

@@ -82,11 +82,11 @@ int allgather_locked(const float* send_dev, float* recv_dev, int count) {
     // BASELINE.md cfg4 asks for the latency of the collective on its own: HIP events around it on the communicator's stream (device
     // time of the exchange) and the host's wall clock from issue to completion (what a step pays for it)
     const auto t0 = std::chrono::steady_clock::now();
-    if (d.ev0) VK_CHECK(hipEventRecord(d.ev0, d.stream));
+    const bool timed = d.ev0 && d.ev1 && hipEventRecord(d.ev0, d.stream) == hipSuccess;  // timing is optional: an event that cannot be recorded must not keep this rank out of the collective (the peers are waiting in it)
     VK_NCCL(g_rccl.AllGather(send_dev, recv_dev, (size_t)count, ncclFloat, d.comm, d.stream));
-    if (d.ev1) VK_CHECK(hipEventRecord(d.ev1, d.stream));
+    const bool timed1 = timed && hipEventRecord(d.ev1, d.stream) == hipSuccess;
     VK_CHECK(hipStreamSynchronize(d.stream));
-    if (d.ev0 && d.ev1 && d.ag_dev_us.size() < (size_t)VK_DIST_STATS_MAX) {
+    if (timed1 && d.ag_dev_us.size() < (size_t)VK_DIST_STATS_MAX) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, d.ev0, d.ev1) == hipSuccess) {
             d.ag_dev_us.push_back(ms * 1e3f);
@@ -139,6 +139,9 @@ int vk_dist_init(int rank, int world, const void* id_in) {
         return r != ncclSuccess ? 1000 + (int)r : (int)hipErrorOutOfMemory;
     }
     d.rank = rank; d.world = world;
+    // the exchange buffers for the largest record there is (MAX_FRAMES frames: 2.7 KB per rank) now, so that a batch step has nothing left that
+    // could fail between "my window is done" and the collective the peers are already waiting in
+    if (int e = ensure_records((size_t)(1 + 42 * MAX_FRAMES))) return e;
     return 0;
 }
 
@@ -225,7 +228,7 @@ int vk_voldor_sharded(const float* flows, const float* disparity, const float* d
     {
         std::lock_guard<std::mutex> lk(g_dmu);
         if (!g_dist.comm) return (int)hipErrorNotInitialized;
-        if (int e = ensure_records((size_t)len)) return e;
+        if (int e = ensure_records((size_t)len)) return e;  // (cannot fail: vk_dist_init allocated the records for MAX_FRAMES -- nothing between here and the collective returns early)
         send = g_dist.send; recv = g_dist.recv; st = g_dist.stream; world = g_dist.world;
     }
     // A rank whose own window fails must STILL take part in the collective: the other ranks are already inside ncclAllGather +
@@ -243,6 +246,8 @@ int vk_voldor_sharded(const float* flows, const float* disparity, const float* d
         if (n_registered) *n_registered = -1;
     }
     if (local_err) {
+        (void)hipGetLastError();
+        (void)hipDeviceSynchronize();  // a failed window may have left kernels in flight on ITS stream that still write `send`: the marker goes in after them
         (void)hipGetLastError();
         hipLaunchKernelGGL(k_mark_empty, dim3((len + 255) / 256), dim3(256), 0, st, send, len, (float)VK_DIST_FAILED, (float)local_err);
         if (hipGetLastError() != hipSuccess) {  // not even a marker launch: the device is gone.  Send what the buffer holds, marked from the host if that still works

@@ -75,6 +75,7 @@ bool fb_smooth_segmented(int w, int h);  // the segmented kernels take this size
 // vk_strict.hip
 int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr);
 int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
+int strict_coop_fallbacks(Context* c);  // cameras the single-workgroup strict mode kernel took over from the cooperative one (read and cleared); -1: device error
 int meanshift_strict_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_strict_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int fill_device(Context* c, float* p, float v, size_t n);

@@ -19,6 +19,7 @@
 #include "vk_ref_cv.h"
 #include "vk_lu.hpp"
 #include "vk_internal.hpp"
+#include <cstddef>
 
 namespace vk {
 
@@ -560,37 +561,49 @@ struct CoopGlobal {
     // reader that finds the epoch has the value -- no counter, no fence, no second round trip (tagged[.][.][.] = 0 never matches: epochs start at 1)
     unsigned long long tagged[2][16][32];
     unsigned long long tagged_raw[32];
-    int used; unsigned err; unsigned pad[2];
+    int used; unsigned err; unsigned max_polls;
+    unsigned fallbacks;  // cameras the single-workgroup kernel had to take over (never reset by a launch: vk_debug_counter reads and clears it)
 };
 // The workgroups of the cooperative form meet once per sum, in the tagged block sums themselves (CoopGlobal): lane k (< NV) of every workgroup reads
 // block sums k of all blocks until each carries this sum's epoch.  A slot is reused two sums later; a workgroup can be at most ONE sum ahead of the
-// slowest (it needs everybody's sums to get on), so nobody overwrites a word that is still being waited for.  Round 4, first form: an arrival counter
-// + release / acquire fences + the loads (three dependent round trips per sum); this form: one.  The spin is BOUNDED: a workgroup that never sees
-// the others (it cannot happen while all of them are resident -- 16 waves on a 256-CU chip -- but a hang here would take the GPU box with it) raises
-// G->err, and the pose is reported as failed.
+// slowest PARTICIPANT (it needs everybody's sums to get on), so nobody overwrites a word that is still being waited for -- participants are the
+// workgroups that own a block of the pool: the others leave right after reading the pool size (k_pose_strict_par), they would wait on words nobody
+// waits for in return.  Round 4, first form: an arrival counter + release / acquire fences + the loads (three dependent round trips per
+// sum); this form: one.
+// FORWARD PROGRESS (round 5).  The launcher only takes this form when the whole grid fits the chip next to itself (occupancy query, pose_mode_strict_device):
+// 16 single-wave workgroups without LDS pressure, so every one of them is dispatched as soon as any wave slot frees -- other kernels on the chip end,
+// these are the only ones that wait.  The spin is still BOUNDED (2^20 polls, ~1 s; vk_debug_switch "strict_coop_max_polls" lowers it to force the path
+// in tests): a workgroup that gives up raises G->err, every other one sees the flag in its own poll loop and leaves too, NOTHING of the camera record is
+// written, and the single-workgroup kernel launched behind it (k_pose_strict_par<false>, gated on the flag: it returns at once when the flag is down)
+// computes the camera from the same pool -- the same bits, never a failed pose because of a meeting.
 __device__ __forceinline__ unsigned long long coop_pack(float v, unsigned epoch) { return (unsigned long long)__builtin_bit_cast(unsigned, v) | ((unsigned long long)epoch << 32); }
-// the words p[t * stride], t < nb (<= 16), all read together until every one carries `epoch`; out[t] = its value (0 beyond nb)
-__device__ __forceinline__ void coop_wait(const unsigned long long* p, int stride, int nb, unsigned epoch, CoopGlobal* G, float (&out)[16]) {
+// the words p[t * stride], t < nb (<= 16), all read together until every one carries `epoch`; out[t] = its value (0 beyond nb).  false: gave up
+// (own bound reached, or somebody else's flag seen) -- uniform over the wave.
+__device__ __forceinline__ bool coop_wait(const unsigned long long* p, int stride, int nb, unsigned epoch, CoopGlobal* G, float (&out)[16]) {
     unsigned spins = 0;
+    const unsigned bound = G->max_polls;
     for (;;) {
         unsigned long long w[16];
 #pragma unroll
         for (int t = 0; t < 16; t++) w[t] = t < nb ? __hip_atomic_load(p + (size_t)t * stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned long long)epoch << 32);
+        const unsigned err = __hip_atomic_load(&G->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         bool all = true;
 #pragma unroll
         for (int t = 0; t < 16; t++) all = all && (unsigned)(w[t] >> 32) == epoch;
-        if (all || ++spins > (1u << 22)) {
-            if (!all) __hip_atomic_store(&G->err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-            for (int t = 0; t < 16; t++) out[t] = t < nb ? __builtin_bit_cast(float, (unsigned)w[t]) : 0.f;
-            return;
+        for (int t = 0; t < 16; t++) out[t] = t < nb ? __builtin_bit_cast(float, (unsigned)w[t]) : 0.f;
+        if (all) return true;
+        if (err != 0u || ++spins > bound) {  // 1: a meeting was given up; 2: the writer has finished (nothing left to meet for)
+            unsigned expect = 0u;
+            (void)__hip_atomic_compare_exchange_strong(&G->err, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return false;
         }
         __builtin_amdgcn_s_sleep(1);
     }
 }
 template <int NV, bool COOP, typename RowFn>
 __device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared& S, CoopGlobal* G, unsigned& sync_target, int& parity, float (&out)[NV],
-                                             float* lane_total = nullptr) {
+                                             float* lane_total = nullptr, bool* dead = nullptr /* COOP: a meeting was given up (uniform); the caller leaves */) {
 #pragma clang fp contract(off)
     constexpr int P = NV <= 8 ? 8 : 32;
     constexpr int NBLK_OWN = COOP ? 1 : 2;  // blocks per wave
@@ -639,8 +652,8 @@ __device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared
     if (lane < NV) {
         float got[16];
         if (COOP) {  // this is where the workgroups meet
-            if (n == 1) coop_wait(&G->tagged_raw[lane], 0, 1, sync_target, G, got);
-            else coop_wait(&G->tagged[parity][0][lane], 32, nb, sync_target, G, got);
+            const bool met = n == 1 ? coop_wait(&G->tagged_raw[lane], 0, 1, sync_target, G, got) : coop_wait(&G->tagged[parity][0][lane], 32, nb, sync_target, G, got);
+            if (!met) *dead = true;
         }
         auto at = [&](int t) { return COOP ? got[t] : S.lvl[parity][t][lane]; };
         if (n == 1) tot = COOP ? got[0] : S.raw[lane];
@@ -660,6 +673,7 @@ __device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared
     for (int k = 0; k < NV; k++) out[k] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tot), k));
     if (lane_total) *lane_total = tot;
     parity ^= 1;
+    if (COOP) *dead = __ballot(*dead) != 0ull;  // (one wave per workgroup: uniform from here on)
 }
 
 // ordered compaction of the finite hypotheses into `pool` (geometry.cpp:156-165): counts per (slice of 512, wave), one prefix, ordered
@@ -710,11 +724,11 @@ __device__ __forceinline__ int strict_compact_pool(const float* __restrict__ rve
 }
 // first launch of the cooperative form: the pool, its size, and the tagged block sums back to zero
 __global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_compact(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, float rvec_scale,
-                                                                            const int* __restrict__ n_points_dev, float* __restrict__ pool, CoopGlobal* G) {
+                                                                            const int* __restrict__ n_points_dev, float* __restrict__ pool, CoopGlobal* G, unsigned max_polls) {
     __shared__ StrictParShared S;
     int used = 0;
     if (*n_points_dev >= 4) used = strict_compact_pool(rvecs, tvecs, n_poses, rvec_scale, pool, S);
-    if (threadIdx.x == 0) { G->used = used; G->err = 0u; }
+    if (threadIdx.x == 0) { G->used = used; G->err = 0u; G->max_polls = max_polls; }
     // epochs restart at 1 with every launch of the mode kernel: no word of an earlier launch may carry one
     unsigned long long* tg = &G->tagged[0][0][0];
     for (int i = threadIdx.x; i < 2 * 16 * 32; i += SP_THREADS) tg[i] = 0ull;
@@ -724,11 +738,16 @@ __global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_compact(const
 template <bool COOP>
 __global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_par(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp,
                                                                                    CamState* cam, PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev,
-                                                                                   float* __restrict__ pool, CoopGlobal* G) {
+                                                                                   float* __restrict__ pool, CoopGlobal* G, const unsigned* __restrict__ gate /* single-workgroup form launched BEHIND the cooperative one: runs only if that one gave up (*gate == 1) */) {
 #pragma clang fp contract(off)
     __shared__ StrictParShared S;
     constexpr int NSLOT = COOP ? 8 : SP_SLOTS;  // rows per lane
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    if (!COOP && gate) {
+        if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) return;
+        if (t == 0) atomicAdd(const_cast<unsigned*>(gate) + 2, 1u);  // CoopGlobal::fallbacks (err, max_polls, fallbacks are consecutive words)
+    }
+    bool dead = false;
     const bool writer = t == 0 && (!COOP || blockIdx.x == 0);  // the one thread that writes the camera record (every cooperative workgroup computes the same numbers)
     unsigned sync_target = 0u;
     if (*n_points_dev < 4) {  // geometry.cpp:84-88
@@ -746,6 +765,8 @@ __global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_p
         if (writer) { cam->success = 0; maybe_decide(mp, P, cam, cam_idx); }
         return;
     }
+    // a workgroup without a block of the pool takes no part in any sum (it would contribute zeros and wait on words nobody waits for in return)
+    if (COOP && blockIdx.x != 0 && (int)blockIdx.x >= (used + 511) / 512) return;
     // ---- this lane's rows into registers
     float X[NSLOT][6];
     {
@@ -793,7 +814,8 @@ __global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_p
                 }
             };
             float o28[28];
-            tree_sum_par<28, COOP>(used, row, S, G, sync_target, parity, o28);
+            tree_sum_par<28, COOP>(used, row, S, G, sync_target, parity, o28, nullptr, &dead);
+            if (COOP && dead) return;
             for (int k = 0; k < nt; k++) {
                 const float wsum = o28[k];
                 if (wsum > best) { best = wsum; best_idx = (int)(rng3(RAND_SEED, (uint32_t)(t0 + k), 0x4D53u) % (uint32_t)used); }
@@ -816,7 +838,8 @@ __global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_p
             for (int d = 0; d < 6; d++) v[1 + d] = X[sl][d] * wgt;
         };
         float o7[7];
-        tree_sum_par<7, COOP>(used, row, S, G, sync_target, parity, o7);
+        tree_sum_par<7, COOP>(used, row, S, G, sync_target, parity, o7, nullptr, &dead);
+        if (COOP && dead) return;
         const float wsum = o7[0];
         float m[6];
         for (int d = 0; d < 6; d++) m[d] = o7[1 + d] / wsum;
@@ -887,7 +910,8 @@ __global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_p
             // only the weight is needed by every thread; thread k (< 28) of wave 0 finishes value k itself
             {
                 float o28[28];
-                tree_sum_par<28, COOP>(N, row, S, G, sync_target, parity, o28, &mine);
+                tree_sum_par<28, COOP>(N, row, S, G, sync_target, parity, o28, &mine, &dead);
+                if (COOP && dead) return;
                 o1[0] = o28[0];
             }
             weight = o1[0];
@@ -926,7 +950,10 @@ __global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_p
     if (writer) {
         bool ok = true;
         for (int d = 0; d < 6; d++) ok = ok && isfinite(pose_opm[d]);  // checkRange :256
-        if (COOP && __hip_atomic_load(&G->err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) ok = false;  // a grid barrier gave up: never report a pose from it
+        if (COOP) {  // the record is written by the cooperative form XOR by the single-workgroup kernel behind it: claim it (0 -> 2), or leave it alone if somebody gave up (1)
+            unsigned expect = 0u;
+            if (!__hip_atomic_compare_exchange_strong(&G->err, &expect, 2u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+        }
         cam->pose_sample_count = used;
         cam->pose_density = density;
         cam->last_used_ms_iters = ms_iters;
@@ -1110,6 +1137,25 @@ int robust_gaussian_strict_device(Context* c, const float* space_dev, int N, con
     return 0;
 }
 
+// The cooperative form spins on its peers: it is only taken when the runtime confirms that the whole grid (at most 16 single-wave workgroups) can be
+// resident at once on this device, i.e. the spin can only ever wait for workgroups that are running or about to be dispatched (asked once per process).
+static bool coop_fits() {
+    static const int fits = [] {
+        int per_cu = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pose_strict_par<true>, 64, 0) != hipSuccess) return 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return (long long)per_cu * cus >= SP_MAX_POSES / 512 ? 1 : 0;
+    }();
+    return fits != 0;
+}
+// cameras of this context whose cooperative mode kernel gave up a meeting and were computed by the single-workgroup kernel instead (read and cleared)
+int strict_coop_fallbacks(Context* c) {
+    if (!c->sp_coop.p) return 0;
+    unsigned v = 0;
+    unsigned* d = &c->sp_coop.as<CoopGlobal>()->fallbacks;
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&v, d, sizeof v, hipMemcpyDeviceToHost) != hipSuccess || hipMemset(d, 0, sizeof v) != hipSuccess) return -1;
+    return (int)v;
+}
 int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx) {
     if (n_poses > 2 * ST_THREADS * ST_MAXBLK) {
         fprintf(stderr, "voldor_hip: strict mode supports up to %d pose hypotheses\n", 2 * ST_THREADS * ST_MAXBLK);
@@ -1117,17 +1163,25 @@ int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamSt
     }
     if (int e = c->pool.reserve(sizeof(float) * 6 * (size_t)n_poses)) return e;
     if (!debug_switches().strict_plain && n_poses <= SP_MAX_POSES) {  // the parallel tree (same bits)
-        if (debug_switches().strict_pose_coop) {  // one single-wave workgroup per 512-row block, block sums through global memory
-            if (int e = c->sp_coop.reserve(sizeof(CoopGlobal))) return e;
+        if (debug_switches().strict_pose_coop && coop_fits()) {  // one single-wave workgroup per 512-row block, block sums through global memory
+            if (!c->sp_coop.p) {
+                if (int e = c->sp_coop.reserve(sizeof(CoopGlobal))) return e;
+                VK_CHECK(hipMemsetAsync(c->sp_coop.p, 0, sizeof(CoopGlobal), c->stream));
+            }
             CoopGlobal* G = c->sp_coop.as<CoopGlobal>();
+            static_assert(offsetof(CoopGlobal, fallbacks) == offsetof(CoopGlobal, err) + 2 * sizeof(unsigned), "k_pose_strict_par<false> counts through the gate pointer");
             const int nblk = (n_poses + 511) / 512;
+            const int cap = debug_switches().strict_coop_max_polls;
             hipLaunchKernelGGL(k_pose_strict_compact, dim3(1), dim3(SP_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp.rvec_scale,
-                               c->n_points.as<int>(), c->pool.as<float>(), G);
+                               c->n_points.as<int>(), c->pool.as<float>(), G, cap > 0 ? (unsigned)cap : (1u << 20));
             hipLaunchKernelGGL(k_pose_strict_par<true>, dim3(nblk), dim3(64), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp, cam_dev, P, cam_idx,
-                               c->n_points.as<int>(), c->pool.as<float>(), G);
+                               c->n_points.as<int>(), c->pool.as<float>(), G, (const unsigned*)nullptr);
+            // behind it, gated on the give-up flag: the same camera on ONE workgroup (same bits); returns at once when the meetings all took place
+            hipLaunchKernelGGL(k_pose_strict_par<false>, dim3(1), dim3(SP_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp, cam_dev, P, cam_idx,
+                               c->n_points.as<int>(), c->pool.as<float>(), (CoopGlobal*)nullptr, (const unsigned*)&G->err);
         } else
             hipLaunchKernelGGL(k_pose_strict_par<false>, dim3(1), dim3(SP_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp, cam_dev, P, cam_idx,
-                               c->n_points.as<int>(), c->pool.as<float>(), (CoopGlobal*)nullptr);
+                               c->n_points.as<int>(), c->pool.as<float>(), (CoopGlobal*)nullptr, (const unsigned*)nullptr);
         VK_CHECK_LAST();
         return 0;
     }

@@ -129,6 +129,9 @@ struct Voldor {
         ref_rng = strict && (cfg.reference_rng < 0 ? reference_rng_default() : cfg.reference_rng != 0);  // (the fast kernels keep D1 / D2: their arithmetic is not the reference's anyway)
         ref_tex = strict && (cfg.reference_tex < 0 ? reference_tex_default() : cfg.reference_tex != 0);
         if (ref_rng && !cfg.reference_draw) { std::cout << "--reference_rng 1 needs --reference_draw 1" << std::endl; return (int)hipErrorInvalidValue; }
+        if (cfg.bootstrap_points != 5 && cfg.bootstrap_points != 8) { std::cout << "--bootstrap_points takes 5 or 8 (got " << cfg.bootstrap_points << ")" << std::endl; return (int)hipErrorInvalidValue; }
+        if (cfg.reference_stale_depth && !(strict && cfg.exclusive_gpu_context && cfg.norm_world_scale && N_dp_in == 0 && !disparity) && !cfg.silent)
+            std::cout << "--reference_stale_depth 1 has no effect here (it needs --strict_math 1, --exclusive_gpu_context 1, --norm_world_scale 1 and a window without depth priors)" << std::endl;
         n_flows = n_flows_init = N;
         iters_cur = 0; iters_remain = cfg.max_iters;
         n_dp = N_dp_in + (disparity ? 1 : 0);

@@ -12,6 +12,8 @@ from __future__ import annotations
 
 import numpy as np
 
+VK_DIST_FAILED = -2  # include/voldor_hip.h: n_registered slot of a rank whose window failed (slot 1 = its error code); -1 = no sequence in the slot
+
 
 def block_len(n_flows: int) -> int:
     return 1 + 6 * n_flows + 36 * n_flows
@@ -76,6 +78,7 @@ def run_sharded(sequences, run_window, n_flows: int, group=None, device=None):
     mine = list(shard(len(sequences), rank, world))
     steps = -(-len(sequences) // world)
     results = [None] * len(sequences)
+    failed = []  # (sequence, rank, error code) of windows that failed on their rank: raised after the last step, when every rank has left every collective
     # where the collective runs: the caller's `device`, else what the backend needs (nccl = RCCL: this process's current device), else
     # wherever the previous record of this rank lived -- an idle rank must not feed a CPU tensor to a collective whose peers send
     # device tensors (it would error or hang on the last, uneven step)
@@ -101,6 +104,10 @@ def run_sharded(sequences, run_window, n_flows: int, group=None, device=None):
             sh = list(shard(len(sequences), r, world))
             if s < len(sh) and allb[r, 0] >= 0:
                 results[sh[s]] = unpack_pose_block(allb[r], n_flows)
+            elif s < len(sh) and int(allb[r, 0]) == VK_DIST_FAILED:  # that rank's window FAILED (vk_voldor_sharded's marker: error code in slot 1): not an empty slot
+                failed.append((sh[s], r, int(allb[r, 1])))
+    if failed:
+        raise RuntimeError("sharded VO: " + "; ".join(f"sequence {q} failed on rank {r} (error {code})" for q, r, code in failed))
     return results
 
 
@@ -180,10 +187,15 @@ def capi_run_sharded(sequences, run_step, n_flows: int):
     mine = list(shard(len(sequences), rank, world))
     steps = -(-len(sequences) // world)
     results = [None] * len(sequences)
+    failed = []  # (sequence, rank, error code) of windows that failed on their rank: raised after the last step, when every rank has left every collective
     for s in range(steps):
         allb = run_step(sequences[mine[s]] if s < len(mine) else None)
         for r in range(world):
             sh = list(shard(len(sequences), r, world))
             if s < len(sh) and allb[r, 0] >= 0:
                 results[sh[s]] = unpack_pose_block(allb[r], n_flows)
+            elif s < len(sh) and int(allb[r, 0]) == VK_DIST_FAILED:  # that rank's window FAILED (vk_voldor_sharded's marker: error code in slot 1): not an empty slot
+                failed.append((sh[s], r, int(allb[r, 1])))
+    if failed:
+        raise RuntimeError("sharded VO: " + "; ".join(f"sequence {q} failed on rank {r} (error {code})" for q, r, code in failed))
     return results
