@@ -17,11 +17,6 @@ int Context::init(int dev) {
     device = dev;
     VK_CHECK(hipSetDevice(dev));
     VK_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    VK_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-    VK_CHECK(hipEventCreateWithFlags(&ev_estep, hipEventDisableTiming));
-    VK_CHECK(hipEventCreateWithFlags(&ev_fb, hipEventDisableTiming));
-    VK_CHECK(hipEventCreate(&ev4));
-    VK_CHECK(hipEventCreate(&ev5));
     VK_CHECK(hipEventCreate(&ev0));
     VK_CHECK(hipEventCreate(&ev1));
     VK_CHECK(hipEventCreate(&ev2));
@@ -32,6 +27,17 @@ int Context::init(int dev) {
     VK_CHECK(hipHostMalloc((void**)&h_cams_up, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
     VK_CHECK(hipHostMalloc((void**)&h_brief, sizeof(CamBrief) * MAX_FRAMES, hipHostMallocMapped));
     VK_CHECK(hipHostGetDevicePointer((void**)&h_brief_dev, h_brief, 0));
+    return 0;
+}
+// the second stream and its events, on first use (a context that never overlaps anything -- the pool contexts of windows in flight -- keeps its one
+// stream: streams map onto a handful of hardware queues, and every extra stream makes two windows share one sooner)
+int Context::ensure_stream2() {
+    if (stream2) return 0;
+    VK_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+    VK_CHECK(hipEventCreateWithFlags(&ev_estep, hipEventDisableTiming | hipEventReleaseToDevice));
+    VK_CHECK(hipEventCreateWithFlags(&ev_fb, hipEventDisableTiming | hipEventReleaseToDevice));
+    VK_CHECK(hipEventCreate(&ev4));
+    VK_CHECK(hipEventCreate(&ev5));
     return 0;
 }
 void Context::destroy() {

@@ -205,6 +205,7 @@ struct Context {
     CamState* h_cams = nullptr;    // pinned staging for that copy (a pageable destination would make the copy synchronous)
     int ensure_n_points() { return n_points.reserve(sizeof(int) * 4); }
     int init(int dev);
+    int ensure_stream2();
     void destroy();
 };
 

@@ -143,7 +143,7 @@ struct Voldor {
         }
         ImageSet& S = c->od;
         hipStream_t st = c->stream;
-        VK_CHECK(hipStreamWaitEvent(st, c->ev_fb, 0));  // (a window that ended on an error may have left work on the second stream)
+        if (c->stream2) VK_CHECK(hipStreamWaitEvent(st, c->ev_fb, 0));  // (a window that ended on an error may have left work on the second stream)
         const size_t npx = (size_t)w * h;
         S.w = w; S.h = h;
         if (int e = S.ensure_pose()) return e;
@@ -193,7 +193,10 @@ struct Voldor {
             VK_CHECK(hipMemcpyAsync(S.depth.p, S.priors.p, sizeof(float) * npx, hipMemcpyDeviceToDevice, st));
             if (!disparity) { if (int e = optimize_depth(OD_ONLY_USE_DEPTH_PRIOR)) return e; }
         } else if (int e = fill_device(c, S.depth.as<float>(), 1.f, npx)) return e;
-        VK_CHECK(hipEventRecord(c->ev_estep, st));  // the rigidness / prior-confidence maps the first fb_smooth reads are enqueued
+        if (fb_overlap_ok()) {
+            if (int e = c->ensure_stream2()) return e;
+            VK_CHECK(hipEventRecord(c->ev_estep, st));  // the rigidness / prior-confidence maps the first fb_smooth reads are enqueued
+        }
         return 0;
     }
 
@@ -209,6 +212,7 @@ struct Voldor {
     }
     int enqueue_fb_overlap() {
         ImageSet& S = c->od;
+        if (int e = c->ensure_stream2()) return e;
         VK_CHECK(hipStreamWaitEvent(c->stream2, c->ev_estep, 0));
         if (c->prof) VK_CHECK(hipEventRecord(c->ev4, c->stream2));
         if (int e = fb_smooth_device(c, S.rig.as<float>(), n_flows, w, h, cfg.fb_emm, cfg.fb_no_change_prob, nullptr, nullptr, 0, 0, nullptr, S.rig2.as<float>(), c->stream2)) return e;
@@ -252,7 +256,7 @@ struct Voldor {
         }
         const int e = optimize_depth_device(c, c->od, p);  // with world_scale_out: depth and poses leave normalised (voldor.cpp:309-317)
         if (e) return e;
-        VK_CHECK(hipEventRecord(c->ev_estep, c->stream));
+        if (c->stream2 && fb_overlap_ok()) VK_CHECK(hipEventRecord(c->ev_estep, c->stream));
         return 0;
     }
 
