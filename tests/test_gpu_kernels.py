@@ -591,18 +591,19 @@ def test_sample_pass_with_survivor_queue_matches_strict(small_scene, with_priors
     _assert_map_close(sr[:, same], fr[:, same])
 
 
-@pytest.mark.parametrize("switch", ["pose_persist", "fb_overlap", "local_table4"])
+@pytest.mark.parametrize("switch", ["pose_fused", "fb_overlap", "local_table4"])
 @pytest.mark.parametrize("case", ["mono_320x240", "stereo_312x96", "mono_640x480_refit_every_iteration", "ap3p", "double_solver", "low_density", "batch_of_4", "odd_323x241_truncating"])
 def test_round5_launch_structures_change_no_bit(case, switch):
     """The launch structures of round 5 against the ones they replace, every output of a window bit for bit:
-    "fb_overlap"    fb_smooth of the rigidness maps out of place on the second stream, next to the pose half, against in place on the window's stream;
+    "fb_overlap"    fb_smooth of the rigidness maps out of place in extra workgroups of the pose half's P3P launches against its own two launches, in place, at the
+                    head of the depth half;
     "local_table4"  one table sweep for the four local-propagation directions + repair of the entries whose neighbour changed, against one sweep per direction;
-    "pose_persist"  k_pose_persist (round 5): the pose half of an EM iteration -- collect, P3P batch, mean shift for every camera -- as ONE launch whose workgroups
-    meet in tagged data (vk_debug_switch "pose_persist" = 1, the default where it applies) against one launch per stage ("pose_persist" = 0): every
-    output of the window, bit for bit.  Windows with and without depth priors, the refit in every iteration (the persistent kernel hands those
-    iterations to the launch chain), AP3P and the fp64 solver (launch chain either way: same answer by construction), a window whose correspondence
-    density collapses (truncation decided inside the kernel), four windows in flight (pool contexts take the launch chain), and a ragged size whose
-    last frames are noise (the window truncates: maps of dropped frames, partial tiles and chains)."""
+    "pose_fused"    k_solve_fc (round 5): the launch of a camera's P3P batch first finishes the camera's correspondences from the state the previous launch
+                    traced (the pose it needed was not there yet), its workgroups meet in the tagged block counts, then solve, while extra workgroups trace the
+                    next camera's pixels -- against collect / P3P batch as two launches.
+    Windows with and without depth priors, the refit in every iteration, AP3P and the fp64 solver (unfused either way: same answer by construction), a window
+    whose correspondence density collapses, four windows in flight (pool contexts), and a ragged size whose last frames are noise (the window truncates: maps
+    of dropped frames, partial tiles and chains)."""
     import ref_window_cases as rc
     from voldor_amd import kernels, pyvoldor, synth
     extra, batch = "", 1

@@ -27,35 +27,26 @@ int Context::init(int dev) {
     VK_CHECK(hipHostMalloc((void**)&h_cams_up, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
     VK_CHECK(hipHostMalloc((void**)&h_brief, sizeof(CamBrief) * MAX_FRAMES, hipHostMallocMapped));
     VK_CHECK(hipHostGetDevicePointer((void**)&h_brief_dev, h_brief, 0));
-    return 0;
-}
-// the second stream and its events, on first use (a context that never overlaps anything -- the pool contexts of windows in flight -- keeps its one
-// stream: streams map onto a handful of hardware queues, and every extra stream makes two windows share one sooner)
-int Context::ensure_stream2() {
-    if (stream2) return 0;
-    VK_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-    VK_CHECK(hipEventCreateWithFlags(&ev_estep, hipEventDisableTiming | hipEventReleaseToDevice));
-    VK_CHECK(hipEventCreateWithFlags(&ev_fb, hipEventDisableTiming | hipEventReleaseToDevice));
-    VK_CHECK(hipEventCreate(&ev4));
-    VK_CHECK(hipEventCreate(&ev5));
+    VK_CHECK(hipHostMalloc((void**)&h_fc_err, sizeof(int) * 4, hipHostMallocMapped));
+    h_fc_err[0] = 0;
+    VK_CHECK(hipHostGetDevicePointer((void**)&h_fc_err_dev, h_fc_err, 0));
     return 0;
 }
 void Context::destroy() {
     DevBuf* bufs[] = { &od.flows, &od.rig, &od.rig2, &od.depth, &od.cost, &od.priors, &od.pconfs, &od.confs, &od.pose,
                        &cp.flows, &cp.rig, &cp.depth, &cp.cost, &cp.priors, &cp.pconfs, &cp.confs, &cp.pose,
                        &rig_partial, &local_tbl, &p2_map, &p3_map, &blk_counts, &blk_offsets, &valid_mask, &pts2, &pts3, &n_points,
-                       &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp, &fb_scratch, &stale_depth, &sp_coop, &xw_jumps, &xw_px_states, &xw_pose_states };
+                       &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp, &fb_scratch, &stale_depth, &sp_coop, &fc_stage, &fc_cnt_tag, &xw_jumps, &xw_px_states, &xw_pose_states };
     for (DevBuf* b : bufs) b->release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
     if (ev2) (void)hipEventDestroy(ev2);
     if (ev3) (void)hipEventDestroy(ev3);
     if (ev_cams) (void)hipEventDestroy(ev_cams);
-    for (hipEvent_t* e : { &ev_estep, &ev_fb, &ev4, &ev5 }) { if (*e) (void)hipEventDestroy(*e); *e = nullptr; }
-    if (stream2) (void)hipStreamDestroy(stream2);
-    stream2 = nullptr;
     if (h_cams) (void)hipHostFree(h_cams);
     if (h_brief) (void)hipHostFree(h_brief);
+    if (h_fc_err) (void)hipHostFree(h_fc_err);
+    h_fc_err = h_fc_err_dev = nullptr;
     if (h_pb) (void)hipHostFree(h_pb);
     if (h_cams_up) (void)hipHostFree(h_cams_up);
     h_pb = nullptr; h_cams_up = nullptr;
@@ -165,7 +156,7 @@ static const DebugEntry g_debug_tab[] = {
     { "local_serial", &DebugSwitches::local_serial, 0 }, { "cost_rand_plain", &DebugSwitches::cost_rand_plain, 0 }, { "fb_segment", &DebugSwitches::fb_segment, 1 },
     { "global_split", &DebugSwitches::global_split, 0 }, { "refit_partition", &DebugSwitches::refit_partition, 0 }, { "split_trials", &DebugSwitches::split_trials, 0 },
     { "strict_plain", &DebugSwitches::strict_plain, 0 }, { "strict_pose_coop", &DebugSwitches::strict_pose_coop, 0 },
-    { "pose_persist", &DebugSwitches::pose_persist, 0 }, { "fb_overlap", &DebugSwitches::fb_overlap, 0 }, { "solve_fp32", &DebugSwitches::solve_fp32, 0 },
+    { "pose_fused", &DebugSwitches::pose_fused, 0 }, { "fb_overlap", &DebugSwitches::fb_overlap, 0 },
     { "local_table4", &DebugSwitches::local_table4, 0 }, { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 },
 };
 // returns the previous value; -1: unknown name; -2: a value the switch does not take

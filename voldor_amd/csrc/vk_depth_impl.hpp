@@ -1217,7 +1217,7 @@ int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_
     // fast mode: the projective maps of the chain (and the world-scale factor) are prepared by an extra workgroup of the first fb_smooth
     // launch when there is one, by their own small launch otherwise
     const bool cum_in_fb = !STRICT && !cost_only && !p.update_rigidness_only && p.fb_smooth && p.N > 0 && !p.fb_done;
-    if constexpr (!STRICT) { if (!cum_in_fb) cum_poses_launch(c, S.pb(), p.N, p.N_dp, p.world_scale_out); }
+    if constexpr (!STRICT) { if (!cum_in_fb && !p.cum_done) cum_poses_launch(c, S.pb(), p.N, p.N_dp, p.world_scale_out); }
     auto cost_rand = [&](int n_rand, uint32_t epoch) {
         if constexpr (STRICT) {
             if (plain || debug_switches().cost_rand_plain || p.N_dp > 1) hipLaunchKernelGGL(k_cost_rand_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);

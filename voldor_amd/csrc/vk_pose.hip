@@ -15,11 +15,12 @@
 #include "vk_common.hpp"
 #include "vk_device.hpp"
 #include "vk_p3p.hpp"
-#include "vk_p3p_fast.hpp"
 #include "vk_ref_svd.h"
 #include "vk_lu.hpp"
 #include "vk_ref_cuda.h"
 #include "vk_internal.hpp"
+#include "vk_cum_poses.hpp"
+#include "vk_fb.hpp"
 
 namespace vk {
 
@@ -202,7 +203,7 @@ __device__ __forceinline__ float draw_uniform(const vrc_xorwow* __restrict__ xw,
 }
 constexpr int DRAW_MAX_TRIES = 256;
 constexpr int DRAW_RANK_INV_DENSITY = 20;  // rank select below 5 % valid pixels (rejection then needs > 90 tries for 1 % of the points)
-template <int SOLVER, bool FROM_MAP, bool FAST = false>  // SOLVER: 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>; FAST (SOLVER 0, fast window pipeline): plain fp32 (vk_p3p_fast.hpp)
+template <int SOLVER, bool FROM_MAP>  // SOLVER: 0 lambdatwist<float>, 1 ap3p, 2 lambdatwist<double>
 __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2, const float* __restrict__ pts3,
                                                       float* __restrict__ rvecs, float* __restrict__ tvecs,
                                                       int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk,
@@ -420,8 +421,7 @@ __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2
 #endif
         PH_MARK(10);
         if (drawn) {
-            if (SOLVER == 0 && FAST) ok = p3pf::lambdatwist_candidate(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf);
-            else if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf);
+            if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errf);
             else if (SOLVER == 2) ok = lambdatwist_p4p<double>(yu, yv, xp, fx, fy, cx, cy, R, t, sub, &errd);
             else ok = ap3p_p4p(yu, yv, xp, fx, fy, cx, cy, R, t, (strict & 1) != 0);
         }
@@ -430,7 +430,7 @@ __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2
     float aa[3] = { qnan, qnan, qnan };
     if (ok) {
         // rodrigues.h:82-114.  Default: the exact polar factor (D8); --reference_svd 1: U V^T of the reference's approximate SVD, bit for bit
-        if (strict & 2) vrs_project_rotation(R); else if (FAST) p3pf::nearest_rotation(R); else nearest_rotation(R);
+        if (strict & 2) vrs_project_rotation(R); else nearest_rotation(R);
         rotmat_to_angle_axis(R, aa, (strict & 1) != 0);
     }
     PH_MARK(12);
@@ -460,12 +460,303 @@ __device__ __forceinline__ static void solve_body(const float* __restrict__ pts2
     }
     PH_MARK(13); PH_ADD(14, 1);
 }
-template <int SOLVER, bool FROM_MAP, bool FAST = false>
+template <int SOLVER, bool FROM_MAP>
 __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ pts2, const float* __restrict__ pts3, float* __restrict__ rvecs, float* __restrict__ tvecs,
                                                       int* __restrict__ n_pts_dev, const int* __restrict__ blk_counts, int nblk, CamState* cam, int npx, float fx, float fy,
                                                       float cx, float cy, int n_poses, int draw, int strict, const int* __restrict__ blk_offsets,
                                                       const unsigned long long* __restrict__ valid_mask, const vrc_xorwow* __restrict__ xw) {
-    solve_body<SOLVER, FROM_MAP, FAST>(pts2, pts3, rvecs, tvecs, n_pts_dev, blk_counts, nblk, cam, npx, fx, fy, cx, cy, n_poses, draw, strict, blk_offsets, valid_mask, xw);
+    solve_body<SOLVER, FROM_MAP>(pts2, pts3, rvecs, tvecs, n_pts_dev, blk_counts, nblk, cam, npx, fx, fy, cx, cy, n_poses, draw, strict, blk_offsets, valid_mask, xw);
+}
+
+// ---- round 5: TWO launches per camera (vk_debug_switch "pose_fused") --------------------------------------------------------------------
+// The pose half of an EM iteration was three launches per camera -- k_collect, k_solve, k_pose_mode -- each a few hundred waves at most on a 256-CU
+// chip and each paying a launch boundary (2.85 us from the end of one dependent kernel to the start of the next, scripts/micro/event_cost.hip).
+// k_collect is the only one of the three that moves data (~130 bytes per pixel through the caches: 8.6 us at 640x480, at the L2 / MALL's rate), and
+// nearly all of it does NOT depend on the pose the previous camera's mode kernel has just produced: the pixel of camera a is traced through the
+// flows of frames start .. a from the projection of its 3-D point in frame `start`, which needs the poses 0 .. start - 1 <= a - 2 unless the trace
+// is one frame long; pose a - 1 only enters through the last rigid transform of the 3-D point (and through the projection of a one-frame trace).  So:
+//   * the launch that solves camera a's hypotheses carries EXTRA workgroups that trace camera a + 1's pixels as far as pose a - 1... no further --
+//     "prestage": validity of depth and rigidness, 3-D point in frame a coordinates (transforms 0 .. a - 1), flow trace where it does not need pose a;
+//     per pixel { flag, px, py, o } to a staging buffer -- concurrently with the P3P chains, which occupy half a wave per SIMD and no bandwidth;
+//   * the launch of camera a + 1 starts by FINISHING those pixels in the workgroups that will solve: last transform, projection + one gather for the
+//     one-frame traces ("late" pixels), validity, ordered compaction inside each 256-pixel block -- exactly k_collect<true>'s values and layout --
+//     then the workgroups MEET in the block counts: a count and the launch's tag in one 32-bit word (count | tag << 9, agent-scope store after the
+//     block's correspondences are out: sc1 stores + s_waitcnt), every solver workgroup reads all words until each carries the tag (the same words it
+//     needs for the rank select's prefix anyway: the meeting costs one memory round trip), and solves.
+// Per camera: (collect 8.6 + boundary 2.85) -> ~4 us of finishing + meeting.  The meeting is among the 128 solver workgroups only (the first 128 of
+// the grid: dispatched first, 4 waves and < 128 VGPRs each -- resident at once on any free eighth of the chip); the spin is bounded, a timeout raises
+// a flag in pinned host memory and the window is run again on the three-launch chain (vk_voldor.hip).
+// The same launches carry fb_smooth of the depth half that follows (vk_debug_switch "fb_overlap"): its row pass as extra workgroups of camera 0's
+// launch, its column pass of camera 1's -- out of place (ImageSet::rig2), the pose half still reads the raw maps.
+struct FcAuxJob {  // one fb_smooth pass over a stack of maps as extra workgroups (vk_fb.hpp)
+    int kind;      // 0 none, 1 row pass src -> dst, 2 column pass in place on dst
+    const float* src; float* dst;
+    int n_maps, S, CW, vec4, blocks_x, n_wg;
+};
+struct FcArgs {
+    const float2* flows; const float* rig; const float* depth; const PoseBlock* P;
+    int N, w, h; float rig_thresh, rig_sum_thresh, min_depth, max_depth; int max_trace;
+    int cam, finalize, prestage_next;
+    float* stage_cur; float* stage_next;  // [6][npx] planes: flag, px, py, o.x, o.y, o.z
+    float* p2_map; float* p3_map; unsigned* cnt_tag; const int* blk_counts; int nblk; unsigned tag;
+    float* rvecs; float* tvecs; int* n_pts_dev; CamState* camrec; float fx, fy, cx, cy; int n_poses, solver, ref_svd;
+    int n_solve_wg, n_pre_wg;
+    FcAuxJob aux[2]; float fb_e0, fb_p;
+    unsigned max_polls; int* host_err;
+};
+__device__ __forceinline__ float ld_coh(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_coh(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// camera a's pixel pi as far as the poses 0 .. a - 2 take it (collect_p3p_instances.cu:70-145, the operations of k_collect in their order)
+__device__ __forceinline__ void fc_prestage_pixel(const FcArgs& A, int a, int pi, float& flag, float& px, float& py, P3& o) {
+    const int w = A.w, h = A.h, npx = w * h, N = A.N;
+    const PoseBlock* P = A.P;
+    flag = 0.f; px = 0.f; py = 0.f; o = { 0.f, 0.f, 0.f };
+    const int x = pi % w, y = pi / w;
+    const float d = A.depth[pi];
+    const float rig_a = A.rig[(size_t)a * npx + pi];
+    bool ok = !(d < A.min_depth || (A.max_depth > 0.f && d > A.max_depth));
+    if (ok && A.rig_sum_thresh > (float)(N + 1)) {  // inert unless thr > N+1 (sic, :88-90)
+        float rs = 0.f;
+        for (int i = 0; i < N; i++) rs += A.rig[(size_t)i * npx + pi];
+        if (rs < A.rig_sum_thresh) ok = false;
+    }
+    int n_trace = 0;
+    if (ok) {
+        float prod = 1.f;
+        const int lo = A.max_trace > 0 ? max(0, a - A.max_trace + 1) : 0;
+        for (int i = a; i >= lo; i--) {
+            prod *= i == a ? rig_a : A.rig[(size_t)i * npx + pi];
+            if (prod > A.rig_thresh) n_trace++;
+            else break;
+        }
+        ok = n_trace > 0;
+    }
+    if (!ok) return;
+    o = backproject(P, (float)x, (float)y, d);
+    const int start = a - n_trace + 1;
+    bool out = false;
+    float qx = 0.f, qy = 0.f;
+    for (int i = 0; i < a; i++) {  // frames 0 .. a - 1: their trace steps, and the transforms 0 .. a - 2 (transform a - 1 waits for its pose)
+        if (i >= start) {
+            if (i == start) project(P, o, qx, qy);
+            if (qx > 0.f && qx < (float)w && qy > 0.f && qy < (float)h) {  // strict (:120)
+                const float2 f2 = bilinear2(A.flows + (size_t)i * npx, w, h, qx, qy);
+                qx += f2.x; qy += f2.y;
+            } else { out = true; break; }
+        }
+        if (i < a - 1) o = transform(P->Rs[i], P->ts[i], o);
+    }
+    if (out) return;
+    if (start <= a - 1) {  // frame a's own trace step continues from a known position: it does not see pose a - 1
+        if (qx > 0.f && qx < (float)w && qy > 0.f && qy < (float)h) {
+            const float2 f2 = bilinear2(A.flows + (size_t)a * npx, w, h, qx, qy);
+            qx += f2.x; qy += f2.y;
+            flag = 1.f; px = qx; py = qy;
+        }
+    } else flag = 2.f;  // a one-frame trace: the projection of the point in frame a, hence pose a - 1, comes first ("late")
+}
+
+// FB: the instantiation that can carry fb_smooth workgroups (cameras 0 and 1 of an iteration: 150 VGPRs and 16 KB of LDS per workgroup against 137 and none)
+template <int SOLVER, int TMAX, bool FB>
+__global__ __launch_bounds__(256) static void k_solve_fc(FcArgs A) {
+    extern __shared__ int s_pref[];
+    __shared__ int s_cnt[TMAX][4];
+    __shared__ int s_flag;
+    __shared__ FbMat s_fb[FB ? 4 : 1][FB ? 256 : 1];  // (fb_smooth workgroups: sF[2][256], sB[2][256])
+    const int bid = blockIdx.x, tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
+    const int w = A.w, h = A.h, npx = w * h;
+    if (bid >= A.n_solve_wg) {
+        int r = bid - A.n_solve_wg;
+        if (r < A.n_pre_wg) {  // ---- trace the next camera's pixels as far as the known poses go
+            const int tile = xcd_band_tile(r, A.n_pre_wg), pi = tile * 256 + tid;
+            if (pi >= npx) return;
+            float flag, px, py; P3 o;
+            fc_prestage_pixel(A, A.cam + 1, pi, flag, px, py, o);
+            float* st = A.stage_next;
+            st[pi] = flag; st[(size_t)npx + pi] = px; st[(size_t)2 * npx + pi] = py;
+            st[(size_t)3 * npx + pi] = o.x; st[(size_t)4 * npx + pi] = o.y; st[(size_t)5 * npx + pi] = o.z;
+            return;
+        }
+        r -= A.n_pre_wg;
+        // ---- fb_smooth of the depth half that follows, riding along (20-step segments only: the sizes this launch exists for)
+        auto run_aux = [&](const FcAuxJob& J, int q) {
+            const int bx = q % J.blocks_x, by = q / J.blocks_x;
+            if (J.kind == 1) {
+                if (J.vec4) fb_rows_body<true, 20>(J.src, J.dst, w, h, J.S, A.fb_e0, A.fb_p, bx, by, &s_fb[0][0], &s_fb[2][0]);
+                else fb_rows_body<false, 20>(J.src, J.dst, w, h, J.S, A.fb_e0, A.fb_p, bx, by, &s_fb[0][0], &s_fb[2][0]);
+            } else fb_cols_body<20>(J.dst, w, h, J.S, J.CW, A.fb_e0, A.fb_p, bx, by, &s_fb[0][0], &s_fb[2][0]);
+        };
+        if constexpr (FB) {
+            if (A.aux[0].kind && r < A.aux[0].n_wg) { run_aux(A.aux[0], r); return; }
+            if (A.aux[0].kind) r -= A.aux[0].n_wg;
+            if (A.aux[1].kind && r < A.aux[1].n_wg) run_aux(A.aux[1], r);
+        }
+        return;
+    }
+    // ---- solver workgroup
+    const PoseBlock* P = A.P;
+    const int nblk = A.nblk;
+    auto pref_at = [](int i) { return i + (i >> 5); };
+    if (A.finalize) {
+        // (1) finish this camera's correspondences for blocks bid, bid + n_solve_wg, ..: everything of a block's pixels in flight together
+        const int a = A.cam;
+        const float* st = A.stage_cur;
+        float fl[TMAX], px[TMAX], py[TMAX], ox[TMAX], oy[TMAX], oz[TMAX];
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) {
+            const int t = bid + k * A.n_solve_wg, pi = t * 256 + tid;
+            const bool in = t < nblk && pi < npx;
+            const int q = in ? pi : 0;
+            fl[k] = st[q]; px[k] = st[(size_t)npx + q]; py[k] = st[(size_t)2 * npx + q];
+            ox[k] = st[(size_t)3 * npx + q]; oy[k] = st[(size_t)4 * npx + q]; oz[k] = st[(size_t)5 * npx + q];
+            if (!in) fl[k] = 0.f;
+        }
+        bool valid[TMAX];
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) {
+            P3 o = { ox[k], oy[k], oz[k] };
+            o = transform(P->Rs[a - 1], P->ts[a - 1], o);  // (finalize is only ever set for a >= 1)
+            bool ok = fl[k] != 0.f;
+            if (fl[k] == 2.f) {  // the one-frame trace: project, then frame a's step
+                float qx, qy;
+                project(P, o, qx, qy);
+                if (qx > 0.f && qx < (float)w && qy > 0.f && qy < (float)h) {
+                    const float2 f2 = bilinear2(A.flows + (size_t)a * npx, w, h, qx, qy);
+                    px[k] = qx + f2.x; py[k] = qy + f2.y;
+                } else ok = false;
+            }
+            ok = ok && o.z > A.min_depth && (A.max_depth <= 0.f || o.z < A.max_depth);
+            ok = ok && isfinite(px[k] + py[k] + o.x + o.y + o.z);  // geometry.cpp:73 keeps only entries whose sum is finite
+            valid[k] = ok; ox[k] = o.x; oy[k] = o.y; oz[k] = o.z;
+        }
+        unsigned long long m[TMAX];
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) {
+            m[k] = __ballot(valid[k]);
+            if (ln == 0) s_cnt[k][wv] = __popcll(m[k]);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) {
+            if (valid[k]) {
+                const int t = bid + k * A.n_solve_wg;
+                int r = __popcll(m[k] & ((1ull << ln) - 1ull));
+                for (int j = 0; j < wv; j++) r += s_cnt[k][j];
+                const size_t slot = (size_t)t * 256 + r;
+                st_coh(A.p2_map + slot * 2, px[k]); st_coh(A.p2_map + slot * 2 + 1, py[k]);
+                st_coh(A.p3_map + slot * 3, ox[k]); st_coh(A.p3_map + slot * 3 + 1, oy[k]); st_coh(A.p3_map + slot * 3 + 2, oz[k]);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's correspondences have left for memory (write-through stores) ...
+        __syncthreads();                                   // ... and so have everybody else's in the workgroup: the counts may say so
+        if (tid < TMAX) {
+            const int t = bid + tid * A.n_solve_wg;
+            if (t < nblk) {
+                const unsigned cnt = (unsigned)(s_cnt[tid][0] + s_cnt[tid][1] + s_cnt[tid][2] + s_cnt[tid][3]);
+                __hip_atomic_store(A.cnt_tag + t, cnt | (A.tag << 9), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+    }
+    // (2) the counts of ALL blocks -> inclusive prefix in LDS (what the rank select bisects).  finalize: every word must carry this launch's tag --
+    // that is where the solver workgroups meet.  Wave 0: (a) the words, coalesced (lane l reads words l, l + 64, ..: 32 in flight), raw counts to
+    // the LDS; (b) lane l sums 32 CONSECUTIVE counts in registers, one 6-step wave scan per 2048 blocks, running sums back to the same slots
+    // (k_solve's prefix_to_lds; padded layout pref_at: conflict-free either way).
+    if (wv == 0) {
+        bool gave_up = false;
+        for (int i0 = 0; i0 < nblk && !gave_up; i0 += 64 * 32) {
+            unsigned spins = 0;
+            for (;;) {
+                bool all = true;
+#pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    const int i = i0 + j * 64 + ln;
+                    unsigned wd = A.tag << 9;
+                    if (i < nblk) wd = A.finalize ? __hip_atomic_load(A.cnt_tag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned)A.blk_counts[i] | (A.tag << 9));
+                    all = all && (wd >> 9) == A.tag;
+                    if (i < nblk) s_pref[pref_at(i)] = (int)(wd & 0x1ffu);
+                }
+                if (__all(all)) break;
+                if (++spins > A.max_polls) { gave_up = true; break; }
+                __builtin_amdgcn_s_sleep(2);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        int carry = 0;
+        for (int i0 = 0; i0 < nblk && !gave_up; i0 += 64 * 32) {
+            const int b0 = i0 + ln * 32;
+            int v[32];
+#pragma unroll
+            for (int j = 0; j < 32; j++) v[j] = b0 + j < nblk ? s_pref[pref_at(b0 + j)] : 0;
+#pragma unroll
+            for (int j = 1; j < 32; j++) v[j] += v[j - 1];
+            int incl = v[31];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (ln >= o) incl += t; }
+            const int base = carry + incl - v[31];
+#pragma unroll
+            for (int j = 0; j < 32; j++) if (b0 + j < nblk) s_pref[pref_at(b0 + j)] = base + v[j];
+            carry += __shfl(incl, 63, 64);
+        }
+        if (ln == 0) {
+            s_flag = gave_up ? 1 : 0;
+            if (gave_up && A.host_err) { *A.host_err = 1; __threadfence_system(); }  // the window is run again on the three-launch chain (vk_voldor.hip)
+        }
+    }
+    __syncthreads();
+    if (s_flag) return;
+    const int n_pts = nblk > 0 ? s_pref[pref_at(nblk - 1)] : 0;
+    // (3) this wave's 16 hypotheses, four lanes each (k_solve's rank-select draw over block-compacted correspondences, LambdaTwist)
+    const int gtid = (bid * 4 + wv) * 64 + ln, idx = gtid / 4, sub = gtid % 4;
+    if (gtid == 0) { *A.n_pts_dev = n_pts; if (A.camrec) A.camrec->n_points = n_pts; }
+    if (idx >= A.n_poses) return;
+    const float qnan = __builtin_nanf("");
+    float R[9], t[3];
+    bool ok = false;
+    float errf = 0.f; double errd = 0.0;
+    if (n_pts >= 4) {
+        // (int)(curand_uniform * N_pts), clamped (D3): solve_batch_lambdatwist.cu:16-19; lane `sub` finds point `sub`
+        const int rk = min((int)(draw_uniform(nullptr, idx, sub) * (float)n_pts), n_pts - 1);
+        int lo = 0, hi = nblk - 1;  // first block whose inclusive prefix exceeds the rank
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[pref_at(mid)] > rk) hi = mid; else lo = mid + 1; }
+        const int found = lo * 256 + (rk - (lo > 0 ? s_pref[pref_at(lo - 1)] : 0));
+        float yu[4], yv[4], xp[4][3];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int i = __shfl(found, (ln & ~3) + k, 64);
+            // (the correspondences of this launch's own finalize phase come from other compute units: coherent loads; k_collect's are a launch old)
+            if (A.finalize) {
+                yu[k] = ld_coh(A.p2_map + (size_t)i * 2); yv[k] = ld_coh(A.p2_map + (size_t)i * 2 + 1);
+                xp[k][0] = ld_coh(A.p3_map + (size_t)i * 3); xp[k][1] = ld_coh(A.p3_map + (size_t)i * 3 + 1); xp[k][2] = ld_coh(A.p3_map + (size_t)i * 3 + 2);
+            } else {
+                yu[k] = A.p2_map[(size_t)i * 2]; yv[k] = A.p2_map[(size_t)i * 2 + 1];
+                xp[k][0] = A.p3_map[(size_t)i * 3]; xp[k][1] = A.p3_map[(size_t)i * 3 + 1]; xp[k][2] = A.p3_map[(size_t)i * 3 + 2];
+            }
+        }
+        if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, A.fx, A.fy, A.cx, A.cy, R, t, sub, &errf);
+        else ok = lambdatwist_p4p<double>(yu, yv, xp, A.fx, A.fy, A.cx, A.cy, R, t, sub, &errd);
+    }
+    float aa[3] = { qnan, qnan, qnan };
+    if (ok) {
+        if (A.ref_svd) vrs_project_rotation(R); else nearest_rotation(R);
+        rotmat_to_angle_axis(R, aa, false);
+    }
+    // fold the four candidates in root order: the first valid one, then any later one with a strictly smaller 4th-point error (lambdatwist_p4p.h:43-58)
+    const int base = ln & ~3;
+    int win = -1;
+    double werr = 0.0;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int okc = __shfl((int)ok, base + c, 64);
+        const double ec = (SOLVER == 2) ? __shfl(errd, base + c, 64) : (double)__shfl(errf, base + c, 64);
+        if (okc && (win < 0 || werr > ec)) { win = c; werr = ec; }
+    }
+    const bool writer = (win < 0) ? (sub == 0) : (sub == win);  // no candidate: lane 0 writes the NaN marker
+    if (writer) {
+        const int n_poses = A.n_poses;
+        A.rvecs[idx] = aa[0]; A.rvecs[(size_t)n_poses + idx] = aa[1]; A.rvecs[(size_t)2 * n_poses + idx] = aa[2];
+        A.tvecs[idx] = ok ? t[0] : qnan; A.tvecs[(size_t)n_poses + idx] = ok ? t[1] : qnan; A.tvecs[(size_t)2 * n_poses + idx] = ok ? t[2] : qnan;
+    }
 }
 
 // ---- single-workgroup mode finding ---------------------------------------------------------------
@@ -1199,7 +1490,7 @@ __device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], i
 // THREADS: the per-iteration all-reduce, the mean update and the convergence test are executed by every wave (~100 instructions next
 // to ~30 per pair of hypotheses), so fewer, fatter waves do less redundant work: THREADS * SPT = PM_POOL.
 template <bool DEFER, int THREADS>
-__device__ __forceinline__ static void pose_mode_body(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
+__device__ __forceinline__ static void pose_mode_main(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
                                                       int n_poses, const ModeParams& mp, CamState* cam, PoseBlock* P, int cam_idx,
                                                       const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
 #pragma clang fp contract(fast)  // kernel-weighted sums: not part of the solver's exact-rounding contract (file-wide: off)
@@ -1419,6 +1710,20 @@ __device__ __forceinline__ static void pose_mode_body(const float* __restrict__ 
     }
     PH_MARK(22);
 }
+// pose_mode_main (every exit of which has written the camera record and, on the last camera, the truncation decision), then -- on the last camera of an
+// iteration whose fb_smooth rides in the pose half -- the projective maps of the depth half that follows and the world-scale factor (vk_cum_poses.hpp):
+// thread 0's stores (pose, n_active) are pushed out and the workgroup meets before anybody reads them back.
+template <bool DEFER, int THREADS>
+__device__ __forceinline__ static void pose_mode_body(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
+                                                      int n_poses, const ModeParams& mp, CamState* cam, PoseBlock* P, int cam_idx,
+                                                      const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
+    pose_mode_main<DEFER, THREADS>(rvecs, tvecs, n_poses, mp, cam, P, cam_idx, n_points_dev, trials_in);
+    if (mp.decide_n > 0 && mp.cum_N >= 0) {  // (uniform)
+        __threadfence();
+        __syncthreads();
+        cum_poses_block(P, mp.cum_N, mp.cum_Ndp, mp.world_scale);
+    }
+}
 template <bool DEFER, int THREADS>
 __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp, CamState* cam,
                                                                   PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
@@ -1618,10 +1923,7 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
     }
     const int st = (strict ? 1 : 0) | (ref_svd ? 2 : 0) | ((FROM_MAP && c->maps_block_compact) ? 4 : 0);
     const unsigned long long* vm = FROM_MAP ? c->valid_mask.as<unsigned long long>() : nullptr;
-    // fast window pipeline, float LambdaTwist: plain fp32 (vk_p3p_fast.hpp); strict mode and the host-pointer API keep the reference's rounding sequence
-    if (solver == 0 && FROM_MAP && !strict && !ref_rng && debug_switches().solve_fp32)
-        hipLaunchKernelGGL((k_solve<0, FROM_MAP, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, xw);
-    else if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, xw);
+    if (solver == 0) hipLaunchKernelGGL((k_solve<0, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, xw);
     else if (solver == 1) hipLaunchKernelGGL((k_solve<1, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, xw);
     else hipLaunchKernelGGL((k_solve<2, FROM_MAP>), g, b, lds, c->stream, pts2, pts3, rv, tv, n_pts_dev, bc, nb, cam, npx, fx, fy, cx, cy, n_poses, draw, st, offs, vm, xw);
     VK_CHECK_LAST();
@@ -1672,6 +1974,87 @@ int xorwow_pose_states_device(Context* c, int n_poses) {
     hipLaunchKernelGGL(k_xorwow_init, dim3((n_poses + 255) / 256), dim3(256), 0, c->stream, c->xw_pose_states.as<vrc_xorwow>(), c->xw_jumps.as<uint32_t>(), n_poses, 0u);
     VK_CHECK_LAST();
     c->xw_pose_n = n_poses;
+    return 0;
+}
+
+// ---- k_solve_fc launcher -------------------------------------------------------------------------------------------------------------------
+constexpr int FC_T_SMALL = 10, FC_T_LARGE = 16;  // blocks a solver workgroup finishes (template bound of k_solve_fc): 640x480 needs 9.4, 1241x376 14.3
+static int fc_solve_wgs(int n_poses) { return (n_poses * 4 + 255) / 256; }
+bool fused_eligible(Context* c, int w, int h, int n_poses, int solver) {
+    if (c->fused_broken || solver != 0 || n_poses < 64 || n_poses > PM_POOL) return false;
+    const int npx = w * h, nblk = (npx + 255) / 256, ns = fc_solve_wgs(n_poses);
+    if (nblk > FC_T_LARGE * ns) return false;  // larger images: the three-launch chain (their collect is throughput, not latency)
+    if (sizeof(int) * ((size_t)nblk + nblk / 32 + 1) > 40 * 1024) return false;
+    // the solver workgroups wait for each other: they must all fit the device at once (asked once per process; they are the first `ns` of the grid)
+    static const int fits = [] {
+        int a = 0, b = 0, dev = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_solve_fc<0, FC_T_SMALL, true>, 256, 12 * 1024) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_solve_fc<0, FC_T_LARGE, true>, 256, 12 * 1024) != hipSuccess) return 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        return (a < b ? a : b) * cus;
+    }();
+    return fits >= 2 * ns;  // (twice: two windows may be at it at once)
+}
+int solve_fused_device(Context* c, ImageSet& S, int N, int N_dp, int w, int h, int cam, bool finalize, bool prestage_next, const CollectParams& cp, float fx, float fy,
+                       float cx, float cy, int n_poses, bool ref_svd, CamState* cam_dev, int fb_kind, float fb_e0, float fb_p) {
+    const int npx = w * h, nblk = (npx + 255) / 256;
+    if (int e = c->p2_map.reserve(sizeof(float) * 2 * (size_t)npx)) return e;
+    if (int e = c->p3_map.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
+    if (int e = c->blk_counts.reserve(sizeof(int) * (size_t)nblk)) return e;
+    if (int e = c->ensure_n_points()) return e;
+    if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
+    if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
+    if (int e = c->fc_stage.reserve(sizeof(float) * 12 * (size_t)npx)) return e;
+    if (c->fc_cnt_tag.cap < sizeof(unsigned) * (size_t)nblk || c->fc_tag >= (1u << 23) - 2u) {  // fresh words, or the tag is about to wrap: no word may carry a tag of the coming launches
+        if (int e = c->fc_cnt_tag.reserve(sizeof(unsigned) * (size_t)nblk)) return e;
+        VK_CHECK(hipMemsetAsync(c->fc_cnt_tag.p, 0, c->fc_cnt_tag.cap, c->stream));
+        c->fc_tag = 0;
+    }
+    FcArgs A{};
+    A.flows = S.flows.as<float2>(); A.rig = S.rig.as<float>(); A.depth = S.depth.as<float>(); A.P = S.pb();
+    A.N = N; A.w = w; A.h = h; A.rig_thresh = cp.rig_thresh; A.rig_sum_thresh = cp.rig_sum_thresh; A.min_depth = cp.min_depth; A.max_depth = cp.max_depth; A.max_trace = cp.max_trace;
+    A.cam = cam; A.finalize = finalize ? 1 : 0; A.prestage_next = prestage_next ? 1 : 0;
+    float* st = c->fc_stage.as<float>();
+    A.stage_cur = st + (size_t)(cam & 1) * 6 * npx; A.stage_next = st + (size_t)((cam + 1) & 1) * 6 * npx;
+    A.p2_map = c->p2_map.as<float>(); A.p3_map = c->p3_map.as<float>(); A.cnt_tag = c->fc_cnt_tag.as<unsigned>(); A.blk_counts = c->blk_counts.as<int>(); A.nblk = nblk;
+    A.tag = ++c->fc_tag;
+    A.rvecs = c->rvecs.as<float>(); A.tvecs = c->tvecs.as<float>(); A.n_pts_dev = c->n_points.as<int>(); A.camrec = cam_dev;
+    A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.n_poses = n_poses; A.solver = 0; A.ref_svd = ref_svd ? 1 : 0;
+    A.n_solve_wg = fc_solve_wgs(n_poses); A.n_pre_wg = prestage_next ? nblk : 0;
+    A.fb_e0 = fb_e0; A.fb_p = fb_p; A.max_polls = 1u << 19; A.host_err = c->h_fc_err_dev;
+    int aux_wg = 0;
+    if (fb_kind) {
+        struct { const float* src; float* dst; int n; } stacks[2] = { { S.rig.as<float>(), S.rig2.as<float>(), N }, { S.confs.as<float>(), S.confs.as<float>(), N_dp } };
+        for (int j = 0; j < 2; j++) {
+            if (stacks[j].n <= 0) continue;
+            int rs = 20, cs = 20;
+            fb_smooth_plan(w, h, stacks[j].n, &rs, &cs);
+            FcAuxJob& J = A.aux[j];
+            J.kind = fb_kind; J.src = stacks[j].src; J.dst = stacks[j].dst; J.n_maps = stacks[j].n;
+            if (fb_kind == 1) {
+                if (rs != 20) return (int)hipErrorInvalidValue;  // (fb_overlap_ok: sizes of 20-step segments only)
+                J.S = (w + rs - 1) / rs;
+                const int lpb = 256 / J.S;
+                J.blocks_x = (h + lpb - 1) / lpb;
+                J.vec4 = ((w % 4) == 0 && (reinterpret_cast<uintptr_t>(J.src) % 16) == 0 && (reinterpret_cast<uintptr_t>(J.dst) % 16) == 0) ? 1 : 0;
+            } else {
+                if (cs != 20) return (int)hipErrorInvalidValue;
+                J.S = (h + cs - 1) / cs;
+                J.CW = 256 / J.S < 16 ? 256 / J.S : 16;
+                J.blocks_x = (w + J.CW - 1) / J.CW;
+            }
+            J.n_wg = J.blocks_x * J.n_maps;
+            aux_wg += J.n_wg;
+        }
+    }
+    const size_t lds = sizeof(int) * ((size_t)nblk + nblk / 32 + 1);
+    const dim3 g(A.n_solve_wg + A.n_pre_wg + aux_wg), b(256);
+    const bool small = nblk <= FC_T_SMALL * A.n_solve_wg;
+    if (aux_wg > 0) { if (small) hipLaunchKernelGGL((k_solve_fc<0, FC_T_SMALL, true>), g, b, lds, c->stream, A); else hipLaunchKernelGGL((k_solve_fc<0, FC_T_LARGE, true>), g, b, lds, c->stream, A); }
+    else { if (small) hipLaunchKernelGGL((k_solve_fc<0, FC_T_SMALL, false>), g, b, lds, c->stream, A); else hipLaunchKernelGGL((k_solve_fc<0, FC_T_LARGE, false>), g, b, lds, c->stream, A); }
+    c->n_map_blocks = nblk;
+    c->maps_block_compact = true;
+    VK_CHECK_LAST();
     return 0;
 }
 
