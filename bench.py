@@ -107,6 +107,8 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("VOLDOR_HIP_FORCE_DEVICE") is not None:  # tests: several ranks of a torchrun launch on ONE device (through the file-backed RCCL stand-in)
+        local_rank = int(os.environ["VOLDOR_HIP_FORCE_DEVICE"])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs a torch.distributed.run launch with {args.gpus} ranks (WORLD_SIZE={world})")

@@ -160,6 +160,128 @@ def test_capi_two_ranks_on_one_gpu_through_the_file_backed_stand_in(tmp_path):
         assert p.returncode == 0 and f"RANK_OK {r}" in so, (r, so[-1000:], se[-3000:])
 
 
+_EIGHT_RANK = r"""
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, {root!r})
+rank, world, path, fail_rank = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+from voldor_amd import capi, synth
+from voldor_amd import dist as vd
+lib = capi.lib()
+capi.check(lib.vk_set_device(0), "vk_set_device")            # all ranks on GPU 0: the stand-in stages through the host
+capi.check(lib.vk_dist_init_file(rank, world, path.encode(), 120), "vk_dist_init_file")
+assert lib.vk_dist_world() == world and lib.vk_dist_rank() == rank
+N, h, w = 3, 96, 128
+good = b"--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 2"
+bad = good + b" --resize_factor 0.5"                          # rejected by the window call: a LOCAL error
+seeds = list(range(233, 233 + 11))                             # eleven sequences over eight ranks: three ranks run two windows, five run one and send an empty record
+scenes = {{s: synth.make_scene(w=w, h=h, n_flows=N, fx=64, fy=64, cx=64, cy=48, seed=s) for s in seeds}}
+rcs = []
+def window(fn, seed, cfg, *tail):
+    poses = np.zeros((N, 6), np.float32); covar = np.zeros((N, 36), np.float32); n = C.c_int(0)
+    lib.vk_set_rand_epoch(0)
+    fl = scenes[seed]["flows"] if seed is not None else None
+    rc = fn(capi.fp(fl), None, None, None, None, None, C.c_float(64), C.c_float(64), C.c_float(64), C.c_float(48), C.c_float(0), N, 0, w, h, cfg,
+            C.byref(n), capi.fp(poses), capi.fp(covar), None, None, *tail)
+    return rc, n.value, poses, covar
+def step(seed):
+    blocks = np.zeros((world, 1 + 42 * N), np.float32)
+    rc, _, _, _ = window(lib.vk_voldor_sharded, seed, bad if (rank == fail_rank and seed is not None) else good, capi.fp(blocks))
+    rcs.append(rc)
+    return blocks
+try:
+    res = vd.capi_run_sharded(seeds, step, N)
+    assert fail_rank < 0, "a failed window must surface on every rank"
+    assert len(res) == len(seeds) and all(r is not None for r in res)
+    for s, r in zip(seeds[rank::world] + seeds[:2], [res[seeds.index(q)] for q in seeds[rank::world] + seeds[:2]]):   # own sequences + two of rank 0 / 1: equal to the one-at-a-time window
+        rc, n0, p0, c0 = window(lib.vk_voldor_device, s, good)
+        assert rc == 0 and r["n_registered"] == n0 == N and np.array_equal(r["poses"], p0[:n0]) and np.array_equal(r["poses_covar"].reshape(n0, 36), c0[:n0]), s
+    assert all(rc == 0 for rc in rcs)
+except RuntimeError as e:                                        # dist.py: a peer's VK_DIST_FAILED record is an error on EVERY rank, raised after the last step
+    assert fail_rank >= 0 and f"failed on rank {{fail_rank}}" in str(e), str(e)
+    assert all((rc != 0) == (rank == fail_rank) for rc in rcs[:1]), rcs   # the failing rank's own call returned its error, the others 0; nobody hung
+v = C.c_double(10.0 + rank); capi.check(lib.vk_dist_allreduce_max(C.byref(v)), "max"); assert v.value == 10.0 + world - 1
+capi.check(lib.vk_dist_barrier(), "barrier")
+lib.vk_dist_finalize()
+print("RANK_OK", rank)
+"""
+
+
+@pytest.mark.parametrize("fail_rank", [-1, 5])
+def test_capi_eight_ranks_on_one_gpu_through_the_stand_in(tmp_path, fail_rank):
+    """the world size the driver's scaling run uses.  Eight processes share GPU 0 through the file-backed stand-in: eleven
+    sequences over eight ranks (uneven shards, empty records in the second step), file rendezvous, max-over-ranks, barrier; and the same job
+    with rank 5's windows failing locally -- it still joins every all-gather, every rank learns which sequence failed where, nobody hangs.
+    (RCCL itself with N > 1 has still not run this code: that is the driver's 8-GPU run.)"""
+    from voldor_amd import build
+    build.build_test_lib()
+    fake = os.path.join(ROOT, "voldor_amd", "lib", "libfake_rccl_test.so")
+    env = dict(os.environ, VOLDOR_HIP_RCCL=fake, VOLDOR_HIP_JOB_ID=f"eight-{fail_rank}")
+    path = str(tmp_path / "id")
+    procs = [subprocess.Popen([sys.executable, "-c", _EIGHT_RANK.format(root=ROOT), str(r), "8", path, str(fail_rank)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              cwd=ROOT, env=env) for r in range(8)]
+    outs = [p.communicate(timeout=900) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"RANK_OK {r}" in so, (r, so[-1000:], se[-3000:])
+
+
+def test_file_rendezvous_times_out_instead_of_waiting_forever(tmp_path):
+    """A rank whose rank 0 never shows up gets an error from vk_dist_init_file after the timeout it asked for (a launcher can then fail the job)."""
+    code = r"""
+import sys, time
+sys.path.insert(0, {root!r})
+from voldor_amd import capi
+lib = capi.lib()
+capi.check(lib.vk_set_device(0), "vk_set_device")
+t0 = time.time()
+rc = lib.vk_dist_init_file(1, 2, sys.argv[1].encode(), 3)
+assert rc != 0 and 2.0 < time.time() - t0 < 30.0, (rc, time.time() - t0)
+assert lib.vk_dist_world() == 0
+print("TIMEOUT_OK")
+"""
+    r = subprocess.run([sys.executable, "-c", code.format(root=ROOT), str(tmp_path / "never")], capture_output=True, text=True, cwd=ROOT, timeout=300)
+    assert r.returncode == 0 and "TIMEOUT_OK" in r.stdout, (r.stdout[-1000:], r.stderr[-2000:])
+
+
+def test_bench_with_eight_ranks_on_one_gpu_through_the_stand_in():
+    """bench.py's whole N = 8 flow as the driver launches it (`--gpus 8`, RANK 0..7, env:// rendezvous), all ranks on GPU 0 through the stand-in:
+    the line carries n_gpus 8, the exchange object with 8-rank all-gathers, the per-GPU rate; ranks 1..7 print nothing."""
+    from voldor_amd import build
+    build.build_test_lib()
+    fake = os.path.join(ROOT, "voldor_amd", "lib", "libfake_rccl_test.so")
+    procs = []
+    for r in range(8):
+        env = dict(os.environ, VOLDOR_HIP_RCCL=fake, RANK=str(r), WORLD_SIZE="8", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29549")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--in-flight", "0", "--no-workloads"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, cwd=ROOT, env=env))
+    outs = [p.communicate(timeout=1500) for p in procs]
+    for r, (p, (so, se)) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, (r, so[-500:], se[-3000:])
+    j = _line(outs[0][0])
+    assert j["n_gpus"] == 8 and j["n_registered"] == 5 and j["value"] > 5 and "x8" in j["config"]["parallelism"] and "fell back" not in j["config"]["parallelism"]
+    ex = j["exchange"]
+    assert ex["samples"] == 2 and "8 ranks" in ex["collective"] and abs(ex["per_gpu_frames_per_s"] * 8 - j["value"]) < 0.01 * j["value"]
+    for r in range(1, 8):
+        assert not [ln for ln in outs[r][0].splitlines() if ln.startswith("{")]
+
+
+def test_bench_under_torchrun_with_eight_ranks_on_one_gpu():
+    """The driver's own launch line -- python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 ... bench.py --gpus 8 -- with the eight ranks pinned to
+    GPU 0 (VOLDOR_HIP_FORCE_DEVICE) and the stand-in for RCCL: torchrun's agent store hands rank 0's id to the others (no second bind of MASTER_PORT), every
+    rank agrees on the C-ABI front end, the timed steps run, rank 0 prints the line."""
+    from voldor_amd import build
+    build.build_test_lib()
+    fake = os.path.join(ROOT, "voldor_amd", "lib", "libfake_rccl_test.so")
+    env = dict(os.environ, VOLDOR_HIP_RCCL=fake, VOLDOR_HIP_FORCE_DEVICE="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29551",
+                        os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--in-flight", "0", "--no-workloads"],
+                       capture_output=True, text=True, cwd=ROOT, env=env, timeout=1800)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    j = _line(r.stdout)
+    assert j["n_gpus"] == 8 and j["n_registered"] == 5 and "x8" in j["config"]["parallelism"] and "fell back" not in j["config"]["parallelism"], j["config"]
+    assert j["exchange"]["samples"] == 2
+
+
 _FAILING_RANK = r"""
 import ctypes as C, os, sys
 import numpy as np

@@ -65,13 +65,13 @@ __global__ __launch_bounds__(256) static void k_fb_rows(const float* maps, float
         return;
     }
     if (n_dev && (int)blockIdx.y >= *n_dev) return;  // map of a frame the device-side decision has dropped
-    fb_rows_body<VEC4, FB_SEG>(maps, maps_out, w, h, S, e0, p, blockIdx.x, blockIdx.y, &sF[0][0], &sB[0][0]);
+    fb_rows_body<VEC4, FB_SEG>(maps, maps_out, w, h, S, e0, p, blockIdx.x, blockIdx.y, &sF[0][0], &sB[0][0], threadIdx.x);
 }
 template <int FB_SEG>
 __global__ __launch_bounds__(1024) static void k_fb_cols(float* __restrict__ maps, int w, int h, int S, float e0, float p, const int* __restrict__ n_dev) {
     __shared__ FbMat sF[1024], sB[1024];
     if (n_dev && (int)blockIdx.y >= *n_dev) return;
-    fb_cols_body<FB_SEG>(maps, w, h, S, FB_CW, e0, p, blockIdx.x, blockIdx.y, sF, sB);
+    fb_cols_body<FB_SEG>(maps, w, h, S, FB_CW, e0, p, blockIdx.x, blockIdx.y, sF, sB, threadIdx.x);
 }
 
 template <int SEG>

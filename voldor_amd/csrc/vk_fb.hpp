@@ -139,12 +139,14 @@ __device__ __forceinline__ void fb_incoming_scan(FbMat* sF, FbMat* sB, int nt /*
 }
 
 // Row pass: thread = (row, segment), segments of a row on adjacent lanes -> a wave reads whole contiguous row
-// pieces (160 bytes per lane).  256 threads = floor(256/S) rows.  (bx, by) = (row block, map); called by ALL 256 threads of the workgroup
-// (barriers); sF / sB: [2][256] each.  maps_out == maps: in place.
+// pieces (160 bytes per lane).  256 threads = floor(256/S) rows.  (bx, by) = (row block, map); called by ALL threads of the workgroup (barriers): a
+// 256-thread workgroup (tid = threadIdx.x), or the two 256-thread halves of a 512-thread one, each with its own block, tid = threadIdx.x & 255 and its
+// own sF / sB ([2][256] each).  A block past the job (bx * lpb >= h; by any valid map) takes part in the barriers and does nothing else.
+// maps_out == maps: in place.
 struct __attribute__((packed, aligned(4))) FbQuad { float x, y, z, w; };  // 16 bytes at 4-byte alignment: one global_load_dwordx4 on gfx950
 template <bool VEC4, int FB_SEG>
-__device__ __forceinline__ void fb_rows_body(const float* maps, float* maps_out, int w, int h, int S, float e0, float p, int bx, int by, FbMat* sF, FbMat* sB) {
-    const int lpb = 256 / S, tid = threadIdx.x;
+__device__ __forceinline__ void fb_rows_body(const float* maps, float* maps_out, int w, int h, int S, float e0, float p, int bx, int by, FbMat* sF, FbMat* sB, int tid) {
+    const int lpb = 256 / S;
     const int ll = tid / S, seg = tid - ll * S, row = bx * lpb + ll;
     const bool live = ll < lpb && row < h;
     const int c0 = seg * FB_SEG, n = live ? min(FB_SEG, w - c0) : 0;
@@ -200,8 +202,8 @@ __device__ __forceinline__ void fb_rows_body(const float* maps, float* maps_out,
 // a workgroup uses CW * S threads (the own launch: CW = 16, up to 64 segments; as extra workgroups of a 256-thread launch: CW = 256 / S columns).
 // (bx, by) = (column block, map); called by ALL threads of the workgroup (one barrier; threads beyond CW * S idle); sF / sB: [CW * S] each.
 template <int FB_SEG>
-__device__ __forceinline__ void fb_cols_body(float* __restrict__ maps, int w, int h, int S, int CW, float e0, float p, int bx, int by, FbMat* sF, FbMat* sB) {
-    const int tid = threadIdx.x, seg = tid / CW, cl = tid - seg * CW, col = bx * CW + cl;
+__device__ __forceinline__ void fb_cols_body(float* __restrict__ maps, int w, int h, int S, int CW, float e0, float p, int bx, int by, FbMat* sF, FbMat* sB, int tid) {
+    const int seg = tid / CW, cl = tid - seg * CW, col = bx * CW + cl;
     const bool live = seg < S && col < w;
     const int r0 = seg * FB_SEG, n = live ? min(FB_SEG, h - r0) : 0;
     float* m = maps + (size_t)by * w * h + (live ? col : 0);

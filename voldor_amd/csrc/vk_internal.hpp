@@ -101,14 +101,18 @@ int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, fl
 int xorwow_jumps_device(Context* c);                              // c->xw_jumps ready
 int xorwow_pixel_states_device(Context* c, int npx, uint32_t epoch);  // c->xw_px_states = states `epoch` draws after curand_init(RAND_SEED, pixel, 0)
 int xorwow_pose_states_device(Context* c, int n_poses);           // c->xw_pose_states = states after curand_init(RAND_SEED, idx, 0)
-int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first = false);
+// round 5: what rides in a mode kernel's launch on the compute units the mode kernel leaves idle (vk_pose.hip ModeAux, opaque here)
+struct ModeAuxPlan { alignas(8) unsigned char bytes[256]; int n_wg = 0; bool has_fb = false; };
+int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first = false, const ModeAuxPlan* plan = nullptr);
 // round 5 (k_solve_fc): the P3P batch of camera `cam` in a launch that first finishes the camera's correspondences from the staged trace (finalize; camera 0: k_collect
-// has written them), traces camera cam + 1 in extra workgroups (prestage_next) and carries fb_smooth passes along (fb_kind: 0 none, 1 rows rig -> rig2 and confs, 2
-// columns on rig2 and confs).  fused_eligible: the launch exists for this window (else the three-launch chain).
+// has written them).  mode_aux_plan: what rides in the launch of camera `cam`'s mode kernel -- the trace of camera cam + 1 (prestage_next) and fb_smooth blocks (fb_kind: 0
+// none, 1 rows rig -> rig2 and the prior confidences, 2 columns on rig2 and the prior confidences).  fused_eligible: the launches exist for this window (else the
+// three-launch chain).
 struct CollectParams { float rig_thresh, rig_sum_thresh, min_depth, max_depth; int max_trace; };
 bool fused_eligible(Context* c, int w, int h, int n_poses, int solver);
-int solve_fused_device(Context* c, ImageSet& S, int N, int N_dp, int w, int h, int cam, bool finalize, bool prestage_next, const CollectParams& cp, float fx, float fy,
-                       float cx, float cy, int n_poses, bool ref_svd, CamState* cam_dev, int fb_kind, float fb_e0, float fb_p);
+int solve_fused_device(Context* c, ImageSet& S, int w, int h, int cam, bool finalize, float min_depth, float max_depth, float fx, float fy, float cx, float cy, int n_poses, bool ref_svd,
+                       CamState* cam_dev);
+int mode_aux_plan(Context* c, ImageSet& S, int N, int N_dp, int w, int h, int cam, bool prestage_next, const CollectParams& cp, int fb_kind, float fb_e0, float fb_p, ModeAuxPlan* out);
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 

@@ -475,125 +475,154 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
 // nearly all of it does NOT depend on the pose the previous camera's mode kernel has just produced: the pixel of camera a is traced through the
 // flows of frames start .. a from the projection of its 3-D point in frame `start`, which needs the poses 0 .. start - 1 <= a - 2 unless the trace
 // is one frame long; pose a - 1 only enters through the last rigid transform of the 3-D point (and through the projection of a one-frame trace).  So:
-//   * the launch that solves camera a's hypotheses carries EXTRA workgroups that trace camera a + 1's pixels as far as pose a - 1... no further --
-//     "prestage": validity of depth and rigidness, 3-D point in frame a coordinates (transforms 0 .. a - 1), flow trace where it does not need pose a;
-//     per pixel { flag, px, py, o } to a staging buffer -- concurrently with the P3P chains, which occupy half a wave per SIMD and no bandwidth;
-//   * the launch of camera a + 1 starts by FINISHING those pixels in the workgroups that will solve: last transform, projection + one gather for the
-//     one-frame traces ("late" pixels), validity, ordered compaction inside each 256-pixel block -- exactly k_collect<true>'s values and layout --
-//     then the workgroups MEET in the block counts: a count and the launch's tag in one 32-bit word (count | tag << 9, agent-scope store after the
-//     block's correspondences are out: sc1 stores + s_waitcnt), every solver workgroup reads all words until each carries the tag (the same words it
-//     needs for the rank select's prefix anyway: the meeting costs one memory round trip), and solves.
-// Per camera: (collect 8.6 + boundary 2.85) -> ~4 us of finishing + meeting.  The meeting is among the 128 solver workgroups only (the first 128 of
-// the grid: dispatched first, 4 waves and < 128 VGPRs each -- resident at once on any free eighth of the chip); the spin is bounded, a timeout raises
-// a flag in pinned host memory and the window is run again on the three-launch chain (vk_voldor.hip).
-// The same launches carry fb_smooth of the depth half that follows (vk_debug_switch "fb_overlap"): its row pass as extra workgroups of camera 0's
-// launch, its column pass of camera 1's -- out of place (ImageSet::rig2), the pose half still reads the raw maps.
-struct FcAuxJob {  // one fb_smooth pass over a stack of maps as extra workgroups (vk_fb.hpp)
-    int kind;      // 0 none, 1 row pass src -> dst, 2 column pass in place on dst
-    const float* src; float* dst;
-    int n_maps, S, CW, vec4, blocks_x, n_wg;
-};
+//   * the MODE kernel's launch of camera a (one workgroup of 512 threads on one compute unit, 255 idle) carries extra workgroups that trace camera
+//     a + 1's pixels as far as the poses 0 .. a - 1 take them -- "prestage" (mode_prestage): validity of depth and rigidness, 3-D point in frame a
+//     coordinates, the flow trace where it does not need pose a; per pixel { flag, px, py, o } to a staging buffer.  Four pixels per lane, their
+//     gathers in flight together: the launch is compiled for the mode kernel's 256 registers, which buys memory-level parallelism per wave instead
+//     of waves (a first form with these workgroups in the P3P launch -- 150 registers, three waves per SIMD, the P3P chains on the same SIMDs --
+//     took 40 us against 8.6 + 17.7: profiles/r05c_*);
+//   * the P3P launch of camera a + 1 (k_solve_fc) starts by FINISHING those pixels in the workgroups that will solve: last transform, projection + one
+//     gather for the one-frame traces ("late" pixels), validity, ordered compaction inside each 256-pixel block -- exactly k_collect<true>'s values and
+//     layout -- then the workgroups MEET in the block counts: a count and the launch's tag in one 32-bit word (count | tag << 9, agent-scope store
+//     after the block's correspondences are out: write-through stores + s_waitcnt), every solver workgroup reads all words until each carries the tag
+//     (the same words it needs for the rank select's prefix anyway: the meeting costs one memory round trip), and solves.
+// Per camera: collect 8.6 + boundary 2.85 -> a few microseconds of finishing + meeting.  The meeting is among the 128 solver workgroups only (4 waves
+// and < 128 VGPRs... each -- resident at once on any free part of the chip); the spin is bounded, a timeout raises a flag in pinned host memory and the
+// window is run again on the three-launch chain (vk_voldor.hip).
+// The mode kernels' launches also carry fb_smooth of the depth half that follows (vk_debug_switch "fb_overlap"): its row pass with camera 0's, its
+// column pass with camera 1's -- out of place (ImageSet::rig2), the pose half still reads the raw maps.
 struct FcArgs {
-    const float2* flows; const float* rig; const float* depth; const PoseBlock* P;
-    int N, w, h; float rig_thresh, rig_sum_thresh, min_depth, max_depth; int max_trace;
-    int cam, finalize, prestage_next;
-    float* stage_cur; float* stage_next;  // [6][npx] planes: flag, px, py, o.x, o.y, o.z
+    const float2* flows; const PoseBlock* P;
+    int w, h; float min_depth, max_depth;
+    int cam, finalize;
+    const float* stage;  // [6][npx] planes: flag, px, py, o.x, o.y, o.z (mode_prestage)
     float* p2_map; float* p3_map; unsigned* cnt_tag; const int* blk_counts; int nblk; unsigned tag;
-    float* rvecs; float* tvecs; int* n_pts_dev; CamState* camrec; float fx, fy, cx, cy; int n_poses, solver, ref_svd;
-    int n_solve_wg, n_pre_wg;
-    FcAuxJob aux[2]; float fb_e0, fb_p;
+    float* rvecs; float* tvecs; int* n_pts_dev; CamState* camrec; float fx, fy, cx, cy; int n_poses, ref_svd;
+    int n_solve_wg;
     unsigned max_polls; int* host_err;
 };
 __device__ __forceinline__ float ld_coh(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_coh(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// camera a's pixel pi as far as the poses 0 .. a - 2 take it (collect_p3p_instances.cu:70-145, the operations of k_collect in their order)
-__device__ __forceinline__ void fc_prestage_pixel(const FcArgs& A, int a, int pi, float& flag, float& px, float& py, P3& o) {
-    const int w = A.w, h = A.h, npx = w * h, N = A.N;
+// What rides in a mode kernel's launch (workgroups 1 ..): the next camera's prestage, then fb_smooth blocks two per workgroup
+struct PreArgs { const float2* flows; const float* rig; const float* depth; const PoseBlock* P; int N, w, h; float rig_thresh, rig_sum_thresh, min_depth, max_depth; int max_trace, cam; float* stage; int n_wg; };
+struct FbJob { int kind /* 0 none, 1 rows src -> dst, 2 columns in place on dst */; const float* src; float* dst; int n_maps, S, CW, vec4, blocks_x, n_blocks; };
+struct ModeAux { PreArgs pre; FbJob fb[2]; float fb_e0, fb_p; int n_fb_wg; };
+constexpr int PRE_K = 4;  // pixels per lane of the prestage
+
+// Camera a's pixels as far as the poses 0 .. a - 2 take them (collect_p3p_instances.cu:70-145: the operations of k_collect, in its order per pixel),
+// PRE_K pixels per lane side by side: workgroup r takes pixels [r * PRE_K * 512, (r + 1) * PRE_K * 512), pixel (r * PRE_K + k) * 512 + tid in slot k.
+__device__ __forceinline__ void mode_prestage(const PreArgs& A, int r) {
+    constexpr int K = PRE_K;
+    const int w = A.w, h = A.h, npx = w * h, a = A.cam, N = A.N, tid = threadIdx.x;
     const PoseBlock* P = A.P;
-    flag = 0.f; px = 0.f; py = 0.f; o = { 0.f, 0.f, 0.f };
-    const int x = pi % w, y = pi / w;
-    const float d = A.depth[pi];
-    const float rig_a = A.rig[(size_t)a * npx + pi];
-    bool ok = !(d < A.min_depth || (A.max_depth > 0.f && d > A.max_depth));
-    if (ok && A.rig_sum_thresh > (float)(N + 1)) {  // inert unless thr > N+1 (sic, :88-90)
-        float rs = 0.f;
-        for (int i = 0; i < N; i++) rs += A.rig[(size_t)i * npx + pi];
-        if (rs < A.rig_sum_thresh) ok = false;
+    int pi[K];
+    bool ok[K];
+    float d[K], rg[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        pi[k] = (r * K + k) * 512 + tid;
+        const bool in = pi[k] < npx;
+        if (!in) pi[k] = 0;
+        d[k] = A.depth[pi[k]]; rg[k] = A.rig[(size_t)a * npx + pi[k]];
+        ok[k] = in;
     }
-    int n_trace = 0;
-    if (ok) {
-        float prod = 1.f;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        ok[k] = ok[k] && !(d[k] < A.min_depth || (A.max_depth > 0.f && d[k] > A.max_depth));
+        if (ok[k] && A.rig_sum_thresh > (float)(N + 1)) {  // inert unless thr > N+1 (sic, :88-90)
+            float rs = 0.f;
+            for (int i = 0; i < N; i++) rs += A.rig[(size_t)i * npx + pi[k]];
+            if (rs < A.rig_sum_thresh) ok[k] = false;
+        }
+    }
+    int n_trace[K];
+    {
+        float prod[K];
+        bool go[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) { n_trace[k] = 0; prod[k] = 1.f; go[k] = ok[k]; }
         const int lo = A.max_trace > 0 ? max(0, a - A.max_trace + 1) : 0;
         for (int i = a; i >= lo; i--) {
-            prod *= i == a ? rig_a : A.rig[(size_t)i * npx + pi];
-            if (prod > A.rig_thresh) n_trace++;
-            else break;
+            float rv[K];
+#pragma unroll
+            for (int k = 0; k < K; k++) rv[k] = i == a ? rg[k] : A.rig[(size_t)i * npx + pi[k]];  // (k_collect reads a factor only while the product is alive: same values where they are used)
+#pragma unroll
+            for (int k = 0; k < K; k++)
+                if (go[k]) { prod[k] *= rv[k]; if (prod[k] > A.rig_thresh) n_trace[k]++; else go[k] = false; }
         }
-        ok = n_trace > 0;
+#pragma unroll
+        for (int k = 0; k < K; k++) ok[k] = ok[k] && n_trace[k] > 0;
     }
-    if (!ok) return;
-    o = backproject(P, (float)x, (float)y, d);
-    const int start = a - n_trace + 1;
-    bool out = false;
-    float qx = 0.f, qy = 0.f;
+    P3 o[K];
+    float qx[K], qy[K];
+    int start[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        o[k] = backproject(P, (float)(pi[k] % w), (float)(pi[k] / w), d[k]);
+        start[k] = a - n_trace[k] + 1; qx[k] = 0.f; qy[k] = 0.f;
+    }
     for (int i = 0; i < a; i++) {  // frames 0 .. a - 1: their trace steps, and the transforms 0 .. a - 2 (transform a - 1 waits for its pose)
-        if (i >= start) {
-            if (i == start) project(P, o, qx, qy);
-            if (qx > 0.f && qx < (float)w && qy > 0.f && qy < (float)h) {  // strict (:120)
-                const float2 f2 = bilinear2(A.flows + (size_t)i * npx, w, h, qx, qy);
-                qx += f2.x; qy += f2.y;
-            } else { out = true; break; }
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (ok[k] && i >= start[k]) {
+                if (i == start[k]) project(P, o[k], qx[k], qy[k]);
+                if (qx[k] > 0.f && qx[k] < (float)w && qy[k] > 0.f && qy[k] < (float)h) {  // strict (:120)
+                    const float2 f2 = bilinear2(A.flows + (size_t)i * npx, w, h, qx[k], qy[k]);
+                    qx[k] += f2.x; qy[k] += f2.y;
+                } else ok[k] = false;  // out of the image: the pixel is dropped
+            }
         }
-        if (i < a - 1) o = transform(P->Rs[i], P->ts[i], o);
+        if (i < a - 1) {
+#pragma unroll
+            for (int k = 0; k < K; k++) o[k] = transform(P->Rs[i], P->ts[i], o[k]);
+        }
     }
-    if (out) return;
-    if (start <= a - 1) {  // frame a's own trace step continues from a known position: it does not see pose a - 1
-        if (qx > 0.f && qx < (float)w && qy > 0.f && qy < (float)h) {
-            const float2 f2 = bilinear2(A.flows + (size_t)a * npx, w, h, qx, qy);
-            qx += f2.x; qy += f2.y;
-            flag = 1.f; px = qx; py = qy;
+    float* st = A.stage;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        float flag = 0.f;
+        if (ok[k]) {
+            if (start[k] <= a - 1) {  // frame a's own trace step continues from a known position: it does not see pose a - 1
+                if (qx[k] > 0.f && qx[k] < (float)w && qy[k] > 0.f && qy[k] < (float)h) {
+                    const float2 f2 = bilinear2(A.flows + (size_t)a * npx, w, h, qx[k], qy[k]);
+                    qx[k] += f2.x; qy[k] += f2.y;
+                    flag = 1.f;
+                }
+            } else flag = 2.f;  // a one-frame trace: the projection of the point in frame a, hence pose a - 1, comes first ("late")
         }
-    } else flag = 2.f;  // a one-frame trace: the projection of the point in frame a, hence pose a - 1, comes first ("late")
+        const int q = (r * K + k) * 512 + tid;
+        if (q < npx) {
+            st[q] = flag; st[(size_t)npx + q] = qx[k]; st[(size_t)2 * npx + q] = qy[k];
+            st[(size_t)3 * npx + q] = o[k].x; st[(size_t)4 * npx + q] = o[k].y; st[(size_t)5 * npx + q] = o[k].z;
+        }
+    }
+}
+// fb_smooth blocks riding in the (non-refit) mode kernel's launch: workgroup q of the fb range takes blocks 2 q and 2 q + 1 of the two jobs laid end
+// to end, one per 256-thread half (each half with its own LDS; both halves run the same kind of pass: the same barriers)
+__device__ __forceinline__ void mode_fb(const ModeAux& M, int q, int w, int h) {
+    __shared__ FbMat s_fb[2][4][256];  // [half][sF 2 x 256 | sB 2 x 256]
+    const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    int b = 2 * q + half;
+    const FbJob* J = &M.fb[0];
+    if (M.fb[0].kind && b >= M.fb[0].n_blocks && M.fb[1].kind) { b -= M.fb[0].n_blocks; J = &M.fb[1]; }
+    else if (!M.fb[0].kind) J = &M.fb[1];
+    // (a block index past its job: bx lands past the image, the half keeps the barriers company)
+    const int bx = b < J->n_blocks ? b % J->blocks_x : (1 << 20), by = b < J->n_blocks ? b / J->blocks_x : 0;
+    FbMat* sF = &s_fb[half][0][0]; FbMat* sB = &s_fb[half][2][0];
+    if (J->kind == 1) {
+        if (J->vec4) fb_rows_body<true, 20>(J->src, J->dst, w, h, J->S, M.fb_e0, M.fb_p, bx, by, sF, sB, tid);
+        else fb_rows_body<false, 20>(J->src, J->dst, w, h, J->S, M.fb_e0, M.fb_p, bx, by, sF, sB, tid);
+    } else fb_cols_body<20>(J->dst, w, h, J->S, J->CW, M.fb_e0, M.fb_p, bx, by, sF, sB, tid);
 }
 
-// FB: the instantiation that can carry fb_smooth workgroups (cameras 0 and 1 of an iteration: 150 VGPRs and 16 KB of LDS per workgroup against 137 and none)
-template <int SOLVER, int TMAX, bool FB>
+template <int SOLVER, int TMAX>
 __global__ __launch_bounds__(256) static void k_solve_fc(FcArgs A) {
     extern __shared__ int s_pref[];
     __shared__ int s_cnt[TMAX][4];
     __shared__ int s_flag;
-    __shared__ FbMat s_fb[FB ? 4 : 1][FB ? 256 : 1];  // (fb_smooth workgroups: sF[2][256], sB[2][256])
     const int bid = blockIdx.x, tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
     const int w = A.w, h = A.h, npx = w * h;
-    if (bid >= A.n_solve_wg) {
-        int r = bid - A.n_solve_wg;
-        if (r < A.n_pre_wg) {  // ---- trace the next camera's pixels as far as the known poses go
-            const int tile = xcd_band_tile(r, A.n_pre_wg), pi = tile * 256 + tid;
-            if (pi >= npx) return;
-            float flag, px, py; P3 o;
-            fc_prestage_pixel(A, A.cam + 1, pi, flag, px, py, o);
-            float* st = A.stage_next;
-            st[pi] = flag; st[(size_t)npx + pi] = px; st[(size_t)2 * npx + pi] = py;
-            st[(size_t)3 * npx + pi] = o.x; st[(size_t)4 * npx + pi] = o.y; st[(size_t)5 * npx + pi] = o.z;
-            return;
-        }
-        r -= A.n_pre_wg;
-        // ---- fb_smooth of the depth half that follows, riding along (20-step segments only: the sizes this launch exists for)
-        auto run_aux = [&](const FcAuxJob& J, int q) {
-            const int bx = q % J.blocks_x, by = q / J.blocks_x;
-            if (J.kind == 1) {
-                if (J.vec4) fb_rows_body<true, 20>(J.src, J.dst, w, h, J.S, A.fb_e0, A.fb_p, bx, by, &s_fb[0][0], &s_fb[2][0]);
-                else fb_rows_body<false, 20>(J.src, J.dst, w, h, J.S, A.fb_e0, A.fb_p, bx, by, &s_fb[0][0], &s_fb[2][0]);
-            } else fb_cols_body<20>(J.dst, w, h, J.S, J.CW, A.fb_e0, A.fb_p, bx, by, &s_fb[0][0], &s_fb[2][0]);
-        };
-        if constexpr (FB) {
-            if (A.aux[0].kind && r < A.aux[0].n_wg) { run_aux(A.aux[0], r); return; }
-            if (A.aux[0].kind) r -= A.aux[0].n_wg;
-            if (A.aux[1].kind && r < A.aux[1].n_wg) run_aux(A.aux[1], r);
-        }
-        return;
-    }
     // ---- solver workgroup
     const PoseBlock* P = A.P;
     const int nblk = A.nblk;
@@ -601,7 +630,7 @@ __global__ __launch_bounds__(256) static void k_solve_fc(FcArgs A) {
     if (A.finalize) {
         // (1) finish this camera's correspondences for blocks bid, bid + n_solve_wg, ..: everything of a block's pixels in flight together
         const int a = A.cam;
-        const float* st = A.stage_cur;
+        const float* st = A.stage;
         float fl[TMAX], px[TMAX], py[TMAX], ox[TMAX], oy[TMAX], oz[TMAX];
 #pragma unroll
         for (int k = 0; k < TMAX; k++) {
@@ -1726,7 +1755,13 @@ __device__ __forceinline__ static void pose_mode_body(const float* __restrict__ 
 }
 template <bool DEFER, int THREADS>
 __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp, CamState* cam,
-                                                                  PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
+                                                                  PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev, const float* __restrict__ trials_in, ModeAux aux) {
+    if (blockIdx.x > 0) {  // round 5: what rides along on the 255 compute units the mode kernel leaves idle (workgroup 0 is the mode kernel itself)
+        const int r = (int)blockIdx.x - 1;
+        if (r < aux.pre.n_wg) mode_prestage(aux.pre, r);
+        else if constexpr (!DEFER && THREADS == 512) { if (r - aux.pre.n_wg < aux.n_fb_wg) mode_fb(aux, r - aux.pre.n_wg, aux.pre.w, aux.pre.h); }
+        return;
+    }
     pose_mode_body<DEFER, THREADS>(rvecs, tvecs, n_poses, mp, cam, P, cam_idx, n_points_dev, trials_in);
 }
 // The initial-mode trials of a camera that has no pose yet (first EM iteration; meanshift.cu:72-95: the kernel density at up to
@@ -1984,19 +2019,20 @@ bool fused_eligible(Context* c, int w, int h, int n_poses, int solver) {
     if (c->fused_broken || solver != 0 || n_poses < 64 || n_poses > PM_POOL) return false;
     const int npx = w * h, nblk = (npx + 255) / 256, ns = fc_solve_wgs(n_poses);
     if (nblk > FC_T_LARGE * ns) return false;  // larger images: the three-launch chain (their collect is throughput, not latency)
+    if ((npx + PRE_K * 512 - 1) / (PRE_K * 512) > 240) return false;  // the prestage workgroups of a mode kernel's launch: one per compute unit (256 registers per lane)
     if (sizeof(int) * ((size_t)nblk + nblk / 32 + 1) > 40 * 1024) return false;
-    // the solver workgroups wait for each other: they must all fit the device at once (asked once per process; they are the first `ns` of the grid)
+    // the solver workgroups wait for each other: they must all fit the device at once (asked once per process)
     static const int fits = [] {
         int a = 0, b = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_solve_fc<0, FC_T_SMALL, true>, 256, 12 * 1024) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_solve_fc<0, FC_T_LARGE, true>, 256, 12 * 1024) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_solve_fc<0, FC_T_SMALL>, 256, 12 * 1024) != hipSuccess) return 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_solve_fc<0, FC_T_LARGE>, 256, 12 * 1024) != hipSuccess) return 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
         return (a < b ? a : b) * cus;
     }();
     return fits >= 2 * ns;  // (twice: two windows may be at it at once)
 }
-int solve_fused_device(Context* c, ImageSet& S, int N, int N_dp, int w, int h, int cam, bool finalize, bool prestage_next, const CollectParams& cp, float fx, float fy,
-                       float cx, float cy, int n_poses, bool ref_svd, CamState* cam_dev, int fb_kind, float fb_e0, float fb_p) {
+int solve_fused_device(Context* c, ImageSet& S, int w, int h, int cam, bool finalize, float min_depth, float max_depth, float fx, float fy, float cx, float cy, int n_poses, bool ref_svd,
+                       CamState* cam_dev) {
     const int npx = w * h, nblk = (npx + 255) / 256;
     if (int e = c->p2_map.reserve(sizeof(float) * 2 * (size_t)npx)) return e;
     if (int e = c->p3_map.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
@@ -2004,62 +2040,85 @@ int solve_fused_device(Context* c, ImageSet& S, int N, int N_dp, int w, int h, i
     if (int e = c->ensure_n_points()) return e;
     if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
-    if (int e = c->fc_stage.reserve(sizeof(float) * 12 * (size_t)npx)) return e;
+    if (int e = c->fc_stage.reserve(sizeof(float) * 6 * (size_t)npx)) return e;
     if (c->fc_cnt_tag.cap < sizeof(unsigned) * (size_t)nblk || c->fc_tag >= (1u << 23) - 2u) {  // fresh words, or the tag is about to wrap: no word may carry a tag of the coming launches
         if (int e = c->fc_cnt_tag.reserve(sizeof(unsigned) * (size_t)nblk)) return e;
         VK_CHECK(hipMemsetAsync(c->fc_cnt_tag.p, 0, c->fc_cnt_tag.cap, c->stream));
         c->fc_tag = 0;
     }
     FcArgs A{};
-    A.flows = S.flows.as<float2>(); A.rig = S.rig.as<float>(); A.depth = S.depth.as<float>(); A.P = S.pb();
-    A.N = N; A.w = w; A.h = h; A.rig_thresh = cp.rig_thresh; A.rig_sum_thresh = cp.rig_sum_thresh; A.min_depth = cp.min_depth; A.max_depth = cp.max_depth; A.max_trace = cp.max_trace;
-    A.cam = cam; A.finalize = finalize ? 1 : 0; A.prestage_next = prestage_next ? 1 : 0;
-    float* st = c->fc_stage.as<float>();
-    A.stage_cur = st + (size_t)(cam & 1) * 6 * npx; A.stage_next = st + (size_t)((cam + 1) & 1) * 6 * npx;
+    A.flows = S.flows.as<float2>(); A.P = S.pb();
+    A.w = w; A.h = h; A.min_depth = min_depth; A.max_depth = max_depth;
+    A.cam = cam; A.finalize = finalize ? 1 : 0;
+    A.stage = c->fc_stage.as<float>();
     A.p2_map = c->p2_map.as<float>(); A.p3_map = c->p3_map.as<float>(); A.cnt_tag = c->fc_cnt_tag.as<unsigned>(); A.blk_counts = c->blk_counts.as<int>(); A.nblk = nblk;
     A.tag = ++c->fc_tag;
     A.rvecs = c->rvecs.as<float>(); A.tvecs = c->tvecs.as<float>(); A.n_pts_dev = c->n_points.as<int>(); A.camrec = cam_dev;
-    A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.n_poses = n_poses; A.solver = 0; A.ref_svd = ref_svd ? 1 : 0;
-    A.n_solve_wg = fc_solve_wgs(n_poses); A.n_pre_wg = prestage_next ? nblk : 0;
-    A.fb_e0 = fb_e0; A.fb_p = fb_p; A.max_polls = 1u << 19; A.host_err = c->h_fc_err_dev;
-    int aux_wg = 0;
+    A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.n_poses = n_poses; A.ref_svd = ref_svd ? 1 : 0;
+    A.n_solve_wg = fc_solve_wgs(n_poses);
+    A.max_polls = 1u << 17;  // ~0.3 s of polling: what a meeting can legitimately wait for is the end of somebody else's kernels (milliseconds)
+    A.host_err = c->h_fc_err_dev;
+    const size_t lds = sizeof(int) * ((size_t)nblk + nblk / 32 + 1);
+    const dim3 g(A.n_solve_wg), b(256);
+    if (nblk <= FC_T_SMALL * A.n_solve_wg) hipLaunchKernelGGL((k_solve_fc<0, FC_T_SMALL>), g, b, lds, c->stream, A);
+    else hipLaunchKernelGGL((k_solve_fc<0, FC_T_LARGE>), g, b, lds, c->stream, A);
+    c->n_map_blocks = nblk;
+    c->maps_block_compact = true;
+    VK_CHECK_LAST();
+    return 0;
+}
+// what rides in the launch of camera `cam`'s mode kernel: the prestage of camera cam + 1 (prestage_next), fb_smooth blocks (fb_kind: 0 none, 1 rows rig -> rig2
+// and the prior confidences, 2 columns on rig2 and the prior confidences; not with the refit kernel: its 141 KB of LDS leave no room)
+int mode_aux_plan(Context* c, ImageSet& S, int N, int N_dp, int w, int h, int cam, bool prestage_next, const CollectParams& cp, int fb_kind, float fb_e0, float fb_p, ModeAuxPlan* out) {
+    static_assert(sizeof(ModeAux) <= sizeof(out->bytes), "ModeAuxPlan::bytes holds a ModeAux");
+    ModeAux M{};
+    const int npx = w * h;
+    if (prestage_next) {
+        if (int e = c->fc_stage.reserve(sizeof(float) * 6 * (size_t)npx)) return e;
+        PreArgs& A = M.pre;
+        A.flows = S.flows.as<float2>(); A.rig = S.rig.as<float>(); A.depth = S.depth.as<float>(); A.P = S.pb();
+        A.N = N; A.w = w; A.h = h; A.rig_thresh = cp.rig_thresh; A.rig_sum_thresh = cp.rig_sum_thresh; A.min_depth = cp.min_depth; A.max_depth = cp.max_depth; A.max_trace = cp.max_trace;
+        A.cam = cam + 1; A.stage = c->fc_stage.as<float>();
+        A.n_wg = (npx + PRE_K * 512 - 1) / (PRE_K * 512);
+    }
+    M.pre.w = w; M.pre.h = h;
+    M.fb_e0 = fb_e0; M.fb_p = fb_p;
+    int blocks = 0;
     if (fb_kind) {
         struct { const float* src; float* dst; int n; } stacks[2] = { { S.rig.as<float>(), S.rig2.as<float>(), N }, { S.confs.as<float>(), S.confs.as<float>(), N_dp } };
         for (int j = 0; j < 2; j++) {
             if (stacks[j].n <= 0) continue;
             int rs = 20, cs = 20;
             fb_smooth_plan(w, h, stacks[j].n, &rs, &cs);
-            FcAuxJob& J = A.aux[j];
+            if (rs != 20 || cs != 20) return (int)hipErrorInvalidValue;  // (fb_overlap_ok: sizes of 20-step segments only)
+            FbJob& J = M.fb[j];
             J.kind = fb_kind; J.src = stacks[j].src; J.dst = stacks[j].dst; J.n_maps = stacks[j].n;
             if (fb_kind == 1) {
-                if (rs != 20) return (int)hipErrorInvalidValue;  // (fb_overlap_ok: sizes of 20-step segments only)
-                J.S = (w + rs - 1) / rs;
+                J.S = (w + 19) / 20;
                 const int lpb = 256 / J.S;
                 J.blocks_x = (h + lpb - 1) / lpb;
                 J.vec4 = ((w % 4) == 0 && (reinterpret_cast<uintptr_t>(J.src) % 16) == 0 && (reinterpret_cast<uintptr_t>(J.dst) % 16) == 0) ? 1 : 0;
             } else {
-                if (cs != 20) return (int)hipErrorInvalidValue;
-                J.S = (h + cs - 1) / cs;
+                J.S = (h + 19) / 20;
                 J.CW = 256 / J.S < 16 ? 256 / J.S : 16;
                 J.blocks_x = (w + J.CW - 1) / J.CW;
             }
-            J.n_wg = J.blocks_x * J.n_maps;
-            aux_wg += J.n_wg;
+            J.n_blocks = J.blocks_x * J.n_maps;
+            blocks += J.n_blocks;
         }
     }
-    const size_t lds = sizeof(int) * ((size_t)nblk + nblk / 32 + 1);
-    const dim3 g(A.n_solve_wg + A.n_pre_wg + aux_wg), b(256);
-    const bool small = nblk <= FC_T_SMALL * A.n_solve_wg;
-    if (aux_wg > 0) { if (small) hipLaunchKernelGGL((k_solve_fc<0, FC_T_SMALL, true>), g, b, lds, c->stream, A); else hipLaunchKernelGGL((k_solve_fc<0, FC_T_LARGE, true>), g, b, lds, c->stream, A); }
-    else { if (small) hipLaunchKernelGGL((k_solve_fc<0, FC_T_SMALL, false>), g, b, lds, c->stream, A); else hipLaunchKernelGGL((k_solve_fc<0, FC_T_LARGE, false>), g, b, lds, c->stream, A); }
-    c->n_map_blocks = nblk;
-    c->maps_block_compact = true;
-    VK_CHECK_LAST();
+    M.n_fb_wg = (blocks + 1) / 2;
+    memcpy(out->bytes, &M, sizeof M);
+    out->n_wg = M.pre.n_wg + M.n_fb_wg;
+    out->has_fb = M.n_fb_wg > 0;
     return 0;
 }
 
-int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first) {
+int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first, const ModeAuxPlan* plan) {
     ModeParams mp = mp_in;
+    ModeAux aux{};
+    int n_aux = 0;
+    if (plan) { memcpy(&aux, plan->bytes, sizeof aux); n_aux = plan->n_wg; if (mp.do_rg && plan->has_fb) return (int)hipErrorInvalidValue; }
     mp.rg_partition = debug_switches().refit_partition;
     if (n_poses > PM_POOL) {
         fprintf(stderr, "voldor_hip: n_poses_to_sample=%d exceeds the %d hypotheses the mode kernel keeps in registers\n", n_poses,
@@ -2079,11 +2138,11 @@ int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState*
         trials = out;
     }
     if (mp.do_rg)
-        hipLaunchKernelGGL((k_pose_mode<true, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
-                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials);
+        hipLaunchKernelGGL((k_pose_mode<true, PM_THREADS>), dim3(1 + n_aux), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials, aux);
     else
-        hipLaunchKernelGGL((k_pose_mode<false, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
-                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials);
+        hipLaunchKernelGGL((k_pose_mode<false, PM_THREADS>), dim3(1 + n_aux), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials, aux);
     VK_CHECK_LAST();
     return 0;
 }

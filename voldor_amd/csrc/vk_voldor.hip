@@ -198,10 +198,10 @@ struct Voldor {
     }
 
     // Round 5 (vk_pose.hip k_solve_fc): two launches per camera instead of three, and fb_smooth of the depth half riding in the pose half.
-    //   fused_ok       the launch of a camera's P3P batch also finishes the camera's correspondences (from the trace the previous launch staged) and
-    //                  traces the next camera's pixels: fast mode, the float LambdaTwist solver, the reference's index draw
+    //   fused_ok       the launch of a camera's P3P batch also finishes the camera's correspondences, from the trace that extra workgroups of the PREVIOUS
+    //                  camera's mode launch staged: fast mode, the float LambdaTwist solver, the reference's index draw
     //   fb_overlap_ok  fb_smooth (optimize_depth.cu:462-466) reads what the previous E-step wrote and nothing of this iteration's poses: its row pass
-    //                  runs as extra workgroups of camera 0's launch, its column pass of camera 1's (alone after the cameras when there is only one).
+    //                  runs as extra workgroups of camera 0's mode launch, its column pass of camera 1's (alone after the cameras when there is only one).
     //                  The pose half still reads the unsmoothed rigidness maps (collect_p3p_instances.cu:84-100), so the row pass writes the other
     //                  buffer of a ping-pong (rig -> rig2, columns in place on rig2), the depth half works on rig2, its E-step writes rig2, and the two
     //                  swap.  The prior-confidence maps are not read by the pose half: smoothed in place.  Every map of the frames still registered
@@ -268,18 +268,21 @@ struct Voldor {
             mp.host_brief = c->h_brief_dev;
         }
         if (last && fb_ov) { mp.cum_N = n_flows; mp.cum_Ndp = n_dp; mp.world_scale = with_world_scale ? world_scale_ptr() : nullptr; }
+        ModeAuxPlan plan;
         if (fused) {
+            // this camera's P3P batch (finishing the correspondences the previous mode launch traced: cameras >= 1), and what rides in this camera's mode launch
+            if (int e = solve_fused_device(c, S, w, h, i, /*finalize=*/i > 0, cfg.pose_sample_min_depth, cfg.pose_sample_max_depth, cfg.fx, cfg.fy, cfg.cx, cfg.cy,
+                                           cfg.n_poses_to_sample, ref_svd, dcams() + i))
+                return e;
             const CollectParams cp{ cfg.rigidness_threshold, cfg.rigidness_sum_threshold, cfg.pose_sample_min_depth, cfg.pose_sample_max_depth, cfg.max_trace_on_flow };
             const int fb_kind = fb_ov ? (i == 0 ? 1 : (i == 1 ? 2 : 0)) : 0;
-            if (int e = solve_fused_device(c, S, n_flows, n_dp, w, h, i, /*finalize=*/i > 0, /*prestage_next=*/i + 1 < n_flows, cp, cfg.fx, cfg.fy, cfg.cx, cfg.cy,
-                                           cfg.n_poses_to_sample, ref_svd, dcams() + i, fb_kind, cfg.fb_emm, cfg.fb_no_change_prob))
-                return e;
+            if (int e = mode_aux_plan(c, S, n_flows, n_dp, w, h, i, /*prestage_next=*/i + 1 < n_flows, cp, fb_kind, cfg.fb_emm, cfg.fb_no_change_prob, &plan)) return e;
         } else
         if (int e = solve_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i,
                                            cfg.reference_draw ? 1 : 0, strict, ref_svd, ref_rng))
             return e;
         if (strict) { if (int e = pose_mode_strict_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e; }
-        else if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i, hcams[i].pose_sample_count == 0)) return e;
+        else if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i, hcams[i].pose_sample_count == 0, fused ? &plan : nullptr)) return e;
         if (c->prof) prof_end(c, "optimize_camera_pose");
         return 0;
     }
@@ -290,8 +293,9 @@ struct Voldor {
     // after it has already enqueued this iteration's depth half: the GPU never waits for the host decision.
     // Equivalent to the reference order: a camera that fails or is skipped truncates the window at its index, so whatever
     // the speculatively executed later cameras wrote (their own pose slots only) is never read again.
+    bool refit_iteration() const { return cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0); }
     int enqueue_cameras(bool fused, bool fb_ov, bool with_world_scale) {
-        const bool rg = cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0);
+        const bool rg = refit_iteration();
         for (int i = 0; i < n_flows; i++)
             if (int e = optimize_camera_pose(i, rg, i == n_flows - 1, fused, fb_ov, with_world_scale)) return e;
         if (fb_ov && n_flows == 1) {  // one camera: the column pass had no launch to ride in
@@ -343,7 +347,7 @@ struct Voldor {
         }
         while (iters_remain > 0 && n_flows > 0) {
             iters_cur++; iters_remain--;
-            const bool fused = fused_ok(), fb_ov = fb_overlap_ok(), wsc = cfg.norm_world_scale && n_dp == 0;
+            const bool fused = fused_ok(), fb_ov = fb_overlap_ok() && !refit_iteration() /* the refit kernel's 141 KB of LDS leave no room for the riding passes */, wsc = cfg.norm_world_scale && n_dp == 0;
             if (int e = enqueue_cameras(fused, fb_ov, wsc)) return e;
             // the depth half is enqueued with the pre-decision frame count; on the device it runs with n_active
             if (int e = optimize_depth(cfg.optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY, wsc, fb_ov)) return e;
