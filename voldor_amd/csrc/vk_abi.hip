@@ -36,7 +36,7 @@ void Context::destroy() {
     DevBuf* bufs[] = { &od.flows, &od.rig, &od.rig2, &od.depth, &od.cost, &od.priors, &od.pconfs, &od.confs, &od.pose,
                        &cp.flows, &cp.rig, &cp.depth, &cp.cost, &cp.priors, &cp.pconfs, &cp.confs, &cp.pose,
                        &rig_partial, &local_tbl, &p2_map, &p3_map, &blk_counts, &blk_offsets, &valid_mask, &pts2, &pts3, &n_points,
-                       &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp, &fb_scratch, &stale_depth, &sp_coop, &fc_stage, &fc_cnt_tag, &xw_jumps, &xw_px_states, &xw_pose_states };
+                       &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp, &fb_scratch, &stale_depth, &sp_coop, &fc_stage, &fc_corr, &fc_cnt_tag, &xw_jumps, &xw_px_states, &xw_pose_states };
     for (DevBuf* b : bufs) b->release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);

@@ -181,7 +181,7 @@ struct Context {
     DevBuf tmp;                   // misc scratch (gblur, depth_conf ...)
     DevBuf fb_scratch;            // strict fb_smooth: forward messages [n_maps][h][w]
     DevBuf stale_depth;           // --reference_stale_depth 1: optimize_depth.cu's own device copy of the depth map (OdParams::stale_depth)
-    DevBuf fc_stage, fc_cnt_tag;  // k_solve_fc (round 5): the staged trace of two cameras [2][6][h*w]; per 256-pixel block: valid correspondences | launch tag << 9
+    DevBuf fc_stage, fc_corr, fc_cnt_tag;  // k_solve_fc (round 5): the staged trace of the next camera [6][h*w]; the finished correspondences [block][5][256]; per 256-pixel block: valid correspondences | launch tag << 9
     unsigned fc_tag = 0;          // tag of the last k_solve_fc launch (23 bits; the words are cleared when it wraps)
     int* h_fc_err = nullptr;      // pinned, written by the device: a k_solve_fc workgroup gave up its meeting (the window is run again on the three-launch chain)
     int* h_fc_err_dev = nullptr;

@@ -496,7 +496,7 @@ struct FcArgs {
     int w, h; float min_depth, max_depth;
     int cam, finalize;
     const float* stage;  // [6][npx] planes: flag, px, py, o.x, o.y, o.z (mode_prestage)
-    float* p2_map; float* p3_map; unsigned* cnt_tag; const int* blk_counts; int nblk; unsigned tag;
+    float* p2_map; float* p3_map; float* corr /* finalize: the correspondences, [block][5 planes][256] */; unsigned* cnt_tag; const int* blk_counts; int nblk; unsigned tag;
     float* rvecs; float* tvecs; int* n_pts_dev; CamState* camrec; float fx, fy, cx, cy; int n_poses, ref_svd;
     int n_solve_wg;
     unsigned max_polls; int* host_err;
@@ -562,16 +562,24 @@ __device__ __forceinline__ void mode_prestage(const PreArgs& A, int r) {
         o[k] = backproject(P, (float)(pi[k] % w), (float)(pi[k] / w), d[k]);
         start[k] = a - n_trace[k] + 1; qx[k] = 0.f; qy[k] = 0.f;
     }
+    // A gather inside a per-pixel branch is a memory round trip of its own: the K pixels of a lane would walk their traces one after the other.  So the
+    // decisions are taken first, then the K gathers of a step are issued together, unconditionally (a pixel that does not take the step reads texel (0, 0)
+    // of the layer), then used.  The values that are used are the values of the branching form.
     for (int i = 0; i < a; i++) {  // frames 0 .. a - 1: their trace steps, and the transforms 0 .. a - 2 (transform a - 1 waits for its pose)
+        bool act[K], ins[K];
 #pragma unroll
         for (int k = 0; k < K; k++) {
-            if (ok[k] && i >= start[k]) {
-                if (i == start[k]) project(P, o[k], qx[k], qy[k]);
-                if (qx[k] > 0.f && qx[k] < (float)w && qy[k] > 0.f && qy[k] < (float)h) {  // strict (:120)
-                    const float2 f2 = bilinear2(A.flows + (size_t)i * npx, w, h, qx[k], qy[k]);
-                    qx[k] += f2.x; qy[k] += f2.y;
-                } else ok[k] = false;  // out of the image: the pixel is dropped
-            }
+            act[k] = ok[k] && i >= start[k];
+            if (act[k] && i == start[k]) project(P, o[k], qx[k], qy[k]);
+            ins[k] = act[k] && qx[k] > 0.f && qx[k] < (float)w && qy[k] > 0.f && qy[k] < (float)h;  // strict (:120)
+        }
+        float2 f2[K];
+#pragma unroll
+        for (int k = 0; k < K; k++) f2[k] = bilinear2(A.flows + (size_t)i * npx, w, h, ins[k] ? qx[k] : 0.f, ins[k] ? qy[k] : 0.f);
+#pragma unroll
+        for (int k = 0; k < K; k++) {
+            if (ins[k]) { qx[k] += f2[k].x; qy[k] += f2[k].y; }
+            else if (act[k]) ok[k] = false;  // out of the image: the pixel is dropped
         }
         if (i < a - 1) {
 #pragma unroll
@@ -579,17 +587,18 @@ __device__ __forceinline__ void mode_prestage(const PreArgs& A, int r) {
         }
     }
     float* st = A.stage;
+    bool fin[K];  // frame a's own trace step continues from a known position (start <= a - 1): it does not see pose a - 1
+    float2 g2[K];
+#pragma unroll
+    for (int k = 0; k < K; k++) fin[k] = ok[k] && start[k] <= a - 1 && qx[k] > 0.f && qx[k] < (float)w && qy[k] > 0.f && qy[k] < (float)h;
+#pragma unroll
+    for (int k = 0; k < K; k++) g2[k] = bilinear2(A.flows + (size_t)a * npx, w, h, fin[k] ? qx[k] : 0.f, fin[k] ? qy[k] : 0.f);
 #pragma unroll
     for (int k = 0; k < K; k++) {
         float flag = 0.f;
         if (ok[k]) {
-            if (start[k] <= a - 1) {  // frame a's own trace step continues from a known position: it does not see pose a - 1
-                if (qx[k] > 0.f && qx[k] < (float)w && qy[k] > 0.f && qy[k] < (float)h) {
-                    const float2 f2 = bilinear2(A.flows + (size_t)a * npx, w, h, qx[k], qy[k]);
-                    qx[k] += f2.x; qy[k] += f2.y;
-                    flag = 1.f;
-                }
-            } else flag = 2.f;  // a one-frame trace: the projection of the point in frame a, hence pose a - 1, comes first ("late")
+            if (start[k] <= a - 1) { if (fin[k]) { qx[k] += g2[k].x; qy[k] += g2[k].y; flag = 1.f; } }
+            else flag = 2.f;  // a one-frame trace: the projection of the point in frame a, hence pose a - 1, comes first ("late")
         }
         const int q = (r * K + k) * 512 + tid;
         if (q < npx) {
@@ -641,23 +650,31 @@ __global__ __launch_bounds__(256) static void k_solve_fc(FcArgs A) {
             ox[k] = st[(size_t)3 * npx + q]; oy[k] = st[(size_t)4 * npx + q]; oz[k] = st[(size_t)5 * npx + q];
             if (!in) fl[k] = 0.f;
         }
-        bool valid[TMAX];
+        // (the gathers of the one-frame traces of all blocks together, unconditionally: see mode_prestage)
+        bool valid[TMAX], late_in[TMAX];
+        float qx[TMAX], qy[TMAX];
 #pragma unroll
         for (int k = 0; k < TMAX; k++) {
             P3 o = { ox[k], oy[k], oz[k] };
             o = transform(P->Rs[a - 1], P->ts[a - 1], o);  // (finalize is only ever set for a >= 1)
+            ox[k] = o.x; oy[k] = o.y; oz[k] = o.z;
+            qx[k] = 0.f; qy[k] = 0.f;
+            if (fl[k] == 2.f) project(P, o, qx[k], qy[k]);  // the one-frame trace: project, then frame a's step
+            late_in[k] = fl[k] == 2.f && qx[k] > 0.f && qx[k] < (float)w && qy[k] > 0.f && qy[k] < (float)h;
+        }
+        float2 f2[TMAX];
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) f2[k] = bilinear2(A.flows + (size_t)a * npx, w, h, late_in[k] ? qx[k] : 0.f, late_in[k] ? qy[k] : 0.f);
+#pragma unroll
+        for (int k = 0; k < TMAX; k++) {
             bool ok = fl[k] != 0.f;
-            if (fl[k] == 2.f) {  // the one-frame trace: project, then frame a's step
-                float qx, qy;
-                project(P, o, qx, qy);
-                if (qx > 0.f && qx < (float)w && qy > 0.f && qy < (float)h) {
-                    const float2 f2 = bilinear2(A.flows + (size_t)a * npx, w, h, qx, qy);
-                    px[k] = qx + f2.x; py[k] = qy + f2.y;
-                } else ok = false;
+            if (fl[k] == 2.f) {
+                if (late_in[k]) { px[k] = qx[k] + f2[k].x; py[k] = qy[k] + f2[k].y; }
+                else ok = false;
             }
-            ok = ok && o.z > A.min_depth && (A.max_depth <= 0.f || o.z < A.max_depth);
-            ok = ok && isfinite(px[k] + py[k] + o.x + o.y + o.z);  // geometry.cpp:73 keeps only entries whose sum is finite
-            valid[k] = ok; ox[k] = o.x; oy[k] = o.y; oz[k] = o.z;
+            ok = ok && oz[k] > A.min_depth && (A.max_depth <= 0.f || oz[k] < A.max_depth);
+            ok = ok && isfinite(px[k] + py[k] + ox[k] + oy[k] + oz[k]);  // geometry.cpp:73 keeps only entries whose sum is finite
+            valid[k] = ok;
         }
         unsigned long long m[TMAX];
 #pragma unroll
@@ -672,9 +689,10 @@ __global__ __launch_bounds__(256) static void k_solve_fc(FcArgs A) {
                 const int t = bid + k * A.n_solve_wg;
                 int r = __popcll(m[k] & ((1ull << ln) - 1ull));
                 for (int j = 0; j < wv; j++) r += s_cnt[k][j];
-                const size_t slot = (size_t)t * 256 + r;
-                st_coh(A.p2_map + slot * 2, px[k]); st_coh(A.p2_map + slot * 2 + 1, py[k]);
-                st_coh(A.p3_map + slot * 3, ox[k]); st_coh(A.p3_map + slot * 3 + 1, oy[k]); st_coh(A.p3_map + slot * 3 + 2, oz[k]);
+                // five planes of 256 entries per block: consecutive ranks are consecutive addresses (a wave's store instruction is one or two full lines on
+                // its way to memory, not 64 four-byte pieces of a 20-byte record)
+                float* seg = A.corr + (size_t)t * 1280 + r;
+                st_coh(seg, px[k]); st_coh(seg + 256, py[k]); st_coh(seg + 512, ox[k]); st_coh(seg + 768, oy[k]); st_coh(seg + 1024, oz[k]);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's correspondences have left for memory (write-through stores) ...
@@ -755,8 +773,9 @@ __global__ __launch_bounds__(256) static void k_solve_fc(FcArgs A) {
             const int i = __shfl(found, (ln & ~3) + k, 64);
             // (the correspondences of this launch's own finalize phase come from other compute units: coherent loads; k_collect's are a launch old)
             if (A.finalize) {
-                yu[k] = ld_coh(A.p2_map + (size_t)i * 2); yv[k] = ld_coh(A.p2_map + (size_t)i * 2 + 1);
-                xp[k][0] = ld_coh(A.p3_map + (size_t)i * 3); xp[k][1] = ld_coh(A.p3_map + (size_t)i * 3 + 1); xp[k][2] = ld_coh(A.p3_map + (size_t)i * 3 + 2);
+                const float* seg = A.corr + (size_t)(i >> 8) * 1280 + (i & 255);
+                yu[k] = ld_coh(seg); yv[k] = ld_coh(seg + 256);
+                xp[k][0] = ld_coh(seg + 512); xp[k][1] = ld_coh(seg + 768); xp[k][2] = ld_coh(seg + 1024);
             } else {
                 yu[k] = A.p2_map[(size_t)i * 2]; yv[k] = A.p2_map[(size_t)i * 2 + 1];
                 xp[k][0] = A.p3_map[(size_t)i * 3]; xp[k][1] = A.p3_map[(size_t)i * 3 + 1]; xp[k][2] = A.p3_map[(size_t)i * 3 + 2];
@@ -2041,6 +2060,7 @@ int solve_fused_device(Context* c, ImageSet& S, int w, int h, int cam, bool fina
     if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
     if (int e = c->fc_stage.reserve(sizeof(float) * 6 * (size_t)npx)) return e;
+    if (int e = c->fc_corr.reserve(sizeof(float) * 1280 * (size_t)nblk)) return e;
     if (c->fc_cnt_tag.cap < sizeof(unsigned) * (size_t)nblk || c->fc_tag >= (1u << 23) - 2u) {  // fresh words, or the tag is about to wrap: no word may carry a tag of the coming launches
         if (int e = c->fc_cnt_tag.reserve(sizeof(unsigned) * (size_t)nblk)) return e;
         VK_CHECK(hipMemsetAsync(c->fc_cnt_tag.p, 0, c->fc_cnt_tag.cap, c->stream));
@@ -2051,7 +2071,7 @@ int solve_fused_device(Context* c, ImageSet& S, int w, int h, int cam, bool fina
     A.w = w; A.h = h; A.min_depth = min_depth; A.max_depth = max_depth;
     A.cam = cam; A.finalize = finalize ? 1 : 0;
     A.stage = c->fc_stage.as<float>();
-    A.p2_map = c->p2_map.as<float>(); A.p3_map = c->p3_map.as<float>(); A.cnt_tag = c->fc_cnt_tag.as<unsigned>(); A.blk_counts = c->blk_counts.as<int>(); A.nblk = nblk;
+    A.p2_map = c->p2_map.as<float>(); A.p3_map = c->p3_map.as<float>(); A.corr = c->fc_corr.as<float>(); A.cnt_tag = c->fc_cnt_tag.as<unsigned>(); A.blk_counts = c->blk_counts.as<int>(); A.nblk = nblk;
     A.tag = ++c->fc_tag;
     A.rvecs = c->rvecs.as<float>(); A.tvecs = c->tvecs.as<float>(); A.n_pts_dev = c->n_points.as<int>(); A.camrec = cam_dev;
     A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.n_poses = n_poses; A.ref_svd = ref_svd ? 1 : 0;
