@@ -270,13 +270,6 @@ def main():
             lib.vk_profile_enable(0)
             return g
         groups = profile_groups()
-        # Round 5: fb_smooth of a call rides in the pose half's mode launches (vk_debug_switch "fb_overlap"), so the depth half's own launch group no longer
-        # contains it.  The same window with the switch off -- fb_smooth as the group's first two launches, as in rounds 1-4 -- gives the group with EVERY
-        # launch of the unit in it: that is `frac`; `critical_path` is what the window pays.
-        groups_serial = None
-        if lib.vk_debug_switch(b"fb_overlap", 0) >= 0:
-            groups_serial = profile_groups()
-            lib.vk_debug_switch(b"fb_overlap", 1)
         tot, cnt = C.c_double(0), C.c_long(0)
         b_od = W * H * (40 * N_FLOW + 36 * n_dp + 12)  # bytes per optimize_depth call
         # Dominant streaming kernel of the path: k_cost_rand_q (cost map + 10 random depth samples per pixel, one launch per
@@ -351,21 +344,13 @@ def main():
         if "cost_rand" in groups and "optimize_depth" in groups:
             t_cr = groups["cost_rand"]["avg_us"] * 1e-6
             ach_k = b_cr / t_cr / 1e9
-            # Round 5: the two fb_smooth launches of a call run on the library's second stream NEXT TO the pose half (vk_voldor.hip enqueue_fb_overlap) -- the
-            # events of the group on the main stream no longer contain them.  `frac` stays the conservative figure: B_od / (main-stream group + the two
-            # launches' own duration on their stream); `critical_path` is what a window pays.
-            t_crit = groups["optimize_depth"]["avg_us"] * 1e-6
-            t_od = groups_serial["optimize_depth"]["avg_us"] * 1e-6 if groups_serial and "optimize_depth" in groups_serial else t_crit
-            t_fb = max(0.0, t_od - t_crit)
+            t_od = groups["optimize_depth"]["avg_us"] * 1e-6
             ach = b_od / t_od / 1e9
             # Primary figure = SURVEY.md section 8(d)'s definition: unit = one optimize_depth call (one EM iteration's depth half, a
             # group of dependent launches), achieved = B_od / (duration of the group, HIP events on the library's stream, this run).
             roof = {"bound": "hbm", "kernel": "optimize_depth launch group (fb_smooth rows + columns, cost + random samples, 4 global + 4 local propagation passes, E-step, density reduction)",
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                     "algorithmic_bytes": b_od, "avg_us": round(t_od * 1e6, 2),
-                    "critical_path": {"avg_us": round(t_crit * 1e6, 2), "fb_smooth_moved_out_us": round(t_fb * 1e6, 2), "achieved": round(b_od / t_crit / 1e9, 2), "frac": round(b_od / t_crit / 1e9 / HBM_PEAK_GBS, 5),
-                                      "note": "the group as the window pays for it: fb_smooth (rows + columns) rides in the pose half's mode launches (255 idle compute units), off the depth half's "
-                                              "critical path; `frac` / `avg_us` above are the SAME window with vk_debug_switch fb_overlap = 0: every launch of the unit in the group, as in rounds 1-4"},
                     "kernels": ktable, "sweeps": sweeps,
                     "traffic": None if group_traffic is None else round(group_traffic),
                     "measured": "achieved / frac / avg_us: HIP events of THIS run; traffic, valu_issue_frac, sq_counters_per_launch: replayed from the committed rocprofv3 --pmc passes named in `source` "
@@ -480,12 +465,8 @@ def main():
                     lib.vk_profile_enable(0)
                     return gg
                 g_ = oprof()
-                g_serial = g_
-                if lib.vk_debug_switch(b"fb_overlap", 0) >= 0:  # the group with every launch of the unit in it (see roofline.critical_path)
-                    g_serial = oprof()
-                    lib.vk_debug_switch(b"fb_overlap", 1)
                 ob = ow["w"] * ow["h"] * (40 * ow["n"] + 36 * 1 + 12)
-                t_all = g_serial.get("optimize_depth", 0.0) * 1e-6
+                t_all = g_.get("optimize_depth", 0.0) * 1e-6
                 ts_ = []
                 for i in range(3):  # reference mode: one warm-up window, two timed
                     kernels.set_rand_epoch(0)
@@ -496,7 +477,7 @@ def main():
                         ts_.append(time.perf_counter() - t1)
                 others[oname] = {"workload": ow["name"], "windows": nwin, "ms_per_window": round(float(np.median(tw)) * 1e3, 3), "frames_per_s": round(1.0 / float(np.median(tw)), 2),
                                  "n_registered": int(oo["n_registered"]),
-                                 "optimize_depth": None if not t_all else {"algorithmic_bytes": ob, "avg_us": round(t_all * 1e6, 2), "critical_path_us": round(g_.get("optimize_depth", 0.0), 2),
+                                 "optimize_depth": None if not t_all else {"algorithmic_bytes": ob, "avg_us": round(t_all * 1e6, 2),
                                                                            "achieved": round(ob / t_all / 1e9, 2), "frac": round(ob / t_all / 1e9 / HBM_PEAK_GBS, 5),
                                                                            "cost_rand_us": round(g_.get("cost_rand", 0.0), 2), "local_pass_us": round(g_.get("local_pass", 0.0), 2)},
                                  "reference_mode_ms_per_window": round(float(np.median(ts_)) * 1e3, 2), "reference_mode_n_registered": int(so_["n_registered"]),

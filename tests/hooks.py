@@ -96,9 +96,6 @@ def set_refit_partition(on): debug_switch("refit_partition", int(bool(on)))
 def set_split_trials(on): debug_switch("split_trials", int(bool(on)))
 def set_strict_plain(on): debug_switch("strict_plain", int(bool(on)))
 def set_strict_pose_coop(on): debug_switch("strict_pose_coop", int(bool(on)))
-def set_pose_fused(on): debug_switch("pose_fused", int(bool(on)))
-def set_fb_overlap(on): debug_switch("fb_overlap", int(bool(on)))
-def set_local_table4(on): debug_switch("local_table4", int(bool(on)))
 def set_strict_coop_max_polls(n): debug_switch("strict_coop_max_polls", int(n))
 
 

@@ -590,62 +590,3 @@ def test_sample_pass_with_survivor_queue_matches_strict(small_scene, with_priors
     same = fd == sd
     _assert_map_close(sr[:, same], fr[:, same])
 
-
-@pytest.mark.parametrize("switch", ["pose_fused", "fb_overlap", "local_table4"])
-@pytest.mark.parametrize("case", ["mono_320x240", "stereo_312x96", "mono_640x480_refit_every_iteration", "ap3p", "double_solver", "low_density", "batch_of_4", "odd_323x241_truncating"])
-def test_round5_launch_structures_change_no_bit(case, switch):
-    """The launch structures of round 5 against the ones they replace, every output of a window bit for bit:
-    "fb_overlap"    fb_smooth of the rigidness maps out of place in extra workgroups of the pose half's P3P launches against its own two launches, in place, at the
-                    head of the depth half;
-    "local_table4"  one table sweep for the four local-propagation directions + repair of the entries whose neighbour changed, against one sweep per direction;
-    "pose_fused"    k_solve_fc (round 5): the launch of a camera's P3P batch first finishes the camera's correspondences from the state the previous launch
-                    traced (the pose it needed was not there yet), its workgroups meet in the tagged block counts, then solve, while extra workgroups trace the
-                    next camera's pixels -- against collect / P3P batch as two launches.
-    Windows with and without depth priors, the refit in every iteration, AP3P and the fp64 solver (unfused either way: same answer by construction), a window
-    whose correspondence density collapses, four windows in flight (pool contexts), and a ragged size whose last frames are noise (the window truncates: maps
-    of dropped frames, partial tiles and chains)."""
-    import ref_window_cases as rc
-    from voldor_amd import kernels, pyvoldor, synth
-    extra, batch = "", 1
-    if case == "odd_323x241_truncating":
-        sc = synth.make_scene(w=323, h=241, n_flows=5, fx=160, fy=160, cx=160, cy=120, seed=31)
-        fl = sc["flows"].copy()
-        fl[3:] = np.random.default_rng(4).uniform(-25, 25, fl[3:].shape).astype(np.float32)
-        c = dict(K=sc["K"], flows=fl, basefocal=0.0, disparity=None, depth_priors=None, depth_prior_poses=None, depth_prior_pconfs=None,
-                 config="--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 6")
-    elif case == "mono_320x240":
-        c = dict(rc.window_cases())["mono_320x240"]
-    elif case == "stereo_312x96":
-        c = dict(rc.window_cases())["stereo_312x96"]
-    elif case == "low_density":
-        c = dict(rc.window_cases())["low_density"]
-    else:
-        c = rc.cfg2_case()[1] if case.startswith("mono_640") else dict(rc.window_cases())["mono_320x240"]
-        extra = {"mono_640x480_refit_every_iteration": " --rg_refine_last_only 0", "ap3p": " --lambdatwist 0", "double_solver": " --cpu_p3p 1", "batch_of_4": ""}[case]
-        batch = 4 if case == "batch_of_4" else 1
-    fx, fy, cx, cy = c["K"]
-    kw = dict(basefocal=c["basefocal"], disparity=c["disparity"], depth_priors=c["depth_priors"], depth_prior_poses=c["depth_prior_poses"],
-              depth_prior_pconfs=c["depth_prior_pconfs"], config=c["config"] + extra)
-
-    def run():
-        kernels.set_rand_epoch(0)
-        if batch == 1:
-            return [pyvoldor.voldor(c["flows"], fx, fy, cx, cy, **kw)]
-        import torch
-        fl = [torch.from_numpy(np.ascontiguousarray(c["flows"] * (1.0 + 0.01 * b))).cuda() for b in range(batch)]
-        h, w = c["flows"].shape[1:3]
-        d = [torch.empty(h, w, device="cuda") for _ in range(batch)]; cf = [torch.empty(h, w, device="cuda") for _ in range(batch)]
-        return pyvoldor.voldor_device_batch(fl, fx, fy, cx, cy, config=kw["config"], depth_out=d, depth_conf_out=cf)
-    out = {}
-    try:
-        for on in (1, 0):
-            hooks.debug_switch(switch, on)
-            out[on] = run()
-    finally:
-        hooks.debug_switch(switch, 1)
-    for a, b in zip(out[1], out[0]):
-        assert a["n_registered"] == b["n_registered"] and a["n_registered"] > 0
-        for k in ("poses", "poses_covar", "depth", "depth_conf"):
-            x = a[k].cpu().numpy() if hasattr(a[k], "cpu") else np.asarray(a[k]); y = b[k].cpu().numpy() if hasattr(b[k], "cpu") else np.asarray(b[k])
-            np.testing.assert_array_equal(np.ascontiguousarray(x, np.float32).view(np.uint32), np.ascontiguousarray(y, np.float32).view(np.uint32), err_msg=f"{switch}: {case}/{k}")
-

@@ -27,16 +27,13 @@ int Context::init(int dev) {
     VK_CHECK(hipHostMalloc((void**)&h_cams_up, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
     VK_CHECK(hipHostMalloc((void**)&h_brief, sizeof(CamBrief) * MAX_FRAMES, hipHostMallocMapped));
     VK_CHECK(hipHostGetDevicePointer((void**)&h_brief_dev, h_brief, 0));
-    VK_CHECK(hipHostMalloc((void**)&h_fc_err, sizeof(int) * 4, hipHostMallocMapped));
-    h_fc_err[0] = 0;
-    VK_CHECK(hipHostGetDevicePointer((void**)&h_fc_err_dev, h_fc_err, 0));
     return 0;
 }
 void Context::destroy() {
-    DevBuf* bufs[] = { &od.flows, &od.rig, &od.rig2, &od.depth, &od.cost, &od.priors, &od.pconfs, &od.confs, &od.pose,
+    DevBuf* bufs[] = { &od.flows, &od.rig, &od.depth, &od.cost, &od.priors, &od.pconfs, &od.confs, &od.pose,
                        &cp.flows, &cp.rig, &cp.depth, &cp.cost, &cp.priors, &cp.pconfs, &cp.confs, &cp.pose,
                        &rig_partial, &local_tbl, &p2_map, &p3_map, &blk_counts, &blk_offsets, &valid_mask, &pts2, &pts3, &n_points,
-                       &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp, &fb_scratch, &stale_depth, &sp_coop, &fc_stage, &fc_corr, &fc_cnt_tag, &xw_jumps, &xw_px_states, &xw_pose_states };
+                       &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp, &fb_scratch, &stale_depth, &sp_coop, &xw_jumps, &xw_px_states, &xw_pose_states };
     for (DevBuf* b : bufs) b->release();
     if (ev0) (void)hipEventDestroy(ev0);
     if (ev1) (void)hipEventDestroy(ev1);
@@ -45,8 +42,6 @@ void Context::destroy() {
     if (ev_cams) (void)hipEventDestroy(ev_cams);
     if (h_cams) (void)hipHostFree(h_cams);
     if (h_brief) (void)hipHostFree(h_brief);
-    if (h_fc_err) (void)hipHostFree(h_fc_err);
-    h_fc_err = h_fc_err_dev = nullptr;
     if (h_pb) (void)hipHostFree(h_pb);
     if (h_cams_up) (void)hipHostFree(h_cams_up);
     h_pb = nullptr; h_cams_up = nullptr;
@@ -84,7 +79,6 @@ Context* pool_context(int idx) {
     while ((int)v.size() <= idx) {
         Context* c = new Context();
         if (c->init(dev) != 0) { delete c; return nullptr; }
-        c->is_pool = true;
         v.push_back(c);
     }
     return v[(size_t)idx];
@@ -156,8 +150,7 @@ static const DebugEntry g_debug_tab[] = {
     { "local_serial", &DebugSwitches::local_serial, 0 }, { "cost_rand_plain", &DebugSwitches::cost_rand_plain, 0 }, { "fb_segment", &DebugSwitches::fb_segment, 1 },
     { "global_split", &DebugSwitches::global_split, 0 }, { "refit_partition", &DebugSwitches::refit_partition, 0 }, { "split_trials", &DebugSwitches::split_trials, 0 },
     { "strict_plain", &DebugSwitches::strict_plain, 0 }, { "strict_pose_coop", &DebugSwitches::strict_pose_coop, 0 },
-    { "pose_fused", &DebugSwitches::pose_fused, 0 }, { "fb_overlap", &DebugSwitches::fb_overlap, 0 },
-    { "local_table4", &DebugSwitches::local_table4, 0 }, { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 },
+    { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 },
 };
 // returns the previous value; -1: unknown name; -2: a value the switch does not take
 static int debug_switch_set(const char* name, int value) {

@@ -113,7 +113,6 @@ struct ImageSet {
     int w = 0, h = 0;
     DevBuf flows;   // [N][h][w] float2
     DevBuf rig;     // [N][h][w]
-    DevBuf rig2;    // window pipeline, round 5: the other half of the rigidness ping-pong (fb_smooth writes rig -> rig2 from extra workgroups of the pose half's launches while the pose half still reads rig; the E-step then writes rig2 and the two swap)
     DevBuf depth;   // [h][w]
     DevBuf cost;    // [h][w]
     DevBuf priors, pconfs, confs;  // [N_dp][h][w]
@@ -142,8 +141,6 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
     bool fb_smooth = true;
     float s0_ems_prob = 0.5f, no_change_prob = 0.9f, range_factor = 1.f;
     bool update_rigidness_only = false;
-    bool cum_done = false;  // the projective maps of the rigid chain (and the world-scale factor) are already there: the last camera's mode kernel wrote them (round 5)
-    bool fb_done = false;  // the caller has already smoothed the rigidness / prior-confidence maps of this call (window pipeline: in extra workgroups of the pose half's launches)
     bool strict = false;  // strict-math mode: reference-order arithmetic on vk_strict_math.h (vk_strict.hip)
     // reference mode, round 4 (vk_ref_cuda.h; strict kernels only): cuRAND XORWOW streams for the depth samples / CUDA's 8-bit-fraction
     // linear filter over the stacked layers for every at_tex of the reference (D1 / D2 switched off)
@@ -162,7 +159,6 @@ struct ProfEntry { double ms = 0; long count = 0; };
 struct Context {
     int device = 0;
     hipStream_t stream = nullptr;
-    bool is_pool = false;           // one of the extra contexts of vk_voldor_device_batch (windows in flight next to each other)
     // B-inner keeps the reference's two independent caches (optimize_depth.cu vs
     // collect_p3p_instances.cu statics); the B-outer pipeline uses `od` for everything.
     ImageSet od, cp;
@@ -181,11 +177,6 @@ struct Context {
     DevBuf tmp;                   // misc scratch (gblur, depth_conf ...)
     DevBuf fb_scratch;            // strict fb_smooth: forward messages [n_maps][h][w]
     DevBuf stale_depth;           // --reference_stale_depth 1: optimize_depth.cu's own device copy of the depth map (OdParams::stale_depth)
-    DevBuf fc_stage, fc_corr, fc_cnt_tag;  // k_solve_fc (round 5): the staged trace of the next camera [6][h*w]; the finished correspondences [block][5][256]; per 256-pixel block: valid correspondences | launch tag << 9
-    unsigned fc_tag = 0;          // tag of the last k_solve_fc launch (23 bits; the words are cleared when it wraps)
-    int* h_fc_err = nullptr;      // pinned, written by the device: a k_solve_fc workgroup gave up its meeting (the window is run again on the three-launch chain)
-    int* h_fc_err_dev = nullptr;
-    bool fused_broken = false;    // a meeting was given up on this context: no fused launches any more
     DevBuf sp_coop;               // strict mode kernel, cooperative form: block sums, pool size and the grid barrier's counter (vk_strict.hip CoopGlobal)
     bool strict = false;          // strict-math mode of the B-inner entry points that use this context (vk_set_strict_math)
     // --reference_rng 1: the jump matrices T^(2^67 2^k) (vk_ref_cuda.h), the per-pixel XORWOW states of the depth samples

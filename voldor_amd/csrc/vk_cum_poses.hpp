@@ -1,7 +1,6 @@
 // voldor_amd/csrc/vk_cum_poses.hpp -- the rigid chain of a window folded into one projective map per frame (PoseBlock::cumM / cumT, fast path) and the
 // world-scale factor of normalize_world_scale (voldor.cpp:309-317).  One workgroup's worth of work (12 active lanes, fp64), needed by the first cost
-// kernel of the depth half: run by an extra workgroup of the first fb_smooth launch (rounds 2-4), by its own launch k_cum_poses, or -- round 5, when
-// fb_smooth has moved into the pose half -- by the tail of the kernel that finishes the last camera (vk_pose.hip pose_mode_body).
+// kernel of the depth half: run by an extra workgroup of the first fb_smooth launch, or by its own launch k_cum_poses.
 #pragma once
 #include "vk_common.hpp"
 

@@ -19,13 +19,6 @@ extern "C" {
  *                             barrier per sum) or ONE 512-thread workgroup; the same bits
  *   "strict_plain"    0 | 1   1: strict mode on the plain launch structures (one lane per chain / line, one 256-thread workgroup walking the
  *                             reference's sum tree block by block) instead of the parallel structures -- both give the same bits
- *   "pose_fused"      1 | 0   0: collect, P3P batch and mode kernel of a camera as three launches instead of two (k_solve_fc: the workgroups of the P3P batch first
- *                             finish this camera's correspondences from the state the previous launch traced, meet in the tagged block counts, then solve; extra
- *                             workgroups trace the next camera's pixels meanwhile); the same bits
- *   "fb_overlap"      1 | 0   0: fb_smooth of the rigidness maps as its own two launches at the head of the depth half instead of extra workgroups of the pose
- *                             half's P3P launches (out of place: the pose half still reads the raw maps); the same bits
- *   "local_table4"    1 | 0   0: one table sweep per local-propagation direction instead of one sweep for the four directions + repair of the entries
- *                             whose neighbour changed; the same bits
  *   "strict_coop_max_polls"  0 | n > 0   polls after which a workgroup of the cooperative strict mode kernel gives up a meeting (0: 2^20); tests set 1 to
  *                             force the hand-over to the single-workgroup kernel
  * Returns the previous value, -1 for an unknown name / value. */

@@ -88,35 +88,23 @@ static void fb_cols_launch(hipStream_t st, float* maps, int n_maps, int w, int h
     const int Sc = (h + SEG - 1) / SEG;
     hipLaunchKernelGGL(k_fb_cols<SEG>, dim3((w + FB_CW - 1) / FB_CW, n_maps), dim3(FB_CW * Sc), 0, st, maps, w, h, Sc, e0, p, n_dev);
 }
-bool fb_smooth_segmented(int w, int h) { return !(w > 40 * FB_MAX_ROW_SEGS || h > 40 * FB_MAX_COL_SEGS); }
+static bool fb_smooth_segmented(int w, int h) { return !(w > 40 * FB_MAX_ROW_SEGS || h > 40 * FB_MAX_COL_SEGS); }
 // Steps per lane.  A lane also chains the S - 1 segment matrices of its line up to its own segment (fb_incoming): S - 1 Moebius steps
 // next to the 2 x FB_SEG of its segment.  In the latency regime (one or two waves per SIMD: 640x480, 1241x376) short segments
 // win -- the dependent chain is what takes the time.  Where the pass fills the chip many times over it is bound by VALU issue (0.91
 // at 1080p) and the chaining is half of all instructions with 20-step segments (1920 wide: 95 + 40 steps per lane): 40-step
 // segments then do the same work in 37 % fewer instructions.
-void fb_smooth_plan(int w, int h, int n_maps, int* rows_seg, int* cols_seg) {
+static void fb_smooth_plan(int w, int h, int n_maps, int* rows_seg, int* cols_seg) {
     const int forced = debug_switches().fb_segment;
     const bool many_waves = (size_t)w * h * n_maps >= ((size_t)8 << 20);  // >= 8 waves per SIMD at 20 steps per lane
     *rows_seg = (w > 20 * FB_MAX_ROW_SEGS || (forced ? forced == 40 : many_waves)) ? 40 : 20;
     *cols_seg = (h > 20 * FB_MAX_COL_SEGS || (forced ? forced == 40 : many_waves)) ? 40 : 20;
 }
-int fb_cols_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob) {
-    if (n_maps <= 0) return 0;
-    int rs, cs;
-    fb_smooth_plan(w, h, n_maps, &rs, &cs);
-    if (cs == 20) fb_cols_launch<20>(c->stream, maps, n_maps, w, h, s0_ems_prob, no_change_prob, nullptr);
-    else fb_cols_launch<40>(c->stream, maps, n_maps, w, h, s0_ems_prob, no_change_prob, nullptr);
-    VK_CHECK_LAST();
-    return 0;
-}
-// dst (optional): the smoothed maps go THERE and `maps` stays as it is (the row pass writes dst, the column pass runs in place on dst) -- only with
-// fb_smooth_segmented(w, h); st (optional): the stream of the two launches instead of the context's own
 int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev, PoseBlock* cumP,
-                     int cumN, int cumNdp, float* world_scale, float* dst, hipStream_t st) {
+                     int cumN, int cumNdp, float* world_scale) {
     if (n_maps <= 0) return 0;
-    if (!st) st = c->stream;
+    hipStream_t st = c->stream;
     if (!fb_smooth_segmented(w, h)) {
-        if (dst || st != c->stream) return (int)hipErrorInvalidValue;
         // larger than any segmented launch: one lane per line walks the recurrence step by step (the reference's own structure,
         // fb_smooth.h:26-69; no size limit).  The projective maps of the cost kernels then need their own launch.
         if (cumP) hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, cumP, cumN, cumNdp, world_scale);
@@ -125,7 +113,7 @@ int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0
     int rs, cs;
     fb_smooth_plan(w, h, n_maps, &rs, &cs);
     const bool rows40 = rs == 40, cols40 = cs == 40;
-    float* out = dst ? dst : maps;
+    float* out = maps;
     if (!rows40) fb_rows_launch<20>(st, maps, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
     else fb_rows_launch<40>(st, maps, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
     if (!cols40) fb_cols_launch<20>(st, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);

@@ -1,6 +1,5 @@
 // voldor_amd/csrc/vk_fb.hpp -- the segmented forward-backward smoothing of the fast path (gpu-kernels/fb_smooth.h:17-109) as device functions: the
-// bodies of the row and the column pass, called by their own launches (vk_depth.hip k_fb_rows / k_fb_cols) and, round 5, by extra workgroups of the pose
-// half's P3P launches (vk_pose.hip k_solve_fc).
+// bodies of the row and the column pass (vk_depth.hip k_fb_rows / k_fb_cols).
 #pragma once
 #include "vk_common.hpp"
 #include "vk_device.hpp"
@@ -33,9 +32,8 @@ namespace vk {
 // the dependent chain of 2 x FB_SEG steps (40 -> 20: 15.6 -> 12.5 us per pass); 40 for lines up to twice that (2560x1440, 4K,
 // portrait 1080x1920); beyond (10240 x 2560) the pass falls back to one lane per line (fb_smooth_strict_device: any size).
 struct FbCoef { float p, q, dd, e0, e0p, e0dd, qe0, pqe0, pq; };
-// Every function below evaluates with explicit fused multiply-adds and contraction OFF: the segmented pass is compiled into two translation units
-// (its own launches in vk_depth.hip; extra workgroups of the pose half's launches in vk_pose.hip, round 5) whose build flags differ, and both must give
-// the same bits (tests/test_gpu_kernels.py "fb_overlap").
+// Every function below evaluates with explicit fused multiply-adds and contraction OFF: what a pass computes does not depend on the build flags of the
+// translation unit it is compiled into (round 5 compiled it into two: profiles/r05_summary.md).
 __device__ __forceinline__ FbCoef fb_coef(float e0, float p) {
 #pragma clang fp contract(off)
     FbCoef k;

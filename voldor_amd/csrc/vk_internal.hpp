@@ -15,9 +15,6 @@ struct ModeParams {
     // decide_n cameras (voldor.cpp:171-194 -> PoseBlock::n_active) instead of a separate one-thread launch
     int decide_n = 0, decide_allow_trunc = 0; float decide_trunc_rigidness_density = 0.f, decide_trunc_sample_density = 0.f;
     CamBrief* host_brief = nullptr;  // with decide_n: pinned host records the same thread fills for the host's copy of the decision
-    // with decide_n (round 5, fb_smooth riding in the pose half): the kernel that finishes the last camera also folds the rigid chain into the projective
-    // maps of the depth half (vk_cum_poses.hpp) and leaves the world-scale factor -- what an extra workgroup of the first fb_smooth launch used to do
-    int cum_N = -1, cum_Ndp = 0; float* world_scale = nullptr;
 };
 
 // Verification switches (NOT part of the product C-ABI: declared in vk_debug.h, set through the one entry vk_debug_switch; the test
@@ -32,9 +29,6 @@ struct DebugSwitches {
     int split_trials = 1;      // 0: the mode kernel runs the initial-mode trials itself
     int strict_pose_coop = 1;  // strict mode kernel on one single-wave workgroup per 512-row block of the pool (16 compute units) instead of one 512-thread workgroup; same bits
     // round 5
-    int pose_fused = 1;        // 0: collect, P3P batch and mode kernel of a camera as three launches instead of two (k_solve_fc: the P3P batch's launch also finishes this camera's correspondences and traces the next camera's; same bits)
-    int fb_overlap = 1;        // 0: fb_smooth of the rigidness maps as its own two launches at the head of the depth half (rounds 1-4) instead of extra workgroups of the pose half's P3P launches (same bits)
-    int local_table4 = 1;      // 0: one table sweep per local-propagation direction (rounds 2-4) instead of one sweep for the four directions + dirty-entry repair (same bits)
     int strict_coop_max_polls = 0;  // > 0: the cooperative strict mode kernel gives up a meeting after this many polls (tests force the give-up path); 0: 2^22
     int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
 };
@@ -72,10 +66,7 @@ __device__ __forceinline__ void maybe_decide(const ModeParams& mp, PoseBlock* P,
 int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p);
 int cost_map_device(Context* c, ImageSet& S, const OdParams& p);
 int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr,
-                     PoseBlock* cumP = nullptr, int cumN = 0, int cumNdp = 0, float* world_scale = nullptr, float* dst = nullptr, hipStream_t st = nullptr);
-bool fb_smooth_segmented(int w, int h);
-void fb_smooth_plan(int w, int h, int n_maps, int* rows_seg, int* cols_seg);  // steps per lane (20 | 40) the segmented passes take for this stack of maps
-int fb_cols_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob);  // the column pass alone, in place  // the segmented kernels take this size (else: the step-by-step fallback, in place on the context's stream only)
+                     PoseBlock* cumP = nullptr, int cumN = 0, int cumNdp = 0, float* world_scale = nullptr);
 // vk_strict.hip
 int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr);
 int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
@@ -101,18 +92,7 @@ int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, fl
 int xorwow_jumps_device(Context* c);                              // c->xw_jumps ready
 int xorwow_pixel_states_device(Context* c, int npx, uint32_t epoch);  // c->xw_px_states = states `epoch` draws after curand_init(RAND_SEED, pixel, 0)
 int xorwow_pose_states_device(Context* c, int n_poses);           // c->xw_pose_states = states after curand_init(RAND_SEED, idx, 0)
-// round 5: what rides in a mode kernel's launch on the compute units the mode kernel leaves idle (vk_pose.hip ModeAux, opaque here)
-struct ModeAuxPlan { alignas(8) unsigned char bytes[256]; int n_wg = 0; bool has_fb = false; };
-int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first = false, const ModeAuxPlan* plan = nullptr);
-// round 5 (k_solve_fc): the P3P batch of camera `cam` in a launch that first finishes the camera's correspondences from the staged trace (finalize; camera 0: k_collect
-// has written them).  mode_aux_plan: what rides in the launch of camera `cam`'s mode kernel -- the trace of camera cam + 1 (prestage_next) and fb_smooth blocks (fb_kind: 0
-// none, 1 rows rig -> rig2 and the prior confidences, 2 columns on rig2 and the prior confidences).  fused_eligible: the launches exist for this window (else the
-// three-launch chain).
-struct CollectParams { float rig_thresh, rig_sum_thresh, min_depth, max_depth; int max_trace; };
-bool fused_eligible(Context* c, int w, int h, int n_poses, int solver);
-int solve_fused_device(Context* c, ImageSet& S, int w, int h, int cam, bool finalize, float min_depth, float max_depth, float fx, float fy, float cx, float cy, int n_poses, bool ref_svd,
-                       CamState* cam_dev);
-int mode_aux_plan(Context* c, ImageSet& S, int N, int N_dp, int w, int h, int cam, bool prestage_next, const CollectParams& cp, int fb_kind, float fb_e0, float fb_p, ModeAuxPlan* out);
+int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first = false);
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 

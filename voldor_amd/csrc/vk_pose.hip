@@ -19,8 +19,6 @@
 #include "vk_lu.hpp"
 #include "vk_ref_cuda.h"
 #include "vk_internal.hpp"
-#include "vk_cum_poses.hpp"
-#include "vk_fb.hpp"
 
 namespace vk {
 
@@ -466,345 +464,6 @@ __global__ __launch_bounds__(64) static void k_solve(const float* __restrict__ p
                                                       float cx, float cy, int n_poses, int draw, int strict, const int* __restrict__ blk_offsets,
                                                       const unsigned long long* __restrict__ valid_mask, const vrc_xorwow* __restrict__ xw) {
     solve_body<SOLVER, FROM_MAP>(pts2, pts3, rvecs, tvecs, n_pts_dev, blk_counts, nblk, cam, npx, fx, fy, cx, cy, n_poses, draw, strict, blk_offsets, valid_mask, xw);
-}
-
-// ---- round 5: TWO launches per camera (vk_debug_switch "pose_fused") --------------------------------------------------------------------
-// The pose half of an EM iteration was three launches per camera -- k_collect, k_solve, k_pose_mode -- each a few hundred waves at most on a 256-CU
-// chip and each paying a launch boundary (2.85 us from the end of one dependent kernel to the start of the next, scripts/micro/event_cost.hip).
-// k_collect is the only one of the three that moves data (~130 bytes per pixel through the caches: 8.6 us at 640x480, at the L2 / MALL's rate), and
-// nearly all of it does NOT depend on the pose the previous camera's mode kernel has just produced: the pixel of camera a is traced through the
-// flows of frames start .. a from the projection of its 3-D point in frame `start`, which needs the poses 0 .. start - 1 <= a - 2 unless the trace
-// is one frame long; pose a - 1 only enters through the last rigid transform of the 3-D point (and through the projection of a one-frame trace).  So:
-//   * the MODE kernel's launch of camera a (one workgroup of 512 threads on one compute unit, 255 idle) carries extra workgroups that trace camera
-//     a + 1's pixels as far as the poses 0 .. a - 1 take them -- "prestage" (mode_prestage): validity of depth and rigidness, 3-D point in frame a
-//     coordinates, the flow trace where it does not need pose a; per pixel { flag, px, py, o } to a staging buffer.  Four pixels per lane, their
-//     gathers in flight together: the launch is compiled for the mode kernel's 256 registers, which buys memory-level parallelism per wave instead
-//     of waves (a first form with these workgroups in the P3P launch -- 150 registers, three waves per SIMD, the P3P chains on the same SIMDs --
-//     took 40 us against 8.6 + 17.7: profiles/r05c_*);
-//   * the P3P launch of camera a + 1 (k_solve_fc) starts by FINISHING those pixels in the workgroups that will solve: last transform, projection + one
-//     gather for the one-frame traces ("late" pixels), validity, ordered compaction inside each 256-pixel block -- exactly k_collect<true>'s values and
-//     layout -- then the workgroups MEET in the block counts: a count and the launch's tag in one 32-bit word (count | tag << 9, agent-scope store
-//     after the block's correspondences are out: write-through stores + s_waitcnt), every solver workgroup reads all words until each carries the tag
-//     (the same words it needs for the rank select's prefix anyway: the meeting costs one memory round trip), and solves.
-// Per camera: collect 8.6 + boundary 2.85 -> a few microseconds of finishing + meeting.  The meeting is among the 128 solver workgroups only (4 waves
-// and < 128 VGPRs... each -- resident at once on any free part of the chip); the spin is bounded, a timeout raises a flag in pinned host memory and the
-// window is run again on the three-launch chain (vk_voldor.hip).
-// The mode kernels' launches also carry fb_smooth of the depth half that follows (vk_debug_switch "fb_overlap"): its row pass with camera 0's, its
-// column pass with camera 1's -- out of place (ImageSet::rig2), the pose half still reads the raw maps.
-struct FcArgs {
-    const float2* flows; const PoseBlock* P;
-    int w, h; float min_depth, max_depth;
-    int cam, finalize;
-    const float* stage;  // [6][npx] planes: flag, px, py, o.x, o.y, o.z (mode_prestage)
-    float* p2_map; float* p3_map; float* corr /* finalize: the correspondences, [block][5 planes][256] */; unsigned* cnt_tag; const int* blk_counts; int nblk; unsigned tag;
-    float* rvecs; float* tvecs; int* n_pts_dev; CamState* camrec; float fx, fy, cx, cy; int n_poses, ref_svd;
-    int n_solve_wg;
-    unsigned max_polls; int* host_err;
-};
-__device__ __forceinline__ float ld_coh(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_coh(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-// What rides in a mode kernel's launch (workgroups 1 ..): the next camera's prestage, then fb_smooth blocks two per workgroup
-struct PreArgs { const float2* flows; const float* rig; const float* depth; const PoseBlock* P; int N, w, h; float rig_thresh, rig_sum_thresh, min_depth, max_depth; int max_trace, cam; float* stage; int n_wg; };
-struct FbJob { int kind /* 0 none, 1 rows src -> dst, 2 columns in place on dst */; const float* src; float* dst; int n_maps, S, CW, vec4, blocks_x, n_blocks; };
-struct ModeAux { PreArgs pre; FbJob fb[2]; float fb_e0, fb_p; int n_fb_wg; };
-constexpr int PRE_K = 4;  // pixels per lane of the prestage
-
-// Camera a's pixels as far as the poses 0 .. a - 2 take them (collect_p3p_instances.cu:70-145: the operations of k_collect, in its order per pixel),
-// PRE_K pixels per lane side by side: workgroup r takes pixels [r * PRE_K * 512, (r + 1) * PRE_K * 512), pixel (r * PRE_K + k) * 512 + tid in slot k.
-__device__ __forceinline__ void mode_prestage(const PreArgs& A, int r) {
-    constexpr int K = PRE_K;
-    const int w = A.w, h = A.h, npx = w * h, a = A.cam, N = A.N, tid = threadIdx.x;
-    const PoseBlock* P = A.P;
-    int pi[K];
-    bool ok[K];
-    float d[K], rg[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        pi[k] = (r * K + k) * 512 + tid;
-        const bool in = pi[k] < npx;
-        if (!in) pi[k] = 0;
-        d[k] = A.depth[pi[k]]; rg[k] = A.rig[(size_t)a * npx + pi[k]];
-        ok[k] = in;
-    }
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        ok[k] = ok[k] && !(d[k] < A.min_depth || (A.max_depth > 0.f && d[k] > A.max_depth));
-        if (ok[k] && A.rig_sum_thresh > (float)(N + 1)) {  // inert unless thr > N+1 (sic, :88-90)
-            float rs = 0.f;
-            for (int i = 0; i < N; i++) rs += A.rig[(size_t)i * npx + pi[k]];
-            if (rs < A.rig_sum_thresh) ok[k] = false;
-        }
-    }
-    int n_trace[K];
-    {
-        float prod[K];
-        bool go[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) { n_trace[k] = 0; prod[k] = 1.f; go[k] = ok[k]; }
-        const int lo = A.max_trace > 0 ? max(0, a - A.max_trace + 1) : 0;
-        for (int i = a; i >= lo; i--) {
-            float rv[K];
-#pragma unroll
-            for (int k = 0; k < K; k++) rv[k] = i == a ? rg[k] : A.rig[(size_t)i * npx + pi[k]];  // (k_collect reads a factor only while the product is alive: same values where they are used)
-#pragma unroll
-            for (int k = 0; k < K; k++)
-                if (go[k]) { prod[k] *= rv[k]; if (prod[k] > A.rig_thresh) n_trace[k]++; else go[k] = false; }
-        }
-#pragma unroll
-        for (int k = 0; k < K; k++) ok[k] = ok[k] && n_trace[k] > 0;
-    }
-    P3 o[K];
-    float qx[K], qy[K];
-    int start[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        o[k] = backproject(P, (float)(pi[k] % w), (float)(pi[k] / w), d[k]);
-        start[k] = a - n_trace[k] + 1; qx[k] = 0.f; qy[k] = 0.f;
-    }
-    // A gather inside a per-pixel branch is a memory round trip of its own: the K pixels of a lane would walk their traces one after the other.  So the
-    // decisions are taken first, then the K gathers of a step are issued together, unconditionally (a pixel that does not take the step reads texel (0, 0)
-    // of the layer), then used.  The values that are used are the values of the branching form.
-    for (int i = 0; i < a; i++) {  // frames 0 .. a - 1: their trace steps, and the transforms 0 .. a - 2 (transform a - 1 waits for its pose)
-        bool act[K], ins[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            act[k] = ok[k] && i >= start[k];
-            if (act[k] && i == start[k]) project(P, o[k], qx[k], qy[k]);
-            ins[k] = act[k] && qx[k] > 0.f && qx[k] < (float)w && qy[k] > 0.f && qy[k] < (float)h;  // strict (:120)
-        }
-        float2 f2[K];
-#pragma unroll
-        for (int k = 0; k < K; k++) f2[k] = bilinear2(A.flows + (size_t)i * npx, w, h, ins[k] ? qx[k] : 0.f, ins[k] ? qy[k] : 0.f);
-#pragma unroll
-        for (int k = 0; k < K; k++) {
-            if (ins[k]) { qx[k] += f2[k].x; qy[k] += f2[k].y; }
-            else if (act[k]) ok[k] = false;  // out of the image: the pixel is dropped
-        }
-        if (i < a - 1) {
-#pragma unroll
-            for (int k = 0; k < K; k++) o[k] = transform(P->Rs[i], P->ts[i], o[k]);
-        }
-    }
-    float* st = A.stage;
-    bool fin[K];  // frame a's own trace step continues from a known position (start <= a - 1): it does not see pose a - 1
-    float2 g2[K];
-#pragma unroll
-    for (int k = 0; k < K; k++) fin[k] = ok[k] && start[k] <= a - 1 && qx[k] > 0.f && qx[k] < (float)w && qy[k] > 0.f && qy[k] < (float)h;
-#pragma unroll
-    for (int k = 0; k < K; k++) g2[k] = bilinear2(A.flows + (size_t)a * npx, w, h, fin[k] ? qx[k] : 0.f, fin[k] ? qy[k] : 0.f);
-#pragma unroll
-    for (int k = 0; k < K; k++) {
-        float flag = 0.f;
-        if (ok[k]) {
-            if (start[k] <= a - 1) { if (fin[k]) { qx[k] += g2[k].x; qy[k] += g2[k].y; flag = 1.f; } }
-            else flag = 2.f;  // a one-frame trace: the projection of the point in frame a, hence pose a - 1, comes first ("late")
-        }
-        const int q = (r * K + k) * 512 + tid;
-        if (q < npx) {
-            st[q] = flag; st[(size_t)npx + q] = qx[k]; st[(size_t)2 * npx + q] = qy[k];
-            st[(size_t)3 * npx + q] = o[k].x; st[(size_t)4 * npx + q] = o[k].y; st[(size_t)5 * npx + q] = o[k].z;
-        }
-    }
-}
-// fb_smooth blocks riding in the (non-refit) mode kernel's launch: workgroup q of the fb range takes blocks 2 q and 2 q + 1 of the two jobs laid end
-// to end, one per 256-thread half (each half with its own LDS; both halves run the same kind of pass: the same barriers)
-__device__ __forceinline__ void mode_fb(const ModeAux& M, int q, int w, int h) {
-    __shared__ FbMat s_fb[2][4][256];  // [half][sF 2 x 256 | sB 2 x 256]
-    const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    int b = 2 * q + half;
-    const FbJob* J = &M.fb[0];
-    if (M.fb[0].kind && b >= M.fb[0].n_blocks && M.fb[1].kind) { b -= M.fb[0].n_blocks; J = &M.fb[1]; }
-    else if (!M.fb[0].kind) J = &M.fb[1];
-    // (a block index past its job: bx lands past the image, the half keeps the barriers company)
-    const int bx = b < J->n_blocks ? b % J->blocks_x : (1 << 20), by = b < J->n_blocks ? b / J->blocks_x : 0;
-    FbMat* sF = &s_fb[half][0][0]; FbMat* sB = &s_fb[half][2][0];
-    if (J->kind == 1) {
-        if (J->vec4) fb_rows_body<true, 20>(J->src, J->dst, w, h, J->S, M.fb_e0, M.fb_p, bx, by, sF, sB, tid);
-        else fb_rows_body<false, 20>(J->src, J->dst, w, h, J->S, M.fb_e0, M.fb_p, bx, by, sF, sB, tid);
-    } else fb_cols_body<20>(J->dst, w, h, J->S, J->CW, M.fb_e0, M.fb_p, bx, by, sF, sB, tid);
-}
-
-template <int SOLVER, int TMAX>
-__global__ __launch_bounds__(256) static void k_solve_fc(FcArgs A) {
-    extern __shared__ int s_pref[];
-    __shared__ int s_cnt[TMAX][4];
-    __shared__ int s_flag;
-    const int bid = blockIdx.x, tid = threadIdx.x, ln = tid & 63, wv = tid >> 6;
-    const int w = A.w, h = A.h, npx = w * h;
-    // ---- solver workgroup
-    const PoseBlock* P = A.P;
-    const int nblk = A.nblk;
-    auto pref_at = [](int i) { return i + (i >> 5); };
-    if (A.finalize) {
-        // (1) finish this camera's correspondences for blocks bid, bid + n_solve_wg, ..: everything of a block's pixels in flight together
-        const int a = A.cam;
-        const float* st = A.stage;
-        float fl[TMAX], px[TMAX], py[TMAX], ox[TMAX], oy[TMAX], oz[TMAX];
-#pragma unroll
-        for (int k = 0; k < TMAX; k++) {
-            const int t = bid + k * A.n_solve_wg, pi = t * 256 + tid;
-            const bool in = t < nblk && pi < npx;
-            const int q = in ? pi : 0;
-            fl[k] = st[q]; px[k] = st[(size_t)npx + q]; py[k] = st[(size_t)2 * npx + q];
-            ox[k] = st[(size_t)3 * npx + q]; oy[k] = st[(size_t)4 * npx + q]; oz[k] = st[(size_t)5 * npx + q];
-            if (!in) fl[k] = 0.f;
-        }
-        // (the gathers of the one-frame traces of all blocks together, unconditionally: see mode_prestage)
-        bool valid[TMAX], late_in[TMAX];
-        float qx[TMAX], qy[TMAX];
-#pragma unroll
-        for (int k = 0; k < TMAX; k++) {
-            P3 o = { ox[k], oy[k], oz[k] };
-            o = transform(P->Rs[a - 1], P->ts[a - 1], o);  // (finalize is only ever set for a >= 1)
-            ox[k] = o.x; oy[k] = o.y; oz[k] = o.z;
-            qx[k] = 0.f; qy[k] = 0.f;
-            if (fl[k] == 2.f) project(P, o, qx[k], qy[k]);  // the one-frame trace: project, then frame a's step
-            late_in[k] = fl[k] == 2.f && qx[k] > 0.f && qx[k] < (float)w && qy[k] > 0.f && qy[k] < (float)h;
-        }
-        float2 f2[TMAX];
-#pragma unroll
-        for (int k = 0; k < TMAX; k++) f2[k] = bilinear2(A.flows + (size_t)a * npx, w, h, late_in[k] ? qx[k] : 0.f, late_in[k] ? qy[k] : 0.f);
-#pragma unroll
-        for (int k = 0; k < TMAX; k++) {
-            bool ok = fl[k] != 0.f;
-            if (fl[k] == 2.f) {
-                if (late_in[k]) { px[k] = qx[k] + f2[k].x; py[k] = qy[k] + f2[k].y; }
-                else ok = false;
-            }
-            ok = ok && oz[k] > A.min_depth && (A.max_depth <= 0.f || oz[k] < A.max_depth);
-            ok = ok && isfinite(px[k] + py[k] + ox[k] + oy[k] + oz[k]);  // geometry.cpp:73 keeps only entries whose sum is finite
-            valid[k] = ok;
-        }
-        unsigned long long m[TMAX];
-#pragma unroll
-        for (int k = 0; k < TMAX; k++) {
-            m[k] = __ballot(valid[k]);
-            if (ln == 0) s_cnt[k][wv] = __popcll(m[k]);
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < TMAX; k++) {
-            if (valid[k]) {
-                const int t = bid + k * A.n_solve_wg;
-                int r = __popcll(m[k] & ((1ull << ln) - 1ull));
-                for (int j = 0; j < wv; j++) r += s_cnt[k][j];
-                // five planes of 256 entries per block: consecutive ranks are consecutive addresses (a wave's store instruction is one or two full lines on
-                // its way to memory, not 64 four-byte pieces of a 20-byte record)
-                float* seg = A.corr + (size_t)t * 1280 + r;
-                st_coh(seg, px[k]); st_coh(seg + 256, py[k]); st_coh(seg + 512, ox[k]); st_coh(seg + 768, oy[k]); st_coh(seg + 1024, oz[k]);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread's correspondences have left for memory (write-through stores) ...
-        __syncthreads();                                   // ... and so have everybody else's in the workgroup: the counts may say so
-        if (tid < TMAX) {
-            const int t = bid + tid * A.n_solve_wg;
-            if (t < nblk) {
-                const unsigned cnt = (unsigned)(s_cnt[tid][0] + s_cnt[tid][1] + s_cnt[tid][2] + s_cnt[tid][3]);
-                __hip_atomic_store(A.cnt_tag + t, cnt | (A.tag << 9), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-    }
-    // (2) the counts of ALL blocks -> inclusive prefix in LDS (what the rank select bisects).  finalize: every word must carry this launch's tag --
-    // that is where the solver workgroups meet.  Wave 0: (a) the words, coalesced (lane l reads words l, l + 64, ..: 32 in flight), raw counts to
-    // the LDS; (b) lane l sums 32 CONSECUTIVE counts in registers, one 6-step wave scan per 2048 blocks, running sums back to the same slots
-    // (k_solve's prefix_to_lds; padded layout pref_at: conflict-free either way).
-    if (wv == 0) {
-        bool gave_up = false;
-        for (int i0 = 0; i0 < nblk && !gave_up; i0 += 64 * 32) {
-            unsigned spins = 0;
-            for (;;) {
-                bool all = true;
-#pragma unroll
-                for (int j = 0; j < 32; j++) {
-                    const int i = i0 + j * 64 + ln;
-                    unsigned wd = A.tag << 9;
-                    if (i < nblk) wd = A.finalize ? __hip_atomic_load(A.cnt_tag + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ((unsigned)A.blk_counts[i] | (A.tag << 9));
-                    all = all && (wd >> 9) == A.tag;
-                    if (i < nblk) s_pref[pref_at(i)] = (int)(wd & 0x1ffu);
-                }
-                if (__all(all)) break;
-                if (++spins > A.max_polls) { gave_up = true; break; }
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        int carry = 0;
-        for (int i0 = 0; i0 < nblk && !gave_up; i0 += 64 * 32) {
-            const int b0 = i0 + ln * 32;
-            int v[32];
-#pragma unroll
-            for (int j = 0; j < 32; j++) v[j] = b0 + j < nblk ? s_pref[pref_at(b0 + j)] : 0;
-#pragma unroll
-            for (int j = 1; j < 32; j++) v[j] += v[j - 1];
-            int incl = v[31];
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o, 64); if (ln >= o) incl += t; }
-            const int base = carry + incl - v[31];
-#pragma unroll
-            for (int j = 0; j < 32; j++) if (b0 + j < nblk) s_pref[pref_at(b0 + j)] = base + v[j];
-            carry += __shfl(incl, 63, 64);
-        }
-        if (ln == 0) {
-            s_flag = gave_up ? 1 : 0;
-            if (gave_up && A.host_err) { *A.host_err = 1; __threadfence_system(); }  // the window is run again on the three-launch chain (vk_voldor.hip)
-        }
-    }
-    __syncthreads();
-    if (s_flag) return;
-    const int n_pts = nblk > 0 ? s_pref[pref_at(nblk - 1)] : 0;
-    // (3) this wave's 16 hypotheses, four lanes each (k_solve's rank-select draw over block-compacted correspondences, LambdaTwist)
-    const int gtid = (bid * 4 + wv) * 64 + ln, idx = gtid / 4, sub = gtid % 4;
-    if (gtid == 0) { *A.n_pts_dev = n_pts; if (A.camrec) A.camrec->n_points = n_pts; }
-    if (idx >= A.n_poses) return;
-    const float qnan = __builtin_nanf("");
-    float R[9], t[3];
-    bool ok = false;
-    float errf = 0.f; double errd = 0.0;
-    if (n_pts >= 4) {
-        // (int)(curand_uniform * N_pts), clamped (D3): solve_batch_lambdatwist.cu:16-19; lane `sub` finds point `sub`
-        const int rk = min((int)(draw_uniform(nullptr, idx, sub) * (float)n_pts), n_pts - 1);
-        int lo = 0, hi = nblk - 1;  // first block whose inclusive prefix exceeds the rank
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_pref[pref_at(mid)] > rk) hi = mid; else lo = mid + 1; }
-        const int found = lo * 256 + (rk - (lo > 0 ? s_pref[pref_at(lo - 1)] : 0));
-        float yu[4], yv[4], xp[4][3];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int i = __shfl(found, (ln & ~3) + k, 64);
-            // (the correspondences of this launch's own finalize phase come from other compute units: coherent loads; k_collect's are a launch old)
-            if (A.finalize) {
-                const float* seg = A.corr + (size_t)(i >> 8) * 1280 + (i & 255);
-                yu[k] = ld_coh(seg); yv[k] = ld_coh(seg + 256);
-                xp[k][0] = ld_coh(seg + 512); xp[k][1] = ld_coh(seg + 768); xp[k][2] = ld_coh(seg + 1024);
-            } else {
-                yu[k] = A.p2_map[(size_t)i * 2]; yv[k] = A.p2_map[(size_t)i * 2 + 1];
-                xp[k][0] = A.p3_map[(size_t)i * 3]; xp[k][1] = A.p3_map[(size_t)i * 3 + 1]; xp[k][2] = A.p3_map[(size_t)i * 3 + 2];
-            }
-        }
-        if (SOLVER == 0) ok = lambdatwist_p4p<float>(yu, yv, xp, A.fx, A.fy, A.cx, A.cy, R, t, sub, &errf);
-        else ok = lambdatwist_p4p<double>(yu, yv, xp, A.fx, A.fy, A.cx, A.cy, R, t, sub, &errd);
-    }
-    float aa[3] = { qnan, qnan, qnan };
-    if (ok) {
-        if (A.ref_svd) vrs_project_rotation(R); else nearest_rotation(R);
-        rotmat_to_angle_axis(R, aa, false);
-    }
-    // fold the four candidates in root order: the first valid one, then any later one with a strictly smaller 4th-point error (lambdatwist_p4p.h:43-58)
-    const int base = ln & ~3;
-    int win = -1;
-    double werr = 0.0;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const int okc = __shfl((int)ok, base + c, 64);
-        const double ec = (SOLVER == 2) ? __shfl(errd, base + c, 64) : (double)__shfl(errf, base + c, 64);
-        if (okc && (win < 0 || werr > ec)) { win = c; werr = ec; }
-    }
-    const bool writer = (win < 0) ? (sub == 0) : (sub == win);  // no candidate: lane 0 writes the NaN marker
-    if (writer) {
-        const int n_poses = A.n_poses;
-        A.rvecs[idx] = aa[0]; A.rvecs[(size_t)n_poses + idx] = aa[1]; A.rvecs[(size_t)2 * n_poses + idx] = aa[2];
-        A.tvecs[idx] = ok ? t[0] : qnan; A.tvecs[(size_t)n_poses + idx] = ok ? t[1] : qnan; A.tvecs[(size_t)2 * n_poses + idx] = ok ? t[2] : qnan;
-    }
 }
 
 // ---- single-workgroup mode finding ---------------------------------------------------------------
@@ -1538,7 +1197,7 @@ __device__ __forceinline__ void refit_block(f2 (&X)[PM_POOL / THREADS / 2][6], i
 // THREADS: the per-iteration all-reduce, the mean update and the convergence test are executed by every wave (~100 instructions next
 // to ~30 per pair of hypotheses), so fewer, fatter waves do less redundant work: THREADS * SPT = PM_POOL.
 template <bool DEFER, int THREADS>
-__device__ __forceinline__ static void pose_mode_main(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
+__device__ __forceinline__ static void pose_mode_body(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
                                                       int n_poses, const ModeParams& mp, CamState* cam, PoseBlock* P, int cam_idx,
                                                       const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
 #pragma clang fp contract(fast)  // kernel-weighted sums: not part of the solver's exact-rounding contract (file-wide: off)
@@ -1758,29 +1417,9 @@ __device__ __forceinline__ static void pose_mode_main(const float* __restrict__ 
     }
     PH_MARK(22);
 }
-// pose_mode_main (every exit of which has written the camera record and, on the last camera, the truncation decision), then -- on the last camera of an
-// iteration whose fb_smooth rides in the pose half -- the projective maps of the depth half that follows and the world-scale factor (vk_cum_poses.hpp):
-// thread 0's stores (pose, n_active) are pushed out and the workgroup meets before anybody reads them back.
-template <bool DEFER, int THREADS>
-__device__ __forceinline__ static void pose_mode_body(const float* __restrict__ rvecs, const float* __restrict__ tvecs,
-                                                      int n_poses, const ModeParams& mp, CamState* cam, PoseBlock* P, int cam_idx,
-                                                      const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
-    pose_mode_main<DEFER, THREADS>(rvecs, tvecs, n_poses, mp, cam, P, cam_idx, n_points_dev, trials_in);
-    if (mp.decide_n > 0 && mp.cum_N >= 0) {  // (uniform)
-        __threadfence();
-        __syncthreads();
-        cum_poses_block(P, mp.cum_N, mp.cum_Ndp, mp.world_scale);
-    }
-}
 template <bool DEFER, int THREADS>
 __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp, CamState* cam,
-                                                                  PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev, const float* __restrict__ trials_in, ModeAux aux) {
-    if (blockIdx.x > 0) {  // round 5: what rides along on the 255 compute units the mode kernel leaves idle (workgroup 0 is the mode kernel itself)
-        const int r = (int)blockIdx.x - 1;
-        if (r < aux.pre.n_wg) mode_prestage(aux.pre, r);
-        else if constexpr (!DEFER && THREADS == 512) { if (r - aux.pre.n_wg < aux.n_fb_wg) mode_fb(aux, r - aux.pre.n_wg, aux.pre.w, aux.pre.h); }
-        return;
-    }
+                                                                  PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
     pose_mode_body<DEFER, THREADS>(rvecs, tvecs, n_poses, mp, cam, P, cam_idx, n_points_dev, trials_in);
 }
 // The initial-mode trials of a camera that has no pose yet (first EM iteration; meanshift.cu:72-95: the kernel density at up to
@@ -2031,114 +1670,8 @@ int xorwow_pose_states_device(Context* c, int n_poses) {
     return 0;
 }
 
-// ---- k_solve_fc launcher -------------------------------------------------------------------------------------------------------------------
-constexpr int FC_T_SMALL = 10, FC_T_LARGE = 16;  // blocks a solver workgroup finishes (template bound of k_solve_fc): 640x480 needs 9.4, 1241x376 14.3
-static int fc_solve_wgs(int n_poses) { return (n_poses * 4 + 255) / 256; }
-bool fused_eligible(Context* c, int w, int h, int n_poses, int solver) {
-    if (c->fused_broken || solver != 0 || n_poses < 64 || n_poses > PM_POOL) return false;
-    const int npx = w * h, nblk = (npx + 255) / 256, ns = fc_solve_wgs(n_poses);
-    if (nblk > FC_T_LARGE * ns) return false;  // larger images: the three-launch chain (their collect is throughput, not latency)
-    if ((npx + PRE_K * 512 - 1) / (PRE_K * 512) > 240) return false;  // the prestage workgroups of a mode kernel's launch: one per compute unit (256 registers per lane)
-    if (sizeof(int) * ((size_t)nblk + nblk / 32 + 1) > 40 * 1024) return false;
-    // the solver workgroups wait for each other: they must all fit the device at once (asked once per process)
-    static const int fits = [] {
-        int a = 0, b = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, k_solve_fc<0, FC_T_SMALL>, 256, 12 * 1024) != hipSuccess) return 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, k_solve_fc<0, FC_T_LARGE>, 256, 12 * 1024) != hipSuccess) return 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-        return (a < b ? a : b) * cus;
-    }();
-    return fits >= 2 * ns;  // (twice: two windows may be at it at once)
-}
-int solve_fused_device(Context* c, ImageSet& S, int w, int h, int cam, bool finalize, float min_depth, float max_depth, float fx, float fy, float cx, float cy, int n_poses, bool ref_svd,
-                       CamState* cam_dev) {
-    const int npx = w * h, nblk = (npx + 255) / 256;
-    if (int e = c->p2_map.reserve(sizeof(float) * 2 * (size_t)npx)) return e;
-    if (int e = c->p3_map.reserve(sizeof(float) * 3 * (size_t)npx)) return e;
-    if (int e = c->blk_counts.reserve(sizeof(int) * (size_t)nblk)) return e;
-    if (int e = c->ensure_n_points()) return e;
-    if (int e = c->rvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
-    if (int e = c->tvecs.reserve(sizeof(float) * 3 * (size_t)n_poses)) return e;
-    if (int e = c->fc_stage.reserve(sizeof(float) * 6 * (size_t)npx)) return e;
-    if (int e = c->fc_corr.reserve(sizeof(float) * 1280 * (size_t)nblk)) return e;
-    if (c->fc_cnt_tag.cap < sizeof(unsigned) * (size_t)nblk || c->fc_tag >= (1u << 23) - 2u) {  // fresh words, or the tag is about to wrap: no word may carry a tag of the coming launches
-        if (int e = c->fc_cnt_tag.reserve(sizeof(unsigned) * (size_t)nblk)) return e;
-        VK_CHECK(hipMemsetAsync(c->fc_cnt_tag.p, 0, c->fc_cnt_tag.cap, c->stream));
-        c->fc_tag = 0;
-    }
-    FcArgs A{};
-    A.flows = S.flows.as<float2>(); A.P = S.pb();
-    A.w = w; A.h = h; A.min_depth = min_depth; A.max_depth = max_depth;
-    A.cam = cam; A.finalize = finalize ? 1 : 0;
-    A.stage = c->fc_stage.as<float>();
-    A.p2_map = c->p2_map.as<float>(); A.p3_map = c->p3_map.as<float>(); A.corr = c->fc_corr.as<float>(); A.cnt_tag = c->fc_cnt_tag.as<unsigned>(); A.blk_counts = c->blk_counts.as<int>(); A.nblk = nblk;
-    A.tag = ++c->fc_tag;
-    A.rvecs = c->rvecs.as<float>(); A.tvecs = c->tvecs.as<float>(); A.n_pts_dev = c->n_points.as<int>(); A.camrec = cam_dev;
-    A.fx = fx; A.fy = fy; A.cx = cx; A.cy = cy; A.n_poses = n_poses; A.ref_svd = ref_svd ? 1 : 0;
-    A.n_solve_wg = fc_solve_wgs(n_poses);
-    A.max_polls = 1u << 17;  // ~0.3 s of polling: what a meeting can legitimately wait for is the end of somebody else's kernels (milliseconds)
-    A.host_err = c->h_fc_err_dev;
-    const size_t lds = sizeof(int) * ((size_t)nblk + nblk / 32 + 1);
-    const dim3 g(A.n_solve_wg), b(256);
-    if (nblk <= FC_T_SMALL * A.n_solve_wg) hipLaunchKernelGGL((k_solve_fc<0, FC_T_SMALL>), g, b, lds, c->stream, A);
-    else hipLaunchKernelGGL((k_solve_fc<0, FC_T_LARGE>), g, b, lds, c->stream, A);
-    c->n_map_blocks = nblk;
-    c->maps_block_compact = true;
-    VK_CHECK_LAST();
-    return 0;
-}
-// what rides in the launch of camera `cam`'s mode kernel: the prestage of camera cam + 1 (prestage_next), fb_smooth blocks (fb_kind: 0 none, 1 rows rig -> rig2
-// and the prior confidences, 2 columns on rig2 and the prior confidences; not with the refit kernel: its 141 KB of LDS leave no room)
-int mode_aux_plan(Context* c, ImageSet& S, int N, int N_dp, int w, int h, int cam, bool prestage_next, const CollectParams& cp, int fb_kind, float fb_e0, float fb_p, ModeAuxPlan* out) {
-    static_assert(sizeof(ModeAux) <= sizeof(out->bytes), "ModeAuxPlan::bytes holds a ModeAux");
-    ModeAux M{};
-    const int npx = w * h;
-    if (prestage_next) {
-        if (int e = c->fc_stage.reserve(sizeof(float) * 6 * (size_t)npx)) return e;
-        PreArgs& A = M.pre;
-        A.flows = S.flows.as<float2>(); A.rig = S.rig.as<float>(); A.depth = S.depth.as<float>(); A.P = S.pb();
-        A.N = N; A.w = w; A.h = h; A.rig_thresh = cp.rig_thresh; A.rig_sum_thresh = cp.rig_sum_thresh; A.min_depth = cp.min_depth; A.max_depth = cp.max_depth; A.max_trace = cp.max_trace;
-        A.cam = cam + 1; A.stage = c->fc_stage.as<float>();
-        A.n_wg = (npx + PRE_K * 512 - 1) / (PRE_K * 512);
-    }
-    M.pre.w = w; M.pre.h = h;
-    M.fb_e0 = fb_e0; M.fb_p = fb_p;
-    int blocks = 0;
-    if (fb_kind) {
-        struct { const float* src; float* dst; int n; } stacks[2] = { { S.rig.as<float>(), S.rig2.as<float>(), N }, { S.confs.as<float>(), S.confs.as<float>(), N_dp } };
-        for (int j = 0; j < 2; j++) {
-            if (stacks[j].n <= 0) continue;
-            int rs = 20, cs = 20;
-            fb_smooth_plan(w, h, stacks[j].n, &rs, &cs);
-            if (rs != 20 || cs != 20) return (int)hipErrorInvalidValue;  // (fb_overlap_ok: sizes of 20-step segments only)
-            FbJob& J = M.fb[j];
-            J.kind = fb_kind; J.src = stacks[j].src; J.dst = stacks[j].dst; J.n_maps = stacks[j].n;
-            if (fb_kind == 1) {
-                J.S = (w + 19) / 20;
-                const int lpb = 256 / J.S;
-                J.blocks_x = (h + lpb - 1) / lpb;
-                J.vec4 = ((w % 4) == 0 && (reinterpret_cast<uintptr_t>(J.src) % 16) == 0 && (reinterpret_cast<uintptr_t>(J.dst) % 16) == 0) ? 1 : 0;
-            } else {
-                J.S = (h + 19) / 20;
-                J.CW = 256 / J.S < 16 ? 256 / J.S : 16;
-                J.blocks_x = (w + J.CW - 1) / J.CW;
-            }
-            J.n_blocks = J.blocks_x * J.n_maps;
-            blocks += J.n_blocks;
-        }
-    }
-    M.n_fb_wg = (blocks + 1) / 2;
-    memcpy(out->bytes, &M, sizeof M);
-    out->n_wg = M.pre.n_wg + M.n_fb_wg;
-    out->has_fb = M.n_fb_wg > 0;
-    return 0;
-}
-
-int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first, const ModeAuxPlan* plan) {
+int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first) {
     ModeParams mp = mp_in;
-    ModeAux aux{};
-    int n_aux = 0;
-    if (plan) { memcpy(&aux, plan->bytes, sizeof aux); n_aux = plan->n_wg; if (mp.do_rg && plan->has_fb) return (int)hipErrorInvalidValue; }
     mp.rg_partition = debug_switches().refit_partition;
     if (n_poses > PM_POOL) {
         fprintf(stderr, "voldor_hip: n_poses_to_sample=%d exceeds the %d hypotheses the mode kernel keeps in registers\n", n_poses,
@@ -2158,11 +1691,11 @@ int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState*
         trials = out;
     }
     if (mp.do_rg)
-        hipLaunchKernelGGL((k_pose_mode<true, PM_THREADS>), dim3(1 + n_aux), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
-                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials, aux);
+        hipLaunchKernelGGL((k_pose_mode<true, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials);
     else
-        hipLaunchKernelGGL((k_pose_mode<false, PM_THREADS>), dim3(1 + n_aux), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
-                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials, aux);
+        hipLaunchKernelGGL((k_pose_mode<false, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials);
     VK_CHECK_LAST();
     return 0;
 }

@@ -21,7 +21,6 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
-#include <utility>
 #include <vector>
 
 namespace vk {
@@ -110,7 +109,6 @@ struct Config {
     }
 };
 
-constexpr int VK_ERR_FUSED_GAVE_UP = 20001;  // internal: never leaves voldor_run_on
 enum OdFlag { OD_DEFAULT = 0, OD_ONLY_USE_DEPTH_PRIOR = 1, OD_UPDATE_RIGIDNESS_ONLY = 2 };  // voldor.h:7-11
 
 struct Voldor {
@@ -149,11 +147,10 @@ struct Voldor {
         if (int e = S.ensure_pose()) return e;
         if (int e = S.flows.reserve(sizeof(float) * 2 * npx * N)) return e;
         if (int e = S.rig.reserve(sizeof(float) * npx * N)) return e;
-        if (int e = S.rig2.reserve(sizeof(float) * npx * N)) return e;
         if (int e = S.depth.reserve(sizeof(float) * npx)) return e;
         if (int e = S.cost.reserve(sizeof(float) * npx)) return e;
         if (int e = c->cams.reserve(sizeof(CamState) * MAX_FRAMES)) return e;
-        if (int e = c->ms_io.reserve(sizeof(float) * (64 + 8 * 64) + sizeof(int) * 4)) return e;  // full size now: world_scale_ptr() is handed to kernels enqueued before the mode kernels ask for it
+        if (int e = c->ms_io.reserve(sizeof(float) * (64 + 8 * 64) + sizeof(int) * 4)) return e;  // at its full size once: world_scale_ptr() stays valid whatever the mode kernels reserve later
         VK_CHECK(hipMemcpyAsync(S.flows.p, flows, sizeof(float) * 2 * npx * N, hipMemcpyDefault, st));
         if (int e = fill_device(c, S.rig.as<float>(), 1.f, npx * N)) return e;
         PoseBlock& pb = *c->h_pb;  // pinned staging: the previous window of this context ended with a stream synchronize, so it is free
@@ -197,34 +194,10 @@ struct Voldor {
         return 0;
     }
 
-    // Round 5 (vk_pose.hip k_solve_fc): two launches per camera instead of three, and fb_smooth of the depth half riding in the pose half.
-    //   fused_ok       the launch of a camera's P3P batch also finishes the camera's correspondences, from the trace that extra workgroups of the PREVIOUS
-    //                  camera's mode launch staged: fast mode, the float LambdaTwist solver, the reference's index draw
-    //   fb_overlap_ok  fb_smooth (optimize_depth.cu:462-466) reads what the previous E-step wrote and nothing of this iteration's poses: its row pass
-    //                  runs as extra workgroups of camera 0's mode launch, its column pass of camera 1's (alone after the cameras when there is only one).
-    //                  The pose half still reads the unsmoothed rigidness maps (collect_p3p_instances.cu:84-100), so the row pass writes the other
-    //                  buffer of a ping-pong (rig -> rig2, columns in place on rig2), the depth half works on rig2, its E-step writes rig2, and the two
-    //                  swap.  The prior-confidence maps are not read by the pose half: smoothed in place.  Every map of the frames still registered
-    //                  is smoothed (a frame this iteration's decision drops is never read again).  The projective maps of the depth half -- an extra
-    //                  workgroup of the first fb_smooth launch until now -- come from the tail of the last camera's mode kernel.
-    // Same values, same bits as the separate launches (vk_debug_switch "pose_fused" / "fb_overlap" = 0; tests/test_gpu_kernels.py).
-    int solver_kind() const { return cfg.lambdatwist ? (cfg.cpu_p3p ? 2 : 0) : 1; }  // cpu_p3p=1 selects the reference's CPU instantiation lambdatwist_p4p<double,...> (geometry.cpp:112)
-    bool fused_ok() const {
-        return !strict && !ref_rng && cfg.reference_draw && debug_switches().pose_fused && n_flows > 0 && fused_eligible(c, w, h, cfg.n_poses_to_sample, solver_kind());
-    }
-    bool fb_overlap_ok() const {
-        if (!(fused_ok() && cfg.optimize_depth && cfg.fb_smooth && debug_switches().fb_overlap && fb_smooth_segmented(w, h))) return false;
-        int rs = 0, cs = 0, rs2 = 20, cs2 = 20;
-        fb_smooth_plan(w, h, n_flows, &rs, &cs);
-        if (n_dp > 0) fb_smooth_plan(w, h, n_dp, &rs2, &cs2);
-        return rs == 20 && cs == 20 && rs2 == 20 && cs2 == 20 && (w + 19) / 20 <= 256 && (h + 19) / 20 <= 256;  // the riding passes are the 20-step ones
-    }
-
     // voldor.cpp:203-307 (the upload / "minimal cache" branches collapse: everything is resident)
-    int optimize_depth(OdFlag flag, bool with_world_scale = false, bool fb_done = false) {
+    int optimize_depth(OdFlag flag, bool with_world_scale = false) {
         if (n_flows == 0 && n_dp == 0) return 0;
         OdParams p;
-        p.fb_done = fb_done; p.cum_done = fb_done;
         p.abs_resize_factor = cfg.abs_resize_factor;
         p.N = (flag == OD_ONLY_USE_DEPTH_PRIOR) ? 0 : n_flows; p.N_dp = n_dp; p.w = w; p.h = h; p.basefocal = cfg.basefocal;
         p.n_rand_samples = cfg.depth_rand_samples; p.global_prop_step = cfg.depth_global_prop_step; p.local_prop_width = cfg.depth_local_prop_width;
@@ -238,23 +211,20 @@ struct Voldor {
             p.stale_refresh = iters_cur < 2;  // voldor.cpp:250: "iters_cur == 0 || iters_cur == 1": the calls that upload the map
         }
         if (with_world_scale) p.world_scale_out = world_scale_ptr();  // voldor.cpp:309-317: the pose half rides on the density launch, the depth half follows
-        if (fb_done) std::swap(c->od.rig, c->od.rig2);  // the smoothed maps are in the other buffer (the pose half's launches wrote them): the depth half works there
         return optimize_depth_device(c, c->od, p);  // with world_scale_out: depth and poses leave normalised (voldor.cpp:309-317)
     }
 
     // voldor/geometry.cpp:5-265, all on the device; success / density come back in CamState
     float* world_scale_ptr() { return c->ms_io.as<float>() + 48; }  // (ms_io is reserved at its full size in init(): the pointer holds for the window)
-    int optimize_camera_pose(int i, bool rg_refine, bool last, bool fused, bool fb_ov, bool with_world_scale) {
+    int optimize_camera_pose(int i, bool rg_refine, bool last = false) {
         ImageSet& S = c->od;
         if (c->prof) prof_begin(c);
-        const int solver = solver_kind();
+        const int solver = cfg.lambdatwist ? (cfg.cpu_p3p ? 2 : 0) : 1;  // cpu_p3p=1 selects the reference's CPU instantiation lambdatwist_p4p<double,...> (geometry.cpp:112)
         const bool ref_svd = cfg.reference_svd < 0 ? reference_svd_default() : cfg.reference_svd != 0;
-        if (!fused || i == 0) {  // (fused: camera 0 has nobody to trace its pixels ahead of it)
-            if (int e = collect_device(c, S, n_flows, w, h, i, cfg.rigidness_threshold, cfg.rigidness_sum_threshold,
-                                       cfg.pose_sample_min_depth, cfg.pose_sample_max_depth, cfg.max_trace_on_flow, dcams() + i, false,
-                                       /*block_compact=*/cfg.reference_draw != 0, ref_tex))  // the index draw reads (block, rank in block) directly
-                return e;
-        }
+        if (int e = collect_device(c, S, n_flows, w, h, i, cfg.rigidness_threshold, cfg.rigidness_sum_threshold,
+                                   cfg.pose_sample_min_depth, cfg.pose_sample_max_depth, cfg.max_trace_on_flow, dcams() + i, false,
+                                   /*block_compact=*/cfg.reference_draw != 0, ref_tex))  // the index draw reads (block, rank in block) directly
+            return e;
         ModeParams mp{};
         mp.dims = 6; mp.kernel_var = cfg.meanshift_kernel_var; mp.ms_epsilon = cfg.meanshift_epsilon;
         mp.ms_max_iters = cfg.meanshift_max_iters; mp.ms_max_init_trials = cfg.meanshift_max_init_trials;
@@ -267,22 +237,11 @@ struct Voldor {
             mp.decide_trunc_rigidness_density = cfg.trunc_rigidness_density; mp.decide_trunc_sample_density = cfg.trunc_sample_density;
             mp.host_brief = c->h_brief_dev;
         }
-        if (last && fb_ov) { mp.cum_N = n_flows; mp.cum_Ndp = n_dp; mp.world_scale = with_world_scale ? world_scale_ptr() : nullptr; }
-        ModeAuxPlan plan;
-        if (fused) {
-            // this camera's P3P batch (finishing the correspondences the previous mode launch traced: cameras >= 1), and what rides in this camera's mode launch
-            if (int e = solve_fused_device(c, S, w, h, i, /*finalize=*/i > 0, cfg.pose_sample_min_depth, cfg.pose_sample_max_depth, cfg.fx, cfg.fy, cfg.cx, cfg.cy,
-                                           cfg.n_poses_to_sample, ref_svd, dcams() + i))
-                return e;
-            const CollectParams cp{ cfg.rigidness_threshold, cfg.rigidness_sum_threshold, cfg.pose_sample_min_depth, cfg.pose_sample_max_depth, cfg.max_trace_on_flow };
-            const int fb_kind = fb_ov ? (i == 0 ? 1 : (i == 1 ? 2 : 0)) : 0;
-            if (int e = mode_aux_plan(c, S, n_flows, n_dp, w, h, i, /*prestage_next=*/i + 1 < n_flows, cp, fb_kind, cfg.fb_emm, cfg.fb_no_change_prob, &plan)) return e;
-        } else
         if (int e = solve_from_maps_device(c, w * h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, cfg.n_poses_to_sample, solver, dcams() + i,
                                            cfg.reference_draw ? 1 : 0, strict, ref_svd, ref_rng))
             return e;
         if (strict) { if (int e = pose_mode_strict_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e; }
-        else if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i, hcams[i].pose_sample_count == 0, fused ? &plan : nullptr)) return e;
+        else if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i, hcams[i].pose_sample_count == 0)) return e;
         if (c->prof) prof_end(c, "optimize_camera_pose");
         return 0;
     }
@@ -293,15 +252,10 @@ struct Voldor {
     // after it has already enqueued this iteration's depth half: the GPU never waits for the host decision.
     // Equivalent to the reference order: a camera that fails or is skipped truncates the window at its index, so whatever
     // the speculatively executed later cameras wrote (their own pose slots only) is never read again.
-    bool refit_iteration() const { return cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0); }
-    int enqueue_cameras(bool fused, bool fb_ov, bool with_world_scale) {
-        const bool rg = refit_iteration();
+    int enqueue_cameras() {
+        const bool rg = cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0);
         for (int i = 0; i < n_flows; i++)
-            if (int e = optimize_camera_pose(i, rg, i == n_flows - 1, fused, fb_ov, with_world_scale)) return e;
-        if (fb_ov && n_flows == 1) {  // one camera: the column pass had no launch to ride in
-            if (int e = fb_cols_device(c, c->od.rig2.as<float>(), n_flows, w, h, cfg.fb_emm, cfg.fb_no_change_prob)) return e;
-            if (int e = fb_cols_device(c, c->od.confs.as<float>(), n_dp, w, h, cfg.fb_emm, cfg.fb_no_change_prob)) return e;
-        }
+            if (int e = optimize_camera_pose(i, rg, i == n_flows - 1)) return e;
         // rigidness densities (reduced on the device by the last optimize_depth, voldor.cpp:171) and results: the last camera's kernel
         // has stored what the host needs into pinned memory (CamBrief); the event marks it complete
         VK_CHECK(hipEventRecord(c->ev_cams, c->stream));
@@ -310,7 +264,6 @@ struct Voldor {
     int finish_cameras() {
         const bool allow_trunc = iters_cur > cfg.no_trunc_iters;
         VK_CHECK(hipEventSynchronize(c->ev_cams));
-        if (c->h_fc_err[0]) return VK_ERR_FUSED_GAVE_UP;  // a workgroup of k_solve_fc gave up its meeting: nothing of this window can be trusted (voldor_run_on runs it again)
         for (int i = 0; i < n_flows; i++) {
             const CamBrief& b = c->h_brief[i];
             hcams[i].success = b.success; hcams[i].pose_sample_count = b.pose_sample_count; hcams[i].last_used_ms_iters = b.last_used_ms_iters;
@@ -347,10 +300,9 @@ struct Voldor {
         }
         while (iters_remain > 0 && n_flows > 0) {
             iters_cur++; iters_remain--;
-            const bool fused = fused_ok(), fb_ov = fb_overlap_ok() && !refit_iteration() /* the refit kernel's 141 KB of LDS leave no room for the riding passes */, wsc = cfg.norm_world_scale && n_dp == 0;
-            if (int e = enqueue_cameras(fused, fb_ov, wsc)) return e;
+            if (int e = enqueue_cameras()) return e;
             // the depth half is enqueued with the pre-decision frame count; on the device it runs with n_active
-            if (int e = optimize_depth(cfg.optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY, wsc, fb_ov)) return e;
+            if (int e = optimize_depth(cfg.optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY, cfg.norm_world_scale && n_dp == 0)) return e;
             if (int e = finish_cameras()) return e;
         }
         return 0;
@@ -378,27 +330,12 @@ static int voldor_run_on(Context* c, const float* flows, const float* disparity,
                          float* poses_covar, float* depth, float* depth_conf, float* pose_block_dev = nullptr) {
     if (!c) return (int)hipErrorNoDevice;
     Voldor& v = g_last;
-    const uint32_t epoch0 = c->rand_epoch; const int rw0 = c->rand_w, rh0 = c->rand_h;
-    for (int attempt = 0;; attempt++) {
-        v = Voldor();
-        v.c = c;
-        v.cfg.fx = fx; v.cfg.cx = cx; v.cfg.fy = fy; v.cfg.cy = cy; v.cfg.basefocal = basefocal;  // py_export.cpp:19-25
-        if (int e = v.cfg.read_config(config ? config : "")) return 1000 + e;
-        c->h_fc_err[0] = 0;
-        if (int e = v.init(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, N, N_dp, w, h)) return e;
-        const int e = v.solve();
-        if (e == VK_ERR_FUSED_GAVE_UP && attempt == 0) {
-            // The solver workgroups of a k_solve_fc launch did not all get to run next to each other within the bound (another process holding the chip?).
-            // Nothing was hung and nothing is lost: this context goes back to three launches per camera for good, and the window runs again from its inputs.
-            fprintf(stderr, "voldor_hip: a fused pose launch gave up its meeting; this context falls back to one launch per stage (window re-run)\n");
-            (void)hipStreamSynchronize(c->stream);
-            c->fused_broken = true;
-            c->rand_epoch = epoch0; c->rand_w = rw0; c->rand_h = rh0;
-            continue;
-        }
-        if (e) return e;
-        break;
-    }
+    v = Voldor();
+    v.c = c;
+    v.cfg.fx = fx; v.cfg.cx = cx; v.cfg.fy = fy; v.cfg.cy = cy; v.cfg.basefocal = basefocal;  // py_export.cpp:19-25
+    if (int e = v.cfg.read_config(config ? config : "")) return 1000 + e;
+    if (int e = v.init(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, N, N_dp, w, h)) return e;
+    if (int e = v.solve()) return e;
     // outputs: py_export.cpp:56-76
     const size_t npx = (size_t)w * h;
     VK_CHECK(hipMemcpyAsync(c->h_cams, c->cams.p, sizeof(CamState) * MAX_FRAMES, hipMemcpyDeviceToHost, c->stream));  // pinned: the host does not wait here
