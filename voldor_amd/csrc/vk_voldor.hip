@@ -119,6 +119,18 @@ struct Voldor {
     CamState hcams[MAX_FRAMES];
 
     CamState* dcams() { return c->cams.as<CamState>(); }
+    const float* host_flows = nullptr;  // flows still (partly) in host memory: frames [frames_up, n_flows_init) are not on the device yet
+    int frames_up = 0;
+    // frames 0 .. upto - 1 of host-resident flows are on the device when this returns (synchronous copies outside the window's stream: the kernels
+    // already enqueued there run meanwhile)
+    int upload_frames_up_to(int upto) {
+        if (!host_flows) return 0;
+        const size_t fb = sizeof(float) * 2 * (size_t)w * h;
+        for (; frames_up < upto && frames_up < n_flows_init; frames_up++)
+            VK_CHECK(hipMemcpy(c->od.flows.as<char>() + (size_t)frames_up * fb, reinterpret_cast<const char*>(host_flows) + (size_t)frames_up * fb, fb, hipMemcpyHostToDevice));
+        if (frames_up >= n_flows_init) host_flows = nullptr;
+        return 0;
+    }
 
     // voldor.cpp:4-128
     int init(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
@@ -151,7 +163,18 @@ struct Voldor {
         if (int e = S.cost.reserve(sizeof(float) * npx)) return e;
         if (int e = c->cams.reserve(sizeof(CamState) * MAX_FRAMES)) return e;
         if (int e = c->ms_io.reserve(sizeof(float) * (64 + 8 * 64) + sizeof(int) * 4)) return e;  // at its full size once: world_scale_ptr() stays valid whatever the mode kernels reserve later
-        VK_CHECK(hipMemcpyAsync(S.flows.p, flows, sizeof(float) * 2 * npx * N, hipMemcpyDefault, st));
+        // Flows in HOST memory (py_voldor_wrapper: what the Cython binding passes) go up frame by frame, each right before the first kernel that reads it
+        // (upload_frames_up_to): camera i of the first EM iteration traces through the flows of frames <= i only (collect_p3p_instances.cu:100-125) and the
+        // bootstrap reads frame 0, so the transfer of frame i + 1 runs while the GPU is busy with camera i instead of in front of everything (round 5:
+        // 12 MB at 640x480 x 5, ~0.25 ms of a 4.1 ms host-inclusive window).  Device-resident flows (vk_voldor_device): one device-to-device copy.
+        {
+            hipPointerAttribute_t at;
+            const bool on_device = hipPointerGetAttributes(&at, flows) == hipSuccess && at.type == hipMemoryTypeDevice;
+            if (!on_device) (void)hipGetLastError();  // (an unregistered host pointer is reported as an error by some runtimes)
+            host_flows = on_device ? nullptr : flows;
+            frames_up = on_device ? N : 0;
+            if (on_device) VK_CHECK(hipMemcpyAsync(S.flows.p, flows, sizeof(float) * 2 * npx * N, hipMemcpyDeviceToDevice, st));
+        }
         if (int e = fill_device(c, S.rig.as<float>(), 1.f, npx * N)) return e;
         PoseBlock& pb = *c->h_pb;  // pinned staging: the previous window of this context ended with a stream synchronize, so it is free
         memset(&pb, 0, sizeof pb);
@@ -254,8 +277,11 @@ struct Voldor {
     // the speculatively executed later cameras wrote (their own pose slots only) is never read again.
     int enqueue_cameras() {
         const bool rg = cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0);
-        for (int i = 0; i < n_flows; i++)
+        for (int i = 0; i < n_flows; i++) {
+            if (int e = upload_frames_up_to(i + 1)) return e;  // (first EM iteration of a host-memory call: frame i arrives while camera i - 1 runs)
             if (int e = optimize_camera_pose(i, rg, i == n_flows - 1)) return e;
+        }
+        if (int e = upload_frames_up_to(n_flows_init)) return e;
         // rigidness densities (reduced on the device by the last optimize_depth, voldor.cpp:171) and results: the last camera's kernel
         // has stored what the host needs into pinned memory (CamBrief); the event marks it complete
         VK_CHECK(hipEventRecord(c->ev_cams, c->stream));
@@ -293,6 +319,7 @@ struct Voldor {
 
     // voldor.cpp:130-149
     int solve() {
+        if (int e = upload_frames_up_to(1)) return e;
         if (n_dp == 0) {  // bootstrap :151-162
             if (c->prof) prof_begin(c);
             if (int e = bootstrap_device(c, c->od, w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, dcams(), strict, cfg.bootstrap_points == 5 ? 5 : 8)) return e;
