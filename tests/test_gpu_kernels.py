@@ -589,38 +589,3 @@ def test_sample_pass_with_survivor_queue_matches_strict(small_scene, with_priors
     assert np.mean(fd != sd) <= 5e-4, np.mean(fd != sd)
     same = fd == sd
     _assert_map_close(sr[:, same], fr[:, same])
-
-
-
-@pytest.mark.parametrize("case", ["mono_320x240", "stereo_312x96", "cfg2", "odd_323x241_truncating"])
-def test_own_table_entry_with_all_gathers_in_flight_changes_no_bit(case):
-    """Round 5: the table entry a chain computes for itself at the head of k_local_runs_lean (small images) with the gathers of all frames of the
-    hypothesis in flight together (vk_debug_switch "runs_table_ch" = 1, default) against one frame at a time: the same sums in the same order --
-    every output of a window, bit for bit."""
-    import ref_window_cases as rc
-    from voldor_amd import kernels, pyvoldor, synth
-    if case == "odd_323x241_truncating":
-        sc = synth.make_scene(w=323, h=241, n_flows=5, fx=160, fy=160, cx=160, cy=120, seed=31)
-        fl = sc["flows"].copy()
-        fl[3:] = np.random.default_rng(4).uniform(-25, 25, fl[3:].shape).astype(np.float32)
-        c = dict(K=sc["K"], flows=fl, basefocal=0.0, disparity=None, depth_priors=None, depth_prior_poses=None, depth_prior_pconfs=None,
-                 config="--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 6")
-    elif case == "cfg2":
-        c = rc.cfg2_case()[1]
-    else:
-        c = dict(rc.window_cases())[case]
-    fx, fy, cx, cy = c["K"]
-    kw = dict(basefocal=c["basefocal"], disparity=c["disparity"], depth_priors=c["depth_priors"], depth_prior_poses=c["depth_prior_poses"],
-              depth_prior_pconfs=c["depth_prior_pconfs"], config=c["config"])
-    out = {}
-    try:
-        for on in (1, 0):
-            hooks.debug_switch("runs_table_ch", on)
-            kernels.set_rand_epoch(0)
-            out[on] = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, **kw)
-    finally:
-        hooks.debug_switch("runs_table_ch", 1)
-    a, b = out[1], out[0]
-    assert a["n_registered"] == b["n_registered"] and a["n_registered"] > 0
-    for k in ("poses", "poses_covar", "depth", "depth_conf"):
-        np.testing.assert_array_equal(np.ascontiguousarray(a[k], np.float32).view(np.uint32), np.ascontiguousarray(b[k], np.float32).view(np.uint32), err_msg=f"{case}/{k}")

@@ -979,7 +979,7 @@ __global__ __launch_bounds__(64) static void k_global_prop_split_lean(Img I, int
 // bookkeeping diverges.
 // The chains of ONE wave (two of up to 32 steps, or one of up to 64): cg / n = the chain of this lane's half (n <= 0: none).  Called by
 // k_local_runs_lean (one launch per pass).
-template <int HALF, int NMAX, int LPP, bool STRICT, int TCH = LEAN_CHUNK>
+template <int HALF, int NMAX, int LPP, bool STRICT>
 __device__ __forceinline__ static void local_runs_body(const Img& I, const LeanK& K, const ChainGeom cg, const int n, const float* __restrict__ tbl) {
     PHD_DECL;
     constexpr int NG = HALF / LPP;  // pixels per round
@@ -994,7 +994,7 @@ __device__ __forceinline__ static void local_runs_body(const Img& I, const LeanK
     const float first_cand = I.depth[cg.prev0];
     float t0 = INFINITY;
     if (tbl) t0 = has ? tbl[mypi] : INFINITY;
-    else if (has) t0 = pixel_cost_any<NMAX, STRICT, TCH>(I, K, mypi % I.w, mypi / I.w, I.depth[mypi - cg.stride]);  // the table entry of my own step
+    else if (has) t0 = pixel_cost_any<NMAX, STRICT>(I, K, mypi % I.w, mypi / I.w, I.depth[mypi - cg.stride]);  // the table entry of my own step
     const unsigned long long tacc = (__ballot(has && t0 < c0) & hmask) >> hshift;  // steps whose table cost beats their current cost
     // number of leading groups of [g0, g0 + cnt) whose lanes are set in `m` (one bit per lane, a group's lanes agree)
     auto lead = [](unsigned long long m, int g0, int cnt) {
@@ -1074,11 +1074,9 @@ __device__ __forceinline__ static void local_runs_body(const Img& I, const LeanK
     if (hl == 0) atomicAdd(&g_phase_d[16 + min(rounds_, 31)], 1ull);  // histogram of the rounds a chain's half took part in
 #endif
 }
-// TCH: frames whose gathers are in flight together in the chain's OWN table entry (the head of the kernel when no table kernel ran: small images).
-// There every lane evaluates one whole hypothesis and the wave has nothing else to do: with one frame at a time (LEAN_CHUNK: what the streaming kernels
-// take for their occupancy) that is N - 1 dependent gathers; the registers of all of them in flight (7 per frame) are below what the run evaluations
-// further down need anyway, so here the chunk is the whole chain.  Same sums in the same order: same bits.
-template <int HALF, int NMAX, int LPP, bool STRICT = false, int TCH = LEAN_CHUNK>
+// (round 5: the chain's own table entry with all gathers of the hypothesis in flight -- lean_rest<NMAX, NMAX - 1> -- measured: 23.3 us per launch either way,
+// profiles/r05f_*: four resident waves per SIMD already hide that latency)
+template <int HALF, int NMAX, int LPP, bool STRICT = false>
 __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, int width, const float* __restrict__ tbl, int lines, int nchains) {
     if (!clamp_active(I)) return;
     constexpr int NH = 64 / HALF;  // chains per wave
@@ -1087,7 +1085,7 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
     const int chain = tile * NH + half;
     const bool in_range = chain < nchains;
     const ChainGeom cg = chain_geom(I.w, I.h, dir, width, in_range ? chain % lines : 0, in_range ? chain / lines : 0);
-    local_runs_body<HALF, NMAX, LPP, STRICT, TCH>(I, lean_consts(I), cg, in_range ? cg.n : 0, tbl);
+    local_runs_body<HALF, NMAX, LPP, STRICT>(I, lean_consts(I), cg, in_range ? cg.n : 0, tbl);
 }
 // E-step (optimize_depth.cu:84-138), lean geometry and model; per-block rigidness sums as k_update_rigidness
 template <int NMAX>
@@ -1299,12 +1297,8 @@ int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_
                     // lanes per pixel of a run evaluation (cost_split_lean): quads up to 8 frames, eight beyond.  (Pairs -- 16 pixels per round, four planned
                     // runs -- halve the rounds again but need 137 registers: 3 waves per SIMD for a pass of 4.7, 46 us instead of 27.)
                     constexpr int LR_LPP = NMAX <= 8 ? 4 : 8;
-                    if (p.local_prop_width <= 33) {  // chains of <= 32 steps: two per wave
-                        if (!STRICT && own_table && NMAX <= 8 && debug_switches().runs_table_ch)
-                            hipLaunchKernelGGL((k_local_runs_lean<32, NMAX, LR_LPP, STRICT, (STRICT || NMAX > 8) ? LEAN_CHUNK : NMAX - 1>), dim3((nchains + 1) / 2), dim3(64), 0, c->stream, I, dir, p.local_prop_width, tblp, lines, nchains);
-                        else
+                    if (p.local_prop_width <= 33)  // chains of <= 32 steps: two per wave
                         hipLaunchKernelGGL((k_local_runs_lean<32, NMAX, LR_LPP, STRICT>), dim3((nchains + 1) / 2), dim3(64), 0, c->stream, I, dir, p.local_prop_width, tblp, lines, nchains);
-                    }
                     else
                         hipLaunchKernelGGL((k_local_runs_lean<64, NMAX, LR_LPP, STRICT>), dim3(nchains), dim3(64), 0, c->stream, I, dir, p.local_prop_width, tblp, lines, nchains);
                 } else

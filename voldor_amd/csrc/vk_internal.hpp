@@ -29,8 +29,6 @@ struct DebugSwitches {
     int split_trials = 1;      // 0: the mode kernel runs the initial-mode trials itself
     int strict_pose_coop = 1;  // strict mode kernel on one single-wave workgroup per 512-row block of the pool (16 compute units) instead of one 512-thread workgroup; same bits
     // round 5
-    int runs_table_ch = 1;     // 0: the own table entry of a chain (head of k_local_runs_lean, small images) walks its frames one gather at a time, as the streaming kernels do; 1: all gathers of the hypothesis in flight (same bits)
-    int solve_lds_pad_kb = 0;  // (tuning) extra dynamic LDS per workgroup of k_solve in the window pipeline, in KB: bounds the workgroups per compute unit, i.e. how the P3P waves spread over the SIMDs
     int strict_coop_max_polls = 0;  // > 0: the cooperative strict mode kernel gives up a meeting after this many polls (tests force the give-up path); 0: 2^22
     int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
 };

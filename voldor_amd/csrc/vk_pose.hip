@@ -1603,7 +1603,6 @@ static int solve_launch(Context* c, const float* pts2, const float* pts3, int* n
     // wave per CU still fit); not allocated when the draw cannot be taken (draw < 0).  Beyond 60 KB (3.9 MP) the counts are scanned
     // into global memory by one extra launch and the bisection reads them from there.
     size_t lds = (FROM_MAP && draw >= 0) ? sizeof(int) * ((size_t)nb + nb / 32 + 1) : 0;  // padded: pref_at() in k_solve
-    if (FROM_MAP && debug_switches().solve_lds_pad_kb > 0 && debug_switches().solve_lds_pad_kb <= 60) lds += (size_t)debug_switches().solve_lds_pad_kb * 1024;
     const int* offs = nullptr;
     if (lds > 60 * 1024) {
         if (int e = c->blk_offsets.reserve(sizeof(int) * (size_t)nb)) return e;
