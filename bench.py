@@ -69,7 +69,7 @@ WORKLOADS = {
                  name="BASELINE cfg5: 1920x1080, N_flow=10, disparity prior from depth (RGB-D), 12 EM iterations + fb_smooth"),
 }
 HBM_PEAK_GBS = 8000.0
-KERNEL_SOURCES = ("vk_depth.hip", "vk_depth_impl.hpp", "vk_pose.hip", "vk_device.hpp", "vk_p3p.hpp", "vk_p3p_fast.hpp", "vk_common.hpp")  # what the replayed counter passes were taken on
+KERNEL_SOURCES = ("vk_depth.hip", "vk_depth_impl.hpp", "vk_fb.hpp", "vk_cum_poses.hpp", "vk_pose.hip", "vk_device.hpp", "vk_p3p.hpp", "vk_common.hpp")  # what the replayed counter passes were taken on
 
 
 def kernel_source_hash():

@@ -40,7 +40,7 @@ import os
 out['commit'] = os.environ.get('COMMIT')
 import hashlib
 h = hashlib.sha256()
-for f in ("vk_depth.hip", "vk_depth_impl.hpp", "vk_pose.hip", "vk_device.hpp", "vk_p3p.hpp", "vk_p3p_fast.hpp", "vk_common.hpp"):  # = bench.KERNEL_SOURCES: bench.py withholds a pass taken on other sources
+for f in ("vk_depth.hip", "vk_depth_impl.hpp", "vk_fb.hpp", "vk_cum_poses.hpp", "vk_pose.hip", "vk_device.hpp", "vk_p3p.hpp", "vk_common.hpp"):  # = bench.KERNEL_SOURCES: bench.py withholds a pass taken on other sources
     h.update(open(os.path.join("voldor_amd", "csrc", f), "rb").read())
 out['kernel_source_sha256'] = h.hexdigest()[:16]  # the tree the counters were collected on (bench.py quotes it as the source of its replayed figures)
 json.dump(out, open(sys.argv[3], 'w'), indent=1)

@@ -27,7 +27,7 @@ out = {"_note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE (pass 1) / --pmc WRIT
        "workload": wl, "commit": os.environ.get("COMMIT"), "kernels": {}}
 import hashlib
 h = hashlib.sha256()
-for f in ("vk_depth.hip", "vk_depth_impl.hpp", "vk_pose.hip", "vk_device.hpp", "vk_p3p.hpp", "vk_p3p_fast.hpp", "vk_common.hpp"):  # = bench.KERNEL_SOURCES: bench.py withholds a pass taken on other sources
+for f in ("vk_depth.hip", "vk_depth_impl.hpp", "vk_fb.hpp", "vk_cum_poses.hpp", "vk_pose.hip", "vk_device.hpp", "vk_p3p.hpp", "vk_common.hpp"):  # = bench.KERNEL_SOURCES: bench.py withholds a pass taken on other sources
     h.update(open(os.path.join("voldor_amd", "csrc", f), "rb").read())
 out["kernel_source_sha256"] = h.hexdigest()[:16]
 # Calibration of the x2 on kernels whose byte count is known (profiles/r02h_pmc_traffic_cfg2.json, r02j_pmc_traffic_cfg5.json): FETCH_SIZE reports
