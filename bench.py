@@ -335,7 +335,7 @@ def main():
                     issue = v["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * us * 1e-6 * 2.4e9)
                     ktable[k] = {"launches_per_call": round(v["launches"] / per_call, 2), "avg_us": round(us, 2), "counter_bytes": by, "TB_per_s": round(tbs, 3),
                                  "frac_of_copy_ceiling": round(tbs / 6.3, 3), "valu_issue_frac": round(issue, 3), "wait_any_frac": round(v.get("frac_wait_any", 0.0), 3),
-                                 "bound": "memory" if tbs / 6.3 >= 0.5 else ("valu issue" if issue >= 0.7 else "latency")}
+                                 "bound": " + ".join(([("valu issue")] if issue >= 0.7 else []) + (["memory"] if tbs / 6.3 >= 0.5 else [])) or "latency"}
                 one_sweep = W * H * (12 * N_FLOW + 12 * n_dp + 8)  # every map of the M-step read once: flows 8N, rigidness 4N, priors + their two confidences 12 N_dp, depth, cost
                 sweeps = {"one_sweep_bytes": one_sweep, "group_counter_bytes": round(group_traffic), "sweeps": round(group_traffic / one_sweep, 2),
                           "per_kernel": {k: round(v["counter_bytes"] * v["launches_per_call"] / one_sweep, 2) for k, v in ktable.items()}}

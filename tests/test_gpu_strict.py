@@ -219,15 +219,6 @@ def _plain_vs_parallel(run):
 _FALLBACKS = {}  # per variant of _plain_vs_parallel: cameras the single-workgroup kernel took over (vk_debug_counter)
 
 
-def test_the_give_up_path_of_the_cooperative_mode_kernel_was_taken(strict):
-    """Runs after the comparisons above (file order): with the poll bound at one, workgroups DID give up and the single-workgroup kernel DID take
-    cameras over (else "gave_up" compared the cooperative form with itself); with the product's bound nobody gave up."""
-    if not _FALLBACKS:
-        pytest.skip("the comparison tests of this file did not run")
-    assert _FALLBACKS.get("gave_up", 0) > 0, _FALLBACKS
-    assert _FALLBACKS.get("coop", 0) == 0 and _FALLBACKS.get("one_wg", 0) == 0, _FALLBACKS
-
-
 @pytest.mark.parametrize("name", ["mono_320x240", "stereo_priors", "truncated", "refit_every_iteration", "ap3p", "cfg2", "wide_1241", "odd_323x241"])
 def test_strict_parallel_structures_equal_the_plain_ones(strict, name):
     """strict mode now runs on the fast launch structures -- survivor queue with an exact rejection bound in the
@@ -306,6 +297,15 @@ def test_strict_mode_kernel_parallel_tree_equals_the_block_walk(orc, small_scene
         assert a["success"] == b["success"] and a["sample_count"] == b["sample_count"] == int(np.isfinite(rv.sum(1) + tv.sum(1)).sum())
         assert a["ms_iters"] == b["ms_iters"] and a["gu_iters"] == b["gu_iters"], (a["ms_iters"], b["ms_iters"], a["gu_iters"], b["gu_iters"])
         assert_bits(a["pose6"], b["pose6"], "pose"); assert_bits(a["covar"], b["covar"], "covar"); assert_bits(np.float32(a["density"]), np.float32(b["density"]), "density")
+
+
+def test_the_give_up_path_of_the_cooperative_mode_kernel_was_taken(strict):
+    """Runs after the comparisons above (file order): with the poll bound at one, workgroups DID give up and the single-workgroup kernel DID take
+    cameras over (else "gave_up" compared the cooperative form with itself); with the product's bound nobody gave up."""
+    if not _FALLBACKS:
+        pytest.skip("the comparison tests of this file did not run")
+    assert _FALLBACKS.get("gave_up", 0) > 0, _FALLBACKS
+    assert _FALLBACKS.get("coop", 0) == 0 and _FALLBACKS.get("one_wg", 0) == 0, _FALLBACKS
 
 
 # ---- the low-density regime (VERDICT r1 item 2) ---------------------------------------------------------------------------------

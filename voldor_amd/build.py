@@ -33,7 +33,10 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hi
          # the SLP vectorizer packs scalar fp32 math into v_pk_* pairs and pays for it with ~30 % extra
          # v_mov traffic and 2x the registers in the latency-bound per-pixel kernels (k_cost_rand: 3335 ->
          # 2541 VALU instructions, 151 -> fewer VGPRs without it); results are equal up to fma-contraction choices.
-         "-fno-slp-vectorize"]
+         "-fno-slp-vectorize",
+         # the device code of the per-frame-bound instantiations is most of the library (12 MB of 12.3): stored compressed (zstd, unpacked by
+         # the HIP runtime when the module loads) the library is ~2 MB
+         "--offload-compress"]
 
 
 LINK_LIBS = ["-ldl"]  # vk_dist.hip binds RCCL with dlopen at the first vk_dist_* call

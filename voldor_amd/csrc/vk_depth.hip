@@ -95,10 +95,15 @@ static bool fb_smooth_segmented(int w, int h) { return !(w > 40 * FB_MAX_ROW_SEG
 // at 1080p) and the chaining is half of all instructions with 20-step segments (1920 wide: 95 + 40 steps per lane): 40-step
 // segments then do the same work in 37 % fewer instructions.
 static void fb_smooth_plan(int w, int h, int n_maps, int* rows_seg, int* cols_seg) {
+    // steps per lane: 12 while the maps give fewer than 8 waves per SIMD at 20 (the pass is its dependent chain: shorter segments, more lanes; rows
+    // 11.5 -> 10.2 us at 1241x376x5, window -1 % at 8 frames, profiles/r05h_*), 40 from 8 M pixels (fewer segment matrices to scan), 20 where 12 does
+    // not cover the line
     const int forced = debug_switches().fb_segment;
-    const bool many_waves = (size_t)w * h * n_maps >= ((size_t)8 << 20);  // >= 8 waves per SIMD at 20 steps per lane
-    *rows_seg = (w > 20 * FB_MAX_ROW_SEGS || (forced ? forced == 40 : many_waves)) ? 40 : 20;
-    *cols_seg = (h > 20 * FB_MAX_COL_SEGS || (forced ? forced == 40 : many_waves)) ? 40 : 20;
+    const bool many_waves = (size_t)w * h * n_maps >= ((size_t)8 << 20);
+    const int want = forced ? forced : (many_waves ? 40 : 12);
+    auto pick = [&](int len, int max_segs) { return (want == 12 && len <= 12 * max_segs) ? 12 : (want <= 20 && len <= 20 * max_segs) ? 20 : 40; };
+    *rows_seg = pick(w, FB_MAX_ROW_SEGS);
+    *cols_seg = pick(h, FB_MAX_COL_SEGS);
 }
 int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev, PoseBlock* cumP,
                      int cumN, int cumNdp, float* world_scale) {
@@ -112,11 +117,12 @@ int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0
     }
     int rs, cs;
     fb_smooth_plan(w, h, n_maps, &rs, &cs);
-    const bool rows40 = rs == 40, cols40 = cs == 40;
     float* out = maps;
-    if (!rows40) fb_rows_launch<20>(st, maps, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
+    if (rs == 12) fb_rows_launch<12>(st, maps, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
+    else if (rs == 20) fb_rows_launch<20>(st, maps, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
     else fb_rows_launch<40>(st, maps, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
-    if (!cols40) fb_cols_launch<20>(st, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
+    if (cs == 12) fb_cols_launch<12>(st, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
+    else if (cs == 20) fb_cols_launch<20>(st, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
     else fb_cols_launch<40>(st, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
     VK_CHECK_LAST();
     return 0;

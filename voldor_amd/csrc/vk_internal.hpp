@@ -23,7 +23,7 @@ struct ModeParams {
 struct DebugSwitches {
     int local_serial = 0;      // 1: local propagation walks every chain step by step (k_local_serial) instead of table + runs
     int cost_rand_plain = 0;   // 1: the sample pass evaluates every random depth in full, one after the other
-    int fb_segment = 0;        // 0: by size; 20 / 40: steps per lane of the segmented fb_smooth
+    int fb_segment = 0;        // 0: by size; 12 / 20 / 40: steps per lane of the segmented fb_smooth
     int global_split = 1;      // 0: global propagation with one lane per site
     int refit_partition = 1;   // 0: every gate pass of the refit walks the whole pool in its arrival order
     int split_trials = 1;      // 0: the mode kernel runs the initial-mode trials itself
