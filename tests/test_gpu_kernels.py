@@ -226,6 +226,37 @@ def test_global_split_equals_one_lane_per_site(step, noise, n_flows, n_dp):
     np.testing.assert_array_equal(r1.view(np.uint32), r2.view(np.uint32))
 
 
+@pytest.mark.parametrize("n_flows,n_dp,w,h", [(5, 0, 211, 97), (1, 0, 64, 4), (8, 1, 211, 97), (10, 2, 130, 61), (16, 0, 211, 97), (3, 0, 63, 3)])
+def test_estep_with_two_pixels_per_lane_equals_one(n_flows, n_dp, w, h):
+    """vk_debug_switch "estep_pairs": the E-step with two pixels per lane on packed fp32 (k_update_rigidness_pairs) against one pixel per lane:
+    identical rigidness maps, prior confidences and depth, bit for bit (the packed instructions round each half like the scalar ones; the
+    wave sums cover the same rows in the same order), ragged tiles included."""
+    from voldor_amd import synth
+    sc = synth.make_scene(w=w, h=h, n_flows=n_flows, fx=100, fy=100, cx=w / 2, cy=h / 2, seed=29, basefocal=40.0 if n_dp else 0.0)
+    rng = np.random.default_rng(n_flows * 10 + n_dp)
+    K = K9(*sc["K"])
+    flows, Rs, ts, depth, rig = _state(sc, rng, noise=0.2)
+    extra = {}
+    if n_dp:
+        pri = np.stack([(sc["depth_gt"] * (1 + rng.normal(0, 0.05, (h, w)))).astype(np.float32) for _ in range(n_dp)])
+        pri[:, ::7, ::5] = 0.0
+        extra = dict(priors=pri, pconfs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32), confs=rng.uniform(0.3, 1.0, (n_dp, h, w)).astype(np.float32),
+                     dp_Rs=np.tile(np.eye(3, dtype=np.float32), (n_dp, 1, 1)), dp_ts=(rng.normal(0, 0.02, (n_dp, 3)) * np.arange(n_dp)[:, None]).astype(np.float32))
+    over = dict(update_rigidness_only=1, basefocal=40.0 if n_dp else 0.0, disp_delta=1.0 if n_dp else -1.0)
+    try:
+        hooks.debug_switch("estep_pairs", 2)
+        d1, r1, c1 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
+        hooks.debug_switch("estep_pairs", 0)
+        d2, r2, c2 = _gpu_only(flows, Rs, ts, depth, rig, K, **extra, **over)
+    finally:
+        hooks.debug_switch("estep_pairs", 1)
+    assert not np.array_equal(r2, rig)
+    np.testing.assert_array_equal(d1.view(np.uint32), d2.view(np.uint32))
+    np.testing.assert_array_equal(r1.view(np.uint32), r2.view(np.uint32))
+    if n_dp:
+        np.testing.assert_array_equal(np.asarray(c1).view(np.uint32), np.asarray(c2).view(np.uint32))
+
+
 def test_local_runs_with_the_tiled_table_equal_the_step_by_step_chain():
     """Above 400k pixels the candidate-cost table of a pass comes from its own tiled kernel (below, every chain tabulates its own steps at
     the head of the runs kernel): the same equality at 832x512."""

@@ -145,12 +145,12 @@ static const bool g_bt_installed = [] {
 static DebugSwitches g_debug;
 // ONE table of the verification switches (vk_debug.h): name, field, accepted values.  vk_debug_switch and the VOLDOR_HIP_DEBUG parser both go
 // through debug_switch_set, so a value the launch paths were never tested with cannot reach them from either side.
-struct DebugEntry { const char* name; int DebugSwitches::*field; int kind; };  // kind 0: 0 | 1; 1: 0 | 12 | 20 | 40; 2: any value >= 0
+struct DebugEntry { const char* name; int DebugSwitches::*field; int kind; };  // kind 0: 0 | 1; 1: 0 | 12 | 20 | 40; 2: any value >= 0; 3: 0 | 1 | 2
 static const DebugEntry g_debug_tab[] = {
     { "local_serial", &DebugSwitches::local_serial, 0 }, { "cost_rand_plain", &DebugSwitches::cost_rand_plain, 0 }, { "fb_segment", &DebugSwitches::fb_segment, 1 },
     { "global_split", &DebugSwitches::global_split, 0 }, { "refit_partition", &DebugSwitches::refit_partition, 0 }, { "split_trials", &DebugSwitches::split_trials, 0 },
     { "strict_plain", &DebugSwitches::strict_plain, 0 }, { "strict_pose_coop", &DebugSwitches::strict_pose_coop, 0 },
-    { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 },
+    { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 }, { "estep_pairs", &DebugSwitches::estep_pairs, 3 },
 };
 // returns the previous value; -1: unknown name; -2: a value the switch does not take
 static int debug_switch_set(const char* name, int value) {
@@ -158,6 +158,7 @@ static int debug_switch_set(const char* name, int value) {
         if (strcmp(t.name, name) == 0) {
             if (t.kind == 0) value = value ? 1 : 0;
             else if (t.kind == 1) { if (value != 0 && value != 12 && value != 20 && value != 40) return -2; }
+            else if (t.kind == 3) { if (value < 0 || value > 2) return -2; }
             else if (value < 0) return -2;
             const int old = g_debug.*t.field;
             g_debug.*t.field = value;

@@ -11,7 +11,7 @@ extern "C" {
  *   "local_serial"    0 | 1   fast mode: local propagation step by step, one lane per chain (optimize_depth.cu:320-396 order), instead of table + planned runs
  *   "cost_rand_plain" 0 | 1   the sample pass evaluates every random depth in full, one after the other (optimize_depth.cu:269-284), instead of exact
  *                             early rejection + survivor queue -- fast AND strict arithmetic
- *   "fb_segment"      0 | 20 | 40   steps per lane of the segmented fb_smooth of the fast mode (0: by image size)
+ *   "fb_segment"      0 | 12 | 20 | 40   steps per lane of the segmented fb_smooth of the fast mode (0: by image size)
  *   "global_split"    1 | 0   0: global propagation with one lane per site instead of a group of lanes
  *   "refit_partition" 1 | 0   0: every gate pass of the refit walks the whole pool in arrival order
  *   "split_trials"    1 | 0   0: the mode kernel evaluates the initial-mode trials itself instead of one workgroup per trial
@@ -21,6 +21,7 @@ extern "C" {
  *                             reference's sum tree block by block) instead of the parallel structures -- both give the same bits
  *   "strict_coop_max_polls"  0 | n > 0   polls after which a workgroup of the cooperative strict mode kernel gives up a meeting (0: 2^20); tests set 1 to
  *                             force the hand-over to the single-workgroup kernel
+ *   "estep_pairs"     1 | 0 | 2   the fast E-step with two pixels per lane on packed fp32 (same bits): from 1.5 M pixels | never | at every size
  * Returns the previous value, -1 for an unknown name / value. */
 int vk_debug_switch(const char* name, int value);
 /* Counters, read and cleared: "strict_coop_fallbacks" = cameras (default context) whose cooperative strict mode kernel gave up a meeting and were

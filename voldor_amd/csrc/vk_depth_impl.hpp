@@ -350,6 +350,18 @@ __device__ __forceinline__ static bool lean_step(const PoseBlock* P, int f, floa
     px2 = fmaf(d, a.x, P->cumT[f][0]) * iz; py2 = fmaf(d, a.y, P->cumT[f][1]) * iz;
     return hz > 0.f;
 }
+// the same step for two pixels of one column (rows y.x, y.y) on float pairs: the bits of lean_step for either
+__device__ __forceinline__ static void lean_step2(const PoseBlock* P, int f, float x, pf2 y, pf2 d, pf2& px2, pf2& py2, bool& zok_a, bool& zok_b) {
+#pragma clang fp contract(off)
+    const float* __restrict__ M = P->cumM[f];
+    const pf2 ax = pk_fma(pk_all(M[0]), pk_all(x), pk_fma(pk_all(M[1]), y, pk_all(M[2])));
+    const pf2 ay = pk_fma(pk_all(M[3]), pk_all(x), pk_fma(pk_all(M[4]), y, pk_all(M[5])));
+    const pf2 az = pk_fma(pk_all(M[6]), pk_all(x), pk_fma(pk_all(M[7]), y, pk_all(M[8])));
+    const pf2 hz = pk_fma(d, az, pk_all(P->cumT[f][2]));
+    const pf2 iz = { fast_rcp(hz.x), fast_rcp(hz.y) };
+    px2 = pk_fma(d, ax, pk_all(P->cumT[f][0])) * iz; py2 = pk_fma(d, ay, pk_all(P->cumT[f][1])) * iz;
+    zok_a = hz.x > 0.f; zok_b = hz.y > 0.f;
+}
 // frame 0 (observed at the pixel itself) + depth priors of one hypothesis; leaves the position the chain continues from
 __device__ __forceinline__ static void lean_head(const Img& I, const LeanK& K, const PoseBlock* P, float x, float y, float d, float2 o0, const ObsTerms& T0,
                                                  float wgt0, float& cs, float& ws, float& px1, float& py1) {
@@ -1087,6 +1099,30 @@ __global__ __launch_bounds__(64) static void k_local_runs_lean(Img I, int dir, i
     const ChainGeom cg = chain_geom(I.w, I.h, dir, width, in_range ? chain % lines : 0, in_range ? chain / lines : 0);
     local_runs_body<HALF, NMAX, LPP, STRICT>(I, lean_consts(I), cg, in_range ? cg.n : 0, tbl);
 }
+// what the E-step does to the pixel besides the rigidness maps: normalize_world_scale's depth half, the confidence of the depth priors
+__device__ __forceinline__ static void estep_pixel_tail(const Img& I, const PoseBlock* P, int pi, float x, float y, float d, const float* __restrict__ world_scale) {
+    const int w = I.w, h = I.h, npx = w * h;
+    const float fw = (float)w, fh = (float)h;
+    if (world_scale) I.depth[pi] = d * *world_scale;  // normalize_world_scale's depth half (voldor.cpp:314): the E-step above saw the unscaled map
+    for (int f = 0; f < I.N_dp; f++) {
+        if ((P->dp_ident >> f) & 1) {  // prior at the identity pose: sampled at the pixel itself (prior_parts)
+            if (d > 0.f) {
+                const float td = I.priors[(size_t)f * npx + pi];
+                if (td > 0.f) I.confs[(size_t)f * npx + pi] = fast_rcp(1.f + depth_ratio(d, td, I.basefocal, I.omega, I.inv_arf));
+            } else
+                I.confs[(size_t)f * npx + pi] = 0.f;
+            continue;
+        }
+        const H3 a = hom_dir(P->dpM[f], x, y);
+        const float hz = fmaf(d, a.z, P->dpT[f][2]);
+        const float qx2 = fmaf(d, a.x, P->dpT[f][0]) / hz, qy2 = fmaf(d, a.y, P->dpT[f][1]) / hz;  // see prior_parts
+        if (hz > 0.f && qx2 >= 0.f && qx2 < fw && qy2 >= 0.f && qy2 < fh) {
+            const float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
+            if (td > 0.f) I.confs[(size_t)f * npx + pi] = fast_rcp(1.f + depth_ratio(hz, td, I.basefocal, I.omega, I.inv_arf));
+        } else
+            I.confs[(size_t)f * npx + pi] = 0.f;
+    }
+}
 // E-step (optimize_depth.cu:84-138), lean geometry and model; per-block rigidness sums as k_update_rigidness
 template <int NMAX>
 __global__ __launch_bounds__(256) static void k_update_rigidness_lean(Img I, float* __restrict__ partial, const float* __restrict__ world_scale) {
@@ -1131,25 +1167,59 @@ __global__ __launch_bounds__(256) static void k_update_rigidness_lean(Img I, flo
         partial[(size_t)f * nblk + blk] = (s_part[f][0] + s_part[f][1]) + (s_part[f][2] + s_part[f][3]);
     }
     if (!live) return;
-    if (world_scale) I.depth[pi] = d * *world_scale;  // normalize_world_scale's depth half (voldor.cpp:314): the E-step above saw the unscaled map
-    for (int f = 0; f < I.N_dp; f++) {
-        if ((P->dp_ident >> f) & 1) {  // prior at the identity pose: sampled at the pixel itself (prior_parts)
-            if (d > 0.f) {
-                const float td = I.priors[(size_t)f * npx + pi];
-                if (td > 0.f) I.confs[(size_t)f * npx + pi] = fast_rcp(1.f + depth_ratio(d, td, I.basefocal, I.omega, I.inv_arf));
-            } else
-                I.confs[(size_t)f * npx + pi] = 0.f;
-            continue;
+    estep_pixel_tail(I, P, pi, x, y, d, world_scale);
+}
+// The same E-step with TWO pixels per lane (rows r and r + 2 of the 64 x 4 tile, 128 threads): geometry and model on float pairs (packed fp32: one
+// instruction for both pixels where a packed form exists), gathers, validity and the wave sums per pixel.  The wave sums cover the same rows in
+// the same order and land in the same slots: every output bit equals k_update_rigidness_lean's.
+template <int NMAX>
+__global__ __launch_bounds__(128) static void k_update_rigidness_pairs(Img I, float* __restrict__ partial, const float* __restrict__ world_scale) {
+    if (!clamp_active(I)) return;
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int xi = (tile % gridDim.x) * 64 + (threadIdx.x & 63), wv = threadIdx.x >> 6;
+    const int ya = (tile / gridDim.x) * 4 + wv, yb = ya + 2;
+    const bool live_a = xi < I.w && ya < I.h, live_b = xi < I.w && yb < I.h;
+    const int w = I.w, h = I.h, npx = w * h, pia = live_a ? ya * w + xi : 0, pib = live_b ? yb * w + xi : 0;
+    const PoseBlock* P = I.P;
+    const LeanK K = lean_consts(I);
+    __shared__ float s_part[NMAX][4];
+    const int blk = tile, nblk = gridDim.x * gridDim.y;
+    const pf2 d = { live_a ? I.depth[pia] : 1.f, live_b ? I.depth[pib] : 1.f };
+    const float x = (float)(xi < w ? xi : 0), fw = (float)w, fh = (float)h;
+    const pf2 y = { (float)(live_a ? ya : 0), (float)(live_b ? yb : 0) };
+    {
+        pf2 px1 = pk_all(x), py1 = y;
+#pragma unroll
+        for (int f = 0; f < NMAX; f++) {
+            if (f < I.N) {
+                pf2 px2, py2;
+                bool zok_a, zok_b;
+                lean_step2(P, f, x, y, d, px2, py2, zok_a, zok_b);
+                const bool ok_a = live_a && zok_a && px1.x >= 0.f && px1.x < fw && py1.x >= 0.f && py1.x < fh;
+                const bool ok_b = live_b && zok_b && px1.y >= 0.f && px1.y < fw && py1.y >= 0.f && py1.y < fh;
+                const pf2 rdx = px2 - px1, rdy = py2 - py1;
+                const float2* __restrict__ layer = I.flows + (size_t)f * npx;
+                const float2 oa = (f == 0) ? I.flows[pia] : bilinear2_inside(layer, w, h, ok_a ? px1.x : 0.f, ok_a ? py1.x : 0.f);
+                const float2 ob = (f == 0) ? I.flows[pib] : bilinear2_inside(layer, w, h, ok_b ? px1.y : 0.f, ok_b ? py1.y : 0.f);
+                px1 = pf2{ ok_a ? px2.x : px1.x, ok_b ? px2.y : px1.y }; py1 = pf2{ ok_a ? py2.x : py1.x, ok_b ? py2.y : py1.y };
+                const pf2 ox = { oa.x, ob.x }, oy = { oa.y, ob.y };
+                const ObsTerms2 T = obs_terms2(ox, oy, K.ia2, K.l2q);
+                const pf2 den = 1.f + obs_ratio2(T, rdx - ox, rdy - oy, K.qia2);
+                const float ra = ok_a ? fast_rcp(den.x) : 0.f, rb = ok_b ? fast_rcp(den.y) : 0.f;
+                if (live_a) I.rig[(size_t)f * npx + pia] = ra;
+                if (live_b) I.rig[(size_t)f * npx + pib] = rb;
+                const float wsa = wave_sum(live_a ? ra : 0.f), wsb = wave_sum(live_b ? rb : 0.f);
+                if ((threadIdx.x & 63) == 0) { s_part[f][wv] = wsa; s_part[f][wv + 2] = wsb; }
+            }
         }
-        const H3 a = hom_dir(P->dpM[f], x, y);
-        const float hz = fmaf(d, a.z, P->dpT[f][2]);
-        const float qx2 = fmaf(d, a.x, P->dpT[f][0]) / hz, qy2 = fmaf(d, a.y, P->dpT[f][1]) / hz;  // see prior_parts
-        if (hz > 0.f && qx2 >= 0.f && qx2 < fw && qy2 >= 0.f && qy2 < fh) {
-            const float td = bilinear1(I.priors + (size_t)f * npx, w, h, qx2, qy2);
-            if (td > 0.f) I.confs[(size_t)f * npx + pi] = fast_rcp(1.f + depth_ratio(hz, td, I.basefocal, I.omega, I.inv_arf));
-        } else
-            I.confs[(size_t)f * npx + pi] = 0.f;
     }
+    __syncthreads();
+    if (threadIdx.x < NMAX && (int)threadIdx.x < I.N) {
+        const int f = threadIdx.x;
+        partial[(size_t)f * nblk + blk] = (s_part[f][0] + s_part[f][1]) + (s_part[f][2] + s_part[f][3]);
+    }
+    if (live_a) estep_pixel_tail(I, P, pia, x, y.x, d.x, world_scale);
+    if (live_b) estep_pixel_tail(I, P, pib, x, y.y, d.y, world_scale);
 }
 
 // ---- serial-chain fallbacks, both modes: global propagation with step 1, local segments longer than one wave
@@ -1309,6 +1379,10 @@ int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_
     }
     const int nblk = gpx.x * gpx.y;
     if constexpr (STRICT) hipLaunchKernelGGL(k_update_rigidness_strict<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>());
+    else if (debug_switches().estep_pairs == 2 || (debug_switches().estep_pairs == 1 && (size_t)w * h >= 1500000))
+        // two pixels per lane on packed fp32 where the pass fills the chip several times over (1920x1080 N=10: 76.9 -> 68.3 us; in the latency regime half
+        // the waves cost more than the instructions save: 1241x376 N=8 17.9 -> 19.9 us; profiles/r05i_*, r05j_*)
+        hipLaunchKernelGGL(k_update_rigidness_pairs<NMAX>, gpx, dim3(128), 0, c->stream, I, c->rig_partial.as<float>(), p.N > 0 ? p.world_scale_out : nullptr);
     else hipLaunchKernelGGL(k_update_rigidness_lean<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>(), p.N > 0 ? p.world_scale_out : nullptr);
     if (p.N > 0)
         reduce_density_launch(c, c->rig_partial.as<float>(), nblk, w * h, S.pb(), p.N, p.world_scale_out, STRICT ? 0 : 1);

@@ -112,6 +112,37 @@ __device__ __forceinline__ float obs_ratio(const ObsTerms& t, float ex, float ey
     return fast_exp2(t.c1 * (l - t.lm)) * a * a;
 }
 
+// Two pixels per lane: the same operation sequence on float pairs.  v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 round each half like the scalar
+// instruction, the transcendentals, max and med3 have no packed form and run per half: the bits of obs_terms / obs_ratio for either pixel.
+typedef float pf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pf2 pk_fma(pf2 a, pf2 b, pf2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ pf2 pk_all(float v) { return pf2{ v, v }; }
+struct ObsTerms2 { pf2 c, c1, ls, lm, rqm; };
+__device__ __forceinline__ ObsTerms2 obs_terms2(pf2 ox, pf2 oy, float ia2, float log2_qlam2) {
+#pragma clang fp contract(off)
+    const pf2 obs2 = pk_fma(ox, ox, oy * oy) * ia2;
+    const pf2 hs = 0.5f * pf2{ fast_sqrt(obs2.x), fast_sqrt(obs2.y) };
+    const pf2 g = { __builtin_amdgcn_fmed3f(hs.x, 2.f, 100.f), __builtin_amdgcn_fmed3f(hs.y, 2.f, 100.f) };
+    ObsTerms2 t;
+    t.c = pk_fma(pk_all(-0.0022f), g, pk_all(1.0f));
+    t.c1 = t.c + 1.f;
+    t.ls = pk_fma(pk_all(-0.12984255368000671f), g, pk_all(6.643856189774724f));
+    const pf2 lg = pf2{ fast_log2(obs2.x), fast_log2(obs2.y) } + log2_qlam2;
+    t.lm = pf2{ fmaxf(lg.x, -45.99999998912693f), fmaxf(lg.y, -45.99999998912693f) } + t.ls;
+    const pf2 e = -t.c * t.lm;
+    t.rqm = pf2{ fast_rcp(1.f + fast_exp2(e.x)), fast_rcp(1.f + fast_exp2(e.y)) };
+    return t;
+}
+__device__ __forceinline__ pf2 obs_ratio2(const ObsTerms2& t, pf2 ex, pf2 ey, float qia2) {
+#pragma clang fp contract(off)
+    const pf2 m = pk_fma(ex, ex, ey * ey) * qia2;
+    const pf2 l = pf2{ fast_log2(fmaxf(m.x, 1.4210854822304103e-14f)), fast_log2(fmaxf(m.y, 1.4210854822304103e-14f)) } + t.ls;
+    const pf2 q = -t.c * l;
+    const pf2 a = (1.f + pf2{ fast_exp2(q.x), fast_exp2(q.y) }) * t.rqm;
+    const pf2 u = t.c1 * (l - t.lm);
+    return pf2{ fast_exp2(u.x), fast_exp2(u.y) } * a * a;
+}
+
 // bilinear flow fetch at a position that is known to lie inside [0,w) x [0,h): two 16-byte texel-pair loads (rows yb, yb+1 at
 // column xb).  At the last column / row the pair is shifted inwards and the weight pinned to 1: the same value as clamping.
 typedef float vf2 __attribute__((ext_vector_type(2)));

@@ -30,6 +30,7 @@ struct DebugSwitches {
     int strict_pose_coop = 1;  // strict mode kernel on one single-wave workgroup per 512-row block of the pool (16 compute units) instead of one 512-thread workgroup; same bits
     // round 5
     int strict_coop_max_polls = 0;  // > 0: the cooperative strict mode kernel gives up a meeting after this many polls (tests force the give-up path); 0: 2^22
+    int estep_pairs = 1;       // the E-step with two pixels per lane on packed fp32 (same bits): 0 never, 1 from 1.5 M pixels, 2 always
     int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
 };
 DebugSwitches& debug_switches();  // vk_abi.hip
