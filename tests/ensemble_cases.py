@@ -7,7 +7,7 @@ import big_window_cases as big
 import ref_window_cases as small
 from voldor_amd import synth
 
-CFG2_SEEDS = (233,) + tuple(range(400, 471))  # 72 windows (24 in round 3); 233 = the window bench.py times
+CFG2_SEEDS = (233,) + tuple(range(400, 543))  # 144 windows (24 in round 3, 72 in round 4); 233 = the window bench.py times
 CFG3_SEEDS = (233,) + tuple(range(500, 547))  # 48 windows (8 in round 3)
 
 

@@ -5,7 +5,7 @@ the CPU) over an ensemble of independent windows, each run under three libms tha
   jA  glibc with every result moved by -1/0/+1 ulp, salt 1      (ref_set_math_mode(2), ref_set_jitter_salt(1))
   jB  the same with an independent pattern, salt 2
 
-  * BASELINE cfg2 (640x480, N=5, monocular, 8 iterations): seeds CFG2_SEEDS (72 windows)
+  * BASELINE cfg2 (640x480, N=5, monocular, 8 iterations): seeds CFG2_SEEDS (144 windows)
   * BASELINE cfg3 (1241x376, N=8, stereo prior):            seeds CFG3_SEEDS (48 windows)
 
 What the distances between those runs are is the estimator's reproducibility under a 1-ulp change of its transcendentals -- the

@@ -9,7 +9,7 @@ logf does to the reference's OWN output; the fast path (v_exp_f32 / v_log_f32, r
        worst rotation, worst relative translation, 90th-percentile relative depth, fraction of the confident pixels within 1e-3 and
        |log covariance-trace ratio| of a window; AND, since a KS test can only fail to reject (round 4): the 95 %
        bootstrap interval of mean(d_hip) / mean(d_ref), windows resampled as pairs (stat_helpers.paired_mean_ratio_ci), lies below 1.25
-       (above 0.8 for the within-1e-3 fraction) -- equivalence within a margin, on 72 cfg2 / 48 cfg3 windows (24 / 8 in round 3).  The
+       (above 0.8 for the within-1e-3 fraction) -- equivalence within a margin, on 144 cfg2 / 48 cfg3 windows (24 / 8 in round 3, 72 / 48 in round 4).  The
        test bites: a 12-step cap on the Newton loop of the P3P cubic (vk_debug_switch "newton_cap", 0.13 ms faster) fails it;
   (ii) the errors against analytic ground truth of {fast HIP} and {reference g} come from one distribution (same test);
   (iii) every window registers the reference's frame count.
