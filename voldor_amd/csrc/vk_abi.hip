@@ -150,7 +150,7 @@ static const DebugEntry g_debug_tab[] = {
     { "local_serial", &DebugSwitches::local_serial, 0 }, { "cost_rand_plain", &DebugSwitches::cost_rand_plain, 0 }, { "fb_segment", &DebugSwitches::fb_segment, 1 },
     { "global_split", &DebugSwitches::global_split, 0 }, { "refit_partition", &DebugSwitches::refit_partition, 0 }, { "split_trials", &DebugSwitches::split_trials, 0 },
     { "strict_plain", &DebugSwitches::strict_plain, 0 }, { "strict_pose_coop", &DebugSwitches::strict_pose_coop, 0 },
-    { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 }, { "estep_pairs", &DebugSwitches::estep_pairs, 3 },
+    { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 }, { "estep_pairs", &DebugSwitches::estep_pairs, 3 }, { "defer_reduce", &DebugSwitches::defer_reduce, 0 },
 };
 // returns the previous value; -1: unknown name; -2: a value the switch does not take
 static int debug_switch_set(const char* name, int value) {

@@ -146,12 +146,24 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
     // linear filter over the stacked layers for every at_tex of the reference (D1 / D2 switched off)
     bool ref_rng = false, ref_tex = false;
     float* world_scale_out = nullptr;  // device float: also run normalize_world_scale's pose half (voldor.cpp:309-317) in the last launch
+    // window pipeline, fast mode: the density reduction that closes the call (a launch of N + 1 workgroups) is not launched but left in
+    // Context::pending_reduce: the correspondence trace of camera 0 -- the next launch of the stream, which reads none of its results -- carries it as
+    // extra workgroups.  One dependent launch per EM iteration less (2.85 us boundary + 4.9 us kernel).
+    bool defer_reduce = false;
     // --reference_stale_depth 1 (strict mode; SURVEY Appendix B-1, deviation D4 switched off): the depth map optimize_depth.cu keeps on the device.
     // With exclusive_gpu_context the reference uploads its depth map for the first call only (voldor.cpp:250-291), so from the second EM
     // iteration on the search starts from a copy that never saw normalize_world_scale().  Non-null: the kernels of this call work on that copy
     // (refreshed from the window's map first when stale_refresh), the window's map then receives the result (and, alone, the world scale).
     float* stale_depth = nullptr;
     bool stale_refresh = false;
+};
+
+// arguments of the density reduction that closes an E-step (reduce_density_block, vk_cum_poses.hpp)
+struct ReduceArgs {
+    const float* partial = nullptr;  // [n_launch][nblk]; NULL: nothing to reduce
+    int nblk = 0, npx = 0, n_launch = 0, scale_ready = 0;
+    CamState* cams = nullptr; PoseBlock* P = nullptr; float* scale_out = nullptr;
+    int n_px_blocks = 0;  // riding in k_collect: workgroups of the trace itself (the reduction blocks follow them)
 };
 
 struct ProfEntry { double ms = 0; long count = 0; };
@@ -163,6 +175,7 @@ struct Context {
     // collect_p3p_instances.cu statics); the B-outer pipeline uses `od` for everything.
     ImageSet od, cp;
     DevBuf rig_partial;           // per-block rigidness sums -> pose_rigidness_density
+    ReduceArgs pending_reduce;    // window pipeline, fast mode: the density reduction of the last E-step, left for the next correspondence trace (partial != NULL: pending)
     DevBuf local_tbl;             // [h][w] candidate-cost table of a local propagation pass
     DevBuf p2_map, p3_map;        // [h*w][2], [h*w][3] (collect_p3p_instances.cu:27-34)
     DevBuf blk_counts, blk_offsets, valid_mask;  // per 256-pixel block: valid correspondences, their exclusive scan; one validity bit per pixel

@@ -3,6 +3,7 @@
 // kernel of the depth half: run by an extra workgroup of the first fb_smooth launch, or by its own launch k_cum_poses.
 #pragma once
 #include "vk_common.hpp"
+#include "vk_device.hpp"
 
 namespace vk {
 
@@ -16,6 +17,32 @@ __device__ __forceinline__ static float world_scale_factor(const PoseBlock* P, i
         ws = (float)((double)ws + sqrt((double)t[0] * t[0] + (double)t[1] * t[1] + (double)t[2] * t[2]));  // float += double (cv::norm, voldor.cpp:312)
     }
     return (float)n / ws;
+}
+// The density reduction that closes an E-step (update_rigidnesses + host cv::sum, optimize_depth.cu:84-138, voldor.cpp:171) as ONE workgroup's work per
+// frame: block f < n_launch sums the per-tile rigidness sums of frame f in a fixed order -> CamState::pose_rigidness_density; block n_launch (present
+// when scale_out != NULL) is the pose half of normalize_world_scale (voldor.cpp:309-317).  Run by k_reduce_density, or -- window pipeline, fast mode --
+// by extra workgroups of the NEXT launch of the stream, the correspondence trace of camera 0 (k_collect), which reads none of what is written here.
+__device__ __forceinline__ static void reduce_density_block(int f, const ReduceArgs& a) {
+    PoseBlock* P = a.P;
+    if (f == a.n_launch) {
+        if (threadIdx.x != 0) return;
+        const int n = min(a.n_launch, P->n_active);  // frames dropped by this iteration's decision do not count
+        // scale_ready: the factor was computed from these poses at the start of the call (cum_poses_block) and the depth map already
+        // carries it (k_update_rigidness_lean); otherwise it is computed here and k_scale follows
+        const float s = a.scale_ready ? *a.scale_out : world_scale_factor(P, a.n_launch, P->ts);
+        for (int i = 0; i < n; i++)
+            for (int d = 0; d < 3; d++) { P->ts[i][d] *= s; a.cams[i].t[d] = P->ts[i][d]; }
+        *a.scale_out = s;
+        return;
+    }
+    if (f >= P->n_active) return;
+    __shared__ float s_red[4];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < a.nblk; i += 256) acc += a.partial[(size_t)f * a.nblk + i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) a.cams[f].pose_rigidness_density = ((s_red[0] + s_red[1]) + (s_red[2] + s_red[3])) / (float)a.npx;
 }
 // world_scale (may be NULL): the factor of normalize_world_scale (voldor.cpp:309-317), n / sum ||t_i|| over the registered frames, from
 // the poses this optimize_depth call runs with; the E-step kernel stores the scaled depth, k_reduce_density then scales the poses.

@@ -21,6 +21,8 @@ extern "C" {
  *                             reference's sum tree block by block) instead of the parallel structures -- both give the same bits
  *   "strict_coop_max_polls"  0 | n > 0   polls after which a workgroup of the cooperative strict mode kernel gives up a meeting (0: 2^20); tests set 1 to
  *                             force the hand-over to the single-workgroup kernel
+ *   "defer_reduce"    1 | 0   0: every optimize_depth call of a window launches its own density reduction instead of leaving it to the extra workgroups
+ *                             of the next correspondence trace
  *   "estep_pairs"     1 | 0 | 2   the fast E-step with two pixels per lane on packed fp32 (same bits): from 1.5 M pixels | never | at every size
  * Returns the previous value, -1 for an unknown name / value. */
 int vk_debug_switch(const char* name, int value);

@@ -32,29 +32,7 @@ __global__ __launch_bounds__(64) static void k_cum_poses(PoseBlock* P, int N, in
 // fixed-order second stage: cams[f].pose_rigidness_density = sum(partial[f][:]) / npx
 // blocks 0..n_launch-1: rigidness density of one frame; block n_launch (only launched when scale_out != NULL): the pose half
 // of normalize_world_scale (voldor.cpp:309-317), scale = n / sum ||t_i|| over the registered frames -- one launch for both
-__global__ static void k_reduce_density(const float* __restrict__ partial, int nblk, int npx, CamState* cams, PoseBlock* P, int n_launch,
-                                        float* scale_out, int scale_ready) {
-    const int f = blockIdx.x;
-    if (f == n_launch) {
-        if (threadIdx.x != 0) return;
-        const int n = min(n_launch, P->n_active);  // frames dropped by this iteration's decision do not count
-        // scale_ready: the factor was computed from these poses at the start of the call (cum_poses_block) and the depth map already
-        // carries it (k_update_rigidness_lean); otherwise it is computed here and k_scale follows
-        const float s = scale_ready ? *scale_out : world_scale_factor(P, n_launch, P->ts);
-        for (int i = 0; i < n; i++)
-            for (int d = 0; d < 3; d++) { P->ts[i][d] *= s; cams[i].t[d] = P->ts[i][d]; }
-        *scale_out = s;
-        return;
-    }
-    if (f >= P->n_active) return;
-    __shared__ float s[4];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < nblk; i += 256) acc += partial[(size_t)f * nblk + i];
-    acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) cams[f].pose_rigidness_density = ((s[0] + s[1]) + (s[2] + s[3])) / (float)npx;
-}
+__global__ __launch_bounds__(256) static void k_reduce_density(ReduceArgs a) { reduce_density_block(blockIdx.x, a); }
 
 template <bool VEC4, int FB_SEG>
 __global__ __launch_bounds__(256) static void k_fb_rows(const float* maps, float* maps_out /* == maps: in place */, int w, int h, int S, float e0, float p, const int* __restrict__ n_dev,
@@ -135,7 +113,18 @@ __global__ static void k_scale(float* p, const float* s_dev, size_t n) {
 
 void cum_poses_launch(Context* c, PoseBlock* P, int N, int N_dp, float* world_scale) { hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, P, N, N_dp, world_scale); }
 void reduce_density_launch(Context* c, const float* partial, int nblk, int npx, PoseBlock* P, int n_launch, float* scale_out, int scale_ready) {
-    hipLaunchKernelGGL(k_reduce_density, dim3(n_launch + (scale_out ? 1 : 0)), dim3(256), 0, c->stream, partial, nblk, npx, c->cams.as<CamState>(), P, n_launch, scale_out, scale_ready);
+    ReduceArgs a;
+    a.partial = partial; a.nblk = nblk; a.npx = npx; a.n_launch = n_launch; a.scale_ready = scale_ready; a.cams = c->cams.as<CamState>(); a.P = P; a.scale_out = scale_out;
+    hipLaunchKernelGGL(k_reduce_density, dim3(n_launch + (scale_out ? 1 : 0)), dim3(256), 0, c->stream, a);
+}
+// a reduction the window pipeline left for the next correspondence trace (Context::pending_reduce) and that no trace has picked up
+int flush_pending_reduce(Context* c) {
+    if (!c->pending_reduce.partial) return 0;
+    const ReduceArgs a = c->pending_reduce;
+    c->pending_reduce = ReduceArgs();
+    hipLaunchKernelGGL(k_reduce_density, dim3(a.n_launch + (a.scale_out ? 1 : 0)), dim3(256), 0, c->stream, a);
+    VK_CHECK_LAST();
+    return 0;
 }
 
 static int optimize_depth_dispatch(Context* c, ImageSet& S, const OdParams& p, bool cost_only) {

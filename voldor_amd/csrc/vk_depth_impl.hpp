@@ -1384,8 +1384,13 @@ int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_
         // the waves cost more than the instructions save: 1241x376 N=8 17.9 -> 19.9 us; profiles/r05i_*, r05j_*)
         hipLaunchKernelGGL(k_update_rigidness_pairs<NMAX>, gpx, dim3(128), 0, c->stream, I, c->rig_partial.as<float>(), p.N > 0 ? p.world_scale_out : nullptr);
     else hipLaunchKernelGGL(k_update_rigidness_lean<NMAX>, gpx, bpx, 0, c->stream, I, c->rig_partial.as<float>(), p.N > 0 ? p.world_scale_out : nullptr);
-    if (p.N > 0)
-        reduce_density_launch(c, c->rig_partial.as<float>(), nblk, w * h, S.pb(), p.N, p.world_scale_out, STRICT ? 0 : 1);
+    if (p.N > 0) {
+        if (!STRICT && p.defer_reduce) {  // left for the next correspondence trace (OdParams::defer_reduce)
+            ReduceArgs& a = c->pending_reduce;
+            a.partial = c->rig_partial.as<float>(); a.nblk = nblk; a.npx = w * h; a.n_launch = p.N; a.scale_ready = 1; a.cams = c->cams.as<CamState>(); a.P = S.pb(); a.scale_out = p.world_scale_out;
+        } else
+            reduce_density_launch(c, c->rig_partial.as<float>(), nblk, w * h, S.pb(), p.N, p.world_scale_out, STRICT ? 0 : 1);
+    }
     // normalize_world_scale's depth half: strict mode as its own pass after the E-step; the fast E-step kernel has stored the scaled map
     if (stale) VK_CHECK(hipMemcpyAsync(S.depth.p, p.stale_depth, sizeof(float) * (size_t)w * h, hipMemcpyDeviceToDevice, c->stream));  // d_depth.copy_to_host(h_o_depth): the host's map, which alone is normalised
     if (STRICT && p.N > 0 && p.world_scale_out) { if (int e = scale_device(c, S.depth.as<float>(), p.world_scale_out, (size_t)w * h)) return e; }

@@ -30,6 +30,7 @@ struct DebugSwitches {
     int strict_pose_coop = 1;  // strict mode kernel on one single-wave workgroup per 512-row block of the pool (16 compute units) instead of one 512-thread workgroup; same bits
     // round 5
     int strict_coop_max_polls = 0;  // > 0: the cooperative strict mode kernel gives up a meeting after this many polls (tests force the give-up path); 0: 2^22
+    int defer_reduce = 1;      // 0: every optimize_depth call of a window launches its own density reduction
     int estep_pairs = 1;       // the E-step with two pixels per lane on packed fp32 (same bits): 0 never, 1 from 1.5 M pixels, 2 always
     int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
 };
@@ -81,6 +82,7 @@ int depth_conf_device(Context* c, const float* rig, const float* confs, float* o
 int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk_dev, int w, int h, int d, float sigma, int ksize);
 
 // vk_pose.hip
+int flush_pending_reduce(Context* c);  // vk_depth.hip
 int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int active_idx, float rig_thresh, float rig_sum_thresh,
                    float min_depth, float max_depth, int max_trace, CamState* cam_dev, bool compact, bool block_compact = false, bool ref_tex = false);
 int solve_device(Context* c, const float* pts2, const float* pts3, int* n_pts_dev, float fx, float fy, float cx, float cy,

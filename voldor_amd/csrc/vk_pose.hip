@@ -19,6 +19,7 @@
 #include "vk_lu.hpp"
 #include "vk_ref_cuda.h"
 #include "vk_internal.hpp"
+#include "vk_cum_poses.hpp"
 
 namespace vk {
 
@@ -46,10 +47,13 @@ __global__ __launch_bounds__(256) static void k_collect(const float2* __restrict
                                                          float* __restrict__ p2_map, float* __restrict__ p3_map,
                                                          int* __restrict__ blk_counts, unsigned long long* __restrict__ valid_mask, int N, int w, int h, int active_idx,
                                                          float rig_thresh, float rig_sum_thresh, float min_depth,
-                                                         float max_depth, int max_trace, int ref_tex /* --reference_tex 1: CUDA's linear filter over the N stacked flow layers (vk_ref_cuda.h) */) {
+                                                         float max_depth, int max_trace, int ref_tex /* --reference_tex 1: CUDA's linear filter over the N stacked flow layers (vk_ref_cuda.h) */,
+                                                         ReduceArgs ra /* partial != NULL: the workgroups after the first n_px_blocks close the previous E-step (reduce_density_block) */) {
     PH_DECL;
     const int npx = w * h;
-    const int tile = xcd_band_tile(blockIdx.x, gridDim.x);  // XCD k works on the k-th band of rows (vk_device.hpp)
+    const int n_px_blocks = ra.partial ? ra.n_px_blocks : (int)gridDim.x;
+    if ((int)blockIdx.x >= n_px_blocks) { reduce_density_block((int)blockIdx.x - n_px_blocks, ra); return; }
+    const int tile = xcd_band_tile(blockIdx.x, n_px_blocks);  // XCD k works on the k-th band of rows (vk_device.hpp)
     const int pi = tile * 256 + threadIdx.x;
     const float qnan = __builtin_nanf("");
     bool valid = false;
@@ -1562,14 +1566,22 @@ int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int activ
     if (int e = c->valid_mask.reserve(sizeof(unsigned long long) * 4 * (size_t)nblk)) return e;
     if (int e = c->ensure_n_points()) return e;
     if (block_compact && compact) return (int)hipErrorInvalidValue;  // the ordered list of the host-pointer API is built from the NaN-marked maps
+    // the density reduction the window pipeline left behind rides in the trace of camera 0 (which reads only depth, the weights of frame 0, the first
+    // flow layer and the intrinsics); any other trace runs behind its own launch
+    ReduceArgs ra;
+    int extra = 0;
+    if (c->pending_reduce.partial) {
+        if (active_idx == 0) { ra = c->pending_reduce; ra.n_px_blocks = nblk; extra = ra.n_launch + (ra.scale_out ? 1 : 0); c->pending_reduce = ReduceArgs(); }
+        else if (int e = flush_pending_reduce(c)) return e;
+    }
     if (block_compact)
-        hipLaunchKernelGGL(k_collect<true>, dim3(nblk), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
+        hipLaunchKernelGGL(k_collect<true>, dim3(nblk + extra), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
                            S.pb(), c->p2_map.as<float>(), c->p3_map.as<float>(), c->blk_counts.as<int>(), c->valid_mask.as<unsigned long long>(), N, w, h, active_idx,
-                           rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace, ref_tex ? 1 : 0);
+                           rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace, ref_tex ? 1 : 0, ra);
     else
-        hipLaunchKernelGGL(k_collect<false>, dim3(nblk), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
+        hipLaunchKernelGGL(k_collect<false>, dim3(nblk + extra), dim3(256), 0, c->stream, S.flows.as<float2>(), S.rig.as<float>(), S.depth.as<float>(),
                            S.pb(), c->p2_map.as<float>(), c->p3_map.as<float>(), c->blk_counts.as<int>(), c->valid_mask.as<unsigned long long>(), N, w, h, active_idx,
-                           rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace, ref_tex ? 1 : 0);
+                           rig_thresh, rig_sum_thresh, min_depth, max_depth, max_trace, ref_tex ? 1 : 0, ra);
     c->n_map_blocks = nblk;
     c->maps_block_compact = block_compact;
     if (compact) {  // the host-pointer API hands the compacted list to its caller (geometry.cpp:68-80)

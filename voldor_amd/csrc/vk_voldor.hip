@@ -136,6 +136,7 @@ struct Voldor {
     int init(const float* flows, const float* disparity, const float* disparity_pconf, const float* depth_priors,
              const float* depth_prior_poses, const float* depth_prior_pconfs, int N, int N_dp_in, int w_, int h_) {
         w = w_; h = h_;
+        c->pending_reduce = ReduceArgs();  // (a window that failed half way may have left one behind)
         strict = cfg.strict_math < 0 ? strict_math_default() : cfg.strict_math != 0;
         ref_rng = strict && (cfg.reference_rng < 0 ? reference_rng_default() : cfg.reference_rng != 0);  // (the fast kernels keep D1 / D2: their arithmetic is not the reference's anyway)
         ref_tex = strict && (cfg.reference_tex < 0 ? reference_tex_default() : cfg.reference_tex != 0);
@@ -218,7 +219,7 @@ struct Voldor {
     }
 
     // voldor.cpp:203-307 (the upload / "minimal cache" branches collapse: everything is resident)
-    int optimize_depth(OdFlag flag, bool with_world_scale = false) {
+    int optimize_depth(OdFlag flag, bool with_world_scale = false, bool defer_reduce = false) {
         if (n_flows == 0 && n_dp == 0) return 0;
         OdParams p;
         p.abs_resize_factor = cfg.abs_resize_factor;
@@ -233,6 +234,7 @@ struct Voldor {
             p.stale_depth = c->stale_depth.as<float>();
             p.stale_refresh = iters_cur < 2;  // voldor.cpp:250: "iters_cur == 0 || iters_cur == 1": the calls that upload the map
         }
+        p.defer_reduce = defer_reduce && !strict && debug_switches().defer_reduce != 0;
         if (with_world_scale) p.world_scale_out = world_scale_ptr();  // voldor.cpp:309-317: the pose half rides on the density launch, the depth half follows
         return optimize_depth_device(c, c->od, p);  // with world_scale_out: depth and poses leave normalised (voldor.cpp:309-317)
     }
@@ -329,10 +331,11 @@ struct Voldor {
             iters_cur++; iters_remain--;
             if (int e = enqueue_cameras()) return e;
             // the depth half is enqueued with the pre-decision frame count; on the device it runs with n_active
-            if (int e = optimize_depth(cfg.optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY, cfg.norm_world_scale && n_dp == 0)) return e;
+            // (another EM iteration follows for certain: its first launch, the trace of camera 0, closes this E-step's density reduction)
+            if (int e = optimize_depth(cfg.optimize_depth ? OD_DEFAULT : OD_UPDATE_RIGIDNESS_ONLY, cfg.norm_world_scale && n_dp == 0, iters_remain > 0)) return e;
             if (int e = finish_cameras()) return e;
         }
-        return 0;
+        return flush_pending_reduce(c);  // (the window was truncated to nothing in between)
     }
 };
 
