@@ -348,7 +348,7 @@ def main():
             ach = b_od / t_od / 1e9
             # Primary figure = SURVEY.md section 8(d)'s definition: unit = one optimize_depth call (one EM iteration's depth half, a
             # group of dependent launches), achieved = B_od / (duration of the group, HIP events on the library's stream, this run).
-            roof = {"bound": "hbm", "kernel": "optimize_depth launch group (fb_smooth rows + columns, cost + random samples, 4 global + 4 local propagation passes, E-step; its density reduction rides in the next launch of the stream, the correspondence trace of camera 0, except after the last call of a window)",
+            roof = {"bound": "hbm", "kernel": "optimize_depth launch group (cost + random samples, 4 global + 4 local propagation passes, E-step; since round 5 fb_smooth -- below 8 M map pixels and outside refit iterations -- rides block by block in the launches of the pose half's mode kernels and the density reduction in the next correspondence trace: inside a window both are in this group only where they still have their own launches)",
                     "achieved": round(ach, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 5),
                     "algorithmic_bytes": b_od, "avg_us": round(t_od * 1e6, 2),
                     "kernels": ktable, "sweeps": sweeps,

@@ -30,7 +30,7 @@ int Context::init(int dev) {
     return 0;
 }
 void Context::destroy() {
-    DevBuf* bufs[] = { &od.flows, &od.rig, &od.depth, &od.cost, &od.priors, &od.pconfs, &od.confs, &od.pose,
+    DevBuf* bufs[] = { &od.flows, &od.rig, &od.rig2, &od.depth, &od.cost, &od.priors, &od.pconfs, &od.confs, &od.pose,
                        &cp.flows, &cp.rig, &cp.depth, &cp.cost, &cp.priors, &cp.pconfs, &cp.confs, &cp.pose,
                        &rig_partial, &local_tbl, &p2_map, &p3_map, &blk_counts, &blk_offsets, &valid_mask, &pts2, &pts3, &n_points,
                        &rvecs, &tvecs, &pool, &ms_io, &cams, &tmp, &fb_scratch, &stale_depth, &sp_coop, &xw_jumps, &xw_px_states, &xw_pose_states };
@@ -150,7 +150,7 @@ static const DebugEntry g_debug_tab[] = {
     { "local_serial", &DebugSwitches::local_serial, 0 }, { "cost_rand_plain", &DebugSwitches::cost_rand_plain, 0 }, { "fb_segment", &DebugSwitches::fb_segment, 1 },
     { "global_split", &DebugSwitches::global_split, 0 }, { "refit_partition", &DebugSwitches::refit_partition, 0 }, { "split_trials", &DebugSwitches::split_trials, 0 },
     { "strict_plain", &DebugSwitches::strict_plain, 0 }, { "strict_pose_coop", &DebugSwitches::strict_pose_coop, 0 },
-    { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 }, { "estep_pairs", &DebugSwitches::estep_pairs, 3 }, { "defer_reduce", &DebugSwitches::defer_reduce, 0 },
+    { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 }, { "estep_pairs", &DebugSwitches::estep_pairs, 3 }, { "fb_ride", &DebugSwitches::fb_ride, 0 }, { "defer_reduce", &DebugSwitches::defer_reduce, 0 },
 };
 // returns the previous value; -1: unknown name; -2: a value the switch does not take
 static int debug_switch_set(const char* name, int value) {

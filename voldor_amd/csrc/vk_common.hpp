@@ -113,6 +113,7 @@ struct ImageSet {
     int w = 0, h = 0;
     DevBuf flows;   // [N][h][w] float2
     DevBuf rig;     // [N][h][w]
+    DevBuf rig2;    // [N][h][w]: where the row pass of a riding fb_smooth puts the maps (FbRide); swapped with `rig` when the pose half ends
     DevBuf depth;   // [h][w]
     DevBuf cost;    // [h][w]
     DevBuf priors, pconfs, confs;  // [N_dp][h][w]
@@ -150,6 +151,7 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
     // Context::pending_reduce: the correspondence trace of camera 0 -- the next launch of the stream, which reads none of its results -- carries it as
     // extra workgroups.  One dependent launch per EM iteration less (2.85 us boundary + 4.9 us kernel).
     bool defer_reduce = false;
+    bool fb_done = false;  // window pipeline, fast mode: fb_smooth and the projective maps of this call were done in the launches of the pose half (FbRide)
     // --reference_stale_depth 1 (strict mode; SURVEY Appendix B-1, deviation D4 switched off): the depth map optimize_depth.cu keeps on the device.
     // With exclusive_gpu_context the reference uploads its depth map for the first call only (voldor.cpp:250-291), so from the second EM
     // iteration on the search starts from a copy that never saw normalize_world_scale().  Non-null: the kernels of this call work on that copy
@@ -158,6 +160,22 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
     bool stale_refresh = false;
 };
 
+// fb_smooth blocks riding in a mode kernel's launch (vk_pose.hip mode_fb_ride): a contiguous range of the 256-thread blocks of ONE pass over up to two
+// stacks of maps (the rigidness maps, the prior confidences).  The window pipeline deals the row blocks (rigidness maps out of place: the traces of the
+// later cameras still read them) and then the column blocks over the mode kernels of an EM iteration's cameras -- launches that keep one compute unit
+// busy -- so that the depth half starts at its cost kernel: two to four dependent launches per EM iteration less (vk_voldor.hip plan_fb_ride).
+struct FbStack { const float* src = nullptr; float* dst = nullptr; int n_maps = 0, S = 0, CW = 0, vec4 = 0, blocks_x = 1, n_blocks = 0; };
+struct FbRide {
+    int kind = 0;   // 0: nothing rides; 1: row pass src -> dst; 2: column pass in place on dst
+    int seg = 12;   // steps per lane (12 | 20)
+    int first = 0, count = 0;  // blocks [first, first + count) of the pass, stack 0's blocks then stack 1's
+    int w = 0, h = 0;
+    float e0 = 0.f, p = 0.f;
+    FbStack st[2];
+    // last mode kernel of the pose half: its own workgroup then prepares the projective maps of the depth half (cum_poses_block); -1: no
+    int cum_N = -1, cum_Ndp = 0;
+    float* world_scale = nullptr;
+};
 // arguments of the density reduction that closes an E-step (reduce_density_block, vk_cum_poses.hpp)
 struct ReduceArgs {
     const float* partial = nullptr;  // [n_launch][nblk]; NULL: nothing to reduce

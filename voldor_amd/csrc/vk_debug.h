@@ -23,6 +23,8 @@ extern "C" {
  *                             force the hand-over to the single-workgroup kernel
  *   "defer_reduce"    1 | 0   0: every optimize_depth call of a window launches its own density reduction instead of leaving it to the extra workgroups
  *                             of the next correspondence trace
+ *   "fb_ride"         1 | 0   0: fb_smooth of a window's depth half always runs as its own launches instead of riding, block by block, in the launches of the
+ *                             pose half's mode kernels (FbRide, vk_common.hpp)
  *   "estep_pairs"     1 | 0 | 2   the fast E-step with two pixels per lane on packed fp32 (same bits): from 1.5 M pixels | never | at every size
  * Returns the previous value, -1 for an unknown name / value. */
 int vk_debug_switch(const char* name, int value);

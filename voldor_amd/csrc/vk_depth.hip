@@ -83,6 +83,10 @@ static void fb_smooth_plan(int w, int h, int n_maps, int* rows_seg, int* cols_se
     *rows_seg = pick(w, FB_MAX_ROW_SEGS);
     *cols_seg = pick(h, FB_MAX_COL_SEGS);
 }
+void fb_smooth_plan_segments(int w, int h, int n_maps, int* rows_seg, int* cols_seg, bool* segmented) {
+    *segmented = fb_smooth_segmented(w, h);
+    fb_smooth_plan(w, h, n_maps, rows_seg, cols_seg);
+}
 int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev, PoseBlock* cumP,
                      int cumN, int cumNdp, float* world_scale) {
     if (n_maps <= 0) return 0;

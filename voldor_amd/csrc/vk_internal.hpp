@@ -31,6 +31,7 @@ struct DebugSwitches {
     // round 5
     int strict_coop_max_polls = 0;  // > 0: the cooperative strict mode kernel gives up a meeting after this many polls (tests force the give-up path); 0: 2^22
     int defer_reduce = 1;      // 0: every optimize_depth call of a window launches its own density reduction
+    int fb_ride = 1;           // 0: fb_smooth of a window's depth half always runs as its own launches (not in the launches of the pose half's mode kernels)
     int estep_pairs = 1;       // the E-step with two pixels per lane on packed fp32 (same bits): 0 never, 1 from 1.5 M pixels, 2 always
     int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
 };
@@ -95,7 +96,8 @@ int solve_from_maps_device(Context* c, int npx, float fx, float fy, float cx, fl
 int xorwow_jumps_device(Context* c);                              // c->xw_jumps ready
 int xorwow_pixel_states_device(Context* c, int npx, uint32_t epoch);  // c->xw_px_states = states `epoch` draws after curand_init(RAND_SEED, pixel, 0)
 int xorwow_pose_states_device(Context* c, int n_poses);           // c->xw_pose_states = states after curand_init(RAND_SEED, idx, 0)
-int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first = false);
+int pose_mode_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first = false, const FbRide* ride = nullptr);
+void fb_smooth_plan_segments(int w, int h, int n_maps, int* rows_seg, int* cols_seg, bool* segmented);  // vk_depth.hip: steps per lane of the two passes
 int meanshift_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 

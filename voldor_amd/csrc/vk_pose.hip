@@ -20,6 +20,7 @@
 #include "vk_ref_cuda.h"
 #include "vk_internal.hpp"
 #include "vk_cum_poses.hpp"
+#include "vk_fb.hpp"
 
 namespace vk {
 
@@ -1421,10 +1422,44 @@ __device__ __forceinline__ static void pose_mode_body(const float* __restrict__ 
     }
     PH_MARK(22);
 }
+// fb_smooth blocks riding in the (non-refit) mode kernel's launch (FbRide, vk_common.hpp): workgroup q of the riders takes blocks 2 q and 2 q + 1 of its
+// range, one per 256-thread half, each half with its own LDS; both halves run the same pass on maps of one size: the same barriers.  A half past the
+// range keeps the barriers company (fb_rows_body / fb_cols_body: a block past the job).
+template <int SEG>
+__device__ __forceinline__ void mode_fb_ride(const FbRide& R, int q) {
+    __shared__ FbMat s_fb[2][4][256];  // [half][sF 2 x 256 | sB 2 x 256]
+    const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
+    const bool in = 2 * q + half < R.count;
+    int b = R.first + 2 * q + half;
+    const FbStack* J = &R.st[0];
+    if (in && b >= R.st[0].n_blocks) { b -= R.st[0].n_blocks; J = &R.st[1]; }
+    const int bx = in ? b % J->blocks_x : (1 << 20), by = in ? b / J->blocks_x : 0;
+    FbMat* sF = &s_fb[half][0][0]; FbMat* sB = &s_fb[half][2][0];
+    if (R.kind == 1) {
+        if (J->vec4) fb_rows_body<true, SEG>(J->src, J->dst, R.w, R.h, J->S, R.e0, R.p, bx, by, sF, sB, tid);
+        else fb_rows_body<false, SEG>(J->src, J->dst, R.w, R.h, J->S, R.e0, R.p, bx, by, sF, sB, tid);
+    } else fb_cols_body<SEG>(J->dst, R.w, R.h, J->S, J->CW, R.e0, R.p, bx, by, sF, sB, tid);
+}
 template <bool DEFER, int THREADS>
 __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp, CamState* cam,
-                                                                  PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev, const float* __restrict__ trials_in) {
+                                                                  PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev, const float* __restrict__ trials_in, FbRide ride) {
+    if constexpr (!DEFER && THREADS == 512) {
+        if (blockIdx.x > 0) {  // what rides along on the 255 compute units the mode kernel leaves idle (workgroup 0 is the mode kernel itself)
+            if (ride.seg == 12) mode_fb_ride<12>(ride, (int)blockIdx.x - 1); else mode_fb_ride<20>(ride, (int)blockIdx.x - 1);
+            return;
+        }
+    }
     pose_mode_body<DEFER, THREADS>(rvecs, tvecs, n_poses, mp, cam, P, cam_idx, n_points_dev, trials_in);
+    if constexpr (!DEFER) {
+        // the last mode kernel of a pose half whose fb_smooth rode along also prepares the projective maps of the depth half and the world-scale factor
+        // (vk_cum_poses.hpp): every exit of pose_mode_body has written the camera record and the truncation decision; thread 0's stores are pushed
+        // out and the workgroup meets before anybody reads them back
+        if (ride.cum_N >= 0) {  // (uniform)
+            __threadfence();
+            __syncthreads();
+            cum_poses_block(P, ride.cum_N, ride.cum_Ndp, ride.world_scale);
+        }
+    }
 }
 // The initial-mode trials of a camera that has no pose yet (first EM iteration; meanshift.cu:72-95: the kernel density at up to
 // max_init_trials random hypotheses, the densest one starts the mean shift) are independent of one another and each is a full pass
@@ -1682,8 +1717,12 @@ int xorwow_pose_states_device(Context* c, int n_poses) {
     return 0;
 }
 
-int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first) {
+int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState* cam_dev, PoseBlock* P, int cam_idx, bool trials_first, const FbRide* ride_in) {
     ModeParams mp = mp_in;
+    FbRide ride;
+    if (ride_in) ride = *ride_in;
+    if (mp.do_rg && (ride.kind != 0 || ride.cum_N >= 0)) return (int)hipErrorInvalidValue;  // (the refit kernel carries nothing: 141 KB of LDS)
+    const int n_riders = ride.kind ? (ride.count + 1) / 2 : 0;
     mp.rg_partition = debug_switches().refit_partition;
     if (n_poses > PM_POOL) {
         fprintf(stderr, "voldor_hip: n_poses_to_sample=%d exceeds the %d hypotheses the mode kernel keeps in registers\n", n_poses,
@@ -1704,10 +1743,10 @@ int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState*
     }
     if (mp.do_rg)
         hipLaunchKernelGGL((k_pose_mode<true, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
-                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials);
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials, ride);
     else
-        hipLaunchKernelGGL((k_pose_mode<false, PM_THREADS>), dim3(1), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
-                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials);
+        hipLaunchKernelGGL((k_pose_mode<false, PM_THREADS>), dim3(1 + n_riders), dim3(PM_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses,
+                           mp, cam_dev, P, cam_idx, c->n_points.as<int>(), trials, ride);
     VK_CHECK_LAST();
     return 0;
 }

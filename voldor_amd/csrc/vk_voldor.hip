@@ -160,6 +160,7 @@ struct Voldor {
         if (int e = S.ensure_pose()) return e;
         if (int e = S.flows.reserve(sizeof(float) * 2 * npx * N)) return e;
         if (int e = S.rig.reserve(sizeof(float) * npx * N)) return e;
+        if (!strict && cfg.fb_smooth) { if (int e = S.rig2.reserve(sizeof(float) * npx * N)) return e; }  // (FbRide: the row pass of a riding fb_smooth writes here)
         if (int e = S.depth.reserve(sizeof(float) * npx)) return e;
         if (int e = S.cost.reserve(sizeof(float) * npx)) return e;
         if (int e = c->cams.reserve(sizeof(CamState) * MAX_FRAMES)) return e;
@@ -235,13 +236,15 @@ struct Voldor {
             p.stale_refresh = iters_cur < 2;  // voldor.cpp:250: "iters_cur == 0 || iters_cur == 1": the calls that upload the map
         }
         p.defer_reduce = defer_reduce && !strict && debug_switches().defer_reduce != 0;
+        p.fb_done = fb_rode && flag != OD_ONLY_USE_DEPTH_PRIOR;  // (enqueue_cameras: fb_smooth and the projective maps rode in the pose half's mode kernels)
+        fb_rode = false;
         if (with_world_scale) p.world_scale_out = world_scale_ptr();  // voldor.cpp:309-317: the pose half rides on the density launch, the depth half follows
         return optimize_depth_device(c, c->od, p);  // with world_scale_out: depth and poses leave normalised (voldor.cpp:309-317)
     }
 
     // voldor/geometry.cpp:5-265, all on the device; success / density come back in CamState
-    float* world_scale_ptr() { return c->ms_io.as<float>() + 48; }  // (ms_io is reserved at its full size in init(): the pointer holds for the window)
-    int optimize_camera_pose(int i, bool rg_refine, bool last = false) {
+    float* world_scale_ptr() const { return c->ms_io.as<float>() + 48; }  // (ms_io is reserved at its full size in init(): the pointer holds for the window)
+    int optimize_camera_pose(int i, bool rg_refine, bool last = false, const FbRide* ride = nullptr) {
         ImageSet& S = c->od;
         if (c->prof) prof_begin(c);
         const int solver = cfg.lambdatwist ? (cfg.cpu_p3p ? 2 : 0) : 1;  // cpu_p3p=1 selects the reference's CPU instantiation lambdatwist_p4p<double,...> (geometry.cpp:112)
@@ -266,7 +269,7 @@ struct Voldor {
                                            cfg.reference_draw ? 1 : 0, strict, ref_svd, ref_rng))
             return e;
         if (strict) { if (int e = pose_mode_strict_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i)) return e; }
-        else if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i, hcams[i].pose_sample_count == 0)) return e;
+        else if (int e = pose_mode_device(c, cfg.n_poses_to_sample, mp, dcams() + i, S.pb(), i, hcams[i].pose_sample_count == 0, ride)) return e;
         if (c->prof) prof_end(c, "optimize_camera_pose");
         return 0;
     }
@@ -277,12 +280,82 @@ struct Voldor {
     // after it has already enqueued this iteration's depth half: the GPU never waits for the host decision.
     // Equivalent to the reference order: a camera that fails or is skipped truncates the window at its index, so whatever
     // the speculatively executed later cameras wrote (their own pose slots only) is never read again.
+    // fb_smooth of the depth half riding in the pose half (FbRide, vk_common.hpp).  The mode kernel of a camera keeps ONE compute unit busy for ~13 us;
+    // fb_smooth -- the first two (with depth priors: four) launches of the depth half -- depends on nothing the pose half computes: the rigidness maps
+    // are only READ there, by the traces.  So its 256-thread blocks are dealt over the mode kernels of the iteration's cameras as extra workgroups: the
+    // row blocks first (rigidness maps out of place, rig -> rig2: the traces of the later cameras still read rig; prior confidences in place), then, in
+    // later launches, the column blocks (in place on rig2); the last mode kernel also prepares the projective maps of the depth half.  rig and rig2
+    // then change names and optimize_depth starts at its cost kernel.  Same arithmetic on the same values: every output bit of a window unchanged.
+    // Not in strict mode, not in an iteration with the refit (that kernel's LDS leaves no room), not where a pass needs 40-step segments (1080p: there
+    // fb_smooth is 110 us of memory pass, not launch latency), not when the blocks do not fit (at most 480 per launch: riders and the mode kernel's own
+    // workgroup should not have to share a compute unit).
+    struct FbRidePlan { bool on = false; int seg = 12, R = 0, C = 0, k_rows = 0, rows_per = 0, cols_per = 0; FbStack rows[2], cols[2]; };
+    FbRidePlan fbp;
+    bool fb_rode = false;
+    void plan_fb_ride(bool rg) {
+        fbp = FbRidePlan();
+        if (strict || rg || !cfg.fb_smooth || !cfg.optimize_depth || n_flows < 2 || !debug_switches().fb_ride) return;
+        ImageSet& S = c->od;
+        if (!S.rig2.p) return;
+        struct { const float* src; float* dst; int n; } stacks[2] = { { S.rig.as<float>(), S.rig2.as<float>(), n_flows }, { S.confs.as<float>(), S.confs.as<float>(), n_dp } };
+        int seg = 0;
+        for (int j = 0; j < 2; j++) {
+            if (stacks[j].n <= 0) continue;
+            int rs = 0, cs = 0;
+            bool segmented = false;
+            fb_smooth_plan_segments(w, h, stacks[j].n, &rs, &cs, &segmented);
+            if (!segmented || rs != cs || (rs != 12 && rs != 20) || (seg && seg != rs)) return;
+            seg = rs;
+        }
+        const int Sr = (w + seg - 1) / seg, Sc = (h + seg - 1) / seg;
+        if (Sr > 256 || Sc > 256) return;
+        const int lpb = 256 / Sr, CW = std::min(16, 256 / Sc);
+        FbRidePlan q;
+        for (int j = 0; j < 2; j++) {
+            if (stacks[j].n <= 0) continue;
+            FbStack& r = q.rows[j];
+            r.src = stacks[j].src; r.dst = stacks[j].dst; r.n_maps = stacks[j].n; r.S = Sr; r.blocks_x = (h + lpb - 1) / lpb;
+            r.vec4 = ((w % 4) == 0 && (reinterpret_cast<uintptr_t>(r.src) % 16) == 0 && (reinterpret_cast<uintptr_t>(r.dst) % 16) == 0) ? 1 : 0;
+            r.n_blocks = r.blocks_x * r.n_maps;
+            FbStack& k = q.cols[j];
+            k.src = stacks[j].dst; k.dst = stacks[j].dst; k.n_maps = stacks[j].n; k.S = Sc; k.CW = CW; k.blocks_x = (w + CW - 1) / CW;
+            k.n_blocks = k.blocks_x * k.n_maps;
+            q.R += r.n_blocks; q.C += k.n_blocks;
+        }
+        // the first k_rows mode kernels carry the row blocks, the others the column blocks: the split with the lightest heaviest launch
+        const int cap = 480;
+        int best = -1, best_load = 1 << 30;
+        for (int k = 1; k < n_flows; k++) {
+            const int load = std::max((q.R + k - 1) / k, (q.C + (n_flows - k) - 1) / (n_flows - k));
+            if (load < best_load) { best_load = load; best = k; }
+        }
+        if (best < 0 || best_load > cap) return;
+        q.k_rows = best; q.rows_per = (q.R + best - 1) / best; q.cols_per = (q.C + (n_flows - best) - 1) / (n_flows - best);
+        q.seg = seg; q.on = true;
+        fbp = q;
+    }
+    FbRide ride_of_camera(int i) const {
+        FbRide r;
+        if (!fbp.on) return r;
+        r.seg = fbp.seg; r.w = w; r.h = h; r.e0 = cfg.fb_emm; r.p = cfg.fb_no_change_prob;
+        const bool rows = i < fbp.k_rows;
+        const int per = rows ? fbp.rows_per : fbp.cols_per, total = rows ? fbp.R : fbp.C;
+        r.first = (rows ? i : i - fbp.k_rows) * per;
+        r.count = std::max(0, std::min(per, total - r.first));
+        r.kind = r.count > 0 ? (rows ? 1 : 2) : 0;
+        for (int j = 0; j < 2; j++) r.st[j] = rows ? fbp.rows[j] : fbp.cols[j];
+        if (i == n_flows - 1) { r.cum_N = n_flows; r.cum_Ndp = n_dp; r.world_scale = (cfg.norm_world_scale && n_dp == 0) ? world_scale_ptr() : nullptr; }
+        return r;
+    }
     int enqueue_cameras() {
         const bool rg = cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0);
+        plan_fb_ride(rg);
         for (int i = 0; i < n_flows; i++) {
             if (int e = upload_frames_up_to(i + 1)) return e;  // (first EM iteration of a host-memory call: frame i arrives while camera i - 1 runs)
-            if (int e = optimize_camera_pose(i, rg, i == n_flows - 1)) return e;
+            const FbRide ride = ride_of_camera(i);
+            if (int e = optimize_camera_pose(i, rg, i == n_flows - 1, fbp.on ? &ride : nullptr)) return e;
         }
+        if (fbp.on) { std::swap(c->od.rig, c->od.rig2); fb_rode = true; }  // the smoothed maps are `rig` from here on
         if (int e = upload_frames_up_to(n_flows_init)) return e;
         // rigidness densities (reduced on the device by the last optimize_depth, voldor.cpp:171) and results: the last camera's kernel
         // has stored what the host needs into pinned memory (CamBrief); the event marks it complete
