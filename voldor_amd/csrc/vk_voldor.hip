@@ -111,6 +111,11 @@ struct Config {
 
 enum OdFlag { OD_DEFAULT = 0, OD_ONLY_USE_DEPTH_PRIOR = 1, OD_UPDATE_RIGIDNESS_ONLY = 2 };  // voldor.h:7-11
 
+// false in a worker of a batch that keeps several windows in flight (WindowPool): the compute units a mode kernel leaves idle are then busy with the other
+// windows' kernels, and fb_smooth as riders (one 512-thread workgroup per compute unit at the mode kernel's 256 registers) costs the batch more than
+// its own launches do (four cfg2 windows in flight: 656 -> 627 windows/s with riders)
+static thread_local bool g_window_alone = true;
+
 struct Voldor {
     Context* c = nullptr;
     Config cfg;
@@ -294,7 +299,7 @@ struct Voldor {
     bool fb_rode = false;
     void plan_fb_ride(bool rg) {
         fbp = FbRidePlan();
-        if (strict || rg || !cfg.fb_smooth || !cfg.optimize_depth || n_flows < 2 || !debug_switches().fb_ride) return;
+        if (strict || rg || !cfg.fb_smooth || !cfg.optimize_depth || n_flows < 2 || !debug_switches().fb_ride || !g_window_alone) return;
         ImageSet& S = c->od;
         if (!S.rig2.p) return;
         struct { const float* src; float* dst; int n; } stacks[2] = { { S.rig.as<float>(), S.rig2.as<float>(), n_flows }, { S.confs.as<float>(), S.confs.as<float>(), n_dp } };
@@ -487,6 +492,7 @@ struct BatchJob {
 class WindowPool {  // persistent workers: worker i owns pool context i of the device it was started on
     std::mutex mu, run_mu; std::condition_variable cv_work, cv_done;  // run_mu: one batch at a time per device (callers queue)
     std::vector<std::thread> workers; std::vector<BatchJob>* jobs = nullptr; size_t next = 0; int pending = 0, device = 0; bool stop = false;
+    int cur_in_flight = 1;  // workers the current batch keeps busy
     void loop(int i) {
         (void)hipSetDevice(device);
         for (;;) {
@@ -500,6 +506,7 @@ class WindowPool {  // persistent workers: worker i owns pool context i of the d
             // every window of a batch starts from the batch's epoch, whichever worker / context picks it up: the result of a
             // window does not depend on how the batch was scheduled
             if (Context* pc = pool_context(i)) { pc->rand_epoch = j->epoch0; pc->rand_w = pc->rand_h = -1; }
+            g_window_alone = cur_in_flight <= 1;
             j->rc = voldor_run_on(pool_context(i), j->flows, j->disparity, j->disparity_pconf, j->depth_priors, j->depth_prior_poses,
                                   j->depth_prior_pconfs, j->fx, j->fy, j->cx, j->cy, j->basefocal, j->N, j->N_dp, j->w, j->h, j->config,
                                   j->n_registered, j->poses, j->poses_covar, j->depth, j->depth_conf);
@@ -516,7 +523,7 @@ public:
         const size_t want = std::min(js.size(), (size_t)std::max(1, width));
         while (workers.size() < want) { const int i = (int)workers.size(); workers.emplace_back([this, i] { loop(i); }); }
         // more workers than `width` may exist from an earlier, wider call: they simply take windows too (each has its own context)
-        jobs = &js; next = 0; pending = (int)js.size();
+        jobs = &js; next = 0; pending = (int)js.size(); cur_in_flight = (int)std::min(js.size(), std::max(want, workers.size()));
         cv_work.notify_all();
         cv_done.wait(lk, [&] { return pending == 0; });
     }
