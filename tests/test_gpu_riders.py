@@ -1,0 +1,72 @@
+"""Work that rides in another kernel's launch (round 5): the 256-thread blocks of fb_smooth in the mode kernels of the pose half (FbRide,
+voldor_amd/csrc/vk_common.hpp; vk_debug_switch "fb_ride") and the density reduction of an E-step in the next correspondence trace
+(OdParams::defer_reduce; "defer_reduce").  Both move work between launches, not arithmetic: every output bit of a window must be that of the plain
+launch chain -- windows with 1, 2, 5 and 8 cameras (how the row and column blocks fall onto the mode kernels), with depth priors (a second stack of
+maps), ragged sizes, a refit in every iteration (nothing rides in a refit kernel), a window that truncates half way, device-resident inputs, and two
+windows in a row on one context (the maps change names after every pose half)."""
+import numpy as np
+import pytest
+
+import hooks
+
+pytestmark = pytest.mark.gpu
+
+MONO = "--silent --meanshift_kernel_var 0.2 --delta 1.5 --max_iters 4"
+STEREO = "--silent --meanshift_kernel_var 0.1 --disp_delta 1 --delta 0.2 --max_iters 4"
+CASES = {
+    "five_cameras": dict(w=320, h=240, n=5, cfg=MONO),
+    "two_cameras": dict(w=320, h=240, n=2, cfg=MONO),
+    "one_camera": dict(w=200, h=160, n=1, cfg=MONO),
+    "eight_cameras_with_prior": dict(w=411, h=203, n=8, cfg=STEREO, basefocal=40.0),
+    "ragged_size": dict(w=333, h=171, n=4, cfg=MONO),
+    "refit_in_every_iteration": dict(w=320, h=240, n=4, cfg=MONO + " --rg_refine_last_only 0"),
+    "no_fb_smooth": dict(w=320, h=240, n=4, cfg=MONO + " --fb_smooth 0"),
+    "truncates": dict(w=160, h=120, n=5, cfg=MONO + " --max_iters 6", noise_from=3),
+}
+
+
+def _run(case, switches, device):
+    import torch
+    from voldor_amd import kernels, pyvoldor, synth
+    c = CASES[case]
+    bf = c.get("basefocal", 0.0)
+    sc = synth.make_scene(w=c["w"], h=c["h"], n_flows=c["n"], fx=c["w"] / 2, fy=c["w"] / 2, cx=c["w"] / 2, cy=c["h"] / 2, seed=241, basefocal=bf)
+    flows = sc["flows"].copy()
+    if "noise_from" in c:
+        flows[c["noise_from"]:] = np.random.default_rng(0).uniform(-40, 40, flows[c["noise_from"]:].shape).astype(np.float32)
+    fx, fy, cx, cy = sc["K"]
+    prev = {k: hooks.debug_switch(k, v) for k, v in switches.items()}
+    try:
+        outs = []
+        for _ in range(2):  # two windows in a row on one context
+            kernels.set_rand_epoch(0)
+            if device:
+                depth = torch.empty(c["h"], c["w"], device="cuda"); conf = torch.empty_like(depth)
+                kw = dict(basefocal=bf, disparity=torch.from_numpy(sc["disparity"]).cuda()) if bf else {}
+                o = pyvoldor.voldor_device(torch.from_numpy(flows).cuda(), fx, fy, cx, cy, config=c["cfg"], depth_out=depth, depth_conf_out=conf, **kw)
+                o = dict(o, depth=depth.cpu().numpy(), depth_conf=conf.cpu().numpy())
+            else:
+                kw = dict(basefocal=bf, disparity=sc["disparity"]) if bf else {}
+                o = pyvoldor.voldor(flows, fx, fy, cx, cy, config=c["cfg"], **kw)
+            outs.append(o)
+    finally:
+        for k, v in prev.items():
+            hooks.debug_switch(k, v)
+    return outs
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+@pytest.mark.parametrize("device", [False, True])
+def test_riding_work_changes_no_bit_of_a_window(case, device):
+    plain = _run(case, {"fb_ride": 0, "defer_reduce": 0}, device)
+    riding = _run(case, {"fb_ride": 1, "defer_reduce": 1}, device)
+    if case == "truncates":
+        assert plain[0]["n_registered"] < CASES[case]["n"]
+    for a, b in zip(plain, riding):
+        assert a["n_registered"] == b["n_registered"]
+        for k in ("depth", "depth_conf", "poses", "poses_covar"):
+            x, y = np.ascontiguousarray(a[k], np.float32), np.ascontiguousarray(b[k], np.float32)
+            np.testing.assert_array_equal(x.view(np.uint32), y.view(np.uint32), err_msg=f"{case}: {k}")
+    # and the two windows of a run are one window twice
+    for k in ("depth", "poses"):
+        np.testing.assert_array_equal(np.asarray(riding[0][k], np.float32).view(np.uint32), np.asarray(riding[1][k], np.float32).view(np.uint32))
