@@ -31,6 +31,10 @@ int vk_debug_switch(const char* name, int value);
 /* Counters, read and cleared: "strict_coop_fallbacks" = cameras (default context) whose cooperative strict mode kernel gave up a meeting and were
  * computed by the single-workgroup kernel launched behind it.  -1: unknown name / device error. */
 int vk_debug_counter(const char* name);
+/* How the 256-thread blocks of a riding fb_smooth (FbRide, vk_common.hpp) would be dealt over the mode kernels of a window with this geometry -- host
+ * arithmetic only, no device.  out: [riding 0 | 1, steps per lane, row blocks R, column blocks C, launches that carry rows, then per camera: kind
+ * (0 nothing, 1 rows, 2 columns), first block, blocks].  Returns the ints written (5 + 3 n_flows), -1 when out is too short. */
+int vk_debug_fb_ride_plan(int w, int h, int n_flows, int n_dp, int* out, int n_out);
 /* The mode kernel of the window pipeline (k_pose_mode: packed-pair mean shift; with do_rg the robust-Gaussian refit on the same registers --
  * geometry.cpp:156-263, meanshift.cu:34-150, fit_robust_gaussian.cu:131-263) on a caller-supplied pool of pose hypotheses, so that the kernels
  * of the timed path can be held against the oracle stage by stage.  h_rvecs / h_tvecs: [n_poses][3], n_poses <= 8192, a non-finite

@@ -116,6 +116,63 @@ enum OdFlag { OD_DEFAULT = 0, OD_ONLY_USE_DEPTH_PRIOR = 1, OD_UPDATE_RIGIDNESS_O
 // its own launches do (four cfg2 windows in flight: 656 -> 627 windows/s with riders)
 static thread_local bool g_window_alone = true;
 
+// How the blocks of a riding fb_smooth fall onto the mode kernels of an EM iteration's cameras (FbRide, vk_common.hpp; Voldor::plan_fb_ride has the
+// story).  Pure arithmetic on the window's geometry -- held to its invariants on the CPU through vk_debug_fb_ride_plan (tests/test_fb_ride_plan.py):
+// every block of the row pass in exactly one launch, then every block of the column pass, no launch with more than 480 blocks.
+struct FbRidePlan { bool on = false; int seg = 12, R = 0, C = 0, k_rows = 0, rows_per = 0, cols_per = 0; FbStack rows[2], cols[2]; };
+static void fb_ride_plan(int w, int h, int n_flows, int n_dp, const float* rig, float* rig2, float* confs, FbRidePlan* out) {
+    *out = FbRidePlan();
+    if (n_flows < 2) return;
+    struct { const float* src; float* dst; int n; } stacks[2] = { { rig, rig2, n_flows }, { confs, confs, n_dp } };
+    int seg = 0;
+    for (int j = 0; j < 2; j++) {
+        if (stacks[j].n <= 0) continue;
+        int rs = 0, cs = 0;
+        bool segmented = false;
+        fb_smooth_plan_segments(w, h, stacks[j].n, &rs, &cs, &segmented);
+        if (!segmented || rs != cs || (rs != 12 && rs != 20) || (seg && seg != rs)) return;
+        seg = rs;
+    }
+    const int Sr = (w + seg - 1) / seg, Sc = (h + seg - 1) / seg;
+    if (Sr > 256 || Sc > 256) return;
+    const int lpb = 256 / Sr, CW = std::min(16, 256 / Sc);
+    FbRidePlan q;
+    for (int j = 0; j < 2; j++) {
+        if (stacks[j].n <= 0) continue;
+        FbStack& r = q.rows[j];
+        r.src = stacks[j].src; r.dst = stacks[j].dst; r.n_maps = stacks[j].n; r.S = Sr; r.blocks_x = (h + lpb - 1) / lpb;
+        r.vec4 = ((w % 4) == 0 && (reinterpret_cast<uintptr_t>(r.src) % 16) == 0 && (reinterpret_cast<uintptr_t>(r.dst) % 16) == 0) ? 1 : 0;
+        r.n_blocks = r.blocks_x * r.n_maps;
+        FbStack& k = q.cols[j];
+        k.src = stacks[j].dst; k.dst = stacks[j].dst; k.n_maps = stacks[j].n; k.S = Sc; k.CW = CW; k.blocks_x = (w + CW - 1) / CW;
+        k.n_blocks = k.blocks_x * k.n_maps;
+        q.R += r.n_blocks; q.C += k.n_blocks;
+    }
+    // the first k_rows mode kernels carry the row blocks, the others the column blocks: the split with the lightest heaviest launch
+    const int cap = 480;
+    int best = -1, best_load = 1 << 30;
+    for (int k = 1; k < n_flows; k++) {
+        const int load = std::max((q.R + k - 1) / k, (q.C + (n_flows - k) - 1) / (n_flows - k));
+        if (load < best_load) { best_load = load; best = k; }
+    }
+    if (best < 0 || best_load > cap) return;
+    q.k_rows = best; q.rows_per = (q.R + best - 1) / best; q.cols_per = (q.C + (n_flows - best) - 1) / (n_flows - best);
+    q.seg = seg; q.on = true;
+    *out = q;
+}
+static FbRide fb_ride_of_camera(const FbRidePlan& P, int i, int n_flows, int w, int h, float e0, float p) {
+    FbRide r;
+    if (!P.on) return r;
+    r.seg = P.seg; r.w = w; r.h = h; r.e0 = e0; r.p = p;
+    const bool rows = i < P.k_rows;
+    const int per = rows ? P.rows_per : P.cols_per, total = rows ? P.R : P.C;
+    r.first = (rows ? i : i - P.k_rows) * per;
+    r.count = std::max(0, std::min(per, total - r.first));
+    r.kind = r.count > 0 ? (rows ? 1 : 2) : 0;
+    for (int j = 0; j < 2; j++) r.st[j] = rows ? P.rows[j] : P.cols[j];
+    return r;
+}
+
 struct Voldor {
     Context* c = nullptr;
     Config cfg;
@@ -294,62 +351,18 @@ struct Voldor {
     // Not in strict mode, not in an iteration with the refit (that kernel's LDS leaves no room), not where a pass needs 40-step segments (1080p: there
     // fb_smooth is 110 us of memory pass, not launch latency), not when the blocks do not fit (at most 480 per launch: riders and the mode kernel's own
     // workgroup should not have to share a compute unit).
-    struct FbRidePlan { bool on = false; int seg = 12, R = 0, C = 0, k_rows = 0, rows_per = 0, cols_per = 0; FbStack rows[2], cols[2]; };
     FbRidePlan fbp;
     bool fb_rode = false;
     void plan_fb_ride(bool rg) {
         fbp = FbRidePlan();
-        if (strict || rg || !cfg.fb_smooth || !cfg.optimize_depth || n_flows < 2 || !debug_switches().fb_ride || !g_window_alone) return;
+        if (strict || rg || !cfg.fb_smooth || !cfg.optimize_depth || !debug_switches().fb_ride || !g_window_alone) return;
         ImageSet& S = c->od;
         if (!S.rig2.p) return;
-        struct { const float* src; float* dst; int n; } stacks[2] = { { S.rig.as<float>(), S.rig2.as<float>(), n_flows }, { S.confs.as<float>(), S.confs.as<float>(), n_dp } };
-        int seg = 0;
-        for (int j = 0; j < 2; j++) {
-            if (stacks[j].n <= 0) continue;
-            int rs = 0, cs = 0;
-            bool segmented = false;
-            fb_smooth_plan_segments(w, h, stacks[j].n, &rs, &cs, &segmented);
-            if (!segmented || rs != cs || (rs != 12 && rs != 20) || (seg && seg != rs)) return;
-            seg = rs;
-        }
-        const int Sr = (w + seg - 1) / seg, Sc = (h + seg - 1) / seg;
-        if (Sr > 256 || Sc > 256) return;
-        const int lpb = 256 / Sr, CW = std::min(16, 256 / Sc);
-        FbRidePlan q;
-        for (int j = 0; j < 2; j++) {
-            if (stacks[j].n <= 0) continue;
-            FbStack& r = q.rows[j];
-            r.src = stacks[j].src; r.dst = stacks[j].dst; r.n_maps = stacks[j].n; r.S = Sr; r.blocks_x = (h + lpb - 1) / lpb;
-            r.vec4 = ((w % 4) == 0 && (reinterpret_cast<uintptr_t>(r.src) % 16) == 0 && (reinterpret_cast<uintptr_t>(r.dst) % 16) == 0) ? 1 : 0;
-            r.n_blocks = r.blocks_x * r.n_maps;
-            FbStack& k = q.cols[j];
-            k.src = stacks[j].dst; k.dst = stacks[j].dst; k.n_maps = stacks[j].n; k.S = Sc; k.CW = CW; k.blocks_x = (w + CW - 1) / CW;
-            k.n_blocks = k.blocks_x * k.n_maps;
-            q.R += r.n_blocks; q.C += k.n_blocks;
-        }
-        // the first k_rows mode kernels carry the row blocks, the others the column blocks: the split with the lightest heaviest launch
-        const int cap = 480;
-        int best = -1, best_load = 1 << 30;
-        for (int k = 1; k < n_flows; k++) {
-            const int load = std::max((q.R + k - 1) / k, (q.C + (n_flows - k) - 1) / (n_flows - k));
-            if (load < best_load) { best_load = load; best = k; }
-        }
-        if (best < 0 || best_load > cap) return;
-        q.k_rows = best; q.rows_per = (q.R + best - 1) / best; q.cols_per = (q.C + (n_flows - best) - 1) / (n_flows - best);
-        q.seg = seg; q.on = true;
-        fbp = q;
+        fb_ride_plan(w, h, n_flows, n_dp, S.rig.as<float>(), S.rig2.as<float>(), S.confs.as<float>(), &fbp);
     }
     FbRide ride_of_camera(int i) const {
-        FbRide r;
-        if (!fbp.on) return r;
-        r.seg = fbp.seg; r.w = w; r.h = h; r.e0 = cfg.fb_emm; r.p = cfg.fb_no_change_prob;
-        const bool rows = i < fbp.k_rows;
-        const int per = rows ? fbp.rows_per : fbp.cols_per, total = rows ? fbp.R : fbp.C;
-        r.first = (rows ? i : i - fbp.k_rows) * per;
-        r.count = std::max(0, std::min(per, total - r.first));
-        r.kind = r.count > 0 ? (rows ? 1 : 2) : 0;
-        for (int j = 0; j < 2; j++) r.st[j] = rows ? fbp.rows[j] : fbp.cols[j];
-        if (i == n_flows - 1) { r.cum_N = n_flows; r.cum_Ndp = n_dp; r.world_scale = (cfg.norm_world_scale && n_dp == 0) ? world_scale_ptr() : nullptr; }
+        FbRide r = fb_ride_of_camera(fbp, i, n_flows, w, h, cfg.fb_emm, cfg.fb_no_change_prob);
+        if (fbp.on && i == n_flows - 1) { r.cum_N = n_flows; r.cum_Ndp = n_dp; r.world_scale = (cfg.norm_world_scale && n_dp == 0) ? world_scale_ptr() : nullptr; }
         return r;
     }
     int enqueue_cameras() {
@@ -609,4 +622,19 @@ int vk_last_camera_stats(int* pose_sample_count, float* pose_density, float* pos
     }
     return 0;
 }
+}
+
+// vk_debug.h: the dealing of a riding fb_smooth for a window geometry, no device involved.  out: [on, seg, R, C, k_rows, then per camera kind, first,
+// count]; returns the number of ints written (5 + 3 n_flows), -1 when `out` is too short
+extern "C" __attribute__((visibility("default"))) int vk_debug_fb_ride_plan(int w, int h, int n_flows, int n_dp, int* out, int n_out) {
+    if (n_flows < 0 || n_flows > vk::MAX_FRAMES || n_out < 5 + 3 * n_flows) return -1;
+    vk::FbRidePlan P;
+    alignas(16) static float dummy[4];
+    vk::fb_ride_plan(w, h, n_flows, n_dp, dummy, dummy, dummy, &P);
+    out[0] = P.on ? 1 : 0; out[1] = P.seg; out[2] = P.R; out[3] = P.C; out[4] = P.k_rows;
+    for (int i = 0; i < n_flows; i++) {
+        const vk::FbRide r = vk::fb_ride_of_camera(P, i, n_flows, w, h, 0.5f, 0.9f);
+        out[5 + 3 * i] = r.kind; out[6 + 3 * i] = r.first; out[7 + 3 * i] = r.count;
+    }
+    return 5 + 3 * n_flows;
 }
