@@ -213,6 +213,33 @@ def test_window_with_xorwow_and_texture_filter_equals_the_reference(name):
         assert (_bits(o2["depth"]) != _bits(o["depth"])).any(), only
 
 
+@pytest.mark.parametrize("name", ["mono_nonexclusive", "stereo_default"])
+def test_texture_filter_window_does_not_read_flow_layers_that_are_not_up_yet(name):
+    """host-resident flows go up frame by frame, each right before its first reader.  CUDA's linear filter over the STACK of layers
+    (`--reference_tex 1`) blends the bottom row of layer i with the top row of layer i + 1, so camera i's trace reads one layer more than the fast
+    path's -- the staggered upload has to be one frame ahead there.  The device copy of the flows is poisoned by a window of NaN flows of the same
+    geometry on the same context; a reader that is ahead of its upload then sees NaNs (or the stale window) and the bits move."""
+    from voldor_amd import kernels, pyvoldor
+    if not os.path.exists(CUDA_GOLD):
+        pytest.skip("tests/golden/ref_window_cuda.npz not generated")
+    g = np.load(CUDA_GOLD)
+    c = dict(CASES)[name]
+    fx, fy, cx, cy = c["K"]
+    kw = dict(basefocal=c["basefocal"], disparity=c["disparity"], depth_priors=c["depth_priors"], depth_prior_poses=c["depth_prior_poses"],
+              depth_prior_pconfs=c["depth_prior_pconfs"])
+    for _ in range(3):
+        kernels.set_rand_epoch(0)
+        try:
+            pyvoldor.voldor(np.full_like(c["flows"], np.nan), fx, fy, cx, cy, config=c["config"] + CUDA_MODE, **kw)  # leaves NaN layers on the device
+        except Exception:
+            pass  # (whatever the window makes of NaN flows: the layers are up)
+        kernels.set_rand_epoch(0)
+        o = pyvoldor.voldor(c["flows"], fx, fy, cx, cy, config=c["config"] + CUDA_MODE, **kw)
+        assert o["n_registered"] == int(g[f"{name}/n_registered"])
+        for k in ("depth", "depth_conf", "poses", "poses_covar"):
+            assert not (_bits(o[k]) != _bits(g[f"{name}/{k}"])).any(), k
+
+
 DEFAULT_GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_window_default.npz")
 
 

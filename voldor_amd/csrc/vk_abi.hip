@@ -22,6 +22,8 @@ int Context::init(int dev) {
     VK_CHECK(hipEventCreate(&ev2));
     VK_CHECK(hipEventCreate(&ev3));
     VK_CHECK(hipEventCreateWithFlags(&ev_cams, hipEventDisableTiming));
+    VK_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    for (int f = 0; f < MAX_FRAMES; f++) VK_CHECK(hipEventCreateWithFlags(&ev_frame[f], hipEventDisableTiming));
     VK_CHECK(hipHostMalloc((void**)&h_cams, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
     VK_CHECK(hipHostMalloc((void**)&h_pb, sizeof(PoseBlock), hipHostMallocDefault));
     VK_CHECK(hipHostMalloc((void**)&h_cams_up, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
@@ -40,6 +42,9 @@ void Context::destroy() {
     if (ev2) (void)hipEventDestroy(ev2);
     if (ev3) (void)hipEventDestroy(ev3);
     if (ev_cams) (void)hipEventDestroy(ev_cams);
+    for (int f = 0; f < MAX_FRAMES; f++) { if (ev_frame[f]) (void)hipEventDestroy(ev_frame[f]); ev_frame[f] = nullptr; }
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    copy_stream = nullptr;
     if (h_cams) (void)hipHostFree(h_cams);
     if (h_brief) (void)hipHostFree(h_brief);
     if (h_pb) (void)hipHostFree(h_pb);
@@ -408,6 +413,8 @@ extern "C" __attribute__((visibility("default"))) int vk_debug_counter(const cha
     vk::Context* c = vk::default_context();
     if (!c) return -1;
     if (strcmp(name, "strict_coop_fallbacks") == 0) return vk::strict_coop_fallbacks(c);
+    if (strcmp(name, "fb_blocks_rode") == 0) { const long v = c->dbg_fb_blocks_rode; c->dbg_fb_blocks_rode = 0; return (int)v; }
+    if (strcmp(name, "reduces_rode") == 0) { const long v = c->dbg_reduces_rode; c->dbg_reduces_rode = 0; return (int)v; }
     return -1;
 }
 extern "C" __attribute__((visibility("default"))) int vk_debug_switch(const char* name, int value) {

@@ -193,6 +193,7 @@ struct Context {
     // collect_p3p_instances.cu statics); the B-outer pipeline uses `od` for everything.
     ImageSet od, cp;
     DevBuf rig_partial;           // per-block rigidness sums -> pose_rigidness_density
+    long dbg_fb_blocks_rode = 0, dbg_reduces_rode = 0;  // verification counters (vk_debug_counter): fb_smooth blocks / density reductions that rode in another kernel's launch
     ReduceArgs pending_reduce;    // window pipeline, fast mode: the density reduction of the last E-step, left for the next correspondence trace (partial != NULL: pending)
     DevBuf local_tbl;             // [h][w] candidate-cost table of a local propagation pass
     DevBuf p2_map, p3_map;        // [h*w][2], [h*w][3] (collect_p3p_instances.cu:27-34)
@@ -223,6 +224,10 @@ struct Context {
     std::map<std::string, ProfEntry> prof_acc;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;  // outer / inner scope
     hipEvent_t ev_cams = nullptr;  // "camera records of this EM iteration are on the host"
+    // host-resident flows of a window go up frame by frame on their own non-blocking stream (no legacy null stream: a blocking hipMemcpy there would
+    // synchronise with every blocking stream of the process); ev_frame[f] = "frame f is on the device", waited for by `stream` before its first reader
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_frame[MAX_FRAMES] = {};
     PoseBlock* h_pb = nullptr;     // pinned staging of the per-window uploads (pose block, camera records): no host sync before the first launch
     CamState* h_cams_up = nullptr;
     CamBrief* h_brief = nullptr;   // pinned, written by the device (CamBrief above); h_brief_dev = its device address

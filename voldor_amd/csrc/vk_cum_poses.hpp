@@ -49,9 +49,9 @@ __device__ __forceinline__ static void reduce_density_block(int f, const ReduceA
 __device__ __forceinline__ static void cum_poses_block(PoseBlock* P, int N, int N_dp, float* world_scale) {
     __shared__ double Rc[9], tc[3];
     __shared__ float sR[MAX_FRAMES][9], sT[MAX_FRAMES][3];  // one round trip to the pose block instead of one per frame of the chain
-    const int l = threadIdx.x;
-    for (int i = l; i < N * 9; i += 64) sR[i / 9][i % 9] = P->Rs[i / 9][i % 9];
-    for (int i = l; i < N * 3; i += 64) sT[i / 3][i % 3] = P->ts[i / 3][i % 3];
+    const int l = threadIdx.x, nt = blockDim.x;  // any workgroup size (its own launch: 64; riding in the 512-thread mode kernel: every element once)
+    for (int i = l; i < N * 9; i += nt) sR[i / 9][i % 9] = P->Rs[i / 9][i % 9];
+    for (int i = l; i < N * 3; i += nt) sT[i / 3][i % 3] = P->ts[i / 3][i % 3];
     const double fx = P->K4[0], cx = P->K4[1], fy = P->K4[2], cy = P->K4[3];
     __syncthreads();
     auto emit = [&](const double* R, const double* t, float* M, float* T) {  // K R K^-1 and K t

@@ -29,7 +29,9 @@ extern "C" {
  * Returns the previous value, -1 for an unknown name / value. */
 int vk_debug_switch(const char* name, int value);
 /* Counters, read and cleared: "strict_coop_fallbacks" = cameras (default context) whose cooperative strict mode kernel gave up a meeting and were
- * computed by the single-workgroup kernel launched behind it.  -1: unknown name / device error. */
+ * computed by the single-workgroup kernel launched behind it; "fb_blocks_rode" = 256-thread fb_smooth blocks the window pipeline (default context) put
+ * into mode-kernel launches instead of launches of their own (FbRide); "reduces_rode" = density reductions it attached to a correspondence trace
+ * (OdParams::defer_reduce) -- counted on the host where the launch is built.  -1: unknown name / device error. */
 int vk_debug_counter(const char* name);
 /* How the 256-thread blocks of a riding fb_smooth (FbRide, vk_common.hpp) would be dealt over the mode kernels of a window with this geometry -- host
  * arithmetic only, no device.  out: [riding 0 | 1, steps per lane, row blocks R, column blocks C, launches that carry rows, then per camera: kind

@@ -1436,7 +1436,7 @@ __device__ __forceinline__ void mode_fb_ride(const FbRide& R, int q) {
     const int bx = in ? b % J->blocks_x : (1 << 20), by = in ? b / J->blocks_x : 0;
     FbMat* sF = &s_fb[half][0][0]; FbMat* sB = &s_fb[half][2][0];
     if (R.kind == 1) {
-        if (J->vec4) fb_rows_body<true, SEG>(J->src, J->dst, R.w, R.h, J->S, R.e0, R.p, bx, by, sF, sB, tid);
+        if (R.st[0].vec4) fb_rows_body<true, SEG>(J->src, J->dst, R.w, R.h, J->S, R.e0, R.p, bx, by, sF, sB, tid);
         else fb_rows_body<false, SEG>(J->src, J->dst, R.w, R.h, J->S, R.e0, R.p, bx, by, sF, sB, tid);
     } else fb_cols_body<SEG>(J->dst, R.w, R.h, J->S, J->CW, R.e0, R.p, bx, by, sF, sB, tid);
 }
@@ -1606,7 +1606,7 @@ int collect_device(Context* c, const ImageSet& S, int N, int w, int h, int activ
     ReduceArgs ra;
     int extra = 0;
     if (c->pending_reduce.partial) {
-        if (active_idx == 0) { ra = c->pending_reduce; ra.n_px_blocks = nblk; extra = ra.n_launch + (ra.scale_out ? 1 : 0); c->pending_reduce = ReduceArgs(); }
+        if (active_idx == 0) { ra = c->pending_reduce; ra.n_px_blocks = nblk; extra = ra.n_launch + (ra.scale_out ? 1 : 0); c->pending_reduce = ReduceArgs(); c->dbg_reduces_rode++; }
         else if (int e = flush_pending_reduce(c)) return e;
     }
     if (block_compact)
@@ -1723,6 +1723,7 @@ int pose_mode_device(Context* c, int n_poses, const ModeParams& mp_in, CamState*
     if (ride_in) ride = *ride_in;
     if (mp.do_rg && (ride.kind != 0 || ride.cum_N >= 0)) return (int)hipErrorInvalidValue;  // (the refit kernel carries nothing: 141 KB of LDS)
     const int n_riders = ride.kind ? (ride.count + 1) / 2 : 0;
+    if (ride.kind) c->dbg_fb_blocks_rode += ride.count;
     mp.rg_partition = debug_switches().refit_partition;
     if (n_poses > PM_POOL) {
         fprintf(stderr, "voldor_hip: n_poses_to_sample=%d exceeds the %d hypotheses the mode kernel keeps in registers\n", n_poses,

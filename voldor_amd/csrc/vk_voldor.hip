@@ -148,6 +148,8 @@ static void fb_ride_plan(int w, int h, int n_flows, int n_dp, const float* rig, 
         k.n_blocks = k.blocks_x * k.n_maps;
         q.R += r.n_blocks; q.C += k.n_blocks;
     }
+    // the two 256-thread halves of a riding workgroup may hold blocks of different stacks: ONE access form for both (workgroup-uniform barriers)
+    { const int v = (stacks[0].n > 0 ? q.rows[0].vec4 : 1) & (stacks[1].n > 0 ? q.rows[1].vec4 : 1); q.rows[0].vec4 = q.rows[1].vec4 = v; }
     // the first k_rows mode kernels carry the row blocks, the others the column blocks: the split with the lightest heaviest launch
     const int cap = 480;
     int best = -1, best_load = 1 << 30;
@@ -183,13 +185,21 @@ struct Voldor {
     CamState* dcams() { return c->cams.as<CamState>(); }
     const float* host_flows = nullptr;  // flows still (partly) in host memory: frames [frames_up, n_flows_init) are not on the device yet
     int frames_up = 0;
-    // frames 0 .. upto - 1 of host-resident flows are on the device when this returns (synchronous copies outside the window's stream: the kernels
-    // already enqueued there run meanwhile)
+    // frames 0 .. upto - 1 of host-resident flows are on their way when this returns: copied on the context's own non-blocking copy stream (the
+    // kernels already enqueued on the window's stream run meanwhile), and the window's stream waits for "frame f is up" before whatever is
+    // enqueued next.  No legacy null stream (a blocking hipMemcpy there synchronises with every blocking stream of the process and
+    // relies on the copy being complete at return).  The caller's buffer is read until the events have fired: every exit of voldor_run_on
+    // drains the copy stream (WindowGuard).
+    bool copies_in_flight = false;
     int upload_frames_up_to(int upto) {
         if (!host_flows) return 0;
         const size_t fb = sizeof(float) * 2 * (size_t)w * h;
-        for (; frames_up < upto && frames_up < n_flows_init; frames_up++)
-            VK_CHECK(hipMemcpy(c->od.flows.as<char>() + (size_t)frames_up * fb, reinterpret_cast<const char*>(host_flows) + (size_t)frames_up * fb, fb, hipMemcpyHostToDevice));
+        for (; frames_up < upto && frames_up < n_flows_init; frames_up++) {
+            VK_CHECK(hipMemcpyAsync(c->od.flows.as<char>() + (size_t)frames_up * fb, reinterpret_cast<const char*>(host_flows) + (size_t)frames_up * fb, fb, hipMemcpyHostToDevice, c->copy_stream));
+            VK_CHECK(hipEventRecord(c->ev_frame[frames_up], c->copy_stream));
+            VK_CHECK(hipStreamWaitEvent(c->stream, c->ev_frame[frames_up], 0));
+            copies_in_flight = true;
+        }
         if (frames_up >= n_flows_init) host_flows = nullptr;
         return 0;
     }
@@ -369,7 +379,9 @@ struct Voldor {
         const bool rg = cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0);
         plan_fb_ride(rg);
         for (int i = 0; i < n_flows; i++) {
-            if (int e = upload_frames_up_to(i + 1)) return e;  // (first EM iteration of a host-memory call: frame i arrives while camera i - 1 runs)
+            // (first EM iteration of a host-memory call: frame i arrives while camera i - 1 runs.  CUDA's linear filter over the STACK of layers
+            // -- --reference_tex 1 -- blends the bottom row of layer i with the top row of layer i + 1 (vk_ref_cuda.h:133-149): one frame more)
+            if (int e = upload_frames_up_to(ref_tex ? i + 2 : i + 1)) return e;
             const FbRide ride = ride_of_camera(i);
             if (int e = optimize_camera_pose(i, rg, i == n_flows - 1, fbp.on ? &ride : nullptr)) return e;
         }
@@ -412,7 +424,7 @@ struct Voldor {
 
     // voldor.cpp:130-149
     int solve() {
-        if (int e = upload_frames_up_to(1)) return e;
+        if (int e = upload_frames_up_to(ref_tex ? 2 : 1)) return e;
         if (n_dp == 0) {  // bootstrap :151-162
             if (c->prof) prof_begin(c);
             if (int e = bootstrap_device(c, c->od, w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, dcams(), strict, cfg.bootstrap_points == 5 ? 5 : 8)) return e;
@@ -453,6 +465,12 @@ static int voldor_run_on(Context* c, const float* flows, const float* disparity,
     Voldor& v = g_last;
     v = Voldor();
     v.c = c;
+    // every exit, the failing ones included: a density reduction left for a trace that will never come must not survive the window (it
+    // holds raw pointers into buffers a later call may re-reserve), and the copy stream must be done with the caller's flow buffer
+    struct WindowGuard {
+        Context* c; Voldor* v;
+        ~WindowGuard() { c->pending_reduce = ReduceArgs(); if (v->copies_in_flight) { (void)hipStreamSynchronize(c->copy_stream); v->copies_in_flight = false; } }
+    } guard{ c, &v };
     v.cfg.fx = fx; v.cfg.cx = cx; v.cfg.fy = fy; v.cfg.cy = cy; v.cfg.basefocal = basefocal;  // py_export.cpp:19-25
     if (int e = v.cfg.read_config(config ? config : "")) return 1000 + e;
     if (int e = v.init(flows, disparity, disparity_pconf, depth_priors, depth_prior_poses, depth_prior_pconfs, N, N_dp, w, h)) return e;
