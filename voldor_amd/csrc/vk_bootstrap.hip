@@ -34,7 +34,10 @@ constexpr int BOOT_HYPS = 256, BOOT_SCORE_MAX = 2048, BOOT_STEP = 4;
 // --bootstrap_points 5: the five-point minimal solver (vk_fivept.hpp), the solver behind the reference's cv::findEssentialMat(.., LMEDS,
 // 0.999, 1.0) (geometry.cpp:316-326).  OpenCV's LMedS draws round(log(1 - 0.999) / log(1 - (1 - 0.45)^5)) = 134 samples; every sample yields up
 // to ten essential matrices and each one is a model of its own (median squared Sampson distance).  192 samples = three waves of lanes.
-constexpr int BOOT5_SAMPLES = 192, BOOT5_MODELS = BOOT5_SAMPLES * 10;
+// five-point LMedS: the number of subsets cv::findEssentialMat(..., LMEDS, 0.999, ...) draws (voldor/geometry.cpp:316-318).  OpenCV 3.4's LMedS registrator fixes it
+// before the loop: RANSACUpdateNumIters(confidence 0.999, outlier ratio 0.45, 5 model points, 1000) = round(log(1 - 0.999) / log(1 - 0.55^5)) = 134 (modules/calib3d/
+// src/ptsetreg.cpp; restated from the published source, OpenCV is not in the tree).  Up to ten models per subset.
+constexpr int BOOT5_SAMPLES = 134, BOOT5_MODELS = BOOT5_SAMPLES * 10;
 constexpr int BOOT_MAX_MODELS = BOOT5_MODELS > BOOT_HYPS ? BOOT5_MODELS : BOOT_HYPS;
 
 // ---- shared host/device numerics --------------------------------------------------------------
@@ -361,13 +364,185 @@ __global__ __launch_bounds__(64) static void k_boot_hyp(const float* __restrict_
     for (int k = 0; k < 9; k++) Es[(size_t)hy * 9 + k] = E[k];
 }
 
-// five-point samples: one lane per sample, up to ten models each (private arrays: the bootstrap runs once per window)
-__global__ __launch_bounds__(64) static void k_boot_hyp5(const float* __restrict__ p2, BootGeom g, double* __restrict__ Es) {
-    const int hy = blockIdx.x * 64 + threadIdx.x;
-    if (hy >= BOOT5_SAMPLES) return;
-    double E[10][9];
-    boot5_sample(g, p2, hy, E);
-    for (int m = 0; m < 10; m++) for (int k = 0; k < 9; k++) Es[((size_t)hy * 10 + m) * 9 + k] = E[m][k];
+// Five-point samples (round 6: a sample over a workgroup instead of a lane).  Rounds 4-5 ran one sample per lane on private arrays -- 134-192 lanes of the chip
+// walking ~10^5 dependent fp64 operations each (the arrays in scratch memory): 1.9 ms, which kept the five-point bootstrap optional.  Now one 128-thread
+// workgroup per sample, wave b on basis b of the null space (vk_fivept.hpp: the system is solved in two bases), the work arrays in LDS:
+//   lane 0    the five correspondences, the null space, the ten cubics, their elimination, the degree-10 polynomial (the serial part: ~5 k flops)
+//   lanes < deg   the Aberth sweeps, one root per lane, the other roots through wave shuffles (registers only: a wave leaves the loop on its own)
+//   lane 0    the real starting values in root order
+//   lane k    starting value k: null vector of B(z), Gauss-Newton on the ten cubics, the residual test -> a model or nothing; survivors keep their order (ballot)
+//   then wave 0 merges the two bases' models (duplicates dropped, ten at most) and the workgroup writes them.
+// The same functions as the host build (fivept::solve), the same operations on the same operands in the same order: the host bits
+// (tests/test_fivept.py::test_five_point_bootstrap_kernels_give_the_host_bits).
+struct Boot5Wave {
+    double NA[5][9]; int perm[9];            // the epipolar system, eliminated in place
+    double N[4][9], e[9][4];                 // the basis, the entries of E as polynomials
+    fivept::BasisWork W;
+    double A[10][20];
+    double c[11];
+    fivept::Cx z[10];
+    double zs[20];
+    double Es[10][9];
+    int deg, nz, ne, ok;
+};
+// the lanes of ONE wave meet: LDS instructions of a wave execute in order, so an earlier store of any lane is seen by a later load of any other; the
+// fences keep the compiler from moving accesses across the meeting point (no workgroup barrier: the two waves of a sample go their own ways)
+__device__ __forceinline__ void wave_meet() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// gauss_jordan_10x20 (vk_fivept.hpp) with the 200 entries over the lanes of a wave: per pivot column the first largest entry at or below the diagonal
+// (a butterfly over (value, row): larger value, lower row among equals -- the serial loop's strict >), the row swap, the pivot row divided, every other
+// row minus its multiple: entry by entry the operations of the serial routine on the same operands.  Uniform result over the wave.
+__device__ __forceinline__ bool gauss_jordan_10x20_wave(double (*A)[20], int lane) {
+    for (int k = 0; k < 10; k++) {
+        const double akk = vk_abs(A[k][k]);
+        if (!(akk == akk)) return false;  // (the serial search starts from it: a NaN there fails the pivot test)
+        double v = (lane >= k && lane < 10) ? vk_abs(A[lane][k]) : -1.0;
+        if (!(v == v)) v = -1.0;          // (a NaN further down is never "greater")
+        int r = lane < 10 ? lane : 99;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            const double ov = __shfl_xor(v, d, 64); const int orr = __shfl_xor(r, d, 64);
+            if (ov > v || (ov == v && orr < r)) { v = ov; r = orr; }
+        }
+        const int pr = __shfl(r, 0, 64);
+        const double best = __shfl(v, 0, 64);
+        if (!(best > 1e-14)) return false;
+        if (pr != k && lane < 20) { const double t = A[k][lane]; A[k][lane] = A[pr][lane]; A[pr][lane] = t; }
+        wave_meet();
+        const double piv = A[k][k];
+        wave_meet();  // (every lane holds the pivot before lane k overwrites it)
+        if (lane >= k && lane < 20) A[k][lane] /= piv;
+        wave_meet();
+        // entries (r, c), c >= k, r != k: four per lane
+        double mr[4], nv[4];
+        int idx[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int e = lane + 64 * u, rr = e / 20, cc = e - rr * 20;
+            idx[u] = (e < 200 && rr != k && cc >= k) ? e : -1;
+            mr[u] = idx[u] >= 0 ? A[rr][k] : 0.0;
+        }
+        wave_meet();  // (the multipliers are read before column k is cleared)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (idx[u] >= 0) {
+                const int rr = idx[u] / 20, cc = idx[u] - rr * 20;
+                nv[u] = A[rr][cc];
+                if (mr[u] != 0.0) nv[u] -= mr[u] * A[k][cc];
+                A[rr][cc] = nv[u];
+            }
+        }
+        wave_meet();
+    }
+    return true;
+}
+// fivept::ns_eliminate with the 45 entries over the lanes of a wave (complete pivoting: the first largest entry in row-major order -- a butterfly over
+// (value, entry index): larger value, lower index among equals), the same operations entry by entry.  Uniform result.
+__device__ __forceinline__ bool ns_eliminate_wave(double (*A)[9], int* perm, int lane) {
+    if (lane < 9) perm[lane] = lane;
+    const int er = lane / 9, ec = lane - er * 9;  // my entry (lanes < 45)
+    wave_meet();
+    for (int k = 0; k < 5; k++) {
+        double v = (lane < 45 && er >= k && ec >= k) ? vk_abs(A[er][ec]) : -2.0;
+        if (!(v == v)) v = -2.0;  // (the serial `v > best` never takes a NaN)
+        int e = lane;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const double ov = __shfl_xor(v, d, 64); const int oe = __shfl_xor(e, d, 64);
+            if (ov > v || (ov == v && oe < e)) { v = ov; e = oe; }
+        }
+        if (!(v > 1e-12)) return false;
+        const int pr = e / 9, pc = e - pr * 9;
+        if (pr != k && lane < 9) { const double t = A[k][lane]; A[k][lane] = A[pr][lane]; A[pr][lane] = t; }
+        wave_meet();
+        if (pc != k) {
+            if (lane < 5) { const double t = A[lane][k]; A[lane][k] = A[lane][pc]; A[lane][pc] = t; }
+            if (lane == 5) { const int t = perm[k]; perm[k] = perm[pc]; perm[pc] = t; }
+        }
+        wave_meet();
+        const double piv = A[k][k];
+        wave_meet();
+        if (lane >= k && lane < 9) A[k][lane] /= piv;
+        wave_meet();
+        const bool mine = lane < 45 && er != k && ec >= k;
+        const double m = mine ? A[er][k] : 0.0;
+        wave_meet();  // (the multipliers are read before column k is cleared)
+        if (mine && m != 0.0) A[er][ec] -= m * A[k][ec];
+        wave_meet();
+    }
+    return true;
+}
+__global__ __launch_bounds__(128) static void k_boot_hyp5(const float* __restrict__ p2, BootGeom g, double* __restrict__ Es) {
+    __shared__ Boot5Wave S[2];
+    const int hy = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    Boot5Wave& w = S[wv];
+    if (lane == 0) {
+        w.deg = 0; w.nz = 0; w.ne = 0; w.ok = 0;
+        double q1[5][2], q2[5][2];
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            const int i = (int)(rng3(RAND_SEED, (uint32_t)hy, 0x200u + (uint32_t)k) % (uint32_t)g.n);
+            boot_corr(g, p2, i, q1[k], q2[k]);
+        }
+        fivept::epipolar_rows(q1, q2, w.NA);  // (the elimination works on the system itself)
+    }
+    wave_meet();
+    {
+        const bool ok = ns_eliminate_wave(w.NA, w.perm, lane);
+        if (lane == 0 && ok) {
+            if (wv == 0) w.ok = fivept::ns_finish(w.NA, w.perm, w.N) ? 1 : 0;
+            else {
+                double (*N0)[9] = reinterpret_cast<double (*)[9]>(&w.A[0][0]);  // (free until the elimination of the constraints)
+                w.ok = fivept::ns_finish(w.NA, w.perm, N0) ? 1 : 0;
+                if (w.ok) fivept::second_basis(N0, w.N);
+            }
+            if (w.ok) fivept::entry_polys(w.N, w.e);
+        }
+    }
+    wave_meet();
+    if (w.ok) {  // (uniform per wave)
+        if (lane < 10) fivept::constraint_row(w.e, lane, w.W.A0[lane]);
+        wave_meet();
+        for (int e = lane; e < 200; e += 64) w.A[e / 20][e % 20] = w.W.A0[e / 20][e % 20];
+        wave_meet();
+        const bool ok = gauss_jordan_10x20_wave(w.A, lane);
+        if (lane == 0 && ok) { fivept::basis_poly(w.A, w.W); w.deg = fivept::poly_trim(w.W.n, 10, w.c); }
+        wave_meet();
+    }
+    const int deg = w.deg;
+    if (deg >= 1) {  // (uniform per wave; nothing below meets the other wave before the barrier after this block)
+        fivept::RootState st = { fivept::aberth_start(lane < 10 ? lane : 0), lane >= deg };
+        for (int sw = 0; sw < fivept::ABERTH_SWEEPS; sw++) {
+            fivept::Cx zs[10];
+#pragma unroll
+            for (int j = 0; j < 10; j++) zs[j] = { __shfl(st.z.re, j, 64), __shfl(st.z.im, j, 64) };
+            if (lane < deg) st = fivept::aberth_move(w.c, deg, zs, st, lane);
+            if (__ballot(!st.done) == 0ull) break;
+        }
+        if (lane < deg) w.z[lane] = st.z;
+        wave_meet();
+        if (lane == 0) w.nz = fivept::real_candidates(w.c, deg, w.z, w.zs);
+        wave_meet();
+    }
+    {
+        double E[9];
+        bool ok = false;
+        if (lane < w.nz) ok = fivept::polish_candidate(w.N, w.W, w.zs[lane], E);
+        const unsigned long long m = __ballot(ok);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && rank < 10) { for (int cc = 0; cc < 9; cc++) w.Es[rank][cc] = E[cc]; }
+        if (lane == 0) w.ne = min(10, __popcll(m));
+    }
+    __syncthreads();  // the one meeting of the two waves
+    if (threadIdx.x == 0) S[0].ne = fivept::merge_models(S[0].Es, S[0].ne, S[1].Es, S[1].ne);
+    __syncthreads();
+    if (threadIdx.x < 90) {
+        const int m = threadIdx.x / 9, k = threadIdx.x % 9;
+        Es[((size_t)hy * 10 + m) * 9 + k] = m < S[0].ne ? S[0].Es[m][k] : __builtin_nan("");
+    }
 }
 
 // one workgroup per hypothesis: squared Sampson distances of the scoring subset and their median = the element of rank ns / 2 in
@@ -520,7 +695,7 @@ int bootstrap_device(Context* c, ImageSet& S, int w, int h, float fx, float fy, 
     if (g.n >= 8) {
         hipLaunchKernelGGL(k_extract_corr, dim3((g.n + 255) / 256), dim3(256), 0, c->stream, S.flows.as<float2>(), d_p2, w, h, g.step, g.nx, g.n);
         const int n_models = points == 5 ? BOOT5_MODELS : BOOT_HYPS;
-        if (points == 5) hipLaunchKernelGGL(k_boot_hyp5, dim3((BOOT5_SAMPLES + 63) / 64), dim3(64), 0, c->stream, d_p2, g, d_E);
+        if (points == 5) hipLaunchKernelGGL(k_boot_hyp5, dim3(BOOT5_SAMPLES), dim3(128), 0, c->stream, d_p2, g, d_E);
         else hipLaunchKernelGGL(k_boot_hyp, dim3(BOOT_HYPS / 64), dim3(64), 0, c->stream, d_p2, g, d_E);
         hipLaunchKernelGGL(k_boot_score, dim3(n_models), dim3(256), 0, c->stream, d_p2, g, d_E, d_med);
         hipLaunchKernelGGL(k_boot_select, dim3(1), dim3(256), 0, c->stream, d_p2, g, d_E, d_med, S.pb(), cam0_dev, d_Mb, strict ? 1 : 0, n_models);

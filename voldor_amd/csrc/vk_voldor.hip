@@ -61,10 +61,14 @@ struct Config {
     //                  call only and which never sees normalize_world_scale() (voldor.cpp:250-291, :309-317) -- instead of the one
     //                  normalised map (D4).  0 (default) = what the reference does with --exclusive_gpu_context 0
     int strict_math = -1, reference_draw = 1, reference_svd = -1, reference_rng = -1, reference_tex = -1, reference_stale_depth = 0;
-    //  bootstrap_points  8 (default): normalised 8-point LMedS for the monocular two-view bootstrap; 5: the five-point minimal solver of
-    //                  cv::findEssentialMat (voldor/geometry.cpp:316-326; vk_fivept.hpp), 192 samples x up to ten models (deviation D5 narrows
-    //                  to "OpenCV's numerics are not reproduced")
-    int bootstrap_points = 8;
+    //  bootstrap_points  the monocular two-view bootstrap (voldor/geometry.cpp:316-330: cv::findEssentialMat(pts1, pts2, K, LMEDS, 0.999, 1.0) + recoverPose).
+    //                  5: the reference's estimator -- the five-point minimal solver inside LMedS over the 134 subsets OpenCV draws at that confidence
+    //                  (vk_fivept.hpp, vk_bootstrap.hip; OpenCV's own numerics are not in the tree: deviation D5 = "not OpenCV's rounding");
+    //                  8: the normalised 8-point LMedS of rounds 1-5 (256 subsets);
+    //                  -1 (default): 5 in the fast mode (round 6: a sample over a workgroup made it +0.09 ms per window instead of +2.0), 8 in strict mode --
+    //                  the reference-mode goldens (tests/golden/ref_window*.npz) were generated with the oracle's 8-point pose injected where the
+    //                  reference calls OpenCV, and a strict window reproduces them bit for bit only from that pose
+    int bootstrap_points = -1;
 
     // Returns 0, or non-zero where the reference prints and calls exit(1) (config.h:101-108,245-248):
     // a library must not exit its host process, so the error is reported to the caller instead.
@@ -213,7 +217,7 @@ struct Voldor {
         ref_rng = strict && (cfg.reference_rng < 0 ? reference_rng_default() : cfg.reference_rng != 0);  // (the fast kernels keep D1 / D2: their arithmetic is not the reference's anyway)
         ref_tex = strict && (cfg.reference_tex < 0 ? reference_tex_default() : cfg.reference_tex != 0);
         if (ref_rng && !cfg.reference_draw) { std::cout << "--reference_rng 1 needs --reference_draw 1" << std::endl; return (int)hipErrorInvalidValue; }
-        if (cfg.bootstrap_points != 5 && cfg.bootstrap_points != 8) { std::cout << "--bootstrap_points takes 5 or 8 (got " << cfg.bootstrap_points << ")" << std::endl; return (int)hipErrorInvalidValue; }
+        if (cfg.bootstrap_points != 5 && cfg.bootstrap_points != 8 && cfg.bootstrap_points != -1) { std::cout << "--bootstrap_points takes 5, 8 or -1 (got " << cfg.bootstrap_points << ")" << std::endl; return (int)hipErrorInvalidValue; }
         if (cfg.reference_stale_depth && !(strict && cfg.exclusive_gpu_context && cfg.norm_world_scale && N_dp_in == 0 && !disparity) && !cfg.silent)
             std::cout << "--reference_stale_depth 1 has no effect here (it needs --strict_math 1, --exclusive_gpu_context 1, --norm_world_scale 1 and a window without depth priors)" << std::endl;
         n_flows = n_flows_init = N;
@@ -427,7 +431,7 @@ struct Voldor {
         if (int e = upload_frames_up_to(ref_tex ? 2 : 1)) return e;
         if (n_dp == 0) {  // bootstrap :151-162
             if (c->prof) prof_begin(c);
-            if (int e = bootstrap_device(c, c->od, w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, dcams(), strict, cfg.bootstrap_points == 5 ? 5 : 8)) return e;
+            if (int e = bootstrap_device(c, c->od, w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, dcams(), strict, cfg.bootstrap_points == 5 || (cfg.bootstrap_points == -1 && !strict) ? 5 : 8)) return e;
             if (c->prof) prof_end(c, "bootstrap");
         }
         while (iters_remain > 0 && n_flows > 0) {
