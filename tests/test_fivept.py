@@ -161,3 +161,96 @@ def test_solution_sets_equal_those_of_an_independent_solver():
     assert g["planted_o"] == g["samples"] and g["planted_p"] == g["samples"]
     assert h["spurious"] <= 0.03 * h["prod"] and h["found"] >= 0.93 * h["orc"]
     assert h["planted_o"] >= 0.95 * h["samples"] and h["planted_p"] >= 0.9 * h["samples"]
+
+
+def _flow_field(w, h, f, depth, R, t):
+    """exact flow of a depth map under the motion X2 = R X + t (intrinsics f, principal point at the image centre)"""
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    X = np.stack([(xs - w / 2) / f * depth, (ys - h / 2) / f * depth, depth], -1)
+    Y = X @ R.T + t
+    return np.stack([f * Y[..., 0] / Y[..., 2] + w / 2 - xs, f * Y[..., 1] / Y[..., 2] + h / 2 - ys], -1).astype(np.float32)
+
+
+def _median_sampson_px2(flow, f, R, t, step=4):
+    """median squared Sampson distance (pixels^2) of the flow's correspondences under the epipolar geometry of (R, t)"""
+    h, w, _ = flow.shape
+    ys, xs = np.mgrid[0:h:step, 0:w:step].astype(np.float64)
+    fl = flow[::step, ::step].astype(np.float64)
+    q1 = np.stack([(xs - w / 2) / f, (ys - h / 2) / f, np.ones_like(xs)], -1).reshape(-1, 3)
+    q2 = np.stack([(xs + fl[..., 0] - w / 2) / f, (ys + fl[..., 1] - h / 2) / f, np.ones_like(xs)], -1).reshape(-1, 3)
+    t = np.asarray(t, np.float64); R = np.asarray(R, np.float64)
+    E = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]) @ R
+    Eq1 = q1 @ E.T; Etq2 = q2 @ E
+    num = np.einsum("ki,ki->k", q2, Eq1) ** 2
+    den = Eq1[:, 0] ** 2 + Eq1[:, 1] ** 2 + Etq2[:, 0] ** 2 + Etq2[:, 1] ** 2
+    return float(np.median(num / den)) * f * f
+
+
+def test_a_single_plane_separates_the_five_point_from_the_eight_point_estimator():
+    """what the reference's estimator (five-point inside LMedS, voldor/geometry.cpp:316-326) can do and the 8-point LMedS of rounds 1-5
+    cannot.  All points on ONE plane: the linear 8-point system is rank deficient (a three-dimensional solution space: its answer is arbitrary), the
+    five-point solver is not degenerate there -- the planted essential matrix is among its solutions (and among the independent solver's,
+    oracle/orc_fivept.py), with the one ambiguity planar scenes have (a second motion / plane pair that explains the same flow; OpenCV's LMedS has it too:
+    the least median cannot tell two exact fits apart).  Host build of the bootstrap's own source, no GPU."""
+    from oracle import orc_fivept
+    from voldor_amd import kernels
+    w, h, f = 320, 240, 160.0
+    K = K9(f, f, w / 2, h / 2)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    ray = np.stack([(xs - w / 2) / f, (ys - h / 2) / f, np.ones_like(xs)], -1)
+    planted5 = fits5 = broken8 = 0
+    for seed in range(6):
+        rng = np.random.default_rng(seed)
+        R = _rodrigues(rng.normal(0, 0.03, 3)); t = rng.normal(0, 1, 3); t = 0.3 * t / np.linalg.norm(t)
+        n = np.array([0.2 * rng.normal(), 0.3 * rng.normal(), 1.0]); n /= np.linalg.norm(n)
+        depth = 6.0 / (ray @ n)
+        flow = _flow_field(w, h, f, depth, R, t) + rng.normal(0, 0.05, (h, w, 2)).astype(np.float32)
+        # (a) the minimal solver on five points of the plane: the planted matrix is a solution, in the product and in the oracle
+        idx = rng.choice(w * h, 5, replace=False); py, px = idx // w, idx % w
+        q1 = np.stack([(px - w / 2) / f, (py - h / 2) / f], 1)
+        X2 = (ray[py, px] * depth[py, px, None]) @ R.T + t
+        q2 = X2[:, :2] / X2[:, 2:]
+        tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]]); E0 = tx @ R; E0 *= np.sqrt(2.0) / np.linalg.norm(E0)
+        near = lambda S: min([min(np.abs(E - E0).max(), np.abs(E + E0).max()) for E in S] + [9.0])
+        assert near(kernels.fivept_solve(q1, q2)) < 1e-6 and near(orc_fivept.solve(q1, q2)) < 1e-6
+        # (b) eight points of the plane: the 8 x 9 epipolar system has a null space of dimension 3
+        idx8 = rng.choice(w * h, 8, replace=False); py, px = idx8 // w, idx8 % w
+        a1 = np.concatenate([np.stack([(px - w / 2) / f, (py - h / 2) / f], 1), np.ones((8, 1))], 1)
+        Y = (ray[py, px] * depth[py, px, None]) @ R.T + t; a2 = Y / Y[:, 2:]
+        sv = np.linalg.svd(np.stack([np.outer(a2[i], a1[i]).ravel() for i in range(8)]), compute_uv=False)
+        assert sv[6] < 1e-9 * sv[0] and sv[5] > 1e-6 * sv[0], sv  # rank 6
+        # (c) the two bootstraps on the whole flow field
+        ok5, R5, t5 = kernels.estimate_pose_epipolar5(flow, K); ok8, R8, t8 = kernels.estimate_pose_epipolar(flow, K)
+        assert ok5 and ok8
+        dirg = t / np.linalg.norm(t)
+        e5 = (_angle(R5.astype(np.float64), R), np.arccos(np.clip(t5 / np.linalg.norm(t5) @ dirg, -1, 1)))
+        e8 = (_angle(R8.astype(np.float64), R), np.arccos(np.clip(t8 / np.linalg.norm(t8) @ dirg, -1, 1)))
+        m5, m8 = _median_sampson_px2(flow, f, R5, t5), _median_sampson_px2(flow, f, R8, t8)
+        print(f"plane, seed {seed}: five-point rot {e5[0]:.1e} rad, t direction {e5[1]:.1e} rad, median Sampson {m5:.1e} px^2 | 8-point {e8[0]:.1e}, {e8[1]:.1e}, {m8:.1e} px^2")
+        planted5 += int(e5[0] < 2e-3 and e5[1] < 0.15); fits5 += int(m5 < 0.1); broken8 += int(e8[0] > 2e-2 and e8[1] > 0.5)
+    # measured (6 scenes): the five-point bootstrap returns the planted pose in 4 (rotation 3e-4 - 6e-4 rad, translation direction 0.01 - 0.1 rad) and the
+    # plane's second interpretation in 2 (0.04 rad / 1 rad) -- a fit of the flow either way (median Sampson distance 1e-3 - 7e-2 px^2 at 0.05 px flow noise);
+    # the 8-point bootstrap never returns the planted pose: off by 0.04 - 0.05 rad in rotation and 0.9 - 1.9 rad in the translation direction in all 6,
+    # with medians just as small -- on a plane a small residual proves nothing, which is the degeneracy
+    assert fits5 == 6 and planted5 >= 3 and broken8 == 6
+
+
+def test_forward_motion_bootstrap():
+    """The hard case of the degree-10 polynomial (near-multiple roots: why the system is solved in two bases): forward motion over a scene with relief.  The
+    five-point LMedS bootstrap recovers the planted pose as the 8-point one does."""
+    from voldor_amd import kernels
+    w, h, f = 320, 240, 160.0
+    K = K9(f, f, w / 2, h / 2)
+    ys, xs = np.mgrid[0:h, 0:w].astype(np.float64)
+    depth = 4 + 3 * np.sin(xs / 40) ** 2 + 2 * (ys / h)
+    for seed in range(4):
+        rng = np.random.default_rng(100 + seed)
+        R = _rodrigues(rng.normal(0, 0.01, 3)); t = np.array([0.02, 0.01, 0.3])
+        flow = _flow_field(w, h, f, depth, R, t) + rng.normal(0, 0.05, (h, w, 2)).astype(np.float32)
+        ok5, R5, t5 = kernels.estimate_pose_epipolar5(flow, K); ok8, R8, t8 = kernels.estimate_pose_epipolar(flow, K)
+        assert ok5 and ok8
+        dirg = t / np.linalg.norm(t)
+        e5 = (_angle(R5.astype(np.float64), R), np.arccos(np.clip(t5 / np.linalg.norm(t5) @ dirg, -1, 1)))
+        e8 = (_angle(R8.astype(np.float64), R), np.arccos(np.clip(t8 / np.linalg.norm(t8) @ dirg, -1, 1)))
+        print(f"forward motion, seed {seed}: five-point rot {e5[0]:.1e} rad, t direction {e5[1]:.1e} rad | 8-point {e8[0]:.1e}, {e8[1]:.1e}")
+        assert e5[0] < 2e-3 and e5[1] < 4e-2 and e8[0] < 3e-3 and e8[1] < 4e-2  # measured: 0 - 7e-4 / 8e-3 - 2e-2 (five-point), 4e-4 - 1.3e-3 / 7e-3 - 1.2e-2 (8-point)
