@@ -54,3 +54,15 @@ def small_scene():
 
 def K9(fx, fy, cx, cy):
     return np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], np.float32)
+
+
+@pytest.fixture
+def eight_point_bootstrap():
+    """The fast mode's default two-view bootstrap is the five-point LMedS (round 6: the reference's estimator, voldor/geometry.cpp:316-326); the oracle and the
+    reference-pipeline goldens (tests/golden/ref_*.npz, where the reference would call OpenCV) start from the 8-point pose.  A test that holds the EM loop of a
+    fast window against them must start it from the same pose -- the bootstrap itself is held in tests/test_fivept.py.  Sets
+    what `--bootstrap_points -1` stands for (vk_debug_switch "bootstrap_default") for the duration of the test."""
+    import hooks
+    prev = hooks.debug_switch("bootstrap_default", 8)
+    yield
+    hooks.debug_switch("bootstrap_default", prev)

@@ -24,7 +24,7 @@ import pytest
 import ensemble_cases as ens
 import stat_helpers as sh
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("eight_point_bootstrap")]  # (fast windows here are held against the oracle / the reference ensembles: same two-view pose, conftest.py)
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_ensemble.npz")
 SUB = 8
 ALPHA = 0.01

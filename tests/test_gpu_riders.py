@@ -36,7 +36,7 @@ def _run(case, switches, device):
         flows[c["noise_from"]:] = np.random.default_rng(0).uniform(-40, 40, flows[c["noise_from"]:].shape).astype(np.float32)
     fx, fy, cx, cy = sc["K"]
     prev = {k: hooks.debug_switch(k, v) for k, v in switches.items()}
-    hooks.debug_counter("fb_blocks_rode"); hooks.debug_counter("reduces_rode")  # (read and clear)
+    hooks.debug_counter("fb_blocks_rode"); hooks.debug_counter("reduces_rode"); hooks.debug_counter("fb_side_passes")  # (read and clear)
     try:
         outs = []
         for _ in range(2):  # two windows in a row on one context
@@ -53,7 +53,7 @@ def _run(case, switches, device):
     finally:
         for k, v in prev.items():
             hooks.debug_switch(k, v)
-    return outs, dict(fb_blocks=hooks.debug_counter("fb_blocks_rode"), reduces=hooks.debug_counter("reduces_rode"))
+    return outs, dict(fb_blocks=hooks.debug_counter("fb_blocks_rode"), reduces=hooks.debug_counter("reduces_rode"), side=hooks.debug_counter("fb_side_passes"))
 
 
 def _plan_rides(c):
@@ -74,7 +74,7 @@ def test_riding_work_changes_no_bit_of_a_window(case, device):
     # the comparison below is only worth something if the second run DID move work into other launches: counted where the
     # launches are built.  Nothing rides with the switches off; with them on every EM iteration but the last leaves its density reduction to the
     # next trace, and fb_smooth rides in every iteration without the refit where the dealing says the geometry allows it -- whole passes at a time
-    assert rode0 == dict(fb_blocks=0, reduces=0), rode0
+    assert rode0["fb_blocks"] == 0 and rode0["reduces"] == 0, rode0
     assert rode1["reduces"] >= 2 * 2, rode1  # two windows, at least three EM iterations each
     on, blocks_per_iter = _plan_rides(CASES[case])
     expect_fb = on and "--fb_smooth 0" not in CASES[case]["cfg"] and "--rg_refine_last_only 0" not in CASES[case]["cfg"]
@@ -94,3 +94,31 @@ def test_riding_work_changes_no_bit_of_a_window(case, device):
     # and the two windows of a run are one window twice
     for k in ("depth", "poses"):
         np.testing.assert_array_equal(np.asarray(riding[0][k], np.float32).view(np.uint32), np.asarray(riding[1][k], np.float32).view(np.uint32))
+
+
+SIDE_CASES = {
+    # strict mode: fb_smooth (the reference's recurrence, step by step) runs on a second stream next to the pose half (round 6)
+    "strict": dict(case="five_cameras", suffix=" --strict_math 1 --reference_draw 1 --reference_svd 1", switches={}),
+    "strict_with_prior": dict(case="eight_cameras_with_prior", suffix=" --strict_math 1", switches={}),
+    "strict_refit_everywhere": dict(case="refit_in_every_iteration", suffix=" --strict_math 1", switches={}),
+    "strict_truncates": dict(case="truncates", suffix=" --strict_math 1", switches={}),
+    "strict_cuda_mode": dict(case="five_cameras", suffix=" --strict_math 1 --reference_draw 1 --reference_svd 1 --reference_rng 1 --reference_tex 1", switches={}),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SIDE_CASES))
+def test_fb_smooth_next_to_the_pose_half_changes_no_bit_of_a_window(name):
+    sc_ = SIDE_CASES[name]
+    old = CASES[sc_["case"]]
+    CASES["_side"] = dict(old, cfg=old["cfg"] + sc_["suffix"])
+    try:
+        inside, c0 = _run("_side", dict(sc_["switches"], fb_side=0), device=False)
+        beside, c1 = _run("_side", dict(sc_["switches"], fb_side=1), device=False)
+    finally:
+        CASES.pop("_side")
+    assert c0["side"] == 0 and c0["fb_blocks"] == 0, c0
+    assert c1["side"] >= 2 * 3 and c1["fb_blocks"] == 0, c1  # two windows, every EM iteration (the refit iterations too: nothing rides in a kernel there, the stream does not care)
+    for a, b in zip(inside, beside):
+        assert a["n_registered"] == b["n_registered"]
+        for k in ("depth", "depth_conf", "poses", "poses_covar"):
+            np.testing.assert_array_equal(np.ascontiguousarray(a[k], np.float32).view(np.uint32), np.ascontiguousarray(b[k], np.float32).view(np.uint32), err_msg=f"{name}: {k}")

@@ -13,7 +13,7 @@ import pytest
 from conftest import K9
 import test_gpu_kernels as tk
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("eight_point_bootstrap")]  # (fast windows here are held against the oracle / the reference ensembles: same two-view pose, conftest.py)
 
 
 def _same_bits(a, b):

@@ -26,7 +26,7 @@ import pytest
 
 import hooks
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("eight_point_bootstrap")]  # (fast windows here are held against the oracle / the reference ensembles: same two-view pose, conftest.py)
 
 
 @pytest.fixture(autouse=True)

@@ -23,6 +23,9 @@ int Context::init(int dev) {
     VK_CHECK(hipEventCreate(&ev3));
     VK_CHECK(hipEventCreateWithFlags(&ev_cams, hipEventDisableTiming));
     VK_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    VK_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    VK_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    VK_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     for (int f = 0; f < MAX_FRAMES; f++) VK_CHECK(hipEventCreateWithFlags(&ev_frame[f], hipEventDisableTiming));
     VK_CHECK(hipHostMalloc((void**)&h_cams, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
     VK_CHECK(hipHostMalloc((void**)&h_pb, sizeof(PoseBlock), hipHostMallocDefault));
@@ -45,6 +48,10 @@ void Context::destroy() {
     for (int f = 0; f < MAX_FRAMES; f++) { if (ev_frame[f]) (void)hipEventDestroy(ev_frame[f]); ev_frame[f] = nullptr; }
     if (copy_stream) (void)hipStreamDestroy(copy_stream);
     copy_stream = nullptr;
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side_stream) (void)hipStreamDestroy(side_stream);
+    side_stream = nullptr; ev_fork = ev_join = nullptr;
     if (h_cams) (void)hipHostFree(h_cams);
     if (h_brief) (void)hipHostFree(h_brief);
     if (h_pb) (void)hipHostFree(h_pb);
@@ -150,12 +157,13 @@ static const bool g_bt_installed = [] {
 static DebugSwitches g_debug;
 // ONE table of the verification switches (vk_debug.h): name, field, accepted values.  vk_debug_switch and the VOLDOR_HIP_DEBUG parser both go
 // through debug_switch_set, so a value the launch paths were never tested with cannot reach them from either side.
-struct DebugEntry { const char* name; int DebugSwitches::*field; int kind; };  // kind 0: 0 | 1; 1: 0 | 12 | 20 | 40; 2: any value >= 0; 3: 0 | 1 | 2
+struct DebugEntry { const char* name; int DebugSwitches::*field; int kind; };  // kind 0: 0 | 1; 1: 0 | 12 | 20 | 40; 2: any value >= 0; 3: 0 | 1 | 2; 4: 0 | 5 | 8
 static const DebugEntry g_debug_tab[] = {
     { "local_serial", &DebugSwitches::local_serial, 0 }, { "cost_rand_plain", &DebugSwitches::cost_rand_plain, 0 }, { "fb_segment", &DebugSwitches::fb_segment, 1 },
     { "global_split", &DebugSwitches::global_split, 0 }, { "refit_partition", &DebugSwitches::refit_partition, 0 }, { "split_trials", &DebugSwitches::split_trials, 0 },
     { "strict_plain", &DebugSwitches::strict_plain, 0 }, { "strict_pose_coop", &DebugSwitches::strict_pose_coop, 0 },
     { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 }, { "estep_pairs", &DebugSwitches::estep_pairs, 3 }, { "fb_ride", &DebugSwitches::fb_ride, 0 }, { "defer_reduce", &DebugSwitches::defer_reduce, 0 },
+    { "fb_side", &DebugSwitches::fb_side, 0 }, { "bootstrap_default", &DebugSwitches::bootstrap_default, 4 },
 };
 // returns the previous value; -1: unknown name; -2: a value the switch does not take
 static int debug_switch_set(const char* name, int value) {
@@ -164,6 +172,7 @@ static int debug_switch_set(const char* name, int value) {
             if (t.kind == 0) value = value ? 1 : 0;
             else if (t.kind == 1) { if (value != 0 && value != 12 && value != 20 && value != 40) return -2; }
             else if (t.kind == 3) { if (value < 0 || value > 2) return -2; }
+            else if (t.kind == 4) { if (value != 0 && value != 5 && value != 8) return -2; }
             else if (value < 0) return -2;
             const int old = g_debug.*t.field;
             g_debug.*t.field = value;
@@ -414,6 +423,7 @@ extern "C" __attribute__((visibility("default"))) int vk_debug_counter(const cha
     if (!c) return -1;
     if (strcmp(name, "strict_coop_fallbacks") == 0) return vk::strict_coop_fallbacks(c);
     if (strcmp(name, "fb_blocks_rode") == 0) { const long v = c->dbg_fb_blocks_rode; c->dbg_fb_blocks_rode = 0; return (int)v; }
+    if (strcmp(name, "fb_side_passes") == 0) { const long v = c->dbg_fb_side_passes; c->dbg_fb_side_passes = 0; return (int)v; }
     if (strcmp(name, "reduces_rode") == 0) { const long v = c->dbg_reduces_rode; c->dbg_reduces_rode = 0; return (int)v; }
     return -1;
 }

@@ -151,7 +151,8 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
     // Context::pending_reduce: the correspondence trace of camera 0 -- the next launch of the stream, which reads none of its results -- carries it as
     // extra workgroups.  One dependent launch per EM iteration less (2.85 us boundary + 4.9 us kernel).
     bool defer_reduce = false;
-    bool fb_done = false;  // window pipeline, fast mode: fb_smooth and the projective maps of this call were done in the launches of the pose half (FbRide)
+    bool fb_done = false;  // window pipeline: fb_smooth of this call was done during the pose half (riding in the mode kernels' launches, FbRide; or on the side stream)
+    bool cum_done = false; // fast mode: so were the projective maps of the chain and the world-scale factor (cum_poses_block in the last mode kernel)
     // --reference_stale_depth 1 (strict mode; SURVEY Appendix B-1, deviation D4 switched off): the depth map optimize_depth.cu keeps on the device.
     // With exclusive_gpu_context the reference uploads its depth map for the first call only (voldor.cpp:250-291), so from the second EM
     // iteration on the search starts from a copy that never saw normalize_world_scale().  Non-null: the kernels of this call work on that copy
@@ -193,7 +194,7 @@ struct Context {
     // collect_p3p_instances.cu statics); the B-outer pipeline uses `od` for everything.
     ImageSet od, cp;
     DevBuf rig_partial;           // per-block rigidness sums -> pose_rigidness_density
-    long dbg_fb_blocks_rode = 0, dbg_reduces_rode = 0;  // verification counters (vk_debug_counter): fb_smooth blocks / density reductions that rode in another kernel's launch
+    long dbg_fb_blocks_rode = 0, dbg_reduces_rode = 0, dbg_fb_side_passes = 0;  // verification counters (vk_debug_counter): fb_smooth blocks / density reductions that rode in another kernel's launch
     ReduceArgs pending_reduce;    // window pipeline, fast mode: the density reduction of the last E-step, left for the next correspondence trace (partial != NULL: pending)
     DevBuf local_tbl;             // [h][w] candidate-cost table of a local propagation pass
     DevBuf p2_map, p3_map;        // [h*w][2], [h*w][3] (collect_p3p_instances.cu:27-34)
@@ -228,6 +229,9 @@ struct Context {
     // synchronise with every blocking stream of the process); ev_frame[f] = "frame f is on the device", waited for by `stream` before its first reader
     hipStream_t copy_stream = nullptr;
     hipEvent_t ev_frame[MAX_FRAMES] = {};
+    // fb_smooth of the coming depth half next to the pose half (round 6): a second stream forked off `stream` after the E-step and joined before the cost kernel
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     PoseBlock* h_pb = nullptr;     // pinned staging of the per-window uploads (pose block, camera records): no host sync before the first launch
     CamState* h_cams_up = nullptr;
     CamBrief* h_brief = nullptr;   // pinned, written by the device (CamBrief above); h_brief_dev = its device address

@@ -26,12 +26,15 @@ extern "C" {
  *   "fb_ride"         1 | 0   0: fb_smooth of a window's depth half always runs as its own launches instead of riding, block by block, in the launches of the
  *                             pose half's mode kernels (FbRide, vk_common.hpp)
  *   "estep_pairs"     1 | 0 | 2   the fast E-step with two pixels per lane on packed fp32 (same bits): from 1.5 M pixels | never | at every size
+ *   "fb_side"         1 | 0   0: strict mode: fb_smooth of a window's depth half runs inside the depth half instead of on a second stream next to the pose half
+ *   "bootstrap_default" 0 | 5 | 8   what the default of --bootstrap_points stands for: five-point in the fast mode and 8-point in strict mode | always that one.  The
+ *                             oracle and the reference goldens start from the 8-point pose: tests that hold a fast window against them set 8
  * Returns the previous value, -1 for an unknown name / value. */
 int vk_debug_switch(const char* name, int value);
 /* Counters, read and cleared: "strict_coop_fallbacks" = cameras (default context) whose cooperative strict mode kernel gave up a meeting and were
  * computed by the single-workgroup kernel launched behind it; "fb_blocks_rode" = 256-thread fb_smooth blocks the window pipeline (default context) put
  * into mode-kernel launches instead of launches of their own (FbRide); "reduces_rode" = density reductions it attached to a correspondence trace
- * (OdParams::defer_reduce) -- counted on the host where the launch is built.  -1: unknown name / device error. */
+ * (OdParams::defer_reduce); "fb_side_passes" = fb_smooth passes it ran on the side stream next to a pose half -- counted on the host where the launch is built.  -1: unknown name / device error. */
 int vk_debug_counter(const char* name);
 /* How the 256-thread blocks of a riding fb_smooth (FbRide, vk_common.hpp) would be dealt over the mode kernels of a window with this geometry -- host
  * arithmetic only, no device.  out: [riding 0 | 1, steps per lane, row blocks R, column blocks C, launches that carry rows, then per camera: kind

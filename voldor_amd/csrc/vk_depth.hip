@@ -88,18 +88,18 @@ void fb_smooth_plan_segments(int w, int h, int n_maps, int* rows_seg, int* cols_
     fb_smooth_plan(w, h, n_maps, rows_seg, cols_seg);
 }
 int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev, PoseBlock* cumP,
-                     int cumN, int cumNdp, float* world_scale) {
+                     int cumN, int cumNdp, float* world_scale, float* dst, hipStream_t st_in) {
     if (n_maps <= 0) return 0;
-    hipStream_t st = c->stream;
+    hipStream_t st = st_in ? st_in : c->stream;
     if (!fb_smooth_segmented(w, h)) {
         // larger than any segmented launch: one lane per line walks the recurrence step by step (the reference's own structure,
         // fb_smooth.h:26-69; no size limit).  The projective maps of the cost kernels then need their own launch.
-        if (cumP) hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, c->stream, cumP, cumN, cumNdp, world_scale);
-        return fb_smooth_strict_device(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev);
+        if (cumP) hipLaunchKernelGGL(k_cum_poses, dim3(1), dim3(64), 0, st, cumP, cumN, cumNdp, world_scale);
+        return fb_smooth_strict_device(c, maps, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, dst, st);
     }
     int rs, cs;
     fb_smooth_plan(w, h, n_maps, &rs, &cs);
-    float* out = maps;
+    float* out = dst ? dst : maps;
     if (rs == 12) fb_rows_launch<12>(st, maps, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
     else if (rs == 20) fb_rows_launch<20>(st, maps, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);
     else fb_rows_launch<40>(st, maps, out, n_maps, w, h, s0_ems_prob, no_change_prob, n_dev, cumP, cumN, cumNdp, world_scale);

@@ -1288,9 +1288,9 @@ int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_
     const bool plain = STRICT && debug_switches().strict_plain;  // strict mode on the plain launch structures of rounds 1-3 (verification: same bits either way)
     // fast mode: the projective maps of the chain (and the world-scale factor) are prepared by an extra workgroup of the first fb_smooth
     // launch when there is one, by their own small launch otherwise
-    const bool fb_done = !STRICT && p.fb_done && !cost_only;  // (OdParams::fb_done: both happened in the launches of the pose half)
+    const bool fb_done = p.fb_done && !cost_only;  // (OdParams::fb_done: fb_smooth of this call ran during the pose half)
     const bool cum_in_fb = !STRICT && !cost_only && !p.update_rigidness_only && p.fb_smooth && p.N > 0 && !fb_done;
-    if constexpr (!STRICT) { if (!cum_in_fb && !fb_done) cum_poses_launch(c, S.pb(), p.N, p.N_dp, p.world_scale_out); }
+    if constexpr (!STRICT) { if (!cum_in_fb && !(fb_done && p.cum_done)) cum_poses_launch(c, S.pb(), p.N, p.N_dp, p.world_scale_out); }
     auto cost_rand = [&](int n_rand, uint32_t epoch) {
         if constexpr (STRICT) {
             if (plain || debug_switches().cost_rand_plain || p.N_dp > 1) hipLaunchKernelGGL(k_cost_rand_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);

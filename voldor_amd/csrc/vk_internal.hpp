@@ -33,6 +33,10 @@ struct DebugSwitches {
     int defer_reduce = 1;      // 0: every optimize_depth call of a window launches its own density reduction
     int fb_ride = 1;           // 0: fb_smooth of a window's depth half always runs as its own launches (not in the launches of the pose half's mode kernels)
     int estep_pairs = 1;       // the E-step with two pixels per lane on packed fp32 (same bits): 0 never, 1 from 1.5 M pixels, 2 always
+    // round 6
+    int fb_side = 1;           // 0: strict mode's fb_smooth runs inside the depth half instead of on the side stream next to the pose half
+    int bootstrap_default = 0; // what --bootstrap_points -1 (the default) means: 0 = five-point in the fast mode, 8-point in strict mode; 5 | 8 = that one.  The test suite sets 8 where a
+                               // window is held against the oracle or the reference goldens, whose two-view pose is the 8-point one
     int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
 };
 DebugSwitches& debug_switches();  // vk_abi.hip
@@ -68,10 +72,11 @@ __device__ __forceinline__ void maybe_decide(const ModeParams& mp, PoseBlock* P,
 // vk_depth.hip
 int optimize_depth_device(Context* c, ImageSet& S, const OdParams& p);
 int cost_map_device(Context* c, ImageSet& S, const OdParams& p);
+// dst: the row pass writes there (the column pass then works on it in place); NULL: in place.  st: the stream to launch on; NULL: the context's
 int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr,
-                     PoseBlock* cumP = nullptr, int cumN = 0, int cumNdp = 0, float* world_scale = nullptr);
+                     PoseBlock* cumP = nullptr, int cumN = 0, int cumNdp = 0, float* world_scale = nullptr, float* dst = nullptr, hipStream_t st = nullptr);
 // vk_strict.hip
-int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr);
+int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr, float* dst = nullptr, hipStream_t st = nullptr);
 int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
 int strict_coop_fallbacks(Context* c);  // cameras the single-workgroup strict mode kernel took over from the cooperative one (read and cleared); -1: device error
 int meanshift_strict_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);

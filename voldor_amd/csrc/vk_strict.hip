@@ -119,7 +119,7 @@ __device__ __forceinline__ void fbs_store_range(float* __restrict__ p, size_t st
 // One chain over steps [s0, s1) of its line: index = DIR ? n - 1 - step : step.  POST: the other chain's messages `other` are there ->
 // posterior to the map; else this chain's messages to `mine`.
 template <int PASS, int DIR, bool POST>
-__device__ __forceinline__ float fb_chain(float* __restrict__ e1, float* __restrict__ mine, const float* __restrict__ other, size_t stride, int n, int s0, int s1,
+__device__ __forceinline__ float fb_chain(const float* e1, float* mine /* POST: where the posterior goes (the map itself, or the out-of-place destination) */, const float* __restrict__ other, size_t stride, int n, int s0, int s1,
                                           float prev, float e0, float p, bool live) {
 #pragma clang fp contract(off)
     if (s0 >= s1) return prev;
@@ -144,7 +144,7 @@ __device__ __forceinline__ float fb_chain(float* __restrict__ e1, float* __restr
             }
         }
         const int lo = max(base, DIR ? last : first), hi = min(base + FBS_CH - 1, DIR ? first : last);
-        if (live) fbs_store_range<PASS>(POST ? e1 : mine, stride, base, lo, hi, out);  // (an idle lane of the last workgroup walks along on line 0 and stores nothing)
+        if (live) fbs_store_range<PASS>(mine, stride, base, lo, hi, out);  // (an idle lane of the last workgroup walks along on line 0 and stores nothing)
         if (DIR ? base <= last : base + FBS_CH - 1 >= last) break;
         base = nbase;
 #pragma unroll
@@ -153,7 +153,7 @@ __device__ __forceinline__ float fb_chain(float* __restrict__ e1, float* __restr
     return prev;
 }
 template <int PASS>
-__global__ __launch_bounds__(128) static void k_fb_strict(float* __restrict__ maps, float* __restrict__ fwd, float* __restrict__ bwd, int w, int h, float e0, float p,
+__global__ __launch_bounds__(128) static void k_fb_strict(const float* maps, float* maps_out /* == maps: in place */, float* __restrict__ fwd, float* __restrict__ bwd, int w, int h, float e0, float p,
                                                           const int* __restrict__ n_dev) {
 #pragma clang fp contract(off)
     if (n_dev && (int)blockIdx.y >= *n_dev) return;
@@ -162,7 +162,8 @@ __global__ __launch_bounds__(128) static void k_fb_strict(float* __restrict__ ma
     const size_t stride = PASS == 0 ? 1 : (size_t)w;
     const bool live = l < lines;
     const size_t base = (size_t)blockIdx.y * w * h + (PASS == 0 ? (size_t)(live ? l : 0) * w : (size_t)(live ? l : 0));
-    float* e1 = maps + base;
+    const float* e1 = maps + base;
+    float* eo = maps_out + base;  // (a chain stores a posterior only where BOTH chains have consumed the raw value: in place or not, the same values)
     float* F = fwd + base;
     float* B = bwd + base;
     const int H = n / 2;  // the forward chain's half is [0, H), the backward chain's [H, n)
@@ -171,16 +172,18 @@ __global__ __launch_bounds__(128) static void k_fb_strict(float* __restrict__ ma
     if (dir == 0) prev = fb_chain<PASS, 0, false>(e1, F, nullptr, stride, n, 0, H, prev, e0, p, live);
     else prev = fb_chain<PASS, 1, false>(e1, B, nullptr, stride, n, 0, n - H, prev, e0, p, live);
     __syncthreads();
-    if (dir == 0) fb_chain<PASS, 0, true>(e1, nullptr, B, stride, n, H, n, prev, e0, p, live);
-    else fb_chain<PASS, 1, true>(e1, nullptr, F, stride, n, n - H, n, prev, e0, p, live);
+    if (dir == 0) fb_chain<PASS, 0, true>(e1, eo, B, stride, n, H, n, prev, e0, p, live);
+    else fb_chain<PASS, 1, true>(e1, eo, F, stride, n, n - H, n, prev, e0, p, live);
 }
-int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev) {
+int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev, float* dst, hipStream_t st_in) {
     if (n_maps <= 0) return 0;
+    hipStream_t st = st_in ? st_in : c->stream;
     const size_t plane = (size_t)n_maps * w * h;
     if (int e = c->fb_scratch.reserve(sizeof(float) * 2 * plane)) return e;  // forward and backward messages
     float* F = c->fb_scratch.as<float>(); float* B = F + plane;
-    hipLaunchKernelGGL(k_fb_strict<0>, dim3((h + 63) / 64, n_maps), dim3(128), 0, c->stream, maps, F, B, w, h, s0_ems_prob, no_change_prob, n_dev);
-    hipLaunchKernelGGL(k_fb_strict<1>, dim3((w + 63) / 64, n_maps), dim3(128), 0, c->stream, maps, F, B, w, h, s0_ems_prob, no_change_prob, n_dev);
+    float* out = dst ? dst : maps;
+    hipLaunchKernelGGL(k_fb_strict<0>, dim3((h + 63) / 64, n_maps), dim3(128), 0, st, maps, out, F, B, w, h, s0_ems_prob, no_change_prob, n_dev);
+    hipLaunchKernelGGL(k_fb_strict<1>, dim3((w + 63) / 64, n_maps), dim3(128), 0, st, out, out, F, B, w, h, s0_ems_prob, no_change_prob, n_dev);
     VK_CHECK_LAST();
     return 0;
 }

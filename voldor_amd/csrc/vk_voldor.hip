@@ -236,7 +236,7 @@ struct Voldor {
         if (int e = S.ensure_pose()) return e;
         if (int e = S.flows.reserve(sizeof(float) * 2 * npx * N)) return e;
         if (int e = S.rig.reserve(sizeof(float) * npx * N)) return e;
-        if (!strict && cfg.fb_smooth) { if (int e = S.rig2.reserve(sizeof(float) * npx * N)) return e; }  // (FbRide: the row pass of a riding fb_smooth writes here)
+        if (cfg.fb_smooth) { if (int e = S.rig2.reserve(sizeof(float) * npx * N)) return e; }  // (the row pass of an fb_smooth that runs during the pose half -- riding, or on the side stream -- writes here)
         if (int e = S.depth.reserve(sizeof(float) * npx)) return e;
         if (int e = S.cost.reserve(sizeof(float) * npx)) return e;
         if (int e = c->cams.reserve(sizeof(CamState) * MAX_FRAMES)) return e;
@@ -312,8 +312,9 @@ struct Voldor {
             p.stale_refresh = iters_cur < 2;  // voldor.cpp:250: "iters_cur == 0 || iters_cur == 1": the calls that upload the map
         }
         p.defer_reduce = defer_reduce && !strict && debug_switches().defer_reduce != 0;
-        p.fb_done = fb_rode && flag != OD_ONLY_USE_DEPTH_PRIOR;  // (enqueue_cameras: fb_smooth and the projective maps rode in the pose half's mode kernels)
-        fb_rode = false;
+        p.fb_done = fb_rode && flag != OD_ONLY_USE_DEPTH_PRIOR;  // (enqueue_cameras: fb_smooth ran during the pose half: in the mode kernels' launches, or on the side stream)
+        p.cum_done = p.fb_done && cum_rode;                      // (and the last mode kernel prepared the projective maps)
+        fb_rode = false; cum_rode = false;
         if (with_world_scale) p.world_scale_out = world_scale_ptr();  // voldor.cpp:309-317: the pose half rides on the density launch, the depth half follows
         return optimize_depth_device(c, c->od, p);  // with world_scale_out: depth and poses leave normalised (voldor.cpp:309-317)
     }
@@ -374,22 +375,49 @@ struct Voldor {
         if (!S.rig2.p) return;
         fb_ride_plan(w, h, n_flows, n_dp, S.rig.as<float>(), S.rig2.as<float>(), S.confs.as<float>(), &fbp);
     }
-    FbRide ride_of_camera(int i) const {
+    FbRide ride_of_camera(int i, bool cum_ok) const {
         FbRide r = fb_ride_of_camera(fbp, i, n_flows, w, h, cfg.fb_emm, cfg.fb_no_change_prob);
-        if (fbp.on && i == n_flows - 1) { r.cum_N = n_flows; r.cum_Ndp = n_dp; r.world_scale = (cfg.norm_world_scale && n_dp == 0) ? world_scale_ptr() : nullptr; }
+        if (cum_ok && i == n_flows - 1) { r.cum_N = n_flows; r.cum_Ndp = n_dp; r.world_scale = (cfg.norm_world_scale && n_dp == 0) ? world_scale_ptr() : nullptr; }
         return r;
+    }
+    // fb_smooth of the coming depth half NEXT TO the pose half on a second stream (round 6), in strict mode: the reference's recurrence step by step is
+    // ~100 waves walking w or h dependent steps with two IEEE divisions each -- 0.2 ms per EM iteration at 640x480, 0.3 ms at 1241x376 -- on a chip the
+    // strict pose half (16 waves of mode kernel, 128 of P3P) leaves just as idle.  Same dependencies as the riders: the smoothing reads what the last
+    // E-step left and the pose half only READS the rigidness maps (the traces), so the row pass writes rig -> rig2, the column pass works on rig2, the
+    // prior confidences in place (no trace reads them); the streams fork after the last launch before the cameras and join before the depth half; rig
+    // and rig2 then change names.  The kernels are the depth half's own: every output bit of a window unchanged (tests/test_gpu_riders.py).  Measured,
+    // reference mode: cfg2 13.5 -> 12.2 ms, cfg3 29.2 -> 24.7 ms per window.  NOT in the fast mode: there the one pass that cannot ride (40-step segments,
+    // 1080p) is 110 us of memory traffic that then competes with the traces of the pose half -- 28.2 -> 28.4 ms per cfg5 window, measured and left out
+    // (profiles/r06_summary.md).
+    bool cum_rode = false;
+    bool plan_fb_side() const {
+        return strict && !fbp.on && cfg.fb_smooth && cfg.optimize_depth && debug_switches().fb_side && g_window_alone && c->od.rig2.p && n_flows >= 1;
+    }
+    int launch_fb_side() {
+        ImageSet& S = c->od;
+        VK_CHECK(hipEventRecord(c->ev_fork, c->stream));
+        VK_CHECK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
+        if (int e = fb_smooth_strict_device(c, S.rig.as<float>(), n_flows, w, h, cfg.fb_emm, cfg.fb_no_change_prob, nullptr, S.rig2.as<float>(), c->side_stream)) return e;
+        if (int e = fb_smooth_strict_device(c, S.confs.as<float>(), n_dp, w, h, cfg.fb_emm, cfg.fb_no_change_prob, nullptr, nullptr, c->side_stream)) return e;
+        VK_CHECK(hipEventRecord(c->ev_join, c->side_stream));
+        return 0;
     }
     int enqueue_cameras() {
         const bool rg = cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0);
         plan_fb_ride(rg);
+        const bool side = plan_fb_side();
+        if (side) { if (int e = launch_fb_side()) return e; c->dbg_fb_side_passes++; }
+        const bool during = fbp.on || side;      // fb_smooth of the coming depth half happens during this pose half
+        const bool cum_ok = during && !strict && !rg;  // ... and the last mode kernel (not the refit kernel: no LDS left) can prepare the projective maps
         for (int i = 0; i < n_flows; i++) {
             // (first EM iteration of a host-memory call: frame i arrives while camera i - 1 runs.  CUDA's linear filter over the STACK of layers
             // -- --reference_tex 1 -- blends the bottom row of layer i with the top row of layer i + 1 (vk_ref_cuda.h:133-149): one frame more)
             if (int e = upload_frames_up_to(ref_tex ? i + 2 : i + 1)) return e;
-            const FbRide ride = ride_of_camera(i);
-            if (int e = optimize_camera_pose(i, rg, i == n_flows - 1, fbp.on ? &ride : nullptr)) return e;
+            const FbRide ride = ride_of_camera(i, cum_ok);
+            if (int e = optimize_camera_pose(i, rg, i == n_flows - 1, (fbp.on || (cum_ok && i == n_flows - 1)) ? &ride : nullptr)) return e;
         }
-        if (fbp.on) { std::swap(c->od.rig, c->od.rig2); fb_rode = true; }  // the smoothed maps are `rig` from here on
+        if (side) VK_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
+        if (during) { std::swap(c->od.rig, c->od.rig2); fb_rode = true; cum_rode = cum_ok; }  // the smoothed maps are `rig` from here on
         if (int e = upload_frames_up_to(n_flows_init)) return e;
         // rigidness densities (reduced on the device by the last optimize_depth, voldor.cpp:171) and results: the last camera's kernel
         // has stored what the host needs into pinned memory (CamBrief); the event marks it complete
@@ -426,12 +454,17 @@ struct Voldor {
                   << "last used gu iters = " << s.last_used_gu_iters << std::endl << std::endl;
     }
 
+    int bootstrap_points_of() const {  // --bootstrap_points, -1 = the default: five-point in the fast mode, 8-point in strict mode (Config::bootstrap_points)
+        if (cfg.bootstrap_points == 5 || cfg.bootstrap_points == 8) return cfg.bootstrap_points;
+        const int d = debug_switches().bootstrap_default;
+        return d ? d : (strict ? 8 : 5);
+    }
     // voldor.cpp:130-149
     int solve() {
         if (int e = upload_frames_up_to(ref_tex ? 2 : 1)) return e;
         if (n_dp == 0) {  // bootstrap :151-162
             if (c->prof) prof_begin(c);
-            if (int e = bootstrap_device(c, c->od, w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, dcams(), strict, cfg.bootstrap_points == 5 || (cfg.bootstrap_points == -1 && !strict) ? 5 : 8)) return e;
+            if (int e = bootstrap_device(c, c->od, w, h, cfg.fx, cfg.fy, cfg.cx, cfg.cy, dcams(), strict, bootstrap_points_of())) return e;
             if (c->prof) prof_end(c, "bootstrap");
         }
         while (iters_remain > 0 && n_flows > 0) {
@@ -473,7 +506,11 @@ static int voldor_run_on(Context* c, const float* flows, const float* disparity,
     // holds raw pointers into buffers a later call may re-reserve), and the copy stream must be done with the caller's flow buffer
     struct WindowGuard {
         Context* c; Voldor* v;
-        ~WindowGuard() { c->pending_reduce = ReduceArgs(); if (v->copies_in_flight) { (void)hipStreamSynchronize(c->copy_stream); v->copies_in_flight = false; } }
+        ~WindowGuard() {
+            c->pending_reduce = ReduceArgs();
+            if (v->copies_in_flight) { (void)hipStreamSynchronize(c->copy_stream); v->copies_in_flight = false; }
+            (void)hipStreamSynchronize(c->side_stream);  // (a window that failed between fork and join: nothing of it may still run when the next one starts; idle otherwise)
+        }
     } guard{ c, &v };
     v.cfg.fx = fx; v.cfg.cx = cx; v.cfg.fy = fy; v.cfg.cy = cy; v.cfg.basefocal = basefocal;  // py_export.cpp:19-25
     if (int e = v.cfg.read_config(config ? config : "")) return 1000 + e;
