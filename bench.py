@@ -50,16 +50,32 @@ sys.path.insert(0, ROOT)
 # GPU_MAX_HW_QUEUES hardware queues (default 4, shared with torch's streams), and streams that share a queue serialise.
 # Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-# cpu_baseline (the oracle on the host cores, OpenMP): threads pinned to cores so that the figure does not wander from run to run (0.126-0.32
-# frames/s across rounds on the same code).  libgomp reads these when it loads -- torch brings it in -- so they are set here; single-process runs only
-# (several ranks of one node must not pin their threads onto the same cores).
-if int(os.environ.get("WORLD_SIZE", "1")) == 1:
-    os.environ.setdefault("OMP_PROC_BIND", "close")
-    os.environ.setdefault("OMP_PLACES", "cores")
 
-import numpy as np
-import torch  # noqa: E402  (first: shares its HIP runtime with libvoldor_hip.so)
-import torch.distributed as dist  # noqa: E402
+
+def _cpu_leg():
+    """`python bench.py --cpu-leg <workload> <windows>`: the cpu_baseline leg in a process of its own (round 6).  The oracle's OpenMP threads are pinned to
+    cores (OMP_PROC_BIND=close, OMP_PLACES=cores: the figure wandered 0.126-0.32 frames/s across rounds on the same code) -- but libgomp binds
+    the INITIAL thread as well, and every thread the process starts later inherits that mask: set in the bench process itself it put the four worker
+    threads of the `concurrent` leg onto one core (651 -> 430 windows/s, measured).  So the pinning lives in this child only.  No torch here."""
+    import numpy as np
+    from oracle import orc
+    from voldor_amd import synth
+    wl = WORKLOADS[sys.argv[sys.argv.index("--cpu-leg") + 1]]
+    nwin = int(sys.argv[sys.argv.index("--cpu-leg") + 2])
+    sc = synth.make_scene(w=wl["w"], h=wl["h"], n_flows=wl["n"], fx=wl["fx"], fy=wl["fx"], cx=wl["cx"], cy=wl["cy"], seed=233,
+                          basefocal=wl["basefocal"] if wl["mode"] != "mono" else 0.0)
+    orc.build()
+    extra = dict(basefocal=wl["basefocal"], disparity=sc["disparity"]) if wl["mode"] == "stereo" else {}
+    orc.voldor(sc["flows"][:, :60, :80].copy(), 40.0, 40.0, 40.0, 30.0, config="--silent --max_iters 1")  # warm-up
+    tws, ref = [], None
+    for _ in range(nwin):
+        t0 = time.perf_counter()
+        ref = orc.voldor(sc["flows"], wl["fx"], wl["fx"], wl["cx"], wl["cy"], config=wl["cfg"], **extra)
+        tws.append(time.perf_counter() - t0)
+    print(json.dumps({"tws": tws, "cores": orc.max_threads(), "poses": np.asarray(ref["poses"], np.float64).tolist(), "n_registered": int(ref["n_registered"]),
+                      "bind": os.environ.get("OMP_PROC_BIND"), "places": os.environ.get("OMP_PLACES")}), flush=True)
+
+
 
 # BASELINE.json configs; cfg2 (configs[1]) is the one the metric is quoted on and the default.  cfg3 / cfg5 are extra
 # measurement points (--workload), never the headline value.
@@ -75,6 +91,13 @@ WORKLOADS = {
                  name="BASELINE cfg5: 1920x1080, N_flow=10, disparity prior from depth (RGB-D), 12 EM iterations + fb_smooth"),
 }
 HBM_PEAK_GBS = 8000.0
+if "--cpu-leg" in sys.argv:  # (before torch: the child of the cpu_baseline leg)
+    _cpu_leg()
+    raise SystemExit(0)
+
+import numpy as np
+import torch  # noqa: E402  (first: shares its HIP runtime with libvoldor_hip.so)
+import torch.distributed as dist  # noqa: E402
 KERNEL_SOURCES = ("vk_depth.hip", "vk_depth_impl.hpp", "vk_fb.hpp", "vk_cum_poses.hpp", "vk_pose.hip", "vk_device.hpp", "vk_p3p.hpp", "vk_common.hpp")  # what the replayed counter passes were taken on
 
 
@@ -735,21 +758,24 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            from oracle import orc
-            orc.build()
-            cores = orc.max_threads()
-            orc.voldor(sc["flows"][:, :60, :80].copy(), 40.0, 40.0, 40.0, 30.0, config="--silent --max_iters 1")  # warm-up
-            tws = []
-            for _ in range(args.cpu_windows):
-                t0 = time.perf_counter()
-                ref = orc.voldor(sc["flows"], FX, FY, CX, CY, config=CONFIG,
-                                 **{k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in extra.items()})
-                tws.append(time.perf_counter() - t0)
+            import subprocess
+            try:
+                import psutil
+                ncores = psutil.cpu_count(logical=False) or (os.cpu_count() or 2) // 2
+            except Exception:
+                ncores = max(1, (os.cpu_count() or 2) // 2)
+            # one thread per PHYSICAL core, pinned (two per core on the hyper-threads with spinning barriers: 32 s per window instead of 3.6, measured)
+            env = dict(os.environ, OMP_PROC_BIND="close", OMP_PLACES="cores", OMP_NUM_THREADS=str(ncores))
+            pr = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-leg", args.workload, str(args.cpu_windows)], env=env, cwd=ROOT,
+                                stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+            doc = json.loads(pr.stdout.decode().strip().splitlines()[-1])
+            tws, cores = doc["tws"], doc["cores"]
+            ref = {"poses": np.asarray(doc["poses"], np.float32)}
             rot, tr = synth.pose_errors(out["poses"], ref["poses"])
             med = float(np.median(tws))
             cpu = {"value": round(1.0 / med, 4), "unit": "frames/s", "cores": cores, "kind": "port",
                    "sample": f"{args.cpu_windows} windows of the same {W}x{H} N_flow={N_FLOW} {EM_ITERS}-iteration workload, each timed; value = 1 / median; oracle/liborc.so (C restatement, OpenMP {cores} threads, "
-                             f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')} OMP_PLACES={os.environ.get('OMP_PLACES')})",
+                             f"in a child process with OMP_PROC_BIND={doc['bind']} OMP_PLACES={doc['places']})",
                    "s_per_window": {"min": round(float(np.min(tws)), 3), "median": round(med, 3), "max": round(float(np.max(tws)), 3)},
                    "value_best": round(1.0 / float(np.min(tws)), 4),
                    "pose_vs_gpu": {"rot_rad_max": float(rot.max()) if len(rot) else None, "rel_trans_max": float(tr.max()) if len(tr) else None}}

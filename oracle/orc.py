@@ -340,17 +340,20 @@ def two_view_pose(flow0, K):
 
 
 def ref_voldor(flows, fx, fy, cx, cy, basefocal=0.0, disparity=None, depth_priors=None, depth_prior_poses=None,
-               depth_prior_pconfs=None, config="", rand_epoch=0):
+               depth_prior_pconfs=None, config="", rand_epoch=0, two_view=None):
     """The REFERENCE's own py_voldor_wrapper (voldor/py_export.cpp) executed on the CPU through oracle/_ref
     (ref_wrap_host.cpp: voldor/*.cpp compiled in place on minicv + the reference's kernel files on the launch emulation).
-    Single-threaded.  Monocular windows get the oracle's two-view pose injected.  Raises if oracle/_ref is not built."""
+    Single-threaded.  Monocular windows get a two-view pose injected where the reference calls OpenCV: the oracle's 8-point one, or `two_view` = (R 3x3, t 3,
+    the unit translation BEFORE the reference's cam.t = R t) when the caller brings its own (tests/golden/gen_golden_ensemble.py --five-point).  Raises if
+    oracle/_ref is not built."""
     r = ref()
     if r is None or not hasattr(r, "ref_py_voldor_wrapper"):
         raise RuntimeError("oracle/_ref with the host pipeline is not built on this box")
     flows = f32(flows)
     N, h, w, _ = flows.shape
     if disparity is None and depth_priors is None:
-        R, t = two_view_pose(flows[0], np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], np.float32))
+        R, t = two_view if two_view is not None else two_view_pose(flows[0], np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], np.float32))
+        R, t = np.asarray(R, np.float32), np.asarray(t, np.float32)
         D = C.POINTER(C.c_double)
         R64, t64 = R.astype(np.float64), t.astype(np.float64)
         r.ref_set_two_view_pose(R64.ctypes.data_as(D), t64.ctypes.data_as(D))

@@ -35,8 +35,12 @@ MODES = {"g": (0, 0), "jA": (2, 1), "jB": (2, 2), "strict": (1, 0)}
 SUB = 8
 
 
+FIVE_POINT = "--five-point" in sys.argv  # cfg2 only, into ref_ensemble5.npz: the reference pipeline started from the product's five-point two-view pose (round 6)
+
+
 def run_one(job):
-    kind, seed, mode = job
+    kind, seed, mode = job[:3]
+    five = len(job) > 3 and job[3]
     os.environ["OMP_NUM_THREADS"] = "1"
     from gen_golden_window import run_reference
     from oracle import orc
@@ -47,14 +51,14 @@ def run_one(job):
     if m == 1:
         orc.lib().orc_set_strict_math(1)  # the injected two-view pose: one mode throughout
     t0 = time.time()
-    r = run_reference(c)
+    r = run_reference(c, five_point=five)
     dt = time.time() - t0
     ref.ref_set_math_mode(0); ref.ref_set_jitter_salt(0)
     out = {"n_registered": np.int32(r["n_registered"]), "poses": r["poses"], "poses_covar": r["poses_covar"],
            "depth_sub": r["depth"][::SUB, ::SUB].copy(), "conf_sub": r["depth_conf"][::SUB, ::SUB].copy(),
            "depth_sha256": np.frombuffer(hashlib.sha256(r["depth"].tobytes()).digest(), np.uint8),
            "conf_sha256": np.frombuffer(hashlib.sha256(r["depth_conf"].tobytes()).digest(), np.uint8)}
-    return job, out, dt
+    return job[:3], out, dt
 
 
 def main():
@@ -62,19 +66,24 @@ def main():
     jobs = [("cfg2", 233, "strict")]
     jobs += [("cfg3", s, m) for s in ens.CFG3_SEEDS for m in ("g", "jA", "jB")]  # the long ones first
     jobs += [("cfg2", s, m) for s in ens.CFG2_SEEDS for m in ("g", "jA", "jB")]
+    if FIVE_POINT:
+        jobs = [("cfg2", s, m, True) for s in ens.CFG2_SEEDS for m in ("g", "jA", "jB")]
     out = {}
-    path = os.path.join(HERE, "ref_ensemble.npz")
+    path = os.path.join(HERE, "ref_ensemble5.npz" if FIVE_POINT else "ref_ensemble.npz")
     if os.path.exists(path) and "--fresh" not in sys.argv:  # incremental: runs already in the file are kept (each is a pure function of (kind, seed, mode))
         with np.load(path) as old:
             out = {k: old[k] for k in old.files}
         jobs = [j for j in jobs if f"{j[0]}/s{j[1]}/{j[2]}/n_registered" not in out]
         print(f"{len(out)} arrays kept, {len(jobs)} runs to do", flush=True)
-    t0 = time.time()
+    t0 = time.time(); done = 0
     with mp.get_context("spawn").Pool(workers, maxtasksperchild=1) as pool:
         for (kind, seed, mode), r, dt in pool.imap_unordered(run_one, jobs):
             for k, v in r.items():
                 out[f"{kind}/s{seed}/{mode}/{k}"] = v
             print(f"[{time.time() - t0:6.0f}s] {kind} seed {seed} {mode:6s} n_registered {int(r['n_registered'])}  ({dt:.0f} s)", flush=True)
+            done += 1
+            if done % 30 == 0:  # (a run is ~20-60 s of one core: keep what is there if the generator is interrupted)
+                np.savez_compressed(path, **out)
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(out)} arrays, {os.path.getsize(path) / 1024:.0f} KiB")
 

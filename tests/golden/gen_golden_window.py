@@ -24,15 +24,29 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import ref_window_cases as cases  # noqa: E402
 from oracle import orc  # noqa: E402
 
-def run_reference(c, rand_epoch=0):
+def five_point_two_view(flow0, K9):
+    """(R, unit t before cam.t = R t) of the PRODUCT's five-point LMedS bootstrap, from the host build of its own source (voldor_amd/csrc/vk_bootstrap.hip
+    lmeds_essential_host5: the kernels give these bits, tests/test_fivept.py) -- what a window of the fast mode starts from since round 6.  The product returns
+    t = R t_b (geometry.cpp:330): t_b = R^T t."""
+    from voldor_amd import kernels
+    ok, R, t = kernels.estimate_pose_epipolar5(flow0, K9)
+    if not ok:
+        raise RuntimeError("five-point bootstrap failed")
+    tb = (R.astype(np.float64).T @ t.astype(np.float64))
+    return np.ascontiguousarray(R, np.float32), (tb / np.linalg.norm(tb)).astype(np.float32)
+
+
+def run_reference(c, rand_epoch=0, five_point=False):
     fx, fy, cx, cy = c["K"]
-    injected = None
+    injected, two_view = None, None
     if c["disparity"] is None and c["depth_priors"] is None:  # monocular: orc.ref_voldor injects this two-view pose (D5)
-        R, t = orc.two_view_pose(c["flows"][0], np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], np.float32))
+        K9 = np.array([fx, 0, cx, 0, fy, cy, 0, 0, 1], np.float32)
+        R, t = five_point_two_view(c["flows"][0], K9) if five_point else orc.two_view_pose(c["flows"][0], K9)
         injected = np.concatenate([R.reshape(9), t])
+        two_view = (R, t) if five_point else None
     r = orc.ref_voldor(c["flows"], fx, fy, cx, cy, basefocal=c["basefocal"], disparity=c["disparity"], depth_priors=c["depth_priors"],
                        depth_prior_poses=c["depth_prior_poses"], depth_prior_pconfs=c["depth_prior_pconfs"], config=c["ref_config"],
-                       rand_epoch=rand_epoch)
+                       rand_epoch=rand_epoch, two_view=two_view)
     r["injected"] = injected
     return r
 

@@ -26,6 +26,7 @@ import stat_helpers as sh
 
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("eight_point_bootstrap")]  # (fast windows here are held against the oracle / the reference ensembles: same two-view pose, conftest.py)
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "ref_ensemble.npz")
+GOLD5 = os.path.join(os.path.dirname(__file__), "golden", "ref_ensemble5.npz")  # the cfg2 ensemble again, the reference pipeline started from the five-point two-view pose (round 6)
 SUB = 8
 ALPHA = 0.01
 FS_SEEDS = ens.CFG2_SEEDS  # windows of the fast-vs-strict test (a strict window costs ~15 ms since round 4)
@@ -60,12 +61,23 @@ def _gt_errors(run, c, mono):
             "depth": float(np.median(np.abs(run["depth"][m] - dgt[m]) / dgt[m])) if m.sum() >= 50 else float("nan")}
 
 
-@pytest.mark.parametrize("kind,seeds", [("cfg2", ens.CFG2_SEEDS), ("cfg3", ens.CFG3_SEEDS)])
+@pytest.mark.parametrize("kind,seeds", [("cfg2", ens.CFG2_SEEDS), ("cfg3", ens.CFG3_SEEDS), ("cfg2-five-point", ens.CFG2_SEEDS)])
 def test_fast_path_is_a_draw_from_the_reference_self_noise(kind, seeds):
+    """cfg2 / cfg3: the fast path started from the 8-point two-view pose (the module's fixture) against the reference pipeline started from the same pose.
+    cfg2-five-point (round 6): the fast path as it ships -- five-point LMedS bootstrap -- against the reference pipeline started from THAT pose
+    (tests/golden/ref_ensemble5.npz: gen_golden_ensemble.py --five-point injects the pose of the product's own host build where the reference calls OpenCV)."""
+    import hooks
     from voldor_amd import kernels, pyvoldor
-    if not os.path.exists(GOLD):
-        pytest.skip("tests/golden/ref_ensemble.npz not generated")
-    g = np.load(GOLD)
+    gold = GOLD
+    if kind == "cfg2-five-point":
+        gold, kind = GOLD5, "cfg2"
+        prev = hooks.debug_switch("bootstrap_default", 0)  # the product's default (the fixture set 8 and restores its own previous value after the test)
+        assert prev == 8
+    if not os.path.exists(gold):
+        pytest.skip(f"{os.path.relpath(gold)} not generated")
+    g = np.load(gold)
+    seeds = [s_ for s_ in seeds if f"{kind}/s{s_}/jB/n_registered" in g.files and f"{kind}/s{s_}/g/n_registered" in g.files and f"{kind}/s{s_}/jA/n_registered" in g.files]
+    assert len(seeds) >= 24, len(seeds)
     mono = kind == "cfg2"
     d_hip = {k: [] for k in sh.METRICS}
     d_ref = {k: [] for k in sh.METRICS}
@@ -92,7 +104,7 @@ def test_fast_path_is_a_draw_from_the_reference_self_noise(kind, seeds):
         eh, er = _gt_errors(hip, c, mono), _gt_errors(rg, c, mono)
         for k in e_hip:
             e_hip[k].append(eh[k]); e_ref[k].append(er[k])
-    _dump(f"ensemble_{kind}", {"d_hip": d_hip, "d_ref": d_ref, "e_hip": e_hip, "e_ref": e_ref, "seeds": list(seeds)})
+    _dump(f"ensemble_{kind}" + ("_five_point" if gold == GOLD5 else ""), {"d_hip": d_hip, "d_ref": d_ref, "e_hip": e_hip, "e_ref": e_ref, "seeds": list(seeds)})
     report = {}
     fails = []
     for k in sh.METRICS:  # (i) KS: "one distribution" cannot be rejected; and the EFFECT SIZE: median ratio inside the equivalence margin

@@ -22,16 +22,27 @@ int Context::init(int dev) {
     VK_CHECK(hipEventCreate(&ev2));
     VK_CHECK(hipEventCreate(&ev3));
     VK_CHECK(hipEventCreateWithFlags(&ev_cams, hipEventDisableTiming));
-    VK_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-    VK_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
-    VK_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
-    VK_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-    for (int f = 0; f < MAX_FRAMES; f++) VK_CHECK(hipEventCreateWithFlags(&ev_frame[f], hipEventDisableTiming));
+    // (copy_stream / side_stream and their events: created when first needed -- ensure_copy_stream / ensure_side_stream.  ROCm maps streams onto a few
+    // hardware queues and streams that share one serialise: a context that never uploads from the host and never runs strict mode keeps ONE stream, so
+    // four windows in flight stay on four queues)
     VK_CHECK(hipHostMalloc((void**)&h_cams, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
     VK_CHECK(hipHostMalloc((void**)&h_pb, sizeof(PoseBlock), hipHostMallocDefault));
     VK_CHECK(hipHostMalloc((void**)&h_cams_up, sizeof(CamState) * MAX_FRAMES, hipHostMallocDefault));
     VK_CHECK(hipHostMalloc((void**)&h_brief, sizeof(CamBrief) * MAX_FRAMES, hipHostMallocMapped));
     VK_CHECK(hipHostGetDevicePointer((void**)&h_brief_dev, h_brief, 0));
+    return 0;
+}
+int Context::ensure_copy_stream() {
+    if (copy_stream) return 0;
+    VK_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+    for (int f = 0; f < MAX_FRAMES; f++) VK_CHECK(hipEventCreateWithFlags(&ev_frame[f], hipEventDisableTiming));
+    return 0;
+}
+int Context::ensure_side_stream() {
+    if (side_stream) return 0;
+    VK_CHECK(hipStreamCreateWithFlags(&side_stream, hipStreamNonBlocking));
+    VK_CHECK(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+    VK_CHECK(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     return 0;
 }
 void Context::destroy() {

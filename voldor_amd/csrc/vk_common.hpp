@@ -239,6 +239,8 @@ struct Context {
     CamState* h_cams = nullptr;    // pinned staging for that copy (a pageable destination would make the copy synchronous)
     int ensure_n_points() { return n_points.reserve(sizeof(int) * 4); }
     int init(int dev);
+    int ensure_copy_stream();  // vk_abi.hip: the stream (and per-frame events) of the staggered flow upload, created at first use
+    int ensure_side_stream();  // the second stream of strict mode's fb_smooth (and its fork / join events), created at first use
     void destroy();
 };
 

@@ -197,6 +197,7 @@ struct Voldor {
     bool copies_in_flight = false;
     int upload_frames_up_to(int upto) {
         if (!host_flows) return 0;
+        if (int e = c->ensure_copy_stream()) return e;
         const size_t fb = sizeof(float) * 2 * (size_t)w * h;
         for (; frames_up < upto && frames_up < n_flows_init; frames_up++) {
             VK_CHECK(hipMemcpyAsync(c->od.flows.as<char>() + (size_t)frames_up * fb, reinterpret_cast<const char*>(host_flows) + (size_t)frames_up * fb, fb, hipMemcpyHostToDevice, c->copy_stream));
@@ -225,6 +226,8 @@ struct Voldor {
         n_dp = N_dp_in + (disparity ? 1 : 0);
         has_disparity = disparity != nullptr;
         if (N < 1 || N > MAX_FRAMES || n_dp > MAX_DISP_FRAMES || w <= 0 || h <= 0) return (int)hipErrorInvalidValue;
+        if (cfg.kitti_estimate_ground && !cfg.silent)  // (parsed and silently ignored)
+            std::cout << "--kitti_estimate_ground 1: ground-plane scale estimation (voldor/voldor.cpp:146-147, :320-) is outside this library's scope (SURVEY section 2: OUT OF SCOPE); the window is computed without it" << std::endl;
         if (cfg.resize_factor != 1.f) {
             std::cout << "resize_factor != 1 is deprecated in the reference (config.h:23) and not supported" << std::endl;
             return (int)hipErrorInvalidValue;
@@ -389,12 +392,13 @@ struct Voldor {
     // reference mode: cfg2 13.5 -> 12.2 ms, cfg3 29.2 -> 24.7 ms per window.  NOT in the fast mode: there the one pass that cannot ride (40-step segments,
     // 1080p) is 110 us of memory traffic that then competes with the traces of the pose half -- 28.2 -> 28.4 ms per cfg5 window, measured and left out
     // (profiles/r06_summary.md).
-    bool cum_rode = false;
+    bool cum_rode = false, side_used = false;
     bool plan_fb_side() const {
         return strict && !fbp.on && cfg.fb_smooth && cfg.optimize_depth && debug_switches().fb_side && g_window_alone && c->od.rig2.p && n_flows >= 1;
     }
     int launch_fb_side() {
         ImageSet& S = c->od;
+        if (int e = c->ensure_side_stream()) return e;
         VK_CHECK(hipEventRecord(c->ev_fork, c->stream));
         VK_CHECK(hipStreamWaitEvent(c->side_stream, c->ev_fork, 0));
         if (int e = fb_smooth_strict_device(c, S.rig.as<float>(), n_flows, w, h, cfg.fb_emm, cfg.fb_no_change_prob, nullptr, S.rig2.as<float>(), c->side_stream)) return e;
@@ -406,7 +410,7 @@ struct Voldor {
         const bool rg = cfg.rg_refine && (!cfg.rg_refine_last_only || iters_remain == 0);
         plan_fb_ride(rg);
         const bool side = plan_fb_side();
-        if (side) { if (int e = launch_fb_side()) return e; c->dbg_fb_side_passes++; }
+        if (side) { side_used = true; if (int e = launch_fb_side()) return e; c->dbg_fb_side_passes++; }
         const bool during = fbp.on || side;      // fb_smooth of the coming depth half happens during this pose half
         const bool cum_ok = during && !strict && !rg;  // ... and the last mode kernel (not the refit kernel: no LDS left) can prepare the projective maps
         for (int i = 0; i < n_flows; i++) {
@@ -508,8 +512,8 @@ static int voldor_run_on(Context* c, const float* flows, const float* disparity,
         Context* c; Voldor* v;
         ~WindowGuard() {
             c->pending_reduce = ReduceArgs();
-            if (v->copies_in_flight) { (void)hipStreamSynchronize(c->copy_stream); v->copies_in_flight = false; }
-            (void)hipStreamSynchronize(c->side_stream);  // (a window that failed between fork and join: nothing of it may still run when the next one starts; idle otherwise)
+            if (v->copies_in_flight && c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); v->copies_in_flight = false; }
+            if (v->side_used && c->side_stream) (void)hipStreamSynchronize(c->side_stream);  // (a window that failed between fork and join: nothing of it may still run when the next one starts)
         }
     } guard{ c, &v };
     v.cfg.fx = fx; v.cfg.cx = cx; v.cfg.fy = fy; v.cfg.cy = cy; v.cfg.basefocal = basefocal;  // py_export.cpp:19-25
