@@ -278,14 +278,14 @@ def main():
                     self.sw(k, v)
             return False
 
-    def fb_blocks_per_call(w_, h_, n_, ndp_):  # blocks of one riding fb_smooth (rows + columns), 0 where this geometry does not ride (vk_debug_fb_ride_plan: host arithmetic)
+    def fb_blocks_per_call(w_, h_, n_, ndp_):  # (slots of one riding fb_smooth (rows + columns), maps that ride); (0, 0) where this geometry does not ride (vk_debug_fb_ride_plan: host arithmetic)
         try:
             outp = (C.c_int * (5 + 3 * 16))()
             if lib.vk_debug_fb_ride_plan(w_, h_, n_, ndp_, outp, len(outp)) > 0 and outp[0]:
-                return int(outp[2] + outp[3])
+                return int(outp[2] + outp[3]), n_ + (ndp_ if outp[0] == 2 else 0)  # (outp[0] = stacks that ride: 1 = the rigidness maps alone)
         except Exception:
             pass
-        return 0
+        return 0, 0
     frontend, frontend_note = None, None
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -447,10 +447,10 @@ def main():
             groups_plain = None
         tot, cnt = C.c_double(0), C.c_long(0)
         b_od = W * H * (40 * N_FLOW + 36 * n_dp + 12)  # bytes per optimize_depth call
-        b_fb = W * H * 16 * (N_FLOW + n_dp)            # of which fb_smooth: rows and columns, each map read once and written once per pass (SURVEY 8(d) S1 + S2)
         # fraction of this window's optimize_depth calls whose fb_smooth rode in the pose half: blocks that rode / blocks of a call (host-side dealing, vk_debug_fb_ride_plan)
         rode_frac = 0.0
-        bpc = fb_blocks_per_call(W, H, N_FLOW, n_dp)
+        bpc, maps_rode = fb_blocks_per_call(W, H, N_FLOW, n_dp)
+        b_fb = W * H * 16 * maps_rode                  # (the maps that ride)
         if fb_rode and bpc and "optimize_depth" in groups:
             rode_frac = min(1.0, fb_rode / float(bpc * nprof * groups["optimize_depth"]["calls_per_window"]))
         # Dominant streaming kernel of the path: k_cost_rand_q (cost map + 10 random depth samples per pixel, one launch per
@@ -557,7 +557,7 @@ def main():
                         "algorithmic_bytes": b_od, "avg_us": round(t_plain * 1e6, 2), "achieved": round(b_od / t_plain / 1e9, 2),
                         "note": "the like-for-like series with rounds 1-4 and SURVEY 8(d): B_od = w*h*(40N+36N_dp+12) over the group timed with fb_smooth and the density "
                                 "reduction as launches of their own inside it (vk_debug_switch fb_ride = 0, defer_reduce = 0, same run).  `frac` above: fb_smooth's "
-                                f"w*h*16*(N+N_dp) = {b_fb} bytes are taken out of the numerator for the {rode_frac:.3f} of the calls in which it rode in the pose half"},
+                                f"w*h*16*(maps that ride) = {b_fb} bytes are taken out of the numerator for the {rode_frac:.3f} of the calls in which it rode in the pose half"},
                     "fb_smooth_rode_frac_of_calls": round(rode_frac, 4),
                     "kernels": ktable, "sweeps": sweeps,
                     "traffic": None if group_traffic is None else round(group_traffic),
@@ -696,9 +696,9 @@ def main():
                 except Exception:
                     g_plain = None
                 ob = ow["w"] * ow["h"] * (40 * ow["n"] + 36 * 1 + 12)
-                o_bpc = fb_blocks_per_call(ow["w"], ow["h"], ow["n"], 1)
+                o_bpc, o_maps = fb_blocks_per_call(ow["w"], ow["h"], ow["n"], 1)
                 o_rf = min(1.0, o_rode / float(o_bpc * 2 * ow["iters"])) if o_bpc else 0.0  # (two profiled windows of ow["iters"] calls)
-                ob_in = ob - o_rf * ow["w"] * ow["h"] * 16 * (ow["n"] + 1)
+                ob_in = ob - o_rf * ow["w"] * ow["h"] * 16 * o_maps
                 t_all = g_.get("optimize_depth", 0.0) * 1e-6
                 t_pl = (g_plain or {}).get("optimize_depth", 0.0) * 1e-6
                 ts_ = []

@@ -22,6 +22,11 @@ CASES = {
     "refit_in_every_iteration": dict(w=320, h=240, n=4, cfg=MONO + " --rg_refine_last_only 0"),
     "no_fb_smooth": dict(w=320, h=240, n=4, cfg=MONO + " --fb_smooth 0"),
     "truncates": dict(w=160, h=120, n=5, cfg=MONO + " --max_iters 6", noise_from=3),
+    # round 6: every stack rides in the segments its own launches use -- a tall window: rows in 12-step, columns in 20-step segments (rounds 1-5: no riding there)
+    "tall_rows_12_columns_20": dict(w=400, h=800, n=3, cfg=MONO.replace("--max_iters 4", "--max_iters 3")),
+    "tall_with_prior": dict(w=300, h=900, n=4, cfg=STEREO.replace("--max_iters 4", "--max_iters 3"), basefocal=40.0),
+    # 40-step segments (what 1080p windows get; forced here on a small one) do not ride -- measured in round 6, vk_voldor.hip fb_ride_plan
+    "forty_step_segments": dict(w=320, h=240, n=5, cfg=MONO, switches={"fb_segment": 40}),
 }
 
 
@@ -35,7 +40,9 @@ def _run(case, switches, device):
     if "noise_from" in c:
         flows[c["noise_from"]:] = np.random.default_rng(0).uniform(-40, 40, flows[c["noise_from"]:].shape).astype(np.float32)
     fx, fy, cx, cy = sc["K"]
+    switches = dict(c.get("switches", {}), **switches)
     prev = {k: hooks.debug_switch(k, v) for k, v in switches.items()}
+    plan = _plan_rides(c)  # (under the case's own switches: a forced segment length changes the dealing)
     hooks.debug_counter("fb_blocks_rode"); hooks.debug_counter("reduces_rode"); hooks.debug_counter("fb_side_passes")  # (read and clear)
     try:
         outs = []
@@ -53,7 +60,7 @@ def _run(case, switches, device):
     finally:
         for k, v in prev.items():
             hooks.debug_switch(k, v)
-    return outs, dict(fb_blocks=hooks.debug_counter("fb_blocks_rode"), reduces=hooks.debug_counter("reduces_rode"), side=hooks.debug_counter("fb_side_passes"))
+    return outs, dict(fb_blocks=hooks.debug_counter("fb_blocks_rode"), reduces=hooks.debug_counter("reduces_rode"), side=hooks.debug_counter("fb_side_passes"), plan=plan)
 
 
 def _plan_rides(c):
@@ -63,7 +70,7 @@ def _plan_rides(c):
     out = (C.c_int * (5 + 3 * 16))()
     n_dp = 1 if c.get("basefocal") else 0
     assert capi.lib().vk_debug_fb_ride_plan(c["w"], c["h"], c["n"], n_dp, out, len(out)) == 5 + 3 * c["n"]
-    return bool(out[0]), int(out[2]) + int(out[3])
+    return int(out[0]), int(out[2]) + int(out[3])  # (stacks that ride: 0 | 1 | 2, slots per EM iteration)
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
@@ -76,7 +83,11 @@ def test_riding_work_changes_no_bit_of_a_window(case, device):
     # next trace, and fb_smooth rides in every iteration without the refit where the dealing says the geometry allows it -- whole passes at a time
     assert rode0["fb_blocks"] == 0 and rode0["reduces"] == 0, rode0
     assert rode1["reduces"] >= 2 * 2, rode1  # two windows, at least three EM iterations each
-    on, blocks_per_iter = _plan_rides(CASES[case])
+    on, blocks_per_iter = rode1["plan"]
+    if case.startswith("tall"):
+        assert on >= 1
+    if case == "forty_step_segments":
+        assert on == 0
     expect_fb = on and "--fb_smooth 0" not in CASES[case]["cfg"] and "--rg_refine_last_only 0" not in CASES[case]["cfg"]
     if case == "truncates":
         assert rode1["fb_blocks"] > 0, rode1  # (the frame count changes on the way: the per-iteration block count with it)
@@ -116,8 +127,8 @@ def test_fb_smooth_next_to_the_pose_half_changes_no_bit_of_a_window(name):
         beside, c1 = _run("_side", dict(sc_["switches"], fb_side=1), device=False)
     finally:
         CASES.pop("_side")
-    assert c0["side"] == 0 and c0["fb_blocks"] == 0, c0
-    assert c1["side"] >= 2 * 3 and c1["fb_blocks"] == 0, c1  # two windows, every EM iteration (the refit iterations too: nothing rides in a kernel there, the stream does not care)
+    assert c0["side"] == 0 and c0["fb_blocks"] == 0, (c0["side"], c0["fb_blocks"])
+    assert c1["side"] >= 2 * 3 and c1["fb_blocks"] == 0, (c1["side"], c1["fb_blocks"])  # two windows, every EM iteration (the refit iterations too: nothing rides in a kernel there, the stream does not care)
     for a, b in zip(inside, beside):
         assert a["n_registered"] == b["n_registered"]
         for k in ("depth", "depth_conf", "poses", "poses_covar"):

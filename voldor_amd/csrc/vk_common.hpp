@@ -151,7 +151,7 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
     // Context::pending_reduce: the correspondence trace of camera 0 -- the next launch of the stream, which reads none of its results -- carries it as
     // extra workgroups.  One dependent launch per EM iteration less (2.85 us boundary + 4.9 us kernel).
     bool defer_reduce = false;
-    bool fb_done = false;  // window pipeline: fb_smooth of this call was done during the pose half (riding in the mode kernels' launches, FbRide; or on the side stream)
+    int fb_done = 0;       // window pipeline: fb_smooth of this call was done during the pose half (riding in the mode kernels' launches, FbRide; or on the side stream): bit 0 the rigidness maps, bit 1 the prior confidences
     bool cum_done = false; // fast mode: so were the projective maps of the chain and the world-scale factor (cum_poses_block in the last mode kernel)
     // --reference_stale_depth 1 (strict mode; SURVEY Appendix B-1, deviation D4 switched off): the depth map optimize_depth.cu keeps on the device.
     // With exclusive_gpu_context the reference uploads its depth map for the first call only (voldor.cpp:250-291), so from the second EM
@@ -165,11 +165,12 @@ struct OdParams {  // scalar arguments of optimize_depth_gpu (gpu_kernels.h:44-5
 // stacks of maps (the rigidness maps, the prior confidences).  The window pipeline deals the row blocks (rigidness maps out of place: the traces of the
 // later cameras still read them) and then the column blocks over the mode kernels of an EM iteration's cameras -- launches that keep one compute unit
 // busy -- so that the depth half starts at its cost kernel: two to four dependent launches per EM iteration less (vk_voldor.hip plan_fb_ride).
-struct FbStack { const float* src = nullptr; float* dst = nullptr; int n_maps = 0, S = 0, CW = 0, vec4 = 0, blocks_x = 1, n_blocks = 0; };
+struct FbStack { const float* src = nullptr; float* dst = nullptr; int n_maps = 0, S = 0, CW = 0, vec4 = 0, blocks_x = 1, n_blocks = 0, seg = 12; };  // seg: steps per lane of this pass over this stack (12 | 20 | 40)
 struct FbRide {
     int kind = 0;   // 0: nothing rides; 1: row pass src -> dst; 2: column pass in place on dst
-    int seg = 12;   // steps per lane (12 | 20)
-    int first = 0, count = 0;  // blocks [first, first + count) of the pass, stack 0's blocks then stack 1's
+    // slots [first, first + count) of the pass: stack 0's blocks, padded to an even number (`split`), then stack 1's.  first, split and the share of a launch are even, a
+    // riding workgroup takes two consecutive slots: its two halves always work on ONE stack -- one segment length, one access form, the same barriers
+    int first = 0, count = 0, split = 0;
     int w = 0, h = 0;
     float e0 = 0.f, p = 0.f;
     FbStack st[2];

@@ -37,7 +37,8 @@ int vk_debug_switch(const char* name, int value);
  * (OdParams::defer_reduce); "fb_side_passes" = fb_smooth passes it ran on the side stream next to a pose half -- counted on the host where the launch is built.  -1: unknown name / device error. */
 int vk_debug_counter(const char* name);
 /* How the 256-thread blocks of a riding fb_smooth (FbRide, vk_common.hpp) would be dealt over the mode kernels of a window with this geometry -- host
- * arithmetic only, no device.  out: [riding 0 | 1, steps per lane, row blocks R, column blocks C, launches that carry rows, then per camera: kind
+ * arithmetic only, no device.  out: [stacks that ride: 0 | 1 (the rigidness maps) | 2 (and the prior confidences), 100 x steps per lane of the rigidness maps' row pass + those of
+ * their column pass, row slots R, column slots C (a stack's blocks padded to an even number), launches that carry rows, then per camera: kind
  * (0 nothing, 1 rows, 2 columns), first block, blocks].  Returns the ints written (5 + 3 n_flows), -1 when out is too short. */
 int vk_debug_fb_ride_plan(int w, int h, int n_flows, int n_dp, int* out, int n_out);
 /* The mode kernel of the window pipeline (k_pose_mode: packed-pair mean shift; with do_rg the robust-Gaussian refit on the same registers --

@@ -1288,9 +1288,9 @@ int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_
     const bool plain = STRICT && debug_switches().strict_plain;  // strict mode on the plain launch structures of rounds 1-3 (verification: same bits either way)
     // fast mode: the projective maps of the chain (and the world-scale factor) are prepared by an extra workgroup of the first fb_smooth
     // launch when there is one, by their own small launch otherwise
-    const bool fb_done = p.fb_done && !cost_only;  // (OdParams::fb_done: fb_smooth of this call ran during the pose half)
-    const bool cum_in_fb = !STRICT && !cost_only && !p.update_rigidness_only && p.fb_smooth && p.N > 0 && !fb_done;
-    if constexpr (!STRICT) { if (!cum_in_fb && !(fb_done && p.cum_done)) cum_poses_launch(c, S.pb(), p.N, p.N_dp, p.world_scale_out); }
+    const int fb_done = cost_only ? 0 : p.fb_done;  // (OdParams::fb_done: which stacks' fb_smooth ran during the pose half)
+    const bool cum_in_fb = !STRICT && !cost_only && !p.update_rigidness_only && p.fb_smooth && p.N > 0 && !(fb_done & 1);
+    if constexpr (!STRICT) { if (!cum_in_fb && !((fb_done & 1) && p.cum_done)) cum_poses_launch(c, S.pb(), p.N, p.N_dp, p.world_scale_out); }
     auto cost_rand = [&](int n_rand, uint32_t epoch) {
         if constexpr (STRICT) {
             if (plain || debug_switches().cost_rand_plain || p.N_dp > 1) hipLaunchKernelGGL(k_cost_rand_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
@@ -1305,14 +1305,14 @@ int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_
         return 0;
     }
     if (!p.update_rigidness_only) {
-        if (p.fb_smooth && !fb_done) {
+        if (p.fb_smooth && fb_done != 3) {
             if (STRICT) {
-                if (int e = fb_smooth_strict_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active)) return e;
-                if (int e = fb_smooth_strict_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e;
+                if (!(fb_done & 1)) { if (int e = fb_smooth_strict_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active)) return e; }
+                if (!(fb_done & 2)) { if (int e = fb_smooth_strict_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e; }
             } else {
-                if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active, cum_in_fb ? S.pb() : nullptr, p.N, p.N_dp,
-                                             p.world_scale_out)) return e;
-                if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e;
+                if (!(fb_done & 1)) { if (int e = fb_smooth_device(c, I.rig, p.N, w, h, p.s0_ems_prob, p.no_change_prob, &S.pb()->n_active, cum_in_fb ? S.pb() : nullptr, p.N, p.N_dp,
+                                                                   p.world_scale_out)) return e; }
+                if (!(fb_done & 2)) { if (int e = fb_smooth_device(c, I.confs, p.N_dp, w, h, p.s0_ems_prob, p.no_change_prob, nullptr)) return e; }
             }
         }
         if (c->prof) prof_begin_inner(c);

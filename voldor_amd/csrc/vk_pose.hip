@@ -1422,30 +1422,37 @@ __device__ __forceinline__ static void pose_mode_body(const float* __restrict__ 
     }
     PH_MARK(22);
 }
-// fb_smooth blocks riding in the (non-refit) mode kernel's launch (FbRide, vk_common.hpp): workgroup q of the riders takes blocks 2 q and 2 q + 1 of its
-// range, one per 256-thread half, each half with its own LDS; both halves run the same pass on maps of one size: the same barriers.  A half past the
-// range keeps the barriers company (fb_rows_body / fb_cols_body: a block past the job).
+// fb_smooth blocks riding in the (non-refit) mode kernel's launch (FbRide, vk_common.hpp): workgroup q of the riders takes slots 2 q and 2 q + 1 of its
+// range, one per 256-thread half, each half with its own LDS.  Slots of one workgroup belong to ONE stack (FbRide::split): both halves run the same pass
+// on maps of one size in segments of one length -- the same instantiation, the same barriers.  A half past the range or in a stack's padding slot keeps the
+// barriers company (fb_rows_body / fb_cols_body: a block past the job).
 template <int SEG>
-__device__ __forceinline__ void mode_fb_ride(const FbRide& R, int q) {
+__device__ __forceinline__ void mode_fb_ride_seg(const FbRide& R, const FbStack* J, int b, bool in) {
     __shared__ FbMat s_fb[2][4][256];  // [half][sF 2 x 256 | sB 2 x 256]
     const int half = threadIdx.x >> 8, tid = threadIdx.x & 255;
-    const bool in = 2 * q + half < R.count;
-    int b = R.first + 2 * q + half;
-    const FbStack* J = &R.st[0];
-    if (in && b >= R.st[0].n_blocks) { b -= R.st[0].n_blocks; J = &R.st[1]; }
     const int bx = in ? b % J->blocks_x : (1 << 20), by = in ? b / J->blocks_x : 0;
     FbMat* sF = &s_fb[half][0][0]; FbMat* sB = &s_fb[half][2][0];
     if (R.kind == 1) {
-        if (R.st[0].vec4) fb_rows_body<true, SEG>(J->src, J->dst, R.w, R.h, J->S, R.e0, R.p, bx, by, sF, sB, tid);
+        if (J->vec4) fb_rows_body<true, SEG>(J->src, J->dst, R.w, R.h, J->S, R.e0, R.p, bx, by, sF, sB, tid);
         else fb_rows_body<false, SEG>(J->src, J->dst, R.w, R.h, J->S, R.e0, R.p, bx, by, sF, sB, tid);
     } else fb_cols_body<SEG>(J->dst, R.w, R.h, J->S, J->CW, R.e0, R.p, bx, by, sF, sB, tid);
+}
+__device__ __forceinline__ void mode_fb_ride(const FbRide& R, int q) {
+    const int half = threadIdx.x >> 8, slot = 2 * q + half, idx = R.first + slot;
+    const int s = (R.first + 2 * q) < R.split ? 0 : 1;  // (first, split even: uniform over the workgroup)
+    const FbStack* J = &R.st[s];
+    const int b = idx - (s ? R.split : 0);
+    const bool in = slot < R.count && b < J->n_blocks;
+    if (J->seg == 12) mode_fb_ride_seg<12>(R, J, b, in);
+    else if (J->seg == 20) mode_fb_ride_seg<20>(R, J, b, in);
+    else mode_fb_ride_seg<40>(R, J, b, in);
 }
 template <bool DEFER, int THREADS>
 __global__ __launch_bounds__(THREADS) static void k_pose_mode(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp, CamState* cam,
                                                                   PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev, const float* __restrict__ trials_in, FbRide ride) {
     if constexpr (!DEFER && THREADS == 512) {
         if (blockIdx.x > 0) {  // what rides along on the 255 compute units the mode kernel leaves idle (workgroup 0 is the mode kernel itself)
-            if (ride.seg == 12) mode_fb_ride<12>(ride, (int)blockIdx.x - 1); else mode_fb_ride<20>(ride, (int)blockIdx.x - 1);
+            mode_fb_ride(ride, (int)blockIdx.x - 1);
             return;
         }
     }

@@ -123,57 +123,65 @@ static thread_local bool g_window_alone = true;
 // How the blocks of a riding fb_smooth fall onto the mode kernels of an EM iteration's cameras (FbRide, vk_common.hpp; Voldor::plan_fb_ride has the
 // story).  Pure arithmetic on the window's geometry -- held to its invariants on the CPU through vk_debug_fb_ride_plan (tests/test_fb_ride_plan.py):
 // every block of the row pass in exactly one launch, then every block of the column pass, no launch with more than 480 blocks.
-struct FbRidePlan { bool on = false; int seg = 12, R = 0, C = 0, k_rows = 0, rows_per = 0, cols_per = 0; FbStack rows[2], cols[2]; };
+struct FbRidePlan { bool on = false; int n_stacks = 0, R = 0, C = 0, k_rows = 0, rows_per = 0, cols_per = 0, split_r = 0, split_c = 0; FbStack rows[2], cols[2]; };
 static void fb_ride_plan(int w, int h, int n_flows, int n_dp, const float* rig, float* rig2, float* confs, FbRidePlan* out) {
     *out = FbRidePlan();
     if (n_flows < 2) return;
     struct { const float* src; float* dst; int n; } stacks[2] = { { rig, rig2, n_flows }, { confs, confs, n_dp } };
-    int seg = 0;
+    FbRidePlan q;
+    bool can[2] = { false, false };
     for (int j = 0; j < 2; j++) {
         if (stacks[j].n <= 0) continue;
         int rs = 0, cs = 0;
         bool segmented = false;
-        fb_smooth_plan_segments(w, h, stacks[j].n, &rs, &cs, &segmented);
-        if (!segmented || rs != cs || (rs != 12 && rs != 20) || (seg && seg != rs)) return;
-        seg = rs;
-    }
-    const int Sr = (w + seg - 1) / seg, Sc = (h + seg - 1) / seg;
-    if (Sr > 256 || Sc > 256) return;
-    const int lpb = 256 / Sr, CW = std::min(16, 256 / Sc);
-    FbRidePlan q;
-    for (int j = 0; j < 2; j++) {
-        if (stacks[j].n <= 0) continue;
+        fb_smooth_plan_segments(w, h, stacks[j].n, &rs, &cs, &segmented);  // (the segments the pass's own launches use: riding must not change the arithmetic)
+        if (!segmented) continue;
+        // 40-step segments (from 8 M map pixels: 1080p) do not ride: measured (round 6, profiles/r06n_*) the mode kernels that carry them take 25.6 us
+        // instead of 12.7 -- 1.4 ms more per 1080p window for 1.2 ms less fb_smooth in the depth half (28.65 against 27.83 ms).  A 40-step block is ~50 us of
+        // strided memory traffic at any occupancy; 12- and 20-step blocks are short dependent chains, which is what hides in a 13 us launch
+        if (rs == 40 || cs == 40) continue;
+        const int Sr = (w + rs - 1) / rs, Sc = (h + cs - 1) / cs;
+        if (Sr > 256 || Sc > 256) continue;
+        const int lpb = 256 / Sr, CW = std::min(16, 256 / Sc);
         FbStack& r = q.rows[j];
-        r.src = stacks[j].src; r.dst = stacks[j].dst; r.n_maps = stacks[j].n; r.S = Sr; r.blocks_x = (h + lpb - 1) / lpb;
+        r.src = stacks[j].src; r.dst = stacks[j].dst; r.n_maps = stacks[j].n; r.S = Sr; r.seg = rs; r.blocks_x = (h + lpb - 1) / lpb;
         r.vec4 = ((w % 4) == 0 && (reinterpret_cast<uintptr_t>(r.src) % 16) == 0 && (reinterpret_cast<uintptr_t>(r.dst) % 16) == 0) ? 1 : 0;
         r.n_blocks = r.blocks_x * r.n_maps;
         FbStack& k = q.cols[j];
-        k.src = stacks[j].dst; k.dst = stacks[j].dst; k.n_maps = stacks[j].n; k.S = Sc; k.CW = CW; k.blocks_x = (w + CW - 1) / CW;
+        k.src = stacks[j].dst; k.dst = stacks[j].dst; k.n_maps = stacks[j].n; k.S = Sc; k.seg = cs; k.CW = CW; k.blocks_x = (w + CW - 1) / CW;
         k.n_blocks = k.blocks_x * k.n_maps;
-        q.R += r.n_blocks; q.C += k.n_blocks;
+        can[j] = true;
     }
-    // the two 256-thread halves of a riding workgroup may hold blocks of different stacks: ONE access form for both (workgroup-uniform barriers)
-    { const int v = (stacks[0].n > 0 ? q.rows[0].vec4 : 1) & (stacks[1].n > 0 ? q.rows[1].vec4 : 1); q.rows[0].vec4 = q.rows[1].vec4 = v; }
-    // the first k_rows mode kernels carry the row blocks, the others the column blocks: the split with the lightest heaviest launch
+    if (!can[0]) return;  // (the rigidness maps are what is worth moving; the prior confidences alone stay in the depth half)
+    // Both stacks if their blocks fit the launches, else the rigidness maps alone (round 6: every stack in the segments its own launches use -- rows and
+    // columns may differ, e.g. 12-step rows and 20-step columns on a tall image).
+    // The first k_rows mode kernels carry the row slots, the others the column slots: the split with the lightest heaviest launch.
     const int cap = 480;
-    int best = -1, best_load = 1 << 30;
-    for (int k = 1; k < n_flows; k++) {
-        const int load = std::max((q.R + k - 1) / k, (q.C + (n_flows - k) - 1) / (n_flows - k));
-        if (load < best_load) { best_load = load; best = k; }
+    for (int ns = (can[1] && stacks[1].n > 0) ? 2 : 1; ns >= 1; ns--) {
+        q.split_r = (q.rows[0].n_blocks + 1) & ~1; q.split_c = (q.cols[0].n_blocks + 1) & ~1;
+        q.R = q.split_r + (ns == 2 ? q.rows[1].n_blocks : 0); q.C = q.split_c + (ns == 2 ? q.cols[1].n_blocks : 0);
+        int best = -1, best_load = 1 << 30;
+        for (int k = 1; k < n_flows; k++) {
+            const int load = std::max(((q.R + k - 1) / k + 1) & ~1, ((q.C + (n_flows - k) - 1) / (n_flows - k) + 1) & ~1);
+            if (load < best_load) { best_load = load; best = k; }
+        }
+        if (best < 0 || best_load > cap) continue;
+        q.k_rows = best; q.rows_per = ((q.R + best - 1) / best + 1) & ~1; q.cols_per = ((q.C + (n_flows - best) - 1) / (n_flows - best) + 1) & ~1;
+        q.n_stacks = ns; q.on = true;
+        if (ns == 1) { q.rows[1] = FbStack(); q.cols[1] = FbStack(); }
+        *out = q;
+        return;
     }
-    if (best < 0 || best_load > cap) return;
-    q.k_rows = best; q.rows_per = (q.R + best - 1) / best; q.cols_per = (q.C + (n_flows - best) - 1) / (n_flows - best);
-    q.seg = seg; q.on = true;
-    *out = q;
 }
 static FbRide fb_ride_of_camera(const FbRidePlan& P, int i, int n_flows, int w, int h, float e0, float p) {
     FbRide r;
     if (!P.on) return r;
-    r.seg = P.seg; r.w = w; r.h = h; r.e0 = e0; r.p = p;
+    r.w = w; r.h = h; r.e0 = e0; r.p = p;
     const bool rows = i < P.k_rows;
     const int per = rows ? P.rows_per : P.cols_per, total = rows ? P.R : P.C;
     r.first = (rows ? i : i - P.k_rows) * per;
     r.count = std::max(0, std::min(per, total - r.first));
+    r.split = rows ? P.split_r : P.split_c;
     r.kind = r.count > 0 ? (rows ? 1 : 2) : 0;
     for (int j = 0; j < 2; j++) r.st[j] = rows ? P.rows[j] : P.cols[j];
     return r;
@@ -315,9 +323,9 @@ struct Voldor {
             p.stale_refresh = iters_cur < 2;  // voldor.cpp:250: "iters_cur == 0 || iters_cur == 1": the calls that upload the map
         }
         p.defer_reduce = defer_reduce && !strict && debug_switches().defer_reduce != 0;
-        p.fb_done = fb_rode && flag != OD_ONLY_USE_DEPTH_PRIOR;  // (enqueue_cameras: fb_smooth ran during the pose half: in the mode kernels' launches, or on the side stream)
-        p.cum_done = p.fb_done && cum_rode;                      // (and the last mode kernel prepared the projective maps)
-        fb_rode = false; cum_rode = false;
+        p.fb_done = flag != OD_ONLY_USE_DEPTH_PRIOR ? fb_rode : 0;  // (enqueue_cameras: fb_smooth ran during the pose half: in the mode kernels' launches, or on the side stream)
+        p.cum_done = p.fb_done && cum_rode;                         // (and the last mode kernel prepared the projective maps)
+        fb_rode = 0; cum_rode = false;
         if (with_world_scale) p.world_scale_out = world_scale_ptr();  // voldor.cpp:309-317: the pose half rides on the density launch, the depth half follows
         return optimize_depth_device(c, c->od, p);  // with world_scale_out: depth and poses leave normalised (voldor.cpp:309-317)
     }
@@ -370,7 +378,7 @@ struct Voldor {
     // fb_smooth is 110 us of memory pass, not launch latency), not when the blocks do not fit (at most 480 per launch: riders and the mode kernel's own
     // workgroup should not have to share a compute unit).
     FbRidePlan fbp;
-    bool fb_rode = false;
+    int fb_rode = 0;  // fb_smooth of the coming depth half ran during the pose half: bit 0 the rigidness maps, bit 1 the prior confidences
     void plan_fb_ride(bool rg) {
         fbp = FbRidePlan();
         if (strict || rg || !cfg.fb_smooth || !cfg.optimize_depth || !debug_switches().fb_ride || !g_window_alone) return;
@@ -421,7 +429,7 @@ struct Voldor {
             if (int e = optimize_camera_pose(i, rg, i == n_flows - 1, (fbp.on || (cum_ok && i == n_flows - 1)) ? &ride : nullptr)) return e;
         }
         if (side) VK_CHECK(hipStreamWaitEvent(c->stream, c->ev_join, 0));
-        if (during) { std::swap(c->od.rig, c->od.rig2); fb_rode = true; cum_rode = cum_ok; }  // the smoothed maps are `rig` from here on
+        if (during) { std::swap(c->od.rig, c->od.rig2); fb_rode = (side || fbp.n_stacks == 2 || n_dp == 0) ? 3 : 1; cum_rode = cum_ok; }  // the smoothed maps are `rig` from here on
         if (int e = upload_frames_up_to(n_flows_init)) return e;
         // rigidness densities (reduced on the device by the last optimize_depth, voldor.cpp:171) and results: the last camera's kernel
         // has stored what the host needs into pinned memory (CamBrief); the event marks it complete
@@ -694,7 +702,7 @@ extern "C" __attribute__((visibility("default"))) int vk_debug_fb_ride_plan(int 
     vk::FbRidePlan P;
     alignas(16) static float dummy[4];
     vk::fb_ride_plan(w, h, n_flows, n_dp, dummy, dummy, dummy, &P);
-    out[0] = P.on ? 1 : 0; out[1] = P.seg; out[2] = P.R; out[3] = P.C; out[4] = P.k_rows;
+    out[0] = P.on ? P.n_stacks : 0; out[1] = P.rows[0].seg * 100 + P.cols[0].seg; out[2] = P.R; out[3] = P.C; out[4] = P.k_rows;
     for (int i = 0; i < n_flows; i++) {
         const vk::FbRide r = vk::fb_ride_of_camera(P, i, n_flows, w, h, 0.5f, 0.9f);
         out[5 + 3 * i] = r.kind; out[6 + 3 * i] = r.first; out[7 + 3 * i] = r.count;
