@@ -12,12 +12,18 @@ HBM when the timed region starts (vk_voldor_device).  With N>1 every rank owns o
 per step.  Rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     SURVEY 8(d)'s unit: one optimize_depth call (a group of dependent launches): B_od = w*h*(40N+36N_dp+12) bytes
-                / the group's duration measured with HIP events on the library's stream in THIS run
-               (vk_profile_*), against the 8 TB/s HBM peak.  `dominant_kernel`: k_cost_rand_q (cost map + random depth samples),
-               w*h*(12N+12N_dp+16) bytes per launch.  `traffic`, `valu`, `sq_counters_per_launch` are REPLAYED from the committed
-               rocprofv3 --pmc passes (scripts/pmc_traffic.sh, scripts/pmc_sq.sh -> profiles/rNN*_pmc_*.json); every pass records the
-               sha256 of the kernel sources it was collected on, and a pass from other sources is flagged `stale` and withheld (null).
+  roofline     SURVEY 8(d)'s unit: one optimize_depth call (a group of dependent launches), HIP events on the library's stream in THIS run
+               (vk_profile_*), against the 8 TB/s HBM peak.  Two fractions (round 6): `frac` = the bytes that ARE in the timed group -- B_od =
+               w*h*(40N+36N_dp+12) minus fb_smooth's w*h*16*(maps) for the share of the calls in which it rode in the pose
+               half -- over the group's time; `frac_with_riders` = all of B_od over the group timed in the same run with fb_smooth and the density
+               reduction back inside as launches of their own: the series that compares with rounds 1-4.  `dominant_kernel`: k_cost_rand_q (cost map
+               + random depth samples), w*h*(12N+12N_dp+16) bytes per launch.  `traffic`, `kernels`, `sweeps`, `valu`, `sq_counters_per_launch` come from
+               rocprofv3 --pmc passes: collected BY THIS RUN in three time-bounded sub-runs (FETCH_SIZE | WRITE_SIZE | eight SQ counters; `--pmc`,
+               `--pmc-budget-s`), or, where rocprofv3 is missing or a pass fails, replayed from the committed passes of profiles/ (labelled; a pass
+               collected on other kernel sources is flagged `stale` and withheld).
+  roofline_valu  the second roofline (bound "valu"): fraction of the chip's VALU issue slots used over the group's duration, group and per kernel;
+               `issue_time_us` = the group with every wait hidden.
+  parity       which parity the headline belongs to: the fast mode's statistical parity, and the rate of the bit-exact reference mode next to it.
   host_inclusive  SURVEY.md 8(d)'s own definition of a frame: py_voldor_wrapper with the flows in pageable HOST memory
                and depth / confidence returned to the host; median of 20 calls after 3 warm-ups (never `value`).
   strict       the window in REFERENCE MODE (--strict_math 1 --reference_draw 1 --reference_svd 1: every output bit equals the
@@ -26,12 +32,12 @@ Extra objects in the line:
                `with_xorwow_and_texture_filter` = the same with --reference_rng 1 --reference_tex 1.
   exchange     (N > 1, C-ABI front end) p50 / p99 of the all-gather on the device clock (HIP events on the communicator's stream)
                and on the host clock (enqueue -> records on the host), and frames/s per GPU next to the aggregate.
-  cpu_baseline the oracle (C restatement of the reference path, OpenMP) timed on this box's host
-               cores on the same workload, a bounded number of windows (rank 0, N=1 only).
+  cpu_baseline the oracle (C restatement of the reference path, OpenMP) timed on this box's host cores on the same workload: four windows, each
+               timed, value = 1 / median (rank 0, N=1 only); in a child process with one thread per physical core, pinned.
   cpu_reference  the reference's own code on one host core (oracle/_ref: voldor/*.cpp + gpu-kernels/*.cu compiled for the
                CPU, BASELINE configs[0] "--cpu_p3p 1"), one whole window.
   workloads    (default run only) BASELINE configs[2] (cfg3) and configs[4] (cfg5), time-bounded: window time, the optimize_depth
-               group against the roofline, the reference-mode window.
+               group against the roofline (both fractions), the reference-mode window.
   value_host_inclusive  = host_inclusive.value at the top level: SURVEY 8(d)'s own frame next to `value` (inputs resident in HBM).
 """
 from __future__ import annotations
