@@ -19,4 +19,4 @@ for wl in cfg2 cfg3 cfg5; do
   timeout 900 python bench.py --workload $wl > gpurun_out/bench_${T}_$wl.json 2> gpurun_out/bench_${T}_$wl.err
   echo "bench $wl rc=$?"; cut -c1-330 gpurun_out/bench_${T}_$wl.json
 done
-python __graft_entry__.py 2>&1 | tail -3
+python __graft_entry__.py smoke 2>&1 | tail -3
