@@ -78,7 +78,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + LINK_LIBS
+    # -z now: every HIP entry point is bound when the library loads.  With lazy binding a call made for the first time AFTER another HIP runtime entered the
+    # process (torch ships its own libamdhip64 and loads it globally) resolved to THAT runtime, while the streams and events the library already held came
+    # from the first one: hipErrorUnknown on the first hipStreamWaitEvent (round 6: __graft_entry__.build() loads the library, smoke() then imports torch)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,-z,now", "-o", LIB] + objs + LINK_LIBS
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -1145,8 +1145,9 @@ int robust_gaussian_strict_device(Context* c, const float* space_dev, int N, con
 static bool coop_fits() {
     static const int fits = [] {
         int per_cu = 0, dev = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pose_strict_par<true>, 64, 0) != hipSuccess) return 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        // (a query that fails must not leave its error behind: the launcher's VK_CHECK_LAST would report it as a failed launch -- seen with two HIP runtimes in one process)
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pose_strict_par<true>, 64, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
         return (long long)per_cu * cus >= SP_MAX_POSES / 512 ? 1 : 0;
     }();
     return fits != 0;
