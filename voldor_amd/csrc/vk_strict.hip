@@ -548,13 +548,19 @@ struct StrictParShared {
     int flag;
     float cov[21], cinv[21], mean[6];
     float cent[28][6];  // centres of a batch of initial-mode trials
+    // cooperative form, four waves per 512-row block (round 6): the partial sums of strides 128 and 64 cross waves here; the totals come back through `tot`
+    float xch[4][28][64];
+    float tot[32];
+    int dead;
 };
+constexpr int COOP_WAVES = 4, COOP_THREADS = 64 * COOP_WAVES;  // a cooperative workgroup: one 512-row block of the pool on four waves, two rows per lane
 // out[k] = sum over rows i < n of row(i)[k], k < NV, in the reference's tree order; rowfn(slot, v) = the NV values of this lane's row in
 // slot `slot` (block 2 wv + slot / 8, row 64 (slot % 8) + bitrev6(lane) of it; called for every slot, rows beyond n are discarded).
 // All threads call it; the result is in every thread.
 // lane_total (optional): the total of value `lane` in lanes < NV of every wave (what the broadcast below reads) -- lets the caller finish
 // per-value work (the refit's 27 divisions by the weight) in one lane per value instead of in every thread.
-// COOPERATIVE form (k_pose_strict_par<true>): the pool's 16 blocks on 16 single-wave workgroups (16 compute units instead of one: a refit
+// COOPERATIVE form (k_pose_strict_par<true>): the pool's 16 blocks on 16 workgroups (round 6: of four waves each, two rows per lane -- tree_sum_par; rounds 4-5: single
+// waves, eight rows per lane) (16 compute units instead of one: a refit
 // iteration's pass over 8192 rows is ~130 instructions per row and was bound by the issue rate of ONE compute unit).  Workgroup b owns
 // block b: the same in-lane pair sums and the same transposing wave reduction, then the block sums meet in GLOBAL memory (agent-scope
 // atomic stores / loads), one grid barrier per sum (double buffered like the LDS form), and every workgroup walks the second-level tree
@@ -574,7 +580,7 @@ struct CoopGlobal {
 // waits for in return.  Round 4, first form: an arrival counter + release / acquire fences + the loads (three dependent round trips per
 // sum); this form: one.
 // FORWARD PROGRESS (round 5).  The launcher only takes this form when the whole grid fits the chip next to itself (occupancy query, pose_mode_strict_device):
-// 16 single-wave workgroups without LDS pressure, so every one of them is dispatched as soon as any wave slot frees -- other kernels on the chip end,
+// 16 workgroups of 256 threads and ~35 KB of LDS (the occupancy query is made with exactly that shape), so every one of them is dispatched as soon as a compute unit has room -- other kernels on the chip end,
 // these are the only ones that wait.  The spin is still BOUNDED (2^20 polls, ~1 s; vk_debug_switch "strict_coop_max_polls" lowers it to force the path
 // in tests): a workgroup that gives up raises G->err, every other one sees the flag in its own poll loop and leaves too, NOTHING of the camera record is
 // written, and the single-workgroup kernel launched behind it (k_pose_strict_par<false>, gated on the flag: it returns at once when the flag is down)
@@ -612,6 +618,81 @@ __device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared
     constexpr int NBLK_OWN = COOP ? 1 : 2;  // blocks per wave
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, q = (int)(__brev((unsigned)lane) >> 26);
     const int nb = (n + 511) / 512;
+    if constexpr (COOP) {
+        // FOUR WAVES PER BLOCK (round 6; rounds 4-5: one wave per block, eight rows per lane -- a pass of the refit was ~130 instructions x 8 rows on ONE wave, the
+        // issue of which was half of a sum's time).  Wave v holds rows q + 64 v and q + 64 (v + 4) of the block: its pair sum s_v is the tree's stride-256 level;
+        // stride 128 adds s_0 + s_2 and s_1 + s_3, stride 64 adds those two -- the same three additions on the same operands as the one-wave form's
+        // (s0 + s2) + (s1 + s3), the operands crossing waves through LDS; wave 0 then carries on alone (strides 32 .. 1 in the wave, the block sum into the
+        // tagged word, the meeting, the second level) and hands the totals back through LDS.
+        const int blk = (int)blockIdx.x, base = blk * 512 + q;
+        float sv[NV];
+        {
+            float v0[NV], v1[NV];
+            rowfn(0, v0);
+            rowfn(1, v1);
+            const bool h0 = base + 64 * wv < n, h1 = base + 64 * wv + 256 < n;
+            if (n == 1 && blk == 0 && lane == 0 && wv == 0) {
+#pragma unroll
+                for (int k = 0; k < NV; k++) __hip_atomic_store(&G->tagged_raw[k], coop_pack(v0[k], sync_target + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < NV; k++) sv[k] = h0 ? (h1 ? v0[k] + v1[k] : v0[k]) : 0.f;
+        }
+        if (wv >= 2) {
+#pragma unroll
+            for (int k = 0; k < NV; k++) S.xch[wv][k][lane] = sv[k];
+        }
+        __syncthreads();
+        if (wv < 2) {  // stride 128: s_0 + s_2 (wave 0), s_1 + s_3 (wave 1)
+#pragma unroll
+            for (int k = 0; k < NV; k++) sv[k] = sv[k] + S.xch[wv + 2][k][lane];
+        }
+        if (wv == 1) {
+#pragma unroll
+            for (int k = 0; k < NV; k++) S.xch[1][k][lane] = sv[k];
+        }
+        __syncthreads();
+        ++sync_target;  // the epoch of this sum
+        bool gave_up = false;
+        if (wv == 0) {
+            float acc[P];
+#pragma unroll
+            for (int k = 0; k < NV; k++) acc[k] = sv[k] + S.xch[1][k][lane];  // stride 64
+#pragma unroll
+            for (int k = NV; k < P; k++) acc[k] = 0.f;
+            const float mine = wave_reduce_transpose<P>(acc);  // strides 32 .. 1 of the rows = lane distances 1 .. 32
+            const int slot = wave_slot<P>(lane);
+            if (lane < P && slot < NV) __hip_atomic_store(&G->tagged[parity][blk][slot], coop_pack(mine, sync_target), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            float tot = 0.f;
+            if (lane < NV) {
+                float got[16];
+                const bool met = n == 1 ? coop_wait(&G->tagged_raw[lane], 0, 1, sync_target, G, got) : coop_wait(&G->tagged[parity][0][lane], 32, nb, sync_target, G, got);
+                if (!met) gave_up = true;
+                if (n == 1) tot = got[0];
+                else if (nb == 1) tot = got[0];
+                else {
+                    float b[16];
+#pragma unroll
+                    for (int t = 0; t < 16; t++) b[t] = (t < nb ? got[t] : 0.f) + 0.f;  // strides 128 .. 16 of the second level add zeros
+#pragma unroll
+                    for (int st = 8; st >= 1; st >>= 1)
+#pragma unroll
+                        for (int t = 0; t < st; t++) b[t] = b[t] + b[t + st];
+                    tot = b[0];
+                }
+                S.tot[lane] = tot;
+            }
+            gave_up = __ballot(gave_up) != 0ull;
+            if (lane == 0) S.dead = gave_up ? 1 : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NV; k++) out[k] = S.tot[k];
+        if (lane_total) *lane_total = lane < NV ? S.tot[lane] : 0.f;
+        *dead = S.dead != 0;
+        parity ^= 1;
+        __syncthreads();  // (S.tot / S.dead / S.xch are free for the next sum)
+    } else {
 #pragma unroll
     for (int h = 0; h < NBLK_OWN; h++) {
         const int blk = COOP ? (int)blockIdx.x : 2 * wv + h, base = blk * 512 + q;
@@ -677,6 +758,7 @@ __device__ __forceinline__ void tree_sum_par(int n, RowFn rowfn, StrictParShared
     if (lane_total) *lane_total = tot;
     parity ^= 1;
     if (COOP) *dead = __ballot(*dead) != 0ull;  // (one wave per workgroup: uniform from here on)
+    }
 }
 
 // ordered compaction of the finite hypotheses into `pool` (geometry.cpp:156-165): counts per (slice of 512, wave), one prefix, ordered
@@ -739,12 +821,12 @@ __global__ __launch_bounds__(SP_THREADS) static void k_pose_strict_compact(const
 }
 
 template <bool COOP>
-__global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_par(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp,
+__global__ __launch_bounds__(COOP ? COOP_THREADS : SP_THREADS) static void k_pose_strict_par(const float* __restrict__ rvecs, const float* __restrict__ tvecs, int n_poses, ModeParams mp,
                                                                                    CamState* cam, PoseBlock* P, int cam_idx, const int* __restrict__ n_points_dev,
                                                                                    float* __restrict__ pool, CoopGlobal* G, const unsigned* __restrict__ gate /* single-workgroup form launched BEHIND the cooperative one: runs only if that one gave up (*gate == 1) */) {
 #pragma clang fp contract(off)
     __shared__ StrictParShared S;
-    constexpr int NSLOT = COOP ? 8 : SP_SLOTS;  // rows per lane
+    constexpr int NSLOT = COOP ? 2 : SP_SLOTS;  // rows per lane (cooperative form: rows q + 64 wv and q + 64 (wv + 4) of the workgroup's block)
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     if (!COOP && gate) {
         if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 1u) return;
@@ -776,7 +858,7 @@ __global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_p
         const int q = (int)(__brev((unsigned)lane) >> 26);
 #pragma unroll
         for (int sl = 0; sl < NSLOT; sl++) {
-            const int i = (COOP ? (int)blockIdx.x : 2 * wv + (sl >> 3)) * 512 + 64 * (sl & 7) + q;
+            const int i = COOP ? (int)blockIdx.x * 512 + 64 * (wv + 4 * sl) + q : (2 * wv + (sl >> 3)) * 512 + 64 * (sl & 7) + q;
 #pragma unroll
             for (int d = 0; d < 6; d++) X[sl][d] = i < used ? pool[(size_t)i * 6 + d] : 0.f;
         }
@@ -802,9 +884,6 @@ __global__ __launch_bounds__(COOP ? 64 : SP_THREADS) static void k_pose_strict_p
             if (t < 28 * 6) {
                 const int k = t / 6, d = t % 6;
                 if (k < nt) S.cent[k][d] = pool[(size_t)(rng3(RAND_SEED, (uint32_t)(t0 + k), 0x4D53u) % (uint32_t)used) * 6 + d];
-            }
-            if (COOP && t < 64) {  // (64 threads: three rounds)
-                for (int e = t + 64; e < 28 * 6; e += 64) { const int k = e / 6, d = e % 6; if (k < nt) S.cent[k][d] = pool[(size_t)(rng3(RAND_SEED, (uint32_t)(t0 + k), 0x4D53u) % (uint32_t)used) * 6 + d]; }
             }
             __syncthreads();
             auto row = [&](int sl, float (&v)[28]) {
@@ -1146,7 +1225,7 @@ static bool coop_fits() {
     static const int fits = [] {
         int per_cu = 0, dev = 0, cus = 0;
         // (a query that fails must not leave its error behind: the launcher's VK_CHECK_LAST would report it as a failed launch -- seen with two HIP runtimes in one process)
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pose_strict_par<true>, 64, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_pose_strict_par<true>, COOP_THREADS, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
         return (long long)per_cu * cus >= SP_MAX_POSES / 512 ? 1 : 0;
     }();
@@ -1178,7 +1257,7 @@ int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamSt
             const int cap = debug_switches().strict_coop_max_polls;
             hipLaunchKernelGGL(k_pose_strict_compact, dim3(1), dim3(SP_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp.rvec_scale,
                                c->n_points.as<int>(), c->pool.as<float>(), G, cap > 0 ? (unsigned)cap : (1u << 20));
-            hipLaunchKernelGGL(k_pose_strict_par<true>, dim3(nblk), dim3(64), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp, cam_dev, P, cam_idx,
+            hipLaunchKernelGGL(k_pose_strict_par<true>, dim3(nblk), dim3(COOP_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp, cam_dev, P, cam_idx,
                                c->n_points.as<int>(), c->pool.as<float>(), G, (const unsigned*)nullptr);
             // behind it, gated on the give-up flag: the same camera on ONE workgroup (same bits); returns at once when the meetings all took place
             hipLaunchKernelGGL(k_pose_strict_par<false>, dim3(1), dim3(SP_THREADS), 0, c->stream, c->rvecs.as<float>(), c->tvecs.as<float>(), n_poses, mp, cam_dev, P, cam_idx,
