@@ -192,3 +192,68 @@ VKT_API float vkt_strict_depth_rigidness(float d1, float d2, float basefocal, fl
     return vk::strict::depth_rigidness(d1, d2, basefocal, omega, abs_rf);
 }
 VKT_API void vkt_strict_rvec_to_rotmat(const float* rv, float* R9) { vk::angle_axis_to_rotmat(rv, R9, true); }
+
+// ---- the fp32 pre-filter of the strict passes against the strict residual model, same inputs (vk_device.hpp filt_neglog): out_s = -vsm_logf(strict::rigidness),
+// out_f = the filter's value, one lane per element
+__global__ static void k_filter_pair(const float* dx1, const float* dy1, const float* ox, const float* oy, int n, float lambda, float arf, float* out_s, float* out_f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float ia = 1.f / arf;
+    const vk::ObsTerms T = vk::obs_terms(ox[i], oy[i], ia * ia, __builtin_amdgcn_logf(0.25f * lambda * lambda));
+    out_f[i] = vk::filt_neglog(T, dx1[i], dy1[i], ox[i], oy[i], 0.25f * ia * ia);
+    out_s[i] = -vsm_logf(vk::strict::rigidness(dx1[i], dy1[i], ox[i], oy[i], lambda, arf));
+}
+VKT_API int vkt_filter_pair_device(const float* dx1, const float* dy1, const float* ox, const float* oy, int n, float lambda, float arf, float* out_s, float* out_f) {
+    float* d[6] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr };
+    for (int k = 0; k < 6; k++) if (hipMalloc(&d[k], sizeof(float) * n) != hipSuccess) return 1;
+    const float* src[4] = { dx1, dy1, ox, oy };
+    for (int k = 0; k < 4; k++) (void)hipMemcpy(d[k], src[k], sizeof(float) * n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_filter_pair, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], d[1], d[2], d[3], n, lambda, arf, d[4], d[5]);
+    int rc = (int)hipMemcpy(out_s, d[4], sizeof(float) * n, hipMemcpyDeviceToHost);
+    rc |= (int)hipMemcpy(out_f, d[5], sizeof(float) * n, hipMemcpyDeviceToHost);
+    for (int k = 0; k < 6; k++) (void)hipFree(d[k]);
+    return rc;
+}
+
+// ---- pow_m2 (vk_strict_model.hpp): the shortcut against the plain call, host build; returns the number of elements whose bits differ, *n_fast = the ones the shortcut answered
+VKT_API long vkt_pow_m2_host(const float* x, long n, long* n_fast) {
+    long bad = 0, fast = 0;
+    for (long i = 0; i < n; i++) {
+        const float a = vk::strict::pow_m2(x[i]), b = vsm_powf(x[i], -2.f);
+        unsigned ua, ub; memcpy(&ua, &a, 4); memcpy(&ub, &b, 4);
+        if (ua != ub && !(a != a && b != b)) bad++;
+        if (x[i] >= 1.0f && x[i] <= 1e18f) { const double xd = (double)x[i]; if (vk::strict::rounds_alike(1.0 / (xd * xd))) fast++; }
+    }
+    *n_fast = fast;
+    return bad;
+}
+// the largest distance, in units of the last place of the shortcut's double, between the shortcut's double and the plain call's (the margin of 2^17 rests on it)
+VKT_API double vkt_pow_m2_gap_host(const float* x, long n) {
+    double worst = 0.0;
+    for (long i = 0; i < n; i++) {
+        if (!(x[i] >= 1.0f && x[i] <= 1e18f)) continue;
+        const double xd = (double)x[i], y = 1.0 / (xd * xd), l = vsm_log(xd), f = l == 0.0 ? 1.0 : vsm_exp(-2.0 * l);
+        const double gap = (double)(long long)(vsm_bits(y) - vsm_bits(f));
+        if (fabs(gap) > worst) worst = fabs(gap);
+    }
+    return worst;
+}
+
+// the same for a depth prior's term: -vsm_logf(strict::depth_rigidness(d1, d2)) against ln2 log2(1 + depth_ratio(d1, d2))
+__global__ static void k_filter_pair_depth(const float* d1, const float* d2, int n, float basefocal, float omega, float arf, float* out_s, float* out_f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    out_f[i] = 0.6931471805599453f * vk::fast_log2(1.f + vk::depth_ratio(d1[i], d2[i], basefocal, omega, 1.f / arf));
+    out_s[i] = -vsm_logf(vk::strict::depth_rigidness(d1[i], d2[i], basefocal, omega, arf));
+}
+VKT_API int vkt_filter_pair_depth_device(const float* d1, const float* d2, int n, float basefocal, float omega, float arf, float* out_s, float* out_f) {
+    float* d[4] = { nullptr, nullptr, nullptr, nullptr };
+    for (int k = 0; k < 4; k++) if (hipMalloc(&d[k], sizeof(float) * n) != hipSuccess) return 1;
+    (void)hipMemcpy(d[0], d1, sizeof(float) * n, hipMemcpyHostToDevice);
+    (void)hipMemcpy(d[1], d2, sizeof(float) * n, hipMemcpyHostToDevice);
+    hipLaunchKernelGGL(k_filter_pair_depth, dim3((n + 255) / 256), dim3(256), 0, 0, d[0], d[1], n, basefocal, omega, arf, d[2], d[3]);
+    int rc = (int)hipMemcpy(out_s, d[2], sizeof(float) * n, hipMemcpyDeviceToHost);
+    rc |= (int)hipMemcpy(out_f, d[3], sizeof(float) * n, hipMemcpyDeviceToHost);
+    for (int k = 0; k < 4; k++) (void)hipFree(d[k]);
+    return rc;
+}

@@ -129,3 +129,23 @@ def pose_mode_pool(rvecs, tvecs, init_pose6, use_external_init_mean=True, refit=
                                             C.c_float(rg_pose_scaling), fp(cov), C.byref(dens), C.byref(cnt), C.byref(msi), C.byref(gui), C.byref(ok)),
                "vk_pose_mode_pool")
     return dict(pose6=pose, covar=cov, density=dens.value, sample_count=cnt.value, ms_iters=msi.value, gu_iters=gui.value, success=ok.value)
+
+
+def filter_pair(dx1, dy1, ox, oy, lam, arf):
+    """(-vsm_logf(strict::rigidness), the fp32 filter's value) for the same float inputs, on the device (vk_device.hpp filt_neglog)."""
+    a = [np.ascontiguousarray(v, np.float32) for v in (dx1, dy1, ox, oy)]
+    n = a[0].size
+    s = np.zeros(n, np.float32); f = np.zeros(n, np.float32)
+    rc = lib().vkt_filter_pair_device(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), n, C.c_float(lam), C.c_float(arf), _p(s), _p(f))
+    assert rc == 0, rc
+    return s, f
+
+
+def filter_pair_depth(d1, d2, basefocal, omega, arf):
+    """(-vsm_logf(strict::depth_rigidness), the fp32 filter's value) for the same float inputs, on the device."""
+    a = [np.ascontiguousarray(v, np.float32) for v in (d1, d2)]
+    n = a[0].size
+    s = np.zeros(n, np.float32); f = np.zeros(n, np.float32)
+    rc = lib().vkt_filter_pair_depth_device(_p(a[0]), _p(a[1]), n, C.c_float(basefocal), C.c_float(omega), C.c_float(arf), _p(s), _p(f))
+    assert rc == 0, rc
+    return s, f

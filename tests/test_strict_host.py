@@ -71,6 +71,35 @@ def test_host_build_of_the_strict_model_gives_the_oracle_bits(orc):
         L.orc_set_strict_math(0)
 
 
+def test_pow_m2_shortcut_gives_the_plain_call_bits():
+    """vk_strict_model.hpp pow_m2: 1 / (x x) in double where that provably rounds like vsm_powf(x, -2), the plain call elsewhere.  EVERY float of four
+    binades, 2^24 random ones over the whole domain, the edges -- equal bits; the shortcut answers > 99.9 % of them; and the two doubles never lie more
+    than a few hundred units of the last place apart, against the 2^17 the shortcut keeps from a float rounding boundary."""
+    import hooks
+    H = hooks.lib()
+    H.vkt_pow_m2_host.restype = C.c_long
+    H.vkt_pow_m2_host.argtypes = [C.POINTER(C.c_float), C.c_long, C.POINTER(C.c_long)]
+    H.vkt_pow_m2_gap_host.restype = C.c_double
+    H.vkt_pow_m2_gap_host.argtypes = [C.POINTER(C.c_float), C.c_long]
+    rng = np.random.default_rng(5)
+    sets = []
+    for lo in (1.0, 2.0, 1024.0, 2.0 ** 40):  # every float of [lo, 2 lo)
+        sets.append((np.arange(1 << 23, dtype=np.uint32) + np.float32(lo).view(np.uint32)).view(np.float32))
+    sets.append(np.exp(rng.uniform(0, np.log(1e18), 1 << 24)).astype(np.float32))
+    sets.append((1.0 + np.exp(rng.uniform(np.log(1e-7), 0, 1 << 22))).astype(np.float32))  # 1 + small: where fisk_pdf's argument sits for a poor fit
+    sets.append(np.array([1.0, np.nextafter(np.float32(1), np.float32(2)), 1e18, np.nextafter(np.float32(1e18), np.float32(np.inf)), 3e38, np.inf, np.nan, 0.5, 0.0, -1.0, -np.inf], np.float32))
+    for x in sets:
+        x = np.ascontiguousarray(x, np.float32)
+        nf = C.c_long(0)
+        bad = H.vkt_pow_m2_host(x.ctypes.data_as(C.POINTER(C.c_float)), x.size, C.byref(nf))
+        assert bad == 0, (bad, x[:4])
+        inside = int(((x >= 1) & (x <= 1e18)).sum())
+        if inside > 1000:
+            assert nf.value > 0.999 * inside, (nf.value, inside)
+        gap = H.vkt_pow_m2_gap_host(x.ctypes.data_as(C.POINTER(C.c_float)), min(x.size, 1 << 22))
+        assert gap < 1024, gap  # (measured: 2 units of the last place near 1, 65 at x ~ 1e18)
+
+
 def test_strict_oracle_is_the_same_estimator(orc):
     """switching the libm does not change what is estimated: against ground truth the strict oracle is as accurate as the
     glibc one, and the residual model agrees to float rounding"""

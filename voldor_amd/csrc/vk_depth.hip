@@ -240,4 +240,13 @@ int gblur_device(Context* c, const float* src, float* dst, float* tmp, float* gk
     return 0;
 }
 
+// counter k of the strict passes' fp32 filter (vk_debug.h "sf_*"): read and cleared
+int strict_filter_stat(Context* c, int k) {
+    if (!c->sf_stats.p) return 0;
+    unsigned long long v = 0;
+    unsigned long long* d = c->sf_stats.as<unsigned long long>() + k;
+    if (hipStreamSynchronize(c->stream) != hipSuccess || hipMemcpy(&v, d, sizeof v, hipMemcpyDeviceToHost) != hipSuccess || hipMemset(d, 0, sizeof v) != hipSuccess) return -1;
+    return v > 0x7fffffffull ? 0x7fffffff : (int)v;
+}
+
 }  // namespace vk

@@ -46,6 +46,7 @@ struct Img {
     // count of the launch, before the device-side truncation clamps N) / of N_dp prior layers; xw = the per-pixel XORWOW states
     int tex, n_layers;
     vrc_xorwow* xw;
+    unsigned long long* sf;  // verification counters of the fp32 filter (k_cost_rand_f_strict), or null
 };
 // at_tex of the reference (gmat.h:175-179) in the strict kernels: D2's exact per-layer bilinear, or CUDA's filter (--reference_tex 1)
 __device__ __forceinline__ static float2 fetch_flow_strict(const Img& I, int f, float x, float y) {
@@ -709,20 +710,29 @@ __device__ __forceinline__ static float cost_split_lean(const Img& I, const Lean
 // frames g, g + LPP, .. and priors g, g + LPP, ..: gathers, strict::rigidness and the product weight * logf(rigidness) (the rounded
 // product cost_acc subtracts); the group then replays cost_sum - term / wsum + weight in the order of pixel_cost_strict: frames, then
 // priors.  Same bits as the one-lane evaluation.
-__device__ __forceinline__ static bool prior_parts_strict(const Img& I, const PoseBlock* P, int f, int px, int py, float depth, float& wg, float& term) {
+// the weight of prior f for a hypothesis (and what its term is taken from): geometry and three gathers, no transcendental
+__device__ __forceinline__ static bool prior_weight_strict(const Img& I, const PoseBlock* P, int f, int px, int py, float depth, float& wg, float& qz, float& td) {
 #pragma clang fp contract(off)
     const int w = I.w, h = I.h;
-    wg = 0.f; term = 0.f;
+    wg = 0.f; qz = 0.f; td = 0.f;
     P3 q = transform(P->dpRs[f], P->dpts[f], backproject(P, (float)px, (float)py, depth));
     float qx2, qy2;
     project(P, q, qx2, qy2);
     if (!(q.z > 0.f && qx2 >= 0.f && qx2 < (float)w && qy2 >= 0.f && qy2 < (float)h)) return false;
-    const float td = fetch_prior_strict(I, I.priors, f, qx2, qy2);
+    td = fetch_prior_strict(I, I.priors, f, qx2, qy2);
     if (!(td > 0.f)) return false;
     const float tpc = fetch_prior_strict(I, I.pconfs, f, qx2, qy2);
     const float tc = fetch_prior_strict(I, I.confs, f, qx2, qy2);
     wg = tpc * tc * ((I.disp_delta > 0.f && f == 0) ? I.disp_delta : I.delta);
-    term = wg * vsm_logf(strict::depth_rigidness(q.z, td, I.basefocal, I.omega, I.arf));  // the product cost_acc subtracts (fun_depth_cost, residual_model.h:64-68)
+    qz = q.z;
+    return true;
+}
+__device__ __forceinline__ static bool prior_parts_strict(const Img& I, const PoseBlock* P, int f, int px, int py, float depth, float& wg, float& term) {
+#pragma clang fp contract(off)
+    float qz, td;
+    term = 0.f;
+    if (!prior_weight_strict(I, P, f, px, py, depth, wg, qz, td)) return false;
+    term = wg * vsm_logf(strict::depth_rigidness(qz, td, I.basefocal, I.omega, I.arf));  // the product cost_acc subtracts (fun_depth_cost, residual_model.h:64-68)
     return true;
 }
 template <int NMAX, int LPP>
@@ -933,6 +943,245 @@ __global__ __launch_bounds__(256) static void k_cost_rand_q_strict(Img I, int n_
             }
         }
         __syncthreads();
+        const unsigned long long key = s_best[tid];
+        if (key != ~0ull) {
+            const float c = __uint_as_float((unsigned)(key >> 32));
+            if (c < c_best) { c_best = c; d_best = s_d[key & 0xffu][tid]; }
+        }
+        __syncthreads();
+    }
+    if (live) { I.depth[pi] = d_best; I.cost[pi] = c_best; if (I.xw) I.xw[pi] = st; }
+}
+
+// ---- the strict sample pass behind an fp32 filter (round 6) --------------------------------------------------------------------------
+// A random depth only matters if its cost is BELOW the pixel's current cost (`cost < best`, optimize_depth.cu:201-207); 98-99 % of the
+// samples are evaluated to be thrown away, and in strict arithmetic an evaluation is ~900 fp64-heavy instructions per frame.  So each
+// sample is first walked on the hardware transcendentals:
+//   * the SAME positions and observations as the strict evaluation -- the un-fused chain (backproject / transform / project) and
+//     fetch_flow_strict, bit for bit, so the two evaluations of a frame differ in the residual model alone: -logf(rigidness) from
+//     strict::rigidness on vsm_* against ln2 log2(1 + obs_ratio) on v_log_f32 / v_exp_f32, two approximations of one real function of the
+//     same four floats.  Analytic bound of their difference: arguments of magnitude <= 60 in the log2 domain carry 1 ulp each, exponents
+//     c + 1 <= 2: <= 1e-5 absolute + 1e-5 relative.  MEASURED over the whole input range (tests/test_gpu_strict_filter.py): 2.5 % of
+//     SF_ABS + SF_REL * value (vk_device.hpp), i.e. the margin is 40 times the largest difference seen;
+//   * a lower bound of the strict numerator chain L from the filter's chain Lf:  L >= Lf (1 - SF_REL) - SF_ABS * (weights so far), every term
+//     being weight * (-log rigidness) >= 0 (the depth priors' terms come first: same margin, fun_depth_rigidness on the strict q.z and prior depth); an upper bound U of the strict
+//     denominator: the chain over ALL frames' weights and the contributing priors' weights (their exact values: geometry and gathers only)
+//     -- monotone rounding, as for k_cost_rand_q_strict;
+//   * discarded iff  Lf (1 - SF_REL) - SF_ABS ws >= best * max(U, eps)  -- then fl(L / max(wsum, eps)) >= best in the reference's own rounding.
+//     A NaN anywhere fails the >= and the sample stays.
+// What is left (the winners, near-ties, the unlucky: 1-2 % without priors) is evaluated in strict arithmetic with one (sample, term) per lane
+// -- frames and priors side by side, the chain of positions re-walked by each lane -- and summed per sample in pixel_cost_strict's order: its
+// bits.  The filter never changes a result, only which losers are looked at closely (identity: vk_debug_switch "strict_filter" 0, and every
+// strict test against the oracle).
+// The same filter in front of the table pass of the local propagation was built three ways and measured (bit-identical each time): 35-40 % of its
+// entries are ACCEPTS -- the neighbour's depth is a good hypothesis -- and need their strict value.  In one kernel with (entry, term) lanes: 640x480
+// 49 -> 50 us, 1241x376 128 -> 205 us; as a 41-register filter launch (26 us) + a launch over the flagged entries, (entry, term) lanes 112 us, one
+// packed lane per entry 80 us, against 103 us for every entry in one launch: no gain, not kept (profiles/r06_summary.md I).
+// (SF_REL / SF_ABS and filt_neglog: vk_device.hpp, next to obs_ratio)
+// what the depth priors add to a sample at depth d: their exact weights to the denominator bound U (wall = the chain over all frames' weights at the pixel) and, on the
+// hardware transcendentals, their terms to the filter's numerator (fun_depth_rigidness's inputs qz, td are the strict ones: same margin as for a frame)
+struct FiltChain { P3 o; float px1, py1, Lf, ws; };
+__device__ __forceinline__ static float filt_begin(FiltChain& C, const Img& I, const PoseBlock* P, int px, int py, float d, float wall) {
+#pragma clang fp contract(off)
+    C.o = backproject(P, (float)px, (float)py, d); C.px1 = (float)px; C.py1 = (float)py; C.Lf = 0.f; C.ws = 0.f;
+    float U = wall;
+    for (int q = 0; q < I.N_dp; q++) {
+        float wg, qz, td;
+        if (prior_weight_strict(I, P, q, px, py, d, wg, qz, td)) {
+            U += wg;
+            C.Lf += wg * (0.6931471805599453f * fast_log2(1.f + depth_ratio(qz, td, I.basefocal, I.omega, I.inv_arf)));
+            C.ws += wg;
+        }
+    }
+    return U;
+}
+// frame f of the chain in three steps: geometry (-> does the frame contribute, where is it observed), the gather (unconditional, at the pixel itself where the
+// frame does not contribute), the model; filt_model returns "cannot win against best"
+struct FiltStep { float px2, py2; bool valid; };
+__device__ __forceinline__ static FiltStep filt_geom(FiltChain& C, const Img& I, const PoseBlock* P, int f) {
+#pragma clang fp contract(off)
+    FiltStep S;
+    C.o = transform(P->Rs[f], P->ts[f], C.o);
+    project(P, C.o, S.px2, S.py2);
+    S.valid = C.o.z > 0.f && C.px1 >= 0.f && C.px1 < (float)I.w && C.py1 >= 0.f && C.py1 < (float)I.h;
+    return S;
+}
+__device__ __forceinline__ static bool filt_model(FiltChain& C, const FiltStep& S, const LeanK& K, float2 ob, float wg, const ObsTerms& T, float U, float best) {
+#pragma clang fp contract(off)
+    if (S.valid) {
+        C.Lf += wg * filt_neglog(T, S.px2 - C.px1, S.py2 - C.py1, ob.x, ob.y, K.qia2);
+        C.ws += wg;
+        C.px1 = S.px2; C.py1 = S.py2;
+    }
+    return U == 0.f || (C.Lf * (1.f - SF_REL) - SF_ABS * C.ws) >= best * fmaxf(U, 1.1920929e-07f);
+}
+// term j of hypothesis (ex, ey, d) in strict arithmetic: frame j < N (the chain re-walked up to it: pixel_cost_strict's own walk), prior j - N beyond
+struct SfTerm { float t, w; bool ok; };
+__device__ __forceinline__ static SfTerm strict_term(const Img& I, const PoseBlock* P, int ex, int ey, float d, int j) {
+#pragma clang fp contract(off)
+    SfTerm r = { 0.f, 0.f, false };
+    float mag = 0.f, diff = 0.f, kstr = 0.f;  // the lanes of a wave hold frames and priors: their ways part here and meet again in ONE evaluation of the model (strict::rig_core)
+    if (j < I.N) {
+        const int w = I.w, h = I.h;
+        P3 o = backproject(P, (float)ex, (float)ey, d);
+        float px1 = (float)ex, py1 = (float)ey, px2 = 0.f, py2 = 0.f;
+        bool valid = false;
+        for (int g = 0; g <= j; g++) {
+            o = transform(P->Rs[g], P->ts[g], o);
+            project(P, o, px2, py2);
+            valid = o.z > 0.f && px1 >= 0.f && px1 < (float)w && py1 >= 0.f && py1 < (float)h;
+            if (g < j && valid) { px1 = px2; py1 = py2; }
+        }
+        if (valid) {
+            const int epi = ey * w + ex;
+            const float2 ob = j == 0 ? I.flows[epi] : fetch_flow_strict(I, j, px1, py1);
+            r.w = I.rig[(size_t)j * w * h + epi];
+            r.ok = true;
+            // strict::rigidness (fun_rigidness, residual_model.h:34-42) up to its call of rig_core
+            const float dx1 = px2 - px1, dy1 = py2 - py1;
+            mag = sqrtf(ob.x * ob.x + ob.y * ob.y) / I.arf;
+            const float fx = dx1 - ob.x, fy = dy1 - ob.y;
+            diff = sqrtf(fx * fx + fy * fy) / I.arf;
+            kstr = I.lambda;
+        }
+    } else {
+        float qz, td;
+        r.ok = prior_weight_strict(I, P, j - I.N, ex, ey, d, r.w, qz, td);
+        if (r.ok) {  // strict::depth_rigidness (fun_depth_rigidness, :51-61) up to its call of rig_core
+            const float disp1 = (I.basefocal / qz) / I.arf, disp2 = (I.basefocal / td) / I.arf;
+            mag = disp2; diff = fabsf(disp1 - disp2); kstr = I.omega;
+        }
+    }
+    if (r.ok) r.t = r.w * vsm_logf(strict::rig_core(mag, diff, kstr));
+    return r;
+}
+// the terms of one hypothesis, NT of them from s_t / s_w / s_v at `at`, in pixel_cost_strict's order
+__device__ __forceinline__ static float strict_close(const float* s_t, const float* s_w, const unsigned char* s_v, int at, int NT) {
+#pragma clang fp contract(off)
+    float cs = 0.f, ws = 0.f;
+    for (int j = 0; j < NT; j++)
+        if (s_v[at + j]) { cs = cs - s_t[at + j]; ws += s_w[at + j]; }
+    return ws == 0.f ? INFINITY : cs / fmaxf(ws, 1.1920929e-07f);
+}
+
+// The sample pass in two launches: the cost of the current depth in strict arithmetic (k_cost_strict: the registers of pixel_cost_strict's gathers-in-flight form stay out
+// of the second kernel, 175 -> 123 VGPRs = 2 -> 4 waves per SIMD; 1241x376: 346 -> 291 us), then the random depths of a round through the filter and the survivors in
+// strict arithmetic.  Any number of depth priors.  Launched with N + N_dp <= 64.  (Measured and left: two samples per lane walked side by side, gathers of both in
+// flight -- 144 registers, 3 waves, 291 -> 346 us; five waves per SIMD at the price of 76 bytes of scratch -- 107 / 226 / 854 us against 119 / 219 / 890.)
+template <int NMAX>
+__global__ __launch_bounds__(256) static void k_cost_strict(Img I) {
+    if (!clamp_active(I)) return;
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int x = (tile % gridDim.x) * 64 + (threadIdx.x & 63), y = (tile / gridDim.x) * 4 + (threadIdx.x >> 6);
+    if (x < I.w && y < I.h) I.cost[y * I.w + x] = pixel_cost_strict<NMAX>(I, x, y, I.depth[y * I.w + x]);
+}
+template <int NMAX>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) static void k_cost_rand_f_strict(Img I, int n_rand, uint32_t epoch0, float range_factor) {
+#pragma clang fp contract(off)
+    __shared__ unsigned long long s_best[256];
+    __shared__ unsigned short s_q[256 * CRQ_NS];  // lane-in-workgroup | sample << 8
+    __shared__ float s_d[CRQ_NS][256];
+    __shared__ float s_f0[3][CRQ_NS][256];  // what frame 0 left of a sample: U, Lf, ws
+    __shared__ float s_t[256], s_w[256];
+    __shared__ unsigned char s_v[256];
+    __shared__ int s_qn;
+    if (!clamp_active(I)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int tile = xcd_band_tile(blockIdx.y * gridDim.x + blockIdx.x, gridDim.x * gridDim.y);
+    const int x0 = (tile % gridDim.x) * 64, y0 = (tile / gridDim.x) * 4;
+    const int xi = x0 + lane, yi = y0 + (tid >> 6);
+    const bool live = xi < I.w && yi < I.h;
+    const int w = I.w, npx = w * I.h, px = live ? xi : 0, py = live ? yi : 0, pi = py * w + px;
+    const PoseBlock* P = I.P;
+    const LeanK K = lean_consts(I);
+    const float2 o0 = I.N > 0 ? I.flows[pi] : make_float2(0.f, 0.f);
+    const ObsTerms T0 = obs_terms(o0.x, o0.y, K.ia2, K.l2q);
+    float wall = 0.f;
+    for (int f = 0; f < I.N; f++) wall += I.rig[(size_t)f * npx + pi];
+    float d_best = I.depth[pi], c_best = I.cost[pi];  // (k_cost_strict, the launch before this one)
+    vrc_xorwow st;
+    if (I.xw) st = I.xw[pi];
+    const int NT = I.N + I.N_dp, per = 256 / NT;
+    for (int it = 0; it < n_rand; it += CRQ_NS) {
+        const int nh = min(CRQ_NS, n_rand - it);
+        s_best[tid] = ~0ull;
+        if (tid == 0) s_qn = 0;
+        for (int k = 0; k < nh; k++)
+            s_d[k][tid] = I.xw ? 1.0f / (range_factor * vrc_uniform(vrc_xorwow_next(&st)) + (1.0f / 1e5f)) : sample_depth(pi, epoch0 + (uint32_t)(it + k), range_factor);
+        __syncthreads();
+        // ---- the filter.  Measured (vk_debug_counter "sf_filter_frames"): a sample lives 1.25 frames on average -- four out of five die on frame 0, which needs no
+        // gather (the pixel's own texel, its ObsTerms shared by all samples) -- but the slowest lane of a wave walks 2.7 per sample.  So frame 0 of every sample first,
+        // all lanes in step; then each lane walks what its pixel has left, one frame per trip, whichever sample it is at.
+        unsigned surv = 0u;
+        if (live) {
+            if (I.N == 0) surv = (1u << nh) - 1u;
+            else {
+                const float wg0 = I.rig[pi];
+                unsigned rest = 0u;
+                for (int k = 0; k < nh; k++) {
+                    FiltChain C;
+                    const float U = filt_begin(C, I, P, px, py, s_d[k][tid], wall);
+                    const FiltStep S = filt_geom(C, I, P, 0);
+                    const bool dead = filt_model(C, S, K, o0, wg0, T0, U, c_best);
+                    s_f0[0][k][tid] = U; s_f0[1][k][tid] = C.Lf; s_f0[2][k][tid] = C.ws;
+                    if (!dead) { if (I.N == 1) surv |= 1u << k; else rest |= 1u << k; }
+                }
+                FiltChain C;
+                float U = 0.f;
+                int k = 0, f = 0;
+                C.o = backproject(P, (float)px, (float)py, 1.f); C.px1 = (float)px; C.py1 = (float)py; C.Lf = 0.f; C.ws = 0.f;
+                while (rest) {
+                    if (f == 0) {  // the sample's frame 0 again, geometry only: where the chain stands, and the sums it left
+                        k = __ffs((int)rest) - 1;
+                        C.o = backproject(P, (float)px, (float)py, s_d[k][tid]); C.px1 = (float)px; C.py1 = (float)py;
+                        const FiltStep S0 = filt_geom(C, I, P, 0);
+                        if (S0.valid) { C.px1 = S0.px2; C.py1 = S0.py2; }
+                        U = s_f0[0][k][tid]; C.Lf = s_f0[1][k][tid]; C.ws = s_f0[2][k][tid];
+                        f = 1;
+                    }
+                    const FiltStep S = filt_geom(C, I, P, f);
+                    const float2 ob = fetch_flow_strict(I, f, S.valid ? C.px1 : (float)px, S.valid ? C.py1 : (float)py);
+                    const float wg = I.rig[(size_t)f * npx + pi];
+                    const bool dead = filt_model(C, S, K, ob, wg, obs_terms(ob.x, ob.y, K.ia2, K.l2q), U, c_best);
+                    if (dead || f == I.N - 1) { if (!dead) surv |= 1u << k; rest &= rest - 1u; f = 0; }
+                    else f++;
+                }
+            }
+        }
+        for (int k = 0; k < nh; k++) {
+            const bool alive = (surv >> k) & 1u;
+            const unsigned long long m = __ballot(alive);
+            int base = 0;
+            if (lane == 0 && m) base = atomicAdd(&s_qn, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (alive) s_q[base + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned short)(tid | (k << 8));
+        }
+        __syncthreads();
+        // ---- the survivors in strict arithmetic: one (survivor, term) per lane
+        const int qn = s_qn;
+        if (I.sf) {
+            const unsigned long long lv = __ballot(live);
+            if (lane == 0) atomicAdd(I.sf + 0, (unsigned long long)(__popcll(lv) * nh));
+            if (tid == 0) atomicAdd(I.sf + 1, (unsigned long long)qn);
+        }
+        for (int e0 = 0; e0 < qn; e0 += per) {
+            const int el = tid / NT, j = tid - el * NT, e = e0 + el;
+            const bool have = el < per && e < qn;
+            SfTerm r = { 0.f, 0.f, false };
+            int t = 0, k = 0;
+            if (have) {
+                const unsigned id = s_q[e];
+                t = (int)(id & 255u); k = (int)(id >> 8);
+                r = strict_term(I, P, x0 + (t & 63), y0 + (t >> 6), s_d[k][t], j);
+            }
+            s_t[tid] = r.t; s_w[tid] = r.w; s_v[tid] = r.ok ? 1 : 0;
+            __syncthreads();
+            if (have && j == 0) {
+                const float c = strict_close(s_t, s_w, s_v, tid, NT);
+                if (c == c) atomicMin(&s_best[t], ((unsigned long long)__float_as_uint(fmaxf(c, 0.f)) << 32) | (unsigned)k);
+            }
+            __syncthreads();
+        }
         const unsigned long long key = s_best[tid];
         if (key != ~0ull) {
             const float c = __uint_as_float((unsigned)(key >> 32));
@@ -1267,7 +1516,7 @@ static Img make_img(const ImageSet& S, const OdParams& p) {
     I.N = p.N; I.N_dp = p.N_dp; I.w = p.w; I.h = p.h;
     I.lambda = p.lambda; I.omega = p.omega; I.inv_arf = 1.f / p.abs_resize_factor; I.arf = p.abs_resize_factor;
     I.basefocal = p.basefocal; I.disp_delta = p.disp_delta; I.delta = p.delta;
-    I.tex = (p.strict && p.ref_tex) ? 1 : 0; I.n_layers = p.N; I.xw = nullptr;
+    I.tex = (p.strict && p.ref_tex) ? 1 : 0; I.n_layers = p.N; I.xw = nullptr; I.sf = nullptr;
     return I;
 }
 
@@ -1285,6 +1534,12 @@ int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_
         I.depth = p.stale_depth;
     }
     const dim3 gpx((w + 63) / 64, (h + 3) / 4), bpx(256);
+    if (STRICT && debug_switches().strict_filter == 2) {
+        const bool fresh = c->sf_stats.p == nullptr;
+        if (int e = c->sf_stats.reserve(sizeof(unsigned long long) * 4)) return e;
+        if (fresh) VK_CHECK(hipMemsetAsync(c->sf_stats.p, 0, sizeof(unsigned long long) * 4, c->stream));
+        I.sf = c->sf_stats.as<unsigned long long>();
+    }
     const bool plain = STRICT && debug_switches().strict_plain;  // strict mode on the plain launch structures of rounds 1-3 (verification: same bits either way)
     // fast mode: the projective maps of the chain (and the world-scale factor) are prepared by an extra workgroup of the first fb_smooth
     // launch when there is one, by their own small launch otherwise
@@ -1293,7 +1548,12 @@ int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_
     if constexpr (!STRICT) { if (!cum_in_fb && !((fb_done & 1) && p.cum_done)) cum_poses_launch(c, S.pb(), p.N, p.N_dp, p.world_scale_out); }
     auto cost_rand = [&](int n_rand, uint32_t epoch) {
         if constexpr (STRICT) {
-            if (plain || debug_switches().cost_rand_plain || p.N_dp > 1) hipLaunchKernelGGL(k_cost_rand_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
+            const bool filt = debug_switches().strict_filter && p.N + p.N_dp <= 64;  // hardware-fp32 pre-filter, strict arithmetic for what it cannot discard
+            if (plain || debug_switches().cost_rand_plain || (p.N_dp > 1 && !filt)) hipLaunchKernelGGL(k_cost_rand_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
+            else if (filt) {
+                hipLaunchKernelGGL(k_cost_strict<NMAX>, gpx, bpx, 0, c->stream, I);
+                if (n_rand > 0) hipLaunchKernelGGL(k_cost_rand_f_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
+            }
             else hipLaunchKernelGGL(k_cost_rand_q_strict<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);
         }
         else if (debug_switches().cost_rand_plain) hipLaunchKernelGGL(k_cost_rand_plain<NMAX>, gpx, bpx, 0, c->stream, I, n_rand, epoch, p.range_factor);

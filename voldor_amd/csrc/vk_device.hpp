@@ -112,6 +112,15 @@ __device__ __forceinline__ float obs_ratio(const ObsTerms& t, float ex, float ey
     return fast_exp2(t.c1 * (l - t.lm)) * a * a;
 }
 
+// -log(rigidness) of one frame for the float inputs strict::rigidness takes (vk_strict_model.hpp): the pre-filter of the strict sample pass
+// (vk_depth_impl.hpp "the strict sample pass behind an fp32 filter").  |filt_neglog - (-vsm_logf(strict::rigidness))| <= SF_ABS + SF_REL * value is what the filter
+// relies on; tests/test_gpu_strict_filter.py measures the difference over the input range and holds it a factor 10 below.
+constexpr float SF_REL = 1e-4f, SF_ABS = 1e-4f;
+__device__ __forceinline__ float filt_neglog(const ObsTerms& T, float dx1, float dy1, float ox, float oy, float qia2) {
+#pragma clang fp contract(off)
+    return 0.6931471805599453f * fast_log2(1.f + obs_ratio(T, dx1 - ox, dy1 - oy, qia2));
+}
+
 // Two pixels per lane: the same operation sequence on float pairs.  v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 round each half like the scalar
 // instruction, the transcendentals, max and med3 have no packed form and run per half: the bits of obs_terms / obs_ratio for either pixel.
 typedef float pf2 __attribute__((ext_vector_type(2)));

@@ -37,6 +37,7 @@ struct DebugSwitches {
     int fb_side = 1;           // 0: strict mode's fb_smooth runs inside the depth half instead of on the side stream next to the pose half
     int bootstrap_default = 0; // what --bootstrap_points -1 (the default) means: 0 = five-point in the fast mode, 8-point in strict mode; 5 | 8 = that one.  The test suite sets 8 where a
                                // window is held against the oracle or the reference goldens, whose two-view pose is the 8-point one
+    int strict_filter = 1;     // 2: as 1, and the pass counts what the filter saw and kept (vk_debug_counter "sf_*").  0: the strict sample pass evaluates every random depth in strict arithmetic (no fp32 pre-filter, vk_depth_impl.hpp); same bits
     int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
 };
 DebugSwitches& debug_switches();  // vk_abi.hip
@@ -78,6 +79,7 @@ int fb_smooth_device(Context* c, float* maps, int n_maps, int w, int h, float s0
 // vk_strict.hip
 int fb_smooth_strict_device(Context* c, float* maps, int n_maps, int w, int h, float s0_ems_prob, float no_change_prob, const int* n_dev = nullptr, float* dst = nullptr, hipStream_t st = nullptr);
 int pose_mode_strict_device(Context* c, int n_poses, const ModeParams& mp, CamState* cam_dev, PoseBlock* P, int cam_idx);
+int strict_filter_stat(Context* c, int k);  // counter k of the strict passes' fp32 filter (vk_debug.h "sf_*"; counted with vk_debug_switch "strict_filter" 2), read and cleared, saturating; -1: device error
 int strict_coop_fallbacks(Context* c);  // cameras the single-workgroup strict mode kernel took over from the cooperative one (read and cleared); -1: device error
 int meanshift_strict_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);
 int robust_gaussian_strict_device(Context* c, const float* space_dev, int N, const ModeParams& mp, float* io_dev, int* ioi_dev);

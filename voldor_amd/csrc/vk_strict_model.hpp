@@ -44,22 +44,54 @@ VK_SHD void powf2_same_base(float x, float y1, float y2, float& o1, float& o2) {
     };
     o1 = one(y1); o2 = one(y2);
 }
+// ---- the same FLOAT with fewer software transcendentals (round 6) ---------------------------------------------------------------------------------------
+// vsm_powf rounds a double that is within ~1e-13 of the true power to float.  Any other double that close to the true value rounds to the same float unless
+// a float rounding boundary lies between the two; the boundaries are the doubles whose 29 low mantissa bits (the ones a float drops) read 0x10000000.  So a
+// cheaper double may stand in for the plain one wherever it keeps 2^17 units of its last place (a relative 1.4e-11) away from every boundary and is a normal
+// float -- all but one value in 2000; elsewhere the plain function runs.  Same bits, decided per value, on the host and on gfx950 alike.  The oracle keeps
+// calling vsm_powf (oracle/orc_math.h): every strict comparison with it checks the shortcut too, tests/test_strict_host.py holds it against the plain
+// call over whole binades and measures the distance between the two doubles.  (Built the same way and measured without gain, not kept: r^(-c-1) from r^(-c) / r --
+// one exponential less, a division and a guard more -- and fused-multiply-add forms of vsm_exp / vsm_log: scripts/experiments/r06_quick_forms.patch.txt.)
+VK_SHD bool rounds_alike(double g) {
+    const unsigned long long u = vsm_bits(g);
+    const unsigned e = (unsigned)(u >> 52) & 0x7ffu, d = (unsigned)(u & 0x1fffffffull);
+    const unsigned dist = d > 0x10000000u ? d - 0x10000000u : 0x10000000u - d;
+    return e >= 1023u - 126u && e <= 1023u + 126u && dist > (1u << 17);
+}
+// (float)vsm_pow(x, -2) for the x = 1 + r^-c >= 1 of fisk_pdf without the logarithm and the exponential: x * x is exact in double (48 bits) and the division
+// rounds once, so y is within 2^-53 of x^-2; vsm_exp(-2 vsm_log(x)) is within 1e-13 of it for x <= 1e18 (|t| <= 83: the rounding of t = -2 l dominates).
+// Measured: the two differ by <= 65 units of the last place.
+VK_SHD float pow_m2(float x) {
+#pragma clang fp contract(off)
+    if (x >= 1.0f && x <= 1e18f) {  // (false for a NaN)
+        const double xd = (double)x;
+        const double y = 1.0 / (xd * xd);
+        if (rounds_alike(y)) return (float)y;
+    }
+    return vsm_powf(x, -2.f);
+}
 VK_SHD float fisk_pdf(float x, float c, float scale) {  // :28-31
 #pragma clang fp contract(off)
     x = fmaxf((float)((double)x * 0.5), 1.1920929e-07f);
     const float r = (x * x) / scale;
     float p1, p2;
     powf2_same_base(r, -c - 1.f, -c, p1, p2);
-    return (c * p1 * vsm_powf(1.f + p2, -2.f)) / scale;
+    return (c * p1 * pow_m2(1.f + p2)) / scale;
+}
+// What fun_rigidness and fun_depth_rigidness share once the magnitude of the observation (flow magnitude / disparity), the magnitude of the difference and the
+// strictness (lambda / omega) are known -- so that a wave whose lanes hold frames AND depth priors runs the software transcendentals once (strict_term, vk_depth_impl.hpp)
+VK_SHD float rig_core(float mag, float diff, float strictness) {
+#pragma clang fp contract(off)
+    const float c = fmag_c(mag), s = fmag_scale(mag);
+    const float p = fisk_pdf(diff, c, s), mu = fisk_pdf(strictness * mag, c, s);
+    return p / (p + mu);
 }
 VK_SHD float rigidness(float dx1, float dy1, float dx2, float dy2, float lambda, float abs_rf) {  // fun_rigidness :34-42
 #pragma clang fp contract(off)
     const float obs_fmag = sqrtf(dx2 * dx2 + dy2 * dy2) / abs_rf;
     const float ex = dx1 - dx2, ey = dy1 - dy2;
     const float diff_fmag = sqrtf(ex * ex + ey * ey) / abs_rf;
-    const float c = fmag_c(obs_fmag), s = fmag_scale(obs_fmag);
-    const float p = fisk_pdf(diff_fmag, c, s), mu = fisk_pdf(lambda * obs_fmag, c, s);
-    return p / (p + mu);
+    return rig_core(obs_fmag, diff_fmag, lambda);
 }
 // fun_rigidness with its observation-only part split off: c, s and mu = fisk_pdf(lambda |obs|) depend on the OBSERVED flow alone, and frame 0
 // observes at the pixel itself -- every depth hypothesis of a pixel shares them (ten random samples: k_cost_rand_q_strict).  The same
@@ -84,10 +116,7 @@ VK_SHD float rigidness_with(const RigObs& o, float dx1, float dy1, float abs_rf)
 VK_SHD float depth_rigidness(float d1, float d2, float basefocal, float omega, float abs_rf) {  // fun_depth_rigidness :51-61
 #pragma clang fp contract(off)
     const float disp1 = (basefocal / d1) / abs_rf, disp2 = (basefocal / d2) / abs_rf;
-    const float diff = fabsf(disp1 - disp2);
-    const float c = fmag_c(disp2), s = fmag_scale(disp2);
-    const float p = fisk_pdf(diff, c, s), mu = fisk_pdf(omega * disp2, c, s);
-    return p / (p + mu);
+    return rig_core(disp2, fabsf(disp1 - disp2), omega);
 }
 // fun_cost / fun_depth_cost (:45-49, :64-68): io_cost -= weight * logf(rigidness)
 VK_SHD float cost_acc(float cost_sum, float weight, float rig) {
