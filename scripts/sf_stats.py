@@ -1,3 +1,4 @@
+"""What the fp32 filters of the strict sample pass saw and kept over one reference-mode window (vk_debug_counter "sf_*").  usage: python scripts/sf_stats.py"""
 import sys; sys.path.insert(0,'.'); sys.path.insert(0,'tests')
 import numpy as np, torch, hooks, bench
 from voldor_amd import pyvoldor, synth, kernels
@@ -9,4 +10,4 @@ for name in ("cfg2","cfg3"):
     for k in ("sf_samples","sf_sample_survivors"): hooks.debug_counter(k)
     o=pyvoldor.voldor(sc["flows"], wl["fx"], wl["fx"], wl["cx"], wl["cy"], config=wl["cfg"]+" --strict_math 1 --reference_draw 1 --reference_svd 1", **kw)
     st={k:hooks.debug_counter(k) for k in ("sf_samples","sf_sample_survivors")}
-    print(name, st, "sample survivors", st["sf_sample_survivors"]/max(st["sf_samples"],1), "flagged table entries per tile", st["sf_table_survivors"]/max(st["sf_table_tiles"],1))
+    print(name, st, "sample survivors", st["sf_sample_survivors"]/max(st["sf_samples"],1))
