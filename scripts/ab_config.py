@@ -20,7 +20,7 @@ def switches(sfx):  # "@name=value" tokens of a suffix set verification switches
     return " ".join(t for t in toks if not t.startswith("@"))
 for rep in range(2):
     for raw in sys.argv[2:]:
-        for k, v in (("strict_plain", 0), ("strict_pose_coop", 1), ("estep_pairs", 1), ("fb_ride", 1), ("defer_reduce", 1), ("fb_segment", 0), ("fb_side", 1), ("strict_filter", 1)):
+        for k, v in (("strict_plain", 0), ("strict_pose_coop", 1), ("estep_pairs", 1), ("fb_ride", 1), ("defer_reduce", 1), ("fb_segment", 0), ("fb_side", 1), ("strict_filter", 1), ("strict_table_filter", 1)):
             capi.lib().vk_debug_switch(k.encode(), v)
         sfx = switches(raw)
         for _ in range(3): pyvoldor.voldor_device(flows, wl["fx"], wl["fx"], wl["cx"], wl["cy"], config=wl["cfg"] + " " + sfx, depth_out=depth, depth_conf_out=conf, **kw)

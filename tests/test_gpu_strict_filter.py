@@ -1,4 +1,4 @@
-"""The fp32 pre-filter of the strict sample pass (vk_depth_impl.hpp "the strict sample pass behind an fp32 filter", round 6).
+"""The fp32 pre-filter of the strict sample pass and of the strict table pass (vk_depth_impl.hpp "the strict sample pass behind an fp32 filter", round 6).
 
 The filter discards a hypothesis only when a lower bound of its strict cost -- the filter's own sum less SF_REL of it and SF_ABS per unit weight --
 is at or above the pixel's current cost, so it changes no result as long as the filter's -log(rigidness) stays within that margin of the strict
@@ -14,6 +14,7 @@ from test_gpu_strict import assert_bits, strict  # noqa: F401  (fixture)
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures("eight_point_bootstrap")]
 
 SF_ABS = SF_REL = 1e-4  # vk_device.hpp
+COUNTERS = ("sf_samples", "sf_sample_survivors", "sf_table_tiles", "sf_table_queued")
 
 
 @pytest.mark.parametrize("arf,lam", [(1.0, 0.15), (2.0, 0.15), (0.5, 0.3), (1.0, 0.05)])
@@ -102,14 +103,14 @@ def test_filter_changes_no_bit_and_discards_most(strict, name):
     out, seen = {}, {}
     try:
         for mode in (2, 0):
-            hooks.debug_switch("strict_filter", mode)
+            hooks.debug_switch("strict_filter", mode); hooks.debug_switch("strict_table_filter", 2)  # (the table pass's filter is on from 1 M pixels by default: forced here)
             kernels.set_rand_epoch(0)
-            for k in ("sf_samples", "sf_sample_survivors"):
+            for k in COUNTERS:
                 hooks.debug_counter(k)
             out[mode] = pyvoldor.voldor(sc["flows"], fx, fy, cx, cy, config=cfg, **kw)
-            seen[mode] = {k: hooks.debug_counter(k) for k in ("sf_samples", "sf_sample_survivors")}
+            seen[mode] = {k: hooks.debug_counter(k) for k in COUNTERS}
     finally:
-        hooks.debug_switch("strict_filter", 1)
+        hooks.debug_switch("strict_filter", 1); hooks.debug_switch("strict_table_filter", 1)
     a, b = out[2], out[0]
     assert a["n_registered"] == b["n_registered"]
     for k in ("depth", "depth_conf", "poses", "poses_covar"):
@@ -118,4 +119,5 @@ def test_filter_changes_no_bit_and_discards_most(strict, name):
     print(name, s)
     assert all(v == 0 for v in seen[0].values()), seen[0]  # filter off: the filtered kernels did not run
     assert s["sf_samples"] > 0
-    assert 0 < s["sf_sample_survivors"] < (0.6 if name == "two_priors" else 0.05) * s["sf_samples"], s  # (two strong priors: their terms are not in the filter's bound)
+    assert 0 < s["sf_sample_survivors"] < (0.6 if name == "two_priors" else 0.05) * s["sf_samples"], s  # (two strong priors on a small scene: a third of the samples beat a poor incumbent)
+    assert s["sf_table_tiles"] > 0 and 0 < s["sf_table_queued"] < (0.9 if name == "two_priors" else 0.7) * 256 * s["sf_table_tiles"], s  # (the accepts and the near-ties: strict arithmetic saw them, and only them)

@@ -175,7 +175,7 @@ static const DebugEntry g_debug_tab[] = {
     { "strict_plain", &DebugSwitches::strict_plain, 0 }, { "strict_pose_coop", &DebugSwitches::strict_pose_coop, 0 },
     { "strict_coop_max_polls", &DebugSwitches::strict_coop_max_polls, 2 }, { "estep_pairs", &DebugSwitches::estep_pairs, 3 }, { "fb_ride", &DebugSwitches::fb_ride, 0 }, { "defer_reduce", &DebugSwitches::defer_reduce, 0 },
     { "fb_side", &DebugSwitches::fb_side, 0 }, { "bootstrap_default", &DebugSwitches::bootstrap_default, 4 },
-    { "strict_filter", &DebugSwitches::strict_filter, 3 },
+    { "strict_filter", &DebugSwitches::strict_filter, 3 }, { "strict_table_filter", &DebugSwitches::strict_table_filter, 3 },
 };
 // returns the previous value; -1: unknown name; -2: a value the switch does not take
 static int debug_switch_set(const char* name, int value) {
@@ -438,6 +438,8 @@ extern "C" __attribute__((visibility("default"))) int vk_debug_counter(const cha
     if (strcmp(name, "fb_side_passes") == 0) { const long v = c->dbg_fb_side_passes; c->dbg_fb_side_passes = 0; return (int)v; }
     if (strcmp(name, "sf_samples") == 0) return vk::strict_filter_stat(c, 0);
     if (strcmp(name, "sf_sample_survivors") == 0) return vk::strict_filter_stat(c, 1);
+    if (strcmp(name, "sf_table_tiles") == 0) return vk::strict_filter_stat(c, 2);
+    if (strcmp(name, "sf_table_queued") == 0) return vk::strict_filter_stat(c, 3);
     if (strcmp(name, "reduces_rode") == 0) { const long v = c->dbg_reduces_rode; c->dbg_reduces_rode = 0; return (int)v; }
     return -1;
 }

@@ -217,6 +217,7 @@ struct Context {
     // (optimize_depth.cu:286-291; they stand xw_px_epoch draws after curand_init for a xw_px_n-pixel image) and the states right after
     // curand_init(RAND_SEED, idx, 0) of the solver's hypotheses (solve_batch_lambdatwist.cu:44-48: re-seeded per call, so a fixed table)
     DevBuf xw_jumps, xw_px_states, xw_pose_states;
+    DevBuf sf_qcnt, sf_qlist;  // the queues of the strict table pass's filter (k_local_table_filter -> k_local_table_exact): 4 passes x SFQ counters, SFQ lists of pixel indices
     DevBuf sf_stats;  // 4 x u64 (two used): what the fp32 filter of the strict sample pass saw / kept (verification counters, vk_debug_switch "strict_filter" 2)
     int xw_px_n = 0, xw_pose_n = 0;
     uint32_t xw_px_epoch = 0;

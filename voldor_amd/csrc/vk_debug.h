@@ -32,14 +32,16 @@ extern "C" {
  *   "strict_filter"   1 | 0 | 2   2: as 1, and the pass counts what the filter saw and kept (vk_debug_counter "sf_*").  0: the strict sample pass evaluates every random depth in
  *                             strict arithmetic (exact progressive rejection, k_cost_rand_q_strict) instead of first discarding, on hardware fp32 transcendentals with a
  *                             margin, the ones that cannot win (k_cost_rand_f_strict, vk_depth_impl.hpp); the same bits
+ *   "strict_table_filter" 1 | 0 | 2   the table pass of the strict local propagation behind the same filter, the entries it cannot discard queued and evaluated in strict arithmetic by a
+ *                             second launch (k_local_table_filter / k_local_table_exact): from 1 M pixels | never | at every size; the same bits
  * Returns the previous value, -1 for an unknown name / value. */
 int vk_debug_switch(const char* name, int value);
 /* Counters, read and cleared: "strict_coop_fallbacks" = cameras (default context) whose cooperative strict mode kernel gave up a meeting and were
  * computed by the single-workgroup kernel launched behind it; "fb_blocks_rode" = 256-thread fb_smooth blocks the window pipeline (default context) put
  * into mode-kernel launches instead of launches of their own (FbRide); "reduces_rode" = density reductions it attached to a correspondence trace
  * (OdParams::defer_reduce); "fb_side_passes" = fb_smooth passes it ran on the side stream next to a pose half -- counted on the host where the launch is built;
- * "sf_samples" / "sf_sample_survivors" = random depths the strict sample pass put through its fp32 filter / the ones left for strict arithmetic (counted on the device
- * while "strict_filter" is 2; saturating).  -1: unknown name / device error. */
+ * "sf_samples" / "sf_sample_survivors" = random depths the strict sample pass put through its fp32 filter / the ones left for strict arithmetic, "sf_table_tiles" /
+ * "sf_table_queued" = 64x4 tiles of the strict table pass that went through the filter / entries it queued for strict arithmetic (counted on the device while "strict_filter" is 2; saturating).  -1: unknown name / device error. */
 int vk_debug_counter(const char* name);
 /* How the 256-thread blocks of a riding fb_smooth (FbRide, vk_common.hpp) would be dealt over the mode kernels of a window with this geometry -- host
  * arithmetic only, no device.  out: [stacks that ride: 0 | 1 (the rigidness maps) | 2 (and the prior confidences), 100 x steps per lane of the rigidness maps' row pass + those of

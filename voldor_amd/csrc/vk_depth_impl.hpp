@@ -973,10 +973,6 @@ __global__ __launch_bounds__(256) static void k_cost_rand_q_strict(Img I, int n_
 // -- frames and priors side by side, the chain of positions re-walked by each lane -- and summed per sample in pixel_cost_strict's order: its
 // bits.  The filter never changes a result, only which losers are looked at closely (identity: vk_debug_switch "strict_filter" 0, and every
 // strict test against the oracle).
-// The same filter in front of the table pass of the local propagation was built three ways and measured (bit-identical each time): 35-40 % of its
-// entries are ACCEPTS -- the neighbour's depth is a good hypothesis -- and need their strict value.  In one kernel with (entry, term) lanes: 640x480
-// 49 -> 50 us, 1241x376 128 -> 205 us; as a 41-register filter launch (26 us) + a launch over the flagged entries, (entry, term) lanes 112 us, one
-// packed lane per entry 80 us, against 103 us for every entry in one launch: no gain, not kept (profiles/r06_summary.md I).
 // (SF_REL / SF_ABS and filt_neglog: vk_device.hpp, next to obs_ratio)
 // what the depth priors add to a sample at depth d: their exact weights to the denominator bound U (wall = the chain over all frames' weights at the pixel) and, on the
 // hardware transcendentals, their terms to the filter's numerator (fun_depth_rigidness's inputs qz, td are the strict ones: same margin as for a frame)
@@ -1190,6 +1186,82 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) sta
         __syncthreads();
     }
     if (live) { I.depth[pi] = d_best; I.cost[pi] = c_best; if (I.xw) I.xw[pi] = st; }
+}
+
+// The table pass of the strict local propagation behind the same filter, in two launches (from 1 M pixels: optimize_depth_launch).  The runs kernel only asks `table < cost` and takes
+// the table value when that holds, so (1) every chain pixel walks its predecessor's depth through the filter (fp32, 41 registers): a reject is written as +inf, anything else -- the
+// accepts, 35-40 % of the entries, and the near-ties -- is appended to one of SFQ queues in global memory (one atomic per 64x4 tile: an atomic on one address takes ~90 ns and they
+// queue up, so the tiles are spread over 256 addresses); (2) the queues are evaluated in strict arithmetic one entry per lane, densely packed.  WHICH queue decides whether that pays: a
+// queue is one of 32 stretches of one XCD's band of the image (xcd_band_tile) and is walked by consecutive workgroups of THAT XCD, so the gathers of the strict evaluation find the flow
+// layers in the L2 the plain kernel's would -- with the tiles dealt round-robin over the queues the packed kernel took as long as evaluating every entry (1920x1080: 479 us against 490;
+// with the stretches: 245).  (Other forms, all bit-identical, profiles/r06_summary.md I: (entry, term) lanes inside the table kernel; flagged entries packed per tile into the tile's own waves.)
+constexpr int SFQ = 256;
+__device__ __forceinline__ static bool table_member(int w, int h, int dir, int width, int x, int y, int& nb) {
+    if (dir == 0) { nb = y * w + x - 1; return x >= 1 && (x % width) != 0; }
+    if (dir == 2) { nb = y * w + x + 1; return x <= w - 2 && (x % width) != width - 1; }
+    if (dir == 1) { nb = (y - 1) * w + x; return y >= 1 && (y % width) != 0; }
+    nb = (y + 1) * w + x; return y <= h - 2 && (y % width) != width - 1;
+}
+template <int NMAX>
+__global__ __launch_bounds__(256) static void k_local_table_filter(Img I, int dir, int width, float* __restrict__ tbl, unsigned* __restrict__ qcnt, unsigned* __restrict__ qlist, int qcap) {
+#pragma clang fp contract(off)
+    __shared__ int s_n, s_base;
+    if (!clamp_active(I)) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int bid = blockIdx.y * gridDim.x + blockIdx.x;
+    const int tile = xcd_band_tile(bid, gridDim.x * gridDim.y);
+    const int x = (tile % gridDim.x) * 64 + lane, y = (tile / gridDim.x) * 4 + (tid >> 6);
+    if (tid == 0) s_n = 0;
+    __syncthreads();
+    int nb = 0;
+    const bool member = x < I.w && y < I.h && table_member(I.w, I.h, dir, width, x, y, nb);
+    const int npx = I.w * I.h, pi = member ? y * I.w + x : 0;
+    const PoseBlock* P = I.P;
+    bool maybe = member;
+    if (member && I.N > 0) {
+        const float d = I.depth[nb], own = I.cost[pi];
+        const LeanK K = lean_consts(I);
+        const float2 o0 = I.flows[pi];
+        const ObsTerms T0 = obs_terms(o0.x, o0.y, K.ia2, K.l2q);
+        float wall = 0.f;
+        for (int f = 0; f < I.N; f++) wall += I.rig[(size_t)f * npx + pi];
+        FiltChain C;
+        const float U = filt_begin(C, I, P, x, y, d, wall);
+        bool dead = false;
+        for (int f = 0; f < I.N && !dead; f++) {
+            const FiltStep S = filt_geom(C, I, P, f);
+            const bool far = S.valid && f > 0;
+            const float2 ob = fetch_flow_strict(I, f, far ? C.px1 : (float)x, far ? C.py1 : (float)y);
+            const float wg = I.rig[(size_t)f * npx + pi];
+            dead = filt_model(C, S, K, f == 0 ? o0 : ob, wg, f == 0 ? T0 : obs_terms(ob.x, ob.y, K.ia2, K.l2q), U, own);
+        }
+        maybe = !dead;
+        if (dead) tbl[pi] = INFINITY;
+    }
+    const unsigned long long m = __ballot(maybe);
+    int wbase = 0;
+    if (lane == 0 && m) wbase = atomicAdd(&s_n, __popcll(m));
+    wbase = __shfl(wbase, 0, 64);
+    __syncthreads();
+    // the queue of this tile: workgroup bid runs on XCD bid % 8 and xcd_band_tile hands it tile bid / 8 of that XCD's band of the image; queue (band, j) collects the j-th of SFQ / 8 stretches
+    // of the band, so that the strict kernel can walk a queue on the XCD whose L2 holds that stretch of the flow layers
+    const int per = (int)(gridDim.x * gridDim.y) / 8;
+    const int q = (bid % 8) + 8 * (bid < per * 8 ? min((bid / 8) * (SFQ / 8) / max(per, 1), SFQ / 8 - 1) : SFQ / 8 - 1);
+    if (tid == 0 && s_n > 0) s_base = (int)atomicAdd(qcnt + q, (unsigned)s_n);
+    __syncthreads();
+    if (maybe) qlist[(size_t)q * qcap + s_base + wbase + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)pi;
+    if (I.sf && tid == 0) { atomicAdd(I.sf + 2, 1ull); atomicAdd(I.sf + 3, (unsigned long long)s_n); }
+}
+template <int NMAX>
+__global__ __launch_bounds__(256) static void k_local_table_exact(Img I, int dir, float* __restrict__ tbl, const unsigned* __restrict__ qcnt, const unsigned* __restrict__ qlist, int qcap) {
+    if (!clamp_active(I)) return;
+    // workgroup B runs on XCD B % 8: it takes chunk (B / 8) % chunks of queue (band B % 8, stretch (B / 8) / chunks) -- consecutive workgroups of an XCD walk one stretch of its band
+    const int chunks = qcap / 256, m = blockIdx.x / 8;
+    const int q = (blockIdx.x % 8) + 8 * (m / chunks), e = (m % chunks) * 256 + threadIdx.x;
+    if (e >= (int)qcnt[q]) return;
+    const int pi = (int)qlist[(size_t)q * qcap + e], x = pi % I.w, y = pi / I.w;
+    const int nb = dir == 0 ? pi - 1 : dir == 2 ? pi + 1 : dir == 1 ? pi - I.w : pi + I.w;
+    tbl[pi] = pixel_cost_strict<NMAX>(I, x, y, I.depth[nb]);
 }
 
 // Global propagation with the candidate of a site evaluated by LPP lanes (cost_split_lean: the bits of pixel_cost_lean).  A pass has
@@ -1540,6 +1612,17 @@ int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_
         if (fresh) VK_CHECK(hipMemsetAsync(c->sf_stats.p, 0, sizeof(unsigned long long) * 4, c->stream));
         I.sf = c->sf_stats.as<unsigned long long>();
     }
+    // the table pass of the local propagation behind the filter (k_local_table_filter + k_local_table_exact) where the pass is several rounds of waves long: at 1920x1080 the packed strict
+    // kernel takes 245 us against 490 for every entry (+ 100 for the filter); at 1241x376 / 640x480 every wave of the plain kernel is resident at once and the pass lasts as long as ONE
+    // wave's dependent chain, whichever number of waves: 77 + 30 us against 103, 41 + 14 against 39 -- there the plain kernel stays
+    const bool table_filter = STRICT && !cost_only && !p.update_rigidness_only && p.local_prop_width > 0 && debug_switches().strict_filter && p.N + p.N_dp <= 64 &&
+                              (debug_switches().strict_table_filter == 2 || (debug_switches().strict_table_filter == 1 && (size_t)w * h >= 1000000));
+    if (table_filter) {  // its queues
+        const int ntiles = gpx.x * gpx.y, qcap = (ntiles / SFQ + 10) * 256;
+        if (int e = c->sf_qcnt.reserve(sizeof(unsigned) * 4 * SFQ)) return e;
+        if (int e = c->sf_qlist.reserve(sizeof(unsigned) * (size_t)SFQ * qcap)) return e;
+        VK_CHECK(hipMemsetAsync(c->sf_qcnt.p, 0, sizeof(unsigned) * 4 * SFQ, c->stream));
+    }
     const bool plain = STRICT && debug_switches().strict_plain;  // strict mode on the plain launch structures of rounds 1-3 (verification: same bits either way)
     // fast mode: the projective maps of the chain (and the world-scale factor) are prepared by an extra workgroup of the first fb_smooth
     // launch when there is one, by their own small launch otherwise
@@ -1622,7 +1705,17 @@ int optimize_depth_launch(Context* c, ImageSet& S, const OdParams& p, bool cost_
                     // pixel, at the head of the runs kernel -- one launch less per pass (cfg2: 28.0 -> 27.0 us).  Larger ones are throughput
                     // bound and the tiled table kernel reads coalesced (column chains do not): measured neutral at 1241x376, 5 % slower at 1080p
                     const bool own_table = (size_t)w * h <= 400000 && !STRICT;  // (strict: the tiled table kernel at every size; own table measured equal)
-                    if (!own_table) hipLaunchKernelGGL((k_local_table_lean<NMAX, STRICT>), gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
+                    bool tabled = own_table;
+                    if constexpr (STRICT) {
+                        if (table_filter) {
+                            const int ntiles = gpx.x * gpx.y, qcap = (ntiles / SFQ + 10) * 256;
+                            unsigned* qcnt = c->sf_qcnt.as<unsigned>() + k * SFQ;
+                            hipLaunchKernelGGL(k_local_table_filter<NMAX>, gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>(), qcnt, c->sf_qlist.as<unsigned>(), qcap);
+                            hipLaunchKernelGGL(k_local_table_exact<NMAX>, dim3((qcap / 256) * SFQ), bpx, 0, c->stream, I, dir, c->local_tbl.as<float>(), qcnt, c->sf_qlist.as<unsigned>(), qcap);
+                            tabled = true;
+                        }
+                    }
+                    if (!tabled) hipLaunchKernelGGL((k_local_table_lean<NMAX, STRICT>), gpx, bpx, 0, c->stream, I, dir, p.local_prop_width, c->local_tbl.as<float>());
                     const float* tblp = own_table ? nullptr : c->local_tbl.as<float>();
                     const int nchains = lines * nseg;
                     // lanes per pixel of a run evaluation (cost_split_lean): quads up to 8 frames, eight beyond.  (Pairs -- 16 pixels per round, four planned

@@ -38,6 +38,7 @@ struct DebugSwitches {
     int bootstrap_default = 0; // what --bootstrap_points -1 (the default) means: 0 = five-point in the fast mode, 8-point in strict mode; 5 | 8 = that one.  The test suite sets 8 where a
                                // window is held against the oracle or the reference goldens, whose two-view pose is the 8-point one
     int strict_filter = 1;     // 2: as 1, and the pass counts what the filter saw and kept (vk_debug_counter "sf_*").  0: the strict sample pass evaluates every random depth in strict arithmetic (no fp32 pre-filter, vk_depth_impl.hpp); same bits
+    int strict_table_filter = 1;  // the table pass of the strict local propagation as filter + queued entries in strict arithmetic (two launches) instead of every entry (one): 1 from 1 M pixels, 2 always, 0 never; same bits
     int strict_plain = 0;      // 1: strict mode on the plain launch structures of rounds 1-3 (one lane per chain / line, one 256-thread workgroup walking the sum tree)
 };
 DebugSwitches& debug_switches();  // vk_abi.hip
