@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) sta
         for (int k = 0; k < nh; k++)
             s_d[k][tid] = I.xw ? 1.0f / (range_factor * vrc_uniform(vrc_xorwow_next(&st)) + (1.0f / 1e5f)) : sample_depth(pi, epoch0 + (uint32_t)(it + k), range_factor);
         __syncthreads();
-        // ---- the filter.  Measured (vk_debug_counter "sf_filter_frames"): a sample lives 1.25 frames on average -- four out of five die on frame 0, which needs no
+        // ---- the filter.  Measured (a step counter in a diagnostic build, profiles/r06_summary.md I): a sample lives 1.25 frames on average -- four out of five die on frame 0, which needs no
         // gather (the pixel's own texel, its ObsTerms shared by all samples) -- but the slowest lane of a wave walks 2.7 per sample.  So frame 0 of every sample first,
         // all lanes in step; then each lane walks what its pixel has left, one frame per trip, whichever sample it is at.
         unsigned surv = 0u;
