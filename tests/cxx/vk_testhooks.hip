@@ -72,6 +72,8 @@ __host__ __device__ static double probe_op(int op, float a, float b) {
         case 22: return (double)(-1.5f * vsm_logf(vk::strict::rigidness(a, b, a * 0.9f + 0.1f, b * 1.1f - 0.05f, 0.15f, 1.f)));
         case 23: return (double)(fabsf(a) / (2.f * fabsf(b) + 1e-3f));
         case 24: return (double)sqrtf(a * a + b * b);
+        case 25: return (double)vk::strict::rig_core(fabsf(a), fabsf(b), 0.15f);        // the straight-line model and its call-by-call form: equal bits, device == host
+        case 26: return (double)vk::strict::rig_core_plain(fabsf(a), fabsf(b), 0.15f);
         default: return 0.0;
     }
 }
@@ -79,7 +81,7 @@ __global__ static void k_probe(int op, const float* a, const float* b, double* o
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = probe_op(op, a[i], b[i]);
 }
-VKT_API int vkt_probe_ops_count(void) { return 25; }
+VKT_API int vkt_probe_ops_count(void) { return 27; }
 VKT_API void vkt_probe_host(int op, const float* a, const float* b, double* out, int n) {
     for (int i = 0; i < n; i++) out[i] = probe_op(op, a[i], b[i]);
 }
@@ -256,4 +258,15 @@ VKT_API int vkt_filter_pair_depth_device(const float* d1, const float* d2, int n
     rc |= (int)hipMemcpy(out_f, d[3], sizeof(float) * n, hipMemcpyDeviceToHost);
     for (int k = 0; k < 4; k++) (void)hipFree(d[k]);
     return rc;
+}
+
+// rig_core (vk_strict_model.hpp: the residual model in one straight line) against rig_core_plain (call by call), host build: elements whose bits differ
+VKT_API long vkt_rig_core_host(const float* mag, const float* diff, const float* k, long n) {
+    long bad = 0;
+    for (long i = 0; i < n; i++) {
+        const float a = vk::strict::rig_core(mag[i], diff[i], k[i]), b = vk::strict::rig_core_plain(mag[i], diff[i], k[i]);
+        unsigned ua, ub; memcpy(&ua, &a, 4); memcpy(&ub, &b, 4);
+        if (ua != ub && !(a != a && b != b)) bad++;
+    }
+    return bad;
 }

@@ -100,6 +100,32 @@ def test_pow_m2_shortcut_gives_the_plain_call_bits():
         assert gap < 1024, gap  # (measured: 2 units of the last place near 1, 65 at x ~ 1e18)
 
 
+def test_straight_line_model_gives_the_call_by_call_bits():
+    """vk_strict_model.hpp rig_core (entry tests first, then the logarithms / exponentials / reciprocal squares of a residual side by side) against rig_core_plain
+    (residual_model.h's calls one after the other): equal bits over the model's domain and far outside it -- zero, denormal, huge, infinite and NaN magnitudes."""
+    import hooks
+    H = hooks.lib()
+    H.vkt_rig_core_host.restype = C.c_long
+    H.vkt_rig_core_host.argtypes = [C.POINTER(C.c_float)] * 3 + [C.c_long]
+    rng = np.random.default_rng(21)
+    n = 1 << 21
+    p = lambda a: np.ascontiguousarray(a, np.float32).ctypes.data_as(C.POINTER(C.c_float))  # noqa: E731
+    mag = np.exp(rng.uniform(np.log(1e-6), np.log(5000.0), n)).astype(np.float32)
+    diff = np.exp(rng.uniform(np.log(1e-9), np.log(1e5), n)).astype(np.float32)
+    k = rng.choice([0.15, 0.05, 0.3, 1.0], n).astype(np.float32)
+    assert H.vkt_rig_core_host(p(mag), p(diff), p(k), n) == 0
+    wild = np.array([0.0, -0.0, 1e-45, 1e-38, 1.0, 2.0, 4.0, 200.0, 1e10, 1e30, 3.4e38, np.inf, -np.inf, np.nan, -1.0, 1.1920929e-07, 2.3841858e-07], np.float32)
+    M, D, K = np.meshgrid(wild, wild, np.array([0.15, 0.0, np.nan, np.inf, 1e30, -0.15], np.float32), indexing="ij")
+    assert H.vkt_rig_core_host(p(M.ravel()), p(D.ravel()), p(K.ravel()), M.size) == 0
+    # differences that put r = x^2 / s at exactly 1 and around it (the base the plain pow answers without a logarithm)
+    g = np.clip(mag * 0.5, 2, 100).astype(np.float32)
+    s_ = (np.float32(0.01) * np.exp(np.float32(0.09) * g)).astype(np.float32)
+    d1 = (2 * np.sqrt(s_.astype(np.float64))).astype(np.float32)
+    for nudge in (0, 1, -1, 2, -2):
+        dd = (d1.view(np.int32) + nudge).view(np.float32)
+        assert H.vkt_rig_core_host(p(mag), p(dd), p(k), n) == 0
+
+
 def test_strict_oracle_is_the_same_estimator(orc):
     """switching the libm does not change what is estimated: against ground truth the strict oracle is as accurate as the
     glibc one, and the residual model agrees to float rounding"""

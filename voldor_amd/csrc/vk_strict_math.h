@@ -43,12 +43,10 @@ VSM_FN double vsm_pow2i(int k) { return vsm_from_bits((unsigned long long)(k + 1
 #define VSM_PIO2_HI 1.57079632673412561417e+00 /* the top 33 bits of pi/2 */
 #define VSM_PIO2_LO 6.07710050650619224932e-11
 
-/* e^x */
-VSM_FN double vsm_exp(double x) {
+/* e^x for -745.2 <= x <= 709.78 (not a NaN): vsm_exp behind its entry tests, one straight line (round 6: callers that have made the tests themselves -- the residual
+ * model, vk_strict_model.hpp -- put several of these side by side so that the instruction scheduler can interleave the dependent chains) */
+VSM_FN double vsm_exp_core(double x) {
     VSM_NO_CONTRACT
-    if (x != x) return x;
-    if (x > 709.782712893384) return vsm_inf();
-    if (x < -745.2) return 0.0;
     const double kf = x * VSM_INV_LN2;
     const int k = (int)(kf + (kf >= 0.0 ? 0.5 : -0.5)); /* nearest integer (conversion truncates) */
     const double kd = (double)k;
@@ -73,20 +71,24 @@ VSM_FN double vsm_exp(double x) {
     const int k1 = k / 2, k2 = k - k1;
     return (p * vsm_pow2i(k1)) * vsm_pow2i(k2);
 }
-
-/* natural logarithm */
-VSM_FN double vsm_log(double x) {
+/* e^x */
+VSM_FN double vsm_exp(double x) {
     VSM_NO_CONTRACT
     if (x != x) return x;
-    if (x < 0.0) return vsm_nan();
-    if (x == 0.0) return -vsm_inf();
-    if (x == vsm_inf()) return x;
-    int e = 0;
-    if (x < 2.2250738585072014e-308) { x = x * 18014398509481984.0; e = -54; } /* subnormal: scale by 2^54 */
+    if (x > 709.782712893384) return vsm_inf();
+    if (x < -745.2) return 0.0;
+    return vsm_exp_core(x);
+}
+
+/* log x for a normal, finite x > 0, plus e0 ln 2: vsm_log behind its entry tests, one straight line */
+VSM_FN double vsm_log_core(double x, int e0) {
+    VSM_NO_CONTRACT
     const unsigned long long u = vsm_bits(x);
-    e += (int)((u >> 52) & 0x7ffull) - 1023;
+    int e = e0 + (int)((u >> 52) & 0x7ffull) - 1023;
     double m = vsm_from_bits((u & 0x000fffffffffffffull) | 0x3ff0000000000000ull); /* [1, 2) */
-    if (m > 1.4142135623730951) { m = m * 0.5; e += 1; }                             /* (0.707, 1.414] */
+    const int upper = m > 1.4142135623730951;                                          /* -> (0.707, 1.414] */
+    m = upper ? m * 0.5 : m;
+    e += upper;
     const double s = (m - 1.0) / (m + 1.0), s2 = s * s;                               /* |s| <= 0.1716 */
     /* log m = 2 atanh s = 2 s (1 + s^2/3 + s^4/5 + ... + s^22/23) */
     double p = 1.0 / 23.0;
@@ -103,6 +105,17 @@ VSM_FN double vsm_log(double x) {
     p = p * s2 + 1.0;
     const double ed = (double)e;
     return ed * VSM_LN2_HI + (ed * VSM_LN2_LO + 2.0 * s * p);
+}
+/* natural logarithm */
+VSM_FN double vsm_log(double x) {
+    VSM_NO_CONTRACT
+    if (x != x) return x;
+    if (x < 0.0) return vsm_nan();
+    if (x == 0.0) return -vsm_inf();
+    if (x == vsm_inf()) return x;
+    int e = 0;
+    if (x < 2.2250738585072014e-308) { x = x * 18014398509481984.0; e = -54; } /* subnormal: scale by 2^54 */
+    return vsm_log_core(x, e);
 }
 
 /* x^y for x >= 0 (the residual model and AP3P never raise a negative base; a negative base returns NaN) */

@@ -79,11 +79,43 @@ VK_SHD float fisk_pdf(float x, float c, float scale) {  // :28-31
     return (c * p1 * pow_m2(1.f + p2)) / scale;
 }
 // What fun_rigidness and fun_depth_rigidness share once the magnitude of the observation (flow magnitude / disparity), the magnitude of the difference and the
-// strictness (lambda / omega) are known -- so that a wave whose lanes hold frames AND depth priors runs the software transcendentals once (strict_term, vk_depth_impl.hpp)
-VK_SHD float rig_core(float mag, float diff, float strictness) {
+// strictness (lambda / omega) are known -- so that a wave whose lanes hold frames AND depth priors runs the software transcendentals once (strict_term, vk_depth_impl.hpp).
+// rig_core_plain is the model as residual_model.h writes it, call by call.
+VK_SHD float rig_core_plain(float mag, float diff, float strictness) {
 #pragma clang fp contract(off)
     const float c = fmag_c(mag), s = fmag_scale(mag);
     const float p = fisk_pdf(diff, c, s), mu = fisk_pdf(strictness * mag, c, s);
+    return p / (p + mu);
+}
+// The same operations on the same values in ONE STRAIGHT LINE (round 6).  Called one after the other, the seven software transcendentals of a residual are seven
+// dependent chains behind entry tests -- branches the scheduler cannot move instructions across -- and a wave advances at the latency of one fp64 operation per
+// instruction (measured: the strict passes do not get faster with fewer waves, and get slower with more, smaller ones).  Here the entry tests of all of them are made
+// first (bases positive, finite, not 1; exponents finite, not 0; every product y log x inside vsm_exp's range: what holds for any pixel that is not degenerate), then the
+// two logarithms, the four exponentials and the two reciprocal squares stand side by side as vsm_log_core / vsm_exp_core -- the bodies vsm_log / vsm_exp run behind
+// their tests -- and the scheduler interleaves them.  Where a test fails the model runs call by call (rig_core_plain's path); a reciprocal square too close to a float
+// rounding boundary takes its plain call alone.  Same bits: tests/test_strict_host.py holds rig_core against rig_core_plain (and both against the oracle).
+VK_SHD float rig_core(float mag, float diff, float strictness) {
+#pragma clang fp contract(off)
+    const float g = clamp_fmag(mag);  // in [2, 100] whatever mag is (a NaN clamps to 2): 0.09 g is inside vsm_expf's plain range
+    const float c = 1.0f + -0.0022f * g;
+    const float s = 0.01f * (float)vsm_exp_core((double)(0.09f * g));
+    const float xm = strictness * mag;
+    const float x1 = fmaxf((float)((double)diff * 0.5), 1.1920929e-07f), x2 = fmaxf((float)((double)xm * 0.5), 1.1920929e-07f);
+    const float r1 = (x1 * x1) / s, r2 = (x2 * x2) / s;
+    const double d1 = (double)r1, d2 = (double)r2, ya = (double)(-c - 1.f), yb = (double)(-c);
+    bool ok = d1 > 0.0 && d1 < 3.5e38 && d1 != 1.0 && d2 > 0.0 && d2 < 3.5e38 && d2 != 1.0 && ya != 0.0 && yb != 0.0;  // (false for a NaN base; c is finite)
+    const double l1 = vsm_log_core(ok ? d1 : 2.0, 0), l2 = vsm_log_core(ok ? d2 : 2.0, 0);
+    double t1a = ya * l1, t1b = yb * l1, t2a = ya * l2, t2b = yb * l2;
+    ok = ok && t1a >= -745.2 && t1a <= 709.782712893384 && t1b >= -745.2 && t1b <= 709.782712893384 && t2a >= -745.2 && t2a <= 709.782712893384 && t2b >= -745.2 && t2b <= 709.782712893384;
+    if (!ok) { t1a = 0.0; t1b = 0.0; t2a = 0.0; t2b = 0.0; }
+    const float p1a = (float)vsm_exp_core(t1a), p1b = (float)vsm_exp_core(t1b), p2a = (float)vsm_exp_core(t2a), p2b = (float)vsm_exp_core(t2b);
+    const float q1 = 1.f + p1b, q2 = 1.f + p2b;
+    const double w1 = 1.0 / ((double)q1 * (double)q1), w2 = 1.0 / ((double)q2 * (double)q2);
+    if (!ok) return rig_core_plain(mag, diff, strictness);
+    float m1 = (float)w1, m2 = (float)w2;
+    if (!(q1 >= 1.0f && q1 <= 1e18f && rounds_alike(w1))) m1 = vsm_powf(q1, -2.f);  // pow_m2's own fallback
+    if (!(q2 >= 1.0f && q2 <= 1e18f && rounds_alike(w2))) m2 = vsm_powf(q2, -2.f);
+    const float p = (c * p1a * m1) / s, mu = (c * p2a * m2) / s;
     return p / (p + mu);
 }
 VK_SHD float rigidness(float dx1, float dy1, float dx2, float dy2, float lambda, float abs_rf) {  // fun_rigidness :34-42
